@@ -1,0 +1,76 @@
+// Shared device helpers for the gfx950 kernels (bf16 storage helpers, launch checks).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/fmri_hip.h"
+
+typedef unsigned short bf16_t;  // raw bf16 bits in memory
+
+__device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((unsigned)h) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {  // round-to-nearest-even; NaN stays NaN (v_cvt_pk_bf16_f32)
+    __bf16 b = (__bf16)f;
+    return __builtin_bit_cast(unsigned short, b);
+}
+
+template <typename T> struct Io;
+template <> struct Io<float> {
+    static __device__ __forceinline__ float ld(const float* p) { return *p; }
+    static __device__ __forceinline__ void st(float* p, float v) { *p = v; }
+};
+template <> struct Io<bf16_t> {
+    static __device__ __forceinline__ float ld(const bf16_t* p) { return bf2f(*p); }
+    static __device__ __forceinline__ void st(bf16_t* p, float v) { *p = f2bf(v); }
+};
+
+#define FMRI_LAUNCH_CHECK()                                   \
+    do {                                                      \
+        if (hipGetLastError() != hipSuccess) return FMRI_E_LAUNCH; \
+    } while (0)
+
+static inline hipStream_t as_stream(fmri_stream_t s) { return (hipStream_t)s; }
+
+static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ---- vector load/store of VEC contiguous elements (address must be VEC*sizeof(T)-aligned) ------------------------
+template <typename T, int VEC> struct alignas(sizeof(T) * VEC) PackT { T e[VEC]; };
+
+template <typename T> __device__ __forceinline__ float to_f(T v);
+template <> __device__ __forceinline__ float to_f<float>(float v) { return v; }
+template <> __device__ __forceinline__ float to_f<bf16_t>(bf16_t v) { return bf2f(v); }
+template <typename T> __device__ __forceinline__ T from_f(float v);
+template <> __device__ __forceinline__ float from_f<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16_t from_f<bf16_t>(float v) { return f2bf(v); }
+
+template <typename T, int VEC> __device__ __forceinline__ void ldv(const T* p, float* out) {
+    PackT<T, VEC> v = *reinterpret_cast<const PackT<T, VEC>*>(p);
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) out[k] = to_f<T>(v.e[k]);
+}
+template <typename T, int VEC> __device__ __forceinline__ void stv(T* p, const float* in) {
+    PackT<T, VEC> v;
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) v.e[k] = from_f<T>(in[k]);
+    *reinterpret_cast<PackT<T, VEC>*>(p) = v;
+}
+
+static inline int pick_vec(int C, int maxvec = 8) {
+    int v = maxvec;
+    while (v > 1 && (C % v)) v >>= 1;
+    return v;
+}
+static inline int grid_for(int64_t total, int block = 256, int cap = 256 * 16) {
+    int64_t g = ceil_div64(total, block);
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+#define LAUNCH_TV(KERN, T, vec, grid, block, s, ...)                                 \
+    do {                                                                             \
+        switch (vec) {                                                               \
+            case 8: KERN<T, 8><<<grid, block, 0, s>>>(__VA_ARGS__); break;           \
+            case 4: KERN<T, 4><<<grid, block, 0, s>>>(__VA_ARGS__); break;           \
+            case 2: KERN<T, 2><<<grid, block, 0, s>>>(__VA_ARGS__); break;           \
+            default: KERN<T, 1><<<grid, block, 0, s>>>(__VA_ARGS__); break;          \
+        }                                                                            \
+    } while (0)

@@ -1,0 +1,541 @@
+// HBM-bound kernels of the U-Net step: pooling, up-sampling, final 1x1x1 conv, sigmoid+Dice, Adam, weight packing,
+// sliding-window tile gather / overlap-add, casts.  All channels-last, vectorised where the channel count allows.
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------------ version / errors
+extern "C" int fmri_version(void) { return 100; }
+extern "C" const char* fmri_error_string(int code) {
+    switch (code) {
+        case FMRI_OK: return "ok";
+        case FMRI_E_SHAPE: return "unsupported shape";
+        case FMRI_E_ALIGN: return "misaligned pointer";
+        case FMRI_E_ARCH: return "unsupported architecture";
+        case FMRI_E_LAUNCH: return "kernel launch failed";
+        case FMRI_E_DTYPE: return "unsupported dtype";
+        default: return "unknown error";
+    }
+}
+
+__device__ __forceinline__ void decode_vox(int64_t v, int Do, int Ho, int Wo, int& n, int& d, int& h, int& w) {
+    w = (int)(v % Wo); v /= Wo;
+    h = (int)(v % Ho); v /= Ho;
+    d = (int)(v % Do);
+    n = (int)(v / Do);
+}
+
+// ------------------------------------------------------------------------------------------------ max-pool 2x2x2
+// One thread per (pooled voxel, channel group of VEC).  Reference: MaxPooling3D(pool_size) at unet3d/unet.py:51.
+template <typename T, int VEC>
+__global__ void k_maxpool_fwd(const T* __restrict__ x, T* __restrict__ y, int N, int D, int H, int W, int C) {
+    const int Do = D >> 1, Ho = H >> 1, Wo = W >> 1, CG = C / VEC;
+    const int64_t total = (int64_t)N * Do * Ho * Wo * CG;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int cg = (int)(i % CG), n, d_o, ho, wo;
+        decode_vox(i / CG, Do, Ho, Wo, n, d_o, ho, wo);
+        float m[VEC];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) m[k] = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            int dd = 2 * d_o + (t >> 2), hh = 2 * ho + ((t >> 1) & 1), ww = 2 * wo + (t & 1);
+            float xv[VEC];
+            ldv<T, VEC>(x + ((((int64_t)n * D + dd) * H + hh) * W + ww) * C + cg * VEC, xv);
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) m[k] = fmaxf(m[k], xv[k]);
+        }
+        stv<T, VEC>(y + ((((int64_t)n * Do + d_o) * Ho + ho) * Wo + wo) * C + cg * VEC, m);
+    }
+}
+
+// backward: one thread per (pooled voxel, channel group): recompute the window max, route dy to the FIRST max in
+// (d,h,w) scan order, add the skip gradient, apply the producer's ReLU mask, write all 8 children.
+template <typename T, int VEC>
+__global__ void k_maxpool_bwd(const T* __restrict__ x, const T* __restrict__ dy, const T* __restrict__ add, int add_ld,
+                              int add_off, T* __restrict__ dx, int N, int D, int H, int W, int C, int relu_mask) {
+    const int Do = D >> 1, Ho = H >> 1, Wo = W >> 1, CG = C / VEC;
+    const int64_t total = (int64_t)N * Do * Ho * Wo * CG;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int cg = (int)(i % CG), n, d_o, ho, wo;
+        decode_vox(i / CG, Do, Ho, Wo, n, d_o, ho, wo);
+        float xv[8][VEC], m[VEC], g[VEC];
+        int64_t off[8];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) m[k] = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            int dd = 2 * d_o + (t >> 2), hh = 2 * ho + ((t >> 1) & 1), ww = 2 * wo + (t & 1);
+            off[t] = (((int64_t)n * D + dd) * H + hh) * W + ww;
+            ldv<T, VEC>(x + off[t] * C + cg * VEC, xv[t]);
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) m[k] = fmaxf(m[k], xv[t][k]);
+        }
+        ldv<T, VEC>(dy + ((((int64_t)n * Do + d_o) * Ho + ho) * Wo + wo) * C + cg * VEC, g);
+        bool taken[VEC];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) taken[k] = false;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            float r[VEC], a[VEC];
+            if (add) ldv<T, VEC>(add + off[t] * add_ld + add_off + cg * VEC, a);
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) {
+                float rr = 0.f;
+                if (!taken[k] && xv[t][k] == m[k]) { rr = g[k]; taken[k] = true; }
+                if (add) rr += a[k];
+                if (relu_mask && !(xv[t][k] > 0.f)) rr = 0.f;
+                r[k] = rr;
+            }
+            stv<T, VEC>(dx + off[t] * C + cg * VEC, r);
+        }
+    }
+}
+
+extern "C" int fmri_maxpool3d_2x_fwd(const void* x, void* y, int N, int D, int H, int W, int C, int dtype,
+                                     fmri_stream_t stream) {
+    if (N <= 0 || C <= 0 || D < 2 || (H & 1) || (W & 1) || (D & 1)) return FMRI_E_SHAPE;
+    int vec = pick_vec(C);
+    int grid = grid_for((int64_t)N * (D / 2) * (H / 2) * (W / 2) * (C / vec));
+    hipStream_t s = as_stream(stream);
+    if (dtype == FMRI_F32) LAUNCH_TV(k_maxpool_fwd, float, vec, grid, 256, s, (const float*)x, (float*)y, N, D, H, W, C);
+    else if (dtype == FMRI_BF16) LAUNCH_TV(k_maxpool_fwd, bf16_t, vec, grid, 256, s, (const bf16_t*)x, (bf16_t*)y, N, D, H, W, C);
+    else return FMRI_E_DTYPE;
+    FMRI_LAUNCH_CHECK();
+    return FMRI_OK;
+}
+
+extern "C" int fmri_maxpool3d_2x_bwd(const void* x, const void* dy, const void* add, int add_ld, int add_off, void* dx,
+                                     int N, int D, int H, int W, int C, int relu_mask, int dtype, fmri_stream_t stream) {
+    if (N <= 0 || C <= 0 || D < 2 || (H & 1) || (W & 1) || (D & 1)) return FMRI_E_SHAPE;
+    int vec = pick_vec(C);
+    if (add) { while (vec > 1 && ((add_ld % vec) || (add_off % vec))) vec >>= 1; }
+    int grid = grid_for((int64_t)N * (D / 2) * (H / 2) * (W / 2) * (C / vec));
+    hipStream_t s = as_stream(stream);
+    if (dtype == FMRI_F32)
+        LAUNCH_TV(k_maxpool_bwd, float, vec, grid, 256, s, (const float*)x, (const float*)dy, (const float*)add, add_ld,
+                  add_off, (float*)dx, N, D, H, W, C, relu_mask);
+    else if (dtype == FMRI_BF16)
+        LAUNCH_TV(k_maxpool_bwd, bf16_t, vec, grid, 256, s, (const bf16_t*)x, (const bf16_t*)dy, (const bf16_t*)add, add_ld,
+                  add_off, (bf16_t*)dx, N, D, H, W, C, relu_mask);
+    else return FMRI_E_DTYPE;
+    FMRI_LAUNCH_CHECK();
+    return FMRI_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ nearest up-sampling x2
+// Reference: UpSampling3D(size=pool_size) at unet3d/unet.py:138.  D,H,W = low-resolution dims.
+template <typename T, int VEC>
+__global__ void k_upsample_fwd(const T* __restrict__ x, T* __restrict__ y, int y_ld, int y_off, int N, int D, int H, int W,
+                               int C) {
+    const int CG = C / VEC;
+    const int64_t total = (int64_t)N * D * H * W * CG;
+    const int D2 = 2 * D, H2 = 2 * H, W2 = 2 * W;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int cg = (int)(i % CG), n, d, h, w;
+        decode_vox(i / CG, D, H, W, n, d, h, w);
+        float v[VEC];
+        ldv<T, VEC>(x + (i / CG) * C + cg * VEC, v);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            int64_t o = (((int64_t)n * D2 + 2 * d + (t >> 2)) * H2 + 2 * h + ((t >> 1) & 1)) * W2 + 2 * w + (t & 1);
+            stv<T, VEC>(y + o * y_ld + y_off + cg * VEC, v);
+        }
+    }
+}
+template <typename T, int VEC>
+__global__ void k_upsample_bwd(const T* __restrict__ dy, int dy_ld, int dy_off, const T* __restrict__ xmask,
+                               T* __restrict__ dx, int N, int D, int H, int W, int C) {
+    const int CG = C / VEC;
+    const int64_t total = (int64_t)N * D * H * W * CG;
+    const int D2 = 2 * D, H2 = 2 * H, W2 = 2 * W;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int cg = (int)(i % CG), n, d, h, w;
+        decode_vox(i / CG, D, H, W, n, d, h, w);
+        float acc[VEC];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            int64_t o = (((int64_t)n * D2 + 2 * d + (t >> 2)) * H2 + 2 * h + ((t >> 1) & 1)) * W2 + 2 * w + (t & 1);
+            float g[VEC];
+            ldv<T, VEC>(dy + o * dy_ld + dy_off + cg * VEC, g);
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) acc[k] += g[k];
+        }
+        if (xmask) {
+            float m[VEC];
+            ldv<T, VEC>(xmask + (i / CG) * C + cg * VEC, m);
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) if (!(m[k] > 0.f)) acc[k] = 0.f;
+        }
+        stv<T, VEC>(dx + (i / CG) * C + cg * VEC, acc);
+    }
+}
+
+extern "C" int fmri_upsample_nearest2x_fwd(const void* x, void* y, int y_ld, int y_off, int N, int D, int H, int W, int C,
+                                           int dtype, fmri_stream_t stream) {
+    if (N <= 0 || C <= 0 || D <= 0 || H <= 0 || W <= 0 || y_ld < y_off + C) return FMRI_E_SHAPE;
+    int vec = pick_vec(C);
+    while (vec > 1 && ((y_ld % vec) || (y_off % vec))) vec >>= 1;
+    int grid = grid_for((int64_t)N * D * H * W * (C / vec));
+    hipStream_t s = as_stream(stream);
+    if (dtype == FMRI_F32) LAUNCH_TV(k_upsample_fwd, float, vec, grid, 256, s, (const float*)x, (float*)y, y_ld, y_off, N, D, H, W, C);
+    else if (dtype == FMRI_BF16) LAUNCH_TV(k_upsample_fwd, bf16_t, vec, grid, 256, s, (const bf16_t*)x, (bf16_t*)y, y_ld, y_off, N, D, H, W, C);
+    else return FMRI_E_DTYPE;
+    FMRI_LAUNCH_CHECK();
+    return FMRI_OK;
+}
+extern "C" int fmri_upsample_nearest2x_bwd(const void* dy, int dy_ld, int dy_off, const void* xmask, void* dx, int N, int D,
+                                           int H, int W, int C, int dtype, fmri_stream_t stream) {
+    if (N <= 0 || C <= 0 || D <= 0 || H <= 0 || W <= 0 || dy_ld < dy_off + C) return FMRI_E_SHAPE;
+    int vec = pick_vec(C);
+    while (vec > 1 && ((dy_ld % vec) || (dy_off % vec))) vec >>= 1;
+    int grid = grid_for((int64_t)N * D * H * W * (C / vec));
+    hipStream_t s = as_stream(stream);
+    if (dtype == FMRI_F32)
+        LAUNCH_TV(k_upsample_bwd, float, vec, grid, 256, s, (const float*)dy, dy_ld, dy_off, (const float*)xmask, (float*)dx, N, D, H, W, C);
+    else if (dtype == FMRI_BF16)
+        LAUNCH_TV(k_upsample_bwd, bf16_t, vec, grid, 256, s, (const bf16_t*)dy, dy_ld, dy_off, (const bf16_t*)xmask, (bf16_t*)dx, N, D, H, W, C);
+    else return FMRI_E_DTYPE;
+    FMRI_LAUNCH_CHECK();
+    return FMRI_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ final 1x1x1 conv
+// Reference: Conv3D(n_labels,(1,1,1)) at unet3d/unet.py:68.  AI ~ 1 flop/B: one pass over x, C small (<= 256).
+// One thread per voxel, channel loop vectorised; weights broadcast from LDS.
+template <typename T, int VEC>
+__global__ void k_conv1x1_fwd(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
+                              float* __restrict__ logits, int64_t nvox, int C, int L) {
+    extern __shared__ __attribute__((aligned(16))) float sw[];  // [L][C]
+    for (int i = threadIdx.x; i < L * C; i += blockDim.x) sw[i] = w[i];
+    __syncthreads();
+    for (int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; v < nvox; v += (int64_t)gridDim.x * blockDim.x) {
+        for (int l = 0; l < L; ++l) {
+            float acc = b ? b[l] : 0.f;
+            for (int c = 0; c < C; c += VEC) {
+                float xv[VEC];
+                ldv<T, VEC>(x + v * C + c, xv);
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) acc = fmaf(xv[k], sw[l * C + c + k], acc);
+            }
+            logits[v * L + l] = acc;
+        }
+    }
+}
+// backward: dx (masked), and block-reduced dw/db with one atomic per (block, output).
+template <typename T, int VEC>
+__global__ void k_conv1x1_bwd(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ dl,
+                              T* __restrict__ dx, float* __restrict__ dw, float* __restrict__ db, int64_t nvox, int C, int L,
+                              int relu_mask) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];  // [L][C] weights, then [L][C+1] accumulators
+    float* sw = sm;
+    float* sacc = sm + L * C;
+    for (int i = threadIdx.x; i < L * C; i += blockDim.x) sw[i] = w[i];
+    for (int i = threadIdx.x; i < L * (C + 1); i += blockDim.x) sacc[i] = 0.f;
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    for (int64_t v0 = blockIdx.x * (int64_t)blockDim.x; v0 < nvox; v0 += (int64_t)gridDim.x * blockDim.x) {
+        int64_t v = v0 + threadIdx.x;
+        bool ok = v < nvox;
+        for (int c = 0; c < C; c += VEC) {
+            float xv[VEC], gx[VEC];
+            if (ok) ldv<T, VEC>(x + v * C + c, xv);
+            else {
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) xv[k] = 0.f;
+            }
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) gx[k] = 0.f;
+            for (int l = 0; l < L; ++l) {
+                float g = ok ? dl[v * L + l] : 0.f;
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) {
+                    gx[k] = fmaf(g, sw[l * C + c + k], gx[k]);
+                    float p = g * xv[k];  // dw contribution: wave-reduce then one LDS atomic
+                    for (int o = 32; o > 0; o >>= 1) p += __shfl_down(p, o);
+                    if (lane == 0) atomicAdd(&sacc[l * (C + 1) + c + k], p);
+                }
+            }
+            if (ok && dx) {
+                if (relu_mask) {
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) if (!(xv[k] > 0.f)) gx[k] = 0.f;
+                }
+                stv<T, VEC>(dx + v * C + c, gx);
+            }
+        }
+        for (int l = 0; l < L; ++l) {
+            float g = ok ? dl[v * L + l] : 0.f;
+            for (int o = 32; o > 0; o >>= 1) g += __shfl_down(g, o);
+            if (lane == 0) atomicAdd(&sacc[l * (C + 1) + C], g);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < L * (C + 1); i += blockDim.x) {
+        int l = i / (C + 1), c = i % (C + 1);
+        if (c < C) atomicAdd(&dw[l * C + c], sacc[i]);
+        else if (db) atomicAdd(&db[l], sacc[i]);
+    }
+}
+
+extern "C" int fmri_conv1x1_fwd(const void* x, const float* w, const float* b, float* logits, int64_t nvox, int C, int L,
+                                int dtype, fmri_stream_t stream) {
+    if (nvox <= 0 || C <= 0 || L <= 0 || (size_t)L * C * 4 > 64 * 1024) return FMRI_E_SHAPE;
+    int vec = pick_vec(C);
+    int grid = grid_for(nvox, 256, 256 * 8);
+    hipStream_t s = as_stream(stream);
+    size_t sh = (size_t)L * C * 4;
+    if (dtype == FMRI_F32) {
+        switch (vec) {
+            case 8: k_conv1x1_fwd<float, 8><<<grid, 256, sh, s>>>((const float*)x, w, b, logits, nvox, C, L); break;
+            case 4: k_conv1x1_fwd<float, 4><<<grid, 256, sh, s>>>((const float*)x, w, b, logits, nvox, C, L); break;
+            case 2: k_conv1x1_fwd<float, 2><<<grid, 256, sh, s>>>((const float*)x, w, b, logits, nvox, C, L); break;
+            default: k_conv1x1_fwd<float, 1><<<grid, 256, sh, s>>>((const float*)x, w, b, logits, nvox, C, L); break;
+        }
+    } else if (dtype == FMRI_BF16) {
+        switch (vec) {
+            case 8: k_conv1x1_fwd<bf16_t, 8><<<grid, 256, sh, s>>>((const bf16_t*)x, w, b, logits, nvox, C, L); break;
+            case 4: k_conv1x1_fwd<bf16_t, 4><<<grid, 256, sh, s>>>((const bf16_t*)x, w, b, logits, nvox, C, L); break;
+            case 2: k_conv1x1_fwd<bf16_t, 2><<<grid, 256, sh, s>>>((const bf16_t*)x, w, b, logits, nvox, C, L); break;
+            default: k_conv1x1_fwd<bf16_t, 1><<<grid, 256, sh, s>>>((const bf16_t*)x, w, b, logits, nvox, C, L); break;
+        }
+    } else return FMRI_E_DTYPE;
+    FMRI_LAUNCH_CHECK();
+    return FMRI_OK;
+}
+
+extern "C" int fmri_conv1x1_bwd(const void* x, const float* w, const float* dlogits, void* dx, float* dw, float* db,
+                                int64_t nvox, int C, int L, int relu_mask, int dtype, fmri_stream_t stream) {
+    if (nvox <= 0 || C <= 0 || L <= 0 || (size_t)L * (2 * C + 1) * 4 > 64 * 1024) return FMRI_E_SHAPE;
+    int vec = pick_vec(C, 4);
+    int grid = grid_for(nvox, 256, 256 * 4);
+    hipStream_t s = as_stream(stream);
+    size_t sh = (size_t)L * (2 * C + 1) * 4;
+    if (dtype == FMRI_F32) {
+        switch (vec) {
+            case 4: k_conv1x1_bwd<float, 4><<<grid, 256, sh, s>>>((const float*)x, w, dlogits, (float*)dx, dw, db, nvox, C, L, relu_mask); break;
+            case 2: k_conv1x1_bwd<float, 2><<<grid, 256, sh, s>>>((const float*)x, w, dlogits, (float*)dx, dw, db, nvox, C, L, relu_mask); break;
+            default: k_conv1x1_bwd<float, 1><<<grid, 256, sh, s>>>((const float*)x, w, dlogits, (float*)dx, dw, db, nvox, C, L, relu_mask); break;
+        }
+    } else if (dtype == FMRI_BF16) {
+        switch (vec) {
+            case 4: k_conv1x1_bwd<bf16_t, 4><<<grid, 256, sh, s>>>((const bf16_t*)x, w, dlogits, (bf16_t*)dx, dw, db, nvox, C, L, relu_mask); break;
+            case 2: k_conv1x1_bwd<bf16_t, 2><<<grid, 256, sh, s>>>((const bf16_t*)x, w, dlogits, (bf16_t*)dx, dw, db, nvox, C, L, relu_mask); break;
+            default: k_conv1x1_bwd<bf16_t, 1><<<grid, 256, sh, s>>>((const bf16_t*)x, w, dlogits, (bf16_t*)dx, dw, db, nvox, C, L, relu_mask); break;
+        }
+    } else return FMRI_E_DTYPE;
+    FMRI_LAUNCH_CHECK();
+    return FMRI_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ sigmoid + Dice
+// Reference: Activation('sigmoid') unet.py:69; dice_coefficient metrics.py:11-15; vod_coefficient :18-28;
+// Keras 'binary_accuracy' (unet.py:81).  Block-reduce in double, one atomic per block and sum.
+__device__ __forceinline__ double wave_sum(double v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+    return v;
+}
+__global__ void k_sigmoid_dice_fwd(const float* __restrict__ logits, const uint8_t* __restrict__ y, float* __restrict__ probs,
+                                   double* __restrict__ sums, int64_t n) {
+    double s[7] = {0, 0, 0, 0, 0, 0, 0};
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float z = logits[i];
+        float p = 1.f / (1.f + __expf(-z));
+        if (probs) probs[i] = p;
+        float t = (float)y[i];
+        s[0] += (double)(t * p);
+        s[1] += (double)t;
+        s[2] += (double)p;
+        float tb = t > 0.5f ? 1.f : 0.f, pb = p > 0.5f ? 1.f : 0.f;
+        s[3] += tb * pb;
+        s[4] += tb;
+        s[5] += pb;
+        s[6] += (rintf(p) == t) ? 1.0 : 0.0;
+    }
+    __shared__ double red[7][4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+        double r = wave_sum(s[k]);
+        if (lane == 0) red[k][wv] = r;
+    }
+    __syncthreads();
+    if (threadIdx.x < 7) {
+        double r = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
+        atomicAdd(&sums[threadIdx.x], r);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 7) atomicAdd(&sums[7], (double)n);
+}
+__global__ void k_sigmoid_dice_bwd(const float* __restrict__ probs, const uint8_t* __restrict__ y, const double* __restrict__ sums,
+                                   float* __restrict__ dl, int64_t n, float smooth, float grad_scale) {
+    const double I = sums[0], den = sums[1] + sums[2] + (double)smooth;
+    const float a = (float)(2.0 / den);                       // coefficient of y
+    const float c = (float)((2.0 * I + (double)smooth) / (den * den));
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float p = probs[i], t = (float)y[i];
+        float dLdp = -(a * t - c);
+        dl[i] = grad_scale * dLdp * p * (1.f - p);
+    }
+}
+extern "C" int fmri_sigmoid_dice_fwd(const float* logits, const uint8_t* y_true, float* probs, double* sums, int64_t n,
+                                     fmri_stream_t stream) {
+    if (n <= 0) return FMRI_E_SHAPE;
+    k_sigmoid_dice_fwd<<<grid_for(n, 256, 1024), 256, 0, as_stream(stream)>>>(logits, y_true, probs, sums, n);
+    FMRI_LAUNCH_CHECK();
+    return FMRI_OK;
+}
+extern "C" int fmri_sigmoid_dice_bwd(const float* probs, const uint8_t* y_true, const double* sums, float* dlogits, int64_t n,
+                                     float smooth, float grad_scale, fmri_stream_t stream) {
+    if (n <= 0) return FMRI_E_SHAPE;
+    k_sigmoid_dice_bwd<<<grid_for(n, 256, 2048), 256, 0, as_stream(stream)>>>(probs, y_true, sums, dlogits, n, smooth, grad_scale);
+    FMRI_LAUNCH_CHECK();
+    return FMRI_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ Keras Adam
+// Reference: Adam(lr=initial_learning_rate) at unet3d/unet.py:85; Keras 2.2 update rule (epsilon outside the sqrt).
+__global__ void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                       int64_t n, float lr_t, float b1, float b2, float eps, float gs) {
+    const int64_t n4 = n >> 2;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        float4 pp = ((float4*)p)[i], gg = ((const float4*)g)[i], mm = ((float4*)m)[i], vv = ((float4*)v)[i];
+        float* pa = (float*)&pp; float* ga = (float*)&gg; float* ma = (float*)&mm; float* va = (float*)&vv;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float gr = ga[k] * gs;
+            ma[k] = b1 * ma[k] + (1.f - b1) * gr;
+            va[k] = b2 * va[k] + (1.f - b2) * gr * gr;
+            pa[k] -= lr_t * ma[k] / (sqrtf(va[k]) + eps);
+        }
+        ((float4*)p)[i] = pp; ((float4*)m)[i] = mm; ((float4*)v)[i] = vv;
+    }
+    for (int64_t i = (n4 << 2) + blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float gr = g[i] * gs;
+        float mi = b1 * m[i] + (1.f - b1) * gr, vi = b2 * v[i] + (1.f - b2) * gr * gr;
+        m[i] = mi; v[i] = vi;
+        p[i] -= lr_t * mi / (sqrtf(vi) + eps);
+    }
+}
+extern "C" int fmri_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr_t, float beta1, float beta2,
+                              float eps, float grad_scale, fmri_stream_t stream) {
+    if (n <= 0) return FMRI_E_SHAPE;
+    if ((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)m) | ((uintptr_t)v)) & 15) return FMRI_E_ALIGN;
+    k_adam<<<grid_for(n / 4 + 1, 256, 2048), 256, 0, as_stream(stream)>>>(p, g, m, v, n, lr_t, beta1, beta2, eps, grad_scale);
+    FMRI_LAUNCH_CHECK();
+    return FMRI_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ weight packing
+// fp32 master [27][Cout][Cin] -> compute-dtype copies: forward layout and the tap-flipped transposed dgrad layout.
+template <typename T>
+__global__ void k_pack_weights(const float* __restrict__ w, T* __restrict__ wf, T* __restrict__ wd, int Cout, int Cin) {
+    const int64_t total = (int64_t)27 * Cout * Cin;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        float val = w[i];
+        if (wf) wf[i] = from_f<T>(val);
+        if (wd) {
+            int ci = (int)(i % Cin);
+            int64_t r = i / Cin;
+            int co = (int)(r % Cout);
+            int tap = (int)(r / Cout);
+            wd[((int64_t)(26 - tap) * Cin + ci) * Cout + co] = from_f<T>(val);
+        }
+    }
+}
+extern "C" int fmri_conv3d_pack_weights(const float* w, void* w_fwd, void* w_dgrad, int Cout, int Cin, int dtype,
+                                        fmri_stream_t stream) {
+    if (Cout <= 0 || Cin <= 0) return FMRI_E_SHAPE;
+    int grid = grid_for((int64_t)27 * Cout * Cin, 256, 1024);
+    if (dtype == FMRI_F32) k_pack_weights<float><<<grid, 256, 0, as_stream(stream)>>>(w, (float*)w_fwd, (float*)w_dgrad, Cout, Cin);
+    else if (dtype == FMRI_BF16) k_pack_weights<bf16_t><<<grid, 256, 0, as_stream(stream)>>>(w, (bf16_t*)w_fwd, (bf16_t*)w_dgrad, Cout, Cin);
+    else return FMRI_E_DTYPE;
+    FMRI_LAUNCH_CHECK();
+    return FMRI_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ sliding-window tiles
+// Reference: batch_iterator / get_patch_from_3d_data (prediction.py:98-114, utils/patches.py:57-72) and the
+// overlap-add loop prediction.py:188-193 and the final division :210.
+template <typename T>
+__global__ void k_tile_gather(const float* __restrict__ vol, int X, int Y, int Z, const int32_t* __restrict__ idx, int B, int px,
+                              int py, int pz, T* __restrict__ tiles) {
+    const int64_t per = (int64_t)px * py * pz, total = per * B;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int b = (int)(i / per);
+        int64_t r = i % per;
+        int z = (int)(r % pz); r /= pz;
+        int y = (int)(r % py);
+        int x = (int)(r / py);
+        int gx = idx[3 * b] + x, gy = idx[3 * b + 1] + y, gz = idx[3 * b + 2] + z;
+        // out-of-bound corners replicate the edge (utils/patches.py:75-91, np.pad mode="edge")
+        gx = min(max(gx, 0), X - 1); gy = min(max(gy, 0), Y - 1); gz = min(max(gz, 0), Z - 1);
+        tiles[i] = from_f<T>(vol[((int64_t)gx * Y + gy) * Z + gz]);
+    }
+}
+__global__ void k_tile_scatter(const float* __restrict__ pred, const int32_t* __restrict__ idx, int B, int px, int py, int pz,
+                               int C, double* __restrict__ acc, int32_t* __restrict__ cnt, int X, int Y, int Z) {
+    const int64_t per = (int64_t)px * py * pz, total = per * B;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int b = (int)(i / per);
+        int64_t r = i % per;
+        int z = (int)(r % pz); r /= pz;
+        int y = (int)(r % py);
+        int x = (int)(r / py);
+        int gx = idx[3 * b] + x, gy = idx[3 * b + 1] + y, gz = idx[3 * b + 2] + z;
+        if (gx < 0 || gy < 0 || gz < 0 || gx >= X || gy >= Y || gz >= Z) continue;
+        int64_t o = ((int64_t)gx * Y + gy) * Z + gz;
+        for (int c = 0; c < C; ++c) atomicAdd(&acc[o * C + c], (double)pred[i * C + c]);
+        atomicAdd(&cnt[o], 1);
+    }
+}
+__global__ void k_tile_finalize(const double* __restrict__ acc, const int32_t* __restrict__ cnt, double* __restrict__ out,
+                                int32_t* __restrict__ bad, int64_t nvox, int C) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nvox; i += (int64_t)gridDim.x * blockDim.x) {
+        int c = cnt[i];
+        if (c <= 0) { atomicAdd(bad, 1); c = 1; }
+        for (int k = 0; k < C; ++k) out[i * C + k] = acc[i * C + k] / (double)c;
+    }
+}
+extern "C" int fmri_tile_gather(const float* vol, int X, int Y, int Z, const int32_t* idx, int B, int px, int py, int pz,
+                                void* tiles, int dtype, fmri_stream_t stream) {
+    if (B <= 0 || px <= 0 || py <= 0 || pz <= 0 || X <= 0 || Y <= 0 || Z <= 0) return FMRI_E_SHAPE;
+    int grid = grid_for((int64_t)B * px * py * pz, 256, 4096);
+    if (dtype == FMRI_F32) k_tile_gather<float><<<grid, 256, 0, as_stream(stream)>>>(vol, X, Y, Z, idx, B, px, py, pz, (float*)tiles);
+    else if (dtype == FMRI_BF16) k_tile_gather<bf16_t><<<grid, 256, 0, as_stream(stream)>>>(vol, X, Y, Z, idx, B, px, py, pz, (bf16_t*)tiles);
+    else return FMRI_E_DTYPE;
+    FMRI_LAUNCH_CHECK();
+    return FMRI_OK;
+}
+extern "C" int fmri_tile_scatter_accumulate(const float* pred, const int32_t* idx, int B, int px, int py, int pz, int C,
+                                            double* acc, int32_t* cnt, int X, int Y, int Z, fmri_stream_t stream) {
+    if (B <= 0 || px <= 0 || py <= 0 || pz <= 0 || C <= 0) return FMRI_E_SHAPE;
+    k_tile_scatter<<<grid_for((int64_t)B * px * py * pz, 256, 4096), 256, 0, as_stream(stream)>>>(pred, idx, B, px, py, pz, C, acc, cnt, X, Y, Z);
+    FMRI_LAUNCH_CHECK();
+    return FMRI_OK;
+}
+extern "C" int fmri_tile_finalize(const double* acc, const int32_t* cnt, double* out, int32_t* bad, int64_t nvox, int C,
+                                  fmri_stream_t stream) {
+    if (nvox <= 0 || C <= 0) return FMRI_E_SHAPE;
+    k_tile_finalize<<<grid_for(nvox, 256, 4096), 256, 0, as_stream(stream)>>>(acc, cnt, out, bad, nvox, C);
+    FMRI_LAUNCH_CHECK();
+    return FMRI_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ casts
+template <typename S, typename Dd>
+__global__ void k_cast(const S* __restrict__ s, Dd* __restrict__ d, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        d[i] = from_f<Dd>(to_f<S>(s[i]));
+}
+extern "C" int fmri_cast(const void* src, int sd, void* dst, int dd, int64_t n, fmri_stream_t stream) {
+    if (n <= 0) return FMRI_E_SHAPE;
+    int grid = grid_for(n, 256, 4096);
+    hipStream_t s = as_stream(stream);
+    if (sd == FMRI_F32 && dd == FMRI_BF16) k_cast<float, bf16_t><<<grid, 256, 0, s>>>((const float*)src, (bf16_t*)dst, n);
+    else if (sd == FMRI_BF16 && dd == FMRI_F32) k_cast<bf16_t, float><<<grid, 256, 0, s>>>((const bf16_t*)src, (float*)dst, n);
+    else if (sd == FMRI_F32 && dd == FMRI_F32) k_cast<float, float><<<grid, 256, 0, s>>>((const float*)src, (float*)dst, n);
+    else if (sd == FMRI_BF16 && dd == FMRI_BF16) k_cast<bf16_t, bf16_t><<<grid, 256, 0, s>>>((const bf16_t*)src, (bf16_t*)dst, n);
+    else return FMRI_E_DTYPE;
+    FMRI_LAUNCH_CHECK();
+    return FMRI_OK;
+}

@@ -1,0 +1,164 @@
+"""torch-tensor front-ends of the C ABI.  torch is plumbing only: device memory, the current HIP stream, dtypes."""
+import torch
+
+from ._lib import lib, check, F32, BF16, ACT_NONE, ACT_RELU, IMPL_AUTO
+
+
+def dt(t):
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise TypeError("unsupported dtype %s" % t.dtype)
+
+
+def _s():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("fmri_hip ops need device tensors (no CPU path)")
+        if t is not None and not t.is_contiguous():
+            raise RuntimeError("fmri_hip ops need contiguous tensors")
+
+
+def conv3d_fwd(src0, src1, w, bias, y, up0=False, act=ACT_RELU, alpha=0.0, mask=None, impl=IMPL_AUTO):
+    """src0 [N,d,h,w,C0] (half-res when up0), src1 [N,D,H,W,C1] or None, w [27,Cout,C0+C1], y [N,D,H,W,Cout]."""
+    _need_cuda(src0, src1, w, bias, y, mask)
+    N, D, H, W, Cout = y.shape
+    C0 = src0.shape[-1]
+    C1 = 0 if src1 is None else src1.shape[-1]
+    assert w.shape == (27, Cout, C0 + C1), (w.shape, Cout, C0, C1)
+    check(lib().fmri_conv3d_fwd(_p(src0), C0, int(up0), _p(src1), C1, _p(w), _p(bias), _p(mask), _p(y), N, D, H, W, Cout,
+                                act, float(alpha), dt(y), impl, _s()), "fmri_conv3d_fwd")
+    return y
+
+
+def conv3d_dgrad(dy, w_dgrad, dx, mask=None, impl=IMPL_AUTO):
+    _need_cuda(dy, w_dgrad, dx, mask)
+    N, D, H, W, Cin = dx.shape
+    Cout = dy.shape[-1]
+    assert w_dgrad.shape == (27, Cin, Cout)
+    check(lib().fmri_conv3d_dgrad(_p(dy), Cout, _p(w_dgrad), _p(mask), _p(dx), N, D, H, W, Cin, dt(dx), impl, _s()),
+          "fmri_conv3d_dgrad")
+    return dx
+
+
+def conv3d_wgrad(src0, src1, dy, dw, db, up0=False, impl=IMPL_AUTO):
+    _need_cuda(src0, src1, dy, dw, db)
+    N, D, H, W, Cout = dy.shape
+    C0 = src0.shape[-1]
+    C1 = 0 if src1 is None else src1.shape[-1]
+    assert dw.dtype == torch.float32 and dw.numel() == 27 * Cout * (C0 + C1)
+    check(lib().fmri_conv3d_wgrad(_p(src0), C0, int(up0), _p(src1), C1, _p(dy), _p(dw), _p(db), N, D, H, W, Cout, dt(dy),
+                                  impl, _s()), "fmri_conv3d_wgrad")
+
+
+def pack_weights(w, w_fwd, w_dgrad):
+    _need_cuda(w, w_fwd, w_dgrad)
+    _, Cout, Cin = w.shape
+    d = dt(w_fwd if w_fwd is not None else w_dgrad)
+    check(lib().fmri_conv3d_pack_weights(_p(w), _p(w_fwd), _p(w_dgrad), Cout, Cin, d, _s()), "fmri_conv3d_pack_weights")
+
+
+def conv1x1_fwd(x, w, b, logits):
+    _need_cuda(x, w, b, logits)
+    C = x.shape[-1]
+    L = w.shape[0]
+    nvox = x.numel() // C
+    check(lib().fmri_conv1x1_fwd(_p(x), _p(w), _p(b), _p(logits), nvox, C, L, dt(x), _s()), "fmri_conv1x1_fwd")
+    return logits
+
+
+def conv1x1_bwd(x, w, dlogits, dx, dw, db, relu_mask=True):
+    _need_cuda(x, w, dlogits, dx, dw, db)
+    C = x.shape[-1]
+    L = w.shape[0]
+    nvox = x.numel() // C
+    check(lib().fmri_conv1x1_bwd(_p(x), _p(w), _p(dlogits), _p(dx), _p(dw), _p(db), nvox, C, L, int(relu_mask), dt(x), _s()),
+          "fmri_conv1x1_bwd")
+
+
+def sigmoid_dice_fwd(logits, y_true, probs, sums):
+    _need_cuda(logits, y_true, probs, sums)
+    assert y_true.dtype == torch.uint8 and sums.dtype == torch.float64 and sums.numel() >= 8
+    check(lib().fmri_sigmoid_dice_fwd(_p(logits), _p(y_true), _p(probs), _p(sums), logits.numel(), _s()), "fmri_sigmoid_dice_fwd")
+
+
+def sigmoid_dice_bwd(probs, y_true, sums, dlogits, smooth=1.0, grad_scale=1.0):
+    _need_cuda(probs, y_true, sums, dlogits)
+    check(lib().fmri_sigmoid_dice_bwd(_p(probs), _p(y_true), _p(sums), _p(dlogits), probs.numel(), float(smooth),
+                                      float(grad_scale), _s()), "fmri_sigmoid_dice_bwd")
+
+
+def maxpool_fwd(x, y):
+    _need_cuda(x, y)
+    N, D, H, W, Cc = x.shape
+    check(lib().fmri_maxpool3d_2x_fwd(_p(x), _p(y), N, D, H, W, Cc, dt(x), _s()), "fmri_maxpool3d_2x_fwd")
+    return y
+
+
+def maxpool_bwd(x, dy, dx, add=None, add_off=0, relu_mask=True):
+    _need_cuda(x, dy, dx, add)
+    N, D, H, W, Cc = x.shape
+    add_ld = 0 if add is None else add.shape[-1]
+    check(lib().fmri_maxpool3d_2x_bwd(_p(x), _p(dy), _p(add), add_ld, add_off, _p(dx), N, D, H, W, Cc, int(relu_mask), dt(x), _s()),
+          "fmri_maxpool3d_2x_bwd")
+    return dx
+
+
+def upsample_fwd(x, y, y_off=0):
+    _need_cuda(x, y)
+    N, D, H, W, Cc = x.shape
+    check(lib().fmri_upsample_nearest2x_fwd(_p(x), _p(y), y.shape[-1], y_off, N, D, H, W, Cc, dt(x), _s()),
+          "fmri_upsample_nearest2x_fwd")
+    return y
+
+
+def upsample_bwd(dy, dx, dy_off=0, xmask=None):
+    _need_cuda(dy, dx, xmask)
+    N, D, H, W, Cc = dx.shape
+    check(lib().fmri_upsample_nearest2x_bwd(_p(dy), dy.shape[-1], dy_off, _p(xmask), _p(dx), N, D, H, W, Cc, dt(dx), _s()),
+          "fmri_upsample_nearest2x_bwd")
+    return dx
+
+
+def adam_step(p, g, m, v, lr_t, beta1=0.9, beta2=0.999, eps=1e-7, grad_scale=1.0):
+    _need_cuda(p, g, m, v)
+    check(lib().fmri_adam_step(_p(p), _p(g), _p(m), _p(v), p.numel(), float(lr_t), beta1, beta2, eps, float(grad_scale), _s()),
+          "fmri_adam_step")
+
+
+def tile_gather(vol, idx, patch, tiles):
+    _need_cuda(vol, idx, tiles)
+    X, Y, Z = vol.shape
+    B = idx.shape[0]
+    check(lib().fmri_tile_gather(_p(vol), X, Y, Z, _p(idx), B, patch[0], patch[1], patch[2], _p(tiles), dt(tiles), _s()),
+          "fmri_tile_gather")
+    return tiles
+
+
+def tile_scatter_accumulate(pred, idx, patch, acc, cnt):
+    _need_cuda(pred, idx, acc, cnt)
+    X, Y, Z, Cc = acc.shape
+    B = idx.shape[0]
+    check(lib().fmri_tile_scatter_accumulate(_p(pred), _p(idx), B, patch[0], patch[1], patch[2], Cc, _p(acc), _p(cnt), X, Y, Z,
+                                             _s()), "fmri_tile_scatter_accumulate")
+
+
+def tile_finalize(acc, cnt, out, bad):
+    _need_cuda(acc, cnt, out, bad)
+    Cc = acc.shape[-1]
+    check(lib().fmri_tile_finalize(_p(acc), _p(cnt), _p(out), _p(bad), cnt.numel(), Cc, _s()), "fmri_tile_finalize")
+
+
+def cast(src, dst):
+    _need_cuda(src, dst)
+    check(lib().fmri_cast(_p(src), dt(src), _p(dst), dt(dst), src.numel(), _s()), "fmri_cast")
+    return dst

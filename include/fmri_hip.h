@@ -1,0 +1,125 @@
+/*
+ * fmri_hip.h — C ABI of the MI355X (gfx950) hot path for the fetal-MRI 3D/2D U-Net.
+ *
+ * The reference (GalDude33/Fetal-MRI-Segmentation) has no FFI layer: its hot path is the chain of TensorFlow ops
+ * that Keras emits for fetal_net/model/unet3d/unet.py:17-138 (+ metrics.py:11-32, Adam at unet.py:85) and the numpy
+ * overlap-add of fetal_net/prediction.py:118-210.  Each entry point below names the reference line whose implicit
+ * TF/numpy op it replaces.  The host side (fetal-mri-segmentation_amd/fetal_net/) binds these with ctypes.
+ *
+ * Conventions
+ *   - extern "C", int return: FMRI_OK or a negative FMRI_E_* code; no exceptions, no allocation, no host sync.
+ *   - every call only ENQUEUES work on the caller's HIP stream (`stream` = hipStream_t, may be NULL = default stream).
+ *   - all pointers are caller-owned DEVICE pointers unless stated otherwise.
+ *   - activations are channels-last: [N][D][H][W][C] ("NDHWC"); a 2-D slice batch is D == 1.
+ *   - dtype = FMRI_F32 (parity mode, plain fp32 arithmetic) or FMRI_BF16 (bf16 storage, fp32 accumulate; MFMA path
+ *     when channel counts are multiples of 32 and the spatial tile divides, generic VALU path otherwise).
+ *   - 3x3x3 filters are stored [27 taps = kd*9+kh*3+kw][Cout][Cin] (Cin contiguous).  Keras' (kD,kH,kW,Cin,Cout)
+ *     kernels are permuted by the host when weights are loaded.
+ */
+#ifndef FMRI_HIP_H
+#define FMRI_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* fmri_stream_t; /* hipStream_t */
+
+enum { FMRI_OK = 0, FMRI_E_SHAPE = -1, FMRI_E_ALIGN = -2, FMRI_E_ARCH = -3, FMRI_E_LAUNCH = -4, FMRI_E_DTYPE = -5 };
+enum { FMRI_F32 = 0, FMRI_BF16 = 1 };
+enum { FMRI_ACT_NONE = 0, FMRI_ACT_RELU = 1, FMRI_ACT_LEAKY = 2 };
+/* which implementation a conv call may use: AUTO picks MFMA when the shape allows it */
+enum { FMRI_IMPL_AUTO = 0, FMRI_IMPL_GENERIC = 1, FMRI_IMPL_MFMA = 2 };
+
+int fmri_version(void);
+const char* fmri_error_string(int code);
+/* 0/1: would fmri_conv3d_fwd / _wgrad take the MFMA path for this shape and dtype? (host-side query, no GPU needed) */
+int fmri_conv3d_uses_mfma(int C0, int C1, int Cout, int D, int H, int W, int dtype);
+
+/* ---- Conv3D 3x3x3, stride 1, 'same' (+BiasAdd +activation) — reference unet3d/unet.py:102,113 (create_convolution_block)
+ * The input is the channel concatenation [src0 | src1] (reference unet.py:61 `concatenate([up, skip], axis=1)`):
+ *   src0: C0 channels.  up0 != 0: src0 is stored at HALF resolution [N][D/2][H/2][W/2][C0] and is read through a fused
+ *         nearest-neighbour x2 (reference unet.py:138 UpSampling3D) — the up-sampled tensor / concat is never built.
+ *   src1: C1 channels at full resolution, or NULL with C1 == 0.
+ * w [27][Cout][C0+C1] (dtype), bias fp32 [Cout] or NULL.  act per FMRI_ACT_*, leaky slope `alpha`.
+ * mask (optional, [N][D][H][W][Cout], dtype): y = mask > 0 ? y : 0  — the ReluGrad of the producing layer, used when this
+ * kernel runs as Conv3DBackpropInput. */
+int fmri_conv3d_fwd(const void* src0, int C0, int up0, const void* src1, int C1, const void* w, const float* bias,
+                    const void* mask, void* y, int N, int D, int H, int W, int Cout, int act, float alpha, int dtype,
+                    int impl, fmri_stream_t stream);
+
+/* ---- Conv3DBackpropInputV2 (autodiff of unet.py:102): dx = conv(dy, w_dgrad) * (mask > 0).
+ * w_dgrad [27][Cin][Cout] is the tap-flipped, transposed copy made by fmri_conv3d_pack_weights. */
+int fmri_conv3d_dgrad(const void* dy, int Cout, const void* w_dgrad, const void* mask, void* dx, int N, int D, int H,
+                      int W, int Cin, int dtype, int impl, fmri_stream_t stream);
+
+/* ---- Conv3DBackpropFilterV2 + BiasAddGrad: dw[27][Cout][C0+C1] (fp32) += sum_v x[v+tap][ci]*dy[v][co];
+ * db[Cout] (fp32) += sum_v dy[v][co] (db may be NULL).  ACCUMULATES: the caller zeroes dw/db once per step.
+ * Same dual-source / fused-upsample input description as fmri_conv3d_fwd. */
+int fmri_conv3d_wgrad(const void* src0, int C0, int up0, const void* src1, int C1, const void* dy, float* dw, float* db,
+                      int N, int D, int H, int W, int Cout, int dtype, int impl, fmri_stream_t stream);
+
+/* fp32 master filter [27][Cout][Cin] -> w_fwd (dtype, same layout) and w_dgrad (dtype, [26-tap][Cin][Cout]).
+ * Either destination may be NULL. */
+int fmri_conv3d_pack_weights(const float* w, void* w_fwd, void* w_dgrad, int Cout, int Cin, int dtype,
+                             fmri_stream_t stream);
+
+/* ---- final Conv3D(n_labels,(1,1,1)) — reference unet.py:68.  logits[v][l] (fp32) = sum_c x[v][c]*w[l][c] + b[l]. */
+int fmri_conv1x1_fwd(const void* x, const float* w, const float* b, float* logits, int64_t nvox, int C, int L,
+                     int dtype, fmri_stream_t stream);
+/* dx[v][c] = (x[v][c] > 0 || !relu_mask) ? sum_l dlogits[v][l]*w[l][c] : 0 ; dw[l][c] += sum_v dlogits*x ; db[l] += sum_v dlogits */
+int fmri_conv1x1_bwd(const void* x, const float* w, const float* dlogits, void* dx, float* dw, float* db, int64_t nvox,
+                     int C, int L, int relu_mask, int dtype, fmri_stream_t stream);
+
+/* ---- Activation('sigmoid') + dice_coefficient_loss + the compiled metrics — reference unet.py:69,81-85, metrics.py:11-32.
+ * probs = sigmoid(logits); sums (8 doubles, ACCUMULATED, caller zeroes) =
+ *   [0] sum y*p  [1] sum y  [2] sum p  [3] sum (y>.5)(p>.5)  [4] sum (y>.5)  [5] sum (p>.5)  [6] sum (round(p)==y)  [7] n
+ * y_true is uint8 (reference generator emits uint8 truth) with the same [v][l] indexing as logits. */
+int fmri_sigmoid_dice_fwd(const float* logits, const uint8_t* y_true, float* probs, double* sums, int64_t n,
+                          fmri_stream_t stream);
+/* dlogits = grad_scale * dL/dp * p(1-p),  L = -(2I+s)/(Sy+Sp+s),  dL/dp = -[2y(Sy+Sp+s) - (2I+s)]/(Sy+Sp+s)^2, s = smooth.
+ * `sums` are the (possibly all-reduced, global-batch) sums produced above. */
+int fmri_sigmoid_dice_bwd(const float* probs, const uint8_t* y_true, const double* sums, float* dlogits, int64_t n,
+                          float smooth, float grad_scale, fmri_stream_t stream);
+
+/* ---- MaxPooling3D(2,2,2) — reference unet.py:51.  D,H,W are the INPUT dims (even). */
+int fmri_maxpool3d_2x_fwd(const void* x, void* y, int N, int D, int H, int W, int C, int dtype, fmri_stream_t stream);
+/* MaxPool3DGrad fused with the skip-gradient add and the ReluGrad of the producer:
+ *   dx[v][c] = ( (add ? add[v*add_ld + add_off + c] : 0) + (x[v][c] is the first max of its window ? dy[win][c] : 0) ) * (x>0 || !relu_mask) */
+int fmri_maxpool3d_2x_bwd(const void* x, const void* dy, const void* add, int add_ld, int add_off, void* dx, int N,
+                          int D, int H, int W, int C, int relu_mask, int dtype, fmri_stream_t stream);
+
+/* ---- UpSampling3D(2) — reference unet.py:138.  Materialising forward (writes channel slice [y_off, y_off+C) of a
+ * tensor with y_ld channels); D,H,W are the LOW-resolution dims.  The conv kernels do not need it (fused). */
+int fmri_upsample_nearest2x_fwd(const void* x, void* y, int y_ld, int y_off, int N, int D, int H, int W, int C, int dtype,
+                                fmri_stream_t stream);
+/* backward: dx[v][c] = (sum over the 2x2x2 children of dy[child*dy_ld + dy_off + c]) * (xmask[v][c] > 0 || !xmask) */
+int fmri_upsample_nearest2x_bwd(const void* dy, int dy_ld, int dy_off, const void* xmask, void* dx, int N, int D, int H,
+                                int W, int C, int dtype, fmri_stream_t stream);
+
+/* ---- Keras Adam.get_updates — reference unet.py:85.  lr_t = lr*sqrt(1-b2^t)/(1-b1^t) is computed by the host.
+ * g is multiplied by grad_scale first.  p -= lr_t * m/(sqrt(v)+eps). One launch over the flat parameter buffer. */
+int fmri_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr_t, float beta1, float beta2,
+                   float eps, float grad_scale, fmri_stream_t stream);
+
+/* ---- sliding-window overlap-add — reference prediction.py:98-114 (batch_iterator/get_patch_from_3d_data), :188-193, :210.
+ * vol fp32 [X][Y][Z] (already padded by the host as prediction.py:138-146); idx int32 [B][3] device; tiles out (dtype)
+ * [B][px][py][pz] (C = 1, NDHWC == NCDHW). */
+int fmri_tile_gather(const float* vol, int X, int Y, int Z, const int32_t* idx, int B, int px, int py, int pz, void* tiles,
+                     int dtype, fmri_stream_t stream);
+/* acc (double) [X][Y][Z][C] += pred[b][px][py][pz][C] (fp32); cnt (int32) [X][Y][Z] += 1 */
+int fmri_tile_scatter_accumulate(const float* pred, const int32_t* idx, int B, int px, int py, int pz, int C, double* acc,
+                                 int32_t* cnt, int X, int Y, int Z, fmri_stream_t stream);
+/* out (double) [n][C] = acc / cnt ; *bad (int32, accumulated) counts voxels with cnt == 0 (reference asserts none) */
+int fmri_tile_finalize(const double* acc, const int32_t* cnt, double* out, int32_t* bad, int64_t nvox, int C,
+                       fmri_stream_t stream);
+
+/* ---- plumbing: dtype casts used around the boundary (fp32 <-> bf16), n elements */
+int fmri_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, fmri_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FMRI_HIP_H */

@@ -1,0 +1,249 @@
+"""GPU parity of each C-ABI kernel against torch-CPU fp64 restatements (checker).  Run with -m gpu on an MI355X.
+
+Tolerances: fp32 mode 1e-5 relative (plain fmaf chains, only summation order differs); bf16 mode: inputs are rounded to
+bf16 first and the checker uses those rounded inputs in fp64, so the remaining error is the bf16 rounding of the stored
+output (2^-9 relative) plus fp32 accumulation order -> 1e-2.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from gpu_util import (assert_close, f64, keras_kernel_from_packed, ref_concat_input, ref_conv_fwd, rnd, to_ncdhw, to_ndhwc)
+
+pytestmark = pytest.mark.gpu
+
+TOL = {torch.float32: (1e-5, 1e-5), torch.bfloat16: (1e-2, 1e-2)}
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "these tests need the GPU box"
+    from fmri_hip import ops as o
+    return o
+
+
+CONV_CASES = [
+    # name, N,D,H,W, C0, up0, C1, Cout, impl
+    ("generic_small_f32", torch.float32, 1, 4, 8, 16, 3, False, 0, 5, 1),
+    ("generic_odd_f32", torch.float32, 2, 3, 5, 7, 2, False, 0, 3, 1),
+    ("generic_dual_up_f32", torch.float32, 1, 4, 8, 16, 8, True, 4, 6, 1),
+    ("generic_cin1_f32", torch.float32, 1, 4, 16, 16, 1, False, 0, 8, 1),
+    ("generic_2d_f32", torch.float32, 2, 1, 16, 16, 5, False, 0, 8, 1),
+    ("generic_bf16", torch.bfloat16, 1, 4, 8, 16, 8, False, 0, 16, 1),
+    ("mfma_32_64", torch.bfloat16, 1, 4, 8, 16, 32, False, 0, 64, 2),
+    ("mfma_64_32", torch.bfloat16, 1, 4, 8, 16, 64, False, 0, 32, 2),
+    ("mfma_multi_tile", torch.bfloat16, 2, 8, 16, 32, 64, False, 0, 64, 2),
+    ("mfma_dual_up", torch.bfloat16, 1, 8, 16, 32, 64, True, 32, 64, 2),
+    ("mfma_dual_noup_128", torch.bfloat16, 1, 4, 8, 16, 32, False, 64, 128, 2),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv3d_fwd(ops, case):
+    name, dtype, N, D, H, W, C0, up0, C1, Cout, impl = case
+    s0 = (N, D // 2, H // 2, W // 2, C0) if up0 else (N, D, H, W, C0)
+    src0 = rnd(s0, 1, dtype)
+    src1 = rnd((N, D, H, W, C1), 2, dtype) if C1 else None
+    w = rnd((27, Cout, C0 + C1), 3, dtype, scale=0.2)
+    bias = rnd((Cout,), 4, torch.float32)
+    y = torch.full((N, D, H, W, Cout), float("nan"), dtype=dtype, device="cuda")
+    ops.conv3d_fwd(src0, src1, w, bias, y, up0=up0, act=1, impl=impl)
+    torch.cuda.synchronize()
+    ref = ref_conv_fwd(f64(src0), None if src1 is None else f64(src1), up0, f64(w), f64(bias), 1)
+    assert_close(y, ref, *TOL[dtype], what=name)
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv3d_fwd_noact_mask(ops, case):
+    """the dgrad form: no bias, no activation, ReLU mask epilogue"""
+    name, dtype, N, D, H, W, C0, up0, C1, Cout, impl = case
+    s0 = (N, D // 2, H // 2, W // 2, C0) if up0 else (N, D, H, W, C0)
+    src0 = rnd(s0, 5, dtype)
+    src1 = rnd((N, D, H, W, C1), 6, dtype) if C1 else None
+    w = rnd((27, Cout, C0 + C1), 7, dtype, scale=0.2)
+    mask = rnd((N, D, H, W, Cout), 8, dtype)
+    y = torch.full((N, D, H, W, Cout), float("nan"), dtype=dtype, device="cuda")
+    ops.conv3d_fwd(src0, src1, w, None, y, up0=up0, act=0, mask=mask, impl=impl)
+    torch.cuda.synchronize()
+    ref = ref_conv_fwd(f64(src0), None if src1 is None else f64(src1), up0, f64(w), None, 0)
+    ref = ref * (f64(mask) > 0)
+    assert_close(y, ref, *TOL[dtype], what=name)
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv3d_wgrad(ops, case):
+    name, dtype, N, D, H, W, C0, up0, C1, Cout, impl = case
+    if impl == 2 and Cout % 64:
+        pytest.skip("MFMA wgrad needs Cout % 64 == 0")
+    s0 = (N, D // 2, H // 2, W // 2, C0) if up0 else (N, D, H, W, C0)
+    src0 = rnd(s0, 9, dtype)
+    src1 = rnd((N, D, H, W, C1), 10, dtype) if C1 else None
+    dy = rnd((N, D, H, W, Cout), 11, dtype)
+    dw = torch.zeros((27, Cout, C0 + C1), dtype=torch.float32, device="cuda")
+    db = torch.zeros((Cout,), dtype=torch.float32, device="cuda")
+    ops.conv3d_wgrad(src0, src1, dy, dw, db, up0=up0, impl=impl)
+    torch.cuda.synchronize()
+    x = ref_concat_input(f64(src0), None if src1 is None else f64(src1), up0)
+    wk = torch.zeros((Cout, C0 + C1, 3, 3, 3), dtype=torch.float64, requires_grad=True)
+    out = F.conv3d(x, wk, None, padding=1)
+    out.backward(to_ncdhw(f64(dy)))
+    ref = wk.grad.permute(2, 3, 4, 0, 1).reshape(27, Cout, C0 + C1)
+    rt = (1e-4, 1e-5) if dtype == torch.float32 else (2e-3, 2e-3)
+    assert_close(dw, ref, *rt, what=name + " dw")
+    assert_close(db, f64(dy).sum(dim=(0, 1, 2, 3)), *rt, what=name + " db")
+
+
+@pytest.mark.parametrize("dtype,Cin,Cout,impl", [(torch.float32, 5, 7, 1), (torch.bfloat16, 32, 64, 2), (torch.bfloat16, 64, 32, 2),
+                                                 (torch.bfloat16, 192, 64, 2)])
+def test_pack_and_dgrad(ops, dtype, Cin, Cout, impl):
+    """dgrad through the tap-flipped transposed copy == autograd of the forward conv wrt its input"""
+    N, D, H, W = 1, 4, 8, 16
+    wm = rnd((27, Cout, Cin), 12, torch.float32, scale=0.2)
+    wf = torch.empty((27, Cout, Cin), dtype=dtype, device="cuda")
+    wd = torch.empty((27, Cin, Cout), dtype=dtype, device="cuda")
+    ops.pack_weights(wm, wf, wd)
+    dy = rnd((N, D, H, W, Cout), 13, dtype)
+    mask = rnd((N, D, H, W, Cin), 14, dtype)
+    dx = torch.full((N, D, H, W, Cin), float("nan"), dtype=dtype, device="cuda")
+    ops.conv3d_dgrad(dy, wd, dx, mask=mask, impl=impl)
+    torch.cuda.synchronize()
+    assert torch.equal(wf.float().cpu(), wm.to(dtype).float().cpu())
+    x = torch.zeros((N, Cin, D, H, W), dtype=torch.float64, requires_grad=True)
+    out = F.conv3d(x, keras_kernel_from_packed(f64(wf)), None, padding=1)
+    out.backward(to_ncdhw(f64(dy)))
+    ref = to_ndhwc(x.grad) * (f64(mask) > 0)
+    assert_close(dx, ref, *TOL[dtype], what="dgrad")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("C", [1, 6, 16, 64])
+def test_maxpool_fwd_bwd(ops, dtype, C):
+    N, D, H, W = 2, 4, 6, 8
+    x = torch.relu(rnd((N, D, H, W, C), 20, dtype))  # post-ReLU like in the network (ties at 0)
+    y = torch.empty((N, D // 2, H // 2, W // 2, C), dtype=dtype, device="cuda")
+    ops.maxpool_fwd(x, y)
+    xr = to_ncdhw(f64(x)).requires_grad_(True)
+    yr = F.max_pool3d(xr, 2)
+    torch.cuda.synchronize()
+    assert torch.equal(f64(y), to_ndhwc(yr.detach()))
+    dy = rnd(tuple(y.shape), 21, dtype)
+    add = rnd((N, D, H, W, C + 8), 22, dtype)
+    dx = torch.full_like(x, float("nan"))
+    ops.maxpool_bwd(x, dy, dx, add=add, add_off=8, relu_mask=True)
+    torch.cuda.synchronize()
+    yr.backward(to_ncdhw(f64(dy)))
+    ref = (to_ndhwc(xr.grad) + f64(add)[..., 8:]) * (f64(x) > 0)
+    assert_close(dx, ref, 1e-6 if dtype == torch.float32 else 1e-2, 1e-6 if dtype == torch.float32 else 4e-3, what="maxpool_bwd")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_upsample_fwd_bwd(ops, dtype):
+    N, D, H, W, C = 2, 2, 3, 4, 8
+    x = rnd((N, D, H, W, C), 30, dtype)
+    y = torch.zeros((N, 2 * D, 2 * H, 2 * W, C + 4), dtype=dtype, device="cuda")
+    ops.upsample_fwd(x, y, y_off=4)
+    torch.cuda.synchronize()
+    ref = to_ndhwc(ref_concat_input(f64(x), None, True))
+    assert torch.equal(f64(y)[..., 4:], ref) and float(f64(y)[..., :4].abs().max()) == 0
+    dy = rnd(tuple(y.shape), 31, dtype)
+    dx = torch.empty_like(x)
+    ops.upsample_bwd(dy, dx, dy_off=4, xmask=x)
+    torch.cuda.synchronize()
+    g = f64(dy)[..., 4:].reshape(N, D, 2, H, 2, W, 2, C).sum(dim=(2, 4, 6)) * (f64(x) > 0)
+    assert_close(dx, g, *TOL[dtype], what="upsample_bwd")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("C,L", [(64, 1), (16, 2), (6, 1)])
+def test_conv1x1_fwd_bwd(ops, dtype, C, L):
+    nv = 1000
+    x = torch.relu(rnd((nv, C), 40, dtype))
+    w = rnd((L, C), 41, torch.float32)
+    b = rnd((L,), 42, torch.float32)
+    logits = torch.empty((nv, L), dtype=torch.float32, device="cuda")
+    ops.conv1x1_fwd(x, w, b, logits)
+    torch.cuda.synchronize()
+    ref = f64(x) @ f64(w).T + f64(b)
+    assert_close(logits, ref, 1e-5, 1e-5, what="conv1x1_fwd")
+    dl = rnd((nv, L), 43, torch.float32)
+    dx = torch.empty_like(x)
+    dw = torch.zeros_like(w)
+    db = torch.zeros_like(b)
+    ops.conv1x1_bwd(x, w, dl, dx, dw, db, relu_mask=True)
+    torch.cuda.synchronize()
+    assert_close(dx, (f64(dl) @ f64(w)) * (f64(x) > 0), *TOL[dtype], what="conv1x1 dx")
+    assert_close(dw, f64(dl).T @ f64(x), 1e-4, 1e-5, what="conv1x1 dw")
+    assert_close(db, f64(dl).sum(0), 1e-4, 1e-5, what="conv1x1 db")
+
+
+def test_sigmoid_dice_fwd_bwd(ops):
+    from oracle import metrics_oracle as M
+    n = 5000
+    logits = rnd((n,), 50, torch.float32, scale=2.0)
+    y = (torch.rand(n, generator=torch.Generator().manual_seed(51)) > 0.7).to(torch.uint8).cuda()
+    probs = torch.empty_like(logits)
+    sums = torch.zeros(8, dtype=torch.float64, device="cuda")
+    ops.sigmoid_dice_fwd(logits, y, probs, sums)
+    dl = torch.empty_like(logits)
+    ops.sigmoid_dice_bwd(probs, y, sums, dl)
+    torch.cuda.synchronize()
+    p64 = torch.sigmoid(f64(logits)).requires_grad_(False)
+    s = sums.cpu().numpy()
+    dice = (2 * s[0] + 1) / (s[1] + s[2] + 1)
+    assert dice == pytest.approx(M.dice_coefficient(y.cpu().numpy(), p64.numpy()), rel=1e-6)
+    vod = (s[3] + 1) / (s[4] + s[5] - s[3] + 1)
+    assert vod == pytest.approx(M.vod_coefficient(y.cpu().numpy(), p64.numpy()), rel=1e-6)
+    assert s[6] / s[7] == pytest.approx(M.binary_accuracy(y.cpu().numpy(), p64.numpy()), abs=2e-4)
+    z = f64(logits).requires_grad_(True)
+    yy = f64(y)
+    pp = torch.sigmoid(z)
+    loss = -(2 * (yy * pp).sum() + 1) / (yy.sum() + pp.sum() + 1)
+    loss.backward()
+    assert_close(dl, z.grad, 1e-4, 1e-5, what="dice bwd")
+
+
+def test_adam(ops):
+    from oracle.unet_oracle import KerasAdam
+    n = 1003
+    p = rnd((1024,), 60, torch.float32)[:n].contiguous()
+    W = {"a": p.cpu().numpy().astype(np.float64)}
+    opt = KerasAdam(W, lr=1e-3)
+    m = torch.zeros(n, device="cuda")
+    v = torch.zeros(n, device="cuda")
+    import math
+    for t in range(1, 4):
+        g = rnd((n,), 60 + t, torch.float32)
+        lr_t = 1e-3 * math.sqrt(1 - 0.999 ** t) / (1 - 0.9 ** t)
+        ops.adam_step(p, g, m, v, lr_t)
+        opt.step(W, {"a": g.cpu().numpy().astype(np.float64)})
+    torch.cuda.synchronize()
+    assert_close(p, torch.tensor(W["a"]), 1e-5, 1e-6, what="adam")
+
+
+def test_tiles(ops):
+    rs = np.random.RandomState(70)
+    vol = torch.tensor(rs.randn(20, 18, 12).astype(np.float32)).cuda()
+    idx = torch.tensor([[0, 0, 0], [12, 10, 4], [5, 3, 2]], dtype=torch.int32).cuda()
+    patch = (8, 8, 8)
+    tiles = torch.empty((3,) + patch, dtype=torch.float32, device="cuda")
+    ops.tile_gather(vol, idx, patch, tiles)
+    torch.cuda.synchronize()
+    for b, (x, y, z) in enumerate(idx.cpu().tolist()):
+        assert torch.equal(tiles[b].cpu(), vol[x:x + 8, y:y + 8, z:z + 8].cpu())
+    acc = torch.zeros((20, 18, 12, 2), dtype=torch.float64, device="cuda")
+    cnt = torch.zeros((20, 18, 12), dtype=torch.int32, device="cuda")
+    pred = torch.tensor(rs.randn(3, 8, 8, 8, 2).astype(np.float32)).cuda()
+    ops.tile_scatter_accumulate(pred, idx, patch, acc, cnt)
+    out = torch.empty_like(acc)
+    bad = torch.zeros(1, dtype=torch.int32, device="cuda")
+    ops.tile_finalize(acc, cnt, out, bad)
+    torch.cuda.synchronize()
+    ra = np.zeros((20, 18, 12, 2))
+    rc = np.zeros((20, 18, 12))
+    for b, (x, y, z) in enumerate(idx.cpu().tolist()):
+        ra[x:x + 8, y:y + 8, z:z + 8] += pred[b].cpu().numpy().astype(np.float64)
+        rc[x:x + 8, y:y + 8, z:z + 8] += 1
+    np.testing.assert_allclose(acc.cpu().numpy(), ra, atol=1e-12)
+    assert np.array_equal(cnt.cpu().numpy(), rc)
+    assert int(bad.item()) == int((rc == 0).sum())
