@@ -1,0 +1,224 @@
+#!/usr/bin/env python3
+"""Headline benchmark: 3-D patches/s (64x128x128, bf16) of the full training step (forward + Dice + backward + Adam) of the
+depth-4 / 32-base-filter U-Net (BASELINE.json configs[1]; reference fetal_net/model/unet3d/unet.py:17-86 defaults), batch 4
+per GPU, synthetic data resident in HBM, random-init (glorot) weights.
+
+  python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+Prints ONE JSON line on rank 0.  Besides the driver contract it carries
+  "roofline"     for the dominant kernel (live HIP-event timing of every conv launch in the timed steps), and
+  "cpu_baseline" the CPU oracle (torch-CPU restatement; Keras/TF are absent here and on the GPU box) timed on the host.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "fetal-mri-segmentation_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np
+import torch
+
+PEAK_BF16_TFLOPS = 2500.0     # dense MFMA bf16, /opt/skills/guides/MI355X_MICROARCH.md chip table
+PEAK_HBM_GBS = 8000.0         # HBM3E spec, same table
+# algorithmic bf16 bytes of the 3x3x3 convs, fwd+dgrad+wgrad, per 64x128x128 patch
+ALGO_BYTES_PER_PATCH = 4337e6
+
+
+def conv_flops(eng):
+    """algorithmic FLOPs (2*27*Cin*Cout*voxels) of every 3x3x3 conv launch class in ONE step of this engine"""
+    p, N = eng.plan, eng.N
+    out = {"fwd": 0.0, "dgrad": 0.0, "wgrad": 0.0, "fwd_mfma": 0.0, "dgrad_mfma": 0.0, "wgrad_mfma": 0.0}
+    from fmri_hip._lib import lib, BF16
+    first = p.enc[0][0]["name"]
+    for c in p.convs_forward_order():
+        D, H, W = p.level_dims(c["level"])
+        fl = 2.0 * 27 * c["cin"] * c["cout"] * N * D * H * W
+        c0, c1 = (c["c_up"], c["c_skip"]) if "c_up" in c else (c["cin"], 0)
+        m = lib().fmri_conv3d_uses_mfma(c0, c1, c["cout"], D, H, W, BF16)
+        out["fwd"] += fl
+        out["wgrad"] += fl
+        if m & 1:
+            out["fwd_mfma"] += fl
+        if m & 2:
+            out["wgrad_mfma"] += fl
+        if c["name"] != first:
+            out["dgrad"] += fl
+            md = lib().fmri_conv3d_uses_mfma(c["cout"], 0, c["cin"], D, H, W, BF16)
+            if md & 1:
+                out["dgrad_mfma"] += fl
+    return out
+
+
+class LaunchTimer:
+    """HIP-event brackets around C-ABI launches on torch's current stream (the stream the kernels run on)."""
+
+    def __init__(self):
+        self.rec = {}
+        self.on = False
+
+    def wrap(self, ops_mod, fn_name, label_fn):
+        orig = getattr(ops_mod, fn_name)
+
+        def wrapped(*a, **k):
+            if not self.on:
+                return orig(*a, **k)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = orig(*a, **k)
+            e1.record()
+            self.rec.setdefault(label_fn(*a, **k), []).append((e0, e1))
+            return r
+
+        setattr(ops_mod, fn_name, wrapped)
+
+    def totals_ms(self):
+        return {k: (sum(a.elapsed_time(b) for a, b in v), len(v)) for k, v in self.rec.items()}
+
+
+def cpu_baseline(budget_s=25.0):
+    """the oracle's training step on ONE 64x128x128 patch of the same model, all host cores"""
+    from oracle import unet_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    spec = O.Spec((1, 64, 128, 128))
+    W = spec.init_weights(42)
+    x, y = O.synthetic_batch((1, 1, 64, 128, 128))
+    opt = O.KerasAdam(W, lr=1e-4, dtype=np.float32)
+    t0 = time.time()
+    n = 0
+    while True:
+        O.train_step(spec, W, opt, x, y, dtype=torch.float32)
+        n += 1
+        if n >= 2 or time.time() - t0 > budget_s:
+            break
+    dt = time.time() - t0
+    return {"value": n / dt, "unit": "patches/s", "cores": cores, "kind": "port",
+            "sample": "%d full training steps (fwd+Dice+bwd+Adam, fp32, torch-CPU/oneDNN restatement of the Keras path) on one "
+                      "1x64x128x128 patch of the same depth-4/32-filter model; Keras/TF not installed" % n}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=4, help="patches per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-launch-timing", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    torch.cuda.set_device(local_rank)
+    dctx = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+        from fmri_hip.dist import DataParallel
+        dctx = DataParallel(world, rank)
+
+    from fmri_hip import ops
+    from fmri_hip.engine import UNetEngine, UNetPlan
+    from oracle.unet_oracle import synthetic_batch  # synthetic data generator only (SURVEY §8d recipe)
+
+    spatial = (64, 128, 128)
+    plan = UNetPlan(1, spatial, depth=4, n_base_filters=32)
+    eng = UNetEngine(plan, a.batch, dtype=torch.bfloat16, dist_ctx=dctx, seed=42)
+    if dctx is not None:
+        dctx.broadcast_params(eng)
+    x, y = synthetic_batch((a.batch, 1) + spatial, seed_x=1234 + rank, seed_y=1235 + rank)
+    xd = torch.from_numpy(x).cuda().to(torch.bfloat16).reshape(a.batch, *spatial, 1).contiguous()
+    yd = torch.from_numpy(y).cuda().reshape(-1).contiguous()
+    lr = 1e-4
+
+    timer = LaunchTimer()
+    if not a.no_launch_timing:
+        def lab_fwd(src0, src1, w, bias, y_, up0=False, act=1, alpha=0.0, mask=None, impl=0):
+            c0, c1 = src0.shape[-1], (0 if src1 is None else src1.shape[-1])
+            return ("conv_fwd_mfma" if (c0 % 32 == 0 and c1 % 32 == 0 and y_.shape[-1] % 32 == 0) else "conv_fwd_generic")
+
+        def lab_dgrad(dy, wd, dx, mask=None, impl=0):
+            return "conv_fwd_mfma" if (dy.shape[-1] % 32 == 0 and dx.shape[-1] % 32 == 0) else "conv_fwd_generic"
+
+        def lab_wgrad(src0, src1, dy, dw, db, up0=False, impl=0):
+            c0, c1 = src0.shape[-1], (0 if src1 is None else src1.shape[-1])
+            return ("conv_wgrad_mfma" if (c0 % 32 == 0 and c1 % 32 == 0 and dy.shape[-1] % 64 == 0) else "conv_wgrad_generic")
+
+        timer.wrap(ops, "conv3d_fwd", lab_fwd)
+        timer.wrap(ops, "conv3d_dgrad", lab_dgrad)
+        timer.wrap(ops, "conv3d_wgrad", lab_wgrad)
+        for nm in ("maxpool_fwd", "maxpool_bwd", "upsample_bwd", "conv1x1_fwd", "conv1x1_bwd", "sigmoid_dice_fwd",
+                   "sigmoid_dice_bwd", "adam_step", "pack_weights"):
+            timer.wrap(ops, nm, (lambda n_: (lambda *aa, **kk: n_))(nm))
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+
+    for _ in range(a.warmup):
+        eng.train_step(xd, yd, lr)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    timer.on = True
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        sums = eng.train_step(xd, yd, lr)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    timer.on = False
+    if world > 1:
+        import torch.distributed as dist
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    if rank != 0:
+        return
+    ms = dt / a.steps * 1e3
+    value = a.batch * world * a.steps / dt
+    m = eng.metrics_from_sums(sums.cpu().numpy())
+    out = {
+        "metric": "3D patches/sec (64x128x128, bf16) fwd+bwd", "value": value, "unit": "patches/s", "n_gpus": world,
+        "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": "configs[1]: depth-4 3D U-Net, 32 base filters, bf16, batch %dx1x64x128x128 per GPU, "
+                               "full step = fwd + Dice + bwd + Keras-Adam" % a.batch,
+                   "global_batch": a.batch * world, "parallelism": "dp%d" % world},
+        "train_dice_last_step": m["dice_coefficient"],
+        "hbm_roofline_frac_conv_algorithmic": (value / world) * ALGO_BYTES_PER_PATCH / 1e9 / PEAK_HBM_GBS,
+    }
+    if not a.no_launch_timing:
+        fl = conv_flops(eng)
+        tot = timer.totals_ms()
+        per_step = {k: (v[0] / a.steps, v[1] // a.steps) for k, v in tot.items()}
+        out["kernel_ms_per_step"] = {k: round(v[0], 4) for k, v in sorted(per_step.items(), key=lambda kv: -kv[1][0])}
+        dom = max(("conv_fwd_mfma", "conv_wgrad_mfma"), key=lambda k: per_step.get(k, (0, 0))[0])
+        if dom in per_step:
+            flops = (fl["fwd_mfma"] + fl["dgrad_mfma"]) if dom == "conv_fwd_mfma" else fl["wgrad_mfma"]
+            t_ms, launches = per_step[dom]
+            ach = flops / (t_ms * 1e-3) / 1e12
+            out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                               "frac": ach / PEAK_BF16_TFLOPS, "traffic": None, "launches_per_step": launches,
+                               "avg_launch_ms": t_ms / max(launches, 1)}
+            other = "conv_wgrad_mfma" if dom == "conv_fwd_mfma" else "conv_fwd_mfma"
+            if other in per_step:
+                fo = (fl["fwd_mfma"] + fl["dgrad_mfma"]) if other == "conv_fwd_mfma" else fl["wgrad_mfma"]
+                out["roofline_other"] = {"kernel": other, "achieved": fo / (per_step[other][0] * 1e-3) / 1e12, "unit": "TFLOP/s"}
+    if world == 1 and not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline()
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,126 @@
+"""End-to-end GPU parity of the U-Net engine (forward logits, Dice loss, all gradients, Adam trajectory) vs the oracle.
+
+Bars (BASELINE.json north_star): fp32 mode logits <= 1e-3 relative, |dDice| <= 1e-4 vs the CPU restatement on identical
+seeded weights / synthetic volumes.  bf16 mode is checked against the same oracle at bf16-appropriate tolerances.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(spatial, depth, base, N, dtype, seed=42):
+    from fmri_hip.engine import UNetEngine, UNetPlan
+    from oracle import unet_oracle as O
+    spec = O.Spec((1,) + tuple(spatial), depth=depth, n_base_filters=base)
+    W = spec.init_weights(seed)
+    rs = np.random.RandomState(7)
+    for k in W:  # non-zero biases so that the bias path is exercised
+        if k.endswith("/bias"):
+            W[k] = (rs.randn(*W[k].shape) * 0.05).astype(np.float32)
+    plan = UNetPlan(1, spatial, depth=depth, n_base_filters=base)
+    eng = UNetEngine(plan, N, dtype=dtype)
+    eng.load_keras_weights(W)
+    x, y = O.synthetic_batch((N, 1) + tuple(spatial))
+    return spec, W, eng, x, y
+
+
+def _dev_inputs(eng, x, y):
+    xd = torch.from_numpy(x).to("cuda").to(eng.dtype).reshape(x.shape[0], *x.shape[2:], 1).contiguous()
+    yd = torch.from_numpy(y).to("cuda").reshape(-1).contiguous()
+    return xd, yd
+
+
+def _rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+def test_cfg1_fp32_forward_backward_adam():
+    """BASELINE config 1: depth 3 / 8 base filters, 1x16x64x64 patch, fp32 parity mode."""
+    from oracle import unet_oracle as O
+    spec, W, eng, x, y = _setup((16, 64, 64), 3, 8, 1, torch.float32)
+    xd, yd = _dev_inputs(eng, x, y)
+    ref = O.loss_and_grads(spec, W, x, y, dtype=torch.float64)
+    eng.forward(xd)
+    sums = eng.loss_forward(yd)
+    eng.backward(yd)
+    torch.cuda.synchronize()
+    logits = eng.logits.cpu().numpy().reshape(ref["logits"].shape)
+    assert _rel(logits, ref["logits"]) <= 1e-3
+    m = eng.metrics_from_sums(sums.cpu().numpy())
+    assert abs(m["dice_coefficient"] - ref["dice"]) <= 1e-4
+    # gradients of every tensor
+    G = eng.G
+    for name, L in eng.layout.items():
+        gk = ref["grads"][name + "/kernel"]
+        if L["kind"] == "conv":
+            mine = eng.w_view(name, G).cpu().numpy().reshape(3, 3, 3, L["cout"], L["cin"]).transpose(0, 1, 2, 4, 3)
+        else:
+            mine = eng.w_view(name, G).cpu().numpy().T.reshape(gk.shape)
+        assert _rel(mine, gk) <= 2e-3, name
+        assert _rel(eng.b_view(name, G).cpu().numpy(), ref["grads"][name + "/bias"]) <= 2e-3, name + " bias"
+    # three optimizer steps track the oracle's Keras-Adam trajectory
+    opt = O.KerasAdam(W, lr=1e-3)
+    eng.t = 0
+    for step in range(3):
+        r = O.train_step(spec, W, opt, x, y)
+        s = eng.train_step(xd, yd, 1e-3)
+        torch.cuda.synchronize()
+        mm = eng.metrics_from_sums(s.cpu().numpy())
+        assert abs(mm["loss"] - r["loss"]) <= 1e-4, (step, mm["loss"], r["loss"])
+    Wm = eng.export_keras_weights()
+    for k in W:
+        assert _rel(Wm[k], W[k]) <= 2e-3, k
+
+
+def test_depth4_base32_bf16_small_patch():
+    """BASELINE config-2 topology (depth 4 / 32 filters, MFMA kernels) on a small 1x8x16x32... patch vs the oracle."""
+    from oracle import unet_oracle as O
+    spec, W, eng, x, y = _setup((32, 64, 128), 4, 32, 1, torch.bfloat16)
+    xd, yd = _dev_inputs(eng, x, y)
+    ref = O.loss_and_grads(spec, W, x, y, dtype=torch.float32)
+    eng.forward(xd)
+    sums = eng.loss_forward(yd)
+    eng.backward(yd)
+    torch.cuda.synchronize()
+    logits = eng.logits.cpu().numpy().reshape(ref["logits"].shape)
+    assert _rel(logits, ref["logits"]) <= 3e-2      # bf16 storage of 14 stacked conv outputs
+    m = eng.metrics_from_sums(sums.cpu().numpy())
+    assert abs(m["dice_coefficient"] - ref["dice"]) <= 2e-3
+    worst = 0.0
+    for name, L in eng.layout.items():
+        gk = ref["grads"][name + "/kernel"]
+        if L["kind"] == "conv":
+            mine = eng.w_view(name, eng.G).cpu().numpy().reshape(3, 3, 3, L["cout"], L["cin"]).transpose(0, 1, 2, 4, 3)
+        else:
+            mine = eng.w_view(name, eng.G).cpu().numpy().T.reshape(gk.shape)
+        e = np.linalg.norm(mine.astype(np.float64) - gk) / (np.linalg.norm(gk) + 1e-30)
+        worst = max(worst, e)
+        assert e <= 6e-2, (name, e)
+    print("bf16 worst relative L2 gradient error", worst)
+
+
+def test_bf16_matches_fp32_engine_on_gpu():
+    """the two HIP paths (generic fp32 vs MFMA bf16) agree with each other on the same inputs"""
+    spec, W, e32, x, y = _setup((16, 32, 32), 3, 32, 2, torch.float32)
+    from fmri_hip.engine import UNetEngine
+    e16 = UNetEngine(e32.plan, 2, dtype=torch.bfloat16)
+    e16.load_keras_weights(W)
+    x32, yd = _dev_inputs(e32, x, y)
+    x16, _ = _dev_inputs(e16, x, y)
+    e32.forward(x32)
+    e16.forward(x16)
+    torch.cuda.synchronize()
+    assert _rel(e16.logits.cpu().numpy(), e32.logits.cpu().numpy()) <= 3e-2
+
+
+def test_training_loss_decreases_bf16():
+    spec, W, eng, x, y = _setup((16, 32, 32), 3, 32, 2, torch.bfloat16)
+    xd, yd = _dev_inputs(eng, x, y)
+    losses = []
+    for _ in range(12):
+        s = eng.train_step(xd, yd, 1e-3)
+        losses.append(eng.metrics_from_sums(s.cpu().numpy())["loss"])
+    assert losses[-1] < losses[0] - 0.02, losses
