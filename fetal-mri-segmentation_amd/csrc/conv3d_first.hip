@@ -1,0 +1,232 @@
+// First-layer specialisation: single-channel input (the MRI volume), Cout a multiple of 32, bf16.
+//
+// With Cin = 1 the 3x3x3 convolution is a [voxels x 27] x [27 x Cout] product: the 27 taps ARE the contraction
+// dimension (padded to 32 = two k-steps of v_mfma_f32_32x32x16_bf16).  The "im2col" operand is never built in memory:
+// each lane gathers its 8 tap values straight from a bf16 halo tile of x in LDS.  Both kernels are HBM-bound
+// (forward writes the 32-channel activation, the weight gradient reads dy once), so the point of MFMA here is only to
+// get the arithmetic out of the way of the memory stream.
+//
+// Reference ops replaced: the first Conv3D(+BiasAdd+Relu) of unet_model_3d (unet3d/unet.py:45-46,102,113) and its
+// Conv3DBackpropFilterV2 / BiasAddGrad.
+#include "common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(8))) unsigned short u16x8;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+// ---------------------------------------------------------------------------------------------------------- forward
+namespace ff {
+constexpr int TD = 4, TH = 16, TW = 32;                 // 2048 voxels per workgroup = 64 column tiles of 32 (one w-row each)
+constexpr int HD = TD + 2, HH = TH + 2, HW = TW + 2;    // 6 x 18 x 34 halo of bf16 scalars (7.3 KB)
+constexpr int NTHREADS = 256;
+}  // namespace ff
+
+__device__ __forceinline__ int tap_off(int tap, int HHs, int HWs) {
+    tap = tap > 26 ? 26 : tap;                            // taps 27..31 are zero-weighted padding: any in-tile address will do
+    const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+    return (kd * HHs + kh) * HWs + kw;
+}
+
+__global__ void __launch_bounds__(ff::NTHREADS)
+k_conv_first_fwd(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wt /*[27][Cout][1]*/, const float* __restrict__ bias,
+                 bf16_t* __restrict__ y, int N, int D, int H, int W, int Cout, int act, float alpha) {
+    using namespace ff;
+    __shared__ __attribute__((aligned(16))) bf16_t sx[HD * HH * HW];
+    int tile = blockIdx.x;
+    const int twn = W / TW, thn = H / TH, tdn = D / TD;
+    const int w0 = (tile % twn) * TW; tile /= twn;
+    const int h0 = (tile % thn) * TH; tile /= thn;
+    const int d0 = (tile % tdn) * TD;
+    const int n = tile / tdn;
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6, r = lane & 31, hk = lane >> 5;
+
+    for (int i = t; i < HD * HH * HW; i += NTHREADS) {
+        const int hw_ = i % HW, q = i / HW, hh_ = q % HH, hd_ = q / HH;
+        const int gd = d0 - 1 + hd_, gh = h0 - 1 + hh_, gw = w0 - 1 + hw_;
+        bf16_t v = 0;
+        if ((unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W)
+            v = x[(((int64_t)n * D + gd) * H + gh) * W + gw];
+        sx[i] = v;
+    }
+    // per-lane tap offsets for the two k-steps (k = 16*ks + 8*hk + j)
+    int toff[2][8];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) toff[ks][j] = tap_off(16 * ks + 8 * hk + j, HH, HW);
+    __syncthreads();
+
+    for (int cot = 0; cot < Cout / 32; ++cot) {
+        // A = W^T[co = r][tap], zero for tap >= 27
+        bf16x8_t a[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            u16x8 u;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int tap = 16 * ks + 8 * hk + j;
+                u[j] = tap < 27 ? wt[tap * Cout + cot * 32 + r] : (bf16_t)0;
+            }
+            a[ks] = __builtin_bit_cast(bf16x8_t, u);
+        }
+        float bv[4][4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) bv[g][i] = bias ? bias[cot * 32 + 8 * g + 4 * hk + i] : 0.f;
+
+        // 64 column tiles (d, h) pairs; each wave takes 16
+        for (int ctile = wv; ctile < TD * TH; ctile += 4) {
+            const int dl = ctile / TH, hl = ctile % TH;
+            const int base = (dl * HH + hl) * HW + r;
+            f32x16 acc;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) acc[k] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                u16x8 u;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) u[j] = sx[base + toff[ks][j]];
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks], __builtin_bit_cast(bf16x8_t, u), acc, 0, 0, 0);
+            }
+            const int64_t vo = ((((int64_t)n * D + d0 + dl) * H + h0 + hl) * W + w0 + r) * Cout + cot * 32;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float o[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float v = acc[4 * g + i] + bv[g][i];
+                    if (act == FMRI_ACT_RELU) v = fmaxf(v, 0.f);
+                    else if (act == FMRI_ACT_LEAKY) v = v > 0.f ? v : alpha * v;
+                    o[i] = v;
+                }
+                stv<bf16_t, 4>(y + vo + 8 * g + 4 * hk, o);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------- weight gradient
+namespace fg {
+constexpr int TD = 2, TH = 8, TW = 32;                  // 512 voxels of dy per tile = 32 k-steps of 16 voxels
+constexpr int HD = TD + 2, HH = TH + 2, HW = TW + 2;    // x halo 4 x 10 x 34
+constexpr int YVOX = TD * TH * TW;
+constexpr int NTHREADS = 256;
+}  // namespace fg
+
+// dw[tap][co] (Cin = 1) += sum_v dy[v][co] * x[v+tap];  db[co] += sum_v dy[v][co].  One 32-wide co tile per blockIdx.y.
+__global__ void __launch_bounds__(fg::NTHREADS)
+k_conv_first_wgrad(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy, float* __restrict__ dw, float* __restrict__ db,
+                   int N, int D, int H, int W, int Cout) {
+    using namespace fg;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[YVOX * 64 + HD * HH * HW * 2 + 16];
+    unsigned char* const lds_y = lds;                                  // [voxel][32 co] 64-B rows
+    bf16_t* const sx = reinterpret_cast<bf16_t*>(lds + YVOX * 64);     // halo scalars
+    const int cot = blockIdx.y;
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6, r = lane & 31, hk = lane >> 5;
+    const int twn = W / TW, thn = H / TH, tdn = D / TD;
+    const int ntiles = N * tdn * thn * twn;
+    // B operand: lane r = tap, 8 consecutive voxels (k = 8*hk + j) along w
+    const int toff = tap_off(r, HH, HW) + 8 * hk;
+    f32x16 acc;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) acc[k] = 0.f;
+    float bsum = 0.f;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        int q = tile;
+        const int w0 = (q % twn) * TW; q /= twn;
+        const int h0 = (q % thn) * TH; q /= thn;
+        const int d0 = (q % tdn) * TD;
+        const int n = q / tdn;
+        // dy tile: 512 rows x 4 slots of 16 B
+        {
+            uint4 v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int i = t + k * NTHREADS;
+                const int row = i >> 2, ps = i & 3;
+                const int yw = row & 31, yh = (row >> 5) & 7, yd = row >> 8;
+                v[k] = *reinterpret_cast<const uint4*>(dy + ((((int64_t)n * D + d0 + yd) * H + h0 + yh) * W + w0 + yw) * Cout + cot * 32 + ps * 8);
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) *reinterpret_cast<uint4*>(lds_y + (t + k * NTHREADS) * 16) = v[k];
+        }
+        for (int i = t; i < HD * HH * HW; i += NTHREADS) {
+            const int hw_ = i % HW, qq = i / HW, hh_ = qq % HH, hd_ = qq / HH;
+            const int gd = d0 - 1 + hd_, gh = h0 - 1 + hh_, gw = w0 - 1 + hw_;
+            bf16_t v = 0;
+            if ((unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W)
+                v = x[(((int64_t)n * D + gd) * H + gh) * W + gw];
+            sx[i] = v;
+        }
+        __syncthreads();
+        // 32 k-steps: (dl, hl, half of the 32-wide row); each wave takes 8
+#pragma unroll 2
+        for (int ks = wv; ks < 32; ks += 4) {
+            const int wh = ks & 1, hl = (ks >> 1) & 7, dl = ks >> 4;
+            const int row0 = (dl * TH + hl) * TW + 16 * wh;
+            // A[co][k = voxel] through the transposing read (64-B rows, no swizzle needed)
+            const int g = lane >> 4, qd = (lane & 15) >> 2, p = lane & 3;
+            const unsigned char* pa = lds_y + (row0 + 8 * (g >> 1) + qd) * 64 + 32 * (g & 1) + 8 * p;
+            s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)pa);
+            s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(pa + 4 * 64));
+            u16x8 au;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { au[j] = (unsigned short)v0[j]; au[4 + j] = (unsigned short)v1[j]; }
+            if (db) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) bsum += bf2f(au[j]);
+            }
+            u16x8 bu;
+            const int xb = (dl * HH + hl) * HW + 16 * wh + toff;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) bu[j] = sx[xb + j];
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, au), __builtin_bit_cast(bf16x8_t, bu), acc, 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // D rows = co, cols = tap: reduce the four waves in LDS, then ONE global atomic per (tap, co) and workgroup
+    float* const red = reinterpret_cast<float*>(lds);          // [32 tap][32 co] + [32] bias, tile buffers are dead now
+    for (int i = t; i < 32 * 32 + 32; i += NTHREADS) red[i] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const int col = (reg & 3) + 8 * (reg >> 2) + 4 * hk;
+        atomicAdd(&red[r * 32 + col], acc[reg]);
+    }
+    if (db) {
+        bsum += __shfl_down(bsum, 32);
+        if (hk == 0) atomicAdd(&red[1024 + r], bsum);
+    }
+    __syncthreads();
+    for (int i = t; i < 27 * 32; i += NTHREADS) atomicAdd(&dw[(i >> 5) * Cout + cot * 32 + (i & 31)], red[i]);
+    if (db && t < 32) atomicAdd(&db[cot * 32 + t], red[1024 + t]);
+}
+
+}  // namespace
+
+bool conv3d_first_ok(int C0, int C1, int Cout, int D, int H, int W, int dtype, int up0) {
+    return dtype == FMRI_BF16 && C0 == 1 && C1 == 0 && !up0 && (Cout % 32) == 0 && (D % 4) == 0 && (H % 16) == 0 && (W % 32) == 0;
+}
+
+int conv3d_first_fwd(const void* x, const void* w, const float* bias, void* y, int N, int D, int H, int W, int Cout, int act,
+                     float alpha, hipStream_t st) {
+    const int ntile = N * (D / ff::TD) * (H / ff::TH) * (W / ff::TW);
+    k_conv_first_fwd<<<ntile, ff::NTHREADS, 0, st>>>((const bf16_t*)x, (const bf16_t*)w, bias, (bf16_t*)y, N, D, H, W, Cout, act, alpha);
+    FMRI_LAUNCH_CHECK();
+    return FMRI_OK;
+}
+
+int conv3d_first_wgrad(const void* x, const void* dy, float* dw, float* db, int N, int D, int H, int W, int Cout, hipStream_t st) {
+    const int ntiles = N * (D / fg::TD) * (H / fg::TH) * (W / fg::TW);
+    int gx = 512 / (Cout / 32);
+    if (gx > ntiles) gx = ntiles;
+    if (gx < 1) gx = 1;
+    k_conv_first_wgrad<<<dim3(gx, Cout / 32), fg::NTHREADS, 0, st>>>((const bf16_t*)x, (const bf16_t*)dy, dw, db, N, D, H, W, Cout);
+    FMRI_LAUNCH_CHECK();
+    return FMRI_OK;
+}

@@ -195,13 +195,22 @@ k_conv_fwd_mfma(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__
 }
 
 // ======================================================================================================== weight gradient
+// One "unit" of work = one d-plane tile of 8 x 16 output voxels (8 k-steps of 16 voxels along w) for one kd.  A workgroup
+// (4 waves, 2 workgroups per CU) owns a (kd, 64-wide Cout block, CIB-wide Cin block) slice of dw, keeps its 9 taps x
+// 32x32 accumulators in registers (144 VGPRs) and walks a strided list of units.  The x plane (10 x 18 halo rows) and
+// the dy plane are brought in by LDS-DMA (global_load_lds_dwordx4: no staging VGPRs, asynchronous) into a 2-deep LDS
+// ring: the DMA of unit u+1 is in flight while the MFMAs of unit u run; a counted s_waitcnt + raw s_barrier hand the
+// buffers over.  Out-of-volume halo rows are sourced from a zero page, the LDS swizzle is applied on the SOURCE address
+// (the DMA destination is lane-linear).
 namespace wg {
-constexpr int TD = 2, TH = 8, TW = 16;                 // 256 voxels of dy per tile = 16 k-steps of 16 voxels
-constexpr int XH = TH + 2, XW = TW + 2;                // x tile for ONE kd plane: 2 x 10 x 18
-constexpr int XVOX = TD * XH * XW;                     // 360
-constexpr int YVOX = TD * TH * TW;                     // 256
+constexpr int TH = 8, TW = 16;
+constexpr int XH = TH + 2, XW = TW + 2;                // 10 x 18 halo rows of one d-plane
+constexpr int XROWS = XH * XW;                         // 180
+constexpr int YROWS = TH * TW;                         // 128
 constexpr int NTHREADS = 256;
 }  // namespace wg
+
+__device__ uint4 g_zero_page[8];                       // 128 B of zeros: DMA source for out-of-volume halo rows
 
 // byte offset of 16-B slot `slot` of row `row`; 128-B rows flip their 64-B halves on bit 1 of the row so that the four
 // rows touched by one transposing read land in four different 64-B bank quarters.  64-B rows need no swizzle.
@@ -230,6 +239,20 @@ __device__ __forceinline__ bf16x8_t tr_frag(const unsigned char* base, int row0,
     return __builtin_bit_cast(bf16x8_t, f);
 }
 
+// LDS-DMA of 16 B per lane: LDS destination = wave-uniform byte address `lds_dst` + lane*16 (M0-based), global source per
+// lane.  Issued from inline asm so that hipcc does not put its own `s_waitcnt vmcnt(0)` in front of the LDS reads of the
+// OTHER ring slot (it cannot prove the two slots disjoint); completion is tracked by hand with counted vmcnt waits.
+__device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst)
+                 : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+    return (unsigned)(size_t)(__attribute__((address_space(3))) const unsigned char*)p;
+}
+
 template <int CI_T>  // CI_T = 32-wide input-channel tiles per workgroup (1 or 2); output-channel block is always 64
 __global__ void __launch_bounds__(wg::NTHREADS, 2)
 k_conv_wgrad_mfma(SrcB s, const bf16_t* __restrict__ dy, float* __restrict__ dw, float* __restrict__ db, int N, int D, int H,
@@ -238,10 +261,14 @@ k_conv_wgrad_mfma(SrcB s, const bf16_t* __restrict__ dy, float* __restrict__ dw,
     constexpr int CIB = 32 * CI_T;
     constexpr int XROWB = CIB * 2;                       // bytes per x row
     constexpr int XS = XROWB / 16;                       // 16-B slots per x row
-    constexpr int X_BYTES = XVOX * XROWB;
-    constexpr int Y_BYTES = YVOX * 128;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[X_BYTES + Y_BYTES];
-    unsigned char* const lds_y = lds + X_BYTES;
+    constexpr int X_INSTR = (XROWS * XS + 63) / 64;      // DMA wave-instructions for the x plane (23 or 12)
+    constexpr int Y_INSTR = YROWS * 8 / 64;              // 16
+    constexpr int PER_WAVE = (X_INSTR + Y_INSTR + 3) / 4;  // 10 or 7 DMA instructions per wave per unit (padded with dummies)
+    constexpr int X_BYTES = X_INSTR * 1024;
+    constexpr int Y_BYTES = Y_INSTR * 1024;
+    constexpr int DUMMY_BYTES = (PER_WAVE * 4 - X_INSTR - Y_INSTR) * 1024;
+    constexpr int STAGE_BYTES = X_BYTES + Y_BYTES + DUMMY_BYTES;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * STAGE_BYTES];
 
     const int Cin = s.C0 + s.C1;
     const int ncib = Cin / CIB, ncob = Cout / 64;
@@ -259,7 +286,8 @@ k_conv_wgrad_mfma(SrcB s, const bf16_t* __restrict__ dy, float* __restrict__ dw,
     const int sh = (from0 && s.up0) ? 1 : 0;
     const int sD = D >> sh, sH = H >> sh, sW = W >> sh;
 
-    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int t = threadIdx.x, lane = t & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
     const int r = lane & 31, hk = lane >> 5;
     const int ct = wv & 1;
     const int it = (CI_T == 2) ? (wv >> 1) : 0;
@@ -274,68 +302,64 @@ k_conv_wgrad_mfma(SrcB s, const bf16_t* __restrict__ dy, float* __restrict__ dw,
         for (int k = 0; k < 16; ++k) acc[a][k] = 0.f;
     float bsum = 0.f;
 
-    const int twn = W / TW, thn = H / TH, tdn = D / TD;
-    const int ntiles = N * tdn * thn * twn;
-    for (int tile = slab; tile < ntiles; tile += nslab) {
-        int q = tile;
+    const int twn = W / TW, thn = H / TH;
+    const int nunits = N * D * thn * twn;
+
+    // issue the DMA of unit `u` into ring slot `buf`: this wave's PER_WAVE instructions (instr = wv + 4*j), branch-free
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr(lds));
+    auto issue = [&](int u, int buf) {
+        int q = u;
         const int w0 = (q % twn) * TW; q /= twn;
         const int h0 = (q % thn) * TH; q /= thn;
-        const int d0 = (q % tdn) * TD;
-        const int n = q / tdn;
-        // ---- stage x (one kd plane of the halo: planes d0+kd-1 .. d0+kd, rows h0-1.., cols w0-1..), 4 loads in flight
-        {
-            constexpr int ITEMS = XVOX * XS;
-            constexpr int ITERS = (ITEMS + NTHREADS - 1) / NTHREADS;
+        const int d = q % D;
+        const int n = q / D;
+        const int gd = d + kd - 1;
+        const bool dok = (unsigned)gd < (unsigned)D;
+        const int gdc = min(max(gd, 0), D - 1) >> sh;
+        const int64_t xplane = ((int64_t)n * sD + gdc) * sH;
+        const int64_t yplane = (((int64_t)n * D + d) * H + h0) * W + w0;
 #pragma unroll
-            for (int k0 = 0; k0 < ITERS; k0 += 4) {
-                uint4 v[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int i = t + (k0 + k) * NTHREADS;
-                    v[k] = make_uint4(0, 0, 0, 0);
-                    if (k0 + k < ITERS && i < ITEMS) {
-                        const int row = i / XS, ps = i % XS;
-                        const int ls = (XROWB == 128) ? (ps ^ (((row >> 1) & 1) << 2)) : ps;
-                        const int xw = row % XW, xq = row / XW;
-                        const int xh = xq % XH, xd = xq / XH;
-                        const int gd = d0 + xd + kd - 1, gh = h0 - 1 + xh, gw = w0 - 1 + xw;
-                        if ((unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W) {
-                            const int64_t o = ((((int64_t)n * sD + (gd >> sh)) * sH + (gh >> sh)) * sW + (gw >> sh)) * sC + coff + ls * 8;
-                            v[k] = *reinterpret_cast<const uint4*>(sp + o);
-                        }
-                    }
-                }
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int i = t + (k0 + k) * NTHREADS;
-                    if (k0 + k < ITERS && i < ITEMS) *reinterpret_cast<uint4*>(lds + i * 16) = v[k];
-                }
+        for (int j = 0; j < PER_WAVE; ++j) {
+            const int instr = wv + 4 * j;                       // wave-uniform
+            const void* src = (const void*)g_zero_page;
+            if (instr < X_INSTR) {
+                const int i = instr * 64 + lane;
+                const int row = i / XS, ps = i % XS;
+                const int ls = (XROWB == 128) ? (ps ^ (((row >> 1) & 1) << 2)) : ps;
+                const int xh = row / XW, xw = row % XW;
+                const int gh = h0 - 1 + xh, gw = w0 - 1 + xw;
+                const bool ok = dok && row < XROWS && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W;
+                const int ghc = min(max(gh, 0), H - 1) >> sh, gwc = min(max(gw, 0), W - 1) >> sh;
+                const bf16_t* real = sp + (((xplane + ghc) * sW + gwc) * sC + coff + ls * 8);
+                src = ok ? (const void*)real : (const void*)g_zero_page;
+            } else if (instr < X_INSTR + Y_INSTR) {
+                const int i = (instr - X_INSTR) * 64 + lane;
+                const int row = i >> 3, ps = i & 7;
+                const int ls = ps ^ (((row >> 1) & 1) << 2);
+                const int yh = row >> 4, yw = row & 15;
+                src = dy + ((yplane + (int64_t)yh * W + yw) * Cout + co0 + ls * 8);
             }
+            dma16(src, __builtin_amdgcn_readfirstlane(lds0 + buf * STAGE_BYTES + instr * 1024));
         }
-        // ---- stage dy tile: 256 voxels x 64 output channels
-        {
-            constexpr int ITERS = YVOX * 8 / NTHREADS;  // 8
-#pragma unroll
-            for (int k0 = 0; k0 < ITERS; k0 += 4) {
-                uint4 v[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int i = t + (k0 + k) * NTHREADS;
-                    const int row = i >> 3, ps = i & 7;
-                    const int ls = ps ^ (((row >> 1) & 1) << 2);
-                    const int yw = row & 15, yh = (row >> 4) & 7, yd = row >> 7;
-                    const int64_t o = ((((int64_t)n * D + d0 + yd) * H + h0 + yh) * W + w0 + yw) * Cout + co0 + ls * 8;
-                    v[k] = *reinterpret_cast<const uint4*>(dy + o);
-                }
-#pragma unroll
-                for (int k = 0; k < 4; ++k) *reinterpret_cast<uint4*>(lds_y + (t + (k0 + k) * NTHREADS) * 16) = v[k];
-            }
+    };
+
+    int u = slab;
+    int buf = 0;
+    if (u < nunits) issue(u, 0);
+    for (; u < nunits; u += nslab, buf ^= 1) {
+        const bool more = (u + nslab) < nunits;
+        if (more) {
+            issue(u + nslab, buf ^ 1);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_WAVE) : "memory");   // this unit's DMA (older) has landed
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        __syncthreads();
+        __builtin_amdgcn_s_barrier();
+        const unsigned char* const xb = lds + buf * STAGE_BYTES;
+        const unsigned char* const yb = xb + X_BYTES;
 #pragma unroll 1
-        for (int ks = ksl; ks < 16; ks += KSTEP) {
-            const int dl = ks >> 3, hl = ks & 7;
-            const bf16x8_t a = tr_frag<128>(lds_y, (dl * TH + hl) * TW, ct, lane);     // A[co][k=voxel]
+        for (int ks = ksl; ks < 8; ks += KSTEP) {
+            const bf16x8_t a = tr_frag<128>(yb, ks * TW, ct, lane);                      // A[co][k = voxel]
             if (do_bias) {
                 typedef __attribute__((ext_vector_type(8))) unsigned short u16x8;
                 const u16x8 au = __builtin_bit_cast(u16x8, a);
@@ -345,11 +369,12 @@ k_conv_wgrad_mfma(SrcB s, const bf16_t* __restrict__ dy, float* __restrict__ dw,
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
                 const int kh = tap / 3, kw = tap % 3;
-                const bf16x8_t b = tr_frag<XROWB>(lds, (dl * XH + hl + kh) * XW + kw, it, lane);  // B[k=voxel][ci]
+                const bf16x8_t b = tr_frag<XROWB>(xb, (ks + kh) * XW + kw, it, lane);    // B[k = voxel][ci]
                 acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[tap], 0, 0, 0);
             }
         }
-        __syncthreads();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                                                 // ring slot `buf` may be refilled
     }
     // ---- flush: D rows = co, cols = ci; one fp32 atomic per element (128-B contiguous per half-wave)
 #pragma unroll
@@ -379,7 +404,7 @@ bool conv3d_fwd_mfma_ok(int C0, int C1, int Cout, int D, int H, int W, int dtype
 bool conv3d_wgrad_mfma_ok(int C0, int C1, int Cout, int D, int H, int W, int dtype) {
     if (dtype != FMRI_BF16) return false;
     if ((C0 % 32) || (C1 % 32) || C0 + C1 < 32 || (Cout % 64)) return false;
-    if ((D % wg::TD) || (H % wg::TH) || (W % wg::TW)) return false;
+    if ((H % wg::TH) || (W % wg::TW)) return false;
     return true;
 }
 
@@ -405,7 +430,7 @@ int conv3d_wgrad_mfma(const void* src0, int C0, int up0, const void* src1, int C
     const bool wide = (C0 % 64 == 0) && (C1 % 64 == 0);
     const int CIB = wide ? 64 : 32;
     const int combos = 3 * (Cout / 64) * (Cin / CIB);
-    const int ntiles = N * (D / wg::TD) * (H / wg::TH) * (W / wg::TW);
+    const int ntiles = N * D * (H / wg::TH) * (W / wg::TW);
     int nslab = (1024 + combos - 1) / combos;        // aim for ~1024 workgroups (2 per CU, 2 rounds)
     if (nslab > ntiles) nslab = ntiles;
     if (nslab < 1) nslab = 1;

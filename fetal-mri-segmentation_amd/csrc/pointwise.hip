@@ -278,6 +278,107 @@ __global__ void k_conv1x1_bwd(const T* __restrict__ x, const float* __restrict__
     }
 }
 
+
+// ---- fast path: LPV = C/8 lanes cooperate on one voxel (16-B loads, whole 128-B lines per voxel group), L <= 4.
+template <typename T, int LPV>
+__global__ void __launch_bounds__(256)
+k_conv1x1_fwd_v2(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b, float* __restrict__ logits,
+                 int64_t nvox, int C, int L) {
+    const int sub = threadIdx.x % LPV;                 // which 8-channel group of the voxel
+    float wr[4][8];
+#pragma unroll
+    for (int l = 0; l < 4; ++l)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) wr[l][k] = l < L ? w[l * C + sub * 8 + k] : 0.f;
+    const int64_t vpb = blockDim.x / LPV;
+    for (int64_t v = blockIdx.x * vpb + threadIdx.x / LPV; v < nvox + (vpb - 1); v += (int64_t)gridDim.x * vpb) {
+        const bool ok = v < nvox;                      // keep whole waves in the shuffles
+        float xv[8];
+        if (ok) ldv<T, 8>(x + v * C + sub * 8, xv);
+        else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) xv[k] = 0.f;
+        }
+#pragma unroll
+        for (int l = 0; l < 4; ++l) {
+            if (l < L) {
+                float a = 0.f;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) a = fmaf(xv[k], wr[l][k], a);
+#pragma unroll
+                for (int o = LPV / 2; o > 0; o >>= 1) a += __shfl_xor(a, o);
+                if (ok && sub == 0) logits[v * L + l] = a + (b ? b[l] : 0.f);
+            }
+        }
+    }
+}
+template <typename T, int LPV>
+__global__ void __launch_bounds__(256)
+k_conv1x1_bwd_v2(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ dl, T* __restrict__ dx,
+                 float* __restrict__ dw, float* __restrict__ db, int64_t nvox, int C, int L, int relu_mask) {
+    extern __shared__ __attribute__((aligned(16))) float sacc[];   // [L][C+1]
+    for (int i = threadIdx.x; i < L * (C + 1); i += blockDim.x) sacc[i] = 0.f;
+    __syncthreads();
+    const int sub = threadIdx.x % LPV;
+    float wr[4][8], aw[4][8], ab[4];
+#pragma unroll
+    for (int l = 0; l < 4; ++l) {
+        ab[l] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { wr[l][k] = l < L ? w[l * C + sub * 8 + k] : 0.f; aw[l][k] = 0.f; }
+    }
+    const int64_t vpb = blockDim.x / LPV;
+    for (int64_t v = blockIdx.x * vpb + threadIdx.x / LPV; v < nvox; v += (int64_t)gridDim.x * vpb) {
+        float xv[8], gx[8];
+        ldv<T, 8>(x + v * C + sub * 8, xv);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) gx[k] = 0.f;
+#pragma unroll
+        for (int l = 0; l < 4; ++l) {
+            if (l < L) {
+                const float g = dl[v * L + l];
+                ab[l] += g;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { gx[k] = fmaf(g, wr[l][k], gx[k]); aw[l][k] = fmaf(g, xv[k], aw[l][k]); }
+            }
+        }
+        if (dx) {
+            if (relu_mask) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) if (!(xv[k] > 0.f)) gx[k] = 0.f;
+            }
+            stv<T, 8>(dx + v * C + sub * 8, gx);
+        }
+    }
+    for (int l = 0; l < L; ++l) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) atomicAdd(&sacc[l * (C + 1) + sub * 8 + k], aw[l][k]);
+        if (sub == 0) atomicAdd(&sacc[l * (C + 1) + C], ab[l]);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < L * (C + 1); i += blockDim.x) {
+        int l = i / (C + 1), c = i % (C + 1);
+        if (c < C) atomicAdd(&dw[l * C + c], sacc[i]);
+        else if (db) atomicAdd(&db[l], sacc[i]);
+    }
+}
+static int lpv_of(int C, int L) {
+    if ((C % 8) || L > 4) return 0;
+    int lpv = C / 8;
+    if (lpv > 64 || (lpv & (lpv - 1))) return 0;
+    return lpv;
+}
+#define LAUNCH_LPV(KERN, T, lpv, grid, sh, s, ...)                              \
+    switch (lpv) {                                                              \
+        case 1: KERN<T, 1><<<grid, 256, sh, s>>>(__VA_ARGS__); break;           \
+        case 2: KERN<T, 2><<<grid, 256, sh, s>>>(__VA_ARGS__); break;           \
+        case 4: KERN<T, 4><<<grid, 256, sh, s>>>(__VA_ARGS__); break;           \
+        case 8: KERN<T, 8><<<grid, 256, sh, s>>>(__VA_ARGS__); break;           \
+        case 16: KERN<T, 16><<<grid, 256, sh, s>>>(__VA_ARGS__); break;         \
+        case 32: KERN<T, 32><<<grid, 256, sh, s>>>(__VA_ARGS__); break;         \
+        default: KERN<T, 64><<<grid, 256, sh, s>>>(__VA_ARGS__); break;         \
+    }
+
 extern "C" int fmri_conv1x1_fwd(const void* x, const float* w, const float* b, float* logits, int64_t nvox, int C, int L,
                                 int dtype, fmri_stream_t stream) {
     if (nvox <= 0 || C <= 0 || L <= 0 || (size_t)L * C * 4 > 64 * 1024) return FMRI_E_SHAPE;
@@ -285,6 +386,14 @@ extern "C" int fmri_conv1x1_fwd(const void* x, const float* w, const float* b, f
     int grid = grid_for(nvox, 256, 256 * 8);
     hipStream_t s = as_stream(stream);
     size_t sh = (size_t)L * C * 4;
+    if (int lpv = lpv_of(C, L)) {
+        int g2 = grid_for(nvox * lpv, 256, 256 * 8);
+        if (dtype == FMRI_F32) { LAUNCH_LPV(k_conv1x1_fwd_v2, float, lpv, g2, 0, s, (const float*)x, w, b, logits, nvox, C, L) }
+        else if (dtype == FMRI_BF16) { LAUNCH_LPV(k_conv1x1_fwd_v2, bf16_t, lpv, g2, 0, s, (const bf16_t*)x, w, b, logits, nvox, C, L) }
+        else return FMRI_E_DTYPE;
+        FMRI_LAUNCH_CHECK();
+        return FMRI_OK;
+    }
     if (dtype == FMRI_F32) {
         switch (vec) {
             case 8: k_conv1x1_fwd<float, 8><<<grid, 256, sh, s>>>((const float*)x, w, b, logits, nvox, C, L); break;
@@ -311,6 +420,15 @@ extern "C" int fmri_conv1x1_bwd(const void* x, const float* w, const float* dlog
     int grid = grid_for(nvox, 256, 256 * 4);
     hipStream_t s = as_stream(stream);
     size_t sh = (size_t)L * (2 * C + 1) * 4;
+    if (int lpv = lpv_of(C, L)) {
+        int g2 = grid_for(nvox * lpv, 256, 256 * 4);
+        size_t sh2 = (size_t)L * (C + 1) * 4;
+        if (dtype == FMRI_F32) { LAUNCH_LPV(k_conv1x1_bwd_v2, float, lpv, g2, sh2, s, (const float*)x, w, dlogits, (float*)dx, dw, db, nvox, C, L, relu_mask) }
+        else if (dtype == FMRI_BF16) { LAUNCH_LPV(k_conv1x1_bwd_v2, bf16_t, lpv, g2, sh2, s, (const bf16_t*)x, w, dlogits, (bf16_t*)dx, dw, db, nvox, C, L, relu_mask) }
+        else return FMRI_E_DTYPE;
+        FMRI_LAUNCH_CHECK();
+        return FMRI_OK;
+    }
     if (dtype == FMRI_F32) {
         switch (vec) {
             case 4: k_conv1x1_bwd<float, 4><<<grid, 256, sh, s>>>((const float*)x, w, dlogits, (float*)dx, dw, db, nvox, C, L, relu_mask); break;
