@@ -1,0 +1,562 @@
+"""Keras-`Model` duck type backed by the MI355X engine (fmri_hip.engine.UNetEngine).
+
+Covers exactly the surface the reference's callers use: `.summary()`, `.load_weights()`, `.save()`,
+`.fit_generator(...)`, `.predict()`, `.output_shape`, `.layers[i].name`, `.optimizer`, `.loss`, `.metrics`, `.compile()`,
+plus `train_on_batch` / `test_on_batch` / `evaluate_generator` / `metrics_names` / `get_weights` / `set_weights`.
+Loop semantics follow Keras 2.2's `fit_generator` (reference fetal_net/training.py:110-124): per-epoch logs are the
+batch-size-weighted means of the per-batch values, `val_*` are means over `validation_steps` batches, callbacks see
+`loss`, `binary_accuracy`, `vod_coefficient`, their `val_` twins and `lr`.
+"""
+import csv
+import io
+import json
+import os
+import threading
+import time
+from collections import OrderedDict
+from queue import Queue
+
+import numpy as np
+
+from . import metrics as M
+
+
+# ----------------------------------------------------------------------------------------------------------------- layers
+class Layer(object):
+    def __init__(self, name, class_name, output_shape, config=None, inbound=()):
+        self.name = name
+        self.class_name = class_name
+        self.output_shape = tuple(output_shape)
+        self.config = dict(config or {})
+        self.inbound = list(inbound)
+
+    def __repr__(self):
+        return "<%s %s %s>" % (self.class_name, self.name, self.output_shape)
+
+
+class Adam(object):
+    """Optimizer token with the Keras attribute the callbacks touch (`lr`)."""
+
+    def __init__(self, lr=0.001, beta_1=0.9, beta_2=0.999, epsilon=1e-7):
+        self.lr, self.beta_1, self.beta_2, self.epsilon = float(lr), beta_1, beta_2, epsilon
+
+    def get_config(self):
+        return dict(lr=self.lr, beta_1=self.beta_1, beta_2=self.beta_2, epsilon=self.epsilon)
+
+
+# ----------------------------------------------------------------------------------------------------------------- callbacks
+class Callback(object):
+    def set_model(self, model):
+        self.model = model
+
+    def on_train_begin(self, logs=None): pass
+    def on_train_end(self, logs=None): pass
+    def on_epoch_begin(self, epoch, logs=None): pass
+    def on_epoch_end(self, epoch, logs=None): pass
+    def on_batch_begin(self, batch, logs=None): pass
+    def on_batch_end(self, batch, logs=None): pass
+
+
+class History(Callback):
+    def on_train_begin(self, logs=None):
+        self.epoch, self.history = [], {}
+
+    def on_epoch_end(self, epoch, logs=None):
+        self.epoch.append(epoch)
+        for k, v in (logs or {}).items():
+            self.history.setdefault(k, []).append(v)
+
+
+class ModelCheckpoint(Callback):
+    def __init__(self, filepath, monitor='val_loss', verbose=0, save_best_only=False, save_weights_only=False, mode='auto',
+                 period=1):
+        self.filepath, self.monitor, self.verbose = filepath, monitor, verbose
+        self.save_best_only, self.save_weights_only, self.period = save_best_only, save_weights_only, period
+        self.epochs_since_last_save = 0
+        if mode == 'max' or (mode == 'auto' and ('acc' in monitor or monitor.startswith('fmeasure'))):
+            self.monitor_op, self.best = np.greater, -np.inf
+        else:
+            self.monitor_op, self.best = np.less, np.inf
+
+    def on_epoch_end(self, epoch, logs=None):
+        logs = logs or {}
+        self.epochs_since_last_save += 1
+        if self.epochs_since_last_save < self.period:
+            return
+        self.epochs_since_last_save = 0
+        filepath = self.filepath.format(epoch=epoch + 1, **logs)
+        if self.save_best_only:
+            current = logs.get(self.monitor)
+            if current is None:
+                return
+            if self.monitor_op(current, self.best):
+                if self.verbose:
+                    print('\nEpoch %05d: %s improved from %0.5f to %0.5f, saving model to %s' % (epoch + 1, self.monitor, self.best, current, filepath))
+                self.best = current
+                self.model.save(filepath)
+            elif self.verbose:
+                print('\nEpoch %05d: %s did not improve from %0.5f' % (epoch + 1, self.monitor, self.best))
+        else:
+            self.model.save(filepath)
+
+
+class CSVLogger(Callback):
+    def __init__(self, filename, separator=',', append=False):
+        self.filename, self.sep, self.append = filename, separator, append
+        self.keys, self.append_header, self.csv_file = None, True, None
+
+    def on_train_begin(self, logs=None):
+        if self.append:
+            if os.path.exists(self.filename):
+                with open(self.filename, 'r') as f:
+                    self.append_header = not bool(len(f.readline()))
+            self.csv_file = open(self.filename, 'a')
+        else:
+            self.csv_file = open(self.filename, 'w')
+
+    def on_epoch_end(self, epoch, logs=None):
+        logs = logs or {}
+        if self.keys is None:
+            self.keys = sorted(logs.keys())
+            if self.append_header:
+                self.csv_file.write(self.sep.join(['epoch'] + self.keys) + '\n')
+        row = [str(epoch)] + [repr(float(logs[k])) if k in logs else 'NA' for k in self.keys]
+        self.csv_file.write(self.sep.join(row) + '\n')
+        self.csv_file.flush()
+
+    def on_train_end(self, logs=None):
+        if self.csv_file:
+            self.csv_file.close()
+            self.csv_file = None
+
+
+class LearningRateScheduler(Callback):
+    def __init__(self, schedule, verbose=0):
+        self.schedule, self.verbose = schedule, verbose
+
+    def on_epoch_begin(self, epoch, logs=None):
+        try:
+            lr = self.schedule(epoch, self.model.optimizer.lr)
+        except TypeError:
+            lr = self.schedule(epoch)
+        self.model.optimizer.lr = float(lr)
+
+    def on_epoch_end(self, epoch, logs=None):
+        if logs is not None:
+            logs['lr'] = self.model.optimizer.lr
+
+
+class ReduceLROnPlateau(Callback):
+    def __init__(self, monitor='val_loss', factor=0.1, patience=10, verbose=0, mode='auto', min_delta=1e-4, cooldown=0, min_lr=0):
+        if factor >= 1.0:
+            raise ValueError('ReduceLROnPlateau does not support a factor >= 1.0.')
+        self.monitor, self.factor, self.patience, self.verbose = monitor, factor, patience, verbose
+        self.min_delta, self.cooldown, self.min_lr, self.mode = min_delta, cooldown, min_lr, mode
+        self._reset()
+
+    def _reset(self):
+        if self.mode == 'max' or (self.mode == 'auto' and 'acc' in self.monitor):
+            self.monitor_op, self.best = (lambda a, b: np.greater(a, b + self.min_delta)), -np.inf
+        else:
+            self.monitor_op, self.best = (lambda a, b: np.less(a, b - self.min_delta)), np.inf
+        self.cooldown_counter, self.wait = 0, 0
+
+    def on_train_begin(self, logs=None):
+        self._reset()
+
+    def on_epoch_end(self, epoch, logs=None):
+        logs = logs if logs is not None else {}
+        logs['lr'] = self.model.optimizer.lr
+        current = logs.get(self.monitor)
+        if current is None:
+            return
+        if self.cooldown_counter > 0:
+            self.cooldown_counter -= 1
+            self.wait = 0
+        if self.monitor_op(current, self.best):
+            self.best, self.wait = current, 0
+        elif self.cooldown_counter <= 0:
+            self.wait += 1
+            if self.wait >= self.patience:
+                old_lr = float(self.model.optimizer.lr)
+                if old_lr > self.min_lr:
+                    new_lr = max(old_lr * self.factor, self.min_lr)
+                    self.model.optimizer.lr = new_lr
+                    if self.verbose:
+                        print('\nEpoch %05d: ReduceLROnPlateau reducing learning rate to %s.' % (epoch + 1, new_lr))
+                    self.cooldown_counter, self.wait = self.cooldown, 0
+
+
+class EarlyStopping(Callback):
+    def __init__(self, monitor='val_loss', min_delta=0, patience=0, verbose=0, mode='auto'):
+        self.monitor, self.patience, self.verbose, self.min_delta = monitor, patience, verbose, abs(min_delta)
+        if mode == 'max' or (mode == 'auto' and 'acc' in monitor):
+            self.monitor_op = np.greater
+        else:
+            self.monitor_op = np.less
+            self.min_delta *= -1
+        self.wait, self.stopped_epoch = 0, 0
+
+    def on_train_begin(self, logs=None):
+        self.wait, self.stopped_epoch = 0, 0
+        self.best = np.inf if self.monitor_op == np.less else -np.inf
+
+    def on_epoch_end(self, epoch, logs=None):
+        current = (logs or {}).get(self.monitor)
+        if current is None:
+            return
+        if self.monitor_op(current - self.min_delta, self.best):
+            self.best, self.wait = current, 0
+        else:
+            self.wait += 1
+            if self.wait >= self.patience:
+                self.stopped_epoch = epoch
+                self.model.stop_training = True
+
+    def on_train_end(self, logs=None):
+        if self.stopped_epoch > 0 and self.verbose:
+            print('Epoch %05d: early stopping' % (self.stopped_epoch + 1))
+
+
+class LambdaCallback(Callback):
+    def __init__(self, **fns):
+        for k, f in fns.items():
+            if f is not None:
+                setattr(self, k, f)
+
+
+# ----------------------------------------------------------------------------------------------------------------- model
+def _prefetch(generator, max_queue_size):
+    """one producer thread, bounded queue (Keras GeneratorEnqueuer with workers=1, reference training.py:115-117)"""
+    q = Queue(maxsize=max(1, max_queue_size))
+    stop = threading.Event()
+
+    def run():
+        try:
+            while not stop.is_set():
+                q.put(("ok", next(generator)))
+        except StopIteration:
+            q.put(("stop", None))
+        except BaseException as e:
+            q.put(("err", e))
+
+    th = threading.Thread(target=run, daemon=True)
+    th.start()
+
+    def get():
+        kind, val = q.get()
+        if kind == "err":
+            raise val
+        if kind == "stop":
+            raise StopIteration
+        return val
+
+    return get, stop
+
+
+class Model(object):
+    """Keras-Model duck type.  `builder`/`builder_kwargs` are remembered so that `.save()` files can be re-opened by
+    `load_old_model` without the original config (reference training.py:45-86)."""
+
+    def __init__(self, layers, plan_args, builder, builder_kwargs, input_layout, name=None):
+        self.layers = layers
+        self.name = name or "model_1"
+        self._plan_args = plan_args            # dict(in_channels, spatial, depth, n_base_filters, n_labels, ndim) or None if unsupported
+        self._builder, self._builder_kwargs = builder, builder_kwargs
+        self._input_layout = input_layout      # "channels_first_3d" | "channels_last_2d"
+        self.inputs = [layers[0]]
+        self.outputs = [layers[-1]]
+        self.input_shape = layers[0].output_shape
+        self.output_shape = layers[-1].output_shape
+        self.optimizer, self.loss, self.metrics = None, None, []
+        self.stop_training = False
+        self._engine = None
+        self._unsupported = None               # reason string when the engine cannot run this topology yet
+        self._pending_weights = None
+        self.history = None
+
+    # -- Keras surface -----------------------------------------------------------------------------------------------
+    def compile(self, optimizer=None, loss=None, metrics=None, **kw):
+        self.optimizer = optimizer if optimizer is not None else Adam()
+        self.loss = loss
+        self.metrics = list(metrics or [])
+
+    @property
+    def metrics_names(self):
+        return ['loss'] + [m if isinstance(m, str) else getattr(m, '__name__', str(m)) for m in self.metrics]
+
+    def count_params(self):
+        return int(sum(l.config.get("params", 0) for l in self.layers))
+
+    def summary(self, print_fn=print):
+        line = "_" * 98
+        print_fn(line)
+        print_fn("%-34s %-30s %-12s %s" % ("Layer (type)", "Output Shape", "Param #", "Connected to"))
+        print_fn("=" * 98)
+        for l in self.layers:
+            print_fn("%-34s %-30s %-12d %s" % ("%s (%s)" % (l.name, l.class_name), str(l.output_shape), l.config.get("params", 0),
+                                               ", ".join(l.inbound)))
+        print_fn("=" * 98)
+        print_fn("Total params: {:,}".format(self.count_params()))
+        print_fn(line)
+
+    # -- engine ------------------------------------------------------------------------------------------------------
+    def _compute_dtype(self):
+        import torch
+        want = (self._builder_kwargs or {}).get("compute_dtype") or os.environ.get("FMRI_DTYPE", "bf16")
+        return {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "fp32": torch.float32, "float32": torch.float32}[str(want)]
+
+    def engine(self, batch, training=True):
+        if self._unsupported:
+            raise NotImplementedError("the MI355X engine does not run this topology yet: " + self._unsupported)
+        import torch
+        from fmri_hip.engine import UNetEngine, UNetPlan
+        if not torch.cuda.is_available():
+            raise RuntimeError("no GPU visible: the fetal_net hot path has no CPU implementation")
+        if self._engine is None:
+            plan = UNetPlan(**self._plan_args)
+            dist_ctx = None
+            try:
+                import torch.distributed as dist
+                if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                    from fmri_hip.dist import DataParallel
+                    dist_ctx = DataParallel()
+            except Exception:
+                dist_ctx = None
+            self._engine = UNetEngine(plan, batch, dtype=self._compute_dtype(), training=True, dist_ctx=dist_ctx)
+            if self._pending_weights is not None:
+                self._engine.load_keras_weights(self._pending_weights)
+                self._pending_weights = None
+            if getattr(self, "_pending_opt", None) is not None:
+                m, v, t = self._pending_opt
+                self._engine.M.copy_(torch.from_numpy(m))
+                self._engine.V.copy_(torch.from_numpy(v))
+                self._engine.t = t
+                self._pending_opt = None
+            if dist_ctx is not None:
+                dist_ctx.broadcast_params(self._engine)
+        self._engine.set_batch(batch)
+        return self._engine
+
+    def _to_device_x(self, x):
+        import torch
+        x = np.asarray(x)
+        eng_dtype = self._compute_dtype()
+        t = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).cuda(non_blocking=True)
+        if self._input_layout == "channels_first_3d":       # (N,C,X,Y,Z) -> (N,X,Y,Z,C)
+            if t.shape[1] == 1:
+                t = t.reshape(t.shape[0], *t.shape[2:], 1)
+            else:
+                t = t.permute(0, 2, 3, 4, 1)
+        else:                                                # (N,X,Y,C) -> (N,1,X,Y,C)
+            t = t.unsqueeze(1)
+        return t.to(eng_dtype).contiguous()
+
+    def _to_device_y(self, y):
+        import torch
+        y = np.asarray(y)
+        t = torch.from_numpy(np.ascontiguousarray(y).astype(np.uint8)).cuda(non_blocking=True)
+        if self._input_layout == "channels_first_3d" and t.shape[1] != 1:
+            t = t.permute(0, 2, 3, 4, 1)
+        return t.contiguous().reshape(-1)
+
+    def _from_device_probs(self, eng, n):
+        p = eng.probs.reshape((n,) + tuple(eng.plan.level_dims(0)) + (eng.plan.n_labels,))
+        if self._input_layout == "channels_first_3d":
+            p = p.permute(0, 4, 1, 2, 3)
+        else:
+            p = p[:, 0]
+        return p.float().cpu().numpy()
+
+    def predict(self, x, batch_size=None, verbose=0):
+        if isinstance(x, (list, tuple)):
+            x = x[0]
+        x = np.asarray(x)
+        n = x.shape[0]
+        eng = self.engine(n)
+        eng.predict(self._to_device_x(x))
+        return self._from_device_probs(eng, n)
+
+    def _check_loss(self):
+        if self.loss not in M.DEVICE_LOSSES:
+            raise NotImplementedError("loss %r is not differentiated on the device yet (available: dice_coefficient_loss)"
+                                      % getattr(self.loss, "__name__", self.loss))
+
+    def _batch_logs(self, sums):
+        from fmri_hip.engine import UNetEngine
+        m = UNetEngine.metrics_from_sums(sums)
+        out = OrderedDict(loss=m["loss"])
+        for name in self.metrics_names[1:]:
+            key = {"dice_coef": "dice_coefficient"}.get(name, name)
+            out[name] = m[key]
+        return out
+
+    def train_on_batch(self, x, y, **kw):
+        self._check_loss()
+        if isinstance(x, (list, tuple)):
+            x = x[0]
+        n = np.asarray(x).shape[0]
+        eng = self.engine(n)
+        sums = eng.train_step(self._to_device_x(x), self._to_device_y(y), self.optimizer.lr)
+        logs = self._batch_logs(sums.cpu().numpy())
+        return [logs[k] for k in self.metrics_names]
+
+    def test_on_batch(self, x, y, **kw):
+        if isinstance(x, (list, tuple)):
+            x = x[0]
+        n = np.asarray(x).shape[0]
+        eng = self.engine(n)
+        eng.forward(self._to_device_x(x))
+        sums = eng.loss_forward(self._to_device_y(y))
+        logs = self._batch_logs(sums.cpu().numpy())
+        return [logs[k] for k in self.metrics_names]
+
+    def evaluate_generator(self, generator, steps, max_queue_size=10, workers=1, use_multiprocessing=False, verbose=0):
+        get, stop = _prefetch(generator, max_queue_size)
+        outs, sizes = [], []
+        try:
+            for _ in range(steps):
+                x, y = get()[:2]
+                outs.append(self.test_on_batch(x, y))
+                sizes.append(np.asarray(x[0] if isinstance(x, (list, tuple)) else x).shape[0])
+        finally:
+            stop.set()
+        return [float(np.average([o[i] for o in outs], weights=sizes)) for i in range(len(outs[0]))]
+
+    def fit_generator(self, generator, steps_per_epoch=None, epochs=1, verbose=1, callbacks=None, validation_data=None,
+                      validation_steps=None, class_weight=None, max_queue_size=10, workers=1, use_multiprocessing=False,
+                      shuffle=True, initial_epoch=0):
+        self._check_loss()
+        self.history = History()
+        cbs = list(callbacks or []) + [self.history]
+        for cb in cbs:
+            cb.set_model(self)
+        self.stop_training = False
+        names = self.metrics_names
+        get, stop = _prefetch(generator, max_queue_size)
+        vget, vstop = (None, None)
+        if validation_data is not None and not isinstance(validation_data, (tuple, list)):
+            vget, vstop = _prefetch(validation_data, max_queue_size)
+        for cb in cbs:
+            cb.on_train_begin({})
+        try:
+            for epoch in range(initial_epoch, epochs):
+                for cb in cbs:
+                    cb.on_epoch_begin(epoch, {})
+                t0 = time.time()
+                tot, seen = np.zeros(len(names)), 0
+                for step in range(steps_per_epoch):
+                    batch = get()
+                    x, y = batch[0], batch[1]
+                    bs = np.asarray(x[0] if isinstance(x, (list, tuple)) else x).shape[0]
+                    for cb in cbs:
+                        cb.on_batch_begin(step, {"batch": step, "size": bs})
+                    vals = self.train_on_batch(x, y)
+                    tot += np.asarray(vals) * bs
+                    seen += bs
+                    blog = dict(zip(names, vals), batch=step, size=bs)
+                    for cb in cbs:
+                        cb.on_batch_end(step, blog)
+                    if self.stop_training:
+                        break
+                logs = OrderedDict((k, float(v)) for k, v in zip(names, tot / max(seen, 1)))
+                if validation_data is not None:
+                    if vget is not None:
+                        vouts, vsizes = [], []
+                        for _ in range(validation_steps):
+                            vb = vget()
+                            vx, vy = vb[0], vb[1]
+                            vouts.append(self.test_on_batch(vx, vy))
+                            vsizes.append(np.asarray(vx[0] if isinstance(vx, (list, tuple)) else vx).shape[0])
+                        vals = [float(np.average([o[i] for o in vouts], weights=vsizes)) for i in range(len(names))]
+                    else:
+                        vals = self.test_on_batch(validation_data[0], validation_data[1])
+                    for k, v in zip(names, vals):
+                        logs['val_' + k] = float(v)
+                for cb in cbs:
+                    cb.on_epoch_end(epoch, logs)
+                if verbose:
+                    print("Epoch %d/%d - %.1fs - %s" % (epoch + 1, epochs, time.time() - t0,
+                                                        " - ".join("%s: %.4f" % kv for kv in logs.items())))
+                if self.stop_training:
+                    break
+        finally:
+            stop.set()
+            if vstop is not None:
+                vstop.set()
+            for cb in cbs:
+                cb.on_train_end({})
+        return self.history
+
+    # -- weights / checkpoints ---------------------------------------------------------------------------------------
+    def get_weights_dict(self):
+        if self._engine is not None:
+            return self._engine.export_keras_weights()
+        if self._pending_weights is not None:
+            return self._pending_weights
+        return self.engine(1).export_keras_weights()
+
+    def set_weights_dict(self, W):
+        if self._engine is not None:
+            self._engine.load_keras_weights(W)
+        else:
+            self._pending_weights = OrderedDict((k, np.asarray(v)) for k, v in W.items())
+
+    def save_weights(self, path):
+        self.save(path, include_optimizer=False)
+
+    def save(self, path, include_optimizer=True):
+        """Full-model checkpoint.  The reference writes Keras HDF5 (`.h5`, training.py:31-32); h5py is not available in this
+        stack, so the container is a numpy .npz written under the SAME file name (naming and resume-by-mtime keep working:
+        reference fetal/utils.py:42-43)."""
+        W = self.get_weights_dict()
+        arrays = {"w/" + k: v for k, v in W.items()}
+        meta = dict(format="fmri-npz-1", builder=self._builder, builder_kwargs=_jsonable(self._builder_kwargs),
+                    optimizer=self.optimizer.get_config() if self.optimizer else None,
+                    loss=getattr(self.loss, "__name__", None),
+                    metrics=[m if isinstance(m, str) else getattr(m, "__name__", str(m)) for m in self.metrics])
+        if include_optimizer and self._engine is not None and self._engine.training:
+            arrays["opt/m"] = self._engine.M.cpu().numpy()
+            arrays["opt/v"] = self._engine.V.cpu().numpy()
+            meta["opt_t"] = self._engine.t
+        arrays["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+        tmp = path + ".tmp"
+        with open(tmp, "wb") as f:
+            np.savez(f, **arrays)
+        os.replace(tmp, path)
+
+    def load_weights(self, path, by_name=False):
+        z = np.load(path, allow_pickle=False)
+        W = OrderedDict((k[2:], z[k]) for k in z.files if k.startswith("w/"))
+        self.set_weights_dict(W)
+        if "opt/m" in z.files:
+            t = int(json.loads(bytes(z["meta"]).decode()).get("opt_t", 0))
+            if self._engine is not None and self._engine.training:
+                import torch
+                self._engine.M.copy_(torch.from_numpy(z["opt/m"]))
+                self._engine.V.copy_(torch.from_numpy(z["opt/v"]))
+                self._engine.t = t
+            else:
+                self._pending_opt = (z["opt/m"], z["opt/v"], t)
+        return self
+
+
+def read_checkpoint_meta(path):
+    z = np.load(path, allow_pickle=False)
+    return json.loads(bytes(z["meta"]).decode())
+
+
+def _jsonable(d):
+    out = {}
+    for k, v in (d or {}).items():
+        if callable(v):
+            out[k] = {"__callable__": getattr(v, "__name__", str(v))}
+        elif isinstance(v, (np.integer,)):
+            out[k] = int(v)
+        elif isinstance(v, (np.floating,)):
+            out[k] = float(v)
+        elif isinstance(v, (tuple, list)):
+            out[k] = [int(a) if isinstance(a, (int, np.integer)) else a for a in v]
+        else:
+            out[k] = v
+    return out

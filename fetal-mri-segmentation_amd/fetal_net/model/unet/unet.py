@@ -1,0 +1,52 @@
+"""`unet_model_2d` with the reference signature and topology (reference fetal_net/model/unet/unet.py:22-141): the 2-D twin of
+unet_model_3d with channels-LAST input (X, Y, C) wrapped in Permute layers, optional SpatialDropout2D."""
+from ...engine_model import Adam, Model
+from ...metrics import dice_coefficient, dice_coefficient_loss, vod_coefficient
+from ..graph import Graph
+
+
+def _block(g, x, n_filters, batch_normalization):
+    h = g.conv(x, n_filters, (3, 3), strides=(1, 1), padding='same')
+    if batch_normalization:
+        h = g.batch_norm(h, axis=1)
+    return g.activation(h, 'relu')
+
+
+def unet_model_2d(input_shape, pool_size=(2, 2), n_labels=1, initial_learning_rate=0.00001, deconvolution=False, depth=4,
+                  n_base_filters=32, include_label_wise_dice_coefficients=False, batch_normalization=False,
+                  activation_name="sigmoid", loss_function=dice_coefficient_loss, dropout_rate=0, **kargs):
+    input_shape = tuple(int(v) for v in input_shape)
+    pool_size = tuple(pool_size)
+    g = Graph()
+    x = g.input(input_shape)
+    h = g.permute(x, (3, 1, 2))
+    skips = []
+    for level in range(depth):
+        h = _block(g, h, n_base_filters * (2 ** level), batch_normalization)
+        if dropout_rate > 0:
+            h = g.spatial_dropout(h, dropout_rate, 2)
+        h = _block(g, h, n_base_filters * (2 ** level) * 2, batch_normalization)
+        skips.append(h)
+        if level < depth - 1:
+            h = g.max_pool(h, pool_size)
+    for level in range(depth - 2, -1, -1):
+        up = g.deconv(h, h.shape[1], (2, 2), (2, 2)) if deconvolution else g.up_sample(h, pool_size)
+        cat = g.concat([up, skips[level]], axis=1)
+        h = _block(g, cat, skips[level].shape[1], batch_normalization)
+        if dropout_rate > 0:
+            h = g.spatial_dropout(h, dropout_rate, 2)
+        h = _block(g, h, skips[level].shape[1], batch_normalization)
+    h = g.conv(h, n_labels, (1, 1))
+    h = g.activation(h, activation_name)
+    g.permute(h, (2, 3, 1))
+    builder_kwargs = dict(input_shape=input_shape, pool_size=pool_size, n_labels=n_labels, initial_learning_rate=initial_learning_rate,
+                          deconvolution=deconvolution, depth=depth, n_base_filters=n_base_filters,
+                          batch_normalization=batch_normalization, activation_name=activation_name, loss_function=loss_function,
+                          dropout_rate=dropout_rate)
+    model = Model(g.layers, None, "unet_model_2d", builder_kwargs, "channels_last_2d")
+    model._unsupported = "the 2-D execution path (BASELINE config 4) is scheduled after the 3-D path (SURVEY.md §8 row a13)"
+    metrics = ['binary_accuracy', vod_coefficient]
+    if loss_function != dice_coefficient_loss:
+        metrics += [dice_coefficient]
+    model.compile(optimizer=Adam(lr=initial_learning_rate), loss=loss_function, metrics=metrics)
+    return model

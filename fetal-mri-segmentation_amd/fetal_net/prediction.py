@@ -1,0 +1,238 @@
+"""Sliding-window inference with the reference surface (reference fetal_net/prediction.py:88-210, :277-361).
+
+`patch_wise_prediction` keeps the reference's geometry exactly (overlap interpolation, 1st-percentile padding, tile
+index set, mean of overlapping tiles in float64).  With a model built by this package the whole tile loop stays on the
+MI355X: the padded volume is uploaded once, tiles are gathered on the device (fmri_tile_gather), pushed through the
+engine and overlap-added in float64 on the device (fmri_tile_scatter_accumulate / fmri_tile_finalize); one hipGraph per
+tile-batch size replays gather -> network -> scatter.  Any other object with `.output_shape` / `.predict(ndarray)` (the
+reference's duck-typing contract) is driven through the same geometry with host-side tiles.
+"""
+import itertools
+import os
+
+import numpy as np
+
+from .engine_model import Model
+from .utils.patches import get_patch_from_3d_data
+from .utils.threaded_generator import ThreadedGenerator
+
+
+def get_set_of_patch_indices_full(start, stop, step):
+    axes = []
+    for a, b, s in zip(start, stop, step):
+        idx = list(range(int(a), int(b) + 1, int(s)))
+        if int(b) % int(s) > 0:
+            idx.append(int(b))
+        axes.append(idx)
+    return np.array(list(itertools.product(*axes)))
+
+
+def batch_iterator(indices, batch_size, data_0, patch_shape, truth_0, prev_truth_index, truth_patch_shape):
+    i = 0
+    while i < len(indices):
+        batch, curr = [], []
+        while len(batch) < batch_size and i < len(indices):
+            ix = indices[i]
+            patch = get_patch_from_3d_data(data_0, patch_shape=patch_shape, patch_index=ix)
+            if truth_0 is not None:
+                t_ix = list(ix[:2]) + [ix[2] + prev_truth_index]
+                patch = np.concatenate([patch, get_patch_from_3d_data(truth_0, patch_shape=truth_patch_shape, patch_index=t_ix)],
+                                       axis=-1)
+            batch.append(patch)
+            curr.append(ix)
+            i += 1
+        yield [batch, curr]
+
+
+def _half_pads(delta):
+    return [(int(np.ceil(d / 2)), int(np.floor(d / 2))) for d in delta]
+
+
+def _geometry(model, data, patch_shape, overlap_factor):
+    out_shape = model.output_shape
+    is3d = int(np.sum(np.array(out_shape[1:]) > 1)) > 2
+    prediction_shape = tuple(out_shape[-3:]) if is3d else tuple(out_shape[-3:-1]) + (1,)
+    min_overlap = np.subtract(patch_shape, prediction_shape)
+    max_overlap = np.subtract(patch_shape, (1, 1, 1))
+    overlap = min_overlap + (overlap_factor * (max_overlap - min_overlap)).astype(int)
+    pad0 = _half_pads(np.subtract(patch_shape, prediction_shape))
+    data_0 = np.pad(data[0], pad0, mode='constant', constant_values=np.percentile(data[0], q=1))
+    pad_for_fit = _half_pads(np.maximum(np.subtract(patch_shape, data_0.shape), 0))
+    data_0 = np.pad(data_0, pad_for_fit, 'constant', constant_values=np.percentile(data_0, q=1))
+    indices = get_set_of_patch_indices_full((0, 0, 0), np.subtract(data_0.shape, patch_shape), np.subtract(patch_shape, overlap))
+    data_shape = list(np.asarray(data.shape[-3:]) + np.sum(pad_for_fit, -1))
+    data_shape += [out_shape[1]] if is3d else [out_shape[-1]]
+    return is3d, pad0, pad_for_fit, data_0, indices, data_shape
+
+
+def _unpad(arr, pad_for_fit):
+    if np.sum(pad_for_fit) > 0:
+        sl = tuple(slice(p[0] if p[0] else None, -p[1] if p[1] else None) for p in pad_for_fit)
+        arr = arr[sl]
+    return arr
+
+
+def patch_wise_prediction(model, data, patch_shape, overlap_factor=0, batch_size=5, permute=False, truth_data=None,
+                          prev_truth_index=None, prev_truth_size=None):
+    """data (1,X,Y,Z) -> (X,Y,Z,C) float64 mean of all tiles covering each voxel."""
+    is3d, pad0, pad_for_fit, data_0, indices, data_shape = _geometry(model, data, patch_shape, overlap_factor)
+    on_device = isinstance(model, Model) and is3d and truth_data is None and not permute and model._unsupported is None
+    if on_device:
+        out, count_ok = _device_overlap_add(model, data_0, indices, patch_shape, batch_size, data_shape)
+        assert count_ok, 'Found zeros in count'
+        out = _unpad(out, pad_for_fit)
+        assert np.array_equal(out.shape[:-1], data[0].shape), 'prediction shape wrong'
+        return out
+
+    if truth_data is not None:
+        truth_0 = np.pad(truth_data[0], pad0, mode='constant', constant_values=0)
+        truth_0 = np.pad(truth_0, pad_for_fit, 'constant', constant_values=0)
+        truth_patch_shape = list(patch_shape[:2]) + [prev_truth_size]
+    else:
+        truth_0, truth_patch_shape = None, None
+    tb_iter = iter(ThreadedGenerator(batch_iterator(indices, batch_size, data_0, patch_shape, truth_0, prev_truth_index,
+                                                    truth_patch_shape), queue_maxsize=50))
+    predicted_output = np.zeros(data_shape)
+    predicted_count = np.zeros(data_shape, dtype=np.int16)
+    for curr_batch, batch_indices in tb_iter:
+        curr_batch = np.asarray(curr_batch)
+        if is3d:
+            curr_batch = np.expand_dims(curr_batch, 1)
+        prediction = predict(model, curr_batch, permute=permute)
+        prediction = prediction.transpose([0, 2, 3, 4, 1]) if is3d else np.expand_dims(prediction, -2)
+        for patch, (x, y, z) in zip(prediction, batch_indices):
+            xl, yl, zl = patch.shape[:-1]
+            predicted_output[x:x + xl, y:y + yl, z:z + zl, :] += patch
+            predicted_count[x:x + xl, y:y + yl, z:z + zl] += 1
+    assert np.all(predicted_count > 0), 'Found zeros in count'
+    predicted_output, predicted_count = _unpad(predicted_output, pad_for_fit), _unpad(predicted_count, pad_for_fit)
+    assert np.array_equal(predicted_count.shape[:-1], data[0].shape), 'prediction shape wrong'
+    return predicted_output / predicted_count
+
+
+def _device_overlap_add(model, data_0, indices, patch_shape, batch_size, data_shape):
+    """Upload once, then per tile batch: gather -> network -> float64 overlap-add, all on the device.  The static buffers
+    (volume, accumulators, tile batch, index list) and one captured hipGraph per distinct batch size are cached on the
+    model and re-used for every following volume of the same padded shape."""
+    import torch
+    from fmri_hip import ops
+    patch = tuple(int(p) for p in patch_shape)
+    vshape = tuple(int(s) for s in data_0.shape)
+    ashape = tuple(int(s) for s in data_shape)
+    use_graph = os.environ.get("FMRI_HIPGRAPH", "1") == "1"
+    n = len(indices)
+    sizes = sorted({min(batch_size, n - i) for i in range(0, n, batch_size)}, reverse=True)
+    key = (vshape, ashape, patch, tuple(sizes), use_graph)
+    st = model.__dict__.get("_tile_state")
+    if st is None or st["key"] != key:
+        st = dict(key=key, vol=torch.empty(vshape, dtype=torch.float32, device="cuda"),
+                  acc=torch.zeros(ashape, dtype=torch.float64, device="cuda"),
+                  cnt=torch.zeros(ashape[:3], dtype=torch.int32, device="cuda"), per_b={})
+        for B in sizes:
+            eng = model.engine(B)
+            pb = dict(idx=torch.zeros((B, 3), dtype=torch.int32, device="cuda"),
+                      tiles=torch.empty((B,) + patch + (1,), dtype=eng.dtype, device="cuda"), graph=None)
+
+            def body(pb=pb, B=B):
+                e = model.engine(B)
+                ops.tile_gather(st["vol"], pb["idx"], patch, pb["tiles"])
+                e.predict(pb["tiles"])
+                ops.tile_scatter_accumulate(e.probs, pb["idx"], patch, st["acc"], st["cnt"])
+
+            pb["body"] = body
+            if use_graph:
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    body()                                   # warm-up outside capture (lazy allocations, module loads)
+                torch.cuda.current_stream().wait_stream(side)
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    body()
+                pb["graph"] = g
+            st["per_b"][B] = pb
+        model.__dict__["_tile_state"] = st
+    st["vol"].copy_(torch.from_numpy(np.ascontiguousarray(data_0, dtype=np.float32)))
+    st["acc"].zero_()
+    st["cnt"].zero_()
+    idx_all = torch.from_numpy(np.ascontiguousarray(indices, dtype=np.int32)).cuda()
+    for i in range(0, n, batch_size):
+        bidx = idx_all[i:i + batch_size]
+        pb = st["per_b"][int(bidx.shape[0])]
+        pb["idx"].copy_(bidx)
+        if pb["graph"] is not None:
+            pb["graph"].replay()
+        else:
+            pb["body"]()
+    out = torch.empty_like(st["acc"])
+    bad = torch.zeros(1, dtype=torch.int32, device="cuda")
+    ops.tile_finalize(st["acc"], st["cnt"], out, bad)
+    torch.cuda.synchronize()
+    return out.cpu().numpy(), int(bad.item()) == 0
+
+
+def predict(model, data, permute=False):
+    if permute:
+        raise NotImplementedError("48-permutation test-time augmentation is out of the hot-path scope (SURVEY.md §8f row 3)")
+    return model.predict(data)
+
+
+def run_validation_case(data_index, output_dir, model, data_file, training_modalities, patch_shape, overlap_factor=0,
+                        permute=False, prev_truth_index=None, prev_truth_size=None, use_augmentations=False):
+    """Predict one case of an opened data file (any object with `.root.data[i]` / `.root.truth[i]`) and write
+    data_<modality>.nii.gz, truth.nii.gz, prediction.nii.gz under output_dir (reference prediction.py:277-330)."""
+    from .utils.nifti import save_nifti
+    if use_augmentations:
+        raise NotImplementedError("test-time augmentation is out of the hot-path scope (SURVEY.md §8f row 3)")
+    if not os.path.exists(output_dir):
+        os.makedirs(output_dir)
+    test_data = np.asarray([data_file.root.data[data_index]])
+    test_truth_data = np.asarray([data_file.root.truth[data_index]]) if prev_truth_index is not None else None
+    for i, modality in enumerate(training_modalities):
+        save_nifti(test_data[i], os.path.join(output_dir, "data_{0}.nii.gz".format(modality)))
+    save_nifti(np.asarray(data_file.root.truth[data_index]), os.path.join(output_dir, "truth.nii.gz"))
+    if tuple(patch_shape) == tuple(test_data.shape[-3:]):
+        prediction = predict(model, test_data[:, np.newaxis] if test_data.ndim == 4 else test_data, permute=permute)
+    else:
+        prediction = patch_wise_prediction(model=model, data=test_data, overlap_factor=overlap_factor, patch_shape=patch_shape,
+                                           truth_data=test_truth_data, prev_truth_index=prev_truth_index,
+                                           prev_truth_size=prev_truth_size)[np.newaxis]
+    prediction = prediction.squeeze()
+    filename = os.path.join(output_dir, "prediction.nii.gz")
+    save_nifti(prediction, filename)
+    return filename
+
+
+def run_validation_cases(validation_keys_file, model_file, training_modalities, hdf5_file, patch_shape, output_dir=".",
+                         overlap_factor=0, permute=False, prev_truth_index=None, prev_truth_size=None, use_augmentations=False,
+                         data_file=None, model=None):
+    """reference prediction.py:333-351.  `hdf5_file` is opened with PyTables when that is installed; callers may instead
+    pass an already opened duck-typed `data_file` (and a `model`)."""
+    import glob
+    import pickle
+    from .training import load_old_model
+    with open(validation_keys_file, "rb") as f:
+        validation_indices = pickle.load(f)
+    if model is None:
+        candidates = glob.glob(model_file + '*.h5')
+        model = load_old_model(max(candidates, key=os.path.getmtime))      # newest checkpoint (reference fetal/utils.py:42-43)
+    own = data_file is None
+    if own:
+        import tables
+        data_file = tables.open_file(hdf5_file, "r")
+    file_names = []
+    try:
+        for index in validation_indices:
+            if 'subject_ids' in data_file.root:
+                case_directory = os.path.join(output_dir, data_file.root.subject_ids[index].decode('utf-8'))
+            else:
+                case_directory = os.path.join(output_dir, "validation_case_{}".format(index))
+            file_names.append(run_validation_case(data_index=index, output_dir=case_directory, model=model, data_file=data_file,
+                                                  training_modalities=training_modalities, overlap_factor=overlap_factor,
+                                                  permute=permute, patch_shape=patch_shape, prev_truth_index=prev_truth_index,
+                                                  prev_truth_size=prev_truth_size, use_augmentations=use_augmentations))
+    finally:
+        if own:
+            data_file.close()
+    return file_names

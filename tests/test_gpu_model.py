@@ -1,0 +1,118 @@
+"""Drop-in surface on the GPU: builder -> train_model (fit_generator + callbacks + checkpoints) -> load_old_model ->
+patch_wise_prediction (device overlap-add, hipGraph) -> run_validation_case, checked against the oracle."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _gen(shape, seed, n_batches=None):
+    from oracle.unet_oracle import synthetic_batch
+    k = 0
+    while True:
+        x, y = synthetic_batch(shape, seed_x=seed + k % 4, seed_y=seed + 100 + k % 4)
+        yield x.astype(np.float64), y
+        k += 1
+
+
+def test_train_model_predict_and_resume(tmp_path, monkeypatch):
+    monkeypatch.setenv("FMRI_DTYPE", "fp32")
+    import fetal_net.metrics as FM
+    import fetal_net.model as fmodel
+    from fetal_net.training import load_old_model, train_model
+    from oracle import unet_oracle as O
+    shape = (2, 1, 8, 16, 16)
+    model = fmodel.unet_model_3d(input_shape=shape[1:], depth=2, n_base_filters=8, initial_learning_rate=1e-2,
+                                 loss_function=FM.dice_coefficient_loss)
+    # identical weights in the oracle
+    spec = O.Spec(shape[1:], depth=2, n_base_filters=8)
+    W = spec.init_weights(42)
+    model.set_weights_dict(W)
+    x0, y0 = next(_gen(shape, 1))
+    p_gpu = model.predict(x0)
+    _, p_ref = O.forward(spec, O.to_torch(W, torch.float64), torch.tensor(x0))
+    assert p_gpu.shape == (2, 1, 8, 16, 16)
+    np.testing.assert_allclose(p_gpu, p_ref.numpy(), atol=2e-5)
+    # Keras-semantics training loop with the reference's callbacks
+    model_file = str(tmp_path / "fetal_net_model")
+    hist = train_model(model, model_file, _gen(shape, 1), _gen(shape, 50), steps_per_epoch=6, validation_steps=2,
+                       initial_learning_rate=1e-2, learning_rate_drop=0.5, learning_rate_patience=2, early_stopping_patience=5,
+                       n_epochs=4, output_folder=str(tmp_path))
+    h = hist.history
+    assert set(h) >= {"loss", "binary_accuracy", "vod_coefficient", "val_loss", "val_binary_accuracy", "val_vod_coefficient", "lr"}
+    assert h["loss"][-1] < h["loss"][0]
+    # first epoch's mean training loss == oracle trajectory (same batches, Keras Adam)
+    opt = O.KerasAdam(W, lr=1e-2)
+    g = _gen(shape, 1)
+    ref_losses = [O.train_step(spec, W, opt, *next(g))["loss"] for _ in range(6)]
+    assert h["loss"][0] == pytest.approx(np.mean(ref_losses), abs=2e-4)
+    ckpts = sorted(glob.glob(model_file + "*.h5"), key=os.path.getmtime)
+    assert ckpts and "-epoch" in ckpts[-1] and "-loss" in ckpts[-1] and "-acc" in ckpts[-1]
+    assert os.path.exists(str(tmp_path / "training"))
+    # resume: newest checkpoint re-opens without any config
+    m2 = load_old_model(ckpts[-1])
+    assert m2.count_params() == model.count_params()
+    W_saved = m2.get_weights_dict()
+    p2 = m2.predict(x0)
+    assert p2.shape == p_gpu.shape and np.isfinite(p2).all()
+    for k, v in W_saved.items():
+        assert v.shape == W[k].shape
+
+
+@pytest.mark.parametrize("graph", ["1", "0"])
+def test_patch_wise_prediction_device_vs_oracle(monkeypatch, graph):
+    monkeypatch.setenv("FMRI_DTYPE", "fp32")
+    monkeypatch.setenv("FMRI_HIPGRAPH", graph)
+    import fetal_net.model as fmodel
+    from fetal_net.prediction import patch_wise_prediction
+    from oracle import tiler_oracle, unet_oracle as O
+    patch = (8, 16, 16)
+    model = fmodel.unet_model_3d(input_shape=(1,) + patch, depth=2, n_base_filters=8)
+    spec = O.Spec((1,) + patch, depth=2, n_base_filters=8)
+    W = spec.init_weights(3)
+    model.set_weights_dict(W)
+
+    class OracleModel:
+        output_shape = (None, 1) + patch
+
+        def predict(self, x):
+            return O.forward(spec, O.to_torch(W, torch.float64), torch.tensor(np.asarray(x, np.float64)))[1].numpy()
+
+    data = np.random.RandomState(9).randn(1, 20, 40, 27)
+    for factor, bs in ((0.5, 5), (0.0, 4)):
+        out = patch_wise_prediction(model=model, data=data, patch_shape=patch, overlap_factor=factor, batch_size=bs)
+        ref = tiler_oracle.patch_wise_prediction(OracleModel(), data, patch, factor, bs)
+        assert out.shape == ref.shape == (20, 40, 27, 1) and out.dtype == np.float64
+        np.testing.assert_allclose(out, ref, atol=3e-5)
+
+
+def test_run_validation_case_writes_reference_files(tmp_path, monkeypatch):
+    monkeypatch.setenv("FMRI_DTYPE", "bf16")
+    import fetal_net.model as fmodel
+    from fetal_net.prediction import run_validation_case
+    from fetal_net.utils.nifti import load_nifti
+    from oracle import metrics_oracle as M
+
+    class Root:
+        pass
+
+    class DataFile:
+        root = Root()
+
+    rs = np.random.RandomState(4)
+    DataFile.root.data = [rs.randn(24, 48, 32)]
+    DataFile.root.truth = [(rs.rand(24, 48, 32) > 0.7).astype(np.uint8)]
+    patch = (16, 32, 32)
+    model = fmodel.unet_model_3d(input_shape=(1,) + patch, depth=3, n_base_filters=32)
+    fn = run_validation_case(0, str(tmp_path / "case0"), model, DataFile, ["volume"], patch_shape=patch, overlap_factor=0.5)
+    assert os.path.basename(fn) == "prediction.nii.gz"
+    for f in ("data_volume.nii.gz", "truth.nii.gz", "prediction.nii.gz"):
+        assert os.path.exists(str(tmp_path / "case0" / f))
+    pred = load_nifti(fn)
+    assert pred.shape == (24, 48, 32) and np.isfinite(pred).all() and 0 <= pred.min() and pred.max() <= 1
+    d = M.hard_dice(DataFile.root.truth[0], pred > 0.5)      # reference fetal/evaluate.py:13-17 (value itself is arbitrary here)
+    assert 0.0 <= d <= 1.0

@@ -1,0 +1,176 @@
+"""Host-side mirror of the reference API (no GPU): builders, naming, callbacks, metrics tokens, tiler geometry, checkpoints."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import fetal_net.metrics as FM
+import fetal_net.model as fmodel
+from fetal_net import prediction as P
+from fetal_net import training as T
+from fetal_net.engine_model import (CSVLogger, EarlyStopping, LearningRateScheduler, ModelCheckpoint, ReduceLROnPlateau)
+
+
+@pytest.fixture(scope="module")
+def topo(golden_dir):
+    with open(os.path.join(golden_dir, "topology_golden.json")) as f:
+        return json.load(f)
+
+
+def test_reference_test_model_naming():
+    # reference test/test_model.py:7-15
+    model = fmodel.unet_model_3d(input_shape=(1, 16, 16, 16), depth=2, deconvolution=True, metrics=[], n_labels=1,
+                                 batch_normalization=True)
+    names = [l.name for l in model.layers]
+    for name in names[:-3]:
+        if 'conv3d' in name and 'transpose' not in name:
+            assert name.replace('conv3d', 'batch_normalization') in names
+
+
+@pytest.mark.parametrize("case,fn,kw", [
+    ("unet3d_cfg1", "unet_model_3d", dict(input_shape=(1, 16, 64, 64), depth=3, n_base_filters=8)),
+    ("unet3d_default", "unet_model_3d", dict(input_shape=(1, 64, 128, 128))),
+    ("unet3d_test_model", "unet_model_3d", dict(input_shape=(1, 16, 16, 16), depth=2, deconvolution=True, metrics=[], n_labels=1,
+                                               batch_normalization=True)),
+    ("unet2d_cfg4", "unet_model_2d", dict(input_shape=(256, 256, 5))),
+    ("unet2d_dropout", "unet_model_2d", dict(input_shape=(64, 64, 5), depth=3, n_base_filters=16, dropout_rate=0.2)),
+])
+def test_builder_graph_matches_reference(topo, case, fn, kw):
+    model = getattr(fmodel, fn)(**kw)
+    gold = topo[case]
+    assert [l.name for l in model.layers] == [l["name"] for l in gold["layers"]]
+    for mine, ref in zip(model.layers, gold["layers"]):
+        assert list(mine.output_shape) == ref["output_shape"], mine.name
+        assert mine.inbound == ref["inputs"], mine.name
+    assert list(model.output_shape) == gold["output_shape"]
+    assert model.optimizer.lr == gold["compile"]["optimizer"]["lr"]
+    assert model.metrics_names[1:] == gold["compile"]["metrics"]
+    assert getattr(model.loss, "__name__") == gold["compile"]["loss"]
+
+
+def test_train_fetal_call_signature(topo):
+    # exactly how reference fetal/train_fetal.py:33-39 calls a builder (unknown kwargs are swallowed)
+    m = fmodel.unet_model_3d(input_shape=[1, 32, 32, 16], initial_learning_rate=1e-4,
+                             **{'dropout_rate': 0, 'loss_function': FM.dice_and_xent, 'mask_shape': None, 'old_model_path': None})
+    assert m.metrics_names == ['loss', 'binary_accuracy', 'vod_coefficient', 'dice_coefficient']
+    assert m.count_params() == 16315585
+    assert getattr(fmodel, 'unet_model_3d') is fmodel.unet_model_3d
+
+
+def test_param_counts():
+    assert fmodel.unet_model_3d(input_shape=(1, 16, 64, 64), depth=3, n_base_filters=8).count_params() == 245873
+    assert fmodel.unet_model_2d(input_shape=(256, 256, 5)).count_params() == 5441281
+
+
+def test_callbacks_list():
+    # reference test/test_training.py:8-15
+    _, _, scheduler = T.get_callbacks(model_file='model.h5', learning_rate_patience=50, learning_rate_drop=0.5)
+    assert isinstance(scheduler, ReduceLROnPlateau)
+    _, _, _, stopper = T.get_callbacks(model_file='model.h5', early_stopping_patience=100)
+    assert isinstance(stopper, EarlyStopping)
+    ck, csvl, sched = T.get_callbacks(model_file='model.h5', learning_rate_epochs=10)
+    assert isinstance(ck, ModelCheckpoint) and isinstance(csvl, CSVLogger) and isinstance(sched, LearningRateScheduler)
+    assert T.step_decay(9, 1e-3, 0.5, 10) == pytest.approx(5e-4)
+
+
+class _DummyModel:
+    def __init__(self):
+        from fetal_net.engine_model import Adam
+        self.optimizer = Adam(lr=1.0)
+        self.stop_training = False
+        self.saved = []
+
+    def save(self, path):
+        self.saved.append(path)
+
+
+def test_callback_semantics(tmp_path):
+    m = _DummyModel()
+    ck = ModelCheckpoint(str(tmp_path / 'm') + '-epoch{epoch:02d}-loss{val_loss:.3f}-acc{val_binary_accuracy:.3f}.h5',
+                         save_best_only=True, monitor='val_loss')
+    rl = ReduceLROnPlateau(factor=0.5, patience=2)
+    es = EarlyStopping(patience=3)
+    cl = CSVLogger(str(tmp_path / 'training'), append=True)
+    for cb in (ck, rl, es, cl):
+        cb.set_model(m)
+        cb.on_train_begin({})
+    vals = [-0.5, -0.6, -0.6, -0.6, -0.6, -0.6]
+    for ep, v in enumerate(vals):
+        logs = {'loss': v, 'val_loss': v, 'val_binary_accuracy': 0.9, 'binary_accuracy': 0.9}
+        for cb in (ck, cl, rl, es):
+            cb.on_epoch_end(ep, logs)
+        if m.stop_training:
+            break
+    assert [os.path.basename(p) for p in m.saved] == ['m-epoch01-loss-0.500-acc0.900.h5', 'm-epoch02-loss-0.600-acc0.900.h5']
+    assert m.optimizer.lr == 0.5            # one reduction after two epochs without a 1e-4 improvement (epochs 2,3)
+    assert m.stop_training and es.stopped_epoch == 4   # three epochs (2,3,4) without improvement
+    cl.on_train_end({})
+    rows = open(str(tmp_path / 'training')).read().strip().split('\n')
+    # CSVLogger sits BEFORE the lr callback in get_callbacks' order, so (as in Keras) its key set is fixed without 'lr'
+    assert rows[0] == 'epoch,binary_accuracy,loss,val_binary_accuracy,val_loss' and len(rows) == 6
+
+
+def test_metrics_tokens_match_reference(golden_dir):
+    with open(os.path.join(golden_dir, "metrics_golden.json")) as f:
+        gold = json.load(f)
+    for c in gold["cases"]:
+        rs = np.random.RandomState(c["seed"])
+        y = (rs.rand(*c["shape"]) > c["thr"]).astype(np.float32)
+        p = rs.rand(*c["shape"]).astype(np.float32)
+        assert FM.dice_coefficient(y, p) == pytest.approx(c["dice"], rel=1e-12)
+        assert FM.dice_coefficient_loss(y, p) == pytest.approx(c["dice_loss"], rel=1e-12)
+        assert FM.vod_coefficient(y, p) == pytest.approx(c["vod"], rel=1e-6)
+        assert FM.weighted_dice_coefficient(y, p) == pytest.approx(c["weighted_dice"], rel=1e-12)
+        assert FM.dice_and_xent(y, p) == pytest.approx(c["dice_and_xent"], rel=1e-10)
+        assert FM.focal_loss(y, p) == pytest.approx(c["focal_loss"], rel=1e-10)
+        assert FM.double_dice_loss(y, p) == pytest.approx(c["double_dice_loss"], rel=1e-10)
+    assert FM.dice_coef is FM.dice_coefficient and FM.dice_coef_loss is FM.dice_coefficient_loss
+
+
+def test_patch_wise_prediction_host_geometry(golden_dir):
+    """product tiler (foreign-model path) vs outputs of the reference's own patch_wise_prediction"""
+    from test_oracle_tiler import FakeModel2D, FakeModel3D
+    with open(os.path.join(golden_dir, "tiler_golden.json")) as f:
+        meta = json.load(f)
+    arrs = np.load(os.path.join(golden_dir, "tiler_golden.npz"))
+    for c in meta["volume_cases"]:
+        data = np.random.RandomState(c["seed"]).randn(1, *c["vol"])
+        fm = FakeModel3D(c["patch"], c["n_out"]) if c["kind"] == "3d" else FakeModel2D(c["patch"][:2], c["patch"][2])
+        out = P.patch_wise_prediction(model=fm, data=data, patch_shape=c["patch"], overlap_factor=c["overlap_factor"],
+                                      batch_size=c["batch_size"])
+        assert fm.calls == c["predict_calls"]
+        np.testing.assert_allclose(out, arrs["out_" + c["name"]], rtol=0, atol=1e-13, err_msg=c["name"])
+    for c in meta["index_cases"]:
+        ov = np.subtract(c["patch"], c["pred"]) + (c["overlap_factor"] * (np.subtract(c["patch"], 1) - np.subtract(c["patch"], c["pred"]))).astype(int)
+        idx = P.get_set_of_patch_indices_full((0, 0, 0), np.subtract(c["vol"], c["patch"]), np.subtract(c["patch"], ov))
+        assert np.array_equal(idx, arrs["idx_" + c["name"]])
+
+
+def test_checkpoint_roundtrip_without_gpu(tmp_path):
+    from oracle.unet_oracle import Spec
+    m = fmodel.unet_model_3d(input_shape=(1, 8, 16, 16), depth=2, n_base_filters=4, initial_learning_rate=3e-4)
+    W = Spec((1, 8, 16, 16), depth=2, n_base_filters=4).init_weights(5)
+    m.set_weights_dict(W)
+    path = str(tmp_path / "fetal_net_model-epoch01-loss-0.500-acc0.900.h5")
+    m.save(path)
+    m2 = T.load_old_model(path)
+    W2 = m2.get_weights_dict()
+    assert m2.optimizer.lr == pytest.approx(3e-4) and m2.count_params() == m.count_params()
+    for k in W:
+        assert np.array_equal(W[k], W2[k])
+
+
+def test_nifti_roundtrip(tmp_path):
+    from fetal_net.utils.nifti import load_nifti, save_nifti
+    a = np.random.RandomState(0).rand(5, 6, 7).astype(np.float32)
+    p = save_nifti(a, str(tmp_path / "prediction.nii.gz"))
+    assert np.array_equal(load_nifti(p), a)
+
+
+def test_unsupported_topologies_fail_loudly():
+    m = fmodel.unet_model_3d(input_shape=(1, 16, 16, 16), depth=2, deconvolution=True)
+    with pytest.raises(NotImplementedError):
+        m.predict(np.zeros((1, 1, 16, 16, 16)))
+    with pytest.raises(NotImplementedError):
+        fmodel.isensee2017_model_3d(input_shape=(1, 32, 32, 32))
