@@ -26,16 +26,44 @@ struct SrcB {
 };
 
 // ======================================================================================================== forward / dgrad
+// Persistent workgroups (one per CU, 8 waves) walk a list of (spatial tile, Cout block) pairs.  For every 32-channel input
+// chunk the 6x10x18 halo tile lives in LDS and is re-used by all 27 taps; the filters arrive as nine 3-tap slabs
+// (one per (kd,kh)).  Everything is brought in by LDS-DMA (global_load_lds_dwordx4) one phase ahead of its use:
+//   phase g:  s_waitcnt vmcnt(0) ; s_barrier ; issue DMA {filter slab of phase g+1, 1/9 of the NEXT chunk's halo} ;
+//             24 MFMAs per wave on filter ring slot g&1 and halo ring slot item&1
+// so one barrier per phase hands over both rings and no load latency is exposed after the prologue.  LDS is used to the
+// last byte: 2 x 68 KiB halo + 2 x 12 KiB filter = 160 KiB.
 namespace fw {
 constexpr int TD = 4, TH = 8, TW = 16;                 // 512 output voxels per workgroup = 16 MFMA column tiles of 32
 constexpr int HD = TD + 2, HH = TH + 2, HW = TW + 2;   // halo 6 x 10 x 18
 constexpr int HVOX = HD * HH * HW;                     // 1080
-constexpr int HALO_BYTES = HVOX * 64;                  // one 32-channel chunk, 64 B per voxel
+constexpr int H_INSTR = (HVOX * 4 + 63) / 64;          // 68 DMA wave-instructions per halo chunk
+constexpr int HALO_BYTES = H_INSTR * 1024;             // 69,632 (1080 rows x 64 B + pad)
 constexpr int NTHREADS = 512;
 }  // namespace fw
 
+__device__ uint4 g_zero_page[8];                       // 128 B of zeros: DMA source for out-of-volume halo rows
+
+// LDS-DMA of 16 B per lane: LDS destination = wave-uniform byte address `lds_dst` + lane*16 (M0-based), global source per
+// lane.  Issued from inline asm so that hipcc does not put its own `s_waitcnt vmcnt(0)` in front of the LDS reads of the
+// OTHER ring slot (it cannot prove the two slots disjoint); completion is tracked by hand with counted vmcnt waits.
+__device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst)
+                 : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+    return (unsigned)(size_t)(__attribute__((address_space(3))) const unsigned char*)p;
+}
+
 // 16-byte slot swizzle for 64-byte rows: 4 consecutive rows x 4 slots cover a 256-B bank row exactly once per slot index
 __device__ __forceinline__ int swz64(int row, int slot) { return row * 64 + ((slot ^ ((row >> 2) & 3)) << 4); }
+
+struct FwdItem {          // one (tile, Cout block, 32-channel chunk) unit of the persistent stream
+    int n, d0, h0, w0, co0, ch;
+};
 
 template <int NT>  // NT = 32-wide output-channel tiles per workgroup (BN = 32*NT)
 __global__ void __launch_bounds__(fw::NTHREADS)
@@ -43,24 +71,87 @@ k_conv_fwd_mfma(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__
                 bf16_t* __restrict__ y, int N, int D, int H, int W, int Cout, int act, float alpha) {
     using namespace fw;
     constexpr int BN = 32 * NT;
-    constexpr int FILT_BYTES = 9 * BN * 64;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[HALO_BYTES + FILT_BYTES];
-    unsigned char* const lds_f = lds + HALO_BYTES;
+    constexpr int FILT_BYTES = 3 * BN * 64;              // one (kd,kh) slab: 3 kw taps x BN rows x 64 B
+    constexpr int F_INSTR = FILT_BYTES / 1024;           // 12 or 6
+    constexpr int F_PER_WAVE = (F_INSTR + 7) / 8;        // 2 or 1 (short waves re-issue their first instruction)
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * HALO_BYTES + 2 * FILT_BYTES];
 
     const int Cin = s.C0 + s.C1;
+    const int nch = Cin >> 5;
     const int ncb = Cout / BN;
-    const int cb = blockIdx.x % ncb;
-    int tile = blockIdx.x / ncb;
     const int twn = W / TW, thn = H / TH, tdn = D / TD;
-    const int w0 = (tile % twn) * TW; tile /= twn;
-    const int h0 = (tile % thn) * TH; tile /= thn;
-    const int d0 = (tile % tdn) * TD;
-    const int n = tile / tdn;
-    const int co0 = cb * BN;
+    const int npairs = N * tdn * thn * twn * ncb;
 
-    const int t = threadIdx.x;
-    const int lane = t & 63, wv = t >> 6;
+    const int t = threadIdx.x, lane = t & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
     const int r = lane & 31, hk = lane >> 5;
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr(lds));
+    const unsigned ldsf0 = lds0 + 2 * HALO_BYTES;
+
+    auto decode = [&](int pair, int ch) {
+        FwdItem it;
+        it.ch = ch;
+        it.co0 = (pair % ncb) * BN;
+        int q = pair / ncb;
+        it.w0 = (q % twn) * TW; q /= twn;
+        it.h0 = (q % thn) * TH; q /= thn;
+        it.d0 = (q % tdn) * TD;
+        it.n = q / tdn;
+        return it;
+    };
+
+    // ---- per-lane constants of the DMA address generation (hoisted: the phase loop only adds wave-uniform bases)
+    int f_soff[F_PER_WAVE];        // element offset of this lane's 16 B inside a filter slab's global image
+    unsigned f_doff[F_PER_WAVE];   // LDS byte offset of the wave-instruction inside a filter ring slot
+#pragma unroll
+    for (int k = 0; k < F_PER_WAVE; ++k) {
+        int instr = wv + 8 * k;
+        if (instr >= F_INSTR) instr = wv % F_INSTR;                // duplicate: keeps the per-wave DMA count uniform
+        const int i = instr * 64 + lane;
+        const int row = i >> 2, ps = i & 3;
+        const int ls = ps ^ ((row >> 2) & 3);
+        f_soff[k] = ((row / BN) * Cout + (row % BN)) * Cin + ls * 8;
+        f_doff[k] = instr * 1024;
+    }
+    int h_pack[9];                 // halo piece ph: hd | hh<<4 | hw<<8 | ls<<13 | valid<<15
+    unsigned h_doff[9];
+#pragma unroll
+    for (int ph = 0; ph < 9; ++ph) {
+        int instr = ph * 8 + wv;
+        if (instr >= H_INSTR) instr -= 8;                          // duplicate of this wave's previous piece
+        const int i = instr * 64 + lane;
+        const int hv = i >> 2, ps = i & 3;
+        const int ls = ps ^ ((hv >> 2) & 3);
+        const int hvc = hv < HVOX ? hv : 0;
+        const int hw_ = hvc % HW, hq = hvc / HW;
+        h_pack[ph] = (hq / HH) | ((hq % HH) << 4) | (hw_ << 8) | (ls << 13) | ((hv < HVOX ? 1 : 0) << 15);
+        h_doff[ph] = instr * 1024;
+    }
+    // filter slab of phase `ph` = (kd,kh) for item `it` into filter ring slot `fb`
+    auto issue_filter = [&](const FwdItem& it, int ph, int fb) {
+        const bf16_t* const base = wt + (((int64_t)ph * 3 * Cout + it.co0) * Cin + (it.ch << 5));
+#pragma unroll
+        for (int k = 0; k < F_PER_WAVE; ++k)
+            dma16(base + f_soff[k], __builtin_amdgcn_readfirstlane(ldsf0 + fb * FILT_BYTES + f_doff[k]));
+    };
+    // 1/9 of the halo tile of item `it` into halo ring slot `hb` (ph must be a compile-time constant at the call site)
+    auto issue_halo = [&](const FwdItem& it, int pk, unsigned doff, int hb) {
+        const int cc = it.ch << 5;
+        const bool from0 = cc < s.C0;
+        const bf16_t* sp = from0 ? s.p0 : s.p1;
+        const int sC = from0 ? s.C0 : s.C1;
+        const int coff = from0 ? cc : cc - s.C0;
+        const int sh = (from0 && s.up0) ? 1 : 0;
+        const int sD = D >> sh, sH = H >> sh, sW = W >> sh;
+        const int gd = it.d0 - 1 + (pk & 15), gh = it.h0 - 1 + ((pk >> 4) & 15), gw = it.w0 - 1 + ((pk >> 8) & 31);
+        const int ls = (pk >> 13) & 3;
+        const bool ok = (pk >> 15) && (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W;
+        const int gdc = min(max(gd, 0), D - 1) >> sh, ghc = min(max(gh, 0), H - 1) >> sh, gwc = min(max(gw, 0), W - 1) >> sh;
+        const int off = ((gdc * sH + ghc) * sW + gwc) * sC + coff + ls * 8;      // inside one sample: < 2^31 elements
+        const bf16_t* real = sp + (int64_t)it.n * sD * sH * sW * sC + off;
+        const void* src = ok ? (const void*)real : (const void*)g_zero_page;
+        dma16(src, __builtin_amdgcn_readfirstlane(lds0 + hb * HALO_BYTES + doff));
+    };
 
     f32x16 acc[2][NT];
 #pragma unroll
@@ -77,80 +168,52 @@ k_conv_fwd_mfma(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__
         const int rt = 2 * wv + j;                       // 0..15 : d = rt>>2, h-pair = rt&3
         hv0[j] = ((rt >> 2) * HH + (2 * (rt & 3) + (r >> 4))) * HW + (r & 15);
     }
+    // filter fragment read offset inside a slab for k-step 0 (k-step 1 = same address with bit 5 flipped): rows kw*BN + c*32 + r
+    // keep the swizzle term of row r because kw*BN + c*32 is a multiple of 16
+    const int fa[2] = {swz64(r, hk), swz64(r, hk) ^ 32};
 
-    const int nch = Cin >> 5;
-    for (int ch = 0; ch < nch; ++ch) {
-        // ---- which source holds this 32-channel chunk
-        const int cc = ch << 5;
-        const bool from0 = cc < s.C0;
-        const bf16_t* sp = from0 ? s.p0 : s.p1;
-        const int sC = from0 ? s.C0 : s.C1;
-        const int coff = from0 ? cc : cc - s.C0;
-        const int sh = (from0 && s.up0) ? 1 : 0;
-        const int sD = D >> sh, sH = H >> sh, sW = W >> sh;
-        // ---- stage the halo tile: 1080 voxels x 4 slots of 16 B
-        {
-            uint4 v[9];
+    int pair = blockIdx.x;
+    if (pair >= npairs) return;
+    FwdItem cur = decode(pair, 0);
+    // prologue: the whole halo of the first item and its first filter slab
 #pragma unroll
-            for (int it = 0; it < 9; ++it) {
-                const int i = t + it * NTHREADS;
-                v[it] = make_uint4(0, 0, 0, 0);
-                if (i < HVOX * 4) {
-                    const int hv = i >> 2, ps = i & 3;
-                    const int ls = ps ^ ((hv >> 2) & 3);
-                    const int hw_ = hv % HW, hq = hv / HW;
-                    const int hh_ = hq % HH, hd_ = hq / HH;
-                    const int gd = d0 - 1 + hd_, gh = h0 - 1 + hh_, gw = w0 - 1 + hw_;
-                    if ((unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W) {
-                        const int64_t o = ((((int64_t)n * sD + (gd >> sh)) * sH + (gh >> sh)) * sW + (gw >> sh)) * sC + coff + ls * 8;
-                        v[it] = *reinterpret_cast<const uint4*>(sp + o);
-                    }
-                }
-            }
-#pragma unroll
-            for (int it = 0; it < 9; ++it) {
-                const int i = t + it * NTHREADS;
-                if (i < HVOX * 4) *reinterpret_cast<uint4*>(lds + i * 16) = v[it];
-            }
+    for (int ph = 0; ph < 9; ++ph) issue_halo(cur, h_pack[ph], h_doff[ph], 0);
+    issue_filter(cur, 0, 0);
+    int g = 0, hb = 0;
+    while (true) {
+        // the item after `cur` in this workgroup's stream
+        bool has_next = true;
+        FwdItem nxt = cur;
+        int npair = pair;
+        if (cur.ch + 1 < nch) nxt.ch = cur.ch + 1;
+        else {
+            npair = pair + gridDim.x;
+            has_next = npair < npairs;
+            if (has_next) nxt = decode(npair, 0);
         }
-        for (int kd = 0; kd < 3; ++kd) {
-            // ---- stage the 9 filter taps of this kd plane: rows = tapl*BN + co, 64 B each
-            {
-                constexpr int ITEMS = 9 * BN * 4;
-                constexpr int ITERS = (ITEMS + NTHREADS - 1) / NTHREADS;
-                uint4 v[ITERS];
+        const unsigned char* const lh = lds + hb * HALO_BYTES;
 #pragma unroll
-                for (int it = 0; it < ITERS; ++it) {
-                    const int i = t + it * NTHREADS;
-                    v[it] = make_uint4(0, 0, 0, 0);
-                    if (i < ITEMS) {
-                        const int row = i >> 2, ps = i & 3;
-                        const int ls = ps ^ ((row >> 2) & 3);
-                        const int tapl = row / BN, co = row % BN;
-                        const int64_t o = ((int64_t)(kd * 9 + tapl) * Cout + co0 + co) * Cin + cc + ls * 8;
-                        v[it] = *reinterpret_cast<const uint4*>(wt + o);
-                    }
-                }
+        for (int ph = 0; ph < 9; ++ph, ++g) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's DMA of the previous phase has landed
+            __builtin_amdgcn_s_barrier();                          // ... and everybody else's; previous phase fully read
+            if (ph < 8) issue_filter(cur, ph + 1, (g + 1) & 1);
+            else if (has_next) issue_filter(nxt, 0, (g + 1) & 1);
+            if (has_next) issue_halo(nxt, h_pack[ph], h_doff[ph], hb ^ 1);
+            const unsigned char* const lf = lds + 2 * HALO_BYTES + (g & 1) * FILT_BYTES;
+            const int hoff = ((ph / 3) * HH + (ph % 3)) * HW;
 #pragma unroll
-                for (int it = 0; it < ITERS; ++it) {
-                    const int i = t + it * NTHREADS;
-                    if (i < ITEMS) *reinterpret_cast<uint4*>(lds_f + i * 16) = v[it];
-                }
-            }
-            __syncthreads();
+            for (int kw = 0; kw < 3; ++kw) {
+                int hb0[2];
 #pragma unroll
-            for (int tapl = 0; tapl < 9; ++tapl) {
-                const int kh = tapl / 3, kw = tapl % 3;
-                const int hoff = (kd * HH + kh) * HW + kw;
+                for (int j = 0; j < 2; ++j) hb0[j] = swz64(hv0[j] + hoff + kw, hk);
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
                     bf16x8_t a[NT], b[2];
 #pragma unroll
                     for (int c = 0; c < NT; ++c)
-                        a[c] = *reinterpret_cast<const bf16x8_t*>(lds_f + swz64(tapl * BN + c * 32 + r, 2 * ks + hk));
+                        a[c] = *reinterpret_cast<const bf16x8_t*>(lf + fa[ks] + (kw * BN + c * 32) * 64);
 #pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        b[j] = *reinterpret_cast<const bf16x8_t*>(lds + swz64(hv0[j] + hoff, 2 * ks + hk));
+                    for (int j = 0; j < 2; ++j) b[j] = *reinterpret_cast<const bf16x8_t*>(lh + (hb0[j] ^ (ks << 5)));
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -158,39 +221,46 @@ k_conv_fwd_mfma(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__
                             acc[j][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[c], b[j], acc[j][c], 0, 0, 0);
                 }
             }
-            __syncthreads();
         }
-    }
-
-    // ---- epilogue: D rows = output channel (reg&3)+8*(reg>>2)+4*hk, D cols = voxel r
+        if (cur.ch == nch - 1) {
+            // ---- epilogue: D rows = output channel (reg&3)+8*(reg>>2)+4*hk, D cols = voxel r
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int rt = 2 * wv + j;
-        const int d = d0 + (rt >> 2), h = h0 + 2 * (rt & 3) + (r >> 4), w = w0 + (r & 15);
-        const int64_t vo = ((((int64_t)n * D + d) * H + h) * W + w) * Cout + co0;
+            for (int j = 0; j < 2; ++j) {
+                const int rt = 2 * wv + j;
+                const int d = cur.d0 + (rt >> 2), h = cur.h0 + 2 * (rt & 3) + (r >> 4), w = cur.w0 + (r & 15);
+                const int64_t vo = ((((int64_t)cur.n * D + d) * H + h) * W + w) * Cout + cur.co0;
 #pragma unroll
-        for (int c = 0; c < NT; ++c) {
+                for (int c = 0; c < NT; ++c) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int cch = c * 32 + 8 * g + 4 * hk;
-                float o[4];
+                    for (int gq = 0; gq < 4; ++gq) {
+                        const int cch = c * 32 + 8 * gq + 4 * hk;
+                        float o[4];
+                        float4 bv4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (bias) bv4 = *reinterpret_cast<const float4*>(bias + cur.co0 + cch);
+                        const float bvv[4] = {bv4.x, bv4.y, bv4.z, bv4.w};
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    float v = acc[j][c][4 * g + i];
-                    if (bias) v += bias[co0 + cch + i];
-                    if (act == FMRI_ACT_RELU) v = fmaxf(v, 0.f);
-                    else if (act == FMRI_ACT_LEAKY) v = v > 0.f ? v : alpha * v;
-                    o[i] = v;
+                        for (int i = 0; i < 4; ++i) {
+                            float v = acc[j][c][4 * gq + i] + bvv[i];
+                            if (act == FMRI_ACT_RELU) v = fmaxf(v, 0.f);
+                            else if (act == FMRI_ACT_LEAKY) v = v > 0.f ? v : alpha * v;
+                            o[i] = v;
+                            acc[j][c][4 * gq + i] = 0.f;
+                        }
+                        if (mask) {
+                            float m[4];
+                            ldv<bf16_t, 4>(mask + vo + cch, m);
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) if (!(m[i] > 0.f)) o[i] = 0.f;
+                        }
+                        stv<bf16_t, 4>(y + vo + cch, o);
+                    }
                 }
-                if (mask) {
-                    float m[4];
-                    ldv<bf16_t, 4>(mask + vo + cch, m);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) if (!(m[i] > 0.f)) o[i] = 0.f;
-                }
-                stv<bf16_t, 4>(y + vo + cch, o);
             }
         }
+        if (!has_next) break;
+        cur = nxt;
+        pair = npair;
+        hb ^= 1;
     }
 }
 
@@ -210,7 +280,6 @@ constexpr int YROWS = TH * TW;                         // 128
 constexpr int NTHREADS = 256;
 }  // namespace wg
 
-__device__ uint4 g_zero_page[8];                       // 128 B of zeros: DMA source for out-of-volume halo rows
 
 // byte offset of 16-B slot `slot` of row `row`; 128-B rows flip their 64-B halves on bit 1 of the row so that the four
 // rows touched by one transposing read land in four different 64-B bank quarters.  64-B rows need no swizzle.
@@ -237,20 +306,6 @@ __device__ __forceinline__ bf16x8_t tr_frag(const unsigned char* base, int row0,
 #pragma unroll
     for (int j = 0; j < 4; ++j) { f[j] = v0[j]; f[4 + j] = v1[j]; }
     return __builtin_bit_cast(bf16x8_t, f);
-}
-
-// LDS-DMA of 16 B per lane: LDS destination = wave-uniform byte address `lds_dst` + lane*16 (M0-based), global source per
-// lane.  Issued from inline asm so that hipcc does not put its own `s_waitcnt vmcnt(0)` in front of the LDS reads of the
-// OTHER ring slot (it cannot prove the two slots disjoint); completion is tracked by hand with counted vmcnt waits.
-__device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_dst) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(gsrc), "s"(lds_dst)
-                 : "memory");
-}
-__device__ __forceinline__ unsigned lds_addr(const void* p) {
-    return (unsigned)(size_t)(__attribute__((address_space(3))) const unsigned char*)p;
 }
 
 template <int CI_T>  // CI_T = 32-wide input-channel tiles per workgroup (1 or 2); output-channel block is always 64
@@ -412,11 +467,21 @@ int conv3d_fwd_mfma(const void* src0, int C0, int up0, const void* src1, int C1,
                     const void* mask, void* y, int N, int D, int H, int W, int Cout, int act, float alpha, hipStream_t st) {
     SrcB s{(const bf16_t*)src0, (const bf16_t*)src1, C0, C1, up0};
     const int ntile = N * (D / fw::TD) * (H / fw::TH) * (W / fw::TW);
+    static int ncu = 0;                 // CU count of the current device, queried once (persistent grid = one workgroup per CU)
+    if (ncu == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+            ncu = v;
+        else
+            ncu = 256;
+    }
     if (Cout % 64 == 0) {
-        k_conv_fwd_mfma<2><<<ntile * (Cout / 64), fw::NTHREADS, 0, st>>>(s, (const bf16_t*)w, bias, (const bf16_t*)mask, (bf16_t*)y,
+        const int np = ntile * (Cout / 64);
+        k_conv_fwd_mfma<2><<<np < ncu ? np : ncu, fw::NTHREADS, 0, st>>>(s, (const bf16_t*)w, bias, (const bf16_t*)mask, (bf16_t*)y,
                                                                          N, D, H, W, Cout, act, alpha);
     } else {
-        k_conv_fwd_mfma<1><<<ntile * (Cout / 32), fw::NTHREADS, 0, st>>>(s, (const bf16_t*)w, bias, (const bf16_t*)mask, (bf16_t*)y,
+        const int np = ntile * (Cout / 32);
+        k_conv_fwd_mfma<1><<<np < ncu ? np : ncu, fw::NTHREADS, 0, st>>>(s, (const bf16_t*)w, bias, (const bf16_t*)mask, (bf16_t*)y,
                                                                          N, D, H, W, Cout, act, alpha);
     }
     FMRI_LAUNCH_CHECK();
