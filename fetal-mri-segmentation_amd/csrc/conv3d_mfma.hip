@@ -318,11 +318,12 @@ k_conv_wgrad_mfma(SrcB s, const bf16_t* __restrict__ dy, float* __restrict__ dw,
     constexpr int XS = XROWB / 16;                       // 16-B slots per x row
     constexpr int X_INSTR = (XROWS * XS + 63) / 64;      // DMA wave-instructions for the x plane (23 or 12)
     constexpr int Y_INSTR = YROWS * 8 / 64;              // 16
-    constexpr int PER_WAVE = (X_INSTR + Y_INSTR + 3) / 4;  // 10 or 7 DMA instructions per wave per unit (padded with dummies)
+    constexpr int XPW = (X_INSTR + 3) / 4;               // x instructions per wave (6 or 3; short waves re-issue their first)
+    constexpr int YPW = Y_INSTR / 4;                     // 4
+    constexpr int PER_WAVE = XPW + YPW;                  // 10 or 7 DMA instructions per wave per unit
     constexpr int X_BYTES = X_INSTR * 1024;
     constexpr int Y_BYTES = Y_INSTR * 1024;
-    constexpr int DUMMY_BYTES = (PER_WAVE * 4 - X_INSTR - Y_INSTR) * 1024;
-    constexpr int STAGE_BYTES = X_BYTES + Y_BYTES + DUMMY_BYTES;
+    constexpr int STAGE_BYTES = X_BYTES + Y_BYTES;
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * STAGE_BYTES];
 
     const int Cin = s.C0 + s.C1;
@@ -347,7 +348,6 @@ k_conv_wgrad_mfma(SrcB s, const bf16_t* __restrict__ dy, float* __restrict__ dw,
     const int ct = wv & 1;
     const int it = (CI_T == 2) ? (wv >> 1) : 0;
     const int ksl = (CI_T == 2) ? 0 : (wv >> 1);
-    constexpr int KSTEP = (CI_T == 2) ? 1 : 2;
     const bool do_bias = (db != nullptr) && kd == 0 && cib == 0 && it == 0;
 
     f32x16 acc[9];
@@ -360,7 +360,31 @@ k_conv_wgrad_mfma(SrcB s, const bf16_t* __restrict__ dy, float* __restrict__ dw,
     const int twn = W / TW, thn = H / TH;
     const int nunits = N * D * thn * twn;
 
-    // issue the DMA of unit `u` into ring slot `buf`: this wave's PER_WAVE instructions (instr = wv + 4*j), branch-free
+    // ---- per-lane constants of the DMA address generation
+    int x_pack[XPW];               // xh | xw<<4 | ls<<9 | valid<<12
+    unsigned x_doff[XPW];
+#pragma unroll
+    for (int j = 0; j < XPW; ++j) {
+        int instr = wv + 4 * j;
+        if (instr >= X_INSTR) instr = wv;
+        const int i = instr * 64 + lane;
+        const int row = i / XS, ps = i % XS;
+        const int ls = (XROWB == 128) ? (ps ^ (((row >> 1) & 1) << 2)) : ps;
+        const int rowc = row < XROWS ? row : 0;
+        x_pack[j] = (rowc / XW) | ((rowc % XW) << 4) | (ls << 9) | ((row < XROWS ? 1 : 0) << 12);
+        x_doff[j] = instr * 1024;
+    }
+    int y_soff[YPW];
+    unsigned y_doff[YPW];
+#pragma unroll
+    for (int j = 0; j < YPW; ++j) {
+        const int instr = wv + 4 * j;
+        const int i = instr * 64 + lane;
+        const int row = i >> 3, ps = i & 7;
+        const int ls = ps ^ (((row >> 1) & 1) << 2);
+        y_soff[j] = ((row >> 4) * W + (row & 15)) * Cout + ls * 8;
+        y_doff[j] = X_BYTES + instr * 1024;
+    }
     const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr(lds));
     auto issue = [&](int u, int buf) {
         int q = u;
@@ -371,32 +395,31 @@ k_conv_wgrad_mfma(SrcB s, const bf16_t* __restrict__ dy, float* __restrict__ dw,
         const int gd = d + kd - 1;
         const bool dok = (unsigned)gd < (unsigned)D;
         const int gdc = min(max(gd, 0), D - 1) >> sh;
-        const int64_t xplane = ((int64_t)n * sD + gdc) * sH;
-        const int64_t yplane = (((int64_t)n * D + d) * H + h0) * W + w0;
+        const bf16_t* const xbase = sp + ((int64_t)n * sD + gdc) * sH * sW * sC + coff;
+        const bf16_t* const ybase = dy + ((((int64_t)n * D + d) * H + h0) * W + w0) * Cout + co0;
+        const unsigned sbase = lds0 + buf * STAGE_BYTES;
 #pragma unroll
-        for (int j = 0; j < PER_WAVE; ++j) {
-            const int instr = wv + 4 * j;                       // wave-uniform
-            const void* src = (const void*)g_zero_page;
-            if (instr < X_INSTR) {
-                const int i = instr * 64 + lane;
-                const int row = i / XS, ps = i % XS;
-                const int ls = (XROWB == 128) ? (ps ^ (((row >> 1) & 1) << 2)) : ps;
-                const int xh = row / XW, xw = row % XW;
-                const int gh = h0 - 1 + xh, gw = w0 - 1 + xw;
-                const bool ok = dok && row < XROWS && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W;
-                const int ghc = min(max(gh, 0), H - 1) >> sh, gwc = min(max(gw, 0), W - 1) >> sh;
-                const bf16_t* real = sp + (((xplane + ghc) * sW + gwc) * sC + coff + ls * 8);
-                src = ok ? (const void*)real : (const void*)g_zero_page;
-            } else if (instr < X_INSTR + Y_INSTR) {
-                const int i = (instr - X_INSTR) * 64 + lane;
-                const int row = i >> 3, ps = i & 7;
-                const int ls = ps ^ (((row >> 1) & 1) << 2);
-                const int yh = row >> 4, yw = row & 15;
-                src = dy + ((yplane + (int64_t)yh * W + yw) * Cout + co0 + ls * 8);
-            }
-            dma16(src, __builtin_amdgcn_readfirstlane(lds0 + buf * STAGE_BYTES + instr * 1024));
+        for (int j = 0; j < XPW; ++j) {
+            const int pk = x_pack[j];
+            const int gh = h0 - 1 + (pk & 15), gw = w0 - 1 + ((pk >> 4) & 31);
+            const bool ok = dok && (pk >> 12) && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W;
+            const int ghc = min(max(gh, 0), H - 1) >> sh, gwc = min(max(gw, 0), W - 1) >> sh;
+            const bf16_t* real = xbase + ((ghc * sW + gwc) * sC + ((pk >> 9) & 7) * 8);
+            dma16(ok ? (const void*)real : (const void*)g_zero_page, __builtin_amdgcn_readfirstlane(sbase + x_doff[j]));
         }
+#pragma unroll
+        for (int j = 0; j < YPW; ++j) dma16(ybase + y_soff[j], __builtin_amdgcn_readfirstlane(sbase + y_doff[j]));
     };
+
+    // ---- per-lane constants of the transposing fragment reads.  A row index is (lane part) + (wave-uniform constant c);
+    // adding a multiple of 4 rows never changes the swizzle, so addr(c) = pre[c & 3] + (c >> 2) * 4 * ROWB.
+    const int gq = lane >> 4, qd = (lane & 15) >> 2, pp = lane & 3;
+    const int lrow = 8 * (gq >> 1) + qd;                              // 0..11
+    const int lslot_x = it * 4 + 2 * (gq & 1) + (pp >> 1), lslot_y = ct * 4 + 2 * (gq & 1) + (pp >> 1);
+    int pre_x[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) pre_x[m] = wg_slot_off<XROWB>(lrow + m, lslot_x) + (pp & 1) * 8;
+    const int pre_y = X_BYTES + wg_slot_off<128>(lrow, lslot_y) + (pp & 1) * 8;   // y row0 = ks*16 is a multiple of 4
 
     int u = slab;
     int buf = 0;
@@ -410,22 +433,34 @@ k_conv_wgrad_mfma(SrcB s, const bf16_t* __restrict__ dy, float* __restrict__ dw,
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __builtin_amdgcn_s_barrier();
-        const unsigned char* const xb = lds + buf * STAGE_BYTES;
-        const unsigned char* const yb = xb + X_BYTES;
-#pragma unroll 1
-        for (int ks = ksl; ks < 8; ks += KSTEP) {
-            const bf16x8_t a = tr_frag<128>(yb, ks * TW, ct, lane);                      // A[co][k = voxel]
-            if (do_bias) {
-                typedef __attribute__((ext_vector_type(8))) unsigned short u16x8;
-                const u16x8 au = __builtin_bit_cast(u16x8, a);
+        const unsigned char* const sb = lds + buf * STAGE_BYTES;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) bsum += bf2f(au[j]);
+        for (int ks8 = 0; ks8 < 8; ++ks8) {
+            if (CI_T == 1 && (ks8 & 1) != ksl) continue;              // Cin-block 32: the two wave pairs split the k-steps
+            typedef __attribute__((ext_vector_type(8))) short s16x8;
+            s16x8 af;
+            {
+                const unsigned char* pa = sb + pre_y + ks8 * TW * 128;
+                s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)pa);
+                s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(pa + 4 * 128));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { af[j] = v0[j]; af[4 + j] = v1[j]; }
+            }
+            const bf16x8_t a = __builtin_bit_cast(bf16x8_t, af);                     // A[co][k = voxel]
+            if (do_bias) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) bsum += bf2f((unsigned short)af[j]);
             }
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
-                const int kh = tap / 3, kw = tap % 3;
-                const bf16x8_t b = tr_frag<XROWB>(xb, (ks + kh) * XW + kw, it, lane);    // B[k = voxel][ci]
-                acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[tap], 0, 0, 0);
+                const int c = (ks8 + tap / 3) * XW + (tap % 3);                      // compile-time row constant
+                const unsigned char* pb = sb + pre_x[c & 3] + (c >> 2) * 4 * XROWB;
+                s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)pb);
+                s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(pb + 4 * XROWB));
+                s16x8 bfv;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { bfv[j] = v0[j]; bfv[4 + j] = v1[j]; }
+                acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bf16x8_t, bfv), acc[tap], 0, 0, 0);   // B[k = voxel][ci]
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

@@ -7,7 +7,7 @@ ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
 IMPL_AUTO, IMPL_GENERIC, IMPL_MFMA = 0, 1, 2
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libfmri_hip.so")
+LIB_PATH = os.environ.get("FMRI_LIB") or os.path.join(os.path.dirname(_HERE), "lib", "libfmri_hip.so")   # FMRI_LIB: A/B builds
 
 
 class LibraryMissing(RuntimeError):
