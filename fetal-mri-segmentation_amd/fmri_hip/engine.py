@@ -190,9 +190,11 @@ class UNetEngine:
             self.N = N
             self._build_buffers()
             self._bufsets[key] = dict(act=self.act, grad=getattr(self, "grad", None), logits=self.logits, probs=self.probs,
-                                      dlogits=getattr(self, "dlogits", None))
+                                      dlogits=getattr(self, "dlogits", None),
+                                      dummy_y=torch.zeros(self.logits.numel(), dtype=torch.uint8, device=self.dev))
         b = self._bufsets[key]
         self.N, self.act, self.grad, self.logits, self.probs, self.dlogits = N, b["act"], b["grad"], b["logits"], b["probs"], b["dlogits"]
+        self._dummy_y = b["dummy_y"]       # per buffer set and never freed: captured hipGraphs keep raw pointers to it
 
     def _build_buffers(self):
         p, N, dt, dev = self.plan, self.N, self.dtype, self.dev
@@ -257,9 +259,7 @@ class UNetEngine:
     def predict(self, x):
         self.forward(x)
         self.sums.zero_()
-        # sigmoid only (y_true is irrelevant for probs): reuse the fused kernel with a dummy label view
-        if not hasattr(self, "_dummy_y") or self._dummy_y.numel() != self.logits.numel():
-            self._dummy_y = torch.zeros(self.logits.numel(), dtype=torch.uint8, device=self.dev)
+        # sigmoid only (y_true is irrelevant for probs): reuse the fused kernel with an all-zero label buffer
         ops.sigmoid_dice_fwd(self.logits, self._dummy_y, self.probs, self.sums)
         return self.probs
 

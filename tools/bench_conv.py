@@ -75,7 +75,10 @@ if __name__ == "__main__":
     acc = {l: [] for l in libs}
     for rd in range(rounds):
         for l in libs:
-            env = dict(os.environ, FMRI_LIB=os.path.abspath(l))
+            path, _, kv = l.partition("@")          # "lib.so@VAR=VAL" adds an environment switch to that arm
+            env = dict(os.environ, FMRI_LIB=os.path.abspath(path))
+            if kv:
+                env[kv.split("=")[0]] = kv.split("=")[1]
             out = subprocess.check_output([sys.executable, __file__, "--child", "--iters", str(a.iters), "--which", a.which], env=env).decode()
             acc[l].append(json.loads([x for x in out.splitlines() if x.startswith("RESULT ")][0][7:]))
     keys = list(acc[libs[0]][0].keys())
