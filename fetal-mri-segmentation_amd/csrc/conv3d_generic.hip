@@ -13,7 +13,7 @@ constexpr int CK = 8;                             // input channels staged per p
 constexpr int COB = 16;                           // output channels per block
 
 struct Src {
-    const void* p0; const void* p1; int C0, C1, up0;
+    const void* p0; const void* p1; int C0, C1, up0, dsh, planar;   // dsh: the fused x2 also doubles D (3-D) or not (2-D slices)
 };
 
 // value of concat channel c at full-res voxel (n,d,h,w); zero outside the volume ('same' zero padding)
@@ -22,7 +22,7 @@ __device__ __forceinline__ float load_in(const Src& s, int n, int d, int h, int 
     if ((unsigned)d >= (unsigned)D || (unsigned)h >= (unsigned)H || (unsigned)w >= (unsigned)W) return 0.f;
     if (c < s.C0) {
         if (s.up0) {
-            int64_t o = ((((int64_t)n * (D >> 1) + (d >> 1)) * (H >> 1) + (h >> 1)) * (W >> 1) + (w >> 1)) * s.C0 + c;
+            int64_t o = ((((int64_t)n * (D >> s.dsh) + (d >> s.dsh)) * (H >> 1) + (h >> 1)) * (W >> 1) + (w >> 1)) * s.C0 + c;
             return to_f<T>(((const T*)s.p0)[o]);
         }
         return to_f<T>(((const T*)s.p0)[((((int64_t)n * D + d) * H + h) * W + w) * s.C0 + c]);
@@ -69,7 +69,7 @@ k_conv_fwd_generic(Src s, const T* __restrict__ wt, const float* __restrict__ bi
         }
         __syncthreads();
 #pragma unroll 1
-        for (int tap = 0; tap < 27; ++tap) {
+        for (int tap = s.planar ? 9 : 0; tap < (s.planar ? 18 : 27); ++tap) {   // planar (2-D slices): centre kd plane only
             const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
             const int hv = ((ld + kd) * HH + (lh + kh)) * HW + lw + kw;
 #pragma unroll
@@ -137,6 +137,7 @@ k_conv_wgrad_generic(Src s, const T* __restrict__ dy, float* __restrict__ dw, fl
             if (o < WG_OUT) {
                 const int ci = o % CK, co = (o / CK) % COB, tap = o / (CK * COB);
                 const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+                if (s.planar && kd != 1) continue;
                 float a = acc[j];
                 for (int v = 0; v < 256; ++v) {
                     const int lw = v & 15, lh = (v >> 4) & 7, ld = v >> 7;
@@ -170,10 +171,10 @@ int ntiles_of(int N, int D, int H, int W) {
 }  // namespace
 
 // internal entry points used by the dispatcher in conv3d_api.hip
-int conv3d_fwd_generic(const void* src0, int C0, int up0, const void* src1, int C1, const void* w, const float* bias,
+int conv3d_fwd_generic(const void* src0, int C0, int up0, int planar, const void* src1, int C1, const void* w, const float* bias,
                        const void* mask, void* y, int N, int D, int H, int W, int Cout, int act, float alpha, int dtype,
                        hipStream_t s) {
-    Src sr{src0, src1, C0, C1, up0};
+    Src sr{src0, src1, C0, C1, up0, planar ? 0 : 1, planar};
     dim3 grid(ntiles_of(N, D, H, W), (Cout + COB - 1) / COB);
     if (dtype == FMRI_F32)
         k_conv_fwd_generic<float><<<grid, 256, 0, s>>>(sr, (const float*)w, bias, (const float*)mask, (float*)y, N, D, H, W, Cout, act, alpha);
@@ -184,9 +185,9 @@ int conv3d_fwd_generic(const void* src0, int C0, int up0, const void* src1, int 
     return FMRI_OK;
 }
 
-int conv3d_wgrad_generic(const void* src0, int C0, int up0, const void* src1, int C1, const void* dy, float* dw, float* db,
+int conv3d_wgrad_generic(const void* src0, int C0, int up0, int planar, const void* src1, int C1, const void* dy, float* dw, float* db,
                          int N, int D, int H, int W, int Cout, int dtype, hipStream_t s) {
-    Src sr{src0, src1, C0, C1, up0};
+    Src sr{src0, src1, C0, C1, up0, planar ? 0 : 1, planar};
     const int Cin = C0 + C1;
     const int nt = ntiles_of(N, D, H, W);
     const int cy = (Cin + CK - 1) / CK, cz = (Cout + COB - 1) / COB;

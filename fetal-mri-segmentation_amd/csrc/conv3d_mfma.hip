@@ -24,7 +24,7 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
 struct SrcB {
-    const bf16_t* p0; const bf16_t* p1; int C0, C1, up0;
+    const bf16_t* p0; const bf16_t* p1; int C0, C1, up0, dsh, planar;   // dsh = 0: the fused x2 leaves D alone (2-D slices)
 };
 
 // ======================================================================================================== forward / dgrad
@@ -67,7 +67,7 @@ struct FwdItem {          // one (tile, Cout block, 32-channel chunk) unit of th
     int n, d0, h0, w0, co0, ch;
 };
 
-template <int NT>  // NT = 32-wide output-channel tiles per workgroup (BN = 32*NT)
+template <int NT, bool PL>  // NT = 32-wide output-channel tiles per workgroup (BN = 32*NT); PL = planar (2-D slices: kd = 1 taps only)
 __global__ void __launch_bounds__(fw::NTHREADS)
 k_conv_fwd_mfma(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ bias, const bf16_t* __restrict__ mask,
                 bf16_t* __restrict__ y, int N, int D, int H, int W, int Cout, int act, float alpha) {
@@ -76,6 +76,9 @@ k_conv_fwd_mfma(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__
     constexpr int FILT_BYTES = 3 * BN * 64;              // one (kd,kh) slab: 3 kw taps x BN rows x 64 B
     constexpr int F_INSTR = FILT_BYTES / 1024;           // 12 or 6
     constexpr int F_PER_WAVE = (F_INSTR + 7) / 8;        // 2 or 1 (short waves re-issue their first instruction)
+    constexpr int NPH = PL ? 3 : 9;                      // phases per chunk = (kd,kh) rows that exist
+    constexpr int PH0 = PL ? 3 : 0;                      // first (kd,kh) row (planar: kd = 1)
+    constexpr int HPP = 9 / NPH;                         // halo DMA pieces issued per phase (9 pieces per chunk)
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * HALO_BYTES + 2 * FILT_BYTES];
 
     const int Cin = s.C0 + s.C1;
@@ -144,11 +147,12 @@ k_conv_fwd_mfma(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__
         const int sC = from0 ? s.C0 : s.C1;
         const int coff = from0 ? cc : cc - s.C0;
         const int sh = (from0 && s.up0) ? 1 : 0;
-        const int sD = D >> sh, sH = H >> sh, sW = W >> sh;
+        const int shd = sh & s.dsh;
+        const int sD = D >> shd, sH = H >> sh, sW = W >> sh;
         const int gd = it.d0 - 1 + (pk & 15), gh = it.h0 - 1 + ((pk >> 4) & 15), gw = it.w0 - 1 + ((pk >> 8) & 31);
         const int ls = (pk >> 13) & 3;
         const bool ok = (pk >> 15) && (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W;
-        const int gdc = min(max(gd, 0), D - 1) >> sh, ghc = min(max(gh, 0), H - 1) >> sh, gwc = min(max(gw, 0), W - 1) >> sh;
+        const int gdc = min(max(gd, 0), D - 1) >> shd, ghc = min(max(gh, 0), H - 1) >> sh, gwc = min(max(gw, 0), W - 1) >> sh;
         const int off = ((gdc * sH + ghc) * sW + gwc) * sC + coff + ls * 8;      // inside one sample: < 2^31 elements
         const bf16_t* real = sp + (int64_t)it.n * sD * sH * sW * sC + off;
         const void* src = ok ? (const void*)real : (const void*)g_zero_page;
@@ -180,7 +184,7 @@ k_conv_fwd_mfma(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__
     // prologue: the whole halo of the first item and its first filter slab
 #pragma unroll
     for (int ph = 0; ph < 9; ++ph) issue_halo(cur, h_pack[ph], h_doff[ph], 0);
-    issue_filter(cur, 0, 0);
+    issue_filter(cur, PH0, 0);
     int g = 0, hb = 0;
     while (true) {
         // the item after `cur` in this workgroup's stream
@@ -195,12 +199,16 @@ k_conv_fwd_mfma(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__
         }
         const unsigned char* const lh = lds + hb * HALO_BYTES;
 #pragma unroll
-        for (int ph = 0; ph < 9; ++ph, ++g) {
+        for (int pl = 0; pl < NPH; ++pl, ++g) {
+            const int ph = PH0 + pl;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's DMA of the previous phase has landed
             __builtin_amdgcn_s_barrier();                          // ... and everybody else's; previous phase fully read
-            if (ph < 8) issue_filter(cur, ph + 1, (g + 1) & 1);
-            else if (has_next) issue_filter(nxt, 0, (g + 1) & 1);
-            if (has_next) issue_halo(nxt, h_pack[ph], h_doff[ph], hb ^ 1);
+            if (pl < NPH - 1) issue_filter(cur, ph + 1, (g + 1) & 1);
+            else if (has_next) issue_filter(nxt, PH0, (g + 1) & 1);
+            if (has_next) {
+#pragma unroll
+                for (int q = 0; q < HPP; ++q) issue_halo(nxt, h_pack[pl * HPP + q], h_doff[pl * HPP + q], hb ^ 1);
+            }
             const unsigned char* const lf = lds + 2 * HALO_BYTES + (g & 1) * FILT_BYTES;
             const int hoff = ((ph / 3) * HH + (ph % 3)) * HW;
 #pragma unroll
@@ -346,11 +354,12 @@ k_conv_fwd_mfma16(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict
         const int sC = from0 ? s.C0 : s.C1;
         const int coff = from0 ? cc : cc - s.C0;
         const int sh = (from0 && s.up0) ? 1 : 0;
-        const int sD = D >> sh, sH = H >> sh, sW = W >> sh;
+        const int shd = sh & s.dsh;
+        const int sD = D >> shd, sH = H >> sh, sW = W >> sh;
         const int gd = it.d0 - 1 + (pk & 15), gh = it.h0 - 1 + ((pk >> 4) & 15), gw = it.w0 - 1 + ((pk >> 8) & 31);
         const int ls = (pk >> 13) & 3;
         const bool ok = (pk >> 15) && (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W;
-        const int gdc = min(max(gd, 0), D - 1) >> sh, ghc = min(max(gh, 0), H - 1) >> sh, gwc = min(max(gw, 0), W - 1) >> sh;
+        const int gdc = min(max(gd, 0), D - 1) >> shd, ghc = min(max(gh, 0), H - 1) >> sh, gwc = min(max(gw, 0), W - 1) >> sh;
         const int off = ((gdc * sH + ghc) * sW + gwc) * sC + coff + ls * 8;      // inside one sample: < 2^31 elements
         const bf16_t* real = sp + (int64_t)it.n * sD * sH * sW * sC + off;
         const void* src = ok ? (const void*)real : (const void*)g_zero_page;
@@ -528,12 +537,12 @@ k_conv_wgrad_mfma(SrcB s, const bf16_t* __restrict__ dy, float* __restrict__ dw,
     // slab-major block order: the (kd, Cout block, Cin block) workgroups that read the SAME planes are adjacent in launch
     // order, so they run at the same time and share those planes in L2 / Infinity Cache instead of re-reading HBM
     // (measured with rocprofv3 FETCH_SIZE: combo-major order fetched 3.6x the algorithmic bytes)
-    const int ncombo = 3 * ncob * ncib;
+    const int ncombo = (s.planar ? 1 : 3) * ncob * ncib;
     int combo = blockIdx.x % ncombo;
     const int slab = blockIdx.x / ncombo;
     const int cib = combo % ncib; combo /= ncib;
     const int cob = combo % ncob;
-    const int kd = combo / ncob;
+    const int kd = s.planar ? 1 : combo / ncob;            // planar (2-D slices): only the centre kd plane exists
     const int co0 = cob * 64, cc = cib * CIB;
 
     const bool from0 = cc < s.C0;
@@ -541,7 +550,8 @@ k_conv_wgrad_mfma(SrcB s, const bf16_t* __restrict__ dy, float* __restrict__ dw,
     const int sC = from0 ? s.C0 : s.C1;
     const int coff = from0 ? cc : cc - s.C0;
     const int sh = (from0 && s.up0) ? 1 : 0;
-    const int sD = D >> sh, sH = H >> sh, sW = W >> sh;
+    const int shd = sh & s.dsh;
+    const int sD = D >> shd, sH = H >> sh, sW = W >> sh;
 
     const int t = threadIdx.x, lane = t & 63;
     const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -549,7 +559,7 @@ k_conv_wgrad_mfma(SrcB s, const bf16_t* __restrict__ dy, float* __restrict__ dw,
     const int ct = wv & 1;
     const int it = (CI_T == 2) ? (wv >> 1) : 0;
     const int ksl = (CI_T == 2) ? 0 : (wv >> 1);
-    const bool do_bias = (db != nullptr) && kd == 0 && cib == 0 && it == 0;
+    const bool do_bias = (db != nullptr) && kd == (s.planar ? 1 : 0) && cib == 0 && it == 0;
 
     f32x16 acc[9];
 #pragma unroll
@@ -595,7 +605,7 @@ k_conv_wgrad_mfma(SrcB s, const bf16_t* __restrict__ dy, float* __restrict__ dw,
         const int n = q / D;
         const int gd = d + kd - 1;
         const bool dok = (unsigned)gd < (unsigned)D;
-        const int gdc = min(max(gd, 0), D - 1) >> sh;
+        const int gdc = min(max(gd, 0), D - 1) >> shd;
         const bf16_t* const xbase = sp + ((int64_t)n * sD + gdc) * sH * sW * sC + coff;
         const bf16_t* const ybase = dy + ((((int64_t)n * D + d) * H + h0) * W + w0) * Cout + co0;
         const unsigned sbase = lds0 + buf * STAGE_BYTES;
@@ -699,9 +709,9 @@ bool conv3d_wgrad_mfma_ok(int C0, int C1, int Cout, int D, int H, int W, int dty
     return true;
 }
 
-int conv3d_fwd_mfma(const void* src0, int C0, int up0, const void* src1, int C1, const void* w, const float* bias,
+int conv3d_fwd_mfma(const void* src0, int C0, int up0, int planar, const void* src1, int C1, const void* w, const float* bias,
                     const void* mask, void* y, int N, int D, int H, int W, int Cout, int act, float alpha, hipStream_t st) {
-    SrcB s{(const bf16_t*)src0, (const bf16_t*)src1, C0, C1, up0};
+    SrcB s{(const bf16_t*)src0, (const bf16_t*)src1, C0, C1, up0, planar ? 0 : 1, planar};
     const int ntile = N * (D / fw::TD) * (H / fw::TH) * (W / fw::TW);
     static int ncu = 0;                 // CU count of the current device, queried once (persistent grid = one workgroup per CU)
     if (ncu == 0) {
@@ -716,7 +726,7 @@ int conv3d_fwd_mfma(const void* src0, int C0, int up0, const void* src1, int C1,
         const char* e = getenv("FMRI_FWD_MFMA");
         use16 = (e && atoi(e) == 16) ? 1 : 0;
     }
-    if (use16) {
+    if (use16 && !planar) {
         if (Cout % 64 == 0) {
             const int np = ntile * (Cout / 64);
             k_conv_fwd_mfma16<2><<<np < ncu ? np : ncu, fw::NTHREADS, 0, st>>>(s, (const bf16_t*)w, bias, (const bf16_t*)mask, (bf16_t*)y,
@@ -729,26 +739,29 @@ int conv3d_fwd_mfma(const void* src0, int C0, int up0, const void* src1, int C1,
         FMRI_LAUNCH_CHECK();
         return FMRI_OK;
     }
+#define FMRI_LAUNCH_FWD(NT_, PL_)                                                                                          \
+    do {                                                                                                                  \
+        const int np = ntile * (Cout / (32 * NT_));                                                                       \
+        k_conv_fwd_mfma<NT_, PL_><<<np < ncu ? np : ncu, fw::NTHREADS, 0, st>>>(s, (const bf16_t*)w, bias, (const bf16_t*)mask, \
+                                                                                (bf16_t*)y, N, D, H, W, Cout, act, alpha); \
+    } while (0)
     if (Cout % 64 == 0) {
-        const int np = ntile * (Cout / 64);
-        k_conv_fwd_mfma<2><<<np < ncu ? np : ncu, fw::NTHREADS, 0, st>>>(s, (const bf16_t*)w, bias, (const bf16_t*)mask, (bf16_t*)y,
-                                                                         N, D, H, W, Cout, act, alpha);
+        if (planar) FMRI_LAUNCH_FWD(2, true); else FMRI_LAUNCH_FWD(2, false);
     } else {
-        const int np = ntile * (Cout / 32);
-        k_conv_fwd_mfma<1><<<np < ncu ? np : ncu, fw::NTHREADS, 0, st>>>(s, (const bf16_t*)w, bias, (const bf16_t*)mask, (bf16_t*)y,
-                                                                         N, D, H, W, Cout, act, alpha);
+        if (planar) FMRI_LAUNCH_FWD(1, true); else FMRI_LAUNCH_FWD(1, false);
     }
+#undef FMRI_LAUNCH_FWD
     FMRI_LAUNCH_CHECK();
     return FMRI_OK;
 }
 
-int conv3d_wgrad_mfma(const void* src0, int C0, int up0, const void* src1, int C1, const void* dy, float* dw, float* db, int N,
+int conv3d_wgrad_mfma(const void* src0, int C0, int up0, int planar, const void* src1, int C1, const void* dy, float* dw, float* db, int N,
                       int D, int H, int W, int Cout, hipStream_t st) {
-    SrcB s{(const bf16_t*)src0, (const bf16_t*)src1, C0, C1, up0};
+    SrcB s{(const bf16_t*)src0, (const bf16_t*)src1, C0, C1, up0, planar ? 0 : 1, planar};
     const int Cin = C0 + C1;
     const bool wide = (C0 % 64 == 0) && (C1 % 64 == 0);
     const int CIB = wide ? 64 : 32;
-    const int combos = 3 * (Cout / 64) * (Cin / CIB);
+    const int combos = (planar ? 1 : 3) * (Cout / 64) * (Cin / CIB);
     const int ntiles = N * D * (H / wg::TH) * (W / wg::TW);
     int nslab = (1024 + combos - 1) / combos;        // aim for ~1024 workgroups (2 per CU, 2 rounds)
     if (nslab > ntiles) nslab = ntiles;

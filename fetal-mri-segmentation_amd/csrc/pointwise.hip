@@ -26,8 +26,8 @@ __device__ __forceinline__ void decode_vox(int64_t v, int Do, int Ho, int Wo, in
 // ------------------------------------------------------------------------------------------------ max-pool 2x2x2
 // One thread per (pooled voxel, channel group of VEC).  Reference: MaxPooling3D(pool_size) at unet3d/unet.py:51.
 template <typename T, int VEC>
-__global__ void k_maxpool_fwd(const T* __restrict__ x, T* __restrict__ y, int N, int D, int H, int W, int C) {
-    const int Do = D >> 1, Ho = H >> 1, Wo = W >> 1, CG = C / VEC;
+__global__ void k_maxpool_fwd(const T* __restrict__ x, T* __restrict__ y, int N, int D, int H, int W, int C, int pd) {
+    const int Do = D >> pd, Ho = H >> 1, Wo = W >> 1, CG = C / VEC;      // pd = 0: planar (2-D slices), window 1x2x2
     const int64_t total = (int64_t)N * Do * Ho * Wo * CG;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         int cg = (int)(i % CG), n, d_o, ho, wo;
@@ -37,7 +37,8 @@ __global__ void k_maxpool_fwd(const T* __restrict__ x, T* __restrict__ y, int N,
         for (int k = 0; k < VEC; ++k) m[k] = -INFINITY;
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
-            int dd = 2 * d_o + (t >> 2), hh = 2 * ho + ((t >> 1) & 1), ww = 2 * wo + (t & 1);
+            if (t >= (4 << pd)) break;
+            int dd = (d_o << pd) + (t >> 2), hh = 2 * ho + ((t >> 1) & 1), ww = 2 * wo + (t & 1);
             float xv[VEC];
             ldv<T, VEC>(x + ((((int64_t)n * D + dd) * H + hh) * W + ww) * C + cg * VEC, xv);
 #pragma unroll
@@ -51,8 +52,8 @@ __global__ void k_maxpool_fwd(const T* __restrict__ x, T* __restrict__ y, int N,
 // (d,h,w) scan order, add the skip gradient, apply the producer's ReLU mask, write all 8 children.
 template <typename T, int VEC>
 __global__ void k_maxpool_bwd(const T* __restrict__ x, const T* __restrict__ dy, const T* __restrict__ add, int add_ld,
-                              int add_off, T* __restrict__ dx, int N, int D, int H, int W, int C, int relu_mask) {
-    const int Do = D >> 1, Ho = H >> 1, Wo = W >> 1, CG = C / VEC;
+                              int add_off, T* __restrict__ dx, int N, int D, int H, int W, int C, int relu_mask, int pd) {
+    const int Do = D >> pd, Ho = H >> 1, Wo = W >> 1, CG = C / VEC;
     const int64_t total = (int64_t)N * Do * Ho * Wo * CG;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         int cg = (int)(i % CG), n, d_o, ho, wo;
@@ -61,9 +62,11 @@ __global__ void k_maxpool_bwd(const T* __restrict__ x, const T* __restrict__ dy,
         int64_t off[8];
 #pragma unroll
         for (int k = 0; k < VEC; ++k) m[k] = -INFINITY;
+        const int nt = 4 << pd;
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
-            int dd = 2 * d_o + (t >> 2), hh = 2 * ho + ((t >> 1) & 1), ww = 2 * wo + (t & 1);
+            if (t >= nt) break;
+            int dd = (d_o << pd) + (t >> 2), hh = 2 * ho + ((t >> 1) & 1), ww = 2 * wo + (t & 1);
             off[t] = (((int64_t)n * D + dd) * H + hh) * W + ww;
             ldv<T, VEC>(x + off[t] * C + cg * VEC, xv[t]);
 #pragma unroll
@@ -75,6 +78,7 @@ __global__ void k_maxpool_bwd(const T* __restrict__ x, const T* __restrict__ dy,
         for (int k = 0; k < VEC; ++k) taken[k] = false;
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
+            if (t >= nt) break;
             float r[VEC], a[VEC];
             if (add) ldv<T, VEC>(add + off[t] * add_ld + add_off + cg * VEC, a);
 #pragma unroll
@@ -90,32 +94,34 @@ __global__ void k_maxpool_bwd(const T* __restrict__ x, const T* __restrict__ dy,
     }
 }
 
-extern "C" int fmri_maxpool3d_2x_fwd(const void* x, void* y, int N, int D, int H, int W, int C, int dtype,
+extern "C" int fmri_maxpool3d_2x_fwd(const void* x, void* y, int N, int D, int H, int W, int C, int dtype, int planar,
                                      fmri_stream_t stream) {
-    if (N <= 0 || C <= 0 || D < 2 || (H & 1) || (W & 1) || (D & 1)) return FMRI_E_SHAPE;
+    const int pd = planar ? 0 : 1;
+    if (N <= 0 || C <= 0 || D < 1 || (H & 1) || (W & 1) || (pd && (D & 1))) return FMRI_E_SHAPE;
     int vec = pick_vec(C);
-    int grid = grid_for((int64_t)N * (D / 2) * (H / 2) * (W / 2) * (C / vec));
+    int grid = grid_for((int64_t)N * (D >> pd) * (H / 2) * (W / 2) * (C / vec));
     hipStream_t s = as_stream(stream);
-    if (dtype == FMRI_F32) LAUNCH_TV(k_maxpool_fwd, float, vec, grid, 256, s, (const float*)x, (float*)y, N, D, H, W, C);
-    else if (dtype == FMRI_BF16) LAUNCH_TV(k_maxpool_fwd, bf16_t, vec, grid, 256, s, (const bf16_t*)x, (bf16_t*)y, N, D, H, W, C);
+    if (dtype == FMRI_F32) LAUNCH_TV(k_maxpool_fwd, float, vec, grid, 256, s, (const float*)x, (float*)y, N, D, H, W, C, pd);
+    else if (dtype == FMRI_BF16) LAUNCH_TV(k_maxpool_fwd, bf16_t, vec, grid, 256, s, (const bf16_t*)x, (bf16_t*)y, N, D, H, W, C, pd);
     else return FMRI_E_DTYPE;
     FMRI_LAUNCH_CHECK();
     return FMRI_OK;
 }
 
 extern "C" int fmri_maxpool3d_2x_bwd(const void* x, const void* dy, const void* add, int add_ld, int add_off, void* dx,
-                                     int N, int D, int H, int W, int C, int relu_mask, int dtype, fmri_stream_t stream) {
-    if (N <= 0 || C <= 0 || D < 2 || (H & 1) || (W & 1) || (D & 1)) return FMRI_E_SHAPE;
+                                     int N, int D, int H, int W, int C, int relu_mask, int dtype, int planar, fmri_stream_t stream) {
+    const int pd = planar ? 0 : 1;
+    if (N <= 0 || C <= 0 || D < 1 || (H & 1) || (W & 1) || (pd && (D & 1))) return FMRI_E_SHAPE;
     int vec = pick_vec(C);
     if (add) { while (vec > 1 && ((add_ld % vec) || (add_off % vec))) vec >>= 1; }
-    int grid = grid_for((int64_t)N * (D / 2) * (H / 2) * (W / 2) * (C / vec));
+    int grid = grid_for((int64_t)N * (D >> pd) * (H / 2) * (W / 2) * (C / vec));
     hipStream_t s = as_stream(stream);
     if (dtype == FMRI_F32)
         LAUNCH_TV(k_maxpool_bwd, float, vec, grid, 256, s, (const float*)x, (const float*)dy, (const float*)add, add_ld,
-                  add_off, (float*)dx, N, D, H, W, C, relu_mask);
+                  add_off, (float*)dx, N, D, H, W, C, relu_mask, pd);
     else if (dtype == FMRI_BF16)
         LAUNCH_TV(k_maxpool_bwd, bf16_t, vec, grid, 256, s, (const bf16_t*)x, (const bf16_t*)dy, (const bf16_t*)add, add_ld,
-                  add_off, (bf16_t*)dx, N, D, H, W, C, relu_mask);
+                  add_off, (bf16_t*)dx, N, D, H, W, C, relu_mask, pd);
     else return FMRI_E_DTYPE;
     FMRI_LAUNCH_CHECK();
     return FMRI_OK;
@@ -125,10 +131,10 @@ extern "C" int fmri_maxpool3d_2x_bwd(const void* x, const void* dy, const void* 
 // Reference: UpSampling3D(size=pool_size) at unet3d/unet.py:138.  D,H,W = low-resolution dims.
 template <typename T, int VEC>
 __global__ void k_upsample_fwd(const T* __restrict__ x, T* __restrict__ y, int y_ld, int y_off, int N, int D, int H, int W,
-                               int C) {
+                               int C, int pd) {
     const int CG = C / VEC;
     const int64_t total = (int64_t)N * D * H * W * CG;
-    const int D2 = 2 * D, H2 = 2 * H, W2 = 2 * W;
+    const int D2 = D << pd, H2 = 2 * H, W2 = 2 * W;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         int cg = (int)(i % CG), n, d, h, w;
         decode_vox(i / CG, D, H, W, n, d, h, w);
@@ -136,17 +142,18 @@ __global__ void k_upsample_fwd(const T* __restrict__ x, T* __restrict__ y, int y
         ldv<T, VEC>(x + (i / CG) * C + cg * VEC, v);
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
-            int64_t o = (((int64_t)n * D2 + 2 * d + (t >> 2)) * H2 + 2 * h + ((t >> 1) & 1)) * W2 + 2 * w + (t & 1);
+            if (t >= (4 << pd)) break;
+            int64_t o = (((int64_t)n * D2 + (d << pd) + (t >> 2)) * H2 + 2 * h + ((t >> 1) & 1)) * W2 + 2 * w + (t & 1);
             stv<T, VEC>(y + o * y_ld + y_off + cg * VEC, v);
         }
     }
 }
 template <typename T, int VEC>
 __global__ void k_upsample_bwd(const T* __restrict__ dy, int dy_ld, int dy_off, const T* __restrict__ xmask,
-                               T* __restrict__ dx, int N, int D, int H, int W, int C) {
+                               T* __restrict__ dx, int N, int D, int H, int W, int C, int pd) {
     const int CG = C / VEC;
     const int64_t total = (int64_t)N * D * H * W * CG;
-    const int D2 = 2 * D, H2 = 2 * H, W2 = 2 * W;
+    const int D2 = D << pd, H2 = 2 * H, W2 = 2 * W;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         int cg = (int)(i % CG), n, d, h, w;
         decode_vox(i / CG, D, H, W, n, d, h, w);
@@ -155,7 +162,8 @@ __global__ void k_upsample_bwd(const T* __restrict__ dy, int dy_ld, int dy_off, 
         for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
-            int64_t o = (((int64_t)n * D2 + 2 * d + (t >> 2)) * H2 + 2 * h + ((t >> 1) & 1)) * W2 + 2 * w + (t & 1);
+            if (t >= (4 << pd)) break;
+            int64_t o = (((int64_t)n * D2 + (d << pd) + (t >> 2)) * H2 + 2 * h + ((t >> 1) & 1)) * W2 + 2 * w + (t & 1);
             float g[VEC];
             ldv<T, VEC>(dy + o * dy_ld + dy_off + cg * VEC, g);
 #pragma unroll
@@ -172,29 +180,31 @@ __global__ void k_upsample_bwd(const T* __restrict__ dy, int dy_ld, int dy_off, 
 }
 
 extern "C" int fmri_upsample_nearest2x_fwd(const void* x, void* y, int y_ld, int y_off, int N, int D, int H, int W, int C,
-                                           int dtype, fmri_stream_t stream) {
+                                           int dtype, int planar, fmri_stream_t stream) {
+    const int pd = planar ? 0 : 1;
     if (N <= 0 || C <= 0 || D <= 0 || H <= 0 || W <= 0 || y_ld < y_off + C) return FMRI_E_SHAPE;
     int vec = pick_vec(C);
     while (vec > 1 && ((y_ld % vec) || (y_off % vec))) vec >>= 1;
     int grid = grid_for((int64_t)N * D * H * W * (C / vec));
     hipStream_t s = as_stream(stream);
-    if (dtype == FMRI_F32) LAUNCH_TV(k_upsample_fwd, float, vec, grid, 256, s, (const float*)x, (float*)y, y_ld, y_off, N, D, H, W, C);
-    else if (dtype == FMRI_BF16) LAUNCH_TV(k_upsample_fwd, bf16_t, vec, grid, 256, s, (const bf16_t*)x, (bf16_t*)y, y_ld, y_off, N, D, H, W, C);
+    if (dtype == FMRI_F32) LAUNCH_TV(k_upsample_fwd, float, vec, grid, 256, s, (const float*)x, (float*)y, y_ld, y_off, N, D, H, W, C, pd);
+    else if (dtype == FMRI_BF16) LAUNCH_TV(k_upsample_fwd, bf16_t, vec, grid, 256, s, (const bf16_t*)x, (bf16_t*)y, y_ld, y_off, N, D, H, W, C, pd);
     else return FMRI_E_DTYPE;
     FMRI_LAUNCH_CHECK();
     return FMRI_OK;
 }
 extern "C" int fmri_upsample_nearest2x_bwd(const void* dy, int dy_ld, int dy_off, const void* xmask, void* dx, int N, int D,
-                                           int H, int W, int C, int dtype, fmri_stream_t stream) {
+                                           int H, int W, int C, int dtype, int planar, fmri_stream_t stream) {
+    const int pd = planar ? 0 : 1;
     if (N <= 0 || C <= 0 || D <= 0 || H <= 0 || W <= 0 || dy_ld < dy_off + C) return FMRI_E_SHAPE;
     int vec = pick_vec(C);
     while (vec > 1 && ((dy_ld % vec) || (dy_off % vec))) vec >>= 1;
     int grid = grid_for((int64_t)N * D * H * W * (C / vec));
     hipStream_t s = as_stream(stream);
     if (dtype == FMRI_F32)
-        LAUNCH_TV(k_upsample_bwd, float, vec, grid, 256, s, (const float*)dy, dy_ld, dy_off, (const float*)xmask, (float*)dx, N, D, H, W, C);
+        LAUNCH_TV(k_upsample_bwd, float, vec, grid, 256, s, (const float*)dy, dy_ld, dy_off, (const float*)xmask, (float*)dx, N, D, H, W, C, pd);
     else if (dtype == FMRI_BF16)
-        LAUNCH_TV(k_upsample_bwd, bf16_t, vec, grid, 256, s, (const bf16_t*)dy, dy_ld, dy_off, (const bf16_t*)xmask, (bf16_t*)dx, N, D, H, W, C);
+        LAUNCH_TV(k_upsample_bwd, bf16_t, vec, grid, 256, s, (const bf16_t*)dy, dy_ld, dy_off, (const bf16_t*)xmask, (bf16_t*)dx, N, D, H, W, C, pd);
     else return FMRI_E_DTYPE;
     FMRI_LAUNCH_CHECK();
     return FMRI_OK;

@@ -348,8 +348,8 @@ class Model(object):
                 t = t.reshape(t.shape[0], *t.shape[2:], 1)
             else:
                 t = t.permute(0, 2, 3, 4, 1)
-        else:                                                # (N,X,Y,C) -> (N,1,X,Y,C)
-            t = t.unsqueeze(1)
+        else:                                                # (N,X,Y,C) -> (1,N,X,Y,C): the slices of the batch are the planar D axis
+            t = t.unsqueeze(0)
         return t.to(eng_dtype).contiguous()
 
     def _to_device_y(self, y):
@@ -361,11 +361,10 @@ class Model(object):
         return t.contiguous().reshape(-1)
 
     def _from_device_probs(self, eng, n):
-        p = eng.probs.reshape((n,) + tuple(eng.plan.level_dims(0)) + (eng.plan.n_labels,))
         if self._input_layout == "channels_first_3d":
-            p = p.permute(0, 4, 1, 2, 3)
-        else:
-            p = p[:, 0]
+            p = eng.probs.reshape((n,) + tuple(eng.plan.level_dims(0)) + (eng.plan.n_labels,)).permute(0, 4, 1, 2, 3)
+        else:                                                # (slices, X, Y, labels)
+            p = eng.probs.reshape((n,) + tuple(eng.plan.spatial) + (eng.plan.n_labels,))
         return p.float().cpu().numpy()
 
     def predict(self, x, batch_size=None, verbose=0):

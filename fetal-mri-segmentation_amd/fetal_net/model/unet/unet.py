@@ -43,8 +43,24 @@ def unet_model_2d(input_shape, pool_size=(2, 2), n_labels=1, initial_learning_ra
                           deconvolution=deconvolution, depth=depth, n_base_filters=n_base_filters,
                           batch_normalization=batch_normalization, activation_name=activation_name, loss_function=loss_function,
                           dropout_rate=dropout_rate)
-    model = Model(g.layers, None, "unet_model_2d", builder_kwargs, "channels_last_2d")
-    model._unsupported = "the 2-D execution path (BASELINE config 4) is scheduled after the 3-D path (SURVEY.md §8 row a13)"
+    if "compute_dtype" in kargs:
+        builder_kwargs["compute_dtype"] = kargs["compute_dtype"]
+    plan_args = dict(in_channels=input_shape[-1], spatial=input_shape[:2], depth=depth, n_base_filters=n_base_filters,
+                     n_labels=n_labels, ndim=2)
+    model = Model(g.layers, plan_args, "unet_model_2d", builder_kwargs, "channels_last_2d")
+    unsupported = []
+    if deconvolution:
+        unsupported.append("deconvolution=True (Conv2DTranspose kernels)")
+    if batch_normalization:
+        unsupported.append("batch_normalization=True")
+    if pool_size != (2, 2):
+        unsupported.append("pool_size != (2,2)")
+    if activation_name != "sigmoid":
+        unsupported.append("activation_name != 'sigmoid'")
+    if dropout_rate > 0:
+        unsupported.append("dropout_rate > 0 (SpatialDropout2D)")
+    if unsupported:
+        model._unsupported = ", ".join(unsupported)
     metrics = ['binary_accuracy', vod_coefficient]
     if loss_function != dice_coefficient_loss:
         metrics += [dice_coefficient]

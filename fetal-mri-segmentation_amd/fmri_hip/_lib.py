@@ -25,18 +25,18 @@ SIGNATURES = {
     "fmri_version": [],
     "fmri_error_string": [i32],
     "fmri_conv3d_uses_mfma": [i32] * 7,
-    "fmri_conv3d_fwd": [p, i32, i32, p, i32, p, p, p, p, i32, i32, i32, i32, i32, i32, f32, i32, i32, p],
-    "fmri_conv3d_dgrad": [p, i32, p, p, p, i32, i32, i32, i32, i32, i32, i32, p],
-    "fmri_conv3d_wgrad": [p, i32, i32, p, i32, p, p, p, i32, i32, i32, i32, i32, i32, i32, p],
+    "fmri_conv3d_fwd": [p, i32, i32, p, i32, p, p, p, p, i32, i32, i32, i32, i32, i32, f32, i32, i32, i32, p],
+    "fmri_conv3d_dgrad": [p, i32, p, p, p, i32, i32, i32, i32, i32, i32, i32, i32, p],
+    "fmri_conv3d_wgrad": [p, i32, i32, p, i32, p, p, p, i32, i32, i32, i32, i32, i32, i32, i32, p],
     "fmri_conv3d_pack_weights": [p, p, p, i32, i32, i32, p],
     "fmri_conv1x1_fwd": [p, p, p, p, i64, i32, i32, i32, p],
     "fmri_conv1x1_bwd": [p, p, p, p, p, p, i64, i32, i32, i32, i32, p],
     "fmri_sigmoid_dice_fwd": [p, p, p, p, i64, p],
     "fmri_sigmoid_dice_bwd": [p, p, p, p, i64, f32, f32, p],
-    "fmri_maxpool3d_2x_fwd": [p, p, i32, i32, i32, i32, i32, i32, p],
-    "fmri_maxpool3d_2x_bwd": [p, p, p, i32, i32, p, i32, i32, i32, i32, i32, i32, i32, p],
-    "fmri_upsample_nearest2x_fwd": [p, p, i32, i32, i32, i32, i32, i32, i32, i32, p],
-    "fmri_upsample_nearest2x_bwd": [p, i32, i32, p, p, i32, i32, i32, i32, i32, i32, p],
+    "fmri_maxpool3d_2x_fwd": [p, p, i32, i32, i32, i32, i32, i32, i32, p],
+    "fmri_maxpool3d_2x_bwd": [p, p, p, i32, i32, p, i32, i32, i32, i32, i32, i32, i32, i32, p],
+    "fmri_upsample_nearest2x_fwd": [p, p, i32, i32, i32, i32, i32, i32, i32, i32, i32, p],
+    "fmri_upsample_nearest2x_bwd": [p, i32, i32, p, p, i32, i32, i32, i32, i32, i32, i32, p],
     "fmri_adam_step": [p, p, p, p, i64, f32, f32, f32, f32, f32, p],
     "fmri_tile_gather": [p, i32, i32, i32, p, i32, i32, i32, i32, p, i32, p],
     "fmri_tile_scatter_accumulate": [p, p, i32, i32, i32, i32, i32, p, p, i32, i32, i32, p],

@@ -66,19 +66,19 @@ class UNetPlan:
             out += lv
         return out
 
-    def level_dims(self, level):
+    def level_dims(self, level, slices=1):
+        """(D,H,W) of the activations at `level`.  2-D plans are planar: D = number of slices in the batch, never pooled."""
         if self.ndim == 3:
             return tuple(s >> level for s in self.spatial)
-        return (1,) + tuple(s >> level for s in self.spatial)
+        return (slices,) + tuple(s >> level for s in self.spatial)
 
 
 class UNetEngine:
     def __init__(self, plan, batch, dtype=torch.bfloat16, device="cuda", seed=42, training=True, dist_ctx=None):
         from ._lib import lib
         lib()  # fail loudly if the HIP library is missing
-        if plan.ndim != 3:
-            raise NotImplementedError("2-D plans run as D == 1 volumes through UNetPlan(ndim=3 semantics) - see model builders")
         self.plan, self.N, self.dtype, self.dev, self.training = plan, batch, dtype, torch.device(device), training
+        self.planar = plan.ndim == 2      # 2-D: tensors are [1][slices][H][W][C], every op is planar (no coupling along D)
         self.dist = dist_ctx
         self.t = 0                       # Adam step counter
         self._bufsets = {}
@@ -136,11 +136,12 @@ class UNetEngine:
         """Keras defaults (glorot_uniform kernels, zero bias), drawn in Keras layer-creation order."""
         rs = np.random.RandomState(seed)
         W = OrderedDict()
+        k3, k1 = ((3, 3, 3), (1, 1, 1)) if self.plan.ndim == 3 else ((3, 3), (1, 1))
         for c in self.plan.convs_forward_order():
-            W[c["name"] + "/kernel"] = _glorot(rs, (3, 3, 3, c["cin"], c["cout"]))
+            W[c["name"] + "/kernel"] = _glorot(rs, k3 + (c["cin"], c["cout"]))
             W[c["name"] + "/bias"] = np.zeros(c["cout"], np.float32)
         f = self.plan.final
-        W[f["name"] + "/kernel"] = _glorot(rs, (1, 1, 1, f["cin"], f["cout"]))
+        W[f["name"] + "/kernel"] = _glorot(rs, k1 + (f["cin"], f["cout"]))
         W[f["name"] + "/bias"] = np.zeros(f["cout"], np.float32)
         self.load_keras_weights(W)
 
@@ -171,9 +172,11 @@ class UNetEngine:
             L = self.layout[name]
             o, n = L["w"]
             if L["kind"] == "conv":
-                W[name + "/kernel"] = host[o:o + n].reshape(3, 3, 3, L["cout"], L["cin"]).transpose(0, 1, 2, 4, 3).copy()
+                k = host[o:o + n].reshape(3, 3, 3, L["cout"], L["cin"]).transpose(0, 1, 2, 4, 3)
+                W[name + "/kernel"] = (k if self.plan.ndim == 3 else k[1]).copy()          # 2-D: the centre kd plane is the 3x3 kernel
             else:
-                W[name + "/kernel"] = host[o:o + n].reshape(L["cout"], L["cin"]).T.reshape(1, 1, 1, L["cin"], L["cout"]).copy()
+                k = host[o:o + n].reshape(L["cout"], L["cin"]).T
+                W[name + "/kernel"] = k.reshape(((1, 1, 1) if self.plan.ndim == 3 else (1, 1)) + (L["cin"], L["cout"])).copy()
             ob, nb = L["b"]
             W[name + "/bias"] = host[ob:ob + nb].copy()
         return W
@@ -196,18 +199,24 @@ class UNetEngine:
         self.N, self.act, self.grad, self.logits, self.probs, self.dlogits = N, b["act"], b["grad"], b["logits"], b["probs"], b["dlogits"]
         self._dummy_y = b["dummy_y"]       # per buffer set and never freed: captured hipGraphs keep raw pointers to it
 
+    def _dims(self, level):
+        """leading (N, D, H, W) of an activation at `level` for the current batch"""
+        if self.planar:
+            return (1,) + self.plan.level_dims(level, self.N)
+        return (self.N,) + self.plan.level_dims(level)
+
     def _build_buffers(self):
         p, N, dt, dev = self.plan, self.N, self.dtype, self.dev
         A = self.act = {}
         for lv in p.enc:
             for c in lv:
-                A[c["name"]] = torch.empty((N,) + p.level_dims(c["level"]) + (c["cout"],), dtype=dt, device=dev)
+                A[c["name"]] = torch.empty(self._dims(c["level"]) + (c["cout"],), dtype=dt, device=dev)
         for ld in range(p.depth - 1):
-            A["pool_%d" % ld] = torch.empty((N,) + p.level_dims(ld + 1) + (p.enc[ld][1]["cout"],), dtype=dt, device=dev)
+            A["pool_%d" % ld] = torch.empty(self._dims(ld + 1) + (p.enc[ld][1]["cout"],), dtype=dt, device=dev)
         for lv in p.dec:
             for c in lv:
-                A[c["name"]] = torch.empty((N,) + p.level_dims(c["level"]) + (c["cout"],), dtype=dt, device=dev)
-        nvox0 = N * int(np.prod(p.level_dims(0)))
+                A[c["name"]] = torch.empty(self._dims(c["level"]) + (c["cout"],), dtype=dt, device=dev)
+        nvox0 = int(np.prod(self._dims(0)))
         self.logits = torch.empty((nvox0, p.n_labels), dtype=torch.float32, device=dev)
         self.probs = torch.empty_like(self.logits)
         self.sums = torch.zeros(8, dtype=torch.float64, device=dev)
@@ -222,27 +231,27 @@ class UNetEngine:
                 Gd[name] = torch.empty_like(t)        # gradient w.r.t. the conv's pre-activation
         for lv in p.dec:
             a = lv[0]
-            Gd["cat_%d" % a["level"]] = torch.empty((N,) + p.level_dims(a["level"]) + (a["cin"],), dtype=dt, device=dev)
+            Gd["cat_%d" % a["level"]] = torch.empty(self._dims(a["level"]) + (a["cin"],), dtype=dt, device=dev)
         self.dlogits = torch.empty_like(self.logits)
 
     # ------------------------------------------------------------------------------------------------ forward
     def forward(self, x):
         """x: [N,D,H,W,Cin] compute dtype, device.  Leaves logits (fp32 [nvox, L]) in self.logits."""
         p, A = self.plan, self.act
-        assert tuple(x.shape) == (self.N,) + p.level_dims(0) + (p.in_channels,), (x.shape,)
+        assert tuple(x.shape) == self._dims(0) + (p.in_channels,), (x.shape,)
         self.x_in = x
         h = x
         for ld, lv in enumerate(p.enc):
             for c in lv:
-                ops.conv3d_fwd(h, None, self.Wf[c["name"]], self.b_view(c["name"]), A[c["name"]], act=ACT_RELU)
+                ops.conv3d_fwd(h, None, self.Wf[c["name"]], self.b_view(c["name"]), A[c["name"]], act=ACT_RELU, planar=self.planar)
                 h = A[c["name"]]
             if ld < p.depth - 1:
-                h = ops.maxpool_fwd(h, A["pool_%d" % ld])
+                h = ops.maxpool_fwd(h, A["pool_%d" % ld], planar=self.planar)
         for lv in p.dec:
             a, b = lv
             skip = A[p.enc[a["level"]][1]["name"]]
-            ops.conv3d_fwd(h, skip, self.Wf[a["name"]], self.b_view(a["name"]), A[a["name"]], up0=True, act=ACT_RELU)
-            ops.conv3d_fwd(A[a["name"]], None, self.Wf[b["name"]], self.b_view(b["name"]), A[b["name"]], act=ACT_RELU)
+            ops.conv3d_fwd(h, skip, self.Wf[a["name"]], self.b_view(a["name"]), A[a["name"]], up0=True, act=ACT_RELU, planar=self.planar)
+            ops.conv3d_fwd(A[a["name"]], None, self.Wf[b["name"]], self.b_view(b["name"]), A[b["name"]], act=ACT_RELU, planar=self.planar)
             h = A[b["name"]]
         f = p.final
         ops.conv1x1_fwd(h, self.w_view(f["name"]), self.b_view(f["name"]), self.logits)
@@ -278,17 +287,17 @@ class UNetEngine:
             a, b = lv
             ld = a["level"]
             # block b: input = A[a]
-            ops.conv3d_wgrad(A[a["name"]], None, Gd[b["name"]], self.w_view(b["name"], self.G), self.b_view(b["name"], self.G))
+            ops.conv3d_wgrad(A[a["name"]], None, Gd[b["name"]], self.w_view(b["name"], self.G), self.b_view(b["name"], self.G), planar=self.planar)
             self._grad_ready(b["name"])
-            ops.conv3d_dgrad(Gd[b["name"]], self.Wd[b["name"]], Gd[a["name"]], mask=A[a["name"]])
+            ops.conv3d_dgrad(Gd[b["name"]], self.Wd[b["name"]], Gd[a["name"]], mask=A[a["name"]], planar=self.planar)
             # block a: input = [up(low) | skip]
             low = self._dec_input_name(ld)
             skip = A[p.enc[ld][1]["name"]]
-            ops.conv3d_wgrad(A[low], skip, Gd[a["name"]], self.w_view(a["name"], self.G), self.b_view(a["name"], self.G), up0=True)
+            ops.conv3d_wgrad(A[low], skip, Gd[a["name"]], self.w_view(a["name"], self.G), self.b_view(a["name"], self.G), up0=True, planar=self.planar)
             self._grad_ready(a["name"])
             cat = Gd["cat_%d" % ld]
-            ops.conv3d_dgrad(Gd[a["name"]], self.Wd[a["name"]], cat)
-            ops.upsample_bwd(cat, Gd[low], dy_off=0, xmask=A[low])
+            ops.conv3d_dgrad(Gd[a["name"]], self.Wd[a["name"]], cat, planar=self.planar)
+            ops.upsample_bwd(cat, Gd[low], dy_off=0, xmask=A[low], planar=self.planar)
         # encoder, deepest level first
         for ld in range(p.depth - 1, -1, -1):
             ca, cb = p.enc[ld]
@@ -296,15 +305,16 @@ class UNetEngine:
                 # gradient of enc[ld].b output = pooled path + skip path, masked by its ReLU
                 cat = Gd["cat_%d" % ld]
                 ops.maxpool_bwd(A[cb["name"]], Gd["pool_%d" % ld], Gd[cb["name"]], add=cat, add_off=cat.shape[-1] - cb["cout"],
-                                relu_mask=True)
-            ops.conv3d_wgrad(A[ca["name"]], None, Gd[cb["name"]], self.w_view(cb["name"], self.G), self.b_view(cb["name"], self.G))
+                                relu_mask=True, planar=self.planar)
+            ops.conv3d_wgrad(A[ca["name"]], None, Gd[cb["name"]], self.w_view(cb["name"], self.G), self.b_view(cb["name"], self.G),
+                             planar=self.planar)
             self._grad_ready(cb["name"])
-            ops.conv3d_dgrad(Gd[cb["name"]], self.Wd[cb["name"]], Gd[ca["name"]], mask=A[ca["name"]])
+            ops.conv3d_dgrad(Gd[cb["name"]], self.Wd[cb["name"]], Gd[ca["name"]], mask=A[ca["name"]], planar=self.planar)
             xin = self.x_in if ld == 0 else A["pool_%d" % (ld - 1)]
-            ops.conv3d_wgrad(xin, None, Gd[ca["name"]], self.w_view(ca["name"], self.G), self.b_view(ca["name"], self.G))
+            ops.conv3d_wgrad(xin, None, Gd[ca["name"]], self.w_view(ca["name"], self.G), self.b_view(ca["name"], self.G), planar=self.planar)
             self._grad_ready(ca["name"])
             if ld > 0:
-                ops.conv3d_dgrad(Gd[ca["name"]], self.Wd[ca["name"]], Gd["pool_%d" % (ld - 1)])
+                ops.conv3d_dgrad(Gd[ca["name"]], self.Wd[ca["name"]], Gd["pool_%d" % (ld - 1)], planar=self.planar)
         if self.dist is not None:
             self.dist.finish(self)
 

@@ -28,7 +28,7 @@ def _need_cuda(*ts):
             raise RuntimeError("fmri_hip ops need contiguous tensors")
 
 
-def conv3d_fwd(src0, src1, w, bias, y, up0=False, act=ACT_RELU, alpha=0.0, mask=None, impl=IMPL_AUTO):
+def conv3d_fwd(src0, src1, w, bias, y, up0=False, act=ACT_RELU, alpha=0.0, mask=None, impl=IMPL_AUTO, planar=False):
     """src0 [N,d,h,w,C0] (half-res when up0), src1 [N,D,H,W,C1] or None, w [27,Cout,C0+C1], y [N,D,H,W,Cout]."""
     _need_cuda(src0, src1, w, bias, y, mask)
     N, D, H, W, Cout = y.shape
@@ -36,28 +36,28 @@ def conv3d_fwd(src0, src1, w, bias, y, up0=False, act=ACT_RELU, alpha=0.0, mask=
     C1 = 0 if src1 is None else src1.shape[-1]
     assert w.shape == (27, Cout, C0 + C1), (w.shape, Cout, C0, C1)
     check(lib().fmri_conv3d_fwd(_p(src0), C0, int(up0), _p(src1), C1, _p(w), _p(bias), _p(mask), _p(y), N, D, H, W, Cout,
-                                act, float(alpha), dt(y), impl, _s()), "fmri_conv3d_fwd")
+                                act, float(alpha), dt(y), impl, int(planar), _s()), "fmri_conv3d_fwd")
     return y
 
 
-def conv3d_dgrad(dy, w_dgrad, dx, mask=None, impl=IMPL_AUTO):
+def conv3d_dgrad(dy, w_dgrad, dx, mask=None, impl=IMPL_AUTO, planar=False):
     _need_cuda(dy, w_dgrad, dx, mask)
     N, D, H, W, Cin = dx.shape
     Cout = dy.shape[-1]
     assert w_dgrad.shape == (27, Cin, Cout)
-    check(lib().fmri_conv3d_dgrad(_p(dy), Cout, _p(w_dgrad), _p(mask), _p(dx), N, D, H, W, Cin, dt(dx), impl, _s()),
+    check(lib().fmri_conv3d_dgrad(_p(dy), Cout, _p(w_dgrad), _p(mask), _p(dx), N, D, H, W, Cin, dt(dx), impl, int(planar), _s()),
           "fmri_conv3d_dgrad")
     return dx
 
 
-def conv3d_wgrad(src0, src1, dy, dw, db, up0=False, impl=IMPL_AUTO):
+def conv3d_wgrad(src0, src1, dy, dw, db, up0=False, impl=IMPL_AUTO, planar=False):
     _need_cuda(src0, src1, dy, dw, db)
     N, D, H, W, Cout = dy.shape
     C0 = src0.shape[-1]
     C1 = 0 if src1 is None else src1.shape[-1]
     assert dw.dtype == torch.float32 and dw.numel() == 27 * Cout * (C0 + C1)
     check(lib().fmri_conv3d_wgrad(_p(src0), C0, int(up0), _p(src1), C1, _p(dy), _p(dw), _p(db), N, D, H, W, Cout, dt(dy),
-                                  impl, _s()), "fmri_conv3d_wgrad")
+                                  impl, int(planar), _s()), "fmri_conv3d_wgrad")
 
 
 def pack_weights(w, w_fwd, w_dgrad):
@@ -97,34 +97,34 @@ def sigmoid_dice_bwd(probs, y_true, sums, dlogits, smooth=1.0, grad_scale=1.0):
                                       float(grad_scale), _s()), "fmri_sigmoid_dice_bwd")
 
 
-def maxpool_fwd(x, y):
+def maxpool_fwd(x, y, planar=False):
     _need_cuda(x, y)
     N, D, H, W, Cc = x.shape
-    check(lib().fmri_maxpool3d_2x_fwd(_p(x), _p(y), N, D, H, W, Cc, dt(x), _s()), "fmri_maxpool3d_2x_fwd")
+    check(lib().fmri_maxpool3d_2x_fwd(_p(x), _p(y), N, D, H, W, Cc, dt(x), int(planar), _s()), "fmri_maxpool3d_2x_fwd")
     return y
 
 
-def maxpool_bwd(x, dy, dx, add=None, add_off=0, relu_mask=True):
+def maxpool_bwd(x, dy, dx, add=None, add_off=0, relu_mask=True, planar=False):
     _need_cuda(x, dy, dx, add)
     N, D, H, W, Cc = x.shape
     add_ld = 0 if add is None else add.shape[-1]
-    check(lib().fmri_maxpool3d_2x_bwd(_p(x), _p(dy), _p(add), add_ld, add_off, _p(dx), N, D, H, W, Cc, int(relu_mask), dt(x), _s()),
+    check(lib().fmri_maxpool3d_2x_bwd(_p(x), _p(dy), _p(add), add_ld, add_off, _p(dx), N, D, H, W, Cc, int(relu_mask), dt(x), int(planar), _s()),
           "fmri_maxpool3d_2x_bwd")
     return dx
 
 
-def upsample_fwd(x, y, y_off=0):
+def upsample_fwd(x, y, y_off=0, planar=False):
     _need_cuda(x, y)
     N, D, H, W, Cc = x.shape
-    check(lib().fmri_upsample_nearest2x_fwd(_p(x), _p(y), y.shape[-1], y_off, N, D, H, W, Cc, dt(x), _s()),
+    check(lib().fmri_upsample_nearest2x_fwd(_p(x), _p(y), y.shape[-1], y_off, N, D, H, W, Cc, dt(x), int(planar), _s()),
           "fmri_upsample_nearest2x_fwd")
     return y
 
 
-def upsample_bwd(dy, dx, dy_off=0, xmask=None):
+def upsample_bwd(dy, dx, dy_off=0, xmask=None, planar=False):
     _need_cuda(dy, dx, xmask)
     N, D, H, W, Cc = dx.shape
-    check(lib().fmri_upsample_nearest2x_bwd(_p(dy), dy.shape[-1], dy_off, _p(xmask), _p(dx), N, D, H, W, Cc, dt(dx), _s()),
+    check(lib().fmri_upsample_nearest2x_bwd(_p(dy), dy.shape[-1], dy_off, _p(xmask), _p(dx), N, D, H, W, Cc, dt(dx), int(planar), _s()),
           "fmri_upsample_nearest2x_bwd")
     return dx
 

@@ -10,7 +10,9 @@
  *   - extern "C", int return: FMRI_OK or a negative FMRI_E_* code; no exceptions, no allocation, no host sync.
  *   - every call only ENQUEUES work on the caller's HIP stream (`stream` = hipStream_t, may be NULL = default stream).
  *   - all pointers are caller-owned DEVICE pointers unless stated otherwise.
- *   - activations are channels-last: [N][D][H][W][C] ("NDHWC"); a 2-D slice batch is D == 1.
+ *   - activations are channels-last: [N][D][H][W][C] ("NDHWC").  `planar` != 0 selects the 2-D slice semantics of the
+ *     reference's 2-D builders (fetal_net/model/unet/unet.py): D indexes independent slices — convolutions use only the
+ *     centre kd plane of the 3x3x3 filter (a 3x3 Conv2D), pooling / up-sampling act on (H, W) only.
  *   - dtype = FMRI_F32 (parity mode, plain fp32 arithmetic) or FMRI_BF16 (bf16 storage, fp32 accumulate; MFMA path
  *     when channel counts are multiples of 32 and the spatial tile divides, generic VALU path otherwise).
  *   - 3x3x3 filters are stored [27 taps = kd*9+kh*3+kw][Cout][Cin] (Cin contiguous).  Keras' (kD,kH,kW,Cin,Cout)
@@ -48,18 +50,18 @@ int fmri_conv3d_uses_mfma(int C0, int C1, int Cout, int D, int H, int W, int dty
  * kernel runs as Conv3DBackpropInput. */
 int fmri_conv3d_fwd(const void* src0, int C0, int up0, const void* src1, int C1, const void* w, const float* bias,
                     const void* mask, void* y, int N, int D, int H, int W, int Cout, int act, float alpha, int dtype,
-                    int impl, fmri_stream_t stream);
+                    int impl, int planar, fmri_stream_t stream);
 
 /* ---- Conv3DBackpropInputV2 (autodiff of unet.py:102): dx = conv(dy, w_dgrad) * (mask > 0).
  * w_dgrad [27][Cin][Cout] is the tap-flipped, transposed copy made by fmri_conv3d_pack_weights. */
 int fmri_conv3d_dgrad(const void* dy, int Cout, const void* w_dgrad, const void* mask, void* dx, int N, int D, int H,
-                      int W, int Cin, int dtype, int impl, fmri_stream_t stream);
+                      int W, int Cin, int dtype, int impl, int planar, fmri_stream_t stream);
 
 /* ---- Conv3DBackpropFilterV2 + BiasAddGrad: dw[27][Cout][C0+C1] (fp32) += sum_v x[v+tap][ci]*dy[v][co];
  * db[Cout] (fp32) += sum_v dy[v][co] (db may be NULL).  ACCUMULATES: the caller zeroes dw/db once per step.
  * Same dual-source / fused-upsample input description as fmri_conv3d_fwd. */
 int fmri_conv3d_wgrad(const void* src0, int C0, int up0, const void* src1, int C1, const void* dy, float* dw, float* db,
-                      int N, int D, int H, int W, int Cout, int dtype, int impl, fmri_stream_t stream);
+                      int N, int D, int H, int W, int Cout, int dtype, int impl, int planar, fmri_stream_t stream);
 
 /* fp32 master filter [27][Cout][Cin] -> w_fwd (dtype, same layout) and w_dgrad (dtype, [26-tap][Cin][Cout]).
  * Either destination may be NULL. */
@@ -85,19 +87,20 @@ int fmri_sigmoid_dice_bwd(const float* probs, const uint8_t* y_true, const doubl
                           float smooth, float grad_scale, fmri_stream_t stream);
 
 /* ---- MaxPooling3D(2,2,2) — reference unet.py:51.  D,H,W are the INPUT dims (even). */
-int fmri_maxpool3d_2x_fwd(const void* x, void* y, int N, int D, int H, int W, int C, int dtype, fmri_stream_t stream);
+int fmri_maxpool3d_2x_fwd(const void* x, void* y, int N, int D, int H, int W, int C, int dtype, int planar,
+                          fmri_stream_t stream);
 /* MaxPool3DGrad fused with the skip-gradient add and the ReluGrad of the producer:
  *   dx[v][c] = ( (add ? add[v*add_ld + add_off + c] : 0) + (x[v][c] is the first max of its window ? dy[win][c] : 0) ) * (x>0 || !relu_mask) */
 int fmri_maxpool3d_2x_bwd(const void* x, const void* dy, const void* add, int add_ld, int add_off, void* dx, int N,
-                          int D, int H, int W, int C, int relu_mask, int dtype, fmri_stream_t stream);
+                          int D, int H, int W, int C, int relu_mask, int dtype, int planar, fmri_stream_t stream);
 
 /* ---- UpSampling3D(2) — reference unet.py:138.  Materialising forward (writes channel slice [y_off, y_off+C) of a
  * tensor with y_ld channels); D,H,W are the LOW-resolution dims.  The conv kernels do not need it (fused). */
 int fmri_upsample_nearest2x_fwd(const void* x, void* y, int y_ld, int y_off, int N, int D, int H, int W, int C, int dtype,
-                                fmri_stream_t stream);
+                                int planar, fmri_stream_t stream);
 /* backward: dx[v][c] = (sum over the 2x2x2 children of dy[child*dy_ld + dy_off + c]) * (xmask[v][c] > 0 || !xmask) */
 int fmri_upsample_nearest2x_bwd(const void* dy, int dy_ld, int dy_off, const void* xmask, void* dx, int N, int D, int H,
-                                int W, int C, int dtype, fmri_stream_t stream);
+                                int W, int C, int dtype, int planar, fmri_stream_t stream);
 
 /* ---- Keras Adam.get_updates — reference unet.py:85.  lr_t = lr*sqrt(1-b2^t)/(1-b1^t) is computed by the host.
  * g is multiplied by grad_scale first.  p -= lr_t * m/(sqrt(v)+eps). One launch over the flat parameter buffer. */

@@ -18,20 +18,29 @@ def keras_kernel_from_packed(w):
     return w.reshape(3, 3, 3, Cout, Cin).permute(3, 4, 0, 1, 2).contiguous()
 
 
-def ref_concat_input(src0, src1, up0):
+def ref_concat_input(src0, src1, up0, planar=False):
     """NDHWC cpu fp64 tensors -> NCDHW concat (up first)"""
     a = to_ncdhw(src0)
     if up0:
-        for ax in (2, 3, 4):
+        for ax in ((3, 4) if planar else (2, 3, 4)):
             a = torch.repeat_interleave(a, 2, dim=ax)
     if src1 is not None:
         a = torch.cat([a, to_ncdhw(src1)], dim=1)
     return a
 
 
-def ref_conv_fwd(src0, src1, up0, w, bias, act):
-    x = ref_concat_input(src0, src1, up0)
-    y = F.conv3d(x, keras_kernel_from_packed(w), bias, padding=1)
+def planar_kernel(k):
+    """zero the kd != 1 planes of a torch conv weight (Cout,Cin,3,3,3): the 2-D slice semantics"""
+    k = k.clone()
+    k[:, :, 0] = 0
+    k[:, :, 2] = 0
+    return k
+
+
+def ref_conv_fwd(src0, src1, up0, w, bias, act, planar=False):
+    x = ref_concat_input(src0, src1, up0, planar)
+    k = keras_kernel_from_packed(w)
+    y = F.conv3d(x, planar_kernel(k) if planar else k, bias, padding=1)
     if act == 1:
         y = F.relu(y)
     return to_ndhwc(y)

@@ -124,3 +124,42 @@ def test_training_loss_decreases_bf16():
         s = eng.train_step(xd, yd, 1e-3)
         losses.append(eng.metrics_from_sums(s.cpu().numpy())["loss"])
     assert losses[-1] < losses[0] - 0.02, losses
+
+
+def test_unet2d_fp32_and_bf16_vs_oracle():
+    """2-D twin (reference model/unet/unet.py:22-88): channels-last (N,X,Y,C) slices, planar kernels."""
+    from fmri_hip.engine import UNetEngine, UNetPlan
+    from oracle import unet_oracle as O
+    N, X, Y, C = 4, 32, 64, 5
+    for dtype, base, tol_l, tol_d, tol_g in ((torch.float32, 8, 1e-3, 1e-4, 2e-3), (torch.bfloat16, 32, 3e-2, 2e-3, 1e-1)):   # bf16: first-layer gradient passes through 13 bf16-stored tensors
+        spec = O.Spec((X, Y, C), ndim=2, depth=3, n_base_filters=base)
+        W = spec.init_weights(11)
+        rs = np.random.RandomState(3)
+        x = rs.randn(N, X, Y, C).astype(np.float32)
+        y = (rs.rand(N, X, Y, 1) > 0.7).astype(np.uint8)
+        ref = O.loss_and_grads(spec, W, x, y, dtype=torch.float64 if dtype == torch.float32 else torch.float32)
+        eng = UNetEngine(UNetPlan(C, (X, Y), depth=3, n_base_filters=base, ndim=2), N, dtype=dtype)
+        eng.load_keras_weights(W)
+        xd = torch.from_numpy(x).cuda().to(dtype).unsqueeze(0).contiguous()
+        yd = torch.from_numpy(y).cuda().reshape(-1).contiguous()
+        eng.forward(xd)
+        sums = eng.loss_forward(yd)
+        eng.backward(yd)
+        torch.cuda.synchronize()
+        logits = eng.logits.cpu().numpy().reshape(ref["logits"].shape)
+        assert _rel(logits, ref["logits"]) <= tol_l, dtype
+        assert abs(eng.metrics_from_sums(sums.cpu().numpy())["dice_coefficient"] - ref["dice"]) <= tol_d
+        Wg = {}
+        for name, L in eng.layout.items():
+            gk = ref["grads"][name + "/kernel"]
+            if L["kind"] == "conv":
+                mine = eng.w_view(name, eng.G).cpu().numpy().reshape(3, 3, 3, L["cout"], L["cin"]).transpose(0, 1, 2, 4, 3)
+                assert float(np.abs(mine[0]).max()) == 0 and float(np.abs(mine[2]).max()) == 0     # dead kd planes stay untouched
+                mine = mine[1]
+            else:
+                mine = eng.w_view(name, eng.G).cpu().numpy().T.reshape(gk.shape)
+            e = np.linalg.norm(mine.astype(np.float64) - gk) / (np.linalg.norm(gk) + 1e-30)
+            assert e <= tol_g, (str(dtype), name, e)
+        Wx = eng.export_keras_weights()
+        for k in W:
+            assert Wx[k].shape == W[k].shape

@@ -116,3 +116,42 @@ def test_run_validation_case_writes_reference_files(tmp_path, monkeypatch):
     assert pred.shape == (24, 48, 32) and np.isfinite(pred).all() and 0 <= pred.min() and pred.max() <= 1
     d = M.hard_dice(DataFile.root.truth[0], pred > 0.5)      # reference fetal/evaluate.py:13-17 (value itself is arbitrary here)
     assert 0.0 <= d <= 1.0
+
+
+def test_unet_model_2d_train_and_slice_wise_prediction(monkeypatch):
+    """BASELINE config-4 style 2-D model through the same surface: fit_generator + patch_wise_prediction (prediction_shape (X,Y,1))."""
+    monkeypatch.setenv("FMRI_DTYPE", "fp32")
+    import fetal_net.model as fmodel
+    from fetal_net.prediction import patch_wise_prediction
+    from oracle import tiler_oracle, unet_oracle as O
+    X, Y, C = 16, 32, 5
+    model = fmodel.unet_model_2d(input_shape=(X, Y, C), depth=2, n_base_filters=8, initial_learning_rate=1e-2)
+    spec = O.Spec((X, Y, C), ndim=2, depth=2, n_base_filters=8)
+    W = spec.init_weights(5)
+    model.set_weights_dict(W)
+    rs = np.random.RandomState(1)
+
+    def gen():
+        while True:
+            x = rs.randn(4, X, Y, C)
+            yield x, (x[..., 2:3] > 0.3).astype(np.uint8)
+
+    x0 = rs.randn(3, X, Y, C)
+    p = model.predict(x0)
+    _, pr = O.forward(spec, O.to_torch(W, torch.float64), torch.tensor(x0))
+    assert p.shape == (3, X, Y, 1)
+    np.testing.assert_allclose(p, pr.numpy(), atol=2e-5)
+
+    class OracleModel:
+        output_shape = (None, X, Y, 1)
+
+        def predict(self, x):
+            return O.forward(spec, O.to_torch(W, torch.float64), torch.tensor(np.asarray(x, np.float64)))[1].numpy()
+
+    data = rs.randn(1, 24, 40, 7)
+    out = patch_wise_prediction(model=model, data=data, patch_shape=(X, Y, C), overlap_factor=0.3, batch_size=6)
+    ref = tiler_oracle.patch_wise_prediction(OracleModel(), data, (X, Y, C), 0.3, 6)
+    assert out.shape == ref.shape == (24, 40, 7, 1)
+    np.testing.assert_allclose(out, ref, atol=3e-5)
+    h = model.fit_generator(gen(), steps_per_epoch=8, epochs=3, verbose=0).history
+    assert h["loss"][-1] < h["loss"][0]

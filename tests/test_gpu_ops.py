@@ -9,7 +9,8 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from gpu_util import (assert_close, f64, keras_kernel_from_packed, ref_concat_input, ref_conv_fwd, rnd, to_ncdhw, to_ndhwc)
+from gpu_util import (assert_close, f64, keras_kernel_from_packed, planar_kernel, ref_concat_input, ref_conv_fwd, rnd, to_ncdhw,
+                      to_ndhwc)
 
 pytestmark = pytest.mark.gpu
 
@@ -249,3 +250,82 @@ def test_tiles(ops):
     np.testing.assert_allclose(acc.cpu().numpy(), ra, atol=1e-12)
     assert np.array_equal(cnt.cpu().numpy(), rc)
     assert int(bad.item()) == int((rc == 0).sum())
+
+
+# ------------------------------------------------------------------------------------------------ planar (2-D slice) semantics
+PLANAR_CASES = [
+    # name, dtype, slices, H, W, C0, up0, C1, Cout, impl
+    ("planar_generic_f32", torch.float32, 3, 8, 16, 5, False, 0, 6, 1),
+    ("planar_generic_dual_up_f32", torch.float32, 2, 8, 16, 4, True, 3, 5, 1),
+    ("planar_mfma", torch.bfloat16, 8, 16, 32, 64, False, 0, 64, 2),
+    ("planar_mfma_dual_up", torch.bfloat16, 4, 16, 32, 64, True, 32, 64, 2),
+    ("planar_mfma_32", torch.bfloat16, 4, 8, 16, 32, False, 0, 32, 2),
+]
+
+
+@pytest.mark.parametrize("case", PLANAR_CASES, ids=[c[0] for c in PLANAR_CASES])
+def test_planar_conv_fwd_dgrad_wgrad(ops, case):
+    name, dtype, S, H, W, C0, up0, C1, Cout, impl = case
+    s0 = (1, S, H // 2, W // 2, C0) if up0 else (1, S, H, W, C0)
+    src0 = rnd(s0, 1, dtype)
+    src1 = rnd((1, S, H, W, C1), 2, dtype) if C1 else None
+    w = rnd((27, Cout, C0 + C1), 3, dtype, scale=0.2)
+    bias = rnd((Cout,), 4, torch.float32)
+    y = torch.full((1, S, H, W, Cout), float("nan"), dtype=dtype, device="cuda")
+    ops.conv3d_fwd(src0, src1, w, bias, y, up0=up0, act=1, impl=impl, planar=True)
+    torch.cuda.synchronize()
+    ref = ref_conv_fwd(f64(src0), None if src1 is None else f64(src1), up0, f64(w), f64(bias), 1, planar=True)
+    assert_close(y, ref, *TOL[dtype], what=name + " fwd")
+    # weight gradient: only the centre kd plane exists
+    if not (impl == 2 and Cout % 64):
+        dy = rnd((1, S, H, W, Cout), 11, dtype)
+        dw = torch.zeros((27, Cout, C0 + C1), dtype=torch.float32, device="cuda")
+        db = torch.zeros((Cout,), dtype=torch.float32, device="cuda")
+        ops.conv3d_wgrad(src0, src1, dy, dw, db, up0=up0, impl=impl, planar=True)
+        torch.cuda.synchronize()
+        x = ref_concat_input(f64(src0), None if src1 is None else f64(src1), up0, planar=True)
+        wk = torch.zeros((Cout, C0 + C1, 3, 3, 3), dtype=torch.float64, requires_grad=True)
+        F.conv3d(x, wk, None, padding=1).backward(to_ncdhw(f64(dy)))
+        refg = planar_kernel(wk.grad).permute(2, 3, 4, 0, 1).reshape(27, Cout, C0 + C1)
+        rt = (1e-4, 1e-5) if dtype == torch.float32 else (2e-3, 2e-3)
+        assert_close(dw, refg, *rt, what=name + " dw")
+        assert_close(db, f64(dy).sum(dim=(0, 1, 2, 3)), *rt, what=name + " db")
+    # input gradient through the packed transposed copy
+    if not up0 and not C1:
+        wm = w.float()
+        wd = torch.empty((27, C0, Cout), dtype=dtype, device="cuda")
+        ops.pack_weights(wm.contiguous(), None, wd)
+        dy = rnd((1, S, H, W, Cout), 12, dtype)
+        dx = torch.full((1, S, H, W, C0), float("nan"), dtype=dtype, device="cuda")
+        ops.conv3d_dgrad(dy, wd, dx, impl=impl, planar=True)
+        torch.cuda.synchronize()
+        xr = torch.zeros((1, C0, S, H, W), dtype=torch.float64, requires_grad=True)
+        F.conv3d(xr, planar_kernel(keras_kernel_from_packed(f64(w))), None, padding=1).backward(to_ncdhw(f64(dy)))
+        assert_close(dx, to_ndhwc(xr.grad), *TOL[dtype], what=name + " dgrad")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_planar_pool_and_upsample(ops, dtype):
+    S, H, W, C = 3, 6, 8, 8
+    x = torch.relu(rnd((1, S, H, W, C), 20, dtype))
+    y = torch.empty((1, S, H // 2, W // 2, C), dtype=dtype, device="cuda")
+    ops.maxpool_fwd(x, y, planar=True)
+    xr = f64(x)[0].permute(0, 3, 1, 2).contiguous().requires_grad_(True)            # (S,C,H,W)
+    yr = F.max_pool2d(xr, 2)
+    torch.cuda.synchronize()
+    assert torch.equal(f64(y)[0], yr.detach().permute(0, 2, 3, 1))
+    dy = rnd(tuple(y.shape), 21, dtype)
+    dx = torch.full_like(x, float("nan"))
+    ops.maxpool_bwd(x, dy, dx, relu_mask=True, planar=True)
+    torch.cuda.synchronize()
+    yr.backward(f64(dy)[0].permute(0, 3, 1, 2))
+    ref = xr.grad.permute(0, 2, 3, 1) * (f64(x)[0] > 0)
+    assert_close(dx[0], ref, 1e-6 if dtype == torch.float32 else 1e-2, 1e-6 if dtype == torch.float32 else 4e-3, what="planar maxpool bwd")
+    g = rnd((1, S, H, W, C), 22, dtype)
+    lo = torch.empty((1, S, H // 2, W // 2, C), dtype=dtype, device="cuda")
+    ops.upsample_bwd(g, lo, planar=True)
+    up = torch.zeros((1, S, H, W, C), dtype=dtype, device="cuda")
+    ops.upsample_fwd(y, up, planar=True)
+    torch.cuda.synchronize()
+    assert_close(lo, f64(g).reshape(1, S, H // 2, 2, W // 2, 2, C).sum(dim=(3, 5)), *TOL[dtype], what="planar upsample bwd")
+    assert torch.equal(f64(up), f64(y).repeat_interleave(2, dim=2).repeat_interleave(2, dim=3))
