@@ -186,16 +186,16 @@ def main():
 
     timer = LaunchTimer()
     if not a.no_launch_timing:
-        def lab_fwd(src0, src1, w, bias, y_, up0=False, act=1, alpha=0.0, mask=None, impl=0):
+        def lab_fwd(src0, src1, w, bias, y_, *aa, **kk):
             c0, c1 = src0.shape[-1], (0 if src1 is None else src1.shape[-1])
             if c0 == 1 and c1 == 0:
                 return "conv_first_fwd"
             return ("conv_fwd_mfma" if (c0 % 32 == 0 and c1 % 32 == 0 and y_.shape[-1] % 32 == 0) else "conv_fwd_generic")
 
-        def lab_dgrad(dy, wd, dx, mask=None, impl=0):
+        def lab_dgrad(dy, wd, dx, *aa, **kk):
             return "conv_fwd_mfma" if (dy.shape[-1] % 32 == 0 and dx.shape[-1] % 32 == 0) else "conv_fwd_generic"
 
-        def lab_wgrad(src0, src1, dy, dw, db, up0=False, impl=0):
+        def lab_wgrad(src0, src1, dy, dw, db, *aa, **kk):
             c0, c1 = src0.shape[-1], (0 if src1 is None else src1.shape[-1])
             if c0 == 1 and c1 == 0:
                 return "conv_first_wgrad"

@@ -67,3 +67,22 @@ def test_full_size_conv_linearity_and_wgrad_paths():
     ops.conv3d_wgrad(a0s, a1s, dy, dw_g, db_g, up0=True, impl=IMPL_GENERIC)
     torch.cuda.synchronize()
     assert _rel(dw_m, dw_g) <= 1e-4 and _rel(db_m, db_g) <= 1e-4
+
+
+def test_bench_contract_smoke():
+    """bench.py runs end to end on one GPU and prints the driver's JSON contract (+ roofline with live HIP-event timing)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.check_output([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+                                  stderr=subprocess.STDOUT, timeout=600).decode()
+    line = [l for l in out.splitlines() if l.startswith("{")][-1]
+    j = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline"):
+        assert k in j, k
+    assert j["n_gpus"] == 1 and j["steps"] == 2 and j["dtype"] == "bf16" and j["value"] > 10
+    r = j["roofline"]
+    assert r["bound"] == "mfma" and 0 < r["frac"] < 1 and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
