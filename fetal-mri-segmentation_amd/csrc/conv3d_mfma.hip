@@ -168,11 +168,15 @@ k_conv_fwd_mfma(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__
             for (int k = 0; k < 16; ++k) acc[j][c][k] = 0.f;
 
     // per-lane halo index (before adding the tap offset) of this lane's voxel in the wave's two column tiles
+    // Lane r of a 32-voxel column tile covers h-row (r>>4) and w = wl.  The second h-row is rotated by 2 (= HW mod 16) so that
+    // the halo rows read by one ds_read_b128 lane group are distinct mod 16: with the plain map rows r and r+18 collided on
+    // 2 of 16 lanes per group (rocprofv3: SQ_LDS_BANK_CONFLICT = 33 % of SQ_LDS_IDX_ACTIVE); the rotation makes it conflict-free.
+    const int wl = (r >> 4) ? (((r & 15) + 16 - (HW & 15)) & 15) : (r & 15);
     int hv0[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int rt = 2 * wv + j;                       // 0..15 : d = rt>>2, h-pair = rt&3
-        hv0[j] = ((rt >> 2) * HH + (2 * (rt & 3) + (r >> 4))) * HW + (r & 15);
+        hv0[j] = ((rt >> 2) * HH + (2 * (rt & 3) + (r >> 4))) * HW + wl;
     }
     // filter fragment read offset inside a slab for k-step 0 (k-step 1 = same address with bit 5 flipped): rows kw*BN + c*32 + r
     // keep the swizzle term of row r because kw*BN + c*32 is a multiple of 16
@@ -237,7 +241,7 @@ k_conv_fwd_mfma(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int rt = 2 * wv + j;
-                const int d = cur.d0 + (rt >> 2), h = cur.h0 + 2 * (rt & 3) + (r >> 4), w = cur.w0 + (r & 15);
+                const int d = cur.d0 + (rt >> 2), h = cur.h0 + 2 * (rt & 3) + (r >> 4), w = cur.w0 + wl;
                 const int64_t vo = ((((int64_t)cur.n * D + d) * H + h) * W + w) * Cout + cur.co0;
 #pragma unroll
                 for (int c = 0; c < NT; ++c) {
