@@ -1,0 +1,319 @@
+// Normalisation (+activation) and 2x2x2 stride-2 transposed convolution — the optional pieces of the reference's conv
+// block and up-convolution (reference fetal_net/model/unet3d/unet.py:102-115 BatchNormalization(axis=1) /
+// keras-contrib InstanceNormalization(axis=1) + activation; unet.py:132-138 Deconvolution3D(k=2, s=2)).
+// All HBM-bound; channels-last, fp32 statistics accumulated in double.
+#include "common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------- statistics
+// ws[g][c][0..1] (double) += sum(x), sum(x^2) over the voxels of group g (g = sample for instance norm, 0 for batch norm).
+// Block = 256 threads = (256/CL) voxel lanes x CL channel lanes, CL = min(C,64) rounded to a power of two.
+template <typename T>
+__global__ void k_norm_reduce(const T* __restrict__ x, double* __restrict__ ws, int64_t V, int C, int per_instance, int vchunk) {
+    const int c = blockIdx.y * 64 + (threadIdx.x & 63);
+    const int g = blockIdx.z;
+    const int vl = threadIdx.x >> 6;                       // 0..3
+    const int64_t v0 = (int64_t)blockIdx.x * vchunk;
+    const int64_t v1 = min(V, v0 + vchunk);
+    float s = 0.f, q = 0.f;
+    if (c < C) {
+        const T* base = x + (int64_t)g * V * C + c;
+        for (int64_t v = v0 + vl; v < v1; v += 4) {
+            const float t = to_f<T>(base[v * C]);
+            s += t;
+            q = fmaf(t, t, q);
+        }
+    }
+    __shared__ float red[2][4][64];
+    red[0][vl][threadIdx.x & 63] = s;
+    red[1][vl][threadIdx.x & 63] = q;
+    __syncthreads();
+    if (threadIdx.x < 64 && c < C) {
+        double ds = (double)red[0][0][threadIdx.x] + red[0][1][threadIdx.x] + red[0][2][threadIdx.x] + red[0][3][threadIdx.x];
+        double dq = (double)red[1][0][threadIdx.x] + red[1][1][threadIdx.x] + red[1][2][threadIdx.x] + red[1][3][threadIdx.x];
+        const int gi = per_instance ? g : 0;
+        atomicAdd(&ws[((int64_t)gi * C + c) * 2 + 0], ds);
+        atomicAdd(&ws[((int64_t)gi * C + c) * 2 + 1], dq);
+    }
+}
+// stats[g][c] = {mean, 1/s, 1/sigma}: s = sqrt(var+eps) (batch norm, Keras) or sqrt(var)+eps (keras-contrib instance norm)
+__global__ void k_norm_finalize(const double* __restrict__ ws, float* __restrict__ stats, int G, int C, double M, float eps,
+                                int eps_on_std) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= G * C) return;
+    const double mean = ws[i * 2] / M;
+    double var = ws[i * 2 + 1] / M - mean * mean;
+    if (var < 0) var = 0;
+    const double sigma = sqrt(var);
+    const double s = eps_on_std ? sigma + (double)eps : sqrt(var + (double)eps);
+    stats[i * 3 + 0] = (float)mean;
+    stats[i * 3 + 1] = (float)(1.0 / s);
+    stats[i * 3 + 2] = (float)(eps_on_std ? 1.0 / sigma : 1.0 / s);
+}
+__global__ void k_zero_d(double* p, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0.0;
+}
+
+template <typename T, int VEC>
+__global__ void k_norm_apply(const T* __restrict__ x, const float* __restrict__ stats, const float* __restrict__ gamma,
+                             const float* __restrict__ beta, T* __restrict__ y, int64_t V, int C, int per_instance, int act, float alpha,
+                             int64_t total) {
+    const int CG = C / VEC;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int cg = (int)(i % CG);
+        const int64_t v = i / CG;
+        const int g = per_instance ? (int)(v / V) : 0;
+        float xv[VEC], o[VEC];
+        ldv<T, VEC>(x + v * C + cg * VEC, xv);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            const int c = cg * VEC + k;
+            const float* st = stats + ((int64_t)g * C + c) * 3;
+            float z = (xv[k] - st[0]) * st[1] * gamma[c] + beta[c];
+            if (act == FMRI_ACT_RELU) z = fmaxf(z, 0.f);
+            else if (act == FMRI_ACT_LEAKY) z = z > 0.f ? z : alpha * z;
+            o[k] = z;
+        }
+        stv<T, VEC>(y + v * C + cg * VEC, o);
+    }
+}
+
+// backward reduction: ws[g][c] += { sum dz, sum dz*xhat },  dz = dy * act'(y)
+template <typename T>
+__global__ void k_norm_bwd_reduce(const T* __restrict__ x, const T* __restrict__ y, const T* __restrict__ dy, const float* __restrict__ stats,
+                                  double* __restrict__ ws, int64_t V, int C, int per_instance, int act, float alpha, int vchunk) {
+    const int c = blockIdx.y * 64 + (threadIdx.x & 63);
+    const int g = blockIdx.z;
+    const int vl = threadIdx.x >> 6;
+    const int64_t v0 = (int64_t)blockIdx.x * vchunk;
+    const int64_t v1 = min(V, v0 + vchunk);
+    float s = 0.f, q = 0.f;
+    if (c < C) {
+        const int gi = per_instance ? g : 0;
+        const float mean = stats[((int64_t)gi * C + c) * 3], inv = stats[((int64_t)gi * C + c) * 3 + 1];
+        const int64_t base = (int64_t)g * V * C + c;
+        for (int64_t v = v0 + vl; v < v1; v += 4) {
+            float d = to_f<T>(dy[base + v * C]);
+            const float yy = to_f<T>(y[base + v * C]);
+            if (act == FMRI_ACT_RELU) d = yy > 0.f ? d : 0.f;
+            else if (act == FMRI_ACT_LEAKY) d = yy > 0.f ? d : alpha * d;
+            const float xh = (to_f<T>(x[base + v * C]) - mean) * inv;
+            s += d;
+            q = fmaf(d, xh, q);
+        }
+    }
+    __shared__ float red[2][4][64];
+    red[0][vl][threadIdx.x & 63] = s;
+    red[1][vl][threadIdx.x & 63] = q;
+    __syncthreads();
+    if (threadIdx.x < 64 && c < C) {
+        double ds = (double)red[0][0][threadIdx.x] + red[0][1][threadIdx.x] + red[0][2][threadIdx.x] + red[0][3][threadIdx.x];
+        double dq = (double)red[1][0][threadIdx.x] + red[1][1][threadIdx.x] + red[1][2][threadIdx.x] + red[1][3][threadIdx.x];
+        const int gi = per_instance ? g : 0;
+        atomicAdd(&ws[((int64_t)gi * C + c) * 2 + 0], ds);
+        atomicAdd(&ws[((int64_t)gi * C + c) * 2 + 1], dq);
+    }
+}
+// dgamma[c] += sum_g ws[g][c][1], dbeta[c] += sum_g ws[g][c][0]
+__global__ void k_norm_bwd_params(const double* __restrict__ ws, float* __restrict__ dgamma, float* __restrict__ dbeta, int G, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double a = 0, b = 0;
+    for (int g = 0; g < G; ++g) { b += ws[((int64_t)g * C + c) * 2]; a += ws[((int64_t)g * C + c) * 2 + 1]; }
+    dgamma[c] += (float)a;
+    dbeta[c] += (float)b;
+}
+// dx = gamma * [ (dz - mean(dz)) * inv_s - xhat * mean(dz*xhat) * inv_sigma ]
+template <typename T, int VEC>
+__global__ void k_norm_bwd_apply(const T* __restrict__ x, const T* __restrict__ y, const T* __restrict__ dy, const float* __restrict__ stats,
+                                 const float* __restrict__ gamma, const double* __restrict__ ws, T* __restrict__ dx, int64_t V, int C,
+                                 int per_instance, int act, float alpha, double M, int64_t total) {
+    const int CG = C / VEC;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int cg = (int)(i % CG);
+        const int64_t v = i / CG;
+        const int g = per_instance ? (int)(v / V) : 0;
+        float xv[VEC], yv[VEC], dv[VEC], o[VEC];
+        ldv<T, VEC>(x + v * C + cg * VEC, xv);
+        ldv<T, VEC>(y + v * C + cg * VEC, yv);
+        ldv<T, VEC>(dy + v * C + cg * VEC, dv);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            const int c = cg * VEC + k;
+            const int64_t sc = (int64_t)g * C + c;
+            float d = dv[k];
+            if (act == FMRI_ACT_RELU) d = yv[k] > 0.f ? d : 0.f;
+            else if (act == FMRI_ACT_LEAKY) d = yv[k] > 0.f ? d : alpha * d;
+            const float mean = stats[sc * 3], inv = stats[sc * 3 + 1], invsig = stats[sc * 3 + 2];
+            const float xh = (xv[k] - mean) * inv;
+            const float m1 = (float)(ws[sc * 2] / M), m2 = (float)(ws[sc * 2 + 1] / M);
+            o[k] = gamma[c] * ((d - m1) * inv - xh * m2 * invsig);
+        }
+        stv<T, VEC>(dx + v * C + cg * VEC, o);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------- deconvolution k2 s2
+// y[n, 2i+a, co] = b[co] + sum_ci x[n,i,ci] * w[a][co][ci]   (a = ad*4+ah*2+aw; 'valid', stride 2: the 8 taps never overlap)
+template <typename T>
+__global__ void k_deconv_fwd(const T* __restrict__ x, const T* __restrict__ w, const float* __restrict__ b, T* __restrict__ y, int N, int D,
+                             int H, int W, int Cin, int Cout, int pd) {
+    const int D2 = D << pd, H2 = 2 * H, W2 = 2 * W;
+    const int64_t total = (int64_t)N * D2 * H2 * W2 * Cout;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int co = (int)(i % Cout);
+        int64_t v = i / Cout;
+        const int ww = (int)(v % W2); v /= W2;
+        const int hh = (int)(v % H2); v /= H2;
+        const int dd = (int)(v % D2);
+        const int n = (int)(v / D2);
+        const int a = ((pd ? (dd & 1) : 0) << 2) | ((hh & 1) << 1) | (ww & 1);
+        const T* xp = x + ((((int64_t)n * D + (dd >> pd)) * H + (hh >> 1)) * W + (ww >> 1)) * Cin;
+        const T* wp = w + ((int64_t)a * Cout + co) * Cin;
+        float acc = b ? b[co] : 0.f;
+        for (int ci = 0; ci < Cin; ++ci) acc = fmaf(to_f<T>(xp[ci]), to_f<T>(wp[ci]), acc);
+        y[i] = from_f<T>(acc);
+    }
+}
+// dx[n,i,ci] = sum_a sum_co dy[n,2i+a, dy_off+co] * w[a][co][ci]  (optionally masked by xmask > 0)
+template <typename T>
+__global__ void k_deconv_dgrad(const T* __restrict__ dy, int dy_ld, int dy_off, const T* __restrict__ w, const T* __restrict__ xmask,
+                               T* __restrict__ dx, int N, int D, int H, int W, int Cin, int Cout, int pd) {
+    const int D2 = D << pd, H2 = 2 * H, W2 = 2 * W;
+    const int64_t total = (int64_t)N * D * H * W * Cin;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int ci = (int)(i % Cin);
+        int64_t v = i / Cin;
+        const int ww = (int)(v % W); v /= W;
+        const int hh = (int)(v % H); v /= H;
+        const int dd = (int)(v % D);
+        const int n = (int)(v / D);
+        float acc = 0.f;
+        for (int a = 0; a < (4 << pd); ++a) {
+            const int ad = pd ? (a >> 2) : 0, ah = (a >> 1) & 1, aw = a & 1;
+            const int wa = (ad << 2) | (ah << 1) | aw;
+            const T* gp = dy + ((((int64_t)n * D2 + (dd << pd) + ad) * H2 + 2 * hh + ah) * W2 + 2 * ww + aw) * dy_ld + dy_off;
+            const T* wp = w + (int64_t)wa * Cout * Cin + ci;
+            for (int co = 0; co < Cout; ++co) acc = fmaf(to_f<T>(gp[co]), to_f<T>(wp[(int64_t)co * Cin]), acc);
+        }
+        if (xmask && !(to_f<T>(xmask[i]) > 0.f)) acc = 0.f;
+        dx[i] = from_f<T>(acc);
+    }
+}
+// dw[a][co][ci] += sum_{n,i} dy[n,2i+a,co] * x[n,i,ci];  db[co] += sum dy.  One block per (a, co): threads over ci, loop voxels.
+template <typename T>
+__global__ void k_deconv_wgrad(const T* __restrict__ x, const T* __restrict__ dy, int dy_ld, int dy_off, float* __restrict__ dw,
+                               float* __restrict__ db, int N, int D, int H, int W, int Cin, int Cout, int pd, int nsplit) {
+    const int a = blockIdx.x, co = blockIdx.y, sp = blockIdx.z;
+    const int ad = pd ? (a >> 2) : 0, ah = (a >> 1) & 1, aw = a & 1;
+    const int D2 = D << pd, H2 = 2 * H, W2 = 2 * W;
+    const int64_t nvox = (int64_t)N * D * H * W;
+    const int64_t v0 = nvox * sp / nsplit, v1 = nvox * (sp + 1) / nsplit;
+    float bsum = 0.f;
+    for (int ci0 = 0; ci0 < Cin; ci0 += blockDim.x) {
+        const int ci = ci0 + threadIdx.x;
+        float acc = 0.f;
+        for (int64_t v = v0; v < v1; ++v) {
+            int64_t q = v;
+            const int ww = (int)(q % W); q /= W;
+            const int hh = (int)(q % H); q /= H;
+            const int dd = (int)(q % D);
+            const int n = (int)(q / D);
+            const float g = to_f<T>(dy[((((int64_t)n * D2 + (dd << pd) + ad) * H2 + 2 * hh + ah) * W2 + 2 * ww + aw) * dy_ld + dy_off + co]);
+            if (ci < Cin) acc = fmaf(g, to_f<T>(x[v * Cin + ci]), acc);
+            if (ci0 == 0 && threadIdx.x == 0) bsum += g;
+        }
+        if (ci < Cin) atomicAdd(&dw[((int64_t)a * Cout + co) * Cin + ci], acc);
+    }
+    if (db && threadIdx.x == 0) atomicAdd(&db[co], bsum);
+}
+
+}  // namespace
+
+// -------------------------------------------------------------------------------------------------------------- C ABI
+extern "C" int fmri_norm_act_fwd(const void* x, const float* gamma, const float* beta, void* y, float* stats, double* ws, int N,
+                                 int64_t V, int C, int per_instance, float eps, int eps_on_std, int act, float alpha, int dtype,
+                                 fmri_stream_t stream) {
+    if (N <= 0 || V <= 0 || C <= 0 || !stats || !ws) return FMRI_E_SHAPE;
+    hipStream_t s = as_stream(stream);
+    const int G = per_instance ? N : 1;
+    k_zero_d<<<(G * C * 2 + 255) / 256, 256, 0, s>>>(ws, G * C * 2);
+    const int vchunk = 4096;
+    dim3 grid((unsigned)ceil_div64(V, vchunk), (C + 63) / 64, N);
+    if (dtype == FMRI_F32) k_norm_reduce<float><<<grid, 256, 0, s>>>((const float*)x, ws, V, C, per_instance, vchunk);
+    else if (dtype == FMRI_BF16) k_norm_reduce<bf16_t><<<grid, 256, 0, s>>>((const bf16_t*)x, ws, V, C, per_instance, vchunk);
+    else return FMRI_E_DTYPE;
+    const double M = per_instance ? (double)V : (double)V * N;
+    k_norm_finalize<<<(G * C + 255) / 256, 256, 0, s>>>(ws, stats, G, C, M, eps, eps_on_std);
+    const int vec = pick_vec(C);
+    const int64_t total = (int64_t)N * V * (C / vec);
+    const int g2 = grid_for(total);
+    if (dtype == FMRI_F32)
+        LAUNCH_TV(k_norm_apply, float, vec, g2, 256, s, (const float*)x, stats, gamma, beta, (float*)y, V, C, per_instance, act, alpha, total);
+    else
+        LAUNCH_TV(k_norm_apply, bf16_t, vec, g2, 256, s, (const bf16_t*)x, stats, gamma, beta, (bf16_t*)y, V, C, per_instance, act, alpha, total);
+    FMRI_LAUNCH_CHECK();
+    return FMRI_OK;
+}
+
+extern "C" int fmri_norm_act_bwd(const void* x, const void* y, const void* dy, const float* gamma, const float* stats, void* dx,
+                                 float* dgamma, float* dbeta, double* ws, int N, int64_t V, int C, int per_instance, int act,
+                                 float alpha, int dtype, fmri_stream_t stream) {
+    if (N <= 0 || V <= 0 || C <= 0 || !stats || !ws) return FMRI_E_SHAPE;
+    hipStream_t s = as_stream(stream);
+    const int G = per_instance ? N : 1;
+    k_zero_d<<<(G * C * 2 + 255) / 256, 256, 0, s>>>(ws, G * C * 2);
+    const int vchunk = 4096;
+    dim3 grid((unsigned)ceil_div64(V, vchunk), (C + 63) / 64, N);
+    if (dtype == FMRI_F32)
+        k_norm_bwd_reduce<float><<<grid, 256, 0, s>>>((const float*)x, (const float*)y, (const float*)dy, stats, ws, V, C, per_instance, act, alpha, vchunk);
+    else if (dtype == FMRI_BF16)
+        k_norm_bwd_reduce<bf16_t><<<grid, 256, 0, s>>>((const bf16_t*)x, (const bf16_t*)y, (const bf16_t*)dy, stats, ws, V, C, per_instance, act, alpha, vchunk);
+    else return FMRI_E_DTYPE;
+    if (dgamma && dbeta) k_norm_bwd_params<<<(C + 255) / 256, 256, 0, s>>>(ws, dgamma, dbeta, G, C);
+    const double M = per_instance ? (double)V : (double)V * N;
+    const int vec = pick_vec(C);
+    const int64_t total = (int64_t)N * V * (C / vec);
+    const int g2 = grid_for(total);
+    if (dtype == FMRI_F32)
+        LAUNCH_TV(k_norm_bwd_apply, float, vec, g2, 256, s, (const float*)x, (const float*)y, (const float*)dy, stats, gamma, ws, (float*)dx, V, C, per_instance, act, alpha, M, total);
+    else
+        LAUNCH_TV(k_norm_bwd_apply, bf16_t, vec, g2, 256, s, (const bf16_t*)x, (const bf16_t*)y, (const bf16_t*)dy, stats, gamma, ws, (bf16_t*)dx, V, C, per_instance, act, alpha, M, total);
+    FMRI_LAUNCH_CHECK();
+    return FMRI_OK;
+}
+
+extern "C" int fmri_deconv3d_k2s2_fwd(const void* x, const void* w, const float* b, void* y, int N, int D, int H, int W, int Cin, int Cout,
+                                      int dtype, int planar, fmri_stream_t stream) {
+    if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return FMRI_E_SHAPE;
+    const int pd = planar ? 0 : 1;
+    const int grid = grid_for((int64_t)N * (D << pd) * 2 * H * 2 * W * Cout, 256, 8192);
+    hipStream_t s = as_stream(stream);
+    if (dtype == FMRI_F32) k_deconv_fwd<float><<<grid, 256, 0, s>>>((const float*)x, (const float*)w, b, (float*)y, N, D, H, W, Cin, Cout, pd);
+    else if (dtype == FMRI_BF16) k_deconv_fwd<bf16_t><<<grid, 256, 0, s>>>((const bf16_t*)x, (const bf16_t*)w, b, (bf16_t*)y, N, D, H, W, Cin, Cout, pd);
+    else return FMRI_E_DTYPE;
+    FMRI_LAUNCH_CHECK();
+    return FMRI_OK;
+}
+extern "C" int fmri_deconv3d_k2s2_bwd(const void* x, const void* w, const void* dy, int dy_ld, int dy_off, const void* xmask, void* dx,
+                                      float* dw, float* db, int N, int D, int H, int W, int Cin, int Cout, int dtype, int planar,
+                                      fmri_stream_t stream) {
+    if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || dy_ld < dy_off + Cout) return FMRI_E_SHAPE;
+    const int pd = planar ? 0 : 1;
+    hipStream_t s = as_stream(stream);
+    const int grid = grid_for((int64_t)N * D * H * W * Cin, 256, 8192);
+    const int nsplit = 16;
+    dim3 gw(4 << pd, Cout, nsplit);
+    const int bt = Cin >= 256 ? 256 : (Cin >= 128 ? 128 : 64);
+    if (dtype == FMRI_F32) {
+        if (dx) k_deconv_dgrad<float><<<grid, 256, 0, s>>>((const float*)dy, dy_ld, dy_off, (const float*)w, (const float*)xmask, (float*)dx, N, D, H, W, Cin, Cout, pd);
+        if (dw) k_deconv_wgrad<float><<<gw, bt, 0, s>>>((const float*)x, (const float*)dy, dy_ld, dy_off, dw, db, N, D, H, W, Cin, Cout, pd, nsplit);
+    } else if (dtype == FMRI_BF16) {
+        if (dx) k_deconv_dgrad<bf16_t><<<grid, 256, 0, s>>>((const bf16_t*)dy, dy_ld, dy_off, (const bf16_t*)w, (const bf16_t*)xmask, (bf16_t*)dx, N, D, H, W, Cin, Cout, pd);
+        if (dw) k_deconv_wgrad<bf16_t><<<gw, bt, 0, s>>>((const bf16_t*)x, (const bf16_t*)dy, dy_ld, dy_off, dw, db, N, D, H, W, Cin, Cout, pd, nsplit);
+    } else return FMRI_E_DTYPE;
+    FMRI_LAUNCH_CHECK();
+    return FMRI_OK;
+}

@@ -37,6 +37,10 @@ SIGNATURES = {
     "fmri_maxpool3d_2x_bwd": [p, p, p, i32, i32, p, i32, i32, i32, i32, i32, i32, i32, i32, p],
     "fmri_upsample_nearest2x_fwd": [p, p, i32, i32, i32, i32, i32, i32, i32, i32, i32, p],
     "fmri_upsample_nearest2x_bwd": [p, i32, i32, p, p, i32, i32, i32, i32, i32, i32, i32, p],
+    "fmri_norm_act_fwd": [p, p, p, p, p, p, i32, i64, i32, i32, f32, i32, i32, f32, i32, p],
+    "fmri_norm_act_bwd": [p, p, p, p, p, p, p, p, p, i32, i64, i32, i32, i32, f32, i32, p],
+    "fmri_deconv3d_k2s2_fwd": [p, p, p, p, i32, i32, i32, i32, i32, i32, i32, i32, p],
+    "fmri_deconv3d_k2s2_bwd": [p, p, p, i32, i32, p, p, p, p, i32, i32, i32, i32, i32, i32, i32, i32, p],
     "fmri_adam_step": [p, p, p, p, i64, f32, f32, f32, f32, f32, p],
     "fmri_tile_gather": [p, i32, i32, i32, p, i32, i32, i32, i32, p, i32, p],
     "fmri_tile_scatter_accumulate": [p, p, i32, i32, i32, i32, i32, p, p, i32, i32, i32, p],

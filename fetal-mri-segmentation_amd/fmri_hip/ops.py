@@ -162,3 +162,40 @@ def cast(src, dst):
     _need_cuda(src, dst)
     check(lib().fmri_cast(_p(src), dt(src), _p(dst), dt(dst), src.numel(), _s()), "fmri_cast")
     return dst
+
+
+def norm_act_fwd(x, gamma, beta, y, stats, ws, per_instance, eps=1e-3, eps_on_std=False, act=ACT_RELU, alpha=0.0):
+    """x,y [N,...,C]; stats [G,C,3] fp32; ws [G,C,2] fp64 scratch"""
+    _need_cuda(x, gamma, beta, y, stats, ws)
+    N, Cc = x.shape[0], x.shape[-1]
+    V = x.numel() // (N * Cc)
+    check(lib().fmri_norm_act_fwd(_p(x), _p(gamma), _p(beta), _p(y), _p(stats), _p(ws), N, V, Cc, int(per_instance), float(eps),
+                                  int(eps_on_std), act, float(alpha), dt(x), _s()), "fmri_norm_act_fwd")
+    return y
+
+
+def norm_act_bwd(x, y, dy, gamma, stats, dx, dgamma, dbeta, ws, per_instance, act=ACT_RELU, alpha=0.0):
+    _need_cuda(x, y, dy, gamma, stats, dx, dgamma, dbeta, ws)
+    N, Cc = x.shape[0], x.shape[-1]
+    V = x.numel() // (N * Cc)
+    check(lib().fmri_norm_act_bwd(_p(x), _p(y), _p(dy), _p(gamma), _p(stats), _p(dx), _p(dgamma), _p(dbeta), _p(ws), N, V, Cc,
+                                  int(per_instance), act, float(alpha), dt(x), _s()), "fmri_norm_act_bwd")
+    return dx
+
+
+def deconv_fwd(x, w, b, y, planar=False):
+    """x [N,D,H,W,Cin], w [8,Cout,Cin] (compute dtype), y [N,2D,2H,2W,Cout]"""
+    _need_cuda(x, w, b, y)
+    N, D, H, W, Cin = x.shape
+    Cout = w.shape[1]
+    check(lib().fmri_deconv3d_k2s2_fwd(_p(x), _p(w), _p(b), _p(y), N, D, H, W, Cin, Cout, dt(x), int(planar), _s()),
+          "fmri_deconv3d_k2s2_fwd")
+    return y
+
+
+def deconv_bwd(x, w, dy, dx, dw, db, dy_off=0, xmask=None, planar=False):
+    _need_cuda(x, w, dy, dx, dw, db, xmask)
+    N, D, H, W, Cin = x.shape
+    Cout = w.shape[1]
+    check(lib().fmri_deconv3d_k2s2_bwd(_p(x), _p(w), _p(dy), dy.shape[-1], dy_off, _p(xmask), _p(dx), _p(dw), _p(db), N, D, H, W, Cin,
+                                       Cout, dt(x), int(planar), _s()), "fmri_deconv3d_k2s2_bwd")

@@ -102,6 +102,28 @@ int fmri_upsample_nearest2x_fwd(const void* x, void* y, int y_ld, int y_off, int
 int fmri_upsample_nearest2x_bwd(const void* dy, int dy_ld, int dy_off, const void* xmask, void* dx, int N, int D, int H,
                                 int W, int C, int dtype, int planar, fmri_stream_t stream);
 
+/* ---- BatchNormalization(axis=1) / keras-contrib InstanceNormalization(axis=1) fused with the block's activation — reference
+ * unet.py:103-115.  x, y: [N][V][C] (V = D*H*W voxels).  per_instance = 0: statistics over all N*V voxels per channel (Keras
+ * training-mode batch norm, eps inside the sqrt); 1: per (sample, channel) (instance norm; eps_on_std = 1 reproduces
+ * keras-contrib's (x-mean)/(std+eps)).  stats [G][C][3] fp32 = {mean, 1/s, 1/sigma} is written for the backward (G = N or 1);
+ * ws = [G][C][2] doubles of scratch (zeroed internally).  y = act(gamma*(x-mean)/s + beta). */
+int fmri_norm_act_fwd(const void* x, const float* gamma, const float* beta, void* y, float* stats, double* ws, int N, int64_t V,
+                      int C, int per_instance, float eps, int eps_on_std, int act, float alpha, int dtype, fmri_stream_t stream);
+/* dy is the gradient w.r.t. y (NOT yet multiplied by act'): dz = dy*act'(y); dgamma/dbeta (fp32, ACCUMULATED) ;
+ * dx = gamma*[(dz-mean(dz))/s - xhat*mean(dz*xhat)/sigma].  dx may alias dy. */
+int fmri_norm_act_bwd(const void* x, const void* y, const void* dy, const float* gamma, const float* stats, void* dx, float* dgamma,
+                      float* dbeta, double* ws, int N, int64_t V, int C, int per_instance, int act, float alpha, int dtype,
+                      fmri_stream_t stream);
+
+/* ---- Deconvolution3D(filters, kernel_size=(2,2,2), strides=(2,2,2)) — reference unet.py:135.  x [N][D][H][W][Cin] ->
+ * y [N][2D][2H][2W][Cout]; w [8 taps = ad*4+ah*2+aw][Cout][Cin] (dtype); planar: (1,2,2) taps 0..3 and D unchanged. */
+int fmri_deconv3d_k2s2_fwd(const void* x, const void* w, const float* b, void* y, int N, int D, int H, int W, int Cin, int Cout,
+                           int dtype, int planar, fmri_stream_t stream);
+/* dy = channel slice [dy_off, dy_off+Cout) of a tensor with dy_ld channels; dx (optional, masked by xmask > 0), dw [8][Cout][Cin]
+ * and db [Cout] fp32 ACCUMULATED (either may be NULL). */
+int fmri_deconv3d_k2s2_bwd(const void* x, const void* w, const void* dy, int dy_ld, int dy_off, const void* xmask, void* dx, float* dw,
+                           float* db, int N, int D, int H, int W, int Cin, int Cout, int dtype, int planar, fmri_stream_t stream);
+
 /* ---- Keras Adam.get_updates — reference unet.py:85.  lr_t = lr*sqrt(1-b2^t)/(1-b1^t) is computed by the host.
  * g is multiplied by grad_scale first.  p -= lr_t * m/(sqrt(v)+eps). One launch over the flat parameter buffer. */
 int fmri_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr_t, float beta1, float beta2,

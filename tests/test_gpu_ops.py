@@ -329,3 +329,77 @@ def test_planar_pool_and_upsample(ops, dtype):
     torch.cuda.synchronize()
     assert_close(lo, f64(g).reshape(1, S, H // 2, 2, W // 2, 2, C).sum(dim=(3, 5)), *TOL[dtype], what="planar upsample bwd")
     assert torch.equal(f64(up), f64(y).repeat_interleave(2, dim=2).repeat_interleave(2, dim=3))
+
+
+# ------------------------------------------------------------------------------------------------ normalisation + deconvolution
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("mode", ["batch", "instance"])
+@pytest.mark.parametrize("act", [1, 2])
+def test_norm_act_fwd_bwd(ops, dtype, mode, act):
+    from oracle import unet_oracle as O
+    N, D, H, W, C = 2, 4, 6, 8, 16
+    alpha = 0.3
+    x = rnd((N, D, H, W, C), 80, dtype, scale=1.5) + 0.3
+    gamma = rnd((C,), 81, torch.float32) * 0.5 + 1.0
+    beta = rnd((C,), 82, torch.float32) * 0.2
+    per = mode == "instance"
+    G = N if per else 1
+    stats = torch.zeros((G, C, 3), device="cuda")
+    ws = torch.zeros((G, C, 2), dtype=torch.float64, device="cuda")
+    y = torch.empty_like(x)
+    ops.norm_act_fwd(x, gamma, beta, y, stats, ws, per, eps=1e-3, eps_on_std=per, act=act, alpha=alpha)
+    xr = to_ncdhw(f64(x)).requires_grad_(True)
+    gr, br = f64(gamma).requires_grad_(True), f64(beta).requires_grad_(True)
+    z = O._instancenorm(xr, gr, br) if per else O._batchnorm_train(xr, gr, br)
+    yr = F.relu(z) if act == 1 else F.leaky_relu(z, alpha)
+    torch.cuda.synchronize()
+    tol = (1e-4, 1e-5) if dtype == torch.float32 else (1e-2, 1e-2)
+    assert_close(y, to_ndhwc(yr.detach()), *tol, what="norm fwd")
+    dy = rnd((N, D, H, W, C), 83, dtype)
+    # the backward reads the STORED y (bf16-rounded in bf16 mode) for act': mirror that in the checker
+    dx = torch.empty_like(x)
+    dg = torch.zeros(C, device="cuda")
+    db = torch.zeros(C, device="cuda")
+    ops.norm_act_bwd(x, y, dy, gamma, stats, dx, dg, db, ws, per, act=act, alpha=alpha)
+    torch.cuda.synchronize()
+    yr.backward(to_ncdhw(f64(dy)))
+    tolb = (2e-4, 2e-5) if dtype == torch.float32 else (2e-2, 2e-2)
+    assert_close(dx, to_ndhwc(xr.grad), *tolb, what="norm dx")
+    assert_close(dg, gr.grad, *tolb, what="norm dgamma")
+    assert_close(db, br.grad, *tolb, what="norm dbeta")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("planar", [False, True])
+def test_deconv_k2s2_fwd_bwd(ops, dtype, planar):
+    N, D, H, W, Cin, Cout = 2, 3, 4, 5, 12, 8
+    x = torch.relu(rnd((N, D, H, W, Cin), 90, dtype))
+    nt = 4 if planar else 8
+    w = rnd((8, Cout, Cin), 91, dtype, scale=0.3)
+    b = rnd((Cout,), 92, torch.float32)
+    D2 = D if planar else 2 * D
+    y = torch.empty((N, D2, 2 * H, 2 * W, Cout), dtype=dtype, device="cuda")
+    ops.deconv_fwd(x, w, b, y, planar=planar)
+    xr = to_ncdhw(f64(x)).requires_grad_(True)
+    wr = f64(w).requires_grad_(True)
+    br = f64(b).requires_grad_(True)
+    if planar:
+        k = wr[:4].reshape(2, 2, Cout, Cin).permute(3, 2, 0, 1)               # (Cin,Cout,2,2)
+        yr = F.conv_transpose2d(xr.permute(0, 2, 1, 3, 4).reshape(N * D, Cin, H, W), k, br, stride=2)
+        yr = yr.reshape(N, D, Cout, 2 * H, 2 * W).permute(0, 2, 1, 3, 4)
+    else:
+        k = wr.reshape(2, 2, 2, Cout, Cin).permute(4, 3, 0, 1, 2)             # (Cin,Cout,2,2,2)
+        yr = F.conv_transpose3d(xr, k, br, stride=2)
+    torch.cuda.synchronize()
+    assert_close(y, to_ndhwc(yr.detach()), *TOL[dtype], what="deconv fwd")
+    dyfull = rnd((N, D2, 2 * H, 2 * W, Cout + 4), 93, dtype)
+    dx = torch.empty_like(x)
+    dw = torch.zeros((8, Cout, Cin), device="cuda")
+    dbg = torch.zeros(Cout, device="cuda")
+    ops.deconv_bwd(x, w, dyfull, dx, dw, dbg, dy_off=4, xmask=x, planar=planar)
+    torch.cuda.synchronize()
+    yr.backward(to_ncdhw(f64(dyfull)[..., 4:]))
+    tolb = (1e-4, 1e-5) if dtype == torch.float32 else (1e-2, 1e-2)
+    assert_close(dx, to_ndhwc(xr.grad) * (f64(x) > 0), *tolb, what="deconv dx")
+    assert_close(dw[:nt], wr.grad[:nt], *tolb, what="deconv dw")
+    assert_close(dbg, br.grad, *tolb, what="deconv db")
