@@ -238,15 +238,19 @@ extern "C" int fmri_norm_act_fwd(const void* x, const float* gamma, const float*
                                  fmri_stream_t stream) {
     if (N <= 0 || V <= 0 || C <= 0 || !stats || !ws) return FMRI_E_SHAPE;
     hipStream_t s = as_stream(stream);
-    const int G = per_instance ? N : 1;
-    k_zero_d<<<(G * C * 2 + 255) / 256, 256, 0, s>>>(ws, G * C * 2);
-    const int vchunk = 4096;
-    dim3 grid((unsigned)ceil_div64(V, vchunk), (C + 63) / 64, N);
-    if (dtype == FMRI_F32) k_norm_reduce<float><<<grid, 256, 0, s>>>((const float*)x, ws, V, C, per_instance, vchunk);
-    else if (dtype == FMRI_BF16) k_norm_reduce<bf16_t><<<grid, 256, 0, s>>>((const bf16_t*)x, ws, V, C, per_instance, vchunk);
-    else return FMRI_E_DTYPE;
-    const double M = per_instance ? (double)V : (double)V * N;
-    k_norm_finalize<<<(G * C + 255) / 256, 256, 0, s>>>(ws, stats, G, C, M, eps, eps_on_std);
+    if (dtype != FMRI_F32 && dtype != FMRI_BF16) return FMRI_E_DTYPE;
+    if (per_instance >= 0) {            // per_instance < 0: inference with the statistics already in `stats` (moving averages)
+        const int G = per_instance ? N : 1;
+        k_zero_d<<<(G * C * 2 + 255) / 256, 256, 0, s>>>(ws, G * C * 2);
+        const int vchunk = 4096;
+        dim3 grid((unsigned)ceil_div64(V, vchunk), (C + 63) / 64, N);
+        if (dtype == FMRI_F32) k_norm_reduce<float><<<grid, 256, 0, s>>>((const float*)x, ws, V, C, per_instance, vchunk);
+        else k_norm_reduce<bf16_t><<<grid, 256, 0, s>>>((const bf16_t*)x, ws, V, C, per_instance, vchunk);
+        const double M = per_instance ? (double)V : (double)V * N;
+        k_norm_finalize<<<(G * C + 255) / 256, 256, 0, s>>>(ws, stats, G, C, M, eps, eps_on_std);
+    } else {
+        per_instance = 0;
+    }
     const int vec = pick_vec(C);
     const int64_t total = (int64_t)N * V * (C / vec);
     const int g2 = grid_for(total);

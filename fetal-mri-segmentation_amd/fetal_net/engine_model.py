@@ -405,7 +405,7 @@ class Model(object):
             x = x[0]
         n = np.asarray(x).shape[0]
         eng = self.engine(n)
-        eng.forward(self._to_device_x(x))
+        eng.forward(self._to_device_x(x), bn_training=False)        # Keras evaluates with learning_phase = 0
         sums = eng.loss_forward(self._to_device_y(y))
         logs = self._batch_logs(sums.cpu().numpy())
         return [logs[k] for k in self.metrics_names]

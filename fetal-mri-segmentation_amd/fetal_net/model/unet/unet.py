@@ -46,13 +46,9 @@ def unet_model_2d(input_shape, pool_size=(2, 2), n_labels=1, initial_learning_ra
     if "compute_dtype" in kargs:
         builder_kwargs["compute_dtype"] = kargs["compute_dtype"]
     plan_args = dict(in_channels=input_shape[-1], spatial=input_shape[:2], depth=depth, n_base_filters=n_base_filters,
-                     n_labels=n_labels, ndim=2)
+                     n_labels=n_labels, ndim=2, norm="batch" if batch_normalization else None, deconvolution=bool(deconvolution))
     model = Model(g.layers, plan_args, "unet_model_2d", builder_kwargs, "channels_last_2d")
     unsupported = []
-    if deconvolution:
-        unsupported.append("deconvolution=True (Conv2DTranspose kernels)")
-    if batch_normalization:
-        unsupported.append("batch_normalization=True")
     if pool_size != (2, 2):
         unsupported.append("pool_size != (2,2)")
     if activation_name != "sigmoid":

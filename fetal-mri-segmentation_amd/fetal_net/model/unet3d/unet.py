@@ -58,10 +58,6 @@ def unet_model_3d(input_shape, pool_size=(2, 2, 2), n_labels=1, initial_learning
     g.activation(h, activation_name)
 
     unsupported = []
-    if deconvolution:
-        unsupported.append("deconvolution=True (Conv3DTranspose kernels)")
-    if batch_normalization:
-        unsupported.append("batch_normalization=True")
     if pool_size != (2, 2, 2):
         unsupported.append("pool_size != (2,2,2)")
     if activation_name != "sigmoid":
@@ -72,7 +68,7 @@ def unet_model_3d(input_shape, pool_size=(2, 2, 2), n_labels=1, initial_learning
     if "compute_dtype" in kargs:
         builder_kwargs["compute_dtype"] = kargs["compute_dtype"]
     plan_args = dict(in_channels=input_shape[0], spatial=input_shape[1:], depth=depth, n_base_filters=n_base_filters,
-                     n_labels=n_labels, ndim=3)
+                     n_labels=n_labels, ndim=3, norm="batch" if batch_normalization else None, deconvolution=bool(deconvolution))
     model = Model(g.layers, plan_args, "unet_model_3d", builder_kwargs, "channels_first_3d")
     if unsupported:
         model._unsupported = ", ".join(unsupported)

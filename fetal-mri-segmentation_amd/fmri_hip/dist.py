@@ -61,7 +61,8 @@ class DataParallel:
     def grad_ready(self, eng, name):
         """called by the engine right after the wgrad of `name` was enqueued (layout order == call order)"""
         L = eng.layout[name]
-        end = L["b"][0] + L["b"][1]
+        last = L.get("beta", L["b"])                    # the layer's last parameter range (norm beta sits behind the bias)
+        end = last[0] + last[1]
         if name == next(iter(eng.layout)):
             self.begin()
         if end - self._start >= self.bucket_elems:

@@ -26,16 +26,26 @@ from ._lib import ACT_NONE, ACT_RELU, IMPL_AUTO
 class UNetPlan:
     """Topology in Keras creation order (names match Keras auto-naming)."""
 
-    def __init__(self, in_channels, spatial, depth=4, n_base_filters=32, n_labels=1, ndim=3):
+    def __init__(self, in_channels, spatial, depth=4, n_base_filters=32, n_labels=1, ndim=3, norm=None, deconvolution=False):
+        """norm: None | 'batch' | 'instance' (reference create_convolution_block options); deconvolution: Conv*DTranspose(k=2,s=2)
+        instead of nearest up-sampling (reference get_up_convolution)."""
         self.in_channels, self.spatial = in_channels, tuple(spatial)
         self.depth, self.n_base_filters, self.n_labels, self.ndim = depth, n_base_filters, n_labels, ndim
+        self.norm, self.deconvolution = norm, deconvolution
         d = "3d" if ndim == 3 else "2d"
         k = 0
+        nk = 0
+        tk = 0
 
         def conv_name():
             nonlocal k
             k += 1
             return "conv%s_%d" % (d, k)
+
+        def norm_name():
+            nonlocal nk
+            nk += 1
+            return "%s_%d" % ("batch_normalization" if norm == "batch" else "instance_normalization", nk)
 
         self.enc = []
         cin = in_channels
@@ -43,14 +53,19 @@ class UNetPlan:
             lv = []
             for mult in (1, 2):
                 cout = n_base_filters * (2 ** ld) * mult
-                lv.append(dict(name=conv_name(), cin=cin, cout=cout, level=ld))
+                lv.append(dict(name=conv_name(), cin=cin, cout=cout, level=ld, norm=norm_name() if norm else None))
                 cin = cout
             self.enc.append(lv)
         self.dec = []
+        self.up = {}          # decoder level -> transposed-conv descriptor (only with deconvolution=True)
         for ld in range(depth - 2, -1, -1):
             skip_c = self.enc[ld][1]["cout"]
-            a = dict(name=conv_name(), cin=cin + skip_c, cout=skip_c, level=ld, c_up=cin, c_skip=skip_c)
-            b = dict(name=conv_name(), cin=skip_c, cout=skip_c, level=ld)
+            if deconvolution:
+                tk += 1
+                self.up[ld] = dict(name="conv%s_transpose_%d" % (d, tk), cin=cin, cout=cin, level=ld)
+            a = dict(name=conv_name(), cin=cin + skip_c, cout=skip_c, level=ld, c_up=cin, c_skip=skip_c,
+                     norm=norm_name() if norm else None)
+            b = dict(name=conv_name(), cin=skip_c, cout=skip_c, level=ld, norm=norm_name() if norm else None)
             self.dec.append([a, b])
             cin = skip_c
         self.final = dict(name=conv_name(), cin=cin, cout=n_labels)
@@ -88,19 +103,28 @@ class UNetEngine:
     # ------------------------------------------------------------------------------------------------ parameters
     def _build_params(self, seed):
         p = self.plan
-        # backward-completion order: final, dec (shallowest level first, b before a), enc (deepest level first, b before a)
+        # backward-completion order: final, dec (shallowest level first: b, a, transposed conv), enc (deepest first, b before a)
         order = [("final", p.final)]
         for lv in reversed(p.dec):
             order += [("conv", lv[1]), ("conv", lv[0])]
+            if lv[0]["level"] in p.up:
+                order.append(("deconv", p.up[lv[0]["level"]]))
         for lv in reversed(p.enc):
             order += [("conv", lv[1]), ("conv", lv[0])]
         self.layout = OrderedDict()
         off = 0
+        ntap = {"conv": 27, "final": 1, "deconv": 8}
         for kind, c in order:
-            nw = (27 if kind == "conv" else 1) * c["cout"] * c["cin"]
+            nw = ntap[kind] * c["cout"] * c["cin"]
             off = (off + 3) & ~3
-            self.layout[c["name"]] = dict(kind=kind, w=(off, nw), b=(((off + nw + 3) & ~3), c["cout"]), cin=c["cin"], cout=c["cout"])
+            L = dict(kind=kind, w=(off, nw), b=(((off + nw + 3) & ~3), c["cout"]), cin=c["cin"], cout=c["cout"], norm=c.get("norm"))
             off = ((off + nw + 3) & ~3) + c["cout"]
+            if c.get("norm"):          # gamma, beta of the block's normalisation layer right behind the bias
+                off = (off + 3) & ~3
+                L["gamma"] = (off, c["cout"])
+                L["beta"] = (off + ((c["cout"] + 3) & ~3), c["cout"])
+                off = L["beta"][0] + c["cout"]
+            self.layout[c["name"]] = L
         self.n_flat = (off + 3) & ~3
         dev = self.dev
         self.P = torch.zeros(self.n_flat, dtype=torch.float32, device=dev)
@@ -110,8 +134,16 @@ class UNetEngine:
             self.V = torch.zeros_like(self.P)
         # compute-dtype copies of the 3x3x3 filters
         self.Wf, self.Wd = {}, {}
+        self.Wt = {}                      # compute-dtype copies of the transposed-conv filters [8][Cout][Cin]
+        self.moving = {}                  # batch-norm moving mean / variance (inference statistics), fp32 [2][C]
         first = p.enc[0][0]["name"]
         for name, L in self.layout.items():
+            if L["kind"] == "deconv":
+                self.Wt[name] = torch.empty((8, L["cout"], L["cin"]), dtype=self.dtype, device=dev)
+            if L.get("norm") and p.norm == "batch":
+                mv = torch.zeros((2, L["cout"]), dtype=torch.float32, device=dev)
+                mv[1].fill_(1.0)
+                self.moving[name] = mv
             if L["kind"] != "conv":
                 continue
             self.Wf[name] = torch.empty((27, L["cout"], L["cin"]), dtype=self.dtype, device=dev)
@@ -123,8 +155,14 @@ class UNetEngine:
         L = self.layout[name]
         buf = self.P if buf is None else buf
         o, n = L["w"]
-        shape = (27, L["cout"], L["cin"]) if L["kind"] == "conv" else (L["cout"], L["cin"])
+        shape = {"conv": (27, L["cout"], L["cin"]), "deconv": (8, L["cout"], L["cin"]), "final": (L["cout"], L["cin"])}[L["kind"]]
         return buf[o:o + n].view(shape)
+
+    def gb_view(self, name, which, buf=None):
+        """gamma / beta of the normalisation layer of conv block `name`"""
+        buf = self.P if buf is None else buf
+        o, n = self.layout[name][which]
+        return buf[o:o + n]
 
     def b_view(self, name, buf=None):
         L = self.layout[name]
@@ -137,9 +175,23 @@ class UNetEngine:
         rs = np.random.RandomState(seed)
         W = OrderedDict()
         k3, k1 = ((3, 3, 3), (1, 1, 1)) if self.plan.ndim == 3 else ((3, 3), (1, 1))
-        for c in self.plan.convs_forward_order():
+        k2 = (2, 2, 2) if self.plan.ndim == 3 else (2, 2)
+        p = self.plan
+        seq = [c for lv in p.enc for c in lv]
+        for lv in p.dec:                                  # Keras creation order: the transposed conv precedes its level's blocks
+            if lv[0]["level"] in p.up:
+                seq.append(dict(p.up[lv[0]["level"]], transpose=True))
+            seq += lv
+        for c in seq:
+            if c.get("transpose"):
+                W[c["name"] + "/kernel"] = _glorot(rs, k2 + (c["cout"], c["cin"]))      # Keras: (k,k,k,Cout,Cin)
+                W[c["name"] + "/bias"] = np.zeros(c["cout"], np.float32)
+                continue
             W[c["name"] + "/kernel"] = _glorot(rs, k3 + (c["cin"], c["cout"]))
             W[c["name"] + "/bias"] = np.zeros(c["cout"], np.float32)
+            if c.get("norm"):
+                W[c["norm"] + "/gamma"] = np.ones(c["cout"], np.float32)
+                W[c["norm"] + "/beta"] = np.zeros(c["cout"], np.float32)
         f = self.plan.final
         W[f["name"] + "/kernel"] = _glorot(rs, k1 + (f["cin"], f["cout"]))
         W[f["name"] + "/bias"] = np.zeros(f["cout"], np.float32)
@@ -150,10 +202,15 @@ class UNetEngine:
         host = np.zeros(self.n_flat, np.float32)
         for name, L in self.layout.items():
             k = np.asarray(W[name + "/kernel"], np.float32)
-            if k.ndim == 4:  # 2-D kernel (kH,kW,Cin,Cout) -> centre plane of a 3x3x3 / 1x1x1 kernel
+            if k.ndim == 4 and L["kind"] != "deconv":  # 2-D kernel (kH,kW,Cin,Cout) -> centre plane of a 3x3x3 / 1x1x1 kernel
                 k = _embed_2d_kernel(k)
             o, n = L["w"]
-            if L["kind"] == "conv":
+            if L["kind"] == "deconv":
+                kk = np.asarray(W[name + "/kernel"], np.float32)
+                if kk.ndim == 4:                                              # (2,2,Cout,Cin) -> taps 0..3 of the 8
+                    kk = np.concatenate([kk.reshape(4, L["cout"], L["cin"]), np.zeros((4, L["cout"], L["cin"]), np.float32)])
+                host[o:o + n] = kk.reshape(8, L["cout"], L["cin"]).reshape(-1)
+            elif L["kind"] == "conv":
                 assert k.shape == (3, 3, 3, L["cin"], L["cout"]), (name, k.shape)
                 host[o:o + n] = k.transpose(0, 1, 2, 4, 3).reshape(-1)        # -> [27][Cout][Cin]
             else:
@@ -161,17 +218,27 @@ class UNetEngine:
                 host[o:o + n] = k.reshape(L["cin"], L["cout"]).T.reshape(-1)  # -> [L][C]
             ob, nb = L["b"]
             host[ob:ob + nb] = np.asarray(W[name + "/bias"], np.float32)
+            if L.get("norm"):
+                host[L["gamma"][0]:L["gamma"][0] + nb] = np.asarray(W[L["norm"] + "/gamma"], np.float32)
+                host[L["beta"][0]:L["beta"][0] + nb] = np.asarray(W[L["norm"] + "/beta"], np.float32)
+                if name in self.moving and (L["norm"] + "/moving_mean") in W:
+                    self.moving[name][0].copy_(torch.from_numpy(np.asarray(W[L["norm"] + "/moving_mean"], np.float32)))
+                    self.moving[name][1].copy_(torch.from_numpy(np.asarray(W[L["norm"] + "/moving_variance"], np.float32)))
         self.P.copy_(torch.from_numpy(host))
         self.refresh_weight_copies()
 
     def export_keras_weights(self):
         host = self.P.detach().cpu().numpy()
         W = OrderedDict()
-        order = [c["name"] for c in self.plan.convs_forward_order()] + [self.plan.final["name"]]
+        order = [c["name"] for c in self.plan.convs_forward_order()] + [u["name"] for u in self.plan.up.values()] + [self.plan.final["name"]]
         for name in order:
             L = self.layout[name]
             o, n = L["w"]
-            if L["kind"] == "conv":
+            if L["kind"] == "deconv":
+                k = host[o:o + n].reshape(8, L["cout"], L["cin"])
+                W[name + "/kernel"] = (k.reshape(2, 2, 2, L["cout"], L["cin"]) if self.plan.ndim == 3
+                                       else k[:4].reshape(2, 2, L["cout"], L["cin"])).copy()
+            elif L["kind"] == "conv":
                 k = host[o:o + n].reshape(3, 3, 3, L["cout"], L["cin"]).transpose(0, 1, 2, 4, 3)
                 W[name + "/kernel"] = (k if self.plan.ndim == 3 else k[1]).copy()          # 2-D: the centre kd plane is the 3x3 kernel
             else:
@@ -179,11 +246,19 @@ class UNetEngine:
                 W[name + "/kernel"] = k.reshape(((1, 1, 1) if self.plan.ndim == 3 else (1, 1)) + (L["cin"], L["cout"])).copy()
             ob, nb = L["b"]
             W[name + "/bias"] = host[ob:ob + nb].copy()
+            if L.get("norm"):
+                W[L["norm"] + "/gamma"] = host[L["gamma"][0]:L["gamma"][0] + nb].copy()
+                W[L["norm"] + "/beta"] = host[L["beta"][0]:L["beta"][0] + nb].copy()
+                if name in self.moving:
+                    mv = self.moving[name].cpu().numpy()
+                    W[L["norm"] + "/moving_mean"], W[L["norm"] + "/moving_variance"] = mv[0].copy(), mv[1].copy()
         return W
 
     def refresh_weight_copies(self):
         for name in self.Wf:
             ops.pack_weights(self.w_view(name), self.Wf[name], self.Wd.get(name))
+        for name, wt in self.Wt.items():
+            ops.cast(self.w_view(name), wt)
 
     # ------------------------------------------------------------------------------------------------ buffers
     def set_batch(self, N):
@@ -193,10 +268,11 @@ class UNetEngine:
             self.N = N
             self._build_buffers()
             self._bufsets[key] = dict(act=self.act, grad=getattr(self, "grad", None), logits=self.logits, probs=self.probs,
-                                      dlogits=getattr(self, "dlogits", None),
+                                      dlogits=getattr(self, "dlogits", None), pre=self.pre, nstats=self.nstats, norm_ws=self.norm_ws,
                                       dummy_y=torch.zeros(self.logits.numel(), dtype=torch.uint8, device=self.dev))
         b = self._bufsets[key]
         self.N, self.act, self.grad, self.logits, self.probs, self.dlogits = N, b["act"], b["grad"], b["logits"], b["probs"], b["dlogits"]
+        self.pre, self.nstats, self.norm_ws = b["pre"], b["nstats"], b["norm_ws"]
         self._dummy_y = b["dummy_y"]       # per buffer set and never freed: captured hipGraphs keep raw pointers to it
 
     def _dims(self, level):
@@ -208,14 +284,30 @@ class UNetEngine:
     def _build_buffers(self):
         p, N, dt, dev = self.plan, self.N, self.dtype, self.dev
         A = self.act = {}
+        self.pre, self.nstats = {}, {}            # conv outputs before normalisation; saved statistics {mean, 1/s, 1/sigma}
+        G = N if (p.norm == "instance" and not self.planar) else 1
+        if p.norm == "instance" and self.planar:
+            G = N                                  # 2-D: every slice is a sample
+
+        def block_bufs(c):
+            A[c["name"]] = torch.empty(self._dims(c["level"]) + (c["cout"],), dtype=dt, device=dev)
+            if c.get("norm"):
+                self.pre[c["name"]] = torch.empty_like(A[c["name"]])
+                self.nstats[c["name"]] = torch.zeros((G, c["cout"], 3), dtype=torch.float32, device=dev)
+
         for lv in p.enc:
             for c in lv:
-                A[c["name"]] = torch.empty(self._dims(c["level"]) + (c["cout"],), dtype=dt, device=dev)
+                block_bufs(c)
         for ld in range(p.depth - 1):
             A["pool_%d" % ld] = torch.empty(self._dims(ld + 1) + (p.enc[ld][1]["cout"],), dtype=dt, device=dev)
         for lv in p.dec:
+            if lv[0]["level"] in p.up:
+                u = p.up[lv[0]["level"]]
+                A[u["name"]] = torch.empty(self._dims(u["level"]) + (u["cout"],), dtype=dt, device=dev)
             for c in lv:
-                A[c["name"]] = torch.empty(self._dims(c["level"]) + (c["cout"],), dtype=dt, device=dev)
+                block_bufs(c)
+        cmax = max(c["cout"] for c in p.convs_forward_order())
+        self.norm_ws = torch.zeros((max(G, 1), cmax, 2), dtype=torch.float64, device=dev) if p.norm else None
         nvox0 = int(np.prod(self._dims(0)))
         self.logits = torch.empty((nvox0, p.n_labels), dtype=torch.float32, device=dev)
         self.probs = torch.empty_like(self.logits)
@@ -225,34 +317,69 @@ class UNetEngine:
             return
         Gd = self.grad = {}
         for name, t in A.items():
-            if name.startswith("pool_"):
-                Gd[name] = torch.empty_like(t)        # gradient w.r.t. the pooled tensor (un-masked)
-            else:
-                Gd[name] = torch.empty_like(t)        # gradient w.r.t. the conv's pre-activation
+            Gd[name] = torch.empty_like(t)            # gradient w.r.t. the tensor (conv blocks: w.r.t. the pre-activation)
         for lv in p.dec:
             a = lv[0]
             Gd["cat_%d" % a["level"]] = torch.empty(self._dims(a["level"]) + (a["cin"],), dtype=dt, device=dev)
         self.dlogits = torch.empty_like(self.logits)
 
     # ------------------------------------------------------------------------------------------------ forward
-    def forward(self, x):
+    def _norm_mode(self):
+        """(per_instance, eps_on_std) of fmri_norm_act_fwd for this plan"""
+        return (1, True) if self.plan.norm == "instance" else (0, False)
+
+    def _as_samples(self, t):
+        """view [N][D][H][W][C] as [samples][voxels...][C] for the normalisation kernels (2-D: slices are the samples)"""
+        return t.reshape((t.shape[1],) + tuple(t.shape[2:])) if self.planar else t
+
+    def _block_fwd(self, c, src0, src1, up0, bn_training):
+        """one [conv -> (norm) -> ReLU] block (reference create_convolution_block, unet.py:89-115)"""
+        name = c["name"]
+        if not c.get("norm"):
+            ops.conv3d_fwd(src0, src1, self.Wf[name], self.b_view(name), self.act[name], up0=up0, act=ACT_RELU, planar=self.planar)
+            return self.act[name]
+        ops.conv3d_fwd(src0, src1, self.Wf[name], self.b_view(name), self.pre[name], up0=up0, act=ACT_NONE, planar=self.planar)
+        per, eos = self._norm_mode()
+        st = self.nstats[name]
+        if self.plan.norm == "batch" and not bn_training:
+            mv = self.moving[name]                                            # inference: moving averages (Keras learning_phase 0)
+            st[0, :, 0] = mv[0]
+            st[0, :, 1] = torch.rsqrt(mv[1] + 1e-3)
+            st[0, :, 2] = st[0, :, 1]
+            per = -1
+        ops.norm_act_fwd(self._as_samples(self.pre[name]), self.gb_view(name, "gamma"), self.gb_view(name, "beta"),
+                         self._as_samples(self.act[name]), st, self.norm_ws, per, eps=1e-3, eps_on_std=eos, act=ACT_RELU)
+        if self.plan.norm == "batch" and bn_training:
+            # Keras moving statistics (momentum 0.99); the variance fed to the moving average is sample-size corrected
+            M = float(self.pre[name].numel() // c["cout"])
+            mv = self.moving[name]
+            var = (1.0 / (st[0, :, 1] * st[0, :, 1]) - 1e-3) * (M / max(M - (1.0 + 1e-3), 1.0))
+            mv[0].mul_(0.99).add_(st[0, :, 0], alpha=0.01)
+            mv[1].mul_(0.99).add_(var, alpha=0.01)
+        return self.act[name]
+
+    def forward(self, x, bn_training=None):
         """x: [N,D,H,W,Cin] compute dtype, device.  Leaves logits (fp32 [nvox, L]) in self.logits."""
         p, A = self.plan, self.act
         assert tuple(x.shape) == self._dims(0) + (p.in_channels,), (x.shape,)
+        bn_training = self.training if bn_training is None else bn_training
         self.x_in = x
         h = x
         for ld, lv in enumerate(p.enc):
             for c in lv:
-                ops.conv3d_fwd(h, None, self.Wf[c["name"]], self.b_view(c["name"]), A[c["name"]], act=ACT_RELU, planar=self.planar)
-                h = A[c["name"]]
+                h = self._block_fwd(c, h, None, False, bn_training)
             if ld < p.depth - 1:
                 h = ops.maxpool_fwd(h, A["pool_%d" % ld], planar=self.planar)
         for lv in p.dec:
             a, b = lv
             skip = A[p.enc[a["level"]][1]["name"]]
-            ops.conv3d_fwd(h, skip, self.Wf[a["name"]], self.b_view(a["name"]), A[a["name"]], up0=True, act=ACT_RELU, planar=self.planar)
-            ops.conv3d_fwd(A[a["name"]], None, self.Wf[b["name"]], self.b_view(b["name"]), A[b["name"]], act=ACT_RELU, planar=self.planar)
-            h = A[b["name"]]
+            if a["level"] in p.up:
+                u = p.up[a["level"]]
+                ops.deconv_fwd(h, self.Wt[u["name"]], self.b_view(u["name"]), A[u["name"]], planar=self.planar)
+                self._block_fwd(a, A[u["name"]], skip, False, bn_training)
+            else:
+                self._block_fwd(a, h, skip, True, bn_training)
+            h = self._block_fwd(b, A[a["name"]], None, False, bn_training)
         f = p.final
         ops.conv1x1_fwd(h, self.w_view(f["name"]), self.b_view(f["name"]), self.logits)
         return self.logits
@@ -266,38 +393,63 @@ class UNetEngine:
         return self.sums
 
     def predict(self, x):
-        self.forward(x)
+        self.forward(x, bn_training=False)
         self.sums.zero_()
         # sigmoid only (y_true is irrelevant for probs): reuse the fused kernel with an all-zero label buffer
         ops.sigmoid_dice_fwd(self.logits, self._dummy_y, self.probs, self.sums)
         return self.probs
 
     # ------------------------------------------------------------------------------------------------ backward
+    def _block_bwd(self, c, src0, src1, up0):
+        """G[c] holds dL/d(output of the block) (already ReLU-masked when the block has no norm).  Leaves dL/d(conv output) in
+        G[c] and accumulates the block's parameter gradients."""
+        name = c["name"]
+        g = self.grad[name]
+        if c.get("norm"):
+            per, _ = self._norm_mode()
+            ops.norm_act_bwd(self._as_samples(self.pre[name]), self._as_samples(self.act[name]), self._as_samples(g),
+                             self.gb_view(name, "gamma"), self.nstats[name], self._as_samples(g), self.gb_view(name, "gamma", self.G),
+                             self.gb_view(name, "beta", self.G), self.norm_ws, per, act=ACT_RELU)
+        ops.conv3d_wgrad(src0, src1, g, self.w_view(name, self.G), self.b_view(name, self.G), up0=up0, planar=self.planar)
+        self._grad_ready(name)
+
+    def _mask_of(self, name):
+        """ReLU mask tensor a consumer applies to the gradient of `name`'s output, or None when the block is normalised (its
+        norm backward applies the activation derivative itself) or `name` is not a conv block."""
+        if name in self.pre:
+            return None
+        return self.act.get(name)
+
     def backward(self, y_true, grad_scale=1.0):
         p, A, Gd = self.plan, self.act, self.grad
+        normed = p.norm is not None
         self.G.zero_()
         ops.sigmoid_dice_bwd(self.probs, y_true, self.sums, self.dlogits, smooth=1.0, grad_scale=grad_scale)
         f = p.final
         last = p.dec[-1][1] if p.dec else p.enc[-1][1]
         ops.conv1x1_bwd(A[last["name"]], self.w_view(f["name"]), self.dlogits, Gd[last["name"]], self.w_view(f["name"], self.G),
-                        self.b_view(f["name"], self.G), relu_mask=True)
+                        self.b_view(f["name"], self.G), relu_mask=not normed)
         self._grad_ready(f["name"])
         # decoder, shallowest level first
         for lv in reversed(p.dec):
             a, b = lv
             ld = a["level"]
-            # block b: input = A[a]
-            ops.conv3d_wgrad(A[a["name"]], None, Gd[b["name"]], self.w_view(b["name"], self.G), self.b_view(b["name"], self.G), planar=self.planar)
-            self._grad_ready(b["name"])
-            ops.conv3d_dgrad(Gd[b["name"]], self.Wd[b["name"]], Gd[a["name"]], mask=A[a["name"]], planar=self.planar)
-            # block a: input = [up(low) | skip]
             low = self._dec_input_name(ld)
             skip = A[p.enc[ld][1]["name"]]
-            ops.conv3d_wgrad(A[low], skip, Gd[a["name"]], self.w_view(a["name"], self.G), self.b_view(a["name"], self.G), up0=True, planar=self.planar)
-            self._grad_ready(a["name"])
+            self._block_bwd(b, A[a["name"]], None, False)
+            ops.conv3d_dgrad(Gd[b["name"]], self.Wd[b["name"]], Gd[a["name"]], mask=self._mask_of(a["name"]), planar=self.planar)
             cat = Gd["cat_%d" % ld]
-            ops.conv3d_dgrad(Gd[a["name"]], self.Wd[a["name"]], cat, planar=self.planar)
-            ops.upsample_bwd(cat, Gd[low], dy_off=0, xmask=A[low], planar=self.planar)
+            if ld in p.up:
+                u = p.up[ld]
+                self._block_bwd(a, A[u["name"]], skip, False)
+                ops.conv3d_dgrad(Gd[a["name"]], self.Wd[a["name"]], cat, planar=self.planar)
+                ops.deconv_bwd(A[low], self.Wt[u["name"]], cat, Gd[low], self.w_view(u["name"], self.G), self.b_view(u["name"], self.G),
+                               dy_off=0, xmask=self._mask_of(low), planar=self.planar)
+                self._grad_ready(u["name"])
+            else:
+                self._block_bwd(a, A[low], skip, True)
+                ops.conv3d_dgrad(Gd[a["name"]], self.Wd[a["name"]], cat, planar=self.planar)
+                ops.upsample_bwd(cat, Gd[low], dy_off=0, xmask=self._mask_of(low), planar=self.planar)
         # encoder, deepest level first
         for ld in range(p.depth - 1, -1, -1):
             ca, cb = p.enc[ld]
@@ -305,14 +457,11 @@ class UNetEngine:
                 # gradient of enc[ld].b output = pooled path + skip path, masked by its ReLU
                 cat = Gd["cat_%d" % ld]
                 ops.maxpool_bwd(A[cb["name"]], Gd["pool_%d" % ld], Gd[cb["name"]], add=cat, add_off=cat.shape[-1] - cb["cout"],
-                                relu_mask=True, planar=self.planar)
-            ops.conv3d_wgrad(A[ca["name"]], None, Gd[cb["name"]], self.w_view(cb["name"], self.G), self.b_view(cb["name"], self.G),
-                             planar=self.planar)
-            self._grad_ready(cb["name"])
-            ops.conv3d_dgrad(Gd[cb["name"]], self.Wd[cb["name"]], Gd[ca["name"]], mask=A[ca["name"]], planar=self.planar)
+                                relu_mask=not normed, planar=self.planar)
+            self._block_bwd(cb, A[ca["name"]], None, False)
+            ops.conv3d_dgrad(Gd[cb["name"]], self.Wd[cb["name"]], Gd[ca["name"]], mask=self._mask_of(ca["name"]), planar=self.planar)
             xin = self.x_in if ld == 0 else A["pool_%d" % (ld - 1)]
-            ops.conv3d_wgrad(xin, None, Gd[ca["name"]], self.w_view(ca["name"], self.G), self.b_view(ca["name"], self.G), planar=self.planar)
-            self._grad_ready(ca["name"])
+            self._block_bwd(ca, xin, None, False)
             if ld > 0:
                 ops.conv3d_dgrad(Gd[ca["name"]], self.Wd[ca["name"]], Gd["pool_%d" % (ld - 1)], planar=self.planar)
         if self.dist is not None:

@@ -197,12 +197,20 @@ def forward(spec, Wt, x, return_intermediates=False):
 
     def block(h, b):
         h = _conv(h, Wt[b["name"] + "/kernel"], Wt[b["name"] + "/bias"], nd)
+        if return_intermediates:
+            inter[b["name"] + "/pre"] = h
+            if h.requires_grad:
+                h.retain_grad()
         if b.get("bn"):
             h = _batchnorm_train(h, Wt[b["bn"] + "/gamma"], Wt[b["bn"] + "/beta"])
         elif b.get("inn"):
             h = _instancenorm(h, Wt[b["inn"] + "/gamma"], Wt[b["inn"] + "/beta"])
+        if return_intermediates:
+            inter[b["name"] + "/z"] = h.detach()           # pre-activation (tests use it to avoid ReLU-boundary ties)
         h = F.relu(h)
         inter[b["name"]] = h
+        if return_intermediates and h.requires_grad:
+            h.retain_grad()
         return h
 
     h = x

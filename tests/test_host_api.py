@@ -169,7 +169,7 @@ def test_nifti_roundtrip(tmp_path):
 
 
 def test_unsupported_topologies_fail_loudly():
-    m = fmodel.unet_model_3d(input_shape=(1, 16, 16, 16), depth=2, deconvolution=True)
+    m = fmodel.unet_model_3d(input_shape=(1, 16, 16, 16), depth=2, activation_name="softmax")
     with pytest.raises(NotImplementedError):
         m.predict(np.zeros((1, 1, 16, 16, 16)))
     with pytest.raises(NotImplementedError):
