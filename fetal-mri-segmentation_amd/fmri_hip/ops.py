@@ -199,3 +199,35 @@ def deconv_bwd(x, w, dy, dx, dw, db, dy_off=0, xmask=None, planar=False):
     Cout = w.shape[1]
     check(lib().fmri_deconv3d_k2s2_bwd(_p(x), _p(w), _p(dy), dy.shape[-1], dy_off, _p(xmask), _p(dx), _p(dw), _p(db), N, D, H, W, Cin,
                                        Cout, dt(x), int(planar), _s()), "fmri_deconv3d_k2s2_bwd")
+
+
+def conv_direct_fwd(x, w, bias, y, ksize, stride, act=ACT_NONE, alpha=0.0):
+    """x [N,D,H,W,Cin], w [k^3,Cout,Cin] (compute dtype), y [N,ceil(D/s),ceil(H/s),ceil(W/s),Cout]"""
+    _need_cuda(x, w, bias, y)
+    N, D, H, W, Cin = x.shape
+    Cout = w.shape[1]
+    check(lib().fmri_conv3d_direct_fwd(_p(x), _p(w), _p(bias), _p(y), N, D, H, W, Cin, Cout, ksize, stride, act, float(alpha), dt(x), _s()),
+          "fmri_conv3d_direct_fwd")
+    return y
+
+
+def conv_direct_bwd(x, w, dy, dx, dw, db, ksize, stride):
+    _need_cuda(x, w, dy, dx, dw, db)
+    N, D, H, W, Cin = x.shape
+    Cout = w.shape[1]
+    check(lib().fmri_conv3d_direct_bwd(_p(x), _p(w), _p(dy), _p(dx), _p(dw), _p(db), N, D, H, W, Cin, Cout, ksize, stride, dt(x), _s()),
+          "fmri_conv3d_direct_bwd")
+
+
+def add(a, b, y):
+    _need_cuda(a, b, y)
+    check(lib().fmri_add(_p(a), _p(b), _p(y), a.numel(), dt(a), _s()), "fmri_add")
+    return y
+
+
+def channel_scale(x, scale, y):
+    """x,y [N,...,C]; scale fp32 [N,C]"""
+    _need_cuda(x, scale, y)
+    N, Cc = x.shape[0], x.shape[-1]
+    check(lib().fmri_channel_scale(_p(x), _p(scale), _p(y), N, x.numel() // (N * Cc), Cc, dt(x), _s()), "fmri_channel_scale")
+    return y

@@ -124,6 +124,19 @@ int fmri_deconv3d_k2s2_fwd(const void* x, const void* w, const float* b, void* y
 int fmri_deconv3d_k2s2_bwd(const void* x, const void* w, const void* dy, int dy_ld, int dy_off, const void* xmask, void* dx, float* dw,
                            float* db, int N, int D, int H, int W, int Cin, int Cout, int dtype, int planar, fmri_stream_t stream);
 
+/* ---- Conv3D with kernel 1x1x1 (any Cin -> Cout) or 3x3x3 stride 2, 'same' (TensorFlow padding: even extent 0 before / 1
+ * after) — reference isensee2017.py:51 (strides=(2,2,2)), :95-98 (1x1x1 localisation conv), :66 (segmentation heads).
+ * x [N][D][H][W][Cin], w [k^3][Cout][Cin] (dtype), y [N][ceil(D/s)][ceil(H/s)][ceil(W/s)][Cout]. */
+int fmri_conv3d_direct_fwd(const void* x, const void* w, const float* bias, void* y, int N, int D, int H, int W, int Cin, int Cout,
+                           int ksize, int stride, int act, float alpha, int dtype, fmri_stream_t stream);
+/* dx (optional) = input gradient; dw [k^3][Cout][Cin], db [Cout] fp32 ACCUMULATED (optional). */
+int fmri_conv3d_direct_bwd(const void* x, const void* w, const void* dy, void* dx, float* dw, float* db, int N, int D, int H, int W,
+                           int Cin, int Cout, int ksize, int stride, int dtype, fmri_stream_t stream);
+/* y = a + b (residual Add, reference isensee2017.py:55; gradient fan-in of multiply-consumed tensors) */
+int fmri_add(const void* a, const void* b, void* y, int64_t n, int dtype, fmri_stream_t stream);
+/* y[n][v][c] = x[n][v][c] * scale[n][c] — SpatialDropout3D (reference isensee2017.py:109): the host draws the 0 | 1/(1-p) mask */
+int fmri_channel_scale(const void* x, const float* scale, void* y, int N, int64_t V, int C, int dtype, fmri_stream_t stream);
+
 /* ---- Keras Adam.get_updates — reference unet.py:85.  lr_t = lr*sqrt(1-b2^t)/(1-b1^t) is computed by the host.
  * g is multiplied by grad_scale first.  p -= lr_t * m/(sqrt(v)+eps). One launch over the flat parameter buffer. */
 int fmri_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr_t, float beta1, float beta2,

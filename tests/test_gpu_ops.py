@@ -403,3 +403,50 @@ def test_deconv_k2s2_fwd_bwd(ops, dtype, planar):
     assert_close(dx, to_ndhwc(xr.grad) * (f64(x) > 0), *tolb, what="deconv dx")
     assert_close(dw[:nt], wr.grad[:nt], *tolb, what="deconv dw")
     assert_close(dbg, br.grad, *tolb, what="deconv db")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("k,s,dims", [(1, 1, (3, 4, 5)), (3, 2, (4, 6, 8)), (3, 2, (5, 7, 6)), (3, 1, (3, 4, 5))])
+def test_conv_direct_fwd_bwd(ops, dtype, k, s, dims):
+    """kernel 1 / stride 2 convolutions with TensorFlow 'same' padding (even extent: 0 before, 1 after)"""
+    N, Cin, Cout = 2, 6, 5
+    D, H, W = dims
+    x = rnd((N, D, H, W, Cin), 100, dtype)
+    w = rnd((k ** 3, Cout, Cin), 101, dtype, scale=0.3)
+    b = rnd((Cout,), 102, torch.float32)
+    od = [-(-n // s) for n in dims]
+    y = torch.empty((N,) + tuple(od) + (Cout,), dtype=dtype, device="cuda")
+    ops.conv_direct_fwd(x, w, b, y, k, s, act=0)
+    xr = to_ncdhw(f64(x)).requires_grad_(True)
+    wr = f64(w).requires_grad_(True)
+    br = f64(b).requires_grad_(True)
+    pads = []
+    for n_, o_ in zip(reversed(dims), reversed(od)):           # F.pad wants (w_before, w_after, h_before, h_after, d_before, d_after)
+        tot = max((o_ - 1) * s + k - n_, 0)
+        pads += [tot // 2, tot - tot // 2]
+    yr = F.conv3d(F.pad(xr, pads), wr.reshape(k, k, k, Cout, Cin).permute(3, 4, 0, 1, 2), br, stride=s)
+    torch.cuda.synchronize()
+    assert_close(y, to_ndhwc(yr.detach()), *TOL[dtype], what="direct fwd")
+    dy = rnd(tuple(y.shape), 103, dtype)
+    dx = torch.empty_like(x)
+    dw = torch.zeros((k ** 3, Cout, Cin), device="cuda")
+    db = torch.zeros(Cout, device="cuda")
+    ops.conv_direct_bwd(x, w, dy, dx, dw, db, k, s)
+    torch.cuda.synchronize()
+    yr.backward(to_ncdhw(f64(dy)))
+    tolb = (1e-4, 1e-5) if dtype == torch.float32 else (1e-2, 1e-2)
+    assert_close(dx, to_ndhwc(xr.grad), *tolb, what="direct dx")
+    assert_close(dw, wr.grad, *tolb, what="direct dw")
+    assert_close(db, br.grad, *tolb, what="direct db")
+
+
+def test_add_and_channel_scale(ops):
+    a, b = rnd((2, 3, 4, 5, 8), 110, torch.bfloat16), rnd((2, 3, 4, 5, 8), 111, torch.bfloat16)
+    y = torch.empty_like(a)
+    ops.add(a, b, y)
+    sc = (torch.rand(2, 8, generator=torch.Generator().manual_seed(1)) > 0.3).float().cuda() / 0.7
+    z = torch.empty_like(a)
+    ops.channel_scale(a, sc, z)
+    torch.cuda.synchronize()
+    assert torch.equal(y, (a.float() + b.float()).to(torch.bfloat16))
+    assert torch.equal(z, (a.float() * sc[:, None, None, None, :]).to(torch.bfloat16))
