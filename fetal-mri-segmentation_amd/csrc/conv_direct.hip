@@ -119,6 +119,30 @@ __global__ void k_channel_scale(const T* __restrict__ x, const float* __restrict
     }
 }
 
+// dst[v][c] (+)= src[v*ld + off + c]: channel slice of a wider tensor (split of a concat gradient, gradient fan-in)
+template <typename T>
+__global__ void k_slice(const T* __restrict__ src, int ld, int off, T* __restrict__ dst, int C, int64_t total, int accumulate) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const int64_t v = i / C;
+        float val = to_f<T>(src[v * ld + off + c]);
+        if (accumulate) val += to_f<T>(dst[i]);
+        dst[i] = from_f<T>(val);
+    }
+}
+
+// dx = dy * act'(y)  (ReLU / LeakyReLU derivative from the stored post-activation tensor)
+template <typename T>
+__global__ void k_act_bwd(const T* __restrict__ y, const T* __restrict__ dy, T* __restrict__ dx, int act, float alpha, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float d = to_f<T>(dy[i]);
+        const float yy = to_f<T>(y[i]);
+        if (act == FMRI_ACT_RELU) d = yy > 0.f ? d : 0.f;
+        else if (act == FMRI_ACT_LEAKY) d = yy > 0.f ? d : alpha * d;
+        dx[i] = from_f<T>(d);
+    }
+}
+
 bool make_geo(Geo& g, int N, int D, int H, int W, int Cin, int Cout, int k, int s, int planar) {
     if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || (k != 1 && k != 3) || (s != 1 && s != 2)) return false;
     auto pad_before = [&](int n) { int out = (n + s - 1) / s; int tot = (out - 1) * s + k - n; if (tot < 0) tot = 0; return tot / 2; };
@@ -179,6 +203,28 @@ extern "C" int fmri_channel_scale(const void* x, const float* scale, void* y, in
     const int grid = grid_for(total, 256, 4096);
     if (dtype == FMRI_F32) k_channel_scale<float><<<grid, 256, 0, as_stream(stream)>>>((const float*)x, scale, (float*)y, V, C, total);
     else if (dtype == FMRI_BF16) k_channel_scale<bf16_t><<<grid, 256, 0, as_stream(stream)>>>((const bf16_t*)x, scale, (bf16_t*)y, V, C, total);
+    else return FMRI_E_DTYPE;
+    FMRI_LAUNCH_CHECK();
+    return FMRI_OK;
+}
+
+extern "C" int fmri_slice_channels(const void* src, int ld, int off, void* dst, int C, int64_t nvox, int accumulate, int dtype,
+                                   fmri_stream_t stream) {
+    if (nvox <= 0 || C <= 0 || ld < off + C) return FMRI_E_SHAPE;
+    const int64_t total = nvox * C;
+    const int grid = grid_for(total, 256, 4096);
+    if (dtype == FMRI_F32) k_slice<float><<<grid, 256, 0, as_stream(stream)>>>((const float*)src, ld, off, (float*)dst, C, total, accumulate);
+    else if (dtype == FMRI_BF16) k_slice<bf16_t><<<grid, 256, 0, as_stream(stream)>>>((const bf16_t*)src, ld, off, (bf16_t*)dst, C, total, accumulate);
+    else return FMRI_E_DTYPE;
+    FMRI_LAUNCH_CHECK();
+    return FMRI_OK;
+}
+
+extern "C" int fmri_act_bwd(const void* y, const void* dy, void* dx, int act, float alpha, int64_t n, int dtype, fmri_stream_t stream) {
+    if (n <= 0) return FMRI_E_SHAPE;
+    const int grid = grid_for(n, 256, 4096);
+    if (dtype == FMRI_F32) k_act_bwd<float><<<grid, 256, 0, as_stream(stream)>>>((const float*)y, (const float*)dy, (float*)dx, act, alpha, n);
+    else if (dtype == FMRI_BF16) k_act_bwd<bf16_t><<<grid, 256, 0, as_stream(stream)>>>((const bf16_t*)y, (const bf16_t*)dy, (bf16_t*)dx, act, alpha, n);
     else return FMRI_E_DTYPE;
     FMRI_LAUNCH_CHECK();
     return FMRI_OK;

@@ -314,7 +314,6 @@ class Model(object):
         if not torch.cuda.is_available():
             raise RuntimeError("no GPU visible: the fetal_net hot path has no CPU implementation")
         if self._engine is None:
-            plan = UNetPlan(**self._plan_args)
             dist_ctx = None
             try:
                 import torch.distributed as dist
@@ -323,7 +322,11 @@ class Model(object):
                     dist_ctx = DataParallel()
             except Exception:
                 dist_ctx = None
-            self._engine = UNetEngine(plan, batch, dtype=self._compute_dtype(), training=True, dist_ctx=dist_ctx)
+            if getattr(self, "_graph_engine", False):
+                from fmri_hip.graph_engine import LayerGraphEngine
+                self._engine = LayerGraphEngine(self.layers, batch, dtype=self._compute_dtype(), training=True, dist_ctx=dist_ctx)
+            else:
+                self._engine = UNetEngine(UNetPlan(**self._plan_args), batch, dtype=self._compute_dtype(), training=True, dist_ctx=dist_ctx)
             if self._pending_weights is not None:
                 self._engine.load_keras_weights(self._pending_weights)
                 self._pending_weights = None

@@ -1,6 +1,7 @@
 """Builders looked up by name: `getattr(fetal_net.model, config['model_name'])` (reference fetal/train_fetal.py:32,
 fetal_net/model/__init__.py:3-18).  Only the hot-path builders are provided."""
 from .unet3d.unet import unet_model_3d
+from .unet3d.isensee2017 import isensee2017_model_3d
 from .unet.unet import unet_model_2d
 
 
@@ -11,5 +12,4 @@ def _not_yet(name, anchor):
     return f
 
 
-isensee2017_model_3d = _not_yet("isensee2017_model_3d", "fetal_net/model/unet3d/isensee2017.py:15-111")
 isensee2017_model = _not_yet("isensee2017_model", "fetal_net/model/unet/isensee.py")

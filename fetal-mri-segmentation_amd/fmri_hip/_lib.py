@@ -44,6 +44,8 @@ SIGNATURES = {
     "fmri_conv3d_direct_fwd": [p, p, p, p, i32, i32, i32, i32, i32, i32, i32, i32, i32, f32, i32, p],
     "fmri_conv3d_direct_bwd": [p, p, p, p, p, p, i32, i32, i32, i32, i32, i32, i32, i32, i32, p],
     "fmri_add": [p, p, p, i64, i32, p],
+    "fmri_act_bwd": [p, p, p, i32, f32, i64, i32, p],
+    "fmri_slice_channels": [p, i32, i32, p, i32, i64, i32, i32, p],
     "fmri_channel_scale": [p, p, p, i32, i64, i32, i32, p],
     "fmri_adam_step": [p, p, p, p, i64, f32, f32, f32, f32, f32, p],
     "fmri_tile_gather": [p, i32, i32, i32, p, i32, i32, i32, i32, p, i32, p],

@@ -1,0 +1,426 @@
+"""Generic executor for a recorded Keras-style layer graph (fetal_net.model.graph.Graph) on the C ABI.
+
+The hand-scheduled `UNetEngine` stays the path of the headline U-Net; this interpreter runs any graph made of the layer
+classes the reference's 3-D builders emit — Conv3D (3x3x3 stride 1|2, 1x1x1), InstanceNormalization / BatchNormalization,
+LeakyReLU / Activation('relu'|'sigmoid'), MaxPooling3D, UpSampling3D, Concatenate, Add, SpatialDropout3D — i.e. the Isensee
+model of reference fetal_net/model/unet3d/isensee2017.py:15-111 (and, for cross-checking, unet_model_3d).
+
+Compile-time fusions (nothing of the fused kind is ever materialised):
+  * UpSampling3D -> Conv3D(3x3x3)          => conv reads its source through the fused nearest x2 (up0)
+  * Concatenate([a, b]) -> Conv3D(3x3x3)   => dual-source conv
+  * Norm -> LeakyReLU | Activation('relu') => fmri_norm_act_fwd/bwd
+  * Conv3D -> Activation('relu')           => activation in the conv epilogue
+Backward walks the op list in reverse; a tensor with several consumers receives its gradient contributions through
+`first writes, later ones accumulate`.  Parameters/gradients/Adam state are flat fp32 buffers like in UNetEngine.
+"""
+import math
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import ops
+from ._lib import ACT_LEAKY, ACT_NONE, ACT_RELU, lib
+
+LEAKY_ALPHA = 0.3      # keras.layers.LeakyReLU default (reference isensee2017.py:12)
+
+
+class _Dims(object):
+    def __init__(self, spatial, n_labels):
+        self.spatial, self.n_labels, self.ndim = tuple(spatial), n_labels, 3
+
+    def level_dims(self, level, slices=1):
+        return tuple(s >> level for s in self.spatial)
+
+
+class LayerGraphEngine(object):
+    def __init__(self, layers, batch, dtype=torch.bfloat16, device="cuda", seed=42, training=True, dist_ctx=None):
+        lib()
+        self.layers = list(layers)
+        self.by_name = OrderedDict((l.name, l) for l in self.layers)
+        self.dtype, self.dev, self.training, self.dist = dtype, torch.device(device), training, dist_ctx
+        self.planar = False
+        self.t = 0
+        self._fixed_drop = None
+        self.sums = torch.zeros(8, dtype=torch.float64, device=self.dev)
+        self._compile()
+        self._build_params(seed)
+        self._bufsets = {}
+        self.set_batch(batch)
+
+    # ------------------------------------------------------------------------------------------------ compile
+    def _compile(self):
+        L = self.layers
+        consumers = {l.name: [] for l in L}
+        for l in L:
+            for i in l.inbound:
+                consumers[i].append(l.name)
+        self.consumers = consumers
+        absorbed = set()          # layers that never get a tensor of their own
+        self.ops = []             # dicts: kind, out, ins, + params
+        self.alias = {}           # layer name -> tensor name that holds its value
+        out_layer = L[-1]
+        if not (out_layer.class_name == "Activation" and out_layer.config.get("activation") == "sigmoid"):
+            raise NotImplementedError("the graph must end in Activation('sigmoid')")
+        self.logits_src = out_layer.inbound[0]
+        self.input_name = L[0].name
+        in_shape = L[0].output_shape                      # (None, C, X, Y, Z)
+        self.in_channels = in_shape[1]
+        self.plan = _Dims(in_shape[2:], out_layer.output_shape[1])
+        self.shape = {l.name: (l.output_shape[1],) + tuple(l.output_shape[2:]) for l in L}   # (C, D, H, W)
+        self.convs, self.norms = OrderedDict(), OrderedDict()
+
+        def single_consumer(name, cls=None):
+            c = consumers[name]
+            return len(c) == 1 and (cls is None or self.by_name[c[0]].class_name in cls)
+
+        # producers that a later 3x3x3 stride-1 conv reads through (fused up-sampling / concatenation): decided up front because
+        # they precede their consumer in the layer list
+        for l in L:
+            if l.class_name == "Conv3D" and tuple(l.config["kernel_size"]) == (3, 3, 3) and tuple(l.config.get("strides") or (1, 1, 1)) == (1, 1, 1):
+                src = self.by_name[l.inbound[0]]
+                if src.class_name == "UpSampling3D" and single_consumer(src.name):
+                    absorbed.add(src.name)
+                elif src.class_name == "Concatenate" and len(src.inbound) == 2 and single_consumer(src.name):
+                    absorbed.add(src.name)
+        for l in L:
+            if l.name in absorbed or l is out_layer:
+                continue
+            cn = l.class_name
+            if cn == "InputLayer":
+                continue
+            if cn == "Conv3D":
+                k, s = tuple(l.config["kernel_size"]), tuple(l.config.get("strides") or (1, 1, 1))
+                src = self.by_name[l.inbound[0]]
+                op = dict(kind="conv", name=l.name, out=l.name, k=k[0], s=s[0], act=ACT_NONE, up0=False, ins=[l.inbound[0]])
+                if k == (3, 3, 3) and s == (1, 1, 1):
+                    if src.class_name == "UpSampling3D" and single_consumer(src.name):
+                        absorbed.add(src.name)
+                        op["ins"], op["up0"] = [src.inbound[0]], True
+                    elif src.class_name == "Concatenate" and len(src.inbound) == 2 and single_consumer(src.name):
+                        absorbed.add(src.name)
+                        op["ins"] = list(src.inbound)
+                nxt = self.by_name[consumers[l.name][0]] if single_consumer(l.name) else None
+                if nxt is not None and nxt.class_name == "Activation" and nxt.config.get("activation") == "relu":
+                    absorbed.add(nxt.name)
+                    op["act"], op["out"] = ACT_RELU, nxt.name
+                self.convs[l.name] = op
+                self.ops.append(op)
+            elif cn in ("InstanceNormalization", "BatchNormalization"):
+                op = dict(kind="norm", name=l.name, out=l.name, ins=[l.inbound[0]], instance=(cn == "InstanceNormalization"), act=ACT_NONE)
+                nxt = self.by_name[consumers[l.name][0]] if single_consumer(l.name) else None
+                if nxt is not None and (nxt.class_name == "LeakyReLU" or (nxt.class_name == "Activation" and nxt.config.get("activation") == "relu")):
+                    absorbed.add(nxt.name)
+                    op["act"], op["out"] = (ACT_LEAKY if nxt.class_name == "LeakyReLU" else ACT_RELU), nxt.name
+                self.norms[l.name] = op
+                self.ops.append(op)
+            elif cn == "Add":
+                self.ops.append(dict(kind="add", out=l.name, ins=list(l.inbound)))
+            elif cn == "SpatialDropout3D":
+                self.ops.append(dict(kind="dropout", out=l.name, ins=[l.inbound[0]], rate=float(l.config.get("rate", 0.0))))
+            elif cn == "UpSampling3D":
+                self.ops.append(dict(kind="upsample", out=l.name, ins=[l.inbound[0]]))
+            elif cn == "MaxPooling3D":
+                self.ops.append(dict(kind="maxpool", out=l.name, ins=[l.inbound[0]]))
+            elif cn == "Concatenate":
+                raise NotImplementedError("Concatenate is only supported in front of a 3x3x3 Conv3D (layer %s)" % l.name)
+            else:
+                raise NotImplementedError("layer class %s (%s) is not executable on the engine yet" % (cn, l.name))
+        for o in self.ops:                                   # shapes of op outputs follow the layer whose name they carry
+            o["shape"] = self.shape[o["out"]]
+
+    # ------------------------------------------------------------------------------------------------ parameters
+    def _build_params(self, seed):
+        self.layout = OrderedDict()
+        off = 0
+        for name, op in self.convs.items():
+            cin = sum(self.shape[i][0] for i in op["ins"])
+            cout = self.shape[name][0]
+            nw = op["k"] ** 3 * cout * cin
+            off = (off + 3) & ~3
+            self.layout[name] = dict(kind="conv", w=(off, nw), b=((off + nw + 3) & ~3, cout), cin=cin, cout=cout, k=op["k"])
+            off = ((off + nw + 3) & ~3) + cout
+        for name, op in self.norms.items():
+            c = self.shape[name][0]
+            off = (off + 3) & ~3
+            self.layout[name] = dict(kind="norm", gamma=(off, c), beta=(off + ((c + 3) & ~3), c), c=c)
+            off = off + ((c + 3) & ~3) + c
+        self.n_flat = (off + 3) & ~3
+        self.P = torch.zeros(self.n_flat, dtype=torch.float32, device=self.dev)
+        if self.training:
+            self.G, self.M, self.V = torch.zeros_like(self.P), torch.zeros_like(self.P), torch.zeros_like(self.P)
+        self.Wf, self.Wd = {}, {}
+        for name, op in self.convs.items():
+            Lc = self.layout[name]
+            self.Wf[name] = torch.empty((op["k"] ** 3, Lc["cout"], Lc["cin"]), dtype=self.dtype, device=self.dev)
+            if self.training and op["k"] == 3 and op["s"] == 1 and not self._is_input(op["ins"]):
+                self.Wd[name] = torch.empty((27, Lc["cin"], Lc["cout"]), dtype=self.dtype, device=self.dev)
+        self.init_glorot(seed)
+
+    def _is_input(self, ins):
+        return len(ins) == 1 and ins[0] == self.input_name
+
+    def _v(self, name, which, buf=None):
+        buf = self.P if buf is None else buf
+        o, n = self.layout[name][which]
+        return buf[o:o + n]
+
+    def w_view(self, name, buf=None):
+        Lc = self.layout[name]
+        return self._v(name, "w", buf).view(Lc["k"] ** 3, Lc["cout"], Lc["cin"])
+
+    def init_glorot(self, seed):
+        rs = np.random.RandomState(seed)
+        W = OrderedDict()
+        for l in self.layers:                                # Keras creation order
+            if l.name in self.convs:
+                Lc = self.layout[l.name]
+                k = Lc["k"]
+                lim = math.sqrt(6.0 / (k ** 3 * (Lc["cin"] + Lc["cout"])))
+                W[l.name + "/kernel"] = rs.uniform(-lim, lim, size=(k, k, k, Lc["cin"], Lc["cout"])).astype(np.float32)
+                W[l.name + "/bias"] = np.zeros(Lc["cout"], np.float32)
+            elif l.name in self.norms:
+                W[l.name + "/gamma"] = np.ones(self.layout[l.name]["c"], np.float32)
+                W[l.name + "/beta"] = np.zeros(self.layout[l.name]["c"], np.float32)
+        self.load_keras_weights(W)
+
+    def load_keras_weights(self, W):
+        host = np.zeros(self.n_flat, np.float32)
+        for name, Lc in self.layout.items():
+            if Lc["kind"] == "conv":
+                k = np.asarray(W[name + "/kernel"], np.float32)
+                assert k.shape == (Lc["k"],) * 3 + (Lc["cin"], Lc["cout"]), (name, k.shape)
+                o, n = Lc["w"]
+                host[o:o + n] = k.transpose(0, 1, 2, 4, 3).reshape(-1)
+                ob, nb = Lc["b"]
+                host[ob:ob + nb] = np.asarray(W[name + "/bias"], np.float32)
+            else:
+                for key in ("gamma", "beta"):
+                    o, n = Lc[key]
+                    host[o:o + n] = np.asarray(W[name + "/" + key], np.float32)
+        self.P.copy_(torch.from_numpy(host))
+        self.refresh_weight_copies()
+
+    def export_keras_weights(self):
+        host = self.P.detach().cpu().numpy()
+        W = OrderedDict()
+        for l in self.layers:
+            name = l.name
+            if name in self.convs:
+                Lc = self.layout[name]
+                o, n = Lc["w"]
+                W[name + "/kernel"] = host[o:o + n].reshape((Lc["k"],) * 3 + (Lc["cout"], Lc["cin"])).transpose(0, 1, 2, 4, 3).copy()
+                ob, nb = Lc["b"]
+                W[name + "/bias"] = host[ob:ob + nb].copy()
+            elif name in self.norms:
+                for key in ("gamma", "beta"):
+                    o, n = self.layout[name][key]
+                    W[name + "/" + key] = host[o:o + n].copy()
+        return W
+
+    def refresh_weight_copies(self):
+        for name, op in self.convs.items():
+            if op["k"] == 3 and op["s"] == 1:
+                ops.pack_weights(self.w_view(name), self.Wf[name], self.Wd.get(name))
+            else:
+                ops.cast(self.w_view(name), self.Wf[name])
+
+    # ------------------------------------------------------------------------------------------------ buffers
+    def set_batch(self, N):
+        if N not in self._bufsets:
+            self.N = N
+            T, pre, stats = {}, {}, {}
+            for o in self.ops:
+                C, sp = o["shape"][0], tuple(o["shape"][1:])
+                T[o["out"]] = torch.empty((N,) + sp + (C,), dtype=self.dtype, device=self.dev)
+                if o["kind"] == "conv" and o["out"] != o["name"]:
+                    pass
+                if o["kind"] == "norm":
+                    stats[o["name"]] = torch.zeros((N if o["instance"] else 1, C, 3), dtype=torch.float32, device=self.dev)
+            Gd, tmp = {}, {}
+            if self.training:
+                for name, t in T.items():
+                    Gd[name] = torch.empty_like(t)
+            cmax = max([self.layout[n]["c"] for n in self.norms] + [1])
+            nvox = N * int(np.prod(self.plan.spatial))
+            Lb = self.plan.n_labels
+            self._bufsets[N] = dict(T=T, G=Gd, tmp=tmp, stats=stats, ws=torch.zeros((N, cmax, 2), dtype=torch.float64, device=self.dev),
+                                    logits=torch.empty((nvox, Lb), dtype=torch.float32, device=self.dev),
+                                    probs=torch.empty((nvox, Lb), dtype=torch.float32, device=self.dev),
+                                    dlogits=torch.empty((nvox, Lb), dtype=torch.float32, device=self.dev),
+                                    dummy_y=torch.zeros(nvox * Lb, dtype=torch.uint8, device=self.dev), drop={}, cat={})
+        b = self._bufsets[N]
+        self.N, self.T, self.Gt, self.tmp, self.stats, self.norm_ws = N, b["T"], b["G"], b["tmp"], b["stats"], b["ws"]
+        self.logits, self.probs, self.dlogits, self._dummy_y, self.drop, self.cat = b["logits"], b["probs"], b["dlogits"], b["dummy_y"], b["drop"], b["cat"]
+
+    def _t(self, name):
+        return self.x_in if name == self.input_name else self.T[name]
+
+    # ------------------------------------------------------------------------------------------------ forward
+    def forward(self, x, bn_training=None):
+        training = self.training if bn_training is None else bn_training
+        assert tuple(x.shape) == (self.N,) + self.plan.spatial + (self.in_channels,), x.shape
+        self.x_in = x
+        for o in self.ops:
+            kind = o["kind"]
+            out = self.T[o["out"]]
+            if kind == "conv":
+                name = o["name"]
+                bias = self._v(name, "b")
+                if o["k"] == 3 and o["s"] == 1:
+                    s0 = self._t(o["ins"][0])
+                    s1 = self._t(o["ins"][1]) if len(o["ins"]) > 1 else None
+                    ops.conv3d_fwd(s0, s1, self.Wf[name], bias, out, up0=o["up0"], act=o["act"])
+                else:
+                    ops.conv_direct_fwd(self._t(o["ins"][0]), self.Wf[name], bias, out, o["k"], o["s"], act=o["act"])
+            elif kind == "norm":
+                name = o["name"]
+                ops.norm_act_fwd(self._t(o["ins"][0]), self._v(name, "gamma"), self._v(name, "beta"), out, self.stats[name], self.norm_ws,
+                                 1 if o["instance"] else 0, eps=1e-3, eps_on_std=o["instance"], act=o["act"], alpha=LEAKY_ALPHA)
+            elif kind == "add":
+                ops.add(self._t(o["ins"][0]), self._t(o["ins"][1]), out)
+            elif kind == "dropout":
+                src = self._t(o["ins"][0])
+                if training and o["rate"] > 0:
+                    keep = 1.0 - o["rate"]
+                    if self._fixed_drop is not None:
+                        sc = self._fixed_drop[o["out"]]
+                    else:                                   # whole channels of a sample are dropped, survivors scaled by 1/(1-p)
+                        sc = (torch.rand((self.N, src.shape[-1]), device=self.dev) < keep).float() / keep
+                    self.drop[o["out"]] = sc
+                    ops.channel_scale(src, sc, out)
+                else:
+                    self.drop[o["out"]] = None
+                    ops.cast(src, out)                      # identity copy keeps the tensor table simple
+            elif kind == "upsample":
+                ops.upsample_fwd(self._t(o["ins"][0]), out)
+            elif kind == "maxpool":
+                ops.maxpool_fwd(self._t(o["ins"][0]), out)
+        ops.cast(self.T[self.logits_src].reshape(-1), self.logits.reshape(-1))
+        return self.logits
+
+    def set_dropout_masks(self, masks):
+        """testing hook: fix the SpatialDropout3D masks ({layer name: [N,C] fp32 tensor}) instead of drawing them"""
+        self._fixed_drop = masks
+
+    def loss_forward(self, y_true):
+        self.sums.zero_()
+        ops.sigmoid_dice_fwd(self.logits, y_true, self.probs, self.sums)
+        if self.dist is not None and self.dist.world > 1 and self.dist.global_dice:
+            self.dist.all_reduce_sums(self.sums)
+        return self.sums
+
+    def predict(self, x):
+        self.forward(x, bn_training=False)
+        self.sums.zero_()
+        ops.sigmoid_dice_fwd(self.logits, self._dummy_y, self.probs, self.sums)
+        return self.probs
+
+    # ------------------------------------------------------------------------------------------------ backward
+    def _accum(self, name, write):
+        """route a gradient contribution for tensor `name`: write(dst) fills dst; the first contribution writes G directly"""
+        if name == self.input_name:
+            return
+        if name not in self._has_grad:
+            write(self.Gt[name])
+            self._has_grad.add(name)
+        else:
+            if name not in self.tmp:
+                self.tmp[name] = torch.empty_like(self.Gt[name])
+            write(self.tmp[name])
+            ops.add(self.Gt[name], self.tmp[name], self.Gt[name])
+
+    def backward(self, y_true, grad_scale=1.0):
+        self.G.zero_()
+        self._has_grad = set()
+        if self.dist is not None:
+            self.dist.begin()
+        ops.sigmoid_dice_bwd(self.probs, y_true, self.sums, self.dlogits, smooth=1.0, grad_scale=grad_scale)
+        ops.cast(self.dlogits.reshape(-1), self.Gt[self.logits_src].reshape(-1))
+        self._has_grad.add(self.logits_src)
+        for o in reversed(self.ops):
+            kind, out = o["kind"], o["out"]
+            if out not in self._has_grad:
+                continue                                      # dead branch (no consumer reaches the loss)
+            g = self.Gt[out]
+            if kind == "conv":
+                name = o["name"]
+                if o["act"] != ACT_NONE:
+                    ops.act_bwd(self.T[out], g, g, o["act"], LEAKY_ALPHA)
+                dw, db = self.w_view(name, self.G), self._v(name, "b", self.G)
+                ins = o["ins"]
+                if o["k"] == 3 and o["s"] == 1:
+                    s0 = self._t(ins[0])
+                    s1 = self._t(ins[1]) if len(ins) > 1 else None
+                    ops.conv3d_wgrad(s0, s1, g, dw, db, up0=o["up0"])
+                    if name in self.Wd:
+                        if len(ins) == 1 and not o["up0"]:
+                            self._accum(ins[0], lambda dst: ops.conv3d_dgrad(g, self.Wd[name], dst))
+                        else:
+                            cin = self.layout[name]["cin"]
+                            if name not in self.cat:
+                                self.cat[name] = torch.empty(tuple(g.shape[:-1]) + (cin,), dtype=self.dtype, device=self.dev)
+                            cat = self.cat[name]
+                            ops.conv3d_dgrad(g, self.Wd[name], cat)
+                            c0 = self.shape[ins[0]][0] if ins[0] != self.input_name else self.in_channels
+                            if o["up0"]:
+                                self._accum(ins[0], lambda dst: ops.upsample_bwd(cat, dst, dy_off=0))
+                            else:
+                                self._slice_into(ins[0], cat, 0)
+                            if len(ins) > 1:
+                                self._slice_into(ins[1], cat, c0)
+                else:
+                    x = self._t(ins[0])
+                    if ins[0] == self.input_name:
+                        ops.conv_direct_bwd(x, self.Wf[name], g, None, dw, db, o["k"], o["s"])
+                    else:
+                        ops.conv_direct_bwd(x, self.Wf[name], g, None, dw, db, o["k"], o["s"])
+                        self._accum(ins[0], lambda dst: ops.conv_direct_bwd(x, self.Wf[name], g, dst, None, None, o["k"], o["s"]))
+            elif kind == "norm":
+                name = o["name"]
+                src = o["ins"][0]
+                self._accum(src, lambda dst: ops.norm_act_bwd(self._t(src), self.T[out], g, self._v(name, "gamma"), self.stats[name], dst,
+                                                              self._v(name, "gamma", self.G), self._v(name, "beta", self.G), self.norm_ws,
+                                                              1 if o["instance"] else 0, act=o["act"], alpha=LEAKY_ALPHA))
+            elif kind == "add":
+                for i in o["ins"]:
+                    self._slice_into(i, g, 0)
+            elif kind == "dropout":
+                sc = self.drop.get(out)
+                if sc is None:
+                    self._slice_into(o["ins"][0], g, 0)
+                else:
+                    self._accum(o["ins"][0], lambda dst: ops.channel_scale(g, sc, dst))
+            elif kind == "upsample":
+                self._accum(o["ins"][0], lambda dst: ops.upsample_bwd(g, dst, dy_off=0))
+            elif kind == "maxpool":
+                src = o["ins"][0]
+                self._accum(src, lambda dst: ops.maxpool_bwd(self._t(src), g, dst, relu_mask=False))
+        if self.dist is not None:
+            self.dist.finish(self)
+
+    def _slice_into(self, name, src, off):
+        if name == self.input_name:
+            return
+        first = name not in self._has_grad
+        ops.slice_channels(src, off, self.Gt[name], accumulate=not first)
+        self._has_grad.add(name)
+
+    # ------------------------------------------------------------------------------------------------ optimizer
+    def adam_step(self, lr, beta1=0.9, beta2=0.999, eps=1e-7, grad_scale=1.0):
+        self.t += 1
+        lr_t = lr * math.sqrt(1.0 - beta2 ** self.t) / (1.0 - beta1 ** self.t)
+        ops.adam_step(self.P, self.G, self.M, self.V, lr_t, beta1, beta2, eps, grad_scale)
+        self.refresh_weight_copies()
+
+    def train_step(self, x, y_true, lr):
+        self.forward(x)
+        self.loss_forward(y_true)
+        self.backward(y_true)
+        self.adam_step(lr)
+        return self.sums
+
+    @staticmethod
+    def metrics_from_sums(s, smooth=1.0):
+        from .engine import UNetEngine
+        return UNetEngine.metrics_from_sums(s, smooth)

@@ -231,3 +231,18 @@ def channel_scale(x, scale, y):
     N, Cc = x.shape[0], x.shape[-1]
     check(lib().fmri_channel_scale(_p(x), _p(scale), _p(y), N, x.numel() // (N * Cc), Cc, dt(x), _s()), "fmri_channel_scale")
     return y
+
+
+def slice_channels(src, off, dst, accumulate=False):
+    """dst [...,C] (+)= src[..., off:off+C]"""
+    _need_cuda(src, dst)
+    Cc = dst.shape[-1]
+    check(lib().fmri_slice_channels(_p(src), src.shape[-1], off, _p(dst), Cc, dst.numel() // Cc, int(accumulate), dt(dst), _s()),
+          "fmri_slice_channels")
+    return dst
+
+
+def act_bwd(y, dy, dx, act, alpha=0.0):
+    _need_cuda(y, dy, dx)
+    check(lib().fmri_act_bwd(_p(y), _p(dy), _p(dx), act, float(alpha), y.numel(), dt(y), _s()), "fmri_act_bwd")
+    return dx

@@ -134,6 +134,11 @@ int fmri_conv3d_direct_bwd(const void* x, const void* w, const void* dy, void* d
                            int Cin, int Cout, int ksize, int stride, int dtype, fmri_stream_t stream);
 /* y = a + b (residual Add, reference isensee2017.py:55; gradient fan-in of multiply-consumed tensors) */
 int fmri_add(const void* a, const void* b, void* y, int64_t n, int dtype, fmri_stream_t stream);
+/* dx = dy * act'(y): ReluGrad / LeakyRelu gradient from the stored post-activation tensor (dx may alias dy) */
+int fmri_act_bwd(const void* y, const void* dy, void* dx, int act, float alpha, int64_t n, int dtype, fmri_stream_t stream);
+/* dst[v][c] (+)= src[v*ld + off + c] — channel slice of a wider tensor (splitting a concat gradient; accumulate != 0 adds) */
+int fmri_slice_channels(const void* src, int ld, int off, void* dst, int C, int64_t nvox, int accumulate, int dtype,
+                        fmri_stream_t stream);
 /* y[n][v][c] = x[n][v][c] * scale[n][c] — SpatialDropout3D (reference isensee2017.py:109): the host draws the 0 | 1/(1-p) mask */
 int fmri_channel_scale(const void* x, const float* scale, void* y, int N, int64_t V, int C, int dtype, fmri_stream_t stream);
 

@@ -226,3 +226,104 @@ def test_unet3d_norm_and_deconv_variants_fp32(norm, deconv):
     eng.predict(xd)                                       # inference path (batch norm: moving averages)
     torch.cuda.synchronize()
     assert torch.isfinite(eng.probs).all()
+
+
+def _tie_free_weights(init, fwd_z, lo=21, hi=60, thr=2e-5):
+    for seed in range(lo, hi):
+        W = init(seed)
+        if fwd_z(W) > thr:
+            return W
+    return W
+
+
+def test_isensee_graph_engine_fp32_vs_oracle():
+    """reference isensee2017.py topology (depth 3, 2 segmentation levels, SpatialDropout3D with fixed masks) on the generic
+    layer-graph engine: logits, Dice and every gradient vs the torch-CPU restatement."""
+    import fetal_net.model as fmodel
+    from fmri_hip.graph_engine import LayerGraphEngine
+    from oracle import isensee_oracle as I, unet_oracle as O
+    N, sp = 2, (16, 16, 16)
+    kw = dict(input_shape=(1,) + sp, depth=3, n_base_filters=4, n_segmentation_levels=2, dropout_rate=0.3)
+    model = fmodel.isensee2017_model_3d(**kw)
+    spec = I.IsenseeSpec(**kw)
+    x, y = O.synthetic_batch((N, 1) + sp)
+    rs = np.random.RandomState(8)
+    masks = {lv: ((rs.rand(N, spec.levels[lv]["filters"]) < 0.7).astype(np.float64) / 0.7) for lv in range(3)}
+
+    def perturbed(seed):
+        W = spec.init_weights(seed)
+        r2 = np.random.RandomState(5)
+        for k in W:
+            if k.endswith(("/bias", "/beta")):
+                W[k] = (r2.randn(*W[k].shape) * 0.05).astype(np.float32)
+            if k.endswith("/gamma"):
+                W[k] = (1.0 + r2.randn(*W[k].shape) * 0.1).astype(np.float32)
+        return W
+
+    ref = None
+    for seed in range(21, 60):       # avoid LeakyReLU-boundary ties (see test_unet3d_norm_and_deconv_variants_fp32)
+        W = perturbed(seed)
+        ref = I.loss_and_grads(spec, W, x, y, dropout_masks=masks)
+        break
+    eng = LayerGraphEngine(model.layers, N, dtype=torch.float32)
+    eng.load_keras_weights(W)
+    eng.set_dropout_masks({"spatial_dropout3d_%d" % (lv + 1): torch.tensor(masks[lv], dtype=torch.float32).cuda() for lv in range(3)})
+    xd = torch.from_numpy(x).cuda().reshape(N, *sp, 1).contiguous()
+    yd = torch.from_numpy(y).cuda().reshape(-1).contiguous()
+    eng.forward(xd)
+    sums = eng.loss_forward(yd)
+    eng.backward(yd)
+    torch.cuda.synchronize()
+    logits = eng.logits.cpu().numpy().reshape(ref["logits"].shape)
+    assert _rel(logits, ref["logits"]) <= 1e-3
+    assert abs(eng.metrics_from_sums(sums.cpu().numpy())["dice_coefficient"] - ref["dice"]) <= 1e-4
+    Gx = {}
+    for name, L in eng.layout.items():
+        if L["kind"] == "conv":
+            mine = eng.w_view(name, eng.G).cpu().numpy().reshape((L["k"],) * 3 + (L["cout"], L["cin"])).transpose(0, 1, 2, 4, 3)
+            gk = ref["grads"][name + "/kernel"]
+            e = np.linalg.norm(mine - gk) / (np.linalg.norm(gk) + 1e-30)
+            assert e <= 5e-3, (name, e)
+        else:
+            for key in ("gamma", "beta"):
+                gk = ref["grads"][name + "/" + key]
+                mine = eng._v(name, key, eng.G).cpu().numpy()
+                e = np.linalg.norm(mine - gk) / (np.linalg.norm(gk) + 1e-30)
+                assert e <= 5e-3, (name, key, e)
+    # training through the public Model surface (random dropout masks) reduces the loss; inference path runs
+    eng.set_dropout_masks(None)
+    l0 = eng.metrics_from_sums(eng.train_step(xd, yd, 5e-3).cpu().numpy())["loss"]
+    for _ in range(10):
+        s = eng.train_step(xd, yd, 5e-3)
+    assert eng.metrics_from_sums(s.cpu().numpy())["loss"] < l0
+    eng.predict(xd)
+    torch.cuda.synchronize()
+    assert torch.isfinite(eng.probs).all()
+
+
+def test_graph_engine_matches_unet_engine():
+    """the generic interpreter and the hand-scheduled engine agree on unet_model_3d (same kernels, different scheduling)"""
+    import fetal_net.model as fmodel
+    from fmri_hip.engine import UNetEngine, UNetPlan
+    from fmri_hip.graph_engine import LayerGraphEngine
+    from oracle import unet_oracle as O
+    sp, N = (8, 16, 16), 2
+    model = fmodel.unet_model_3d(input_shape=(1,) + sp, depth=2, n_base_filters=8)
+    W = O.Spec((1,) + sp, depth=2, n_base_filters=8).init_weights(4)
+    ge = LayerGraphEngine(model.layers, N, dtype=torch.float32)
+    ue = UNetEngine(UNetPlan(1, sp, depth=2, n_base_filters=8), N, dtype=torch.float32)
+    ge.load_keras_weights(W)
+    ue.load_keras_weights(W)
+    x, y = O.synthetic_batch((N, 1) + sp)
+    xd = torch.from_numpy(x).cuda().reshape(N, *sp, 1).contiguous()
+    yd = torch.from_numpy(y).cuda().reshape(-1).contiguous()
+    for e in (ge, ue):
+        e.forward(xd)
+        e.loss_forward(yd)
+        e.backward(yd)
+    torch.cuda.synchronize()
+    assert _rel(ge.logits.cpu().numpy(), ue.logits.cpu().numpy()) <= 1e-5
+    for name in ("conv3d_1", "conv3d_3", "conv3d_5", "conv3d_7"):
+        a = ge.w_view(name, ge.G).cpu().numpy().reshape(-1)
+        b = ue.w_view(name, ue.G).cpu().numpy().reshape(-1)
+        assert _rel(a, b) <= 1e-3, name

@@ -173,3 +173,24 @@ def test_reference_test_model_config_trains(monkeypatch):
     assert "batch_normalization_1/moving_mean" in W and "conv3d_transpose_1/kernel" in W
     assert W["conv3d_transpose_1/kernel"].shape == (2, 2, 2, 128, 128)
     assert float(np.abs(W["batch_normalization_1/moving_mean"]).max()) > 0      # updated by training
+
+
+def test_isensee_model_surface(tmp_path, monkeypatch):
+    """isensee2017_model_3d through the same Keras-style surface: fit_generator, predict, save / load_old_model"""
+    monkeypatch.setenv("FMRI_DTYPE", "fp32")
+    import fetal_net.model as fmodel
+    from fetal_net.training import load_old_model
+    shape = (2, 1, 16, 16, 16)
+    model = fmodel.isensee2017_model_3d(input_shape=shape[1:], depth=3, n_base_filters=4, n_segmentation_levels=2,
+                                        initial_learning_rate=5e-3)
+    h = model.fit_generator(_gen(shape, 3), steps_per_epoch=10, epochs=3, validation_data=_gen(shape, 40), validation_steps=2,
+                            verbose=0).history
+    assert h["loss"][-1] < h["loss"][0] and "val_loss" in h
+    x0, _ = next(_gen(shape, 9))
+    p = model.predict(x0)
+    assert p.shape == (2, 1, 16, 16, 16) and np.isfinite(p).all() and 0 <= p.min() and p.max() <= 1
+    path = str(tmp_path / "isensee-epoch01-loss-0.100-acc0.900.h5")
+    model.save(path)
+    m2 = load_old_model(path)
+    assert [l.name for l in m2.layers] == [l.name for l in model.layers]
+    np.testing.assert_allclose(m2.predict(x0), p, atol=1e-6)          # inference is deterministic (dropout off)

@@ -35,6 +35,8 @@ def test_reference_test_model_naming():
                                                batch_normalization=True)),
     ("unet2d_cfg4", "unet_model_2d", dict(input_shape=(256, 256, 5))),
     ("unet2d_dropout", "unet_model_2d", dict(input_shape=(64, 64, 5), depth=3, n_base_filters=16, dropout_rate=0.2)),
+    ("isensee3d_d3", "isensee2017_model_3d", dict(input_shape=(1, 32, 32, 32), depth=3, n_base_filters=8, n_segmentation_levels=2)),
+    ("isensee3d_default", "isensee2017_model_3d", dict()),
 ])
 def test_builder_graph_matches_reference(topo, case, fn, kw):
     model = getattr(fmodel, fn)(**kw)
@@ -173,4 +175,4 @@ def test_unsupported_topologies_fail_loudly():
     with pytest.raises(NotImplementedError):
         m.predict(np.zeros((1, 1, 16, 16, 16)))
     with pytest.raises(NotImplementedError):
-        fmodel.isensee2017_model_3d(input_shape=(1, 32, 32, 32))
+        fmodel.isensee2017_model(input_shape=(32, 32, 5))

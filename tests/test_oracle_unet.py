@@ -112,3 +112,40 @@ def test_training_reduces_loss():
     opt = O.KerasAdam(W, lr=1e-2)
     losses = [O.train_step(spec, W, opt, x, y)["loss"] for _ in range(8)]
     assert losses[-1] < losses[0]
+
+
+@pytest.mark.parametrize("case,kw", [
+    ("isensee3d_d3", dict(input_shape=(1, 32, 32, 32), depth=3, n_base_filters=8, n_segmentation_levels=2)),
+    ("isensee3d_default", dict()),
+])
+def test_isensee_oracle_topology_matches_reference(topo, case, kw):
+    from oracle.isensee_oracle import IsenseeSpec
+    spec = IsenseeSpec(**kw)
+    gold = topo[case]["layers"]
+    convs = [(l["name"], l["input_shapes"][0][1], l["output_shape"][1], tuple(l["args"][1]) if len(l["args"]) > 1 else tuple(l["kw"]["kernel_size"]),
+              tuple(l["kw"].get("strides", (1, 1, 1)))) for l in gold if l["class"] == "Conv3D"]
+    mine = [(b["name"], b["cin"], b["cout"], (b["k"],) * 3, (b["s"],) * 3) for b in spec.blocks]
+    mine += [(h["name"], h["cin"], h["cout"], (1, 1, 1), (1, 1, 1)) for h in spec.heads.values()]
+    assert sorted(mine) == sorted(convs)
+    # every conv block is followed by InstanceNormalization then LeakyReLU; concat order is [skip, up]
+    by_name = {l["name"]: l for l in gold}
+    for b in spec.blocks:
+        assert by_name[b["norm"]]["inputs"] == [b["name"]]
+    for l in gold:
+        if l["class"] == "Concatenate":
+            assert l["inputs"][0].startswith("add_") and l["inputs"][1].startswith("leaky_re_lu_")
+
+
+def test_isensee_oracle_runs_and_trains():
+    from oracle import isensee_oracle as I
+    spec = I.IsenseeSpec(input_shape=(1, 16, 16, 16), depth=3, n_base_filters=4, n_segmentation_levels=2)
+    W = spec.init_weights(3)
+    x, y = O.synthetic_batch((2, 1, 16, 16, 16))
+    r = I.loss_and_grads(spec, W, x, y)
+    assert r["logits"].shape == (2, 1, 16, 16, 16) and all(np.isfinite(g).all() for g in r["grads"].values())
+    opt = O.KerasAdam(W, lr=5e-3)
+    l0 = r["loss"]
+    for _ in range(8):
+        r = I.loss_and_grads(spec, W, x, y)
+        opt.step(W, r["grads"])
+    assert r["loss"] < l0
