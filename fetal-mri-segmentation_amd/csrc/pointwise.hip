@@ -465,12 +465,17 @@ __device__ __forceinline__ double wave_sum(double v) {
 }
 __global__ void k_sigmoid_dice_fwd(const float* __restrict__ logits, const uint8_t* __restrict__ y, float* __restrict__ probs,
                                    double* __restrict__ sums, int64_t n) {
-    double s[7] = {0, 0, 0, 0, 0, 0, 0};
+    double s[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         float z = logits[i];
         float p = 1.f / (1.f + __expf(-z));
         if (probs) probs[i] = p;
         float t = (float)y[i];
+        {   // binary cross-entropy with Keras' clipping, and the reference focal term (metrics.py:80-87: alpha .5, gamma 2)
+            const float pc = fminf(fmaxf(p, 1e-7f), 1.f - 1e-7f);
+            s[7] += (double)(t > 0.5f ? -__logf(pc) : -__logf(1.f - pc));
+            s[8] += (double)(t > 0.5f ? -0.5f * (1.f - p) * (1.f - p) * __logf(p) : -0.5f * p * p * __logf(1.f - p));
+        }
         s[0] += (double)(t * p);
         s[1] += (double)t;
         s[2] += (double)p;
@@ -480,19 +485,19 @@ __global__ void k_sigmoid_dice_fwd(const float* __restrict__ logits, const uint8
         s[5] += pb;
         s[6] += (rintf(p) == t) ? 1.0 : 0.0;
     }
-    __shared__ double red[7][4];
+    __shared__ double red[9][4];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
-    for (int k = 0; k < 7; ++k) {
+    for (int k = 0; k < 9; ++k) {
         double r = wave_sum(s[k]);
         if (lane == 0) red[k][wv] = r;
     }
     __syncthreads();
-    if (threadIdx.x < 7) {
+    if (threadIdx.x < 9) {
         double r = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
-        atomicAdd(&sums[threadIdx.x], r);
+        atomicAdd(&sums[threadIdx.x < 7 ? threadIdx.x : threadIdx.x + 1], r);     // [8] = sum xent, [9] = sum focal
     }
-    if (blockIdx.x == 0 && threadIdx.x == 7) atomicAdd(&sums[7], (double)n);
+    if (blockIdx.x == 0 && threadIdx.x == 9) atomicAdd(&sums[7], (double)n);
 }
 __global__ void k_sigmoid_dice_bwd(const float* __restrict__ probs, const uint8_t* __restrict__ y, const double* __restrict__ sums,
                                    float* __restrict__ dl, int64_t n, float smooth, float grad_scale) {
@@ -505,6 +510,43 @@ __global__ void k_sigmoid_dice_bwd(const float* __restrict__ probs, const uint8_
         dl[i] = grad_scale * dLdp * p * (1.f - p);
     }
 }
+// general loss gradient w.r.t. the logits from the (global) sums: kind 0 dice, 1 mean binary cross-entropy, 2 dice + w*xent,
+// 3 focal (alpha .5, gamma 2), 4 vod (smoothed IoU on probabilities), 5 double dice (-dice(y,p) + r*dice(1-y,p))
+__global__ void k_sigmoid_loss_bwd(const float* __restrict__ probs, const uint8_t* __restrict__ y, const double* __restrict__ sums,
+                                   float* __restrict__ dl, int64_t n, int kind, float p0, float smooth, float grad_scale) {
+    const double I = sums[0], Sy = sums[1], Sp = sums[2], nn = sums[7];
+    const double den = Sy + Sp + smooth;
+    const float a = (float)(2.0 / den), c = (float)((2.0 * I + smooth) / (den * den));
+    const double U = Sy + Sp - I + smooth;
+    const float vu = (float)(1.0 / U), vc = (float)((I + smooth) / (U * U));
+    const double I2 = Sp - I, den2 = (nn - Sy) + Sp + smooth;
+    const float a2 = (float)(2.0 / den2), c2 = (float)((2.0 * I2 + smooth) / (den2 * den2));
+    const float invn = (float)(1.0 / nn);
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float p = probs[i], t = (float)y[i];
+        const float sg = p * (1.f - p);
+        float g;                                               // dL/dlogit
+        if (kind == 0) g = -(a * t - c) * sg;
+        else if (kind == 1) g = (p - t) * invn;
+        else if (kind == 2) g = -(a * t - c) * sg + p0 * (p - t) * invn;
+        else if (kind == 3) {
+            float dp;
+            if (t > 0.5f) dp = -0.5f * (-2.f * (1.f - p) * __logf(p) + (1.f - p) * (1.f - p) / p);
+            else dp = -0.5f * (2.f * p * __logf(1.f - p) - p * p / (1.f - p));
+            g = dp * sg;
+        } else if (kind == 4) g = -(t * vu - (1.f - t) * vc) * sg;
+        else g = (-(a * t - c) + p0 * (a2 * (1.f - t) - c2)) * sg;
+        dl[i] = grad_scale * g;
+    }
+}
+extern "C" int fmri_sigmoid_loss_bwd(const float* probs, const uint8_t* y_true, const double* sums, float* dlogits, int64_t n, int kind,
+                                     float param, float smooth, float grad_scale, fmri_stream_t stream) {
+    if (n <= 0 || kind < 0 || kind > 5) return FMRI_E_SHAPE;
+    k_sigmoid_loss_bwd<<<grid_for(n, 256, 2048), 256, 0, as_stream(stream)>>>(probs, y_true, sums, dlogits, n, kind, param, smooth, grad_scale);
+    FMRI_LAUNCH_CHECK();
+    return FMRI_OK;
+}
+
 extern "C" int fmri_sigmoid_dice_fwd(const float* logits, const uint8_t* y_true, float* probs, double* sums, int64_t n,
                                      fmri_stream_t stream) {
     if (n <= 0) return FMRI_E_SHAPE;

@@ -339,6 +339,11 @@ class Model(object):
             if dist_ctx is not None:
                 dist_ctx.broadcast_params(self._engine)
         self._engine.set_batch(batch)
+        if self.loss is not None:
+            try:
+                self._engine.loss_kind, self._engine.loss_param = self._loss_kind()
+            except NotImplementedError:
+                pass                    # predict-only use of a model compiled with an unsupported loss
         return self._engine
 
     def _to_device_x(self, x):
@@ -379,14 +384,22 @@ class Model(object):
         eng.predict(self._to_device_x(x))
         return self._from_device_probs(eng, n)
 
+    def _loss_kind(self):
+        """(kind, param) of fmri_sigmoid_loss_bwd for the compiled loss token"""
+        table = {M.dice_coefficient_loss: (0, 1.0), M.binary_crossentropy_loss: (1, 1.0), M.dice_and_xent: (2, 1.0), M.focal_loss: (3, 1.0),
+                 M.vod_coefficient_loss: (4, 1.0), M.double_dice_loss: (5, 10.0)}
+        if self.loss not in table:
+            raise NotImplementedError("loss %r is not differentiated on the device (available: %s)" % (
+                getattr(self.loss, "__name__", self.loss), ", ".join(sorted(f.__name__ for f in table))))
+        return table[self.loss]
+
     def _check_loss(self):
-        if self.loss not in M.DEVICE_LOSSES:
-            raise NotImplementedError("loss %r is not differentiated on the device yet (available: dice_coefficient_loss)"
-                                      % getattr(self.loss, "__name__", self.loss))
+        self._loss_kind()
 
     def _batch_logs(self, sums):
         from fmri_hip.engine import UNetEngine
-        m = UNetEngine.metrics_from_sums(sums)
+        kind, param = self._loss_kind()
+        m = UNetEngine.metrics_from_sums(sums, 1.0, kind, param)
         out = OrderedDict(loss=m["loss"])
         for name in self.metrics_names[1:]:
             key = {"dice_coef": "dice_coefficient"}.get(name, name)

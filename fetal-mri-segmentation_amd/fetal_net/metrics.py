@@ -100,5 +100,5 @@ dice_coef_loss = dice_coefficient_loss
 binary_crossentropy_loss = binary_crossentropy
 focal_loss = _focal_loss()
 
-# losses the device path can differentiate today (others build, but raise at the first training step)
-DEVICE_LOSSES = (dice_coefficient_loss,)
+# losses differentiated on the device (fmri_sigmoid_loss_bwd); the rest build but raise at the first training step
+DEVICE_LOSSES = (dice_coefficient_loss, binary_crossentropy_loss, dice_and_xent, focal_loss, vod_coefficient_loss, double_dice_loss)

@@ -96,6 +96,7 @@ class UNetEngine:
         self.planar = plan.ndim == 2      # 2-D: tensors are [1][slices][H][W][C], every op is planar (no coupling along D)
         self.dist = dist_ctx
         self.t = 0                       # Adam step counter
+        self.loss_kind, self.loss_param = 0, 1.0      # ops.LOSS_KINDS: 0 = dice_coefficient_loss
         self._bufsets = {}
         self._build_params(seed)
         self.set_batch(batch)
@@ -311,7 +312,7 @@ class UNetEngine:
         nvox0 = int(np.prod(self._dims(0)))
         self.logits = torch.empty((nvox0, p.n_labels), dtype=torch.float32, device=dev)
         self.probs = torch.empty_like(self.logits)
-        self.sums = torch.zeros(8, dtype=torch.float64, device=dev)
+        self.sums = torch.zeros(16, dtype=torch.float64, device=dev)
         if not self.training:
             self.grad, self.dlogits = None, None
             return
@@ -424,7 +425,7 @@ class UNetEngine:
         p, A, Gd = self.plan, self.act, self.grad
         normed = p.norm is not None
         self.G.zero_()
-        ops.sigmoid_dice_bwd(self.probs, y_true, self.sums, self.dlogits, smooth=1.0, grad_scale=grad_scale)
+        ops.sigmoid_loss_bwd(self.probs, y_true, self.sums, self.dlogits, self.loss_kind, self.loss_param, smooth=1.0, grad_scale=grad_scale)
         f = p.final
         last = p.dec[-1][1] if p.dec else p.enc[-1][1]
         ops.conv1x1_bwd(A[last["name"]], self.w_view(f["name"]), self.dlogits, Gd[last["name"]], self.w_view(f["name"], self.G),
@@ -497,11 +498,12 @@ class UNetEngine:
         return self.sums
 
     @staticmethod
-    def metrics_from_sums(s, smooth=1.0):
+    def metrics_from_sums(s, smooth=1.0, loss_kind=0, loss_param=1.0):
         s = [float(v) for v in s]
         dice = (2.0 * s[0] + smooth) / (s[1] + s[2] + smooth)
         vod = (s[3] + smooth) / (s[4] + s[5] - s[3] + smooth)
-        return dict(loss=-dice, dice_coefficient=dice, vod_coefficient=vod, binary_accuracy=s[6] / max(s[7], 1.0))
+        return dict(loss=ops.loss_value_from_sums(s, loss_kind, loss_param, smooth), dice_coefficient=dice, vod_coefficient=vod,
+                    binary_accuracy=s[6] / max(s[7], 1.0))
 
 
 def _glorot(rs, shape):

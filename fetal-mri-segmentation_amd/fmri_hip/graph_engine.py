@@ -42,7 +42,8 @@ class LayerGraphEngine(object):
         self.planar = False
         self.t = 0
         self._fixed_drop = None
-        self.sums = torch.zeros(8, dtype=torch.float64, device=self.dev)
+        self.loss_kind, self.loss_param = 0, 1.0
+        self.sums = torch.zeros(16, dtype=torch.float64, device=self.dev)
         self._compile()
         self._build_params(seed)
         self._bufsets = {}
@@ -335,7 +336,7 @@ class LayerGraphEngine(object):
         self._has_grad = set()
         if self.dist is not None:
             self.dist.begin()
-        ops.sigmoid_dice_bwd(self.probs, y_true, self.sums, self.dlogits, smooth=1.0, grad_scale=grad_scale)
+        ops.sigmoid_loss_bwd(self.probs, y_true, self.sums, self.dlogits, self.loss_kind, self.loss_param, smooth=1.0, grad_scale=grad_scale)
         ops.cast(self.dlogits.reshape(-1), self.Gt[self.logits_src].reshape(-1))
         self._has_grad.add(self.logits_src)
         for o in reversed(self.ops):
@@ -421,6 +422,6 @@ class LayerGraphEngine(object):
         return self.sums
 
     @staticmethod
-    def metrics_from_sums(s, smooth=1.0):
+    def metrics_from_sums(s, smooth=1.0, loss_kind=0, loss_param=1.0):
         from .engine import UNetEngine
-        return UNetEngine.metrics_from_sums(s, smooth)
+        return UNetEngine.metrics_from_sums(s, smooth, loss_kind, loss_param)

@@ -87,7 +87,7 @@ def conv1x1_bwd(x, w, dlogits, dx, dw, db, relu_mask=True):
 
 def sigmoid_dice_fwd(logits, y_true, probs, sums):
     _need_cuda(logits, y_true, probs, sums)
-    assert y_true.dtype == torch.uint8 and sums.dtype == torch.float64 and sums.numel() >= 8
+    assert y_true.dtype == torch.uint8 and sums.dtype == torch.float64 and sums.numel() >= 16
     check(lib().fmri_sigmoid_dice_fwd(_p(logits), _p(y_true), _p(probs), _p(sums), logits.numel(), _s()), "fmri_sigmoid_dice_fwd")
 
 
@@ -246,3 +246,30 @@ def act_bwd(y, dy, dx, act, alpha=0.0):
     _need_cuda(y, dy, dx)
     check(lib().fmri_act_bwd(_p(y), _p(dy), _p(dx), act, float(alpha), y.numel(), dt(y), _s()), "fmri_act_bwd")
     return dx
+
+
+LOSS_KINDS = {"dice_coefficient_loss": 0, "binary_crossentropy_loss": 1, "dice_and_xent": 2, "focal_loss": 3, "vod_coefficient_loss": 4,
+              "double_dice_loss": 5}
+
+
+def sigmoid_loss_bwd(probs, y_true, sums, dlogits, kind, param=1.0, smooth=1.0, grad_scale=1.0):
+    _need_cuda(probs, y_true, sums, dlogits)
+    check(lib().fmri_sigmoid_loss_bwd(_p(probs), _p(y_true), _p(sums), _p(dlogits), probs.numel(), int(kind), float(param), float(smooth),
+                                      float(grad_scale), _s()), "fmri_sigmoid_loss_bwd")
+
+
+def loss_value_from_sums(s, kind, param=1.0, smooth=1.0):
+    """host-side value of the loss `kind` from the 16 metric sums (float64)"""
+    I, Sy, Sp, n = float(s[0]), float(s[1]), float(s[2]), float(s[7])
+    dice = (2 * I + smooth) / (Sy + Sp + smooth)
+    if kind == 0:
+        return -dice
+    if kind == 1:
+        return float(s[8]) / n
+    if kind == 2:
+        return -dice + param * float(s[8]) / n
+    if kind == 3:
+        return float(s[9])
+    if kind == 4:
+        return -(I + smooth) / (Sy + Sp - I + smooth)
+    return -dice + param * (2 * (Sp - I) + smooth) / ((n - Sy) + Sp + smooth)

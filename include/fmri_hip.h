@@ -76,8 +76,9 @@ int fmri_conv1x1_bwd(const void* x, const float* w, const float* dlogits, void* 
                      int C, int L, int relu_mask, int dtype, fmri_stream_t stream);
 
 /* ---- Activation('sigmoid') + dice_coefficient_loss + the compiled metrics — reference unet.py:69,81-85, metrics.py:11-32.
- * probs = sigmoid(logits); sums (8 doubles, ACCUMULATED, caller zeroes) =
+ * probs = sigmoid(logits); sums (16 doubles, ACCUMULATED, caller zeroes) =
  *   [0] sum y*p  [1] sum y  [2] sum p  [3] sum (y>.5)(p>.5)  [4] sum (y>.5)  [5] sum (p>.5)  [6] sum (round(p)==y)  [7] n
+ *   [8] sum binary cross-entropy (p clipped to [1e-7, 1-1e-7] as K.binary_crossentropy)  [9] sum focal term (alpha .5, gamma 2)
  * y_true is uint8 (reference generator emits uint8 truth) with the same [v][l] indexing as logits. */
 int fmri_sigmoid_dice_fwd(const float* logits, const uint8_t* y_true, float* probs, double* sums, int64_t n,
                           fmri_stream_t stream);
@@ -85,6 +86,12 @@ int fmri_sigmoid_dice_fwd(const float* logits, const uint8_t* y_true, float* pro
  * `sums` are the (possibly all-reduced, global-batch) sums produced above. */
 int fmri_sigmoid_dice_bwd(const float* probs, const uint8_t* y_true, const double* sums, float* dlogits, int64_t n,
                           float smooth, float grad_scale, fmri_stream_t stream);
+
+/* The other selectable losses of reference fetal_net/metrics.py (config_utils.py loss table), differentiated from the same sums:
+ * kind 0 dice_coefficient_loss, 1 binary_crossentropy_loss (mean), 2 dice_and_xent (param = xent_weight), 3 focal_loss,
+ * 4 vod_coefficient_loss, 5 double_dice_loss (param = ratio). */
+int fmri_sigmoid_loss_bwd(const float* probs, const uint8_t* y_true, const double* sums, float* dlogits, int64_t n, int kind,
+                          float param, float smooth, float grad_scale, fmri_stream_t stream);
 
 /* ---- MaxPooling3D(2,2,2) — reference unet.py:51.  D,H,W are the INPUT dims (even). */
 int fmri_maxpool3d_2x_fwd(const void* x, void* y, int N, int D, int H, int W, int C, int dtype, int planar,

@@ -186,7 +186,7 @@ def test_sigmoid_dice_fwd_bwd(ops):
     logits = rnd((n,), 50, torch.float32, scale=2.0)
     y = (torch.rand(n, generator=torch.Generator().manual_seed(51)) > 0.7).to(torch.uint8).cuda()
     probs = torch.empty_like(logits)
-    sums = torch.zeros(8, dtype=torch.float64, device="cuda")
+    sums = torch.zeros(16, dtype=torch.float64, device="cuda")
     ops.sigmoid_dice_fwd(logits, y, probs, sums)
     dl = torch.empty_like(logits)
     ops.sigmoid_dice_bwd(probs, y, sums, dl)
@@ -450,3 +450,36 @@ def test_add_and_channel_scale(ops):
     torch.cuda.synchronize()
     assert torch.equal(y, (a.float() + b.float()).to(torch.bfloat16))
     assert torch.equal(z, (a.float() * sc[:, None, None, None, :]).to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("name,kind,param", [("dice_coefficient_loss", 0, 1.0), ("binary_crossentropy_loss", 1, 1.0), ("dice_and_xent", 2, 1.0),
+                                             ("focal_loss", 3, 1.0), ("vod_coefficient_loss", 4, 1.0), ("double_dice_loss", 5, 10.0)])
+def test_selectable_losses_value_and_gradient(ops, name, kind, param):
+    """the loss table of reference fetal/config_utils.py / fetal_net/metrics.py: value (vs the pinned numpy restatement) and d/dlogits
+    (vs autograd of the same formula)"""
+    from oracle import metrics_oracle as M
+    n = 4000
+    logits = rnd((n,), 120, torch.float32, scale=2.0)
+    y = (torch.rand(n, generator=torch.Generator().manual_seed(121)) > 0.7).to(torch.uint8).cuda()
+    probs = torch.empty_like(logits)
+    sums = torch.zeros(16, dtype=torch.float64, device="cuda")
+    ops.sigmoid_dice_fwd(logits, y, probs, sums)
+    dl = torch.empty_like(logits)
+    ops.sigmoid_loss_bwd(probs, y, sums, dl, kind, param)
+    torch.cuda.synchronize()
+    yn, pn = y.cpu().numpy().astype(np.float64), torch.sigmoid(f64(logits)).numpy()
+    ref_val = {"dice_coefficient_loss": M.dice_coefficient_loss, "binary_crossentropy_loss": lambda a, b: M.weighted_cross_entropy_loss(a, b),
+               "dice_and_xent": M.dice_and_xent, "focal_loss": M.focal_loss, "vod_coefficient_loss": M.vod_coefficient_loss,
+               "double_dice_loss": M.double_dice_loss}[name](yn, pn)
+    assert ops.loss_value_from_sums(sums.cpu().numpy(), kind, param) == pytest.approx(ref_val, rel=2e-5)
+    z = f64(logits).requires_grad_(True)
+    p = torch.sigmoid(z)
+    t = f64(y)
+    dice = lambda a, b: (2 * (a * b).sum() + 1) / (a.sum() + b.sum() + 1)
+    pc = p.clamp(1e-7, 1 - 1e-7)
+    xent = -(t * torch.log(pc) + (1 - t) * torch.log(1 - pc)).mean()
+    L = {0: -dice(t, p), 1: xent, 2: -dice(t, p) + param * xent,
+         3: -(0.5 * (1 - p) ** 2 * torch.log(p))[t == 1].sum() - (0.5 * p ** 2 * torch.log(1 - p))[t == 0].sum(),
+         4: -((t * p).sum() + 1) / (t.sum() + p.sum() - (t * p).sum() + 1), 5: -dice(t, p) + param * dice(1 - t, p)}[kind]
+    L.backward()
+    assert_close(dl, z.grad, 2e-4, 2e-5, what=name)
