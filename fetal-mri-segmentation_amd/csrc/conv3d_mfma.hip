@@ -767,7 +767,17 @@ int conv3d_wgrad_mfma(const void* src0, int C0, int up0, int planar, const void*
     const int CIB = wide ? 64 : 32;
     const int combos = (planar ? 1 : 3) * (Cout / 64) * (Cin / CIB);
     const int ntiles = N * D * (H / wg::TH) * (W / wg::TW);
-    int nslab = (1024 + combos - 1) / combos;        // aim for ~1024 workgroups (2 per CU, 2 rounds)
+    // Workgroups per launch: every workgroup flushes 9 x 64 x 64 fp32 accumulators with atomics (147 KB), so small layers want few
+    // (their run time is mostly that flush), large ones want many (load balance / tail).  Measured per layer at BASELINE config 2
+    // (tools/bench_conv.py, FMRI_WGRAD_WGS sweep): >= 0.9 TFLOP layers are fastest at ~2048, the rest at ~768, the smallest at ~512.
+    static int forced_wgs = -1;                       // FMRI_WGRAD_WGS overrides the heuristic (tuning)
+    if (forced_wgs < 0) {
+        const char* e = getenv("FMRI_WGRAD_WGS");
+        forced_wgs = e ? atoi(e) : 0;
+    }
+    const double flops = 2.0 * (planar ? 9 : 27) * (double)Cin * Cout * (double)N * D * H * W;
+    int target_wgs = forced_wgs >= 64 ? forced_wgs : (flops >= 0.9e12 ? 2048 : (flops >= 0.06e12 ? 768 : 512));
+    int nslab = (target_wgs + combos - 1) / combos;
     if (nslab > ntiles) nslab = ntiles;
     if (nslab < 1) nslab = 1;
     if (wide) k_conv_wgrad_mfma<2><<<combos * nslab, wg::NTHREADS, 0, st>>>(s, (const bf16_t*)dy, dw, db, N, D, H, W, Cout, nslab);
