@@ -9,7 +9,9 @@ bool conv3d_fwd_mfma_ok(int C0, int C1, int Cout, int D, int H, int W, int dtype
 bool conv3d_wgrad_mfma_ok(int C0, int C1, int Cout, int D, int H, int W, int dtype);
 int conv3d_fwd_mfma(const void*, int, int, int, const void*, int, const void*, const float*, const void*, void*, int, int, int, int, int, int,
                     float, hipStream_t);
-int conv3d_wgrad_mfma(const void*, int, int, int, const void*, int, const void*, float*, float*, int, int, int, int, int, hipStream_t);
+int conv3d_wgrad_mfma(const void*, int, int, int, const void*, int, const void*, float*, float*, int, int, int, int, int, void*, int64_t,
+                      hipStream_t);
+int64_t conv3d_wgrad_mfma_ws_bytes(int C0, int C1, int Cout, int N, int D, int H, int W, int planar);
 
 bool conv3d_first_ok(int C0, int C1, int Cout, int D, int H, int W, int dtype, int up0);
 int conv3d_first_fwd(const void*, const void*, const float*, void*, int, int, int, int, int, int, float, hipStream_t);
@@ -53,7 +55,8 @@ extern "C" int fmri_conv3d_dgrad(const void* dy, int Cout, const void* w_dgrad, 
 }
 
 extern "C" int fmri_conv3d_wgrad(const void* src0, int C0, int up0, const void* src1, int C1, const void* dy, float* dw, float* db,
-                                 int N, int D, int H, int W, int Cout, int dtype, int impl, int planar, fmri_stream_t stream) {
+                                 int N, int D, int H, int W, int Cout, int dtype, int impl, int planar, void* workspace,
+                                 int64_t workspace_bytes, fmri_stream_t stream) {
     int rc = check_common(src0, C0, up0, planar, src1, C1, N, D, H, W, Cout);
     if (rc) return rc;
     if (dtype != FMRI_F32 && dtype != FMRI_BF16) return FMRI_E_DTYPE;
@@ -64,7 +67,13 @@ extern "C" int fmri_conv3d_wgrad(const void* src0, int C0, int up0, const void* 
     if (impl == FMRI_IMPL_MFMA && !can) return FMRI_E_SHAPE;
     if (can && impl != FMRI_IMPL_GENERIC) {
         if ((((uintptr_t)src0) | ((uintptr_t)src1) | ((uintptr_t)dy)) & 15) return FMRI_E_ALIGN;
-        return conv3d_wgrad_mfma(src0, C0, up0, planar, src1, C1, dy, dw, db, N, D, H, W, Cout, as_stream(stream));
+        return conv3d_wgrad_mfma(src0, C0, up0, planar, src1, C1, dy, dw, db, N, D, H, W, Cout, workspace, workspace_bytes, as_stream(stream));
     }
     return conv3d_wgrad_generic(src0, C0, up0, planar, src1, C1, dy, dw, db, N, D, H, W, Cout, dtype, as_stream(stream));
+}
+
+extern "C" int64_t fmri_conv3d_wgrad_workspace_bytes(int C0, int C1, int Cout, int N, int D, int H, int W, int dtype, int planar) {
+    if (!conv3d_wgrad_mfma_ok(C0, C1, Cout, D, H, W, dtype)) return 0;
+    if (!planar && conv3d_first_ok(C0, C1, Cout, D, H, W, dtype, 0)) return 0;
+    return conv3d_wgrad_mfma_ws_bytes(C0, C1, Cout, N, D, H, W, planar);
 }

@@ -521,7 +521,7 @@ __device__ __forceinline__ bf16x8_t tr_frag(const unsigned char* base, int row0,
 template <int CI_T>  // CI_T = 32-wide input-channel tiles per workgroup (1 or 2); output-channel block is always 64
 __global__ void __launch_bounds__(wg::NTHREADS, 2)
 k_conv_wgrad_mfma(SrcB s, const bf16_t* __restrict__ dy, float* __restrict__ dw, float* __restrict__ db, int N, int D, int H,
-                  int W, int Cout, int nslab) {
+                  int W, int Cout, int nslab, float* __restrict__ slab_ws) {
     using namespace wg;
     constexpr int CIB = 32 * CI_T;
     constexpr int XROWB = CIB * 2;                       // bytes per x row
@@ -681,19 +681,90 @@ k_conv_wgrad_mfma(SrcB s, const bf16_t* __restrict__ dy, float* __restrict__ dw,
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                                                 // ring slot `buf` may be refilled
     }
-    // ---- flush: D rows = co, cols = ci; one fp32 atomic per element (128-B contiguous per half-wave)
+    // ---- flush: D rows = co, cols = ci (128-B contiguous per half-wave).  With a workspace: plain stores of this workgroup's partial
+    // slab [9][64][CIB] (summed per element by k_wgrad_reduce: deterministic, ~5x the atomic rate); without: fp32 atomics into dw.
+    if (slab_ws) {
+        constexpr int KSP = (CI_T == 2) ? 1 : 2;          // Cin-block 32: the two k-step halves keep separate slabs
+        float* const my = slab_ws + ((int64_t)blockIdx.x * KSP + ksl) * (9 * 64 * CIB);
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
+        for (int tap = 0; tap < 9; ++tap) {
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            const int co = co0 + ct * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * hk;
-            const int ci = cc + it * 32 + r;
-            atomicAdd(&dw[((int64_t)(kd * 9 + tap) * Cout + co) * Cin + ci], acc[tap][reg]);
+            for (int reg = 0; reg < 16; ++reg) {
+                const int col = ct * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * hk;
+                my[(tap * 64 + col) * CIB + it * 32 + r] = acc[tap][reg];
+            }
+        }
+    } else {
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int co = co0 + ct * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * hk;
+                const int ci = cc + it * 32 + r;
+                atomicAdd(&dw[((int64_t)(kd * 9 + tap) * Cout + co) * Cin + ci], acc[tap][reg]);
+            }
         }
     }
     if (do_bias) {
         bsum += __shfl_down(bsum, 32);
         if (hk == 0) atomicAdd(&db[co0 + ct * 32 + r], bsum);
+    }
+}
+
+// dw[(kd*9+tap)][co0+co][cc+ci] += sum over the slabs of combo (kd, cob, cib).  Block = 32 float4 columns x 8 slab groups: every
+// thread sums its share of the slabs for 4 consecutive elements (4 loads in flight), the 8 partial sums meet in LDS in a fixed order
+// (bit-reproducible), one thread per column adds the total to dw.  Workgroup index of the wgrad launch = slab * ncombo + combo.
+template <int CIB>
+__global__ void __launch_bounds__(256)
+k_wgrad_reduce(const float* __restrict__ ws, float* __restrict__ dw, int Cout, int Cin, int nslab, int ncombo, int ncob, int ncib,
+               int planar, int ksp) {
+    constexpr int PER4 = 9 * 64 * CIB / 4;                     // float4 columns per combo
+    __shared__ float4 red[8][32];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int64_t col = (int64_t)blockIdx.x * 32 + tx;        // global float4 column = combo * PER4 + e4
+    const bool ok = col < (int64_t)ncombo * PER4;
+    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
+    int combo = 0, e4 = 0;
+    if (ok) {
+        combo = (int)(col / PER4);
+        e4 = (int)(col % PER4);
+        const int nsl = nslab * ksp;                           // slabs of this combo: index (sl * ncombo + combo) * ksp + k
+        const float4* base = reinterpret_cast<const float4*>(ws) + e4;
+        int j = ty;
+        for (; j + 24 < nsl; j += 32) {
+            const int64_t i0 = ((int64_t)(j / ksp) * ncombo + combo) * ksp + (j % ksp);
+            const int64_t i1 = ((int64_t)((j + 8) / ksp) * ncombo + combo) * ksp + ((j + 8) % ksp);
+            const int64_t i2 = ((int64_t)((j + 16) / ksp) * ncombo + combo) * ksp + ((j + 16) % ksp);
+            const int64_t i3 = ((int64_t)((j + 24) / ksp) * ncombo + combo) * ksp + ((j + 24) % ksp);
+            const float4 v0 = base[i0 * PER4], v1 = base[i1 * PER4], v2 = base[i2 * PER4], v3 = base[i3 * PER4];
+            a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+            a1.x += v1.x; a1.y += v1.y; a1.z += v1.z; a1.w += v1.w;
+            a2.x += v2.x; a2.y += v2.y; a2.z += v2.z; a2.w += v2.w;
+            a3.x += v3.x; a3.y += v3.y; a3.z += v3.z; a3.w += v3.w;
+        }
+        for (; j < nsl; j += 8) {
+            const int64_t i0 = ((int64_t)(j / ksp) * ncombo + combo) * ksp + (j % ksp);
+            const float4 v0 = base[i0 * PER4];
+            a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+        }
+    }
+    red[ty][tx] = make_float4((a0.x + a1.x) + (a2.x + a3.x), (a0.y + a1.y) + (a2.y + a3.y), (a0.z + a1.z) + (a2.z + a3.z),
+                              (a0.w + a1.w) + (a2.w + a3.w));
+    __syncthreads();
+    if (ty == 0 && ok) {
+        float4 t = red[0][tx];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) { t.x += red[k][tx].x; t.y += red[k][tx].y; t.z += red[k][tx].z; t.w += red[k][tx].w; }
+        const int cib = combo % ncib;
+        int q = combo / ncib;
+        const int cob = q % ncob;
+        const int kd = planar ? 1 : q / ncob;
+        const int e = e4 * 4;
+        const int ci = e % CIB, colo = (e / CIB) % 64, tap = e / (CIB * 64);
+        float4* dst = reinterpret_cast<float4*>(dw + ((int64_t)(kd * 9 + tap) * Cout + cob * 64 + colo) * Cin + cib * CIB + ci);
+        float4 d = *dst;
+        d.x += t.x; d.y += t.y; d.z += t.z; d.w += t.w;
+        *dst = d;
     }
 }
 
@@ -759,29 +830,64 @@ int conv3d_fwd_mfma(const void* src0, int C0, int up0, int planar, const void* s
     return FMRI_OK;
 }
 
-int conv3d_wgrad_mfma(const void* src0, int C0, int up0, int planar, const void* src1, int C1, const void* dy, float* dw, float* db, int N,
-                      int D, int H, int W, int Cout, hipStream_t st) {
-    SrcB s{(const bf16_t*)src0, (const bf16_t*)src1, C0, C1, up0, planar ? 0 : 1, planar};
+static void wgrad_plan(int C0, int C1, int Cout, int N, int D, int H, int W, int planar, bool with_ws, int& CIB, int& combos, int& nslab) {
     const int Cin = C0 + C1;
     const bool wide = (C0 % 64 == 0) && (C1 % 64 == 0);
-    const int CIB = wide ? 64 : 32;
-    const int combos = (planar ? 1 : 3) * (Cout / 64) * (Cin / CIB);
+    CIB = wide ? 64 : 32;
+    combos = (planar ? 1 : 3) * (Cout / 64) * (Cin / CIB);
     const int ntiles = N * D * (H / wg::TH) * (W / wg::TW);
-    // Workgroups per launch: every workgroup flushes 9 x 64 x 64 fp32 accumulators with atomics (147 KB), so small layers want few
-    // (their run time is mostly that flush), large ones want many (load balance / tail).  Measured per layer at BASELINE config 2
-    // (tools/bench_conv.py, FMRI_WGRAD_WGS sweep): >= 0.9 TFLOP layers are fastest at ~2048, the rest at ~768, the smallest at ~512.
-    static int forced_wgs = -1;                       // FMRI_WGRAD_WGS overrides the heuristic (tuning)
+    // Workgroups per launch.  Atomic flush: every workgroup adds 9 x 64 x 64 fp32 accumulators (147 KB) at ~1.3 TB/s, so small layers
+    // want few workgroups and large ones many (load balance / tail): measured per layer at BASELINE config 2 (tools/bench_conv.py,
+    // FMRI_WGRAD_WGS sweep) >= 0.9 TFLOP layers are fastest at ~2048, the rest at ~768, the smallest at ~512.  With a slab workspace the
+    // flush is a plain store + one reduction pass, and the sweep is repeated in FMRI_WGRAD_WGS_SLAB.
+    static int forced_wgs = -1, forced_slab = -1;
     if (forced_wgs < 0) {
         const char* e = getenv("FMRI_WGRAD_WGS");
         forced_wgs = e ? atoi(e) : 0;
+        const char* f = getenv("FMRI_WGRAD_WGS_SLAB");
+        forced_slab = f ? atoi(f) : 0;
     }
     const double flops = 2.0 * (planar ? 9 : 27) * (double)Cin * Cout * (double)N * D * H * W;
-    int target_wgs = forced_wgs >= 64 ? forced_wgs : (flops >= 0.9e12 ? 2048 : (flops >= 0.06e12 ? 768 : 512));
-    int nslab = (target_wgs + combos - 1) / combos;
+    int target_wgs = flops >= 0.9e12 ? 2048 : (flops >= 0.06e12 ? 768 : 512);
+    if (with_ws && forced_slab >= 64) target_wgs = forced_slab;
+    if (!with_ws && forced_wgs >= 64) target_wgs = forced_wgs;
+    nslab = (target_wgs + combos - 1) / combos;
     if (nslab > ntiles) nslab = ntiles;
     if (nslab < 1) nslab = 1;
-    if (wide) k_conv_wgrad_mfma<2><<<combos * nslab, wg::NTHREADS, 0, st>>>(s, (const bf16_t*)dy, dw, db, N, D, H, W, Cout, nslab);
-    else k_conv_wgrad_mfma<1><<<combos * nslab, wg::NTHREADS, 0, st>>>(s, (const bf16_t*)dy, dw, db, N, D, H, W, Cout, nslab);
+}
+
+int64_t conv3d_wgrad_mfma_ws_bytes(int C0, int C1, int Cout, int N, int D, int H, int W, int planar) {
+    int CIB, combos, nslab;
+    wgrad_plan(C0, C1, Cout, N, D, H, W, planar, true, CIB, combos, nslab);
+    return (int64_t)combos * nslab * (CIB == 32 ? 2 : 1) * 9 * 64 * CIB * (int64_t)sizeof(float);
+}
+
+int conv3d_wgrad_mfma(const void* src0, int C0, int up0, int planar, const void* src1, int C1, const void* dy, float* dw, float* db, int N,
+                      int D, int H, int W, int Cout, void* workspace, int64_t workspace_bytes, hipStream_t st) {
+    SrcB s{(const bf16_t*)src0, (const bf16_t*)src1, C0, C1, up0, planar ? 0 : 1, planar};
+    const int Cin = C0 + C1;
+    // The slab flush wins where the flush dominates (small layers: -25..35 %) and loses ~4 % on the >= 0.3 TFLOP layers, whose atomic
+    // flush overlaps other workgroups' MFMA work while the reduction pass is a serial tail (tools/bench_conv.py, BENCH_WGRAD_WS=0|1).
+    static int force_slab = -1;
+    if (force_slab < 0) {
+        const char* e = getenv("FMRI_WGRAD_SLAB");      // 1: always use the workspace when given (bit-reproducible), 0: heuristic
+        force_slab = e ? atoi(e) : 0;
+    }
+    const double flops_ = 2.0 * (planar ? 9 : 27) * (double)(C0 + C1) * Cout * (double)N * D * H * W;
+    const bool use_ws = workspace != nullptr && workspace_bytes >= conv3d_wgrad_mfma_ws_bytes(C0, C1, Cout, N, D, H, W, planar) &&
+                        (force_slab == 1 || flops_ < 0.3e12);
+    int CIB, combos, nslab;
+    wgrad_plan(C0, C1, Cout, N, D, H, W, planar, use_ws, CIB, combos, nslab);
+    float* ws = use_ws ? (float*)workspace : nullptr;
+    if (CIB == 64) k_conv_wgrad_mfma<2><<<combos * nslab, wg::NTHREADS, 0, st>>>(s, (const bf16_t*)dy, dw, db, N, D, H, W, Cout, nslab, ws);
+    else k_conv_wgrad_mfma<1><<<combos * nslab, wg::NTHREADS, 0, st>>>(s, (const bf16_t*)dy, dw, db, N, D, H, W, Cout, nslab, ws);
+    if (use_ws) {
+        const int ncob = Cout / 64, ncib = Cin / CIB;
+        const int64_t cols = (int64_t)combos * 9 * 64 * CIB / 4;
+        const int grid = (int)((cols + 31) / 32);
+        if (CIB == 64) k_wgrad_reduce<64><<<grid, 256, 0, st>>>(ws, dw, Cout, Cin, nslab, combos, ncob, ncib, planar, 1);
+        else k_wgrad_reduce<32><<<grid, 256, 0, st>>>(ws, dw, Cout, Cin, nslab, combos, ncob, ncib, planar, 2);
+    }
     FMRI_LAUNCH_CHECK();
     return FMRI_OK;
 }

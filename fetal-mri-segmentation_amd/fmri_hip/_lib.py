@@ -27,7 +27,8 @@ SIGNATURES = {
     "fmri_conv3d_uses_mfma": [i32] * 7,
     "fmri_conv3d_fwd": [p, i32, i32, p, i32, p, p, p, p, i32, i32, i32, i32, i32, i32, f32, i32, i32, i32, p],
     "fmri_conv3d_dgrad": [p, i32, p, p, p, i32, i32, i32, i32, i32, i32, i32, i32, p],
-    "fmri_conv3d_wgrad": [p, i32, i32, p, i32, p, p, p, i32, i32, i32, i32, i32, i32, i32, i32, p],
+    "fmri_conv3d_wgrad": [p, i32, i32, p, i32, p, p, p, i32, i32, i32, i32, i32, i32, i32, i32, p, i64, p],
+    "fmri_conv3d_wgrad_workspace_bytes": [i32] * 9,
     "fmri_conv3d_pack_weights": [p, p, p, i32, i32, i32, p],
     "fmri_conv1x1_fwd": [p, p, p, p, i64, i32, i32, i32, p],
     "fmri_conv1x1_bwd": [p, p, p, p, p, p, i64, i32, i32, i32, i32, p],
@@ -69,7 +70,7 @@ def lib():
         for name, args in SIGNATURES.items():
             fn = getattr(L, name)
             fn.argtypes = args
-            fn.restype = C.c_char_p if name == "fmri_error_string" else i32
+            fn.restype = C.c_char_p if name == "fmri_error_string" else (i64 if name.endswith("_workspace_bytes") else i32)
         _lib = L
     return _lib
 

@@ -270,10 +270,11 @@ class UNetEngine:
             self._build_buffers()
             self._bufsets[key] = dict(act=self.act, grad=getattr(self, "grad", None), logits=self.logits, probs=self.probs,
                                       dlogits=getattr(self, "dlogits", None), pre=self.pre, nstats=self.nstats, norm_ws=self.norm_ws,
+                                      wgrad_ws=getattr(self, "wgrad_ws", None),
                                       dummy_y=torch.zeros(self.logits.numel(), dtype=torch.uint8, device=self.dev))
         b = self._bufsets[key]
         self.N, self.act, self.grad, self.logits, self.probs, self.dlogits = N, b["act"], b["grad"], b["logits"], b["probs"], b["dlogits"]
-        self.pre, self.nstats, self.norm_ws = b["pre"], b["nstats"], b["norm_ws"]
+        self.pre, self.nstats, self.norm_ws, self.wgrad_ws = b["pre"], b["nstats"], b["norm_ws"], b["wgrad_ws"]
         self._dummy_y = b["dummy_y"]       # per buffer set and never freed: captured hipGraphs keep raw pointers to it
 
     def _dims(self, level):
@@ -314,7 +315,7 @@ class UNetEngine:
         self.probs = torch.empty_like(self.logits)
         self.sums = torch.zeros(16, dtype=torch.float64, device=dev)
         if not self.training:
-            self.grad, self.dlogits = None, None
+            self.grad, self.dlogits, self.wgrad_ws = None, None, None
             return
         Gd = self.grad = {}
         for name, t in A.items():
@@ -323,6 +324,13 @@ class UNetEngine:
             a = lv[0]
             Gd["cat_%d" % a["level"]] = torch.empty(self._dims(a["level"]) + (a["cin"],), dtype=dt, device=dev)
         self.dlogits = torch.empty_like(self.logits)
+        # scratch for the slab flush of the MFMA weight-gradient kernel (max over the layers of this plan)
+        need = 0
+        for c in p.convs_forward_order():
+            dims = self._dims(c["level"])
+            c0, c1 = (c["c_up"], c["c_skip"]) if "c_up" in c else (c["cin"], 0)
+            need = max(need, ops.conv3d_wgrad_workspace_bytes(c0, c1, c["cout"], dims[0], dims[1], dims[2], dims[3], dt, self.planar))
+        self.wgrad_ws = torch.empty(max(need // 4, 1), dtype=torch.float32, device=dev) if need else None
 
     # ------------------------------------------------------------------------------------------------ forward
     def _norm_mode(self):
@@ -411,7 +419,8 @@ class UNetEngine:
             ops.norm_act_bwd(self._as_samples(self.pre[name]), self._as_samples(self.act[name]), self._as_samples(g),
                              self.gb_view(name, "gamma"), self.nstats[name], self._as_samples(g), self.gb_view(name, "gamma", self.G),
                              self.gb_view(name, "beta", self.G), self.norm_ws, per, act=ACT_RELU)
-        ops.conv3d_wgrad(src0, src1, g, self.w_view(name, self.G), self.b_view(name, self.G), up0=up0, planar=self.planar)
+        ops.conv3d_wgrad(src0, src1, g, self.w_view(name, self.G), self.b_view(name, self.G), up0=up0, planar=self.planar,
+                         workspace=self.wgrad_ws)
         self._grad_ready(name)
 
     def _mask_of(self, name):

@@ -50,14 +50,15 @@ def conv3d_dgrad(dy, w_dgrad, dx, mask=None, impl=IMPL_AUTO, planar=False):
     return dx
 
 
-def conv3d_wgrad(src0, src1, dy, dw, db, up0=False, impl=IMPL_AUTO, planar=False):
+def conv3d_wgrad(src0, src1, dy, dw, db, up0=False, impl=IMPL_AUTO, planar=False, workspace=None):
     _need_cuda(src0, src1, dy, dw, db)
     N, D, H, W, Cout = dy.shape
     C0 = src0.shape[-1]
     C1 = 0 if src1 is None else src1.shape[-1]
     assert dw.dtype == torch.float32 and dw.numel() == 27 * Cout * (C0 + C1)
     check(lib().fmri_conv3d_wgrad(_p(src0), C0, int(up0), _p(src1), C1, _p(dy), _p(dw), _p(db), N, D, H, W, Cout, dt(dy),
-                                  impl, int(planar), _s()), "fmri_conv3d_wgrad")
+                                  impl, int(planar), _p(workspace), 0 if workspace is None else workspace.numel() * workspace.element_size(),
+                                  _s()), "fmri_conv3d_wgrad")
 
 
 def pack_weights(w, w_fwd, w_dgrad):
@@ -273,3 +274,8 @@ def loss_value_from_sums(s, kind, param=1.0, smooth=1.0):
     if kind == 4:
         return -(I + smooth) / (Sy + Sp - I + smooth)
     return -dice + param * (2 * (Sp - I) + smooth) / ((n - Sy) + Sp + smooth)
+
+
+def conv3d_wgrad_workspace_bytes(C0, C1, Cout, N, D, H, W, dtype, planar=False):
+    d = BF16 if dtype == torch.bfloat16 else F32
+    return int(lib().fmri_conv3d_wgrad_workspace_bytes(C0, C1, Cout, N, D, H, W, d, int(planar)))

@@ -59,9 +59,15 @@ int fmri_conv3d_dgrad(const void* dy, int Cout, const void* w_dgrad, const void*
 
 /* ---- Conv3DBackpropFilterV2 + BiasAddGrad: dw[27][Cout][C0+C1] (fp32) += sum_v x[v+tap][ci]*dy[v][co];
  * db[Cout] (fp32) += sum_v dy[v][co] (db may be NULL).  ACCUMULATES: the caller zeroes dw/db once per step.
- * Same dual-source / fused-upsample input description as fmri_conv3d_fwd. */
+ * Same dual-source / fused-upsample input description as fmri_conv3d_fwd.
+ * workspace (optional, device, fp32 scratch of at least fmri_conv3d_wgrad_workspace_bytes(...) bytes): the MFMA path then flushes its
+ * per-workgroup partial sums with plain stores and reduces them in a second launch (bit-reproducible, faster than the fp32-atomic
+ * flush used when workspace == NULL). */
 int fmri_conv3d_wgrad(const void* src0, int C0, int up0, const void* src1, int C1, const void* dy, float* dw, float* db,
-                      int N, int D, int H, int W, int Cout, int dtype, int impl, int planar, fmri_stream_t stream);
+                      int N, int D, int H, int W, int Cout, int dtype, int impl, int planar, void* workspace,
+                      int64_t workspace_bytes, fmri_stream_t stream);
+/* bytes of workspace fmri_conv3d_wgrad can use for this shape (0: the shape does not take the slab path) */
+int64_t fmri_conv3d_wgrad_workspace_bytes(int C0, int C1, int Cout, int N, int D, int H, int W, int dtype, int planar);
 
 /* fp32 master filter [27][Cout][Cin] -> w_fwd (dtype, same layout) and w_dgrad (dtype, [26-tap][Cin][Cout]).
  * Either destination may be NULL. */

@@ -87,6 +87,20 @@ def test_conv3d_wgrad(ops, case):
     db = torch.zeros((Cout,), dtype=torch.float32, device="cuda")
     ops.conv3d_wgrad(src0, src1, dy, dw, db, up0=up0, impl=impl)
     torch.cuda.synchronize()
+    nws = ops.conv3d_wgrad_workspace_bytes(C0, C1, Cout, N, D, H, W, dtype)
+    if impl == 2:
+        # slab flush (plain stores + reduction pass) gives the same sums as the atomic flush, and is bit-reproducible
+        assert nws > 0
+        ws = torch.empty(nws // 4, dtype=torch.float32, device="cuda")
+        outs = []
+        for _ in range(2):
+            dw2 = torch.zeros_like(dw)
+            db2 = torch.zeros_like(db)
+            ops.conv3d_wgrad(src0, src1, dy, dw2, db2, up0=up0, impl=impl, workspace=ws)
+            outs.append(dw2)
+        torch.cuda.synchronize()
+        assert torch.equal(outs[0], outs[1])
+        assert_close(outs[0], dw, 1e-5, 1e-5, what=name + " slab vs atomic")
     x = ref_concat_input(f64(src0), None if src1 is None else f64(src1), up0)
     wk = torch.zeros((Cout, C0 + C1, 3, 3, 3), dtype=torch.float64, requires_grad=True)
     out = F.conv3d(x, wk, None, padding=1)

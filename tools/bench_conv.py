@@ -34,11 +34,13 @@ def run(iters, which):
         b = torch.zeros(Cout, device="cuda")
         y = torch.empty((N, D, H, W, Cout), device="cuda", dtype=torch.bfloat16)
         dw = torch.zeros((27, Cout, C0 + C1), device="cuda")
+        nws = ops.conv3d_wgrad_workspace_bytes(C0, C1, Cout, N, D, H, W, torch.bfloat16) if os.environ.get("BENCH_WGRAD_WS", "1") == "1" else 0
+        ws = torch.empty(max(nws // 4, 1), device="cuda") if nws else None
         db = torch.zeros(Cout, device="cuda")
         fl = 2.0 * 27 * (C0 + C1) * Cout * N * D * H * W
         for kind in which:
             f = (lambda: ops.conv3d_fwd(src0, src1, w, b, y, up0=bool(up0))) if kind == "fwd" else \
-                (lambda: ops.conv3d_wgrad(src0, src1, y, dw, db, up0=bool(up0)))
+                (lambda: ops.conv3d_wgrad(src0, src1, y, dw, db, up0=bool(up0), workspace=ws))
             for _ in range(3):
                 f()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
