@@ -44,7 +44,25 @@ constexpr int HALO_BYTES = H_INSTR * 1024;             // 69,632 (1080 rows x 64
 constexpr int NTHREADS = 512;
 }  // namespace fw
 
-__device__ uint4 g_zero_page[8];                       // 128 B of zeros: DMA source for out-of-volume halo rows
+// Zeros: the DMA source for out-of-volume halo rows.  The fwd kernel advances EVERY lane's source pointer by 64 B per channel chunk,
+// zero-page lanes included, so the page must cover Cin * 2 bytes: 8 KiB + slack = Cin <= 4096 (checked in conv3d_fwd_mfma_ok).
+__device__ uint4 g_zero_page[520];
+#ifdef FMRI_CHECK
+__device__ long long g_chk[16];
+extern "C" void fmri_debug_chk(long long* out) { hipMemcpyFromSymbol(out, HIP_SYMBOL(g_chk), sizeof(g_chk)); }
+#endif
+#ifdef FMRI_PROF
+__device__ unsigned long long g_prof[12];
+extern "C" void fmri_debug_prof(unsigned long long* out, int reset) {
+    if (out) hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof), sizeof(g_prof));
+    if (reset) { unsigned long long z[12] = {}; hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof(z)); }
+}
+#define PROF_T(x) const unsigned long long x = __builtin_amdgcn_s_memtime()
+#define PROF_ADD(i, a, b) prof[i] += (b) - (a)
+#else
+#define PROF_T(x)
+#define PROF_ADD(i, a, b)
+#endif                       // 128 B of zeros: DMA source for out-of-volume halo rows
 
 // LDS-DMA of 16 B per lane: LDS destination = wave-uniform byte address `lds_dst` + lane*16 (M0-based), global source per
 // lane.  Issued from inline asm so that hipcc does not put its own `s_waitcnt vmcnt(0)` in front of the LDS reads of the
@@ -54,6 +72,14 @@ __device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_dst) {
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep)
                  : "v"(gsrc), "s"(lds_dst)
+                 : "memory");
+}
+// same with a wave-uniform 64-bit base in SGPRs and a 32-bit per-lane byte offset: no 64-bit VALU address arithmetic at all
+__device__ __forceinline__ void dma16_s(const void* sbase, unsigned voff, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(sbase), "s"(lds_dst)
                  : "memory");
 }
 __device__ __forceinline__ unsigned lds_addr(const void* p) {
@@ -106,41 +132,37 @@ k_conv_fwd_mfma(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__
     };
 
     // ---- per-lane constants of the DMA address generation (hoisted: the phase loop only adds wave-uniform bases)
-    int f_soff[F_PER_WAVE];        // element offset of this lane's 16 B inside a filter slab's global image
-    unsigned f_doff[F_PER_WAVE];   // LDS byte offset of the wave-instruction inside a filter ring slot
+    unsigned f_voff[F_PER_WAVE];   // byte offset of this lane's 16 B inside a filter slab's global image
 #pragma unroll
     for (int k = 0; k < F_PER_WAVE; ++k) {
-        int instr = wv + 8 * k;
-        if (instr >= F_INSTR) instr = wv % F_INSTR;                // duplicate: keeps the per-wave DMA count uniform
+        const int instr = (wv + 8 * k) % F_INSTR;                  // waves past the slab's end repeat an instruction (k = 0 only)
         const int i = instr * 64 + lane;
         const int row = i >> 2, ps = i & 3;
         const int ls = ps ^ ((row >> 2) & 3);
-        f_soff[k] = ((row / BN) * Cout + (row % BN)) * Cin + ls * 8;
-        f_doff[k] = instr * 1024;
+        f_voff[k] = (unsigned)(((row / BN) * Cout + (row % BN)) * Cin + ls * 8) * 2u;
     }
     int h_pack[9];                 // halo piece ph: hd | hh<<4 | hw<<8 | ls<<13 | valid<<15
-    unsigned h_doff[9];
 #pragma unroll
     for (int ph = 0; ph < 9; ++ph) {
-        int instr = ph * 8 + wv;
-        if (instr >= H_INSTR) instr -= 8;                          // duplicate of this wave's previous piece
-        const int i = instr * 64 + lane;
+        const int i = (ph * 8 + wv) * 64 + lane;
         const int hv = i >> 2, ps = i & 3;
         const int ls = ps ^ ((hv >> 2) & 3);
         const int hvc = hv < HVOX ? hv : 0;
         const int hw_ = hvc % HW, hq = hvc / HW;
         h_pack[ph] = (hq / HH) | ((hq % HH) << 4) | (hw_ << 8) | (ls << 13) | ((hv < HVOX ? 1 : 0) << 15);
-        h_doff[ph] = instr * 1024;
     }
-    // filter slab of phase `ph` = (kd,kh) for item `it` into filter ring slot `fb`
+    // filter slab of phase `ph` = (kd,kh) for item `it` into filter ring slot `fb`: scalar base + constant lane offset
     auto issue_filter = [&](const FwdItem& it, int ph, int fb) {
         const bf16_t* const base = wt + (((int64_t)ph * 3 * Cout + it.co0) * Cin + (it.ch << 5));
 #pragma unroll
         for (int k = 0; k < F_PER_WAVE; ++k)
-            dma16(base + f_soff[k], __builtin_amdgcn_readfirstlane(ldsf0 + fb * FILT_BYTES + f_doff[k]));
+            if (k == 0 || wv + 8 * k < F_INSTR)
+                dma16_s(base, f_voff[k], __builtin_amdgcn_readfirstlane(ldsf0 + fb * FILT_BYTES + ((wv + 8 * k) % F_INSTR) * 1024));
     };
-    // 1/9 of the halo tile of item `it` into halo ring slot `hb` (ph must be a compile-time constant at the call site)
-    auto issue_halo = [&](const FwdItem& it, int pk, unsigned doff, int hb) {
+    // Halo source pointers, one per piece (1/9 of the tile) and lane.  They are worked out in full only when the stream moves to
+    // a new tile or crosses from source 0 to source 1 of a concatenation; otherwise the next chunk is 32 channels further on.
+    const bf16_t* hp[9];
+    auto halo_src = [&](const FwdItem& it, int pk) -> const bf16_t* {
         const int cc = it.ch << 5;
         const bool from0 = cc < s.C0;
         const bf16_t* sp = from0 ? s.p0 : s.p1;
@@ -155,11 +177,33 @@ k_conv_fwd_mfma(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__
         const int gdc = min(max(gd, 0), D - 1) >> shd, ghc = min(max(gh, 0), H - 1) >> sh, gwc = min(max(gw, 0), W - 1) >> sh;
         const int off = ((gdc * sH + ghc) * sW + gwc) * sC + coff + ls * 8;      // inside one sample: < 2^31 elements
         const bf16_t* real = sp + (int64_t)it.n * sD * sH * sW * sC + off;
-        const void* src = ok ? (const void*)real : (const void*)g_zero_page;
-        dma16(src, __builtin_amdgcn_readfirstlane(lds0 + hb * HALO_BYTES + doff));
+        return ok ? real : (const bf16_t*)g_zero_page;
+    };
+    auto issue_halo = [&](int ph, int hb) {            // ph is a compile-time constant at every call site
+#ifdef FMRI_CHECK
+        {
+            const char* q = (const char*)hp[ph];
+            const char* z = (const char*)g_zero_page;
+            const char* a0 = (const char*)s.p0; const char* a1 = (const char*)s.p1;
+            const long long e0 = (long long)N * (D >> (s.up0 & s.dsh)) * (H >> s.up0) * (W >> s.up0) * s.C0 * 2;
+            const long long e1 = (long long)N * D * H * W * s.C1 * 2;
+            const bool okz = q >= z && q + 16 <= z + sizeof(g_zero_page);
+            const bool ok0 = q >= a0 && q + 16 <= a0 + e0;
+            const bool ok1 = s.C1 > 0 && q >= a1 && q + 16 <= a1 + e1;
+            if (!(okz || ok0 || ok1)) {
+                if (atomicAdd((unsigned long long*)&g_chk[0], 1ull) == 0) {
+                    g_chk[1] = ph; g_chk[2] = wv; g_chk[3] = lane; g_chk[4] = (long long)q; g_chk[5] = (long long)z; g_chk[6] = (long long)a0;
+                    g_chk[7] = e0; g_chk[8] = blockIdx.x; g_chk[9] = hb;
+                }
+                hp[ph] = (const bf16_t*)g_zero_page;
+            }
+        }
+#endif
+        if (ph * 8 + wv < H_INSTR) dma16(hp[ph], __builtin_amdgcn_readfirstlane(lds0 + hb * HALO_BYTES + (ph * 8 + wv) * 1024));
     };
 
     f32x16 acc[2][NT];
+    float4 bv[NT][4];              // this lane's 4 x 4 bias values per 32-channel tile (fetched during the last chunk's first phase)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -187,9 +231,16 @@ k_conv_fwd_mfma(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__
     FwdItem cur = decode(pair, 0);
     // prologue: the whole halo of the first item and its first filter slab
 #pragma unroll
-    for (int ph = 0; ph < 9; ++ph) issue_halo(cur, h_pack[ph], h_doff[ph], 0);
+    for (int ph = 0; ph < 9; ++ph) {
+        hp[ph] = halo_src(cur, h_pack[ph]);
+        issue_halo(ph, 0);
+    }
     issue_filter(cur, PH0, 0);
     int g = 0, hb = 0;
+#ifdef FMRI_PROF
+    unsigned long long prof[12] = {};
+    PROF_T(tk0);
+#endif
     while (true) {
         // the item after `cur` in this workgroup's stream
         bool has_next = true;
@@ -201,18 +252,51 @@ k_conv_fwd_mfma(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__
             has_next = npair < npairs;
             if (has_next) nxt = decode(npair, 0);
         }
+        const bool fresh = nxt.ch == 0 || (nxt.ch << 5) == s.C0;   // new tile, or first chunk of the second source
         const unsigned char* const lh = lds + hb * HALO_BYTES;
+        // keep the 54 per-(phase,tap) fragment addresses out of long-lived registers: recomputing them costs a few VALU
+        // instructions per MFMA, which issue in the MFMA's shadow, whereas hoisting them spills
+        asm volatile("" : "+v"(hv0[0]), "+v"(hv0[1]));
 #pragma unroll
         for (int pl = 0; pl < NPH; ++pl, ++g) {
             const int ph = PH0 + pl;
+            PROF_T(t0);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's DMA of the previous phase has landed
+            PROF_T(t1);
             __builtin_amdgcn_s_barrier();                          // ... and everybody else's; previous phase fully read
-            if (pl < NPH - 1) issue_filter(cur, ph + 1, (g + 1) & 1);
-            else if (has_next) issue_filter(nxt, PH0, (g + 1) & 1);
-            if (has_next) {
+            PROF_T(t2);
+            // DMA of the next phase (an LDS-DMA instruction costs its wave 100-180 cycles of issue here wherever it is placed:
+            // staggering the two waves of a SIMD, or issuing mid-phase, measured the same or slower - tools/prof_phases.py)
+            auto issue_dma = [&]() {
+                if (pl < NPH - 1) issue_filter(cur, ph + 1, (g + 1) & 1);
+                else if (has_next) issue_filter(nxt, PH0, (g + 1) & 1);
+                if (has_next) {
 #pragma unroll
-                for (int q = 0; q < HPP; ++q) issue_halo(nxt, h_pack[pl * HPP + q], h_doff[pl * HPP + q], hb ^ 1);
+                    for (int q = 0; q < HPP; ++q) {
+                        if (fresh) hp[pl * HPP + q] = halo_src(nxt, h_pack[pl * HPP + q]);
+                        else hp[pl * HPP + q] += 32;
+                        issue_halo(pl * HPP + q, hb ^ 1);
+                    }
+                }
+            };
+            issue_dma();
+            if (pl == 0 && cur.ch == nch - 1) {
+                // the epilogue's bias, fetched a chunk ahead: 8 dependent L2 round trips inside the epilogue cost 23 % of the
+                // kernel at Cin = 32 (tools/prof_phases.py)
+                if (bias) {
+#pragma unroll
+                    for (int c = 0; c < NT; ++c)
+#pragma unroll
+                        for (int gq = 0; gq < 4; ++gq)
+                            bv[c][gq] = *reinterpret_cast<const float4*>(bias + cur.co0 + c * 32 + 8 * gq + 4 * hk);
+                } else {
+#pragma unroll
+                    for (int c = 0; c < NT; ++c)
+#pragma unroll
+                        for (int gq = 0; gq < 4; ++gq) bv[c][gq] = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
             }
+            PROF_T(t3);
             const unsigned char* const lf = lds + 2 * HALO_BYTES + (g & 1) * FILT_BYTES;
             const int hoff = ((ph / 3) * HH + (ph % 3)) * HW;
 #pragma unroll
@@ -235,47 +319,100 @@ k_conv_fwd_mfma(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__
                             acc[j][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[c], b[j], acc[j][c], 0, 0, 0);
                 }
             }
+            PROF_T(t4);
+            PROF_ADD(0, t0, t1); PROF_ADD(1, t1, t2); PROF_ADD(2, t2, t3); PROF_ADD(3, t3, t4);
+#ifdef FMRI_PROF
+            prof[6] += 1;
+#endif
         }
         if (cur.ch == nch - 1) {
-            // ---- epilogue: D rows = output channel (reg&3)+8*(reg>>2)+4*hk, D cols = voxel r
+            // ---- epilogue.  D rows = output channel (reg&3)+8*(reg>>2)+4*hk, D cols = voxel r: a lane owns 4-channel pieces of ONE
+            // voxel, and storing those directly touches 64 cache lines per instruction (measured: 35 % of the kernel at Cin = 32,
+            // store-issue bound).  Instead the wave's 64 voxels x BN channels go through a wave-private 8 KiB of the halo slot that
+            // was just consumed (free until the next phase's DMA; the barrier below retires its readers) and come back
+            // line-major: 8 (4) lanes write one voxel's 128 (64) contiguous bytes.
+            PROF_T(te0);
+            constexpr int CPV = BN / 8;                  // 16-byte pieces per voxel
+            constexpr int VPI = 64 / CPV;                // voxels per store instruction
+            constexpr int SWM = NT == 2 ? 7 : 3;         // piece swizzle: row v keeps piece q at slot q ^ sw(v)
+            __builtin_amdgcn_s_barrier();
+            PROF_T(te2);
+            unsigned char* const stage = lds + hb * HALO_BYTES + wv * (64 * BN * 2);
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const int rt = 2 * wv + j;
-                const int d = cur.d0 + (rt >> 2), h = cur.h0 + 2 * (rt & 3) + (r >> 4), w = cur.w0 + wl;
-                const int64_t vo = ((((int64_t)cur.n * D + d) * H + h) * W + w) * Cout + cur.co0;
+                const int v = j * 32 + r;
+                const int vs = NT == 2 ? (v & 7) : ((v >> 2) & 3);
 #pragma unroll
                 for (int c = 0; c < NT; ++c) {
 #pragma unroll
-                    for (int gq = 0; gq < 4; ++gq) {
-                        const int cch = c * 32 + 8 * gq + 4 * hk;
-                        float o[4];
-                        float4 bv4 = make_float4(0.f, 0.f, 0.f, 0.f);
-                        if (bias) bv4 = *reinterpret_cast<const float4*>(bias + cur.co0 + cch);
-                        const float bvv[4] = {bv4.x, bv4.y, bv4.z, bv4.w};
+                    for (int pq = 0; pq < 2; ++pq) {
+                        unsigned pk[2][2];                          // [group 2pq, 2pq+1][dword]: this lane's 4 channels, bf16
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            float v = acc[j][c][4 * gq + i] + bvv[i];
-                            if (act == FMRI_ACT_RELU) v = fmaxf(v, 0.f);
-                            else if (act == FMRI_ACT_LEAKY) v = v > 0.f ? v : alpha * v;
-                            o[i] = v;
-                            acc[j][c][4 * gq + i] = 0.f;
-                        }
-                        if (mask) {
-                            float m[4];
-                            ldv<bf16_t, 4>(mask + vo + cch, m);
+                        for (int u = 0; u < 2; ++u) {
+                            const int gq = 2 * pq + u;
+                            const float bvv[4] = {bv[c][gq].x, bv[c][gq].y, bv[c][gq].z, bv[c][gq].w};
+                            float o[4];
 #pragma unroll
-                            for (int i = 0; i < 4; ++i) if (!(m[i] > 0.f)) o[i] = 0.f;
+                            for (int i = 0; i < 4; ++i) {
+                                float vv = acc[j][c][4 * gq + i] + bvv[i];
+                                if (act == FMRI_ACT_RELU) vv = fmaxf(vv, 0.f);
+                                else if (act == FMRI_ACT_LEAKY) vv = vv > 0.f ? vv : alpha * vv;
+                                o[i] = vv;
+                                acc[j][c][4 * gq + i] = 0.f;
+                            }
+                            pk[u][0] = (unsigned)f2bf(o[0]) | ((unsigned)f2bf(o[1]) << 16);
+                            pk[u][1] = (unsigned)f2bf(o[2]) | ((unsigned)f2bf(o[3]) << 16);
                         }
-                        stv<bf16_t, 4>(y + vo + cch, o);
+                        // half-wave exchange: lanes 0-31 end up with channels 16pq..16pq+7 of their voxel, lanes 32-63 with +8..+15
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            auto sw = __builtin_amdgcn_permlane32_swap(pk[0][q], pk[1][q], false, false);
+                            pk[0][q] = sw[0];
+                            pk[1][q] = sw[1];
+                        }
+                        const int q = c * 4 + pq * 2 + hk;
+                        *reinterpret_cast<uint4*>(stage + v * (BN * 2) + (((q ^ vs) & SWM) << 4)) =
+                            make_uint4(pk[0][0], pk[0][1], pk[1][0], pk[1][1]);
                     }
                 }
             }
+            PROF_T(te3);
+            PROF_ADD(7, te0, te2); PROF_ADD(8, te2, te3);
+#pragma unroll
+            for (int kk = 0; kk < CPV; ++kk) {
+                const int v = kk * VPI + lane / CPV, q = lane % CPV;
+                const int vs = NT == 2 ? (v & 7) : ((v >> 2) & 3);
+                uint4 o4 = *reinterpret_cast<const uint4*>(stage + v * (BN * 2) + (((q ^ vs) & SWM) << 4));
+                const int rt = 2 * wv + (v >> 5), rr = v & 31;
+                const int wq = (rr >> 4) ? (((rr & 15) + 16 - (HW & 15)) & 15) : (rr & 15);
+                const int d = cur.d0 + (rt >> 2), h = cur.h0 + 2 * (rt & 3) + (rr >> 4), w = cur.w0 + wq;
+                const int64_t ao = ((((int64_t)cur.n * D + d) * H + h) * W + w) * Cout + cur.co0 + q * 8;
+                if (mask) {
+                    const uint4 m4 = *reinterpret_cast<const uint4*>(mask + ao);
+                    const unsigned mm[4] = {m4.x, m4.y, m4.z, m4.w};
+                    unsigned* const oo = reinterpret_cast<unsigned*>(&o4);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        if (!(__uint_as_float(mm[i] << 16) > 0.f)) oo[i] &= 0xffff0000u;
+                        if (!(__uint_as_float(mm[i] & 0xffff0000u) > 0.f)) oo[i] &= 0x0000ffffu;
+                    }
+                }
+                *reinterpret_cast<uint4*>(y + ao) = o4;
+            }
+            PROF_T(te1);
+            PROF_ADD(4, te0, te1);
         }
         if (!has_next) break;
         cur = nxt;
         pair = npair;
         hb ^= 1;
     }
+#ifdef FMRI_PROF
+    PROF_T(tk1);
+    prof[5] = tk1 - tk0;
+    if (lane == 0)
+        for (int i = 0; i < 12; ++i) atomicAdd(&g_prof[i], prof[i]);
+#endif
 }
 
 // slot swizzle for the 16x16x32 operand map (lane = 16*kgroup + column): conflict-free ds_read_b128 when the 16 rows are 4-aligned
@@ -774,6 +911,7 @@ k_wgrad_reduce(const float* __restrict__ ws, float* __restrict__ dw, int Cout, i
 bool conv3d_fwd_mfma_ok(int C0, int C1, int Cout, int D, int H, int W, int dtype) {
     if (dtype != FMRI_BF16) return false;
     if ((C0 % 32) || (C1 % 32) || C0 + C1 < 32 || (Cout % 32)) return false;
+    if (C0 + C1 > 4096) return false;                    // zero-page length (see g_zero_page)
     if ((D % fw::TD) || (H % fw::TH) || (W % fw::TW)) return false;
     return true;
 }

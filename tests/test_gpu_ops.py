@@ -37,6 +37,9 @@ CONV_CASES = [
     ("mfma_multi_tile", torch.bfloat16, 2, 8, 16, 32, 64, False, 0, 64, 2),
     ("mfma_dual_up", torch.bfloat16, 1, 8, 16, 32, 64, True, 32, 64, 2),
     ("mfma_dual_noup_128", torch.bfloat16, 1, 4, 8, 16, 32, False, 64, 128, 2),
+    # 8 channel chunks on an all-boundary tile: the out-of-volume halo rows keep reading zeros as the source pointers advance
+    ("mfma_deep_256", torch.bfloat16, 1, 4, 8, 16, 256, False, 0, 64, 2),
+    ("mfma_dual_up_deep", torch.bfloat16, 1, 8, 16, 16, 128, True, 64, 96, 2),
     ("first_layer_32", torch.bfloat16, 2, 4, 16, 32, 1, False, 0, 32, 0),
     ("first_layer_64_multi", torch.bfloat16, 1, 8, 32, 64, 1, False, 0, 64, 0),
 ]

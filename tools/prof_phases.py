@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Where a fwd-kernel phase spends its cycles (tuning aid).  Needs the instrumented library (make -C fetal-mri-segmentation_amd/csrc prof):
+   FMRI_LIB=.../libfmri_hip_prof.so python tools/prof_phases.py
+Prints, per layer, the share of wave time in: DMA wait | barrier wait | DMA issue | fragment reads + MFMA issue | rest."""
+import ctypes
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "fetal-mri-segmentation_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import torch
+from bench_conv import LAYERS
+from fmri_hip import ops, _lib
+
+L = _lib.lib()
+L.fmri_debug_prof.argtypes = [ctypes.c_void_p, ctypes.c_int]
+buf = (ctypes.c_ulonglong * 12)()
+N = 4
+for name, C0, up0, C1, Cout, D, H, W in LAYERS:
+    s0 = (N, D // 2, H // 2, W // 2, C0) if up0 else (N, D, H, W, C0)
+    src0 = torch.randn(s0, device="cuda").to(torch.bfloat16)
+    src1 = torch.randn((N, D, H, W, C1), device="cuda").to(torch.bfloat16) if C1 else None
+    w = (torch.randn((27, Cout, C0 + C1), device="cuda") * 0.05).to(torch.bfloat16)
+    b = torch.zeros(Cout, device="cuda")
+    y = torch.empty((N, D, H, W, Cout), device="cuda", dtype=torch.bfloat16)
+    for _ in range(3):
+        ops.conv3d_fwd(src0, src1, w, b, y, up0=bool(up0))
+    torch.cuda.synchronize()
+    L.fmri_debug_prof(None, 1)
+    ops.conv3d_fwd(src0, src1, w, b, y, up0=bool(up0))
+    torch.cuda.synchronize()
+    L.fmri_debug_prof(buf, 0)
+    p = list(buf)
+    tot = max(p[5], 1)
+    sec = [p[i] / tot * 100 for i in range(4)]
+    ep = p[4] / tot * 100
+    epd = "(barrier %.1f, bias+pack+lds-write %.1f, lds-read+store %.1f)" % (p[7] / tot * 100, p[8] / tot * 100, (p[4] - p[7] - p[8]) / tot * 100)
+    print("%-7s cyc/phase %6.0f | dma-wait %5.1f%%  barrier %5.1f%%  dma-issue %5.1f%%  mfma-loop %5.1f%%  epilogue %5.1f%% %s  other %5.1f%%"
+          % (name, tot / max(p[6], 1), sec[0], sec[1], sec[2], sec[3], ep, epd, 100 - sum(sec) - ep))
