@@ -1,0 +1,179 @@
+// Device-side patch sampler and intensity augmentation: the reference builds every training patch on the host
+// (fetal_net/generator.py:246-328 -> augment.py:222-377 -> utils/utils.py:100-113, scipy map_coordinates); here the volumes stay in
+// HBM and a patch is one gather launch plus a few elementwise passes.  All of these are HBM-bound byte movers: one thread per output
+// voxel, z (the contiguous axis of the reference's (X,Y,Z) volumes) fastest, coordinates in fp64 so that nearest-neighbour label
+// sampling rounds exactly like the fp64 host code.
+#include "common.h"
+
+namespace {
+
+struct Affine34 { double a[12]; };     // row-major 3x4: source = A . (i, j, k, 1)
+
+template <typename T> __device__ __forceinline__ float ld_any(const T* p, int64_t i);
+template <> __device__ __forceinline__ float ld_any<float>(const float* p, int64_t i) { return p[i]; }
+template <> __device__ __forceinline__ float ld_any<uint8_t>(const uint8_t* p, int64_t i) { return (float)p[i]; }
+template <typename T> __device__ __forceinline__ void st_any(T* p, int64_t i, float v);
+template <> __device__ __forceinline__ void st_any<float>(float* p, int64_t i, float v) { p[i] = v; }
+template <> __device__ __forceinline__ void st_any<bf16_t>(bf16_t* p, int64_t i, float v) { p[i] = f2bf(v); }
+template <> __device__ __forceinline__ void st_any<uint8_t>(uint8_t* p, int64_t i, float v) { p[i] = (uint8_t)v; }
+
+// scipy.ndimage.map_coordinates(mode='constant'): a point outside [0, n-1] on any axis takes cval (no interpolation beyond the
+// edges); inside, order 0 picks floor(c + 0.5) and order 1 is trilinear on the enclosing cell.
+template <typename TI, typename TO>
+__global__ void k_affine_sample(const TI* __restrict__ vol, int X, int Y, int Z, Affine34 A, int x0, int y0, int z0, int nx, int ny, int nz,
+                                int order, float cval, TO* __restrict__ out, int ld) {
+    const int64_t total = (int64_t)nx * ny * nz;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int k = (int)(t % nz);
+        const int64_t q = t / nz;
+        const int j = (int)(q % ny), i = (int)(q / ny);
+        const double pi = x0 + i, pj = y0 + j, pk = z0 + k;
+        const double cx = A.a[0] * pi + A.a[1] * pj + A.a[2] * pk + A.a[3];
+        const double cy = A.a[4] * pi + A.a[5] * pj + A.a[6] * pk + A.a[7];
+        const double cz = A.a[8] * pi + A.a[9] * pj + A.a[10] * pk + A.a[11];
+        float v = cval;
+        if (cx >= 0.0 && cx <= (double)(X - 1) && cy >= 0.0 && cy <= (double)(Y - 1) && cz >= 0.0 && cz <= (double)(Z - 1)) {
+            if (order == 0) {
+                const int ix = (int)floor(cx + 0.5), iy = (int)floor(cy + 0.5), iz = (int)floor(cz + 0.5);
+                v = ld_any<TI>(vol, ((int64_t)ix * Y + iy) * Z + iz);
+            } else {
+                const int ix = (int)floor(cx), iy = (int)floor(cy), iz = (int)floor(cz);
+                const double fx = cx - ix, fy = cy - iy, fz = cz - iz;
+                const int jx = min(ix + 1, X - 1), jy = min(iy + 1, Y - 1), jz = min(iz + 1, Z - 1);
+                auto at = [&](int a, int b, int c) { return (double)ld_any<TI>(vol, ((int64_t)a * Y + b) * Z + c); };
+                const double c00 = at(ix, iy, iz) * (1 - fz) + at(ix, iy, jz) * fz;
+                const double c01 = at(ix, jy, iz) * (1 - fz) + at(ix, jy, jz) * fz;
+                const double c10 = at(jx, iy, iz) * (1 - fz) + at(jx, iy, jz) * fz;
+                const double c11 = at(jx, jy, iz) * (1 - fz) + at(jx, jy, jz) * fz;
+                v = (float)((c00 * (1 - fy) + c01 * fy) * (1 - fx) + (c10 * (1 - fy) + c11 * fy) * fx);
+            }
+        }
+        st_any<TO>(out, q * ld + k, v);
+    }
+}
+
+// order-preserving float <-> uint key, so that min / max are plain unsigned atomics
+__device__ __forceinline__ unsigned f2key(float f) {
+    const unsigned b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float key2f(unsigned k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
+
+__global__ void k_minmax_init(unsigned* mm) {
+    mm[0] = 0xffffffffu;
+    mm[1] = 0u;
+}
+template <typename T>
+__global__ void k_minmax(const T* __restrict__ x, int64_t n, unsigned* mm) {
+    float lo = INFINITY, hi = -INFINITY;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
+        const float v = to_f<T>(x[t]);
+        lo = fminf(lo, v);
+        hi = fmaxf(hi, v);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        lo = fminf(lo, __shfl_xor(lo, o));
+        hi = fmaxf(hi, __shfl_xor(hi, o));
+    }
+    if ((threadIdx.x & 63) == 0 && lo <= hi) {
+        atomicMin(&mm[0], f2key(lo));
+        atomicMax(&mm[1], f2key(hi));
+    }
+}
+__global__ void k_minmax_decode(unsigned* mm) {
+    const float lo = key2f(mm[0]), hi = key2f(mm[1]);
+    reinterpret_cast<float*>(mm)[0] = lo;
+    reinterpret_cast<float*>(mm)[1] = hi;
+}
+
+// skimage.exposure.rescale_intensity(x, in_range=(lo, hi), out_range='image') then x *= mult (reference augment.py:125-128, :348-352)
+template <typename T>
+__global__ void k_rescale(T* __restrict__ x, int64_t n, const float* __restrict__ stats, int contrast, float lo, float hi, float mult) {
+    const float omin = stats[0], omax = stats[1];
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
+        float v = to_f<T>(x[t]);
+        if (contrast) {
+            v = fminf(fmaxf(v, lo), hi);
+            if (lo != hi) v = (v - lo) / (hi - lo) * (omax - omin) + omin;
+            else v = fminf(fmaxf(v, omin), omax);
+        }
+        x[t] = from_f<T>(v * mult);
+    }
+}
+
+// MinMaxScaler((0,1)) -> skimage.util.random_noise(mode = 'gaussian' | 'speckle', clip=True, var=sigma^2) -> inverse scaling
+// (reference augment.py:99-110); `noise` holds the N(0,1) draws
+template <typename T>
+__global__ void k_noise(T* __restrict__ x, int64_t n, const float* __restrict__ stats, const float* __restrict__ noise, int kind, float sigma) {
+    const float dmin = stats[0], rng = stats[1] - stats[0];
+    const float scale = 1.f / (rng != 0.f ? rng : 1.f), mn = -dmin * scale;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
+        float s = fminf(fmaxf(to_f<T>(x[t]) * scale + mn, 0.f), 1.f);
+        const float e = noise[t] * sigma;
+        s = kind == 0 ? s + e : s + s * e;
+        s = fminf(fmaxf(s, 0.f), 1.f);
+        x[t] = from_f<T>((s - mn) / scale);
+    }
+}
+
+}  // namespace
+
+extern "C" int fmri_affine_sample(const void* vol, int vol_dtype, int X, int Y, int Z, const double* affine, int x0, int y0, int z0, int nx,
+                                  int ny, int nz, int order, float cval, void* out, int out_dtype, int out_ld, fmri_stream_t stream) {
+    if (X < 1 || Y < 1 || Z < 1 || nx < 1 || ny < 1 || nz < 1 || out_ld < nz || (order != 0 && order != 1) || !affine) return FMRI_E_SHAPE;
+    Affine34 A;
+    for (int i = 0; i < 12; ++i) A.a[i] = affine[i];
+    const int64_t total = (int64_t)nx * ny * nz;
+    const int grid = grid_for(total);
+    hipStream_t st = as_stream(stream);
+#define FMRI_AS(TI, TO) \
+    k_affine_sample<TI, TO><<<grid, 256, 0, st>>>((const TI*)vol, X, Y, Z, A, x0, y0, z0, nx, ny, nz, order, cval, (TO*)out, out_ld)
+    if (vol_dtype == FMRI_F32 && out_dtype == FMRI_F32) FMRI_AS(float, float);
+    else if (vol_dtype == FMRI_F32 && out_dtype == FMRI_BF16) FMRI_AS(float, bf16_t);
+    else if (vol_dtype == FMRI_U8 && out_dtype == FMRI_U8) FMRI_AS(uint8_t, uint8_t);
+    else if (vol_dtype == FMRI_U8 && out_dtype == FMRI_F32) FMRI_AS(uint8_t, float);
+    else if (vol_dtype == FMRI_U8 && out_dtype == FMRI_BF16) FMRI_AS(uint8_t, bf16_t);
+    else return FMRI_E_DTYPE;
+#undef FMRI_AS
+    FMRI_LAUNCH_CHECK();
+    return FMRI_OK;
+}
+
+extern "C" int fmri_minmax(const void* x, int64_t n, int dtype, float* out2, fmri_stream_t stream) {
+    if (n < 1) return FMRI_E_SHAPE;
+    hipStream_t st = as_stream(stream);
+    unsigned* mm = reinterpret_cast<unsigned*>(out2);
+    k_minmax_init<<<1, 1, 0, st>>>(mm);
+    const int grid = grid_for(n, 256, 1024);
+    if (dtype == FMRI_F32) k_minmax<float><<<grid, 256, 0, st>>>((const float*)x, n, mm);
+    else if (dtype == FMRI_BF16) k_minmax<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)x, n, mm);
+    else return FMRI_E_DTYPE;
+    k_minmax_decode<<<1, 1, 0, st>>>(mm);
+    FMRI_LAUNCH_CHECK();
+    return FMRI_OK;
+}
+
+extern "C" int fmri_rescale_intensity(void* x, int64_t n, int dtype, const float* stats, int contrast, float lo, float hi, float mult,
+                                      fmri_stream_t stream) {
+    if (n < 1) return FMRI_E_SHAPE;
+    hipStream_t st = as_stream(stream);
+    const int grid = grid_for(n);
+    if (dtype == FMRI_F32) k_rescale<float><<<grid, 256, 0, st>>>((float*)x, n, stats, contrast, lo, hi, mult);
+    else if (dtype == FMRI_BF16) k_rescale<bf16_t><<<grid, 256, 0, st>>>((bf16_t*)x, n, stats, contrast, lo, hi, mult);
+    else return FMRI_E_DTYPE;
+    FMRI_LAUNCH_CHECK();
+    return FMRI_OK;
+}
+
+extern "C" int fmri_noise_augment(void* x, int64_t n, int dtype, const float* stats, const float* noise, int kind, float sigma,
+                                  fmri_stream_t stream) {
+    if (n < 1 || (kind != 0 && kind != 1)) return FMRI_E_SHAPE;
+    hipStream_t st = as_stream(stream);
+    const int grid = grid_for(n);
+    if (dtype == FMRI_F32) k_noise<float><<<grid, 256, 0, st>>>((float*)x, n, stats, noise, kind, sigma);
+    else if (dtype == FMRI_BF16) k_noise<bf16_t><<<grid, 256, 0, st>>>((bf16_t*)x, n, stats, noise, kind, sigma);
+    else return FMRI_E_DTYPE;
+    FMRI_LAUNCH_CHECK();
+    return FMRI_OK;
+}

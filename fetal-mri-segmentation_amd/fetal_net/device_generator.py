@@ -1,0 +1,177 @@
+"""Training-patch generator that never leaves the MI355X.
+
+The reference builds each patch on one host thread (fetal_net/generator.py:222-328: random corner -> augment_data or
+extract_patch -> convert_data) and Keras copies the batch to the device; with the convolutions at MFMA speed that thread is the
+bottleneck.  Here every (padded) volume of the split is uploaded once - 288 GB of HBM holds any dataset of this kind - and a patch
+is: the reference's random draws on the host (same order, same generators => same transformation for the same seed), then one
+fmri_affine_sample launch for the image (trilinear, cval = volume minimum) and one for the labels (nearest, cval = 0) straight
+into the batch tensors, then the elementwise intensity passes.  The generator yields torch CUDA tensors in the reference's logical
+layouts ((N,1,X,Y,Z) / (N,X,Y,C) float32 images, uint8 labels); Model.train_on_batch / fit_generator take them as they are.
+
+`device_data_generator` keeps the keyword arguments of the reference's `data_generator` (generator.py:222-225).
+Applied augmenters: flip, scale, iso_scale, rotate, translate, contrast, intensity_multiplication, gaussian_noise, speckle_noise.
+Not applied (their random draws are still consumed so that the affine part stays aligned with a seeded reference run):
+poisson_noise, gaussian_filter, piecewise_affine, elastic_transform, coarse_dropout - a warning is issued once, or
+NotImplementedError with strict=True.  The noise fields come from a torch device generator (`noise_seed`), not numpy.
+"""
+import random
+import warnings
+
+import numpy as np
+
+from .augment import distort_image, draw_augment_parameters
+
+_UNSUPPORTED = ("poisson_noise", "gaussian_filter", "piecewise_affine", "elastic_transform", "coarse_dropout")
+
+
+class DeviceDataFile(object):
+    """The volumes of a data file, padded as the reference pads them for training (generator.py:13-57: DataFileDummy with
+    `samples_pad`, then pad_samples), resident in HBM: .data[i] float32 (X,Y,Z), .truth[i] uint8 (X,Y,Z), .stats min / max."""
+
+    def __init__(self, data_file, patch_shape, samples_pad=3, truth_downsample=None, indices=None, device="cuda"):
+        import torch
+        ds = truth_downsample or 1
+        root = data_file.root
+        n = len(root.data)
+        self.indices = list(range(n)) if indices is None else list(indices)
+        self.data, self.truth, self.min, self.max = {}, {}, {}, {}
+        self.subject_ids = [s for s in root.subject_ids] if hasattr(root, "subject_ids") else None
+        out_shape = [patch_shape[0] // ds, patch_shape[1] // ds, 1]
+        padding = np.ceil(np.subtract(patch_shape, out_shape) / 2).astype(int)
+        for i in self.indices:
+            d = np.asarray(root.data[i])
+            t = np.asarray(root.truth[i])
+            d = np.pad(d, samples_pad, "constant", constant_values=d.min())
+            t = np.pad(t, samples_pad, "constant", constant_values=0)
+            dmin, dmax = float(np.min(d)), float(np.max(d))
+            d = np.pad(d, [(p, p) for p in padding], "constant", constant_values=dmin)
+            t = np.pad(t, [(p, p) for p in padding], "constant", constant_values=0)
+            fit = np.ceil(np.maximum(np.subtract(patch_shape, d.shape) + 1, 0) / 2).astype(int)
+            d = np.pad(d, [(p, p) for p in fit], "constant", constant_values=dmin)
+            fit = np.ceil(np.maximum(np.subtract(patch_shape, t.shape) + 1, 0) / 2).astype(int)
+            t = np.pad(t, [(p, p) for p in fit], "constant", constant_values=0)
+            self.data[i] = torch.from_numpy(np.ascontiguousarray(d, dtype=np.float32)).to(device)
+            self.truth[i] = torch.from_numpy(np.ascontiguousarray(t).astype(np.uint8)).to(device)
+            self.min[i], self.max[i] = dmin, dmax
+        self.device = device
+
+    def nbytes(self):
+        return sum(v.numel() * 4 for v in self.data.values()) + sum(v.numel() for v in self.truth.values())
+
+
+def random_list_generator(index_list):
+    while True:
+        np.random.seed()                                   # the reference re-seeds from the OS on every pass (generator.py:194-197)
+        yield from random.sample(index_list, len(index_list))
+
+
+def list_generator(index_list):
+    while True:
+        yield from index_list
+
+
+class _Sampler(object):
+    def __init__(self, ddf, patch_shape, augment, truth_index, truth_size, prev_truth_index, prev_truth_size, strict, noise_seed):
+        import torch
+        from fmri_hip import ops
+        self.torch, self.ops = torch, ops
+        self.ddf = ddf
+        self.patch_shape = tuple(int(v) for v in patch_shape)
+        self.augment = augment
+        self.truth_index, self.truth_size = truth_index, truth_size
+        self.prev_truth_index, self.prev_truth_size = prev_truth_index, prev_truth_size
+        self.n_chan = self.patch_shape[2] + (prev_truth_size if prev_truth_index is not None else 0)
+        self.stats = torch.empty(2, device=ddf.device, dtype=torch.float32)
+        self.gen = torch.Generator(device=ddf.device)
+        self.gen.manual_seed(noise_seed)
+        if augment is not None:
+            bad = [k for k in _UNSUPPORTED if augment.get(k) is not None and not (k == "gaussian_filter" and augment[k]["prob"] <= 0)
+                   and not (k == "elastic_transform" and augment[k]["alpha"] <= 0)]
+            if bad:
+                msg = "augmenters not applied on the device path: %s" % ", ".join(bad)
+                if strict:
+                    raise NotImplementedError(msg)
+                warnings.warn(msg)
+
+    def sample_into(self, index, x_slot, y_slot):
+        """x_slot: float32 view (X, Y, n_chan) of the batch tensor; y_slot: uint8 view (X, Y, truth_size)"""
+        ops, ddf = self.ops, self.ddf
+        data, truth = ddf.data[index], ddf.truth[index]
+        ps = self.patch_shape
+        corner = [np.random.randint(low=0, high=h) for h in np.array(truth.shape) - np.array(ps)]
+        zt = corner[2] + self.truth_index
+        if self.augment is not None:
+            p = draw_augment_parameters(self.augment, 3, ddf.min[index], ddf.max[index])
+            _, A = distort_image(data, np.eye(4), flip_axis=p["flip_axis"], scale_factor=p["scale_factor"],
+                                 rotate_factor=p["rotate_factor"], translate_factor=p["translate_factor"])
+            _, At = distort_image(truth, np.eye(4), flip_axis=p["flip_axis"], scale_factor=p["scale_factor"],
+                                  rotate_factor=p["rotate_factor"], translate_factor=p["translate_factor"])
+        else:
+            p, A, At = None, np.eye(4), np.eye(4)
+        # image: trilinear, outside = the volume's minimum; labels: nearest, outside = 0 (identity affine = the plain crop)
+        ops.affine_sample(data, A, corner, ps, x_slot, order=1, cval=ddf.min[index], out_ld=self.n_chan)
+        ops.affine_sample(truth, At, (corner[0], corner[1], zt), (ps[0], ps[1], self.truth_size), y_slot, order=0, cval=0.0,
+                          out_ld=self.truth_size)
+        img = x_slot if self.n_chan == ps[2] else None
+        if p is not None:
+            need_intensity = p["contrast"] is not None or p["intensity_multiplication"] != 1 or p["apply_speckle_noise"] or p["apply_gaussian_noise"]
+            if need_intensity:
+                if img is None:                            # image channels interleaved with the previous-slice truth: work on a copy
+                    img = x_slot[..., :ps[2]].contiguous()
+                if p["contrast"] is not None or p["intensity_multiplication"] != 1:
+                    ops.minmax(img, self.stats)
+                    lo, hi = p["contrast"] if p["contrast"] is not None else (0.0, 0.0)
+                    ops.rescale_intensity(img, self.stats, p["contrast"] is not None, lo, hi, p["intensity_multiplication"])
+                for flag, key, kind in (("apply_speckle_noise", "speckle_noise", 1), ("apply_gaussian_noise", "gaussian_noise", 0)):
+                    if p[flag]:
+                        ops.minmax(img, self.stats)
+                        noise = self.torch.randn(img.numel(), device=img.device, dtype=self.torch.float32, generator=self.gen)
+                        ops.noise_augment(img, self.stats, noise, kind, self.augment[key]["sigma"])
+                if img is not x_slot:
+                    x_slot[..., :ps[2]] = img
+        if self.prev_truth_index is not None:
+            zp = corner[2] + self.prev_truth_index
+            prev = self.torch.empty((ps[0], ps[1], self.prev_truth_size), device=x_slot.device, dtype=self.torch.float32)
+            ops.affine_sample(truth, At, (corner[0], corner[1], zp), (ps[0], ps[1], self.prev_truth_size), prev, order=0, cval=0.0)
+            x_slot[..., ps[2]:] = prev
+
+
+def device_data_generator(data_file, index_list, batch_size=1, n_labels=1, labels=None, augment=None, patch_shape=None,
+                          shuffle_index_list=True, skip_blank=True, truth_index=-1, truth_size=1, truth_downsample=None, truth_crop=True,
+                          categorical=True, prev_truth_index=None, prev_truth_size=None, drop_easy_patches=False, is3d=False,
+                          samples_pad=3, strict=False, noise_seed=0, device="cuda"):
+    """Endless generator of (x, y) CUDA tensors.  `data_file`: a DeviceDataFile, or anything with .root.data / .root.truth
+    (uploaded here).  3-D: x (N,1,X,Y,Z), y (N,1,X,Y,truth_size); 2-D: x (N,X,Y,C), y (N,X,Y,truth_size).  skip_blank and
+    drop_easy_patches read one scalar back per patch (they decide on the host whether the patch is kept), everything else is
+    enqueue-only."""
+    import torch
+    if truth_downsample is not None and truth_downsample > 1:
+        raise NotImplementedError("truth_downsample is not part of the device generator")
+    if patch_shape is None:
+        raise ValueError("the device generator samples patches; patch_shape is required")
+    ddf = data_file if isinstance(data_file, DeviceDataFile) else DeviceDataFile(data_file, patch_shape, samples_pad, truth_downsample,
+                                                                                 indices=sorted(set(index_list)), device=device)
+    sampler = _Sampler(ddf, patch_shape, augment, truth_index, truth_size, prev_truth_index, prev_truth_size, strict, noise_seed)
+    index_generator = random_list_generator(index_list) if shuffle_index_list else list_generator(index_list)
+    ps = sampler.patch_shape
+    while True:
+        x = torch.empty((batch_size, ps[0], ps[1], sampler.n_chan), device=ddf.device, dtype=torch.float32)
+        y = torch.empty((batch_size, ps[0], ps[1], truth_size), device=ddf.device, dtype=torch.uint8)
+        filled = 0
+        while filled < batch_size:
+            index = next(index_generator)
+            sampler.sample_into(index, x[filled], y[filled])
+            if drop_easy_patches:
+                truth_mean = float(y[filled][16:-16, 16:-16, :].float().mean().item())
+                if 1 - np.abs(truth_mean - 0.5) < np.random.random():
+                    continue
+            if skip_blank and not bool(y[filled].any().item()):
+                continue
+            filled += 1
+        yy = y
+        if categorical:
+            yy = torch.stack([1 - y, y], dim=-1).float()           # keras.utils.to_categorical(y, 2)
+        if is3d:
+            yield x.unsqueeze(1), yy.unsqueeze(1)
+        else:
+            yield x, yy

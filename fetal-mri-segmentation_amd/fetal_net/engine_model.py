@@ -226,6 +226,16 @@ class LambdaCallback(Callback):
 
 
 # ----------------------------------------------------------------------------------------------------------------- model
+def _is_device_tensor(a):
+    return type(a).__module__.startswith("torch") and getattr(a, "is_cuda", False)
+
+
+def _batch_len(x):
+    if isinstance(x, (list, tuple)):
+        x = x[0]
+    return int(x.shape[0]) if hasattr(x, "shape") else int(np.asarray(x).shape[0])
+
+
 def _prefetch(generator, max_queue_size):
     """one producer thread, bounded queue (Keras GeneratorEnqueuer with workers=1, reference training.py:115-117)"""
     q = Queue(maxsize=max(1, max_queue_size))
@@ -348,9 +358,11 @@ class Model(object):
 
     def _to_device_x(self, x):
         import torch
-        x = np.asarray(x)
         eng_dtype = self._compute_dtype()
-        t = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).cuda(non_blocking=True)
+        if _is_device_tensor(x):                              # already in HBM (fetal_net.device_generator): no host round trip
+            t = x
+        else:
+            t = torch.from_numpy(np.ascontiguousarray(np.asarray(x), dtype=np.float32)).cuda(non_blocking=True)
         if self._input_layout == "channels_first_3d":       # (N,C,X,Y,Z) -> (N,X,Y,Z,C)
             if t.shape[1] == 1:
                 t = t.reshape(t.shape[0], *t.shape[2:], 1)
@@ -362,8 +374,10 @@ class Model(object):
 
     def _to_device_y(self, y):
         import torch
-        y = np.asarray(y)
-        t = torch.from_numpy(np.ascontiguousarray(y).astype(np.uint8)).cuda(non_blocking=True)
+        if _is_device_tensor(y):
+            t = y if y.dtype == torch.uint8 else y.to(torch.uint8)
+        else:
+            t = torch.from_numpy(np.ascontiguousarray(np.asarray(y)).astype(np.uint8)).cuda(non_blocking=True)
         if self._input_layout == "channels_first_3d" and t.shape[1] != 1:
             t = t.permute(0, 2, 3, 4, 1)
         return t.contiguous().reshape(-1)
@@ -410,7 +424,7 @@ class Model(object):
         self._check_loss()
         if isinstance(x, (list, tuple)):
             x = x[0]
-        n = np.asarray(x).shape[0]
+        n = _batch_len(x)
         eng = self.engine(n)
         sums = eng.train_step(self._to_device_x(x), self._to_device_y(y), self.optimizer.lr)
         logs = self._batch_logs(sums.cpu().numpy())
@@ -419,7 +433,7 @@ class Model(object):
     def test_on_batch(self, x, y, **kw):
         if isinstance(x, (list, tuple)):
             x = x[0]
-        n = np.asarray(x).shape[0]
+        n = _batch_len(x)
         eng = self.engine(n)
         eng.forward(self._to_device_x(x), bn_training=False)        # Keras evaluates with learning_phase = 0
         sums = eng.loss_forward(self._to_device_y(y))
@@ -433,7 +447,7 @@ class Model(object):
             for _ in range(steps):
                 x, y = get()[:2]
                 outs.append(self.test_on_batch(x, y))
-                sizes.append(np.asarray(x[0] if isinstance(x, (list, tuple)) else x).shape[0])
+                sizes.append(_batch_len(x))
         finally:
             stop.set()
         return [float(np.average([o[i] for o in outs], weights=sizes)) for i in range(len(outs[0]))]
@@ -463,7 +477,7 @@ class Model(object):
                 for step in range(steps_per_epoch):
                     batch = get()
                     x, y = batch[0], batch[1]
-                    bs = np.asarray(x[0] if isinstance(x, (list, tuple)) else x).shape[0]
+                    bs = _batch_len(x)
                     for cb in cbs:
                         cb.on_batch_begin(step, {"batch": step, "size": bs})
                     vals = self.train_on_batch(x, y)

@@ -12,6 +12,7 @@ import os
 
 import numpy as np
 
+from .augment import contrast_augment, generate_permutation_keys, permute_data, reverse_permute_data
 from .engine_model import Model
 from .utils.patches import get_patch_from_3d_data
 from .utils.threaded_generator import ThreadedGenerator
@@ -173,9 +174,73 @@ def _device_overlap_add(model, data_0, indices, patch_shape, batch_size, data_sh
 
 
 def predict(model, data, permute=False):
+    """reference prediction.py:354-361"""
     if permute:
-        raise NotImplementedError("48-permutation test-time augmentation is out of the hot-path scope (SURVEY.md §8f row 3)")
+        return np.asarray([predict_with_permutations(model, data[b]) for b in range(data.shape[0])])
     return model.predict(data)
+
+
+def predict_with_permutations(model, data):
+    """mean over the 48 permutation keys of un-permuted predictions (reference prediction.py:362-367); data (C, X, Y, Z).
+    Keys that act identically (only rotate_y and the three flips act) are predicted once and weighted by their multiplicity."""
+    groups = {}
+    for key in generate_permutation_keys():
+        groups.setdefault((key[0][0], key[1], key[2], key[3]), []).append(key)
+    total, n = None, 0
+    for keys in groups.values():
+        pred = reverse_permute_data(model.predict(permute_data(data, keys[0])[np.newaxis])[0], keys[0])
+        total = pred * len(keys) if total is None else total + pred * len(keys)
+        n += len(keys)
+    return total / n
+
+
+def flip_it(data_, axes):
+    for ax in axes:
+        data_ = np.flip(data_, ax)
+    return data_
+
+
+def predict_flips(data, model, overlap_factor, config):
+    """the 8 axis-flip variants, each predicted patch-wise and flipped back; returns the list (reference prediction.py:65-85)"""
+    patch_shape = list(config["patch_shape"]) + [config["patch_depth"]]
+    predictions = []
+    for r in range(4):
+        for axes in itertools.combinations([0, 1, 2], r):
+            flipped = flip_it(data, axes)
+            pred = patch_wise_prediction(model=model, data=np.expand_dims(flipped.squeeze(), 0), overlap_factor=overlap_factor,
+                                         patch_shape=patch_shape).squeeze()
+            predictions.append(flip_it(pred, axes).squeeze())
+    return predictions
+
+
+def predict_augment(data, model, overlap_factor, patch_shape, num_augments=32):
+    """Contrast / flip / transpose / in-plane rotation variants of the volume, each predicted patch-wise on the device and mapped
+    back (reference prediction.py:25-62; same numpy draws in the same order).  The volume-sized spline rotations stay on the
+    host (scipy), as in the reference.  Like the reference, the back-rotation uses scipy's default reshape=True, so stacking
+    succeeds only when all predictions end up with one shape (num_augments = 1, or equal angles)."""
+    from scipy import ndimage
+    data_max, data_min = data.max(), data.min()
+    data = data.squeeze()
+    predictions = []
+    for _ in range(num_augments):
+        val_range = data_max - data_min
+        contrast_min_val = data_min + 0.10 * np.random.uniform(-1, 1) * val_range
+        contrast_max_val = data_max + 0.10 * np.random.uniform(-1, 1) * val_range
+        curr = contrast_augment(data, contrast_min_val, contrast_max_val)
+        rotate_factor = np.random.uniform(-30, 30)
+        to_flip = np.arange(0, 3)[np.random.choice([True, False], size=3)]
+        to_transpose = np.random.choice([True, False])
+        curr = flip_it(curr, to_flip)
+        if to_transpose:
+            curr = curr.transpose([1, 0, 2])
+        curr = ndimage.rotate(curr, rotate_factor, order=2, reshape=False)
+        pred = patch_wise_prediction(model=model, data=curr[np.newaxis, ...], overlap_factor=overlap_factor,
+                                     patch_shape=patch_shape).squeeze()
+        pred = ndimage.rotate(pred, -rotate_factor)
+        if to_transpose:
+            pred = pred.transpose([1, 0, 2])
+        predictions.append(flip_it(pred, to_flip).squeeze())
+    return np.stack(predictions, axis=0)
 
 
 def run_validation_case(data_index, output_dir, model, data_file, training_modalities, patch_shape, overlap_factor=0,
@@ -183,8 +248,6 @@ def run_validation_case(data_index, output_dir, model, data_file, training_modal
     """Predict one case of an opened data file (any object with `.root.data[i]` / `.root.truth[i]`) and write
     data_<modality>.nii.gz, truth.nii.gz, prediction.nii.gz under output_dir (reference prediction.py:277-330)."""
     from .utils.nifti import save_nifti
-    if use_augmentations:
-        raise NotImplementedError("test-time augmentation is out of the hot-path scope (SURVEY.md §8f row 3)")
     if not os.path.exists(output_dir):
         os.makedirs(output_dir)
     test_data = np.asarray([data_file.root.data[data_index]])
@@ -194,6 +257,8 @@ def run_validation_case(data_index, output_dir, model, data_file, training_modal
     save_nifti(np.asarray(data_file.root.truth[data_index]), os.path.join(output_dir, "truth.nii.gz"))
     if tuple(patch_shape) == tuple(test_data.shape[-3:]):
         prediction = predict(model, test_data[:, np.newaxis] if test_data.ndim == 4 else test_data, permute=permute)
+    elif use_augmentations:
+        prediction = predict_augment(data=test_data, model=model, overlap_factor=overlap_factor, patch_shape=patch_shape)
     else:
         prediction = patch_wise_prediction(model=model, data=test_data, overlap_factor=overlap_factor, patch_shape=patch_shape,
                                            truth_data=test_truth_data, prev_truth_index=prev_truth_index,

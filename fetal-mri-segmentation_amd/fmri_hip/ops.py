@@ -279,3 +279,48 @@ def loss_value_from_sums(s, kind, param=1.0, smooth=1.0):
 def conv3d_wgrad_workspace_bytes(C0, C1, Cout, N, D, H, W, dtype, planar=False):
     d = BF16 if dtype == torch.bfloat16 else F32
     return int(lib().fmri_conv3d_wgrad_workspace_bytes(C0, C1, Cout, N, D, H, W, d, int(planar)))
+
+
+# ---------------------------------------------------------------------------------------------- patch sampler / intensity augmentation
+U8 = 2
+
+
+def _dt_any(t):
+    return U8 if t.dtype == torch.uint8 else dt(t)
+
+
+def affine_sample(vol, affine, start, size, out, order=1, cval=0.0, out_ld=None):
+    """out[(i*ny + j)*out_ld + k] = vol sampled at affine . (start + (i,j,k), 1); `affine` is a host 3x4 / 4x4 array-like.
+    `out` may be a view into a wider channels-last tensor (pass its row length as out_ld)."""
+    import ctypes
+    import numpy as np
+    if not vol.is_cuda or not out.is_cuda or not vol.is_contiguous():
+        raise RuntimeError("fmri_hip ops need device tensors (no CPU path)")
+    X, Y, Z = vol.shape
+    a = np.ascontiguousarray(np.asarray(affine, dtype=np.float64)[:3, :4]).reshape(12)
+    arr = (ctypes.c_double * 12)(*a.tolist())
+    nx, ny, nz = (int(v) for v in size)
+    check(lib().fmri_affine_sample(_p(vol), _dt_any(vol), X, Y, Z, ctypes.cast(arr, ctypes.c_void_p), int(start[0]), int(start[1]), int(start[2]),
+                                   nx, ny, nz, int(order), float(cval), _p(out), _dt_any(out), int(out_ld if out_ld is not None else nz), _s()),
+          "fmri_affine_sample")
+    return out
+
+
+def minmax(x, out2):
+    _need_cuda(x, out2)
+    check(lib().fmri_minmax(_p(x), x.numel(), dt(x), _p(out2), _s()), "fmri_minmax")
+    return out2
+
+
+def rescale_intensity(x, stats, contrast, lo=0.0, hi=0.0, mult=1.0):
+    _need_cuda(x, stats)
+    check(lib().fmri_rescale_intensity(_p(x), x.numel(), dt(x), _p(stats), 1 if contrast else 0, float(lo), float(hi), float(mult), _s()),
+          "fmri_rescale_intensity")
+    return x
+
+
+def noise_augment(x, stats, noise, kind, sigma):
+    _need_cuda(x, stats, noise)
+    assert noise.dtype == torch.float32 and noise.numel() == x.numel()
+    check(lib().fmri_noise_augment(_p(x), x.numel(), dt(x), _p(stats), _p(noise), int(kind), float(sigma), _s()), "fmri_noise_augment")
+    return x

@@ -30,7 +30,7 @@ extern "C" {
 typedef void* fmri_stream_t; /* hipStream_t */
 
 enum { FMRI_OK = 0, FMRI_E_SHAPE = -1, FMRI_E_ALIGN = -2, FMRI_E_ARCH = -3, FMRI_E_LAUNCH = -4, FMRI_E_DTYPE = -5 };
-enum { FMRI_F32 = 0, FMRI_BF16 = 1 };
+enum { FMRI_F32 = 0, FMRI_BF16 = 1, FMRI_U8 = 2 /* label volumes of fmri_affine_sample only */ };
 enum { FMRI_ACT_NONE = 0, FMRI_ACT_RELU = 1, FMRI_ACT_LEAKY = 2 };
 /* which implementation a conv call may use: AUTO picks MFMA when the shape allows it */
 enum { FMRI_IMPL_AUTO = 0, FMRI_IMPL_GENERIC = 1, FMRI_IMPL_MFMA = 2 };
@@ -170,6 +170,26 @@ int fmri_tile_scatter_accumulate(const float* pred, const int32_t* idx, int B, i
                                  int32_t* cnt, int X, int Y, int Z, fmri_stream_t stream);
 /* out (double) [n][C] = acc / cnt ; *bad (int32, accumulated) counts voxels with cnt == 0 (reference asserts none) */
 int fmri_tile_finalize(const double* acc, const int32_t* cnt, double* out, int32_t* bad, int64_t nvox, int C,
+                       fmri_stream_t stream);
+
+/* ---- device-side patch sampler + intensity augmentation.  Replaces, per training patch, the host chain
+ * reference fetal_net/generator.py:246-328 (add_data / extract_patch) -> augment.py:222-377 (augment_data) ->
+ * utils/utils.py:100-113 (interpolate_affine_range = scipy.ndimage.map_coordinates, mode='constant').
+ * out[(i*ny + j)*out_ld + k] = sample of vol [X][Y][Z] at  affine . (x0+i, y0+j, z0+k, 1)   for i<nx, j<ny, k<nz.
+ * affine: 12 doubles, row-major 3x4, HOST memory (read at enqueue).  order 0 = nearest (floor(c+0.5)), 1 = trilinear; a source
+ * point outside [0, n-1] on any axis gives cval.  vol_dtype F32|U8, out_dtype F32|BF16 (U8 -> U8|F32|BF16).  out_ld >= nz lets a
+ * patch land in a channel slice of a wider [..][C] tensor (2-D models: previous-slice truth appended to the slice stack). */
+int fmri_affine_sample(const void* vol, int vol_dtype, int X, int Y, int Z, const double* affine, int x0, int y0, int z0, int nx, int ny,
+                       int nz, int order, float cval, void* out, int out_dtype, int out_ld, fmri_stream_t stream);
+/* out2 (device, 2 floats) = {min, max} of x[0..n) — the image range rescale_intensity(out_range='image') and MinMaxScaler need */
+int fmri_minmax(const void* x, int64_t n, int dtype, float* out2, fmri_stream_t stream);
+/* contrast != 0: x = clip(x, lo, hi) rescaled from [lo, hi] to [stats[0], stats[1]] (skimage rescale_intensity, reference
+ * augment.py:125-128); then x *= mult (augment.py:351-352).  stats = fmri_minmax of x BEFORE the call (device). In place. */
+int fmri_rescale_intensity(void* x, int64_t n, int dtype, const float* stats, int contrast, float lo, float hi, float mult,
+                           fmri_stream_t stream);
+/* MinMaxScaler((0,1)) -> + noise*sigma (kind 0, gaussian) or + x*noise*sigma (kind 1, speckle) -> clip [0,1] -> inverse scaling
+ * (reference augment.py:99-110).  noise: n fp32 N(0,1) draws on the device; stats = fmri_minmax of x before the call. In place. */
+int fmri_noise_augment(void* x, int64_t n, int dtype, const float* stats, const float* noise, int kind, float sigma,
                        fmri_stream_t stream);
 
 /* ---- plumbing: dtype casts used around the boundary (fp32 <-> bf16), n elements */

@@ -1,0 +1,151 @@
+"""GPU parity of the device-side patch sampler / intensity augmentation (csrc/augment.hip through the C ABI) and of the device
+generator built on it, against scipy (map_coordinates), the numpy oracle and the reference's own generator output
+(tests/golden/augment_golden.*).
+
+Tolerances: label sampling (order 0) bit-exact; image sampling (order 1) 1e-5 absolute on O(1..10) data (the device evaluates the
+source coordinates in fp64 like the host and interpolates in fp64, the volume itself is stored in fp32: 6e-8 relative);
+elementwise intensity passes 1e-5 relative (fp32 arithmetic vs fp64 oracle)."""
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+import scipy.ndimage
+import torch
+
+from oracle import augment_oracle as OA
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "these tests need the GPU box"
+    from fmri_hip import ops as o
+    return o
+
+
+@pytest.fixture(scope="module")
+def gold(golden_dir):
+    with open(os.path.join(golden_dir, "augment_golden.json")) as f:
+        meta = json.load(f)
+    return meta, np.load(os.path.join(golden_dir, "augment_golden.npz"))
+
+
+def _sample(ops, vol, A, ranges, order, cval, out_dtype):
+    v = torch.from_numpy(np.ascontiguousarray(vol)).cuda()
+    size = [e - s for s, e in ranges]
+    out = torch.empty(size, device="cuda", dtype=out_dtype)
+    ops.affine_sample(v, A, [s for s, _ in ranges], size, out, order=order, cval=cval)
+    torch.cuda.synchronize()
+    return out.float().cpu().numpy() if out.dtype == torch.bfloat16 else out.cpu().numpy()
+
+
+def test_affine_sample_matches_reference_fixture(ops, gold):
+    meta, arr = gold
+    vol, lab = arr["interp_vol"].astype(np.float32), arr["interp_lab"]
+    for k, c in enumerate(meta["interp_cases"]):
+        A = arr["interp_A_%d" % k]
+        ranges = [tuple(r) for r in c["ranges"]]
+        got1 = _sample(ops, vol, A, ranges, 1, c["cval1"], torch.float32)
+        np.testing.assert_allclose(got1, arr["interp_o1_%d" % k], rtol=0, atol=1e-5)
+        got0 = _sample(ops, lab, A, ranges, 0, 0.0, torch.uint8)
+        np.testing.assert_array_equal(got0, arr["interp_o0_%d" % k])
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_affine_sample_random_affines_vs_scipy(ops, seed):
+    rs = np.random.RandomState(seed)
+    shape = (int(rs.randint(9, 40)), int(rs.randint(9, 40)), int(rs.randint(5, 24)))
+    vol = rs.randn(*shape).astype(np.float32)
+    lab = (rs.rand(*shape) > 0.5).astype(np.uint8)
+    A = OA.distort_affine(shape, flip_axis=np.arange(3)[rs.rand(3) > 0.5], scale_factor=list(rs.normal(1, 0.2, 3)),
+                          rotate_factor=np.deg2rad(rs.uniform(-90, 90, 3)), translate_factor=rs.uniform(-6, 6, 3))
+    ranges = [(-3, shape[0] + 2), (1, shape[1] - 1), (0, shape[2] + 4)]
+    want1 = OA.interpolate_affine_range(vol.astype(np.float64), A, ranges, order=1, cval=-3.25)
+    want0 = OA.interpolate_affine_range(lab, A, ranges, order=0, cval=0)
+    np.testing.assert_allclose(_sample(ops, vol, A, ranges, 1, -3.25, torch.float32), want1, rtol=0, atol=1e-5)
+    np.testing.assert_array_equal(_sample(ops, lab, A, ranges, 0, 0.0, torch.uint8), want0)
+    # bf16 output = the fp32 result rounded once
+    got_bf = _sample(ops, vol, A, ranges, 1, -3.25, torch.bfloat16)
+    np.testing.assert_allclose(got_bf, want1, rtol=2 ** -8, atol=1e-5)
+
+
+def test_affine_sample_strided_channel_slot(ops):
+    rs = np.random.RandomState(4)
+    vol = rs.randn(12, 10, 9).astype(np.float32)
+    wide = torch.full((8, 8, 7), -99.0, device="cuda")
+    ops.affine_sample(torch.from_numpy(vol).cuda(), np.eye(4), (2, 1, 3), (8, 8, 5), wide, order=1, cval=0.0, out_ld=7)
+    torch.cuda.synchronize()
+    w = wide.cpu().numpy()
+    np.testing.assert_array_equal(w[..., :5], vol[2:10, 1:9, 3:8])
+    assert np.all(w[..., 5:] == -99.0)
+
+
+def test_intensity_passes_vs_oracle(ops):
+    rs = np.random.RandomState(6)
+    x = (rs.randn(16, 16, 8) * 3 + 1).astype(np.float32)
+    t = torch.from_numpy(x.copy()).cuda()
+    stats = torch.empty(2, device="cuda")
+    ops.minmax(t, stats)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(stats.cpu().numpy(), np.array([x.min(), x.max()], dtype=np.float32))
+    lo, hi, mult = float(x.min() + 0.7), float(x.max() - 1.1), 1.13
+    ops.rescale_intensity(t, stats, True, lo, hi, mult)
+    want = OA.contrast_augment(x.astype(np.float64), lo, hi) * mult
+    np.testing.assert_allclose(t.cpu().numpy(), want, rtol=1e-5, atol=1e-5)
+    for kind, fn in ((1, OA.add_speckle_noise), (0, OA.add_gaussian_noise)):
+        cur = t.cpu().numpy().astype(np.float64)
+        noise = rs.randn(x.size).astype(np.float32)
+        ops.minmax(t, stats)
+        ops.noise_augment(t, stats, torch.from_numpy(noise).cuda(), kind, 0.05)
+        want = fn(cur, 0.05, noise.reshape(x.shape).astype(np.float64))
+        np.testing.assert_allclose(t.cpu().numpy(), want, rtol=1e-4, atol=1e-4)
+    # degenerate contrast window (lo == hi) and the all-negative / constant inputs of the min-max keys
+    c = torch.full((64,), -2.5, device="cuda")
+    ops.minmax(c, stats)
+    assert stats.cpu().tolist() == [-2.5, -2.5]
+
+
+def synth_volumes(seed, shapes):
+    rs = np.random.RandomState(seed)
+    vols, truths = [], []
+    for s in shapes:
+        v = scipy.ndimage.gaussian_filter(rs.randn(*s), 1.5) * 4.0 + 0.3 * rs.randn(*s)
+        t = (scipy.ndimage.gaussian_filter(rs.randn(*s), 2.0) > 0.02).astype(np.uint8)
+        vols.append(v.astype(np.float64))
+        truths.append(t)
+    return vols, truths
+
+
+class _Root:
+    pass
+
+
+class FakeDataFile:
+    def __init__(self, vols, truths):
+        self.root = _Root()
+        self.root.data, self.root.truth = vols, truths
+        self.root.subject_ids = [("s%d" % i).encode() for i in range(len(vols))]
+
+
+def test_device_generator_reproduces_the_reference_batches(gold):
+    """seeded like the fixture run of the reference's data_generator: same corners, same transformations, same batches"""
+    from fetal_net.device_generator import device_data_generator
+    meta, arr = gold
+    for c in meta["generator_cases"]:
+        vols, truths = synth_volumes(c["seed"], [tuple(s) for s in c["shapes"]])
+        kw = dict(c["kwargs"])
+        np.random.seed(c["seed"])
+        random.seed(c["seed"])
+        g = device_data_generator(FakeDataFile(vols, truths), list(range(len(vols))), patch_shape=tuple(c["patch"]),
+                                  shuffle_index_list=False, **kw)
+        for b in range(c["n_batches"]):
+            x, y = next(g)
+            torch.cuda.synchronize()
+            gx, gy = arr["%s_x%d" % (c["name"], b)], arr["%s_y%d" % (c["name"], b)]
+            assert tuple(x.shape) == gx.shape and tuple(y.shape) == gy.shape, c["name"]
+            assert x.is_cuda and y.is_cuda
+            np.testing.assert_array_equal(y.cpu().numpy(), gy, err_msg=c["name"])
+            np.testing.assert_allclose(x.cpu().numpy(), gx, rtol=0, atol=2e-5, err_msg=c["name"])

@@ -1,0 +1,103 @@
+#!/usr/bin/env python3
+"""Throughput of the device-side patch generator (fetal_net.device_generator) at BASELINE config-2 patch size, alone and feeding
+training steps, next to the host generator it replaces (the oracle restatement of the reference's numpy/scipy path, one thread as in
+the reference).  Prints one JSON line.   python tools/bench_sampler.py [--batches 20] [--no-host]"""
+import argparse
+import json
+import os
+import random
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "fetal-mri-segmentation_amd"))
+
+AUG = {"flip": [0.5, 0.5, 0.5], "scale": (0.1, 0.1, 0), "rotate": (0, 0, 90), "translate": (15, 15, 7),
+       "contrast": {"min_factor": 0.2, "max_factor": 0.1}, "gaussian_noise": {"prob": 0.5, "sigma": 0.05},
+       "speckle_noise": {"prob": 0.5, "sigma": 0.05}}
+
+
+class _Root:
+    pass
+
+
+class Vols:
+    def __init__(self, n, shape, seed=0):
+        rs = np.random.RandomState(seed)
+        self.root = _Root()
+        self.root.data = [rs.randn(*shape).astype(np.float32) for _ in range(n)]
+        self.root.truth = [(rs.rand(*shape) > 0.7).astype(np.uint8) for _ in range(n)]
+        self.root.subject_ids = [b"s"] * n
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batches", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=4)
+    ap.add_argument("--no-host", action="store_true")
+    a = ap.parse_args()
+    import torch
+    from fetal_net.device_generator import DeviceDataFile, device_data_generator
+    patch = (64, 128, 128)
+    vols = Vols(6, (96, 192, 192))
+    ddf = DeviceDataFile(vols, patch)
+    np.random.seed(0)
+    random.seed(0)
+    out = {"patch": list(patch), "batch": a.batch, "volumes_resident_MB": ddf.nbytes() / 1e6}
+    for name, aug in (("crop_only", None), ("affine_contrast_noise", AUG)):
+        g = device_data_generator(ddf, list(range(6)), batch_size=a.batch, patch_shape=patch, augment=aug, truth_index=0, truth_size=patch[2],
+                                  is3d=True, categorical=False, skip_blank=False)
+        for _ in range(3):
+            next(g)
+        torch.cuda.synchronize()
+        t0 = time.time()
+        for _ in range(a.batches):
+            x, y = next(g)
+        torch.cuda.synchronize()
+        dt = time.time() - t0
+        nvox = patch[0] * patch[1] * patch[2]
+        # algorithmic bytes per patch: write image f32 + label u8, read the same amount (trilinear taps hit cache lines already fetched)
+        out[name] = {"patches_per_s": a.batches * a.batch / dt, "algorithmic_GBps": a.batches * a.batch * nvox * 2 * 5 / dt / 1e9}
+    # feeding training: device generator -> train_on_batch, against the same steps on one resident batch
+    from fetal_net.metrics import dice_coefficient_loss
+    from fetal_net.model import unet_model_3d
+    model = unet_model_3d(input_shape=(1,) + patch, depth=4, n_base_filters=32, initial_learning_rate=1e-4, loss_function=dice_coefficient_loss)
+    g = device_data_generator(ddf, list(range(6)), batch_size=a.batch, patch_shape=patch, augment=AUG, truth_index=0, truth_size=patch[2],
+                              is3d=True, categorical=False, skip_blank=False)
+    x, y = next(g)
+    for _ in range(3):
+        model.train_on_batch(x, y)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for _ in range(a.batches):
+        model.train_on_batch(x, y)
+    torch.cuda.synchronize()
+    fixed = time.time() - t0
+    t0 = time.time()
+    for _ in range(a.batches):
+        x, y = next(g)
+        model.train_on_batch(x, y)
+    torch.cuda.synchronize()
+    fed = time.time() - t0
+    out["train_patches_per_s_resident_batch"] = a.batches * a.batch / fixed
+    out["train_patches_per_s_device_generator"] = a.batches * a.batch / fed
+    if not a.no_host:
+        from oracle import augment_oracle as OA
+        df = OA.DataFileDummy([v.astype(np.float64) for v in vols.root.data[:2]], vols.root.truth[:2], 3, patch)
+        hg = OA.data_generator(df, [0, 1], 1, patch, augment={k: v for k, v in AUG.items() if "noise" not in k}, skip_blank=False, truth_index=0,
+                               truth_size=patch[2], is3d=True)
+        next(hg)
+        t0 = time.time()
+        n = 0
+        while time.time() - t0 < 10 and n < 8:
+            next(hg)
+            n += 1
+        out["host_generator_patches_per_s_1_thread"] = n / (time.time() - t0)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
