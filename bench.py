@@ -32,7 +32,8 @@ ALGO_BYTES_PER_PATCH = 4337e6
 def conv_flops(eng):
     """algorithmic FLOPs (2*27*Cin*Cout*voxels) of every 3x3x3 conv launch class in ONE step of this engine"""
     p, N = eng.plan, eng.N
-    out = {"fwd": 0.0, "dgrad": 0.0, "wgrad": 0.0, "fwd_mfma": 0.0, "dgrad_mfma": 0.0, "wgrad_mfma": 0.0}
+    out = {"fwd": 0.0, "dgrad": 0.0, "wgrad": 0.0, "fwd_mfma": 0.0, "dgrad_mfma": 0.0, "wgrad_mfma": 0.0, "fwd_dgrad_executed": 0.0}
+    upcat = getattr(eng, "upcat", {})
     from fmri_hip._lib import lib, BF16
     first = p.enc[0][0]["name"]
     for c in p.convs_forward_order():
@@ -42,8 +43,14 @@ def conv_flops(eng):
         m = lib().fmri_conv3d_uses_mfma(c0, c1, c["cout"], D, H, W, BF16)
         out["fwd"] += fl
         out["wgrad"] += fl
+        # MACs the device really executes: the parity form of the decoder 'a' layers does 8 instead of 27 taps on the up-sampled channels
+        fl_exec = fl
+        if c["name"] in upcat:
+            cu, cs = upcat[c["name"]]
+            fl_exec = 2.0 * (8 * cu + 27 * cs) * c["cout"] * N * D * H * W
         if m & 1:
             out["fwd_mfma"] += fl
+            out["fwd_dgrad_executed"] += fl_exec
         if m & 2:
             out["wgrad_mfma"] += fl
         if c["name"] != first:
@@ -51,6 +58,7 @@ def conv_flops(eng):
             md = lib().fmri_conv3d_uses_mfma(c["cout"], 0, c["cin"], D, H, W, BF16)
             if md & 1:
                 out["dgrad_mfma"] += fl
+                out["fwd_dgrad_executed"] += fl_exec
     return out
 
 
@@ -61,7 +69,8 @@ class LaunchTimer:
         self.rec = {}
         self.on = False
 
-    def wrap(self, ops_mod, fn_name, label_fn):
+    def wrap(self, ops_mod, fn_name, label_fn, launches=1):
+        """`launches`: kernel launches of the labelled kind one call makes (the parity-form ops launch the conv kernel twice)"""
         orig = getattr(ops_mod, fn_name)
 
         def wrapped(*a, **k):
@@ -71,13 +80,13 @@ class LaunchTimer:
             e0.record()
             r = orig(*a, **k)
             e1.record()
-            self.rec.setdefault(label_fn(*a, **k), []).append((e0, e1))
+            self.rec.setdefault(label_fn(*a, **k), []).append((e0, e1, launches))
             return r
 
         setattr(ops_mod, fn_name, wrapped)
 
     def totals_ms(self):
-        return {k: (sum(a.elapsed_time(b) for a, b in v), len(v)) for k, v in self.rec.items()}
+        return {k: (sum(a.elapsed_time(b) for a, b, _ in v), sum(n for _, _, n in v)) for k, v in self.rec.items()}
 
 
 def synthetic_batch(shape, seed_x=1234, seed_y=1235, fg=0.30):
@@ -204,6 +213,9 @@ def main():
         timer.wrap(ops, "conv3d_fwd", lab_fwd)
         timer.wrap(ops, "conv3d_dgrad", lab_dgrad)
         timer.wrap(ops, "conv3d_wgrad", lab_wgrad)
+        timer.wrap(ops, "conv3d_upcat_fwd", lambda *aa, **kk: "conv_fwd_mfma", launches=2)
+        timer.wrap(ops, "conv3d_upcat_dgrad", lambda *aa, **kk: "conv_fwd_mfma", launches=2)
+        timer.wrap(ops, "conv3d_pack_up_weights", lambda *aa, **kk: "pack_weights")
         for nm in ("maxpool_fwd", "maxpool_bwd", "upsample_bwd", "conv1x1_fwd", "conv1x1_bwd", "sigmoid_dice_fwd",
                    "sigmoid_dice_bwd", "adam_step", "pack_weights"):
             timer.wrap(ops, nm, (lambda n_: (lambda *aa, **kk: n_))(nm))
@@ -260,10 +272,15 @@ def main():
             ach = flops / (t_ms * 1e-3) / 1e12
             out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                                "frac": ach / PEAK_BF16_TFLOPS,
+                               "note": "achieved = the reference's algorithmic FLOPs (2*27*Cin*Cout*voxels per conv, SURVEY 8d) / kernel time; "
+                                       "the decoder 'a' layers run in parity form (8 instead of 27 taps on the up-sampled channels), "
+                                       "executed_tflops counts the MACs really issued",
                                "traffic": pmc_traffic("k_conv_fwd_mfma" if dom == "conv_fwd_mfma" else "k_conv_wgrad_mfma"),
                                "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, separate passes, FETCH_SIZE x2 corrected)",
                                "algorithmic_flop_per_launch": flops / max(launches, 1), "launches_per_step": launches,
                                "avg_launch_ms": t_ms / max(launches, 1)}
+            if dom == "conv_fwd_mfma":
+                out["roofline"]["executed_tflops"] = fl["fwd_dgrad_executed"] / (t_ms * 1e-3) / 1e12
             other = "conv_wgrad_mfma" if dom == "conv_fwd_mfma" else "conv_fwd_mfma"
             if other in per_step:
                 fo = (fl["fwd_mfma"] + fl["dgrad_mfma"]) if other == "conv_fwd_mfma" else fl["wgrad_mfma"]

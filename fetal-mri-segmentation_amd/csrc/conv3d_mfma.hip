@@ -90,26 +90,42 @@ __device__ __forceinline__ unsigned lds_addr(const void* p) {
 __device__ __forceinline__ int swz64(int row, int slot) { return row * 64 + ((slot ^ ((row >> 2) & 3)) << 4); }
 
 struct FwdItem {          // one (tile, Cout block, 32-channel chunk) unit of the persistent stream
-    int n, d0, h0, w0, co0, ch;
+    int n, d0, h0, w0, co0, ch, par;
 };
 
-template <int NT, bool PL>  // NT = 32-wide output-channel tiles per workgroup (BN = 32*NT); PL = planar (2-D slices: kd = 1 taps only)
+// MODE selects what the 3x3x3 machinery computes:
+//   0  the plain convolution (forward, and dgrad with tap-flipped transposed weights);
+//   1  "up-forward": the conv of a nearest x2 up-sampled source WITHOUT the redundant taps.  Output voxel 2g+p (p = parity in
+//      {0,1}^3) only sees the low-res voxels g+e, e in {-1,0} (p = 0) or {0,+1} (p = 1) per axis, with pre-summed weights, so each
+//      parity class is a 2x2x2-tap conv of the LOW-res tensor: the kernel runs on the low-res grid (D,H,W = low-res dims), the
+//      Cout blocks enumerate (parity, channel block), 4 (kd',kh') phases x 2 kw' taps per chunk instead of 9 x 3, and the
+//      epilogue scatters to voxel 2g+p of the [2D][2H][2W] output (no bias / activation: the result is a partial sum that the
+//      MODE 0 + RES launch over the skip channels finishes);
+//   2  "up-backward": gradient of that conv w.r.t. the low-res tensor = the same 2x2x2-tap structure over the space-to-depth view
+//      of dy: chunk -> (parity, 32-channel slice), halo rows are gathered from voxel 2g+p of dy, taps mirrored.
+// RES (MODE 0): the epilogue adds `residual` (same layout as y, may alias it) before bias + activation, in fp32.
+template <int NT, bool PL, int MODE, bool RES>  // NT = 32-wide output-channel tiles per workgroup (BN = 32*NT); PL = planar (kd = 1 taps only)
 __global__ void __launch_bounds__(fw::NTHREADS)
 k_conv_fwd_mfma(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ bias, const bf16_t* __restrict__ mask,
-                bf16_t* __restrict__ y, int N, int D, int H, int W, int Cout, int act, float alpha) {
+                const bf16_t* residual, bf16_t* y, int N, int D, int H, int W, int Cout, int act, float alpha) {
     using namespace fw;
+    static_assert(!(PL && MODE != 0) && !(RES && MODE != 0), "unsupported combination");
+    constexpr bool PAR = MODE != 0;
     constexpr int BN = 32 * NT;
-    constexpr int FILT_BYTES = 3 * BN * 64;              // one (kd,kh) slab: 3 kw taps x BN rows x 64 B
-    constexpr int F_INSTR = FILT_BYTES / 1024;           // 12 or 6
+    constexpr int NKW = PAR ? 2 : 3;                     // kw taps per phase
+    constexpr int FILT_BYTES = 3 * BN * 64;              // ring slot: one (kd,kh) slab of up to 3 kw taps x BN rows x 64 B
+    constexpr int F_INSTR = NKW * BN * 64 / 1024;        // DMA wave-instructions per slab: 12 / 6 (8 / 4 in the up modes)
     constexpr int F_PER_WAVE = (F_INSTR + 7) / 8;        // 2 or 1 (short waves re-issue their first instruction)
-    constexpr int NPH = PL ? 3 : 9;                      // phases per chunk = (kd,kh) rows that exist
+    constexpr int NPH = PAR ? 4 : (PL ? 3 : 9);          // phases per chunk = (kd,kh) rows that exist
     constexpr int PH0 = PL ? 3 : 0;                      // first (kd,kh) row (planar: kd = 1)
-    constexpr int HPP = 9 / NPH;                         // halo DMA pieces issued per phase (9 pieces per chunk)
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * HALO_BYTES + 2 * FILT_BYTES];
 
     const int Cin = s.C0 + s.C1;
-    const int nch = Cin >> 5;
-    const int ncb = Cout / BN;
+    const int kpc = MODE == 2 ? (s.C0 >> 5) : 1;         // up-backward: chunks per parity class (s.C0 = channels of dy)
+    const int nch = MODE == 2 ? 8 * kpc : (Cin >> 5);
+    const int Krow = MODE == 2 ? s.C0 : Cin;             // k-extent of one filter row in global memory
+    const int cbn = Cout / BN;
+    const int ncb = MODE == 1 ? 8 * cbn : cbn;
     const int twn = W / TW, thn = H / TH, tdn = D / TD;
     const int npairs = N * tdn * thn * twn * ncb;
 
@@ -122,7 +138,9 @@ k_conv_fwd_mfma(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__
     auto decode = [&](int pair, int ch) {
         FwdItem it;
         it.ch = ch;
-        it.co0 = (pair % ncb) * BN;
+        const int cb = pair % ncb;
+        it.par = MODE == 1 ? cb / cbn : 0;
+        it.co0 = (MODE == 1 ? cb % cbn : cb) * BN;
         int q = pair / ncb;
         it.w0 = (q % twn) * TW; q /= twn;
         it.h0 = (q % thn) * TH; q /= thn;
@@ -139,7 +157,7 @@ k_conv_fwd_mfma(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__
         const int i = instr * 64 + lane;
         const int row = i >> 2, ps = i & 3;
         const int ls = ps ^ ((row >> 2) & 3);
-        f_voff[k] = (unsigned)(((row / BN) * Cout + (row % BN)) * Cin + ls * 8) * 2u;
+        f_voff[k] = (unsigned)(((row / BN) * Cout + (row % BN)) * Krow + ls * 8) * 2u;
     }
     int h_pack[9];                 // halo piece ph: hd | hh<<4 | hw<<8 | ls<<13 | valid<<15
 #pragma unroll
@@ -151,9 +169,15 @@ k_conv_fwd_mfma(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__
         const int hw_ = hvc % HW, hq = hvc / HW;
         h_pack[ph] = (hq / HH) | ((hq % HH) << 4) | (hw_ << 8) | (ls << 13) | ((hv < HVOX ? 1 : 0) << 15);
     }
-    // filter slab of phase `ph` = (kd,kh) for item `it` into filter ring slot `fb`: scalar base + constant lane offset
-    auto issue_filter = [&](const FwdItem& it, int ph, int fb) {
-        const bf16_t* const base = wt + (((int64_t)ph * 3 * Cout + it.co0) * Cin + (it.ch << 5));
+    // filter slab of phase `pl` (= (kd,kh) row PH0 + pl; up modes: (parity, kd', kh')) for item `it` into filter ring slot `fb`:
+    // scalar base + constant lane offset
+    auto issue_filter = [&](const FwdItem& it, int pl, int fb) {
+        int64_t slab;
+        int koff;
+        if constexpr (MODE == 0) { slab = PH0 + pl; koff = it.ch << 5; }
+        else if constexpr (MODE == 1) { slab = it.par * 4 + pl; koff = it.ch << 5; }
+        else { slab = (it.ch / kpc) * 4 + pl; koff = (it.ch % kpc) << 5; }
+        const bf16_t* const base = wt + ((slab * NKW * Cout + it.co0) * Krow + koff);
 #pragma unroll
         for (int k = 0; k < F_PER_WAVE; ++k)
             if (k == 0 || wv + 8 * k < F_INSTR)
@@ -163,6 +187,17 @@ k_conv_fwd_mfma(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__
     // a new tile or crosses from source 0 to source 1 of a concatenation; otherwise the next chunk is 32 channels further on.
     const bf16_t* hp[9];
     auto halo_src = [&](const FwdItem& it, int pk) -> const bf16_t* {
+        if constexpr (MODE == 2) {
+            // space-to-depth view of dy [N][2D][2H][2W][C0]: chunk -> (parity, 32-channel slice); low-res halo voxel g reads 2g+p
+            const int p = it.ch / kpc, coff = (it.ch % kpc) << 5;
+            const int gd = it.d0 - 1 + (pk & 15), gh = it.h0 - 1 + ((pk >> 4) & 15), gw = it.w0 - 1 + ((pk >> 8) & 31);
+            const int ls = (pk >> 13) & 3;
+            const bool ok = (pk >> 15) && (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W;
+            const int sd = 2 * min(max(gd, 0), D - 1) + (p >> 2), sh = 2 * min(max(gh, 0), H - 1) + ((p >> 1) & 1),
+                      sw = 2 * min(max(gw, 0), W - 1) + (p & 1);
+            const int64_t off = ((((int64_t)it.n * 2 * D + sd) * 2 * H + sh) * 2 * W + sw) * s.C0 + coff + ls * 8;
+            return ok ? s.p0 + off : (const bf16_t*)g_zero_page;
+        }
         const int cc = it.ch << 5;
         const bool from0 = cc < s.C0;
         const bf16_t* sp = from0 ? s.p0 : s.p1;
@@ -204,6 +239,7 @@ k_conv_fwd_mfma(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__
 
     f32x16 acc[2][NT];
     float4 bv[NT][4];              // this lane's 4 x 4 bias values per 32-channel tile (fetched during the last chunk's first phase)
+    float4 bq = make_float4(0.f, 0.f, 0.f, 0.f);   // RES epilogue: bias of the 4 channels this lane finishes (line-major layout)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -235,7 +271,7 @@ k_conv_fwd_mfma(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__
         hp[ph] = halo_src(cur, h_pack[ph]);
         issue_halo(ph, 0);
     }
-    issue_filter(cur, PH0, 0);
+    issue_filter(cur, 0, 0);
     int g = 0, hb = 0;
 #ifdef FMRI_PROF
     unsigned long long prof[12] = {};
@@ -252,14 +288,14 @@ k_conv_fwd_mfma(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__
             has_next = npair < npairs;
             if (has_next) nxt = decode(npair, 0);
         }
-        const bool fresh = nxt.ch == 0 || (nxt.ch << 5) == s.C0;   // new tile, or first chunk of the second source
+        // new tile, first chunk of the second source, or (up-backward) first chunk of the next parity class
+        const bool fresh = MODE == 2 ? (nxt.ch % kpc == 0) : (nxt.ch == 0 || (nxt.ch << 5) == s.C0);
         const unsigned char* const lh = lds + hb * HALO_BYTES;
         // keep the 54 per-(phase,tap) fragment addresses out of long-lived registers: recomputing them costs a few VALU
         // instructions per MFMA, which issue in the MFMA's shadow, whereas hoisting them spills
         asm volatile("" : "+v"(hv0[0]), "+v"(hv0[1]));
 #pragma unroll
         for (int pl = 0; pl < NPH; ++pl, ++g) {
-            const int ph = PH0 + pl;
             PROF_T(t0);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's DMA of the previous phase has landed
             PROF_T(t1);
@@ -267,20 +303,27 @@ k_conv_fwd_mfma(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__
             PROF_T(t2);
             // DMA of the next phase (an LDS-DMA instruction costs its wave 100-180 cycles of issue here wherever it is placed:
             // staggering the two waves of a SIMD, or issuing mid-phase, measured the same or slower - tools/prof_phases.py)
+            const int HP0 = PAR ? (pl == 0 ? 0 : 1 + 2 * pl) : pl * (9 / NPH);     // the chunk's 9 halo pieces spread over its phases
+            const int HPN = PAR ? (pl == 0 ? 3 : 2) : 9 / NPH;
             auto issue_dma = [&]() {
-                if (pl < NPH - 1) issue_filter(cur, ph + 1, (g + 1) & 1);
-                else if (has_next) issue_filter(nxt, PH0, (g + 1) & 1);
+                if (pl < NPH - 1) issue_filter(cur, pl + 1, (g + 1) & 1);
+                else if (has_next) issue_filter(nxt, 0, (g + 1) & 1);
                 if (has_next) {
 #pragma unroll
-                    for (int q = 0; q < HPP; ++q) {
-                        if (fresh) hp[pl * HPP + q] = halo_src(nxt, h_pack[pl * HPP + q]);
-                        else hp[pl * HPP + q] += 32;
-                        issue_halo(pl * HPP + q, hb ^ 1);
+                    for (int q = 0; q < 3; ++q) {
+                        if (q < HPN) {
+                            if (fresh) hp[HP0 + q] = halo_src(nxt, h_pack[HP0 + q]);
+                            else hp[HP0 + q] += 32;
+                            issue_halo(HP0 + q, hb ^ 1);
+                        }
                     }
                 }
             };
             issue_dma();
-            if (pl == 0 && cur.ch == nch - 1) {
+            if (RES && pl == 0 && cur.ch == nch - 1) {
+                bq = bias ? *reinterpret_cast<const float4*>(bias + cur.co0 + 4 * (lane % (BN / 4))) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            if (!RES && pl == 0 && cur.ch == nch - 1) {
                 // the epilogue's bias, fetched a chunk ahead: 8 dependent L2 round trips inside the epilogue cost 23 % of the
                 // kernel at Cin = 32 (tools/prof_phases.py)
                 if (bias) {
@@ -298,12 +341,20 @@ k_conv_fwd_mfma(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__
             }
             PROF_T(t3);
             const unsigned char* const lf = lds + 2 * HALO_BYTES + (g & 1) * FILT_BYTES;
-            const int hoff = ((ph / 3) * HH + (ph % 3)) * HW;
+            // halo row offset of this phase's (kd,kh) and of its kw taps.  Up modes: phase = (kd',kh') in {0,1}^2 shifted by the
+            // parity of the output class (up-forward: offsets {-1,0} / {0,+1} for p = 0 / 1) or of the chunk (up-backward: mirrored)
+            int hoff, kw0 = 0;
+            if constexpr (!PAR) hoff = (((PH0 + pl) / 3) * HH + ((PH0 + pl) % 3)) * HW;
+            else {
+                const int p = MODE == 1 ? cur.par : 7 - cur.ch / kpc;
+                hoff = (((pl >> 1) + (p >> 2)) * HH + ((pl & 1) + ((p >> 1) & 1))) * HW;
+                kw0 = p & 1;
+            }
 #pragma unroll
-            for (int kw = 0; kw < 3; ++kw) {
+            for (int kw = 0; kw < NKW; ++kw) {
                 int hb0[2];
 #pragma unroll
-                for (int j = 0; j < 2; ++j) hb0[j] = swz64(hv0[j] + hoff + kw, hk);
+                for (int j = 0; j < 2; ++j) hb0[j] = swz64(hv0[j] + hoff + kw + kw0, hk);
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
                     bf16x8_t a[NT], b[2];
@@ -325,7 +376,48 @@ k_conv_fwd_mfma(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__
             prof[6] += 1;
 #endif
         }
-        if (cur.ch == nch - 1) {
+        if (RES && cur.ch == nch - 1) {
+            // ---- epilogue with a residual: y = act(acc + residual + bias).  The sum has to be formed in fp32 before the activation,
+            // so the raw accumulators are transposed through LDS as fp32, one 32-voxel column tile at a time (wave-private 8 KiB of
+            // the consumed halo slot), and finished line-major: 16 (8) lanes per voxel, 4 channels each.
+            constexpr int PPV = BN / 4;                  // 16-byte fp32 pieces per voxel
+            constexpr int VPI = 64 / PPV;                // voxels per instruction
+            __builtin_amdgcn_s_barrier();
+            unsigned char* const stage = lds + hb * HALO_BYTES + wv * (32 * BN * 4);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+#pragma unroll
+                for (int c = 0; c < NT; ++c)
+#pragma unroll
+                    for (int gq = 0; gq < 4; ++gq) {
+                        const int q = c * 8 + 2 * gq + hk;
+                        *reinterpret_cast<float4*>(stage + r * (BN * 4) + (((q ^ r) & (PPV - 1)) << 4)) =
+                            make_float4(acc[j][c][4 * gq], acc[j][c][4 * gq + 1], acc[j][c][4 * gq + 2], acc[j][c][4 * gq + 3]);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) acc[j][c][4 * gq + i] = 0.f;
+                    }
+                const int rt = 2 * wv + j;
+#pragma unroll
+                for (int kk = 0; kk < 32 / VPI; ++kk) {
+                    const int rr = kk * VPI + lane / PPV, q = lane % PPV;
+                    const float4 a4 = *reinterpret_cast<const float4*>(stage + rr * (BN * 4) + (((q ^ rr) & (PPV - 1)) << 4));
+                    const int wq = (rr >> 4) ? (((rr & 15) + 16 - (HW & 15)) & 15) : (rr & 15);
+                    const int d = cur.d0 + (rt >> 2), h = cur.h0 + 2 * (rt & 3) + (rr >> 4), w = cur.w0 + wq;
+                    const int64_t ao = ((((int64_t)cur.n * D + d) * H + h) * W + w) * Cout + cur.co0 + q * 4;
+                    const uint2 r2 = *reinterpret_cast<const uint2*>(residual + ao);
+                    float o[4] = {a4.x + __uint_as_float(r2.x << 16) + bq.x, a4.y + __uint_as_float(r2.x & 0xffff0000u) + bq.y,
+                                  a4.z + __uint_as_float(r2.y << 16) + bq.z, a4.w + __uint_as_float(r2.y & 0xffff0000u) + bq.w};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        if (act == FMRI_ACT_RELU) o[i] = fmaxf(o[i], 0.f);
+                        else if (act == FMRI_ACT_LEAKY) o[i] = o[i] > 0.f ? o[i] : alpha * o[i];
+                    }
+                    *reinterpret_cast<uint2*>(y + ao) = make_uint2((unsigned)f2bf(o[0]) | ((unsigned)f2bf(o[1]) << 16),
+                                                                    (unsigned)f2bf(o[2]) | ((unsigned)f2bf(o[3]) << 16));
+                }
+            }
+        }
+        if (!RES && cur.ch == nch - 1) {
             // ---- epilogue.  D rows = output channel (reg&3)+8*(reg>>2)+4*hk, D cols = voxel r: a lane owns 4-channel pieces of ONE
             // voxel, and storing those directly touches 64 cache lines per instruction (measured: 35 % of the kernel at Cin = 32,
             // store-issue bound).  Instead the wave's 64 voxels x BN channels go through a wave-private 8 KiB of the halo slot that
@@ -386,7 +478,12 @@ k_conv_fwd_mfma(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__
                 const int rt = 2 * wv + (v >> 5), rr = v & 31;
                 const int wq = (rr >> 4) ? (((rr & 15) + 16 - (HW & 15)) & 15) : (rr & 15);
                 const int d = cur.d0 + (rt >> 2), h = cur.h0 + 2 * (rt & 3) + (rr >> 4), w = cur.w0 + wq;
-                const int64_t ao = ((((int64_t)cur.n * D + d) * H + h) * W + w) * Cout + cur.co0 + q * 8;
+                int64_t ao;
+                if constexpr (MODE == 1)     // parity class p of the [2D][2H][2W] output
+                    ao = ((((int64_t)cur.n * 2 * D + 2 * d + (cur.par >> 2)) * 2 * H + 2 * h + ((cur.par >> 1) & 1)) * 2 * W + 2 * w + (cur.par & 1)) * Cout +
+                         cur.co0 + q * 8;
+                else
+                    ao = ((((int64_t)cur.n * D + d) * H + h) * W + w) * Cout + cur.co0 + q * 8;
                 if (mask) {
                     const uint4 m4 = *reinterpret_cast<const uint4*>(mask + ao);
                     const unsigned mm[4] = {m4.x, m4.y, m4.z, m4.w};
@@ -922,8 +1019,11 @@ bool conv3d_wgrad_mfma_ok(int C0, int C1, int Cout, int D, int H, int W, int dty
     return true;
 }
 
-int conv3d_fwd_mfma(const void* src0, int C0, int up0, int planar, const void* src1, int C1, const void* w, const float* bias,
-                    const void* mask, void* y, int N, int D, int H, int W, int Cout, int act, float alpha, hipStream_t st) {
+// mode 0: plain conv (residual != nullptr selects the RES epilogue); 1: up-forward (src0 = LOW-res tensor, D/H/W = low-res dims,
+// y = [2D][2H][2W] partial sums); 2: up-backward (src0 = dy [2D][2H][2W][C0], y = gradient of the low-res tensor)
+int conv3d_fwd_mfma_ex(int mode, const void* src0, int C0, int up0, int planar, const void* src1, int C1, const void* w, const float* bias,
+                       const void* mask, const void* residual, void* y, int N, int D, int H, int W, int Cout, int act, float alpha,
+                       hipStream_t st) {
     SrcB s{(const bf16_t*)src0, (const bf16_t*)src1, C0, C1, up0, planar ? 0 : 1, planar};
     const int ntile = N * (D / fw::TD) * (H / fw::TH) * (W / fw::TW);
     static int ncu = 0;                 // CU count of the current device, queried once (persistent grid = one workgroup per CU)
@@ -939,7 +1039,7 @@ int conv3d_fwd_mfma(const void* src0, int C0, int up0, int planar, const void* s
         const char* e = getenv("FMRI_FWD_MFMA");
         use16 = (e && atoi(e) == 16) ? 1 : 0;
     }
-    if (use16 && !planar) {
+    if (use16 && !planar && mode == 0 && !residual) {
         if (Cout % 64 == 0) {
             const int np = ntile * (Cout / 64);
             k_conv_fwd_mfma16<2><<<np < ncu ? np : ncu, fw::NTHREADS, 0, st>>>(s, (const bf16_t*)w, bias, (const bf16_t*)mask, (bf16_t*)y,
@@ -952,20 +1052,32 @@ int conv3d_fwd_mfma(const void* src0, int C0, int up0, int planar, const void* s
         FMRI_LAUNCH_CHECK();
         return FMRI_OK;
     }
-#define FMRI_LAUNCH_FWD(NT_, PL_)                                                                                          \
+#define FMRI_LAUNCH_FWD(NT_, PL_, MODE_, RES_)                                                                             \
     do {                                                                                                                  \
-        const int np = ntile * (Cout / (32 * NT_));                                                                       \
-        k_conv_fwd_mfma<NT_, PL_><<<np < ncu ? np : ncu, fw::NTHREADS, 0, st>>>(s, (const bf16_t*)w, bias, (const bf16_t*)mask, \
-                                                                                (bf16_t*)y, N, D, H, W, Cout, act, alpha); \
+        const int np = ntile * (Cout / (32 * NT_)) * (MODE_ == 1 ? 8 : 1);                                                \
+        k_conv_fwd_mfma<NT_, PL_, MODE_, RES_><<<np < ncu ? np : ncu, fw::NTHREADS, 0, st>>>(                             \
+            s, (const bf16_t*)w, bias, (const bf16_t*)mask, (const bf16_t*)residual, (bf16_t*)y, N, D, H, W, Cout, act, alpha); \
     } while (0)
-    if (Cout % 64 == 0) {
-        if (planar) FMRI_LAUNCH_FWD(2, true); else FMRI_LAUNCH_FWD(2, false);
+    const bool wide = Cout % 64 == 0;
+    if (mode == 1) {
+        if (wide) FMRI_LAUNCH_FWD(2, false, 1, false); else FMRI_LAUNCH_FWD(1, false, 1, false);
+    } else if (mode == 2) {
+        if (wide) FMRI_LAUNCH_FWD(2, false, 2, false); else FMRI_LAUNCH_FWD(1, false, 2, false);
+    } else if (residual) {
+        if (planar) return FMRI_E_SHAPE;
+        if (wide) FMRI_LAUNCH_FWD(2, false, 0, true); else FMRI_LAUNCH_FWD(1, false, 0, true);
+    } else if (wide) {
+        if (planar) FMRI_LAUNCH_FWD(2, true, 0, false); else FMRI_LAUNCH_FWD(2, false, 0, false);
     } else {
-        if (planar) FMRI_LAUNCH_FWD(1, true); else FMRI_LAUNCH_FWD(1, false);
+        if (planar) FMRI_LAUNCH_FWD(1, true, 0, false); else FMRI_LAUNCH_FWD(1, false, 0, false);
     }
 #undef FMRI_LAUNCH_FWD
     FMRI_LAUNCH_CHECK();
     return FMRI_OK;
+}
+int conv3d_fwd_mfma(const void* src0, int C0, int up0, int planar, const void* src1, int C1, const void* w, const float* bias,
+                    const void* mask, void* y, int N, int D, int H, int W, int Cout, int act, float alpha, hipStream_t st) {
+    return conv3d_fwd_mfma_ex(0, src0, C0, up0, planar, src1, C1, w, bias, mask, nullptr, y, N, D, H, W, Cout, act, alpha, st);
 }
 
 static void wgrad_plan(int C0, int C1, int Cout, int N, int D, int H, int W, int planar, bool with_ws, int& CIB, int& combos, int& nslab) {

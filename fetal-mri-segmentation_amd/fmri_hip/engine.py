@@ -134,7 +134,8 @@ class UNetEngine:
             self.M = torch.zeros_like(self.P)
             self.V = torch.zeros_like(self.P)
         # compute-dtype copies of the 3x3x3 filters
-        self.Wf, self.Wd = {}, {}
+        self.Wf, self.Wd, self.Wup = {}, {}, {}
+        self.upcat = self._upcat_layers()
         self.Wt = {}                      # compute-dtype copies of the transposed-conv filters [8][Cout][Cin]
         self.moving = {}                  # batch-norm moving mean / variance (inference statistics), fp32 [2][C]
         first = p.enc[0][0]["name"]
@@ -146,6 +147,17 @@ class UNetEngine:
                 mv[1].fill_(1.0)
                 self.moving[name] = mv
             if L["kind"] != "conv":
+                continue
+            if name in self.upcat:
+                # up-sample + concat + conv in parity form (fmri_conv3d_upcat_*): pre-summed 2x2x2 filters per output parity for the
+                # up-sampled channels, plain 27-tap filters for the skip channels
+                c0, c1 = self.upcat[name]
+                W = dict(up_f=torch.empty((8, 8, L["cout"], c0), dtype=self.dtype, device=dev),
+                         sk_f=torch.empty((27, L["cout"], c1), dtype=self.dtype, device=dev), up_d=None, sk_d=None)
+                if self.training:
+                    W["up_d"] = torch.empty((8, 8, c0, L["cout"]), dtype=self.dtype, device=dev)
+                    W["sk_d"] = torch.empty((27, c1, L["cout"]), dtype=self.dtype, device=dev)
+                self.Wup[name] = W
                 continue
             self.Wf[name] = torch.empty((27, L["cout"], L["cin"]), dtype=self.dtype, device=dev)
             if self.training and name != first:
@@ -255,9 +267,31 @@ class UNetEngine:
                     W[L["norm"] + "/moving_mean"], W[L["norm"] + "/moving_variance"] = mv[0].copy(), mv[1].copy()
         return W
 
+    def _upcat_layers(self):
+        """decoder 'a' convs (UpSampling3D -> concatenate -> Conv3D, reference unet.py:132-138,61,102) that take the parity form:
+        name -> (up-sampled channels, skip channels).  FMRI_UPCAT=0 keeps the 27-tap fused-upsample kernel (A/B switch)."""
+        import os
+        p = self.plan
+        out = {}
+        if self.planar or self.dtype != torch.bfloat16 or os.environ.get("FMRI_UPCAT", "1") == "0":
+            return out
+        for lv in p.dec:
+            a = lv[0]
+            if a["level"] in p.up:
+                continue                                   # Deconvolution3D variant: the up-sampled tensor is materialised
+            c1 = p.enc[a["level"]][1]["cout"]
+            c0 = a["cin"] - c1
+            D, H, W = p.level_dims(a["level"])
+            if ops.conv3d_upcat_ok(c0, c1, a["cout"], D, H, W, self.dtype):
+                out[a["name"]] = (c0, c1)
+        return out
+
     def refresh_weight_copies(self):
         for name in self.Wf:
             ops.pack_weights(self.w_view(name), self.Wf[name], self.Wd.get(name))
+        for name, W in self.Wup.items():
+            c0, c1 = self.upcat[name]
+            ops.conv3d_pack_up_weights(self.w_view(name), c0, c1, W["up_f"], W["up_d"], W["sk_f"], W["sk_d"])
         for name, wt in self.Wt.items():
             ops.cast(self.w_view(name), wt)
 
@@ -322,7 +356,10 @@ class UNetEngine:
             Gd[name] = torch.empty_like(t)            # gradient w.r.t. the tensor (conv blocks: w.r.t. the pre-activation)
         for lv in p.dec:
             a = lv[0]
-            Gd["cat_%d" % a["level"]] = torch.empty(self._dims(a["level"]) + (a["cin"],), dtype=dt, device=dev)
+            # gradient of the concatenated conv input; the parity form writes the up-sampled part straight at low resolution,
+            # so only the skip channels remain
+            ccat = self.upcat[a["name"]][1] if a["name"] in self.upcat else a["cin"]
+            Gd["cat_%d" % a["level"]] = torch.empty(self._dims(a["level"]) + (ccat,), dtype=dt, device=dev)
         self.dlogits = torch.empty_like(self.logits)
         # scratch for the slab flush of the MFMA weight-gradient kernel (max over the layers of this plan)
         need = 0
@@ -344,10 +381,14 @@ class UNetEngine:
     def _block_fwd(self, c, src0, src1, up0, bn_training):
         """one [conv -> (norm) -> ReLU] block (reference create_convolution_block, unet.py:89-115)"""
         name = c["name"]
+        out, act = (self.pre[name], ACT_NONE) if c.get("norm") else (self.act[name], ACT_RELU)
+        if up0 and name in self.Wup:
+            W = self.Wup[name]
+            ops.conv3d_upcat_fwd(src0, src1, W["up_f"], W["sk_f"], self.b_view(name), out, act=act)
+        else:
+            ops.conv3d_fwd(src0, src1, self.Wf[name], self.b_view(name), out, up0=up0, act=act, planar=self.planar)
         if not c.get("norm"):
-            ops.conv3d_fwd(src0, src1, self.Wf[name], self.b_view(name), self.act[name], up0=up0, act=ACT_RELU, planar=self.planar)
             return self.act[name]
-        ops.conv3d_fwd(src0, src1, self.Wf[name], self.b_view(name), self.pre[name], up0=up0, act=ACT_NONE, planar=self.planar)
         per, eos = self._norm_mode()
         st = self.nstats[name]
         if self.plan.norm == "batch" and not bn_training:
@@ -456,6 +497,10 @@ class UNetEngine:
                 ops.deconv_bwd(A[low], self.Wt[u["name"]], cat, Gd[low], self.w_view(u["name"], self.G), self.b_view(u["name"], self.G),
                                dy_off=0, xmask=self._mask_of(low), planar=self.planar)
                 self._grad_ready(u["name"])
+            elif a["name"] in self.Wup:
+                self._block_bwd(a, A[low], skip, True)
+                W = self.Wup[a["name"]]
+                ops.conv3d_upcat_dgrad(Gd[a["name"]], W["up_d"], W["sk_d"], self._mask_of(low), None, Gd[low], cat)
             else:
                 self._block_bwd(a, A[low], skip, True)
                 ops.conv3d_dgrad(Gd[a["name"]], self.Wd[a["name"]], cat, planar=self.planar)

@@ -324,3 +324,30 @@ def noise_augment(x, stats, noise, kind, sigma):
     assert noise.dtype == torch.float32 and noise.numel() == x.numel()
     check(lib().fmri_noise_augment(_p(x), x.numel(), dt(x), _p(stats), _p(noise), int(kind), float(sigma), _s()), "fmri_noise_augment")
     return x
+
+
+# ---------------------------------------------------------------------------------------------- up-sample + concat + conv, parity form
+def conv3d_upcat_ok(C0, C1, Cout, D, H, W, dtype):
+    return bool(lib().fmri_conv3d_upcat_ok(C0, C1, Cout, D, H, W, BF16 if dtype == torch.bfloat16 else F32))
+
+
+def conv3d_pack_up_weights(w, C0, C1, up_f=None, up_d=None, sk_f=None, sk_d=None):
+    _need_cuda(w, up_f, up_d, sk_f, sk_d)
+    Cout = w.shape[1]
+    ref = next(t for t in (up_f, up_d, sk_f, sk_d) if t is not None)
+    check(lib().fmri_conv3d_pack_up_weights(_p(w), C0, C1, Cout, _p(up_f), _p(up_d), _p(sk_f), _p(sk_d), dt(ref), _s()), "fmri_conv3d_pack_up_weights")
+
+
+def conv3d_upcat_fwd(src0_low, src1, w_up_f, w_sk_f, bias, y, act=ACT_RELU, alpha=0.0):
+    _need_cuda(src0_low, src1, w_up_f, w_sk_f, bias, y)
+    N, D, H, W, Cout = y.shape
+    check(lib().fmri_conv3d_upcat_fwd(_p(src0_low), src0_low.shape[-1], _p(src1), src1.shape[-1], _p(w_up_f), _p(w_sk_f), _p(bias), _p(y), N, D, H, W,
+                                      Cout, act, float(alpha), dt(y), _s()), "fmri_conv3d_upcat_fwd")
+    return y
+
+
+def conv3d_upcat_dgrad(dy, w_up_d, w_sk_d, mask_low, mask_skip, dx_low, dx_skip):
+    _need_cuda(dy, w_up_d, w_sk_d, mask_low, mask_skip, dx_low, dx_skip)
+    N, D, H, W, Cout = dy.shape
+    check(lib().fmri_conv3d_upcat_dgrad(_p(dy), Cout, _p(w_up_d), _p(w_sk_d), _p(mask_low), _p(mask_skip), _p(dx_low), _p(dx_skip), N, D, H, W,
+                                        dx_low.shape[-1], dx_skip.shape[-1], dt(dy), _s()), "fmri_conv3d_upcat_dgrad")

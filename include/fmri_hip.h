@@ -69,6 +69,26 @@ int fmri_conv3d_wgrad(const void* src0, int C0, int up0, const void* src1, int C
 /* bytes of workspace fmri_conv3d_wgrad can use for this shape (0: the shape does not take the slab path) */
 int64_t fmri_conv3d_wgrad_workspace_bytes(int C0, int C1, int Cout, int N, int D, int H, int W, int dtype, int planar);
 
+/* ---- [nearest_up2(src0) | src1] -> Conv3D(3x3x3) without the redundant taps (reference unet.py:132-138 UpSampling3D, :61
+ * concatenate, :102 Conv3D).  Output voxel 2g+p of the up-sampled source only sees low-res voxels {g-1,g} (p = 0) or {g,g+1}
+ * (p = 1) per axis with pre-summed weights: 8 parity classes x 8 taps on the LOW-res tensor instead of 27 taps on 8x the voxels.
+ * Same result as fmri_conv3d_fwd(up0 = 1) up to one extra bf16 rounding of the up-sampled channels' partial sum. bf16, 3-D only.
+ * fmri_conv3d_upcat_ok: 1 when the shape is supported (D,H,W = OUTPUT dims). */
+int fmri_conv3d_upcat_ok(int C0, int C1, int Cout, int D, int H, int W, int dtype);
+/* w: fp32 master [27][Cout][C0+C1] (up-sampled channels first).  Outputs (any may be NULL): w_up_fwd [8][8][Cout][C0],
+ * w_up_dgrad [8][8][C0][Cout], w_skip_fwd [27][Cout][C1], w_skip_dgrad [27][C1][Cout] (tap-flipped). */
+int fmri_conv3d_pack_up_weights(const float* w, int C0, int C1, int Cout, void* w_up_fwd, void* w_up_dgrad, void* w_skip_fwd,
+                                void* w_skip_dgrad, int dtype, fmri_stream_t stream);
+/* y [N][D][H][W][Cout] = act(conv(up2(src0_low [N][D/2][H/2][W/2][C0])) + conv(src1 [N][D][H][W][C1]) + bias) */
+int fmri_conv3d_upcat_fwd(const void* src0_low, int C0, const void* src1, int C1, const void* w_up_fwd, const void* w_skip_fwd,
+                          const float* bias, void* y, int N, int D, int H, int W, int Cout, int act, float alpha, int dtype,
+                          fmri_stream_t stream);
+/* dx_low [N][D/2][H/2][W/2][C0] and dx_skip [N][D][H][W][C1] from dy [N][D][H][W][Cout]; mask_* (optional) = the stored
+ * post-ReLU tensors of the two producers (gradient zeroed where they are <= 0).  Replaces dgrad-of-concat + UpSampling3D gradient. */
+int fmri_conv3d_upcat_dgrad(const void* dy, int Cout, const void* w_up_dgrad, const void* w_skip_dgrad, const void* mask_low,
+                            const void* mask_skip, void* dx_low, void* dx_skip, int N, int D, int H, int W, int C0, int C1, int dtype,
+                            fmri_stream_t stream);
+
 /* fp32 master filter [27][Cout][Cin] -> w_fwd (dtype, same layout) and w_dgrad (dtype, [26-tap][Cin][Cout]).
  * Either destination may be NULL. */
 int fmri_conv3d_pack_weights(const float* w, void* w_fwd, void* w_dgrad, int Cout, int Cin, int dtype,

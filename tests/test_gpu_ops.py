@@ -500,3 +500,58 @@ def test_selectable_losses_value_and_gradient(ops, name, kind, param):
          4: -((t * p).sum() + 1) / (t.sum() + p.sum() - (t * p).sum() + 1), 5: -dice(t, p) + param * dice(1 - t, p)}[kind]
     L.backward()
     assert_close(dl, z.grad, 2e-4, 2e-5, what=name)
+
+
+# ---------------------------------------------------------------------------------------------- up-sample + concat + conv, parity form
+UPCAT_CASES = [
+    # name, N, D,H,W (output dims), C0 (up-sampled), C1 (skip), Cout
+    ("one_tile", 1, 8, 16, 32, 64, 32, 64),
+    ("multi_tile", 2, 16, 32, 64, 128, 64, 64),
+    ("narrow_cout", 1, 8, 32, 32, 64, 64, 96),
+    ("deep", 1, 8, 16, 32, 256, 128, 128),
+]
+
+
+@pytest.mark.parametrize("case", UPCAT_CASES, ids=[c[0] for c in UPCAT_CASES])
+def test_upcat_fwd_and_dgrad(ops, case):
+    """fmri_conv3d_upcat_fwd / _dgrad (8 parity classes x 8 pre-summed taps on the low-res tensor) against the plain definition
+    conv3x3x3(concat(nearest_up2(x_low), x_skip)) and its autograd gradients in fp64.  Inputs and master weights are bf16-exact;
+    the parity form rounds the pre-summed weights and the up-sampled channels' partial sum to bf16 once more, hence 1.5e-2."""
+    name, N, D, H, W, C0, C1, Cout = case
+    dtype = torch.bfloat16
+    assert ops.conv3d_upcat_ok(C0, C1, Cout, D, H, W, dtype)
+    x_low = rnd((N, D // 2, H // 2, W // 2, C0), 1, dtype)
+    x_skip = rnd((N, D, H, W, C1), 2, dtype)
+    w = rnd((27, Cout, C0 + C1), 3, dtype, scale=0.05).float().contiguous()            # fp32 master holding bf16-exact values
+    bias = rnd((Cout,), 4, torch.float32)
+    up_f = torch.empty((8, 8, Cout, C0), device="cuda", dtype=dtype)
+    up_d = torch.empty((8, 8, C0, Cout), device="cuda", dtype=dtype)
+    sk_f = torch.empty((27, Cout, C1), device="cuda", dtype=dtype)
+    sk_d = torch.empty((27, C1, Cout), device="cuda", dtype=dtype)
+    ops.conv3d_pack_up_weights(w, C0, C1, up_f, up_d, sk_f, sk_d)
+    y = torch.full((N, D, H, W, Cout), float("nan"), dtype=dtype, device="cuda")
+    ops.conv3d_upcat_fwd(x_low, x_skip, up_f, sk_f, bias, y, act=1)
+    torch.cuda.synchronize()
+    # checker: plain definition with autograd
+    xl = f64(x_low).requires_grad_(True)
+    xs = f64(x_skip).requires_grad_(True)
+    inp = ref_concat_input(xl, xs, True)
+    pre = F.conv3d(inp, keras_kernel_from_packed(f64(w)), f64(bias), padding=1)
+    ref = to_ndhwc(F.relu(pre))
+    assert_close(y, ref, 1.5e-2, 1.5e-2, what=name + " fwd")
+    # the existing fused-upsample kernel computes the same thing with 27 taps: the two device paths agree as well
+    wf = w.to(dtype)
+    y2 = torch.empty_like(y)
+    ops.conv3d_fwd(x_low, x_skip, wf, bias, y2, up0=True, act=1)
+    assert_close(y, f64(y2), 1.5e-2, 1.5e-2, what=name + " fwd vs 27-tap kernel")
+    # gradients w.r.t. both inputs for a random dy, with the producers' ReLU masks
+    dy = rnd((N, D, H, W, Cout), 5, dtype)
+    m_low = rnd((N, D // 2, H // 2, W // 2, C0), 6, dtype).clamp_min(0)
+    m_skip = rnd((N, D, H, W, C1), 7, dtype).clamp_min(0)
+    dx_low = torch.full_like(x_low, float("nan"))
+    dx_skip = torch.full_like(x_skip, float("nan"))
+    ops.conv3d_upcat_dgrad(dy, up_d, sk_d, m_low, m_skip, dx_low, dx_skip)
+    torch.cuda.synchronize()
+    pre.backward(to_ncdhw(f64(dy)))
+    assert_close(dx_low, xl.grad * (f64(m_low) > 0), 1.5e-2, 1.5e-2, what=name + " dx_low")
+    assert_close(dx_skip, xs.grad * (f64(m_skip) > 0), 1e-2, 1e-2, what=name + " dx_skip")
