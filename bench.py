@@ -216,6 +216,7 @@ def main():
         timer.wrap(ops, "conv3d_upcat_fwd", lambda *aa, **kk: "conv_fwd_mfma", launches=2)
         timer.wrap(ops, "conv3d_upcat_dgrad", lambda *aa, **kk: "conv_fwd_mfma", launches=2)
         timer.wrap(ops, "conv3d_pack_up_weights", lambda *aa, **kk: "pack_weights")
+        timer.wrap(ops, "conv3d_upcat_wgrad", lambda *aa, **kk: "conv_wgrad_mfma", launches=2)
         for nm in ("maxpool_fwd", "maxpool_bwd", "upsample_bwd", "conv1x1_fwd", "conv1x1_bwd", "sigmoid_dice_fwd",
                    "sigmoid_dice_bwd", "adam_step", "pack_weights"):
             timer.wrap(ops, nm, (lambda n_: (lambda *aa, **kk: n_))(nm))

@@ -13,6 +13,7 @@
 // Reference ops replaced: Conv3D / Conv3DBackpropInputV2 / Conv3DBackpropFilterV2 / BiasAdd(Grad) / Relu(Grad) /
 // UpSampling3D / ConcatV2 emitted by Keras for fetal_net/model/unet3d/unet.py:45-66,89-115,132-138.
 #include "common.h"
+#include <type_traits>
 #include <cstdlib>
 
 namespace {
@@ -752,10 +753,15 @@ __device__ __forceinline__ bf16x8_t tr_frag(const unsigned char* base, int row0,
     return __builtin_bit_cast(bf16x8_t, f);
 }
 
-template <int CI_T>  // CI_T = 32-wide input-channel tiles per workgroup (1 or 2); output-channel block is always 64
+// UPW ("up weight-gradient"): gradient of the pre-summed parity filters of the up-sampled channels (see k_conv_fwd_mfma MODE 1).
+// dWc[p][t'] = sum over low-res voxels g of dy[2g+p] (x) x_low[g + t' + p - 1]: the kernel runs on the LOW-res grid (D,H,W = low-res
+// dims), the Cout blocks enumerate (parity, 64-channel block), only kd in {pd, pd+1} gets workgroups and only the 4 (kh,kw) taps
+// {ph,ph+1} x {pw,pw+1} are accumulated; the dy tile is gathered from the parity-p voxels of the [2D][2H][2W] gradient.
+// Result layout [8 p][2][2][2][Cout][C0] fp32 (atomics), expanded into the 27-tap gradient by k_expand_up_wgrad.
+template <int CI_T, bool UPW>  // CI_T = 32-wide input-channel tiles per workgroup (1 or 2); output-channel block is always 64
 __global__ void __launch_bounds__(wg::NTHREADS, 2)
 k_conv_wgrad_mfma(SrcB s, const bf16_t* __restrict__ dy, float* __restrict__ dw, float* __restrict__ db, int N, int D, int H,
-                  int W, int Cout, int nslab, float* __restrict__ slab_ws) {
+                  int W, int Cout, int nslab, float* __restrict__ slab_ws, int dw_ld) {
     using namespace wg;
     constexpr int CIB = 32 * CI_T;
     constexpr int XROWB = CIB * 2;                       // bytes per x row
@@ -771,17 +777,19 @@ k_conv_wgrad_mfma(SrcB s, const bf16_t* __restrict__ dy, float* __restrict__ dw,
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * STAGE_BYTES];
 
     const int Cin = s.C0 + s.C1;
-    const int ncib = Cin / CIB, ncob = Cout / 64;
+    const int ncib = Cin / CIB, ncob = (UPW ? 8 : 1) * (Cout / 64);
     // slab-major block order: the (kd, Cout block, Cin block) workgroups that read the SAME planes are adjacent in launch
     // order, so they run at the same time and share those planes in L2 / Infinity Cache instead of re-reading HBM
     // (measured with rocprofv3 FETCH_SIZE: combo-major order fetched 3.6x the algorithmic bytes)
-    const int ncombo = (s.planar ? 1 : 3) * ncob * ncib;
+    const int ncombo = (UPW ? 2 : (s.planar ? 1 : 3)) * ncob * ncib;
     int combo = blockIdx.x % ncombo;
     const int slab = blockIdx.x / ncombo;
     const int cib = combo % ncib; combo /= ncib;
     const int cob = combo % ncob;
-    const int kd = s.planar ? 1 : combo / ncob;            // planar (2-D slices): only the centre kd plane exists
-    const int co0 = cob * 64, cc = cib * CIB;
+    const int par = UPW ? cob / (Cout / 64) : 0;           // output parity class (pd, ph, pw) of this workgroup
+    const int kdp = combo / ncob;                          // UPW: kd' in {0,1}
+    const int kd = UPW ? kdp + (par >> 2) : (s.planar ? 1 : kdp);   // planar (2-D slices): only the centre kd plane exists
+    const int co0 = (UPW ? cob % (Cout / 64) : cob) * 64, cc = cib * CIB;
 
     const bool from0 = cc < s.C0;
     const bf16_t* sp = from0 ? s.p0 : s.p1;
@@ -797,11 +805,12 @@ k_conv_wgrad_mfma(SrcB s, const bf16_t* __restrict__ dy, float* __restrict__ dw,
     const int ct = wv & 1;
     const int it = (CI_T == 2) ? (wv >> 1) : 0;
     const int ksl = (CI_T == 2) ? 0 : (wv >> 1);
-    const bool do_bias = (db != nullptr) && kd == (s.planar ? 1 : 0) && cib == 0 && it == 0;
+    const bool do_bias = !UPW && (db != nullptr) && kd == (s.planar ? 1 : 0) && cib == 0 && it == 0;
 
-    f32x16 acc[9];
+    constexpr int NACC = UPW ? 4 : 9;
+    f32x16 acc[NACC];
 #pragma unroll
-    for (int a = 0; a < 9; ++a)
+    for (int a = 0; a < NACC; ++a)
 #pragma unroll
         for (int k = 0; k < 16; ++k) acc[a][k] = 0.f;
     float bsum = 0.f;
@@ -831,7 +840,7 @@ k_conv_wgrad_mfma(SrcB s, const bf16_t* __restrict__ dy, float* __restrict__ dw,
         const int i = instr * 64 + lane;
         const int row = i >> 3, ps = i & 7;
         const int ls = ps ^ (((row >> 1) & 1) << 2);
-        y_soff[j] = ((row >> 4) * W + (row & 15)) * Cout + ls * 8;
+        y_soff[j] = UPW ? ((row >> 4) * 4 * W + (row & 15) * 2) * Cout + ls * 8 : ((row >> 4) * W + (row & 15)) * Cout + ls * 8;
         y_doff[j] = X_BYTES + instr * 1024;
     }
     const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr(lds));
@@ -845,7 +854,9 @@ k_conv_wgrad_mfma(SrcB s, const bf16_t* __restrict__ dy, float* __restrict__ dw,
         const bool dok = (unsigned)gd < (unsigned)D;
         const int gdc = min(max(gd, 0), D - 1) >> shd;
         const bf16_t* const xbase = sp + ((int64_t)n * sD + gdc) * sH * sW * sC + coff;
-        const bf16_t* const ybase = dy + ((((int64_t)n * D + d) * H + h0) * W + w0) * Cout + co0;
+        const bf16_t* const ybase =
+            UPW ? dy + ((((int64_t)n * 2 * D + 2 * d + (par >> 2)) * 2 * H + 2 * h0 + ((par >> 1) & 1)) * 2 * W + 2 * w0 + (par & 1)) * Cout + co0
+                : dy + ((((int64_t)n * D + d) * H + h0) * W + w0) * Cout + co0;
         const unsigned sbase = lds0 + buf * STAGE_BYTES;
 #pragma unroll
         for (int j = 0; j < XPW; ++j) {
@@ -870,6 +881,9 @@ k_conv_wgrad_mfma(SrcB s, const bf16_t* __restrict__ dy, float* __restrict__ dw,
     for (int m = 0; m < 4; ++m) pre_x[m] = wg_slot_off<XROWB>(lrow + m, lslot_x) + (pp & 1) * 8;
     const int pre_y = X_BYTES + wg_slot_off<128>(lrow, lslot_y) + (pp & 1) * 8;   // y row0 = ks*16 is a multiple of 4
 
+    // the unit loop, instantiated per (ph, pw) in the up mode so that every fragment row constant stays compile-time
+    auto run = [&](auto PHc, auto PWc) {
+    constexpr int PH_ = decltype(PHc)::value, PW_ = decltype(PWc)::value;
     int u = slab;
     int buf = 0;
     if (u < nunits) issue(u, 0);
@@ -901,8 +915,8 @@ k_conv_wgrad_mfma(SrcB s, const bf16_t* __restrict__ dy, float* __restrict__ dw,
                 for (int j = 0; j < 8; ++j) bsum += bf2f((unsigned short)af[j]);
             }
 #pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                const int c = (ks8 + tap / 3) * XW + (tap % 3);                      // compile-time row constant
+            for (int tap = 0; tap < NACC; ++tap) {
+                const int c = UPW ? (ks8 + (tap >> 1) + PH_) * XW + (tap & 1) + PW_ : (ks8 + tap / 3) * XW + (tap % 3);   // compile-time row constant
                 const unsigned char* pb = sb + pre_x[c & 3] + (c >> 2) * 4 * XROWB;
                 s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)pb);
                 s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(pb + 4 * XROWB));
@@ -915,13 +929,35 @@ k_conv_wgrad_mfma(SrcB s, const bf16_t* __restrict__ dy, float* __restrict__ dw,
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                                                 // ring slot `buf` may be refilled
     }
+    };
+    if constexpr (UPW) {
+        switch (par & 3) {
+            case 0: run(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}); break;
+            case 1: run(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}); break;
+            case 2: run(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}); break;
+            default: run(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}); break;
+        }
+    } else {
+        run(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+    }
     // ---- flush: D rows = co, cols = ci (128-B contiguous per half-wave).  With a workspace: plain stores of this workgroup's partial
     // slab [9][64][CIB] (summed per element by k_wgrad_reduce: deterministic, ~5x the atomic rate); without: fp32 atomics into dw.
-    if (slab_ws) {
+    if constexpr (UPW) {
+        // dWc[p][kd'][kh'][kw'][Cout][C0]
+#pragma unroll
+        for (int tap = 0; tap < 4; ++tap) {
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int co = co0 + ct * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * hk;
+                const int ci = cc + it * 32 + r;
+                atomicAdd(&dw[((int64_t)((par * 2 + kdp) * 4 + tap) * Cout + co) * Cin + ci], acc[tap][reg]);
+            }
+        }
+    } else if (slab_ws) {
         constexpr int KSP = (CI_T == 2) ? 1 : 2;          // Cin-block 32: the two k-step halves keep separate slabs
         float* const my = slab_ws + ((int64_t)blockIdx.x * KSP + ksl) * (9 * 64 * CIB);
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
+        for (int tap = 0; tap < NACC; ++tap) {
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
                 const int col = ct * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * hk;
@@ -930,12 +966,12 @@ k_conv_wgrad_mfma(SrcB s, const bf16_t* __restrict__ dy, float* __restrict__ dw,
         }
     } else {
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
+        for (int tap = 0; tap < NACC; ++tap) {
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
                 const int co = co0 + ct * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * hk;
                 const int ci = cc + it * 32 + r;
-                atomicAdd(&dw[((int64_t)(kd * 9 + tap) * Cout + co) * Cin + ci], acc[tap][reg]);
+                atomicAdd(&dw[((int64_t)(kd * 9 + tap) * Cout + co) * dw_ld + ci], acc[tap][reg]);
             }
         }
     }
@@ -1112,8 +1148,10 @@ int64_t conv3d_wgrad_mfma_ws_bytes(int C0, int C1, int Cout, int N, int D, int H
     return (int64_t)combos * nslab * (CIB == 32 ? 2 : 1) * 9 * 64 * CIB * (int64_t)sizeof(float);
 }
 
-int conv3d_wgrad_mfma(const void* src0, int C0, int up0, int planar, const void* src1, int C1, const void* dy, float* dw, float* db, int N,
-                      int D, int H, int W, int Cout, void* workspace, int64_t workspace_bytes, hipStream_t st) {
+// dw_ld: row length of the dw image the gradient is added into (>= C0 + C1; lets a launch over a subset of the input channels write
+// its columns of the full [27][Cout][Cin] gradient: pass dw already offset to the first column)
+int conv3d_wgrad_mfma_ld(const void* src0, int C0, int up0, int planar, const void* src1, int C1, const void* dy, float* dw, int dw_ld,
+                         float* db, int N, int D, int H, int W, int Cout, void* workspace, int64_t workspace_bytes, hipStream_t st) {
     SrcB s{(const bf16_t*)src0, (const bf16_t*)src1, C0, C1, up0, planar ? 0 : 1, planar};
     const int Cin = C0 + C1;
     // The slab flush wins where the flush dominates (small layers: -25..35 %) and loses ~4 % on the >= 0.3 TFLOP layers, whose atomic
@@ -1129,15 +1167,65 @@ int conv3d_wgrad_mfma(const void* src0, int C0, int up0, int planar, const void*
     int CIB, combos, nslab;
     wgrad_plan(C0, C1, Cout, N, D, H, W, planar, use_ws, CIB, combos, nslab);
     float* ws = use_ws ? (float*)workspace : nullptr;
-    if (CIB == 64) k_conv_wgrad_mfma<2><<<combos * nslab, wg::NTHREADS, 0, st>>>(s, (const bf16_t*)dy, dw, db, N, D, H, W, Cout, nslab, ws);
-    else k_conv_wgrad_mfma<1><<<combos * nslab, wg::NTHREADS, 0, st>>>(s, (const bf16_t*)dy, dw, db, N, D, H, W, Cout, nslab, ws);
+    if (CIB == 64) k_conv_wgrad_mfma<2, false><<<combos * nslab, wg::NTHREADS, 0, st>>>(s, (const bf16_t*)dy, dw, db, N, D, H, W, Cout, nslab, ws, dw_ld);
+    else k_conv_wgrad_mfma<1, false><<<combos * nslab, wg::NTHREADS, 0, st>>>(s, (const bf16_t*)dy, dw, db, N, D, H, W, Cout, nslab, ws, dw_ld);
     if (use_ws) {
         const int ncob = Cout / 64, ncib = Cin / CIB;
         const int64_t cols = (int64_t)combos * 9 * 64 * CIB / 4;
         const int grid = (int)((cols + 31) / 32);
-        if (CIB == 64) k_wgrad_reduce<64><<<grid, 256, 0, st>>>(ws, dw, Cout, Cin, nslab, combos, ncob, ncib, planar, 1);
-        else k_wgrad_reduce<32><<<grid, 256, 0, st>>>(ws, dw, Cout, Cin, nslab, combos, ncob, ncib, planar, 2);
+        if (CIB == 64) k_wgrad_reduce<64><<<grid, 256, 0, st>>>(ws, dw, Cout, dw_ld, nslab, combos, ncob, ncib, planar, 1);
+        else k_wgrad_reduce<32><<<grid, 256, 0, st>>>(ws, dw, Cout, dw_ld, nslab, combos, ncob, ncib, planar, 2);
     }
     FMRI_LAUNCH_CHECK();
     return FMRI_OK;
+}
+int conv3d_wgrad_mfma(const void* src0, int C0, int up0, int planar, const void* src1, int C1, const void* dy, float* dw, float* db, int N,
+                      int D, int H, int W, int Cout, void* workspace, int64_t workspace_bytes, hipStream_t st) {
+    return conv3d_wgrad_mfma_ld(src0, C0, up0, planar, src1, C1, dy, dw, C0 + C1, db, N, D, H, W, Cout, workspace, workspace_bytes, st);
+}
+
+// ---- weight gradient of up-sample + concat + conv in parity form.  dwc: fp32 scratch [8][8][Cout][C0] (zeroed here).
+namespace {
+__device__ __forceinline__ int tap_class_w(int p, int k) { return p == 0 ? (k >= 1) : (k >= 2); }
+// dw[kd,kh,kw][co][c0] += sum over the 8 parity classes of dWc[p][class of the tap under p]
+__global__ void k_expand_up_wgrad(const float* __restrict__ dwc, float* __restrict__ dw, int Cout, int C0, int dw_ld) {
+    const int64_t total = (int64_t)27 * Cout * C0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c0 = (int)(i % C0);
+        const int64_t q = i / C0;
+        const int co = (int)(q % Cout), t = (int)(q / Cout);
+        const int kd = t / 9, kh = (t / 3) % 3, kw = t % 3;
+        float acc = 0.f;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const int cls = (tap_class_w(p >> 2, kd) * 2 + tap_class_w((p >> 1) & 1, kh)) * 2 + tap_class_w(p & 1, kw);
+            acc += dwc[((int64_t)(p * 8 + cls) * Cout + co) * C0 + c0];
+        }
+        dw[((int64_t)t * Cout + co) * dw_ld + c0] += acc;
+    }
+}
+}  // namespace
+
+int conv3d_upcat_wgrad_mfma(const void* src0_low, int C0, const void* src1, int C1, const void* dy, float* dw, float* db, float* dwc, int N,
+                            int D, int H, int W, int Cout, void* workspace, int64_t workspace_bytes, hipStream_t st) {
+    // D,H,W = output dims.  1. parity-filter gradients over the low-res grid
+    if (hipMemsetAsync(dwc, 0, (size_t)64 * Cout * C0 * sizeof(float), st) != hipSuccess) return FMRI_E_LAUNCH;
+    {
+        SrcB s{(const bf16_t*)src0_low, nullptr, C0, 0, 0, 1, 0};
+        const int Dl = D / 2, Hl = H / 2, Wl = W / 2;
+        const bool wide = C0 % 64 == 0;
+        const int CIB = wide ? 64 : 32;
+        const int combos = 2 * 8 * (Cout / 64) * (C0 / CIB);
+        const int nunits = N * Dl * (Hl / wg::TH) * (Wl / wg::TW);
+        int nslab = (1536 + combos - 1) / combos;
+        if (nslab > nunits) nslab = nunits;
+        if (nslab < 1) nslab = 1;
+        if (wide) k_conv_wgrad_mfma<2, true><<<combos * nslab, wg::NTHREADS, 0, st>>>(s, (const bf16_t*)dy, dwc, nullptr, N, Dl, Hl, Wl, Cout, nslab, nullptr, C0);
+        else k_conv_wgrad_mfma<1, true><<<combos * nslab, wg::NTHREADS, 0, st>>>(s, (const bf16_t*)dy, dwc, nullptr, N, Dl, Hl, Wl, Cout, nslab, nullptr, C0);
+    }
+    // 2. fold them into the 27-tap gradient of the up-sampled input channels (columns [0, C0) of dw)
+    k_expand_up_wgrad<<<grid_for((int64_t)27 * Cout * C0, 256, 1024), 256, 0, st>>>(dwc, dw, Cout, C0, C0 + C1);
+    FMRI_LAUNCH_CHECK();
+    // 3. the skip channels: plain weight gradient into columns [C0, C0+C1), bias gradient included
+    return conv3d_wgrad_mfma_ld(src1, C1, 0, 0, nullptr, 0, dy, dw + C0, C0 + C1, db, N, D, H, W, Cout, workspace, workspace_bytes, st);
 }

@@ -162,6 +162,10 @@ class UNetEngine:
             self.Wf[name] = torch.empty((27, L["cout"], L["cin"]), dtype=self.dtype, device=dev)
             if self.training and name != first:
                 self.Wd[name] = torch.empty((27, L["cin"], L["cout"]), dtype=self.dtype, device=dev)
+        self.dwc_scratch = None
+        if self.training and self.upcat_wgrad:
+            need = max(64 * self.layout[n]["cout"] * self.upcat[n][0] for n in self.upcat_wgrad)
+            self.dwc_scratch = torch.empty(need, dtype=torch.float32, device=dev)
         self.init_glorot(seed)
 
     def w_view(self, name, buf=None):
@@ -273,6 +277,7 @@ class UNetEngine:
         import os
         p = self.plan
         out = {}
+        self.upcat_wgrad = set()                           # ... of which the weight gradient takes the parity form too
         if self.planar or self.dtype != torch.bfloat16 or os.environ.get("FMRI_UPCAT", "1") == "0":
             return out
         for lv in p.dec:
@@ -282,8 +287,11 @@ class UNetEngine:
             c1 = p.enc[a["level"]][1]["cout"]
             c0 = a["cin"] - c1
             D, H, W = p.level_dims(a["level"])
-            if ops.conv3d_upcat_ok(c0, c1, a["cout"], D, H, W, self.dtype):
+            ok = ops.conv3d_upcat_ok(c0, c1, a["cout"], D, H, W, self.dtype)
+            if ok & 1:
                 out[a["name"]] = (c0, c1)
+                if ok & 2:
+                    self.upcat_wgrad.add(a["name"])
         return out
 
     def refresh_weight_copies(self):
@@ -367,6 +375,8 @@ class UNetEngine:
             dims = self._dims(c["level"])
             c0, c1 = (c["c_up"], c["c_skip"]) if "c_up" in c else (c["cin"], 0)
             need = max(need, ops.conv3d_wgrad_workspace_bytes(c0, c1, c["cout"], dims[0], dims[1], dims[2], dims[3], dt, self.planar))
+            if c["name"] in self.upcat_wgrad:             # parity form: the plain kernel only sees the skip channels
+                need = max(need, ops.conv3d_wgrad_workspace_bytes(c1, 0, c["cout"], dims[0], dims[1], dims[2], dims[3], dt, self.planar))
         self.wgrad_ws = torch.empty(max(need // 4, 1), dtype=torch.float32, device=dev) if need else None
 
     # ------------------------------------------------------------------------------------------------ forward
@@ -460,8 +470,11 @@ class UNetEngine:
             ops.norm_act_bwd(self._as_samples(self.pre[name]), self._as_samples(self.act[name]), self._as_samples(g),
                              self.gb_view(name, "gamma"), self.nstats[name], self._as_samples(g), self.gb_view(name, "gamma", self.G),
                              self.gb_view(name, "beta", self.G), self.norm_ws, per, act=ACT_RELU)
-        ops.conv3d_wgrad(src0, src1, g, self.w_view(name, self.G), self.b_view(name, self.G), up0=up0, planar=self.planar,
-                         workspace=self.wgrad_ws)
+        if up0 and name in self.upcat_wgrad:
+            ops.conv3d_upcat_wgrad(src0, src1, g, self.w_view(name, self.G), self.b_view(name, self.G), self.dwc_scratch, workspace=self.wgrad_ws)
+        else:
+            ops.conv3d_wgrad(src0, src1, g, self.w_view(name, self.G), self.b_view(name, self.G), up0=up0, planar=self.planar,
+                             workspace=self.wgrad_ws)
         self._grad_ready(name)
 
     def _mask_of(self, name):

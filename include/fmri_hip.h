@@ -73,7 +73,7 @@ int64_t fmri_conv3d_wgrad_workspace_bytes(int C0, int C1, int Cout, int N, int D
  * concatenate, :102 Conv3D).  Output voxel 2g+p of the up-sampled source only sees low-res voxels {g-1,g} (p = 0) or {g,g+1}
  * (p = 1) per axis with pre-summed weights: 8 parity classes x 8 taps on the LOW-res tensor instead of 27 taps on 8x the voxels.
  * Same result as fmri_conv3d_fwd(up0 = 1) up to one extra bf16 rounding of the up-sampled channels' partial sum. bf16, 3-D only.
- * fmri_conv3d_upcat_ok: 1 when the shape is supported (D,H,W = OUTPUT dims). */
+ * fmri_conv3d_upcat_ok (D,H,W = OUTPUT dims): bit 0 = forward / input gradients supported, bit 1 = weight gradient too. */
 int fmri_conv3d_upcat_ok(int C0, int C1, int Cout, int D, int H, int W, int dtype);
 /* w: fp32 master [27][Cout][C0+C1] (up-sampled channels first).  Outputs (any may be NULL): w_up_fwd [8][8][Cout][C0],
  * w_up_dgrad [8][8][C0][Cout], w_skip_fwd [27][Cout][C1], w_skip_dgrad [27][C1][Cout] (tap-flipped). */
@@ -87,6 +87,13 @@ int fmri_conv3d_upcat_fwd(const void* src0_low, int C0, const void* src1, int C1
  * post-ReLU tensors of the two producers (gradient zeroed where they are <= 0).  Replaces dgrad-of-concat + UpSampling3D gradient. */
 int fmri_conv3d_upcat_dgrad(const void* dy, int Cout, const void* w_up_dgrad, const void* w_skip_dgrad, const void* mask_low,
                             const void* mask_skip, void* dx_low, void* dx_skip, int N, int D, int H, int W, int C0, int C1, int dtype,
+                            fmri_stream_t stream);
+
+/* dw [27][Cout][C0+C1] fp32 and db [Cout] (optional) ACCUMULATED, like fmri_conv3d_wgrad(up0 = 1) but with 8 instead of 27 taps of
+ * work on the up-sampled channels.  dwc_scratch: 64*Cout*C0 floats of device scratch (overwritten).  workspace: as fmri_conv3d_wgrad
+ * for the skip channels (query fmri_conv3d_wgrad_workspace_bytes(C1, 0, Cout, ...)). */
+int fmri_conv3d_upcat_wgrad(const void* src0_low, int C0, const void* src1, int C1, const void* dy, float* dw, float* db,
+                            float* dwc_scratch, int N, int D, int H, int W, int Cout, int dtype, void* workspace, int64_t workspace_bytes,
                             fmri_stream_t stream);
 
 /* fp32 master filter [27][Cout][Cin] -> w_fwd (dtype, same layout) and w_dgrad (dtype, [26-tap][Cin][Cout]).

@@ -519,7 +519,7 @@ def test_upcat_fwd_and_dgrad(ops, case):
     the parity form rounds the pre-summed weights and the up-sampled channels' partial sum to bf16 once more, hence 1.5e-2."""
     name, N, D, H, W, C0, C1, Cout = case
     dtype = torch.bfloat16
-    assert ops.conv3d_upcat_ok(C0, C1, Cout, D, H, W, dtype)
+    assert ops.conv3d_upcat_ok(C0, C1, Cout, D, H, W, dtype) & 1
     x_low = rnd((N, D // 2, H // 2, W // 2, C0), 1, dtype)
     x_skip = rnd((N, D, H, W, C1), 2, dtype)
     w = rnd((27, Cout, C0 + C1), 3, dtype, scale=0.05).float().contiguous()            # fp32 master holding bf16-exact values
@@ -555,3 +555,16 @@ def test_upcat_fwd_and_dgrad(ops, case):
     pre.backward(to_ncdhw(f64(dy)))
     assert_close(dx_low, xl.grad * (f64(m_low) > 0), 1.5e-2, 1.5e-2, what=name + " dx_low")
     assert_close(dx_skip, xs.grad * (f64(m_skip) > 0), 1e-2, 1e-2, what=name + " dx_skip")
+    # weight / bias gradient: parity form vs autograd of the plain definition (fp32 accumulation of bf16 products: 2e-3)
+    if ops.conv3d_upcat_ok(C0, C1, Cout, D, H, W, dtype) & 2:
+        dw = torch.zeros((27, Cout, C0 + C1), device="cuda")
+        db = torch.zeros(Cout, device="cuda")
+        scratch = torch.empty(64 * Cout * C0, device="cuda")
+        ops.conv3d_upcat_wgrad(x_low, x_skip, dy, dw, db, scratch)
+        torch.cuda.synchronize()
+        kern = keras_kernel_from_packed(f64(w)).requires_grad_(True)
+        pre2 = F.conv3d(ref_concat_input(f64(x_low), f64(x_skip), True), kern, f64(bias), padding=1)
+        pre2.backward(to_ncdhw(f64(dy)))
+        ref_dw = kern.grad.permute(2, 3, 4, 0, 1).reshape(27, Cout, C0 + C1)
+        assert_close(dw, ref_dw, 2e-3, 2e-3, what=name + " dw")
+        assert_close(db, f64(dy).sum(dim=(0, 1, 2, 3)), 2e-3, 2e-3, what=name + " db")

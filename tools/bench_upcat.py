@@ -25,7 +25,7 @@ def timeit(f, iters=10):
     return e0.elapsed_time(e1) / iters
 
 
-tot = [0, 0, 0, 0]
+tot = [0, 0, 0, 0, 0, 0]
 for name, C0, C1, Cout, D, H, W in LAYERS:
     bf = torch.bfloat16
     xl = torch.randn((N, D // 2, H // 2, W // 2, C0), device="cuda").to(bf)
@@ -50,7 +50,13 @@ for name, C0, C1, Cout, D, H, W in LAYERS:
 
     t_b27 = timeit(old_bwd)
     t_bup = timeit(lambda: ops.conv3d_upcat_dgrad(dy, up_d, sk_d, xl, None, dxl, dxs))
-    print("%s  fwd %.3f -> %.3f ms   dgrad(+upsample_bwd) %.3f -> %.3f ms" % (name, t_f27, t_fup, t_b27, t_bup))
-    for i, v in enumerate((t_f27, t_fup, t_b27, t_bup)):
+    dw, db = torch.zeros((27, Cout, C0 + C1), device="cuda"), torch.zeros(Cout, device="cuda")
+    scratch = torch.empty(64 * Cout * C0, device="cuda")
+    nws = ops.conv3d_wgrad_workspace_bytes(C0, C1, Cout, N, D, H, W, bf)
+    ws = torch.empty(max(nws // 4, 1), device="cuda") if nws else None
+    t_w27 = timeit(lambda: ops.conv3d_wgrad(xl, xs, dy, dw, db, up0=True, workspace=ws))
+    t_wup = timeit(lambda: ops.conv3d_upcat_wgrad(xl, xs, dy, dw, db, scratch, workspace=ws))
+    print("%s  fwd %.3f -> %.3f ms   dgrad(+upsample_bwd) %.3f -> %.3f ms   wgrad %.3f -> %.3f ms" % (name, t_f27, t_fup, t_b27, t_bup, t_w27, t_wup))
+    for i, v in enumerate((t_f27, t_fup, t_b27, t_bup, t_w27, t_wup)):
         tot[i] += v
-print("total fwd %.3f -> %.3f   dgrad %.3f -> %.3f" % tuple(tot))
+print("total fwd %.3f -> %.3f   dgrad %.3f -> %.3f   wgrad %.3f -> %.3f" % tuple(tot))
