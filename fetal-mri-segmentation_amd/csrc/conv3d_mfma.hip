@@ -240,7 +240,7 @@ k_conv_fwd_mfma(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__
 
     f32x16 acc[2][NT];
     float4 bv[NT][4];              // this lane's 4 x 4 bias values per 32-channel tile (fetched during the last chunk's first phase)
-    float4 bq = make_float4(0.f, 0.f, 0.f, 0.f);   // RES epilogue: bias of the 4 channels this lane finishes (line-major layout)
+    float4 bq = make_float4(0.f, 0.f, 0.f, 0.f), bq1 = bq;   // RES epilogue: bias of the 8 channels this lane finishes (line-major layout)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -322,7 +322,8 @@ k_conv_fwd_mfma(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__
             };
             issue_dma();
             if (RES && pl == 0 && cur.ch == nch - 1) {
-                bq = bias ? *reinterpret_cast<const float4*>(bias + cur.co0 + 4 * (lane % (BN / 4))) : make_float4(0.f, 0.f, 0.f, 0.f);
+                bq = bias ? *reinterpret_cast<const float4*>(bias + cur.co0 + 8 * (lane % (BN / 8))) : make_float4(0.f, 0.f, 0.f, 0.f);
+                bq1 = bias ? *reinterpret_cast<const float4*>(bias + cur.co0 + 8 * (lane % (BN / 8)) + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
             if (!RES && pl == 0 && cur.ch == nch - 1) {
                 // the epilogue's bias, fetched a chunk ahead: 8 dependent L2 round trips inside the epilogue cost 23 % of the
@@ -380,9 +381,10 @@ k_conv_fwd_mfma(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__
         if (RES && cur.ch == nch - 1) {
             // ---- epilogue with a residual: y = act(acc + residual + bias).  The sum has to be formed in fp32 before the activation,
             // so the raw accumulators are transposed through LDS as fp32, one 32-voxel column tile at a time (wave-private 8 KiB of
-            // the consumed halo slot), and finished line-major: 16 (8) lanes per voxel, 4 channels each.
+            // the consumed halo slot), and finished line-major: 8 (4) lanes per voxel, 8 channels = one 16-byte bf16 piece each.
             constexpr int PPV = BN / 4;                  // 16-byte fp32 pieces per voxel
-            constexpr int VPI = 64 / PPV;                // voxels per instruction
+            constexpr int LPV = BN / 8;                  // lanes per voxel
+            constexpr int VPI = 64 / LPV;                // voxels per instruction
             __builtin_amdgcn_s_barrier();
             unsigned char* const stage = lds + hb * HALO_BYTES + wv * (32 * BN * 4);
 #pragma unroll
@@ -400,21 +402,25 @@ k_conv_fwd_mfma(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__
                 const int rt = 2 * wv + j;
 #pragma unroll
                 for (int kk = 0; kk < 32 / VPI; ++kk) {
-                    const int rr = kk * VPI + lane / PPV, q = lane % PPV;
-                    const float4 a4 = *reinterpret_cast<const float4*>(stage + rr * (BN * 4) + (((q ^ rr) & (PPV - 1)) << 4));
+                    const int rr = kk * VPI + lane / LPV, q8 = lane % LPV;
+                    const float4 a0 = *reinterpret_cast<const float4*>(stage + rr * (BN * 4) + ((((2 * q8) ^ rr) & (PPV - 1)) << 4));
+                    const float4 a1 = *reinterpret_cast<const float4*>(stage + rr * (BN * 4) + ((((2 * q8 + 1) ^ rr) & (PPV - 1)) << 4));
                     const int wq = (rr >> 4) ? (((rr & 15) + 16 - (HW & 15)) & 15) : (rr & 15);
                     const int d = cur.d0 + (rt >> 2), h = cur.h0 + 2 * (rt & 3) + (rr >> 4), w = cur.w0 + wq;
-                    const int64_t ao = ((((int64_t)cur.n * D + d) * H + h) * W + w) * Cout + cur.co0 + q * 4;
-                    const uint2 r2 = *reinterpret_cast<const uint2*>(residual + ao);
-                    float o[4] = {a4.x + __uint_as_float(r2.x << 16) + bq.x, a4.y + __uint_as_float(r2.x & 0xffff0000u) + bq.y,
-                                  a4.z + __uint_as_float(r2.y << 16) + bq.z, a4.w + __uint_as_float(r2.y & 0xffff0000u) + bq.w};
+                    const int64_t ao = ((((int64_t)cur.n * D + d) * H + h) * W + w) * Cout + cur.co0 + q8 * 8;
+                    const uint4 r4 = *reinterpret_cast<const uint4*>(residual + ao);
+                    float o[8] = {a0.x + __uint_as_float(r4.x << 16) + bq.x, a0.y + __uint_as_float(r4.x & 0xffff0000u) + bq.y,
+                                  a0.z + __uint_as_float(r4.y << 16) + bq.z, a0.w + __uint_as_float(r4.y & 0xffff0000u) + bq.w,
+                                  a1.x + __uint_as_float(r4.z << 16) + bq1.x, a1.y + __uint_as_float(r4.z & 0xffff0000u) + bq1.y,
+                                  a1.z + __uint_as_float(r4.w << 16) + bq1.z, a1.w + __uint_as_float(r4.w & 0xffff0000u) + bq1.w};
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
+                    for (int i = 0; i < 8; ++i) {
                         if (act == FMRI_ACT_RELU) o[i] = fmaxf(o[i], 0.f);
                         else if (act == FMRI_ACT_LEAKY) o[i] = o[i] > 0.f ? o[i] : alpha * o[i];
                     }
-                    *reinterpret_cast<uint2*>(y + ao) = make_uint2((unsigned)f2bf(o[0]) | ((unsigned)f2bf(o[1]) << 16),
-                                                                    (unsigned)f2bf(o[2]) | ((unsigned)f2bf(o[3]) << 16));
+                    *reinterpret_cast<uint4*>(y + ao) =
+                        make_uint4((unsigned)f2bf(o[0]) | ((unsigned)f2bf(o[1]) << 16), (unsigned)f2bf(o[2]) | ((unsigned)f2bf(o[3]) << 16),
+                                   (unsigned)f2bf(o[4]) | ((unsigned)f2bf(o[5]) << 16), (unsigned)f2bf(o[6]) | ((unsigned)f2bf(o[7]) << 16));
                 }
             }
         }
