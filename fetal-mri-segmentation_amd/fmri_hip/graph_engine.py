@@ -40,6 +40,12 @@ class LayerGraphEngine(object):
         self.by_name = OrderedDict((l.name, l) for l in self.layers)
         self.dtype, self.dev, self.training, self.dist = dtype, torch.device(device), training, dist_ctx
         self.planar = False
+        # bf16: every tensor carries its channels padded to a multiple of 64 (zero weights / zero activations in the padding) so that
+        # all convolutions - including the 16- and 32-channel levels, the stride-2 and the 1x1x1 ones - run on the MFMA kernels:
+        # stride 2 = the stride-1 conv sampled at every second voxel, 1x1x1 = the centre tap of a 27-tap filter.  fp32 (parity mode)
+        # keeps the exact-size tensors and the fp32 VALU kernels.  FMRI_GRAPH_PAD=0 switches the padding off.
+        import os
+        self.pad = dtype == torch.bfloat16 and os.environ.get("FMRI_GRAPH_PAD", "1") != "0"
         self.t = 0
         self._fixed_drop = None
         self.loss_kind, self.loss_param = 0, 1.0
@@ -127,22 +133,30 @@ class LayerGraphEngine(object):
                 raise NotImplementedError("Concatenate is only supported in front of a 3x3x3 Conv3D (layer %s)" % l.name)
             else:
                 raise NotImplementedError("layer class %s (%s) is not executable on the engine yet" % (cn, l.name))
+        self.clog = {n: sh[0] for n, sh in self.shape.items()}          # logical channel counts
+        if self.pad:
+            for n, sh in self.shape.items():
+                if n != self.input_name:
+                    self.shape[n] = (self._cp(sh[0]),) + tuple(sh[1:])
         for o in self.ops:                                   # shapes of op outputs follow the layer whose name they carry
             o["shape"] = self.shape[o["out"]]
+
+    def _cp(self, c):
+        return ((c + 63) // 64) * 64 if self.pad else c
 
     # ------------------------------------------------------------------------------------------------ parameters
     def _build_params(self, seed):
         self.layout = OrderedDict()
         off = 0
         for name, op in self.convs.items():
-            cin = sum(self.shape[i][0] for i in op["ins"])
-            cout = self.shape[name][0]
+            cin = sum(self.clog[i] for i in op["ins"])
+            cout = self.clog[name]
             nw = op["k"] ** 3 * cout * cin
             off = (off + 3) & ~3
             self.layout[name] = dict(kind="conv", w=(off, nw), b=((off + nw + 3) & ~3, cout), cin=cin, cout=cout, k=op["k"])
             off = ((off + nw + 3) & ~3) + cout
         for name, op in self.norms.items():
-            c = self.shape[name][0]
+            c = self.clog[name]
             off = (off + 3) & ~3
             self.layout[name] = dict(kind="norm", gamma=(off, c), beta=(off + ((c + 3) & ~3), c), c=c)
             off = off + ((c + 3) & ~3) + c
@@ -151,12 +165,47 @@ class LayerGraphEngine(object):
         if self.training:
             self.G, self.M, self.V = torch.zeros_like(self.P), torch.zeros_like(self.P), torch.zeros_like(self.P)
         self.Wf, self.Wd = {}, {}
+        if self.pad:
+            self._build_padded_params()
+        else:
+            for name, op in self.convs.items():
+                Lc = self.layout[name]
+                self.Wf[name] = torch.empty((op["k"] ** 3, Lc["cout"], Lc["cin"]), dtype=self.dtype, device=self.dev)
+                if self.training and op["k"] == 3 and op["s"] == 1 and not self._is_input(op["ins"]):
+                    self.Wd[name] = torch.empty((27, Lc["cin"], Lc["cout"]), dtype=self.dtype, device=self.dev)
+        self.init_glorot(seed)
+
+    def _build_padded_params(self):
+        """physical (channel-padded, always 27-tap) images of the parameters and of their gradients; the flat fp32 buffers P/G/M/V keep
+        the logical Keras-shaped parameters, `refresh_weight_copies` scatters them in, backward gathers the gradients out"""
+        dev, f32 = self.dev, torch.float32
+        self.Wp32, self.bp, self.dWp, self.dbp, self.cin_map = {}, {}, {}, {}, {}
+        self.gp, self.betap, self.dgp, self.dbetap = {}, {}, {}, {}
         for name, op in self.convs.items():
             Lc = self.layout[name]
-            self.Wf[name] = torch.empty((op["k"] ** 3, Lc["cout"], Lc["cin"]), dtype=self.dtype, device=self.dev)
-            if self.training and op["k"] == 3 and op["s"] == 1 and not self._is_input(op["ins"]):
-                self.Wd[name] = torch.empty((27, Lc["cin"], Lc["cout"]), dtype=self.dtype, device=self.dev)
-        self.init_glorot(seed)
+            coutp = self.shape[name][0]
+            idx, base = [], 0
+            for i in op["ins"]:
+                c = self.clog[i]
+                idx += list(range(base, base + c))
+                base += c if i == self.input_name else self.shape[i][0]
+            cinp = base
+            self.cin_map[name] = torch.tensor(idx, dtype=torch.long, device=dev)
+            self.Wp32[name] = torch.zeros((27, coutp, cinp), dtype=f32, device=dev)
+            self.bp[name] = torch.zeros(coutp, dtype=f32, device=dev)
+            self.Wf[name] = torch.empty((27, coutp, cinp), dtype=self.dtype, device=dev)
+            if self.training:
+                self.dWp[name] = torch.zeros((27, coutp, cinp), dtype=f32, device=dev)
+                self.dbp[name] = torch.zeros(coutp, dtype=f32, device=dev)
+                if not self._is_input(op["ins"]):
+                    self.Wd[name] = torch.empty((27, cinp, coutp), dtype=self.dtype, device=dev)
+        for name in self.norms:
+            cp = self.shape[name][0]
+            self.gp[name] = torch.zeros(cp, dtype=f32, device=dev)
+            self.betap[name] = torch.zeros(cp, dtype=f32, device=dev)
+            if self.training:
+                self.dgp[name] = torch.zeros(cp, dtype=f32, device=dev)
+                self.dbetap[name] = torch.zeros(cp, dtype=f32, device=dev)
 
     def _is_input(self, ins):
         return len(ins) == 1 and ins[0] == self.input_name
@@ -220,6 +269,18 @@ class LayerGraphEngine(object):
         return W
 
     def refresh_weight_copies(self):
+        if self.pad:
+            for name, op in self.convs.items():
+                Lc = self.layout[name]
+                taps = self.Wp32[name] if op["k"] == 3 else self.Wp32[name][13:14]        # 1x1x1 = the centre tap
+                taps[:, :Lc["cout"]].index_copy_(2, self.cin_map[name], self.w_view(name))
+                self.bp[name][:Lc["cout"]] = self._v(name, "b")
+                ops.pack_weights(self.Wp32[name], self.Wf[name], self.Wd.get(name))
+            for name in self.norms:
+                c = self.layout[name]["c"]
+                self.gp[name][:c] = self._v(name, "gamma")
+                self.betap[name][:c] = self._v(name, "beta")
+            return
         for name, op in self.convs.items():
             if op["k"] == 3 and op["s"] == 1:
                 ops.pack_weights(self.w_view(name), self.Wf[name], self.Wd.get(name))
@@ -242,17 +303,26 @@ class LayerGraphEngine(object):
             if self.training:
                 for name, t in T.items():
                     Gd[name] = torch.empty_like(t)
-            cmax = max([self.layout[n]["c"] for n in self.norms] + [1])
+            full, gfull = {}, {}
+            if self.pad:                                  # stride-2 convs: the stride-1 result at the input resolution (and its gradient)
+                for o in self.ops:
+                    if o["kind"] == "conv" and o["s"] == 2:
+                        sp_in = tuple(self.shape[o["ins"][0]][1:])
+                        full[o["name"]] = torch.empty((N,) + sp_in + (o["shape"][0],), dtype=self.dtype, device=self.dev)
+                        if self.training:
+                            gfull[o["name"]] = torch.zeros_like(full[o["name"]])
+            cmax = max([self.shape[n][0] for n in self.norms] + [1])
             nvox = N * int(np.prod(self.plan.spatial))
             Lb = self.plan.n_labels
             self._bufsets[N] = dict(T=T, G=Gd, tmp=tmp, stats=stats, ws=torch.zeros((N, cmax, 2), dtype=torch.float64, device=self.dev),
                                     logits=torch.empty((nvox, Lb), dtype=torch.float32, device=self.dev),
                                     probs=torch.empty((nvox, Lb), dtype=torch.float32, device=self.dev),
                                     dlogits=torch.empty((nvox, Lb), dtype=torch.float32, device=self.dev),
-                                    dummy_y=torch.zeros(nvox * Lb, dtype=torch.uint8, device=self.dev), drop={}, cat={})
+                                    dummy_y=torch.zeros(nvox * Lb, dtype=torch.uint8, device=self.dev), drop={}, cat={}, full=full, gfull=gfull)
         b = self._bufsets[N]
         self.N, self.T, self.Gt, self.tmp, self.stats, self.norm_ws = N, b["T"], b["G"], b["tmp"], b["stats"], b["ws"]
         self.logits, self.probs, self.dlogits, self._dummy_y, self.drop, self.cat = b["logits"], b["probs"], b["dlogits"], b["dummy_y"], b["drop"], b["cat"]
+        self.full, self.gfull = b["full"], b["gfull"]
 
     def _t(self, name):
         return self.x_in if name == self.input_name else self.T[name]
@@ -267,6 +337,17 @@ class LayerGraphEngine(object):
             out = self.T[o["out"]]
             if kind == "conv":
                 name = o["name"]
+                if self.pad:
+                    s0 = self._t(o["ins"][0])
+                    s1 = self._t(o["ins"][1]) if len(o["ins"]) > 1 else None
+                    if o["s"] == 1:
+                        ops.conv3d_fwd(s0, s1, self.Wf[name], self.bp[name], out, up0=o["up0"], act=o["act"])
+                    else:
+                        fl = self.full[name]
+                        ops.conv3d_fwd(s0, s1, self.Wf[name], self.bp[name], fl, up0=o["up0"], act=o["act"])
+                        od, oh, ow = self._s2_offsets(fl)
+                        out.copy_(fl[:, od::2, oh::2, ow::2, :])
+                    continue
                 bias = self._v(name, "b")
                 if o["k"] == 3 and o["s"] == 1:
                     s0 = self._t(o["ins"][0])
@@ -276,7 +357,8 @@ class LayerGraphEngine(object):
                     ops.conv_direct_fwd(self._t(o["ins"][0]), self.Wf[name], bias, out, o["k"], o["s"], act=o["act"])
             elif kind == "norm":
                 name = o["name"]
-                ops.norm_act_fwd(self._t(o["ins"][0]), self._v(name, "gamma"), self._v(name, "beta"), out, self.stats[name], self.norm_ws,
+                gam, bet = (self.gp[name], self.betap[name]) if self.pad else (self._v(name, "gamma"), self._v(name, "beta"))
+                ops.norm_act_fwd(self._t(o["ins"][0]), gam, bet, out, self.stats[name], self.norm_ws,
                                  1 if o["instance"] else 0, eps=1e-3, eps_on_std=o["instance"], act=o["act"], alpha=LEAKY_ALPHA)
             elif kind == "add":
                 ops.add(self._t(o["ins"][0]), self._t(o["ins"][1]), out)
@@ -286,6 +368,8 @@ class LayerGraphEngine(object):
                     keep = 1.0 - o["rate"]
                     if self._fixed_drop is not None:
                         sc = self._fixed_drop[o["out"]]
+                        if sc.shape[1] != src.shape[-1]:
+                            sc = torch.nn.functional.pad(sc, (0, src.shape[-1] - sc.shape[1]))
                     else:                                   # whole channels of a sample are dropped, survivors scaled by 1/(1-p)
                         sc = (torch.rand((self.N, src.shape[-1]), device=self.dev) < keep).float() / keep
                     self.drop[o["out"]] = sc
@@ -297,8 +381,18 @@ class LayerGraphEngine(object):
                 ops.upsample_fwd(self._t(o["ins"][0]), out)
             elif kind == "maxpool":
                 ops.maxpool_fwd(self._t(o["ins"][0]), out)
-        ops.cast(self.T[self.logits_src].reshape(-1), self.logits.reshape(-1))
+        src = self.T[self.logits_src]
+        if src.shape[-1] != self.plan.n_labels:                # channel-padded: the logits are the first n_labels channels
+            self.logits.copy_(src.reshape(-1, src.shape[-1])[:, :self.plan.n_labels])
+        else:
+            ops.cast(src.reshape(-1), self.logits.reshape(-1))
         return self.logits
+
+    @staticmethod
+    def _s2_offsets(full):
+        """TF 'same' padding with stride 2 reads x[2o + k - pad_before]; pad_before = 0 for even sizes (output o = stride-1 'same'
+        result at 2o+1), 1 for odd sizes (at 2o)"""
+        return tuple(1 if d % 2 == 0 else 0 for d in full.shape[1:4])
 
     def set_dropout_masks(self, masks):
         """testing hook: fix the SpatialDropout3D masks ({layer name: [N,C] fp32 tensor}) instead of drawing them"""
@@ -337,7 +431,12 @@ class LayerGraphEngine(object):
         if self.dist is not None:
             self.dist.begin()
         ops.sigmoid_loss_bwd(self.probs, y_true, self.sums, self.dlogits, self.loss_kind, self.loss_param, smooth=1.0, grad_scale=grad_scale)
-        ops.cast(self.dlogits.reshape(-1), self.Gt[self.logits_src].reshape(-1))
+        gsrc = self.Gt[self.logits_src]
+        if gsrc.shape[-1] != self.plan.n_labels:
+            gsrc.zero_()
+            gsrc.reshape(-1, gsrc.shape[-1])[:, :self.plan.n_labels] = self.dlogits
+        else:
+            ops.cast(self.dlogits.reshape(-1), gsrc.reshape(-1))
         self._has_grad.add(self.logits_src)
         for o in reversed(self.ops):
             kind, out = o["kind"], o["out"]
@@ -350,15 +449,30 @@ class LayerGraphEngine(object):
                     ops.act_bwd(self.T[out], g, g, o["act"], LEAKY_ALPHA)
                 dw, db = self.w_view(name, self.G), self._v(name, "b", self.G)
                 ins = o["ins"]
-                if o["k"] == 3 and o["s"] == 1:
+                if self.pad and o["s"] == 2:                 # gradient of "sample every second voxel": scatter into the stride-1 grid
+                    gf = self.gfull[name]
+                    od, oh, ow = self._s2_offsets(gf)
+                    gf[:, od::2, oh::2, ow::2, :] = g        # the other voxels stay zero (zeroed at allocation, never written)
+                    g = gf
+                if self.pad or (o["k"] == 3 and o["s"] == 1):
                     s0 = self._t(ins[0])
                     s1 = self._t(ins[1]) if len(ins) > 1 else None
-                    ops.conv3d_wgrad(s0, s1, g, dw, db, up0=o["up0"])
+                    if self.pad:
+                        Lc = self.layout[name]
+                        dwp, dbp = self.dWp[name], self.dbp[name]
+                        dwp.zero_()
+                        dbp.zero_()
+                        ops.conv3d_wgrad(s0, s1, g, dwp, dbp, up0=o["up0"])
+                        taps = dwp if o["k"] == 3 else dwp[13:14]
+                        dw += taps[:, :Lc["cout"]].index_select(2, self.cin_map[name])
+                        db += dbp[:Lc["cout"]]
+                    else:
+                        ops.conv3d_wgrad(s0, s1, g, dw, db, up0=o["up0"])
                     if name in self.Wd:
                         if len(ins) == 1 and not o["up0"]:
                             self._accum(ins[0], lambda dst: ops.conv3d_dgrad(g, self.Wd[name], dst))
                         else:
-                            cin = self.layout[name]["cin"]
+                            cin = self.Wd[name].shape[1]           # physical (channel-padded) width of the concatenated input
                             if name not in self.cat:
                                 self.cat[name] = torch.empty(tuple(g.shape[:-1]) + (cin,), dtype=self.dtype, device=self.dev)
                             cat = self.cat[name]
@@ -380,6 +494,16 @@ class LayerGraphEngine(object):
             elif kind == "norm":
                 name = o["name"]
                 src = o["ins"][0]
+                if self.pad:
+                    c = self.layout[name]["c"]
+                    dg, dbt = self.dgp[name], self.dbetap[name]
+                    dg.zero_()
+                    dbt.zero_()
+                    self._accum(src, lambda dst: ops.norm_act_bwd(self._t(src), self.T[out], g, self.gp[name], self.stats[name], dst, dg, dbt,
+                                                                  self.norm_ws, 1 if o["instance"] else 0, act=o["act"], alpha=LEAKY_ALPHA))
+                    self._v(name, "gamma", self.G).add_(dg[:c])
+                    self._v(name, "beta", self.G).add_(dbt[:c])
+                    continue
                 self._accum(src, lambda dst: ops.norm_act_bwd(self._t(src), self.T[out], g, self._v(name, "gamma"), self.stats[name], dst,
                                                               self._v(name, "gamma", self.G), self._v(name, "beta", self.G), self.norm_ws,
                                                               1 if o["instance"] else 0, act=o["act"], alpha=LEAKY_ALPHA))
