@@ -75,6 +75,9 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise LibraryMissing("%s not found - build it with `python __graft_entry__.py` or `make -C "
                                  "fetal-mri-segmentation_amd/csrc` (no CPU fallback exists)" % LIB_PATH)
+        # torch first: its wheel carries its own HIP runtime, and the library's kernels must register with the runtime whose streams
+        # and allocations they are handed (loading this library before torch puts a second runtime in the process: every launch fails)
+        import torch  # noqa: F401
         L = C.CDLL(LIB_PATH)
         for name, args in SIGNATURES.items():
             fn = getattr(L, name)
