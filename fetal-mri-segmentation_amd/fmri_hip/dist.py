@@ -14,12 +14,13 @@ import torch.distributed as dist
 
 
 class DataParallel:
-    def __init__(self, world=None, rank=None, bucket_bytes=16 << 20, global_dice=True, group=None):
+    def __init__(self, world=None, rank=None, bucket_bytes=16 << 20, global_dice=True, group=None, force_collectives=False):
         self.world = dist.get_world_size(group) if world is None else world
         self.rank = dist.get_rank(group) if rank is None else rank
         self.group = group
         self.bucket_elems = max(1, bucket_bytes // 4)
         self.global_dice = global_dice
+        self.force = force_collectives      # issue the collectives even in a 1-rank group (exercises RCCL on a single GPU)
         self._start = 0
         self._comm = None
         self.launched = []          # (start, end) ranges reduced in the last backward (introspection / tests)
@@ -30,7 +31,7 @@ class DataParallel:
         return 1.0 if self.global_dice else 1.0 / self.world
 
     def all_reduce_sums(self, sums):
-        if self.world > 1:
+        if self.world > 1 or self.force:
             dist.all_reduce(sums, group=self.group)
 
     def broadcast_params(self, eng):
@@ -39,7 +40,7 @@ class DataParallel:
             eng.refresh_weight_copies()
 
     def _reduce_range(self, eng, start, end):
-        if self.world <= 1 or end <= start:
+        if (self.world <= 1 and not self.force) or end <= start:
             return
         g = eng.G[start:end]
         if g.is_cuda:
