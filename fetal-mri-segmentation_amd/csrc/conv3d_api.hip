@@ -131,16 +131,17 @@ extern "C" int fmri_conv3d_upcat_ok(int C0, int C1, int Cout, int D, int H, int 
     // D,H,W = output (full-resolution) dims; both the low-res grid and the full grid must tile.  bit 0: forward + input gradients,
     // bit 1: weight gradient
     if ((D | H | W) & 1) return 0;
-    if (C0 <= 0 || C1 <= 0 || Cout * 8 > 4096) return 0;            // up-backward sends 8*Cout channels of dy through the zero page
-    const bool fb = conv3d_fwd_mfma_ok(C0, 0, Cout, D / 2, H / 2, W / 2, dtype) && conv3d_fwd_mfma_ok(C1, 0, Cout, D, H, W, dtype) &&
-                    conv3d_fwd_mfma_ok(Cout, 0, C0, D / 2, H / 2, W / 2, dtype) && conv3d_fwd_mfma_ok(Cout, 0, C1, D, H, W, dtype);
-    const bool wg_ = conv3d_wgrad_mfma_ok(C0, 0, Cout, D / 2, H / 2, W / 2, dtype) && conv3d_wgrad_mfma_ok(C1, 0, Cout, D, H, W, dtype);
+    if (C0 <= 0 || C1 < 0 || Cout * 8 > 4096) return 0;             // up-backward sends 8*Cout channels of dy through the zero page
+    // C1 = 0: a convolution of a purely up-sampled tensor (reference isensee2017.py:101-104 create_up_sampling_module)
+    const bool fb = conv3d_fwd_mfma_ok(C0, 0, Cout, D / 2, H / 2, W / 2, dtype) && conv3d_fwd_mfma_ok(Cout, 0, C0, D / 2, H / 2, W / 2, dtype) &&
+                    (C1 == 0 || (conv3d_fwd_mfma_ok(C1, 0, Cout, D, H, W, dtype) && conv3d_fwd_mfma_ok(Cout, 0, C1, D, H, W, dtype)));
+    const bool wg_ = conv3d_wgrad_mfma_ok(C0, 0, Cout, D / 2, H / 2, W / 2, dtype) && (C1 == 0 || conv3d_wgrad_mfma_ok(C1, 0, Cout, D, H, W, dtype));
     return (fb ? 1 : 0) | (fb && wg_ ? 2 : 0);
 }
 
 extern "C" int fmri_conv3d_pack_up_weights(const float* w, int C0, int C1, int Cout, void* w_up_fwd, void* w_up_dgrad, void* w_skip_fwd,
                                            void* w_skip_dgrad, int dtype, fmri_stream_t stream) {
-    if (!w || C0 <= 0 || C1 <= 0 || Cout <= 0) return FMRI_E_SHAPE;
+    if (!w || C0 <= 0 || C1 < 0 || Cout <= 0) return FMRI_E_SHAPE;
     const int grid = grid_for((int64_t)64 * Cout * C0 + (int64_t)27 * Cout * C1, 256, 1024);
     if (dtype == FMRI_BF16)
         k_pack_up_weights<bf16_t><<<grid, 256, 0, as_stream(stream)>>>(w, C0, C1, Cout, (bf16_t*)w_up_fwd, (bf16_t*)w_up_dgrad, (bf16_t*)w_skip_fwd,
@@ -156,9 +157,12 @@ extern "C" int fmri_conv3d_pack_up_weights(const float* w, int C0, int C1, int C
 extern "C" int fmri_conv3d_upcat_fwd(const void* src0_low, int C0, const void* src1, int C1, const void* w_up_fwd, const void* w_skip_fwd,
                                      const float* bias, void* y, int N, int D, int H, int W, int Cout, int act, float alpha, int dtype,
                                      fmri_stream_t stream) {
-    if (!src0_low || !src1 || !w_up_fwd || !w_skip_fwd || !y || N <= 0) return FMRI_E_SHAPE;
+    if (!src0_low || !w_up_fwd || !y || N <= 0 || (C1 > 0 && (!src1 || !w_skip_fwd))) return FMRI_E_SHAPE;
     if (!(fmri_conv3d_upcat_ok(C0, C1, Cout, D, H, W, dtype) & 1)) return FMRI_E_SHAPE;
     if ((((uintptr_t)src0_low) | ((uintptr_t)src1) | ((uintptr_t)w_up_fwd) | ((uintptr_t)w_skip_fwd) | ((uintptr_t)y)) & 15) return FMRI_E_ALIGN;
+    if (C1 == 0)        // nothing to add: the parity launch finishes the output itself
+        return conv3d_fwd_mfma_ex(1, src0_low, C0, 0, 0, nullptr, 0, w_up_fwd, bias, nullptr, nullptr, y, N, D / 2, H / 2, W / 2, Cout, act, alpha,
+                                  as_stream(stream));
     // 1. partial sums of the up-sampled channels, scattered by parity class into y
     int rc = conv3d_fwd_mfma_ex(1, src0_low, C0, 0, 0, nullptr, 0, w_up_fwd, nullptr, nullptr, nullptr, y, N, D / 2, H / 2, W / 2, Cout,
                                 FMRI_ACT_NONE, 0.f, as_stream(stream));
@@ -170,7 +174,7 @@ extern "C" int fmri_conv3d_upcat_fwd(const void* src0_low, int C0, const void* s
 extern "C" int fmri_conv3d_upcat_dgrad(const void* dy, int Cout, const void* w_up_dgrad, const void* w_skip_dgrad, const void* mask_low,
                                        const void* mask_skip, void* dx_low, void* dx_skip, int N, int D, int H, int W, int C0, int C1, int dtype,
                                        fmri_stream_t stream) {
-    if (!dy || !w_up_dgrad || !w_skip_dgrad || !dx_low || !dx_skip || N <= 0) return FMRI_E_SHAPE;
+    if (!dy || !w_up_dgrad || !dx_low || N <= 0 || (C1 > 0 && (!w_skip_dgrad || !dx_skip))) return FMRI_E_SHAPE;
     if (!(fmri_conv3d_upcat_ok(C0, C1, Cout, D, H, W, dtype) & 1)) return FMRI_E_SHAPE;
     if ((((uintptr_t)dy) | ((uintptr_t)w_up_dgrad) | ((uintptr_t)w_skip_dgrad) | ((uintptr_t)dx_low) | ((uintptr_t)dx_skip) | ((uintptr_t)mask_low) |
          ((uintptr_t)mask_skip)) & 15)
@@ -178,7 +182,7 @@ extern "C" int fmri_conv3d_upcat_dgrad(const void* dy, int Cout, const void* w_u
     // gradient of the low-res tensor: one launch over the space-to-depth view of dy (8 parity classes x Cout channels, mirrored taps)
     int rc = conv3d_fwd_mfma_ex(2, dy, Cout, 0, 0, nullptr, 0, w_up_dgrad, nullptr, mask_low, nullptr, dx_low, N, D / 2, H / 2, W / 2, C0,
                                 FMRI_ACT_NONE, 0.f, as_stream(stream));
-    if (rc) return rc;
+    if (rc || C1 == 0) return rc;
     // gradient of the skip tensor: the plain tap-flipped transposed convolution restricted to the skip rows
     return conv3d_fwd_mfma_ex(0, dy, Cout, 0, 0, nullptr, 0, w_skip_dgrad, nullptr, mask_skip, nullptr, dx_skip, N, D, H, W, C1, FMRI_ACT_NONE, 0.f,
                               as_stream(stream));
@@ -187,7 +191,7 @@ extern "C" int fmri_conv3d_upcat_dgrad(const void* dy, int Cout, const void* w_u
 extern "C" int fmri_conv3d_upcat_wgrad(const void* src0_low, int C0, const void* src1, int C1, const void* dy, float* dw, float* db,
                                        float* dwc_scratch, int N, int D, int H, int W, int Cout, int dtype, void* workspace,
                                        int64_t workspace_bytes, fmri_stream_t stream) {
-    if (!src0_low || !src1 || !dy || !dw || !dwc_scratch || N <= 0) return FMRI_E_SHAPE;
+    if (!src0_low || !dy || !dw || !dwc_scratch || N <= 0 || (C1 > 0 && !src1)) return FMRI_E_SHAPE;
     if (!(fmri_conv3d_upcat_ok(C0, C1, Cout, D, H, W, dtype) & 2)) return FMRI_E_SHAPE;
     if ((((uintptr_t)src0_low) | ((uintptr_t)src1) | ((uintptr_t)dy)) & 15) return FMRI_E_ALIGN;
     return conv3d_upcat_wgrad_mfma(src0_low, C0, src1, C1, dy, dw, db, dwc_scratch, N, D, H, W, Cout, workspace, workspace_bytes,

@@ -811,7 +811,9 @@ k_conv_wgrad_mfma(SrcB s, const bf16_t* __restrict__ dy, float* __restrict__ dw,
     const int ct = wv & 1;
     const int it = (CI_T == 2) ? (wv >> 1) : 0;
     const int ksl = (CI_T == 2) ? 0 : (wv >> 1);
-    const bool do_bias = !UPW && (db != nullptr) && kd == (s.planar ? 1 : 0) && cib == 0 && it == 0;
+    // bias gradient = sum of dy over all voxels: taken from the A fragments by the workgroups that see every dy tile exactly once
+    // (UPW: each parity class covers its own eighth of the voxels)
+    const bool do_bias = (db != nullptr) && cib == 0 && it == 0 && (UPW ? kdp == 0 : kd == (s.planar ? 1 : 0));
 
     constexpr int NACC = UPW ? 4 : 9;
     f32x16 acc[NACC];
@@ -1226,12 +1228,14 @@ int conv3d_upcat_wgrad_mfma(const void* src0_low, int C0, const void* src1, int 
         int nslab = (1536 + combos - 1) / combos;
         if (nslab > nunits) nslab = nunits;
         if (nslab < 1) nslab = 1;
-        if (wide) k_conv_wgrad_mfma<2, true><<<combos * nslab, wg::NTHREADS, 0, st>>>(s, (const bf16_t*)dy, dwc, nullptr, N, Dl, Hl, Wl, Cout, nslab, nullptr, C0);
-        else k_conv_wgrad_mfma<1, true><<<combos * nslab, wg::NTHREADS, 0, st>>>(s, (const bf16_t*)dy, dwc, nullptr, N, Dl, Hl, Wl, Cout, nslab, nullptr, C0);
+        float* const dbu = C1 == 0 ? db : nullptr;         // with skip channels the plain launch below produces the bias gradient
+        if (wide) k_conv_wgrad_mfma<2, true><<<combos * nslab, wg::NTHREADS, 0, st>>>(s, (const bf16_t*)dy, dwc, dbu, N, Dl, Hl, Wl, Cout, nslab, nullptr, C0);
+        else k_conv_wgrad_mfma<1, true><<<combos * nslab, wg::NTHREADS, 0, st>>>(s, (const bf16_t*)dy, dwc, dbu, N, Dl, Hl, Wl, Cout, nslab, nullptr, C0);
     }
     // 2. fold them into the 27-tap gradient of the up-sampled input channels (columns [0, C0) of dw)
     k_expand_up_wgrad<<<grid_for((int64_t)27 * Cout * C0, 256, 1024), 256, 0, st>>>(dwc, dw, Cout, C0, C0 + C1);
     FMRI_LAUNCH_CHECK();
+    if (C1 == 0) return FMRI_OK;
     // 3. the skip channels: plain weight gradient into columns [C0, C0+C1), bias gradient included
     return conv3d_wgrad_mfma_ld(src1, C1, 0, 0, nullptr, 0, dy, dw + C0, C0 + C1, db, N, D, H, W, Cout, workspace, workspace_bytes, st);
 }

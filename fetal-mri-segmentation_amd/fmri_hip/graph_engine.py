@@ -164,7 +164,7 @@ class LayerGraphEngine(object):
         self.P = torch.zeros(self.n_flat, dtype=torch.float32, device=self.dev)
         if self.training:
             self.G, self.M, self.V = torch.zeros_like(self.P), torch.zeros_like(self.P), torch.zeros_like(self.P)
-        self.Wf, self.Wd = {}, {}
+        self.Wf, self.Wd, self.Wup = {}, {}, {}
         if self.pad:
             self._build_padded_params()
         else:
@@ -199,6 +199,20 @@ class LayerGraphEngine(object):
                 self.dbp[name] = torch.zeros(coutp, dtype=f32, device=dev)
                 if not self._is_input(op["ins"]):
                     self.Wd[name] = torch.empty((27, cinp, coutp), dtype=self.dtype, device=dev)
+        # UpSampling3D -> Conv3D (reference isensee2017.py:101-104): parity form, 8 pre-summed 2x2x2 filters on the low-res tensor
+        self.Wup, self.dwc_scratch = {}, None
+        for name, op in self.convs.items():
+            if op["up0"] and len(op["ins"]) == 1 and op["s"] == 1 and op["k"] == 3:
+                coutp, cinp = self.shape[name][0], self.Wp32[name].shape[2]
+                ok = ops.conv3d_upcat_ok(cinp, 0, coutp, *self.shape[name][1:], self.dtype)
+                if ok & 1:
+                    W = dict(up_f=torch.empty((8, 8, coutp, cinp), dtype=self.dtype, device=dev), up_d=None, wgrad=bool(ok & 2))
+                    if self.training:
+                        W["up_d"] = torch.empty((8, 8, cinp, coutp), dtype=self.dtype, device=dev)
+                    self.Wup[name] = W
+        if self.training and any(W["wgrad"] for W in self.Wup.values()):
+            need = max(64 * self.shape[n][0] * self.Wp32[n].shape[2] for n, W in self.Wup.items() if W["wgrad"])
+            self.dwc_scratch = torch.empty(need, dtype=f32, device=dev)
         for name in self.norms:
             cp = self.shape[name][0]
             self.gp[name] = torch.zeros(cp, dtype=f32, device=dev)
@@ -275,6 +289,10 @@ class LayerGraphEngine(object):
                 taps = self.Wp32[name] if op["k"] == 3 else self.Wp32[name][13:14]        # 1x1x1 = the centre tap
                 taps[:, :Lc["cout"]].index_copy_(2, self.cin_map[name], self.w_view(name))
                 self.bp[name][:Lc["cout"]] = self._v(name, "b")
+                if name in self.Wup:
+                    W = self.Wup[name]
+                    ops.conv3d_pack_up_weights(self.Wp32[name], self.Wp32[name].shape[2], 0, W["up_f"], W["up_d"], None, None)
+                    continue                                  # forward and input gradient use the parity filters only
                 ops.pack_weights(self.Wp32[name], self.Wf[name], self.Wd.get(name))
             for name in self.norms:
                 c = self.layout[name]["c"]
@@ -340,7 +358,9 @@ class LayerGraphEngine(object):
                 if self.pad:
                     s0 = self._t(o["ins"][0])
                     s1 = self._t(o["ins"][1]) if len(o["ins"]) > 1 else None
-                    if o["s"] == 1:
+                    if name in self.Wup:
+                        ops.conv3d_upcat_fwd(s0, None, self.Wup[name]["up_f"], None, self.bp[name], out, act=o["act"], alpha=LEAKY_ALPHA)
+                    elif o["s"] == 1:
                         ops.conv3d_fwd(s0, s1, self.Wf[name], self.bp[name], out, up0=o["up0"], act=o["act"])
                     else:
                         fl = self.full[name]
@@ -462,13 +482,18 @@ class LayerGraphEngine(object):
                         dwp, dbp = self.dWp[name], self.dbp[name]
                         dwp.zero_()
                         dbp.zero_()
-                        ops.conv3d_wgrad(s0, s1, g, dwp, dbp, up0=o["up0"])
+                        if name in self.Wup and self.Wup[name]["wgrad"]:
+                            ops.conv3d_upcat_wgrad(s0, None, g, dwp, dbp, self.dwc_scratch)
+                        else:
+                            ops.conv3d_wgrad(s0, s1, g, dwp, dbp, up0=o["up0"])
                         taps = dwp if o["k"] == 3 else dwp[13:14]
                         dw += taps[:, :Lc["cout"]].index_select(2, self.cin_map[name])
                         db += dbp[:Lc["cout"]]
                     else:
                         ops.conv3d_wgrad(s0, s1, g, dw, db, up0=o["up0"])
-                    if name in self.Wd:
+                    if name in self.Wup and self.training:
+                        self._accum(ins[0], lambda dst: ops.conv3d_upcat_dgrad(g, self.Wup[name]["up_d"], None, None, None, dst, None))
+                    elif name in self.Wd:
                         if len(ins) == 1 and not o["up0"]:
                             self._accum(ins[0], lambda dst: ops.conv3d_dgrad(g, self.Wd[name], dst))
                         else:

@@ -342,7 +342,7 @@ def conv3d_pack_up_weights(w, C0, C1, up_f=None, up_d=None, sk_f=None, sk_d=None
 def conv3d_upcat_fwd(src0_low, src1, w_up_f, w_sk_f, bias, y, act=ACT_RELU, alpha=0.0):
     _need_cuda(src0_low, src1, w_up_f, w_sk_f, bias, y)
     N, D, H, W, Cout = y.shape
-    check(lib().fmri_conv3d_upcat_fwd(_p(src0_low), src0_low.shape[-1], _p(src1), src1.shape[-1], _p(w_up_f), _p(w_sk_f), _p(bias), _p(y), N, D, H, W,
+    check(lib().fmri_conv3d_upcat_fwd(_p(src0_low), src0_low.shape[-1], _p(src1), 0 if src1 is None else src1.shape[-1], _p(w_up_f), _p(w_sk_f), _p(bias), _p(y), N, D, H, W,
                                       Cout, act, float(alpha), dt(y), _s()), "fmri_conv3d_upcat_fwd")
     return y
 
@@ -351,13 +351,13 @@ def conv3d_upcat_dgrad(dy, w_up_d, w_sk_d, mask_low, mask_skip, dx_low, dx_skip)
     _need_cuda(dy, w_up_d, w_sk_d, mask_low, mask_skip, dx_low, dx_skip)
     N, D, H, W, Cout = dy.shape
     check(lib().fmri_conv3d_upcat_dgrad(_p(dy), Cout, _p(w_up_d), _p(w_sk_d), _p(mask_low), _p(mask_skip), _p(dx_low), _p(dx_skip), N, D, H, W,
-                                        dx_low.shape[-1], dx_skip.shape[-1], dt(dy), _s()), "fmri_conv3d_upcat_dgrad")
+                                        dx_low.shape[-1], 0 if dx_skip is None else dx_skip.shape[-1], dt(dy), _s()), "fmri_conv3d_upcat_dgrad")
 
 
 def conv3d_upcat_wgrad(src0_low, src1, dy, dw, db, dwc_scratch, workspace=None):
     _need_cuda(src0_low, src1, dy, dw, db, dwc_scratch, workspace)
     N, D, H, W, Cout = dy.shape
-    C0, C1 = src0_low.shape[-1], src1.shape[-1]
+    C0, C1 = src0_low.shape[-1], (0 if src1 is None else src1.shape[-1])
     assert dwc_scratch.dtype == torch.float32 and dwc_scratch.numel() >= 64 * Cout * C0
     check(lib().fmri_conv3d_upcat_wgrad(_p(src0_low), C0, _p(src1), C1, _p(dy), _p(dw), _p(db), _p(dwc_scratch), N, D, H, W, Cout, dt(dy),
                                         _p(workspace), 0 if workspace is None else workspace.numel() * workspace.element_size(), _s()),

@@ -568,3 +568,35 @@ def test_upcat_fwd_and_dgrad(ops, case):
         ref_dw = kern.grad.permute(2, 3, 4, 0, 1).reshape(27, Cout, C0 + C1)
         assert_close(dw, ref_dw, 2e-3, 2e-3, what=name + " dw")
         assert_close(db, f64(dy).sum(dim=(0, 1, 2, 3)), 2e-3, 2e-3, what=name + " db")
+
+
+def test_upcat_without_skip_channels(ops):
+    """C1 = 0: convolution of a purely up-sampled tensor (the Isensee up-sampling module): one parity launch with bias + LeakyReLU in
+    its own epilogue; gradients incl. the bias gradient taken inside the parity weight-gradient kernel"""
+    N, D, H, W, C0, Cout = 1, 8, 16, 32, 64, 64
+    dtype = torch.bfloat16
+    assert ops.conv3d_upcat_ok(C0, 0, Cout, D, H, W, dtype) == 3
+    x_low = rnd((N, D // 2, H // 2, W // 2, C0), 11, dtype)
+    w = rnd((27, Cout, C0), 12, dtype, scale=0.05).float().contiguous()
+    bias = rnd((Cout,), 13, torch.float32)
+    up_f = torch.empty((8, 8, Cout, C0), device="cuda", dtype=dtype)
+    up_d = torch.empty((8, 8, C0, Cout), device="cuda", dtype=dtype)
+    ops.conv3d_pack_up_weights(w, C0, 0, up_f, up_d, None, None)
+    y = torch.full((N, D, H, W, Cout), float("nan"), dtype=dtype, device="cuda")
+    ops.conv3d_upcat_fwd(x_low, None, up_f, None, bias, y, act=2, alpha=0.3)
+    torch.cuda.synchronize()
+    xl = f64(x_low).requires_grad_(True)
+    kern = keras_kernel_from_packed(f64(w)).requires_grad_(True)
+    b64 = f64(bias).requires_grad_(True)
+    pre = F.conv3d(ref_concat_input(xl, None, True), kern, b64, padding=1)
+    assert_close(y, to_ndhwc(F.leaky_relu(pre, 0.3)), 1.5e-2, 1.5e-2, what="fwd")
+    dy = rnd((N, D, H, W, Cout), 14, dtype)
+    dx_low = torch.full_like(x_low, float("nan"))
+    ops.conv3d_upcat_dgrad(dy, up_d, None, None, None, dx_low, None)
+    dw, db = torch.zeros((27, Cout, C0), device="cuda"), torch.zeros(Cout, device="cuda")
+    ops.conv3d_upcat_wgrad(x_low, None, dy, dw, db, torch.empty(64 * Cout * C0, device="cuda"))
+    torch.cuda.synchronize()
+    pre.backward(to_ncdhw(f64(dy)))
+    assert_close(dx_low, xl.grad, 1.5e-2, 1.5e-2, what="dx_low")
+    assert_close(dw, kern.grad.permute(2, 3, 4, 0, 1).reshape(27, Cout, C0), 2e-3, 2e-3, what="dw")
+    assert_close(db, b64.grad, 2e-3, 2e-3, what="db")
