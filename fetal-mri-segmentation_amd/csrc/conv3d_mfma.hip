@@ -1102,7 +1102,9 @@ int conv3d_fwd_mfma_ex(int mode, const void* src0, int C0, int up0, int planar, 
         k_conv_fwd_mfma<NT_, PL_, MODE_, RES_><<<np < ncu ? np : ncu, fw::NTHREADS, 0, st>>>(                             \
             s, (const bf16_t*)w, bias, (const bf16_t*)mask, (const bf16_t*)residual, (bf16_t*)y, N, D, H, W, Cout, act, alpha); \
     } while (0)
-    const bool wide = Cout % 64 == 0;
+    // 64-wide Cout blocks halve the halo traffic per MFMA, but a launch with fewer (tile, block) pairs than CUs (the 8x16x16 bottleneck
+    // level) leaves CUs idle: 32-wide blocks double the pairs there
+    const bool wide = Cout % 64 == 0 && (int64_t)ntile * (Cout / 64) * (mode == 1 ? 8 : 1) >= ncu;
     if (mode == 1) {
         if (wide) FMRI_LAUNCH_FWD(2, false, 1, false); else FMRI_LAUNCH_FWD(1, false, 1, false);
     } else if (mode == 2) {
