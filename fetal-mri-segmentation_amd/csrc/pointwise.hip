@@ -463,8 +463,8 @@ __device__ __forceinline__ double wave_sum(double v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
     return v;
 }
-__global__ void k_sigmoid_dice_fwd(const float* __restrict__ logits, const uint8_t* __restrict__ y, float* __restrict__ probs,
-                                   double* __restrict__ sums, int64_t n) {
+__global__ void k_sigmoid_dice_fwd(const float* __restrict__ logits, const uint8_t* __restrict__ y, const float* __restrict__ wgt,
+                                   float* __restrict__ probs, double* __restrict__ sums, int64_t n) {
     double s[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         float z = logits[i];
@@ -473,7 +473,7 @@ __global__ void k_sigmoid_dice_fwd(const float* __restrict__ logits, const uint8
         float t = (float)y[i];
         {   // binary cross-entropy with Keras' clipping, and the reference focal term (metrics.py:80-87: alpha .5, gamma 2)
             const float pc = fminf(fmaxf(p, 1e-7f), 1.f - 1e-7f);
-            s[7] += (double)(t > 0.5f ? -__logf(pc) : -__logf(1.f - pc));
+            s[7] += (double)((wgt ? wgt[i] : 1.f) * (t > 0.5f ? -__logf(pc) : -__logf(1.f - pc)));   // weight_mask * xent (metrics.py:72-76)
             s[8] += (double)(t > 0.5f ? -0.5f * (1.f - p) * (1.f - p) * __logf(p) : -0.5f * p * p * __logf(1.f - p));
         }
         s[0] += (double)(t * p);
@@ -512,8 +512,9 @@ __global__ void k_sigmoid_dice_bwd(const float* __restrict__ probs, const uint8_
 }
 // general loss gradient w.r.t. the logits from the (global) sums: kind 0 dice, 1 mean binary cross-entropy, 2 dice + w*xent,
 // 3 focal (alpha .5, gamma 2), 4 vod (smoothed IoU on probabilities), 5 double dice (-dice(y,p) + r*dice(1-y,p))
-__global__ void k_sigmoid_loss_bwd(const float* __restrict__ probs, const uint8_t* __restrict__ y, const double* __restrict__ sums,
-                                   float* __restrict__ dl, int64_t n, int kind, float p0, float smooth, float grad_scale) {
+__global__ void k_sigmoid_loss_bwd(const float* __restrict__ probs, const uint8_t* __restrict__ y, const float* __restrict__ wgt,
+                                   const double* __restrict__ sums, float* __restrict__ dl, int64_t n, int kind, float p0, float smooth,
+                                   float grad_scale) {
     const double I = sums[0], Sy = sums[1], Sp = sums[2], nn = sums[7];
     const double den = Sy + Sp + smooth;
     const float a = (float)(2.0 / den), c = (float)((2.0 * I + smooth) / (den * den));
@@ -527,8 +528,8 @@ __global__ void k_sigmoid_loss_bwd(const float* __restrict__ probs, const uint8_
         const float sg = p * (1.f - p);
         float g;                                               // dL/dlogit
         if (kind == 0) g = -(a * t - c) * sg;
-        else if (kind == 1) g = (p - t) * invn;
-        else if (kind == 2) g = -(a * t - c) * sg + p0 * (p - t) * invn;
+        else if (kind == 1) g = (wgt ? wgt[i] : 1.f) * (p - t) * invn;
+        else if (kind == 2) g = -(a * t - c) * sg + p0 * (wgt ? wgt[i] : 1.f) * (p - t) * invn;
         else if (kind == 3) {
             float dp;
             if (t > 0.5f) dp = -0.5f * (-2.f * (1.f - p) * __logf(p) + (1.f - p) * (1.f - p) / p);
@@ -542,7 +543,24 @@ __global__ void k_sigmoid_loss_bwd(const float* __restrict__ probs, const uint8_
 extern "C" int fmri_sigmoid_loss_bwd(const float* probs, const uint8_t* y_true, const double* sums, float* dlogits, int64_t n, int kind,
                                      float param, float smooth, float grad_scale, fmri_stream_t stream) {
     if (n <= 0 || kind < 0 || kind > 5) return FMRI_E_SHAPE;
-    k_sigmoid_loss_bwd<<<grid_for(n, 256, 2048), 256, 0, as_stream(stream)>>>(probs, y_true, sums, dlogits, n, kind, param, smooth, grad_scale);
+    k_sigmoid_loss_bwd<<<grid_for(n, 256, 2048), 256, 0, as_stream(stream)>>>(probs, y_true, nullptr, sums, dlogits, n, kind, param, smooth, grad_scale);
+    FMRI_LAUNCH_CHECK();
+    return FMRI_OK;
+}
+// the same two passes with a per-voxel weight on the cross-entropy term (reference metrics.py:72-76 weighted_cross_entropy_loss,
+// :89-95 dice_and_xent_mask: weight = exp(-distance_mask / sigma), computed by the caller); kinds 1 and 2 use it
+extern "C" int fmri_sigmoid_dice_fwd_weighted(const float* logits, const uint8_t* y_true, const float* weight, float* probs, double* sums,
+                                              int64_t n, fmri_stream_t stream) {
+    if (n <= 0 || !weight) return FMRI_E_SHAPE;
+    k_sigmoid_dice_fwd<<<grid_for(n, 256, 1024), 256, 0, as_stream(stream)>>>(logits, y_true, weight, probs, sums, n);
+    FMRI_LAUNCH_CHECK();
+    return FMRI_OK;
+}
+extern "C" int fmri_sigmoid_loss_bwd_weighted(const float* probs, const uint8_t* y_true, const float* weight, const double* sums,
+                                              float* dlogits, int64_t n, int kind, float param, float smooth, float grad_scale,
+                                              fmri_stream_t stream) {
+    if (n <= 0 || !weight || (kind != 1 && kind != 2)) return FMRI_E_SHAPE;
+    k_sigmoid_loss_bwd<<<grid_for(n, 256, 2048), 256, 0, as_stream(stream)>>>(probs, y_true, weight, sums, dlogits, n, kind, param, smooth, grad_scale);
     FMRI_LAUNCH_CHECK();
     return FMRI_OK;
 }
@@ -550,7 +568,7 @@ extern "C" int fmri_sigmoid_loss_bwd(const float* probs, const uint8_t* y_true, 
 extern "C" int fmri_sigmoid_dice_fwd(const float* logits, const uint8_t* y_true, float* probs, double* sums, int64_t n,
                                      fmri_stream_t stream) {
     if (n <= 0) return FMRI_E_SHAPE;
-    k_sigmoid_dice_fwd<<<grid_for(n, 256, 1024), 256, 0, as_stream(stream)>>>(logits, y_true, probs, sums, n);
+    k_sigmoid_dice_fwd<<<grid_for(n, 256, 1024), 256, 0, as_stream(stream)>>>(logits, y_true, nullptr, probs, sums, n);
     FMRI_LAUNCH_CHECK();
     return FMRI_OK;
 }

@@ -282,6 +282,7 @@ class Model(object):
         self.stop_training = False
         self._engine = None
         self._unsupported = None               # reason string when the engine cannot run this topology yet
+        self._mask_shape = None                # shape of the second (distance-mask) input of a mask-weighted loss, when there is one
         self._pending_weights = None
         self.history = None
 
@@ -402,6 +403,8 @@ class Model(object):
         """(kind, param) of fmri_sigmoid_loss_bwd for the compiled loss token"""
         table = {M.dice_coefficient_loss: (0, 1.0), M.binary_crossentropy_loss: (1, 1.0), M.dice_and_xent: (2, 1.0), M.focal_loss: (3, 1.0),
                  M.vod_coefficient_loss: (4, 1.0), M.double_dice_loss: (5, 10.0)}
+        if getattr(self.loss, "mask_weighted", False):       # dice_and_xent_mask(mask_input): Dice + w * mean(exp(-mask/sigma) * xent)
+            return (2, self.loss.xent_weight)
         if self.loss not in table:
             raise NotImplementedError("loss %r is not differentiated on the device (available: %s)" % (
                 getattr(self.loss, "__name__", self.loss), ", ".join(sorted(f.__name__ for f in table))))
@@ -420,23 +423,36 @@ class Model(object):
             out[name] = m[key]
         return out
 
+    def _loss_weight(self, x):
+        """per-voxel cross-entropy weight exp(-mask / sigma) from the model's second input (reference metrics.py:89-95), or None"""
+        if not getattr(self.loss, "mask_weighted", False):
+            return None
+        import torch
+        if not isinstance(x, (list, tuple)) or len(x) < 2:
+            raise ValueError("this model was built with mask_shape: feed [x, masks] (reference generator.py:397-401)")
+        m = x[1]
+        t = m if _is_device_tensor(m) else torch.from_numpy(np.ascontiguousarray(np.asarray(m), dtype=np.float32)).cuda(non_blocking=True)
+        return torch.exp(-t.float() / self.loss.dist_sigma).reshape(-1).contiguous()
+
     def train_on_batch(self, x, y, **kw):
         self._check_loss()
+        weight = self._loss_weight(x)
         if isinstance(x, (list, tuple)):
             x = x[0]
         n = _batch_len(x)
         eng = self.engine(n)
-        sums = eng.train_step(self._to_device_x(x), self._to_device_y(y), self.optimizer.lr)
+        sums = eng.train_step(self._to_device_x(x), self._to_device_y(y), self.optimizer.lr, weight=weight)
         logs = self._batch_logs(sums.cpu().numpy())
         return [logs[k] for k in self.metrics_names]
 
     def test_on_batch(self, x, y, **kw):
+        weight = self._loss_weight(x)
         if isinstance(x, (list, tuple)):
             x = x[0]
         n = _batch_len(x)
         eng = self.engine(n)
         eng.forward(self._to_device_x(x), bn_training=False)        # Keras evaluates with learning_phase = 0
-        sums = eng.loss_forward(self._to_device_y(y))
+        sums = eng.loss_forward(self._to_device_y(y), weight)
         logs = self._batch_logs(sums.cpu().numpy())
         return [logs[k] for k in self.metrics_names]
 

@@ -88,10 +88,19 @@ def _focal_loss(gamma=2., alpha=.5):
     return focal_loss_fixed
 
 
+class MaskInput(object):
+    """placeholder for the model's second input (the distance mask) that `dice_and_xent_mask` closes over in the reference
+    (isensee2017.py:85-88: loss_function = loss_function(mask_input))"""
+
+
 def dice_and_xent_mask(weight_mask, xent_weight=1.0, dist_sigma=3):
     def _loss(y_true, y_pred):
         return dice_and_xent(y_true, y_pred, xent_weight=xent_weight, weight_mask=np.exp(-_f(weight_mask) / dist_sigma))
 
+    # what the device path needs to know: Dice + xent_weight * mean(exp(-mask / dist_sigma) * cross-entropy), mask = 2nd model input
+    _loss.mask_weighted = isinstance(weight_mask, MaskInput)
+    _loss.xent_weight, _loss.dist_sigma = float(xent_weight), float(dist_sigma)
+    _loss.__name__ = "dice_and_xent_mask"
     return _loss
 
 

@@ -56,11 +56,18 @@ def isensee2017_model_3d(input_shape=(1, 128, 128, 128), n_base_filters=16, dept
                           loss_function=loss_function, activation_name=activation_name)
     if "compute_dtype" in kargs:
         builder_kwargs["compute_dtype"] = kargs["compute_dtype"]
+    if mask_shape is not None:
+        builder_kwargs["mask_shape"] = tuple(int(v) for v in mask_shape)
     model = Model(g.layers, None, "isensee2017_model_3d", builder_kwargs, "channels_first_3d", name="isensee2017_3d_Model")
     model._graph_engine = True
     unsupported = []
     if mask_shape is not None:
-        unsupported.append("mask_shape (mask-weighted loss input)")
+        # reference isensee2017.py:85-88: a second input carries the distance mask and the loss factory closes over it
+        from ...metrics import MaskInput
+        loss_function = loss_function(MaskInput())
+        model._mask_shape = tuple(int(v) for v in mask_shape)
+        if not getattr(loss_function, "mask_weighted", False):
+            unsupported.append("mask_shape with a loss factory other than dice_and_xent_mask")
     if activation_name != "sigmoid":
         unsupported.append("activation_name != 'sigmoid'")
     if unsupported:

@@ -444,10 +444,10 @@ class UNetEngine:
         ops.conv1x1_fwd(h, self.w_view(f["name"]), self.b_view(f["name"]), self.logits)
         return self.logits
 
-    def loss_forward(self, y_true):
+    def loss_forward(self, y_true, weight=None):
         """y_true uint8 [nvox*L] device.  probs + the 8 metric sums (accumulated into zeroed self.sums)."""
         self.sums.zero_()
-        ops.sigmoid_dice_fwd(self.logits, y_true, self.probs, self.sums)
+        ops.sigmoid_dice_fwd(self.logits, y_true, self.probs, self.sums, weight=weight)
         if self.dist is not None and self.dist.world > 1 and self.dist.global_dice:
             self.dist.all_reduce_sums(self.sums)
         return self.sums
@@ -484,11 +484,12 @@ class UNetEngine:
             return None
         return self.act.get(name)
 
-    def backward(self, y_true, grad_scale=1.0):
+    def backward(self, y_true, grad_scale=1.0, weight=None):
         p, A, Gd = self.plan, self.act, self.grad
         normed = p.norm is not None
         self.G.zero_()
-        ops.sigmoid_loss_bwd(self.probs, y_true, self.sums, self.dlogits, self.loss_kind, self.loss_param, smooth=1.0, grad_scale=grad_scale)
+        ops.sigmoid_loss_bwd(self.probs, y_true, self.sums, self.dlogits, self.loss_kind, self.loss_param, smooth=1.0, grad_scale=grad_scale,
+                             weight=weight)
         f = p.final
         last = p.dec[-1][1] if p.dec else p.enc[-1][1]
         ops.conv1x1_bwd(A[last["name"]], self.w_view(f["name"]), self.dlogits, Gd[last["name"]], self.w_view(f["name"], self.G),
@@ -556,11 +557,11 @@ class UNetEngine:
         ops.adam_step(self.P, self.G, self.M, self.V, lr_t, beta1, beta2, eps, grad_scale)
         self.refresh_weight_copies()
 
-    def train_step(self, x, y_true, lr):
+    def train_step(self, x, y_true, lr, weight=None):
         """one full step: forward, Dice, backward, (all-reduce), Adam.  Returns the device tensor of metric sums."""
         self.forward(x)
-        self.loss_forward(y_true)
-        self.backward(y_true)
+        self.loss_forward(y_true, weight)
+        self.backward(y_true, weight=weight)
         self.adam_step(lr)
         return self.sums
 

@@ -418,9 +418,9 @@ class LayerGraphEngine(object):
         """testing hook: fix the SpatialDropout3D masks ({layer name: [N,C] fp32 tensor}) instead of drawing them"""
         self._fixed_drop = masks
 
-    def loss_forward(self, y_true):
+    def loss_forward(self, y_true, weight=None):
         self.sums.zero_()
-        ops.sigmoid_dice_fwd(self.logits, y_true, self.probs, self.sums)
+        ops.sigmoid_dice_fwd(self.logits, y_true, self.probs, self.sums, weight=weight)
         if self.dist is not None and self.dist.world > 1 and self.dist.global_dice:
             self.dist.all_reduce_sums(self.sums)
         return self.sums
@@ -445,12 +445,13 @@ class LayerGraphEngine(object):
             write(self.tmp[name])
             ops.add(self.Gt[name], self.tmp[name], self.Gt[name])
 
-    def backward(self, y_true, grad_scale=1.0):
+    def backward(self, y_true, grad_scale=1.0, weight=None):
         self.G.zero_()
         self._has_grad = set()
         if self.dist is not None:
             self.dist.begin()
-        ops.sigmoid_loss_bwd(self.probs, y_true, self.sums, self.dlogits, self.loss_kind, self.loss_param, smooth=1.0, grad_scale=grad_scale)
+        ops.sigmoid_loss_bwd(self.probs, y_true, self.sums, self.dlogits, self.loss_kind, self.loss_param, smooth=1.0, grad_scale=grad_scale,
+                             weight=weight)
         gsrc = self.Gt[self.logits_src]
         if gsrc.shape[-1] != self.plan.n_labels:
             gsrc.zero_()
@@ -563,10 +564,10 @@ class LayerGraphEngine(object):
         ops.adam_step(self.P, self.G, self.M, self.V, lr_t, beta1, beta2, eps, grad_scale)
         self.refresh_weight_copies()
 
-    def train_step(self, x, y_true, lr):
+    def train_step(self, x, y_true, lr, weight=None):
         self.forward(x)
-        self.loss_forward(y_true)
-        self.backward(y_true)
+        self.loss_forward(y_true, weight)
+        self.backward(y_true, weight=weight)
         self.adam_step(lr)
         return self.sums
 

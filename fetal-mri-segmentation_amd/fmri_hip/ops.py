@@ -86,9 +86,15 @@ def conv1x1_bwd(x, w, dlogits, dx, dw, db, relu_mask=True):
           "fmri_conv1x1_bwd")
 
 
-def sigmoid_dice_fwd(logits, y_true, probs, sums):
-    _need_cuda(logits, y_true, probs, sums)
+def sigmoid_dice_fwd(logits, y_true, probs, sums, weight=None):
+    """weight (optional, fp32, one per voxel): multiplies the cross-entropy term (dice_and_xent_mask)"""
+    _need_cuda(logits, y_true, probs, sums, weight)
     assert y_true.dtype == torch.uint8 and sums.dtype == torch.float64 and sums.numel() >= 16
+    if weight is not None:
+        assert weight.dtype == torch.float32 and weight.numel() == logits.numel()
+        check(lib().fmri_sigmoid_dice_fwd_weighted(_p(logits), _p(y_true), _p(weight), _p(probs), _p(sums), logits.numel(), _s()),
+              "fmri_sigmoid_dice_fwd_weighted")
+        return
     check(lib().fmri_sigmoid_dice_fwd(_p(logits), _p(y_true), _p(probs), _p(sums), logits.numel(), _s()), "fmri_sigmoid_dice_fwd")
 
 
@@ -253,8 +259,12 @@ LOSS_KINDS = {"dice_coefficient_loss": 0, "binary_crossentropy_loss": 1, "dice_a
               "double_dice_loss": 5}
 
 
-def sigmoid_loss_bwd(probs, y_true, sums, dlogits, kind, param=1.0, smooth=1.0, grad_scale=1.0):
-    _need_cuda(probs, y_true, sums, dlogits)
+def sigmoid_loss_bwd(probs, y_true, sums, dlogits, kind, param=1.0, smooth=1.0, grad_scale=1.0, weight=None):
+    _need_cuda(probs, y_true, sums, dlogits, weight)
+    if weight is not None:
+        check(lib().fmri_sigmoid_loss_bwd_weighted(_p(probs), _p(y_true), _p(weight), _p(sums), _p(dlogits), probs.numel(), int(kind), float(param),
+                                                   float(smooth), float(grad_scale), _s()), "fmri_sigmoid_loss_bwd_weighted")
+        return
     check(lib().fmri_sigmoid_loss_bwd(_p(probs), _p(y_true), _p(sums), _p(dlogits), probs.numel(), int(kind), float(param), float(smooth),
                                       float(grad_scale), _s()), "fmri_sigmoid_loss_bwd")
 

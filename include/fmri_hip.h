@@ -125,6 +125,12 @@ int fmri_sigmoid_dice_bwd(const float* probs, const uint8_t* y_true, const doubl
  * 4 vod_coefficient_loss, 5 double_dice_loss (param = ratio). */
 int fmri_sigmoid_loss_bwd(const float* probs, const uint8_t* y_true, const double* sums, float* dlogits, int64_t n, int kind,
                           float param, float smooth, float grad_scale, fmri_stream_t stream);
+/* the same with a per-voxel weight (device, n floats) on the cross-entropy term: sums[8] = sum(weight * xent); gradient kinds 1 and 2.
+ * reference metrics.py:72-76 weighted_cross_entropy_loss and :89-95 dice_and_xent_mask (weight = exp(-distance_mask / sigma)) */
+int fmri_sigmoid_dice_fwd_weighted(const float* logits, const uint8_t* y_true, const float* weight, float* probs, double* sums, int64_t n,
+                                   fmri_stream_t stream);
+int fmri_sigmoid_loss_bwd_weighted(const float* probs, const uint8_t* y_true, const float* weight, const double* sums, float* dlogits,
+                                   int64_t n, int kind, float param, float smooth, float grad_scale, fmri_stream_t stream);
 
 /* ---- MaxPooling3D(2,2,2) — reference unet.py:51.  D,H,W are the INPUT dims (even). */
 int fmri_maxpool3d_2x_fwd(const void* x, void* y, int N, int D, int H, int W, int C, int dtype, int planar,

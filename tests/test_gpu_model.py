@@ -194,3 +194,37 @@ def test_isensee_model_surface(tmp_path, monkeypatch):
     m2 = load_old_model(path)
     assert [l.name for l in m2.layers] == [l.name for l in model.layers]
     np.testing.assert_allclose(m2.predict(x0), p, atol=1e-6)          # inference is deterministic (dropout off)
+
+
+def test_isensee_mask_weighted_loss(tmp_path):
+    """isensee2017_model_3d(mask_shape=..., loss_function=dice_and_xent_mask) takes [x, masks] batches (reference isensee2017.py:85-88,
+    generator.py:397-401); its loss is Dice + mean(exp(-mask/3) * BCE) and differs from the unweighted dice_and_xent on the same
+    weights; save / load_old_model keep the second input."""
+    import fetal_net.model as fmodel
+    from fetal_net import metrics as M
+    from fetal_net.training import load_old_model
+    shape = (1, 16, 16, 16)
+    kw = dict(input_shape=shape, depth=3, n_base_filters=4, n_segmentation_levels=2, dropout_rate=0.0, compute_dtype="fp32")
+    m1 = fmodel.isensee2017_model_3d(loss_function=M.dice_and_xent_mask, mask_shape=shape, **kw)
+    m2 = fmodel.isensee2017_model_3d(loss_function=M.dice_and_xent, **kw)
+    m2.set_weights_dict(m1.get_weights_dict())
+    rs = np.random.RandomState(0)
+    x = rs.randn(2, *shape)
+    y = (rs.rand(2, *shape) > 0.6).astype(np.uint8)
+    masks = rs.rand(2, *shape) * 12
+    with pytest.raises(ValueError):
+        m1.test_on_batch(x, y)
+    l1 = m1.test_on_batch([x, masks], y)[0]
+    l0 = m1.test_on_batch([x, np.zeros_like(masks)], y)[0]          # zero distance = weight 1 = plain dice_and_xent
+    l2 = m2.test_on_batch(x, y)[0]
+    assert abs(l0 - l2) <= 1e-5 and l1 < l2 - 1e-3
+    # reference value from the host-side metric on the model's own probabilities
+    p = m1.predict(x)
+    want = M.dice_and_xent(y.astype(np.float64), p.astype(np.float64), weight_mask=np.exp(-masks / 3.0))
+    assert abs(l1 - want) <= 1e-4
+    losses = [m1.train_on_batch([x, masks], y)[0] for _ in range(15)]
+    assert min(losses[-4:]) < losses[0]
+    path = str(tmp_path / "m-epoch01-loss0.100-acc0.900.h5")
+    m1.save(path)
+    m3 = load_old_model(path)
+    assert getattr(m3.loss, "mask_weighted", False) and abs(m3.test_on_batch([x, masks], y)[0] - m1.test_on_batch([x, masks], y)[0]) <= 1e-5

@@ -600,3 +600,31 @@ def test_upcat_without_skip_channels(ops):
     assert_close(dx_low, xl.grad, 1.5e-2, 1.5e-2, what="dx_low")
     assert_close(dw, kern.grad.permute(2, 3, 4, 0, 1).reshape(27, Cout, C0), 2e-3, 2e-3, what="dw")
     assert_close(db, b64.grad, 2e-3, 2e-3, what="db")
+
+
+def test_weighted_cross_entropy_loss_value_and_gradient(ops):
+    """fmri_sigmoid_dice_fwd_weighted / _loss_bwd_weighted = Dice + w * mean(exp(-mask/sigma) * BCE) (reference metrics.py:66-76,89-95)
+    against the metrics oracle's dice_and_xent with a weight mask, value and finite-difference-free analytic gradient (torch fp64)."""
+    from oracle import metrics_oracle as MO
+    rs = np.random.RandomState(3)
+    n = 4096
+    logits = torch.tensor(rs.randn(n) * 2, dtype=torch.float32, device="cuda")
+    y = torch.tensor((rs.rand(n) > 0.6).astype(np.uint8), device="cuda")
+    mask = torch.tensor(rs.rand(n) * 9, dtype=torch.float32, device="cuda")
+    weight = torch.exp(-mask / 3.0)
+    probs, sums, dl = torch.empty_like(logits), torch.zeros(16, dtype=torch.float64, device="cuda"), torch.empty_like(logits)
+    ops.sigmoid_dice_fwd(logits, y, probs, sums, weight=weight)
+    ops.sigmoid_loss_bwd(probs, y, sums, dl, 2, param=0.7, weight=weight)
+    torch.cuda.synchronize()
+    got = ops.loss_value_from_sums(sums.cpu().numpy(), 2, 0.7)
+    z = logits.cpu().double().requires_grad_(True)
+    p = torch.sigmoid(z)
+    t = y.cpu().double()
+    w64 = weight.cpu().double()
+    dice = (2 * (t * p).sum() + 1) / (t.sum() + p.sum() + 1)
+    pc = p.clamp(1e-7, 1 - 1e-7)
+    loss = -dice + 0.7 * (w64 * -(t * torch.log(pc) + (1 - t) * torch.log(1 - pc))).mean()
+    loss.backward()
+    want = MO.dice_and_xent(t.numpy(), p.detach().numpy(), xent_weight=0.7, weight_mask=w64.numpy()) if hasattr(MO, "dice_and_xent") else float(loss)
+    assert abs(got - float(loss)) <= 1e-5 and abs(got - float(want)) <= 1e-5
+    assert_close(dl, z.grad, 1e-4, 1e-5, what="weighted dice+xent gradient")
