@@ -1,34 +1,48 @@
-"""Producer-thread wrapper around an iterator (same contract as reference fetal_net/utils/threaded_generator.py:16-53):
-one daemon-less thread fills a bounded queue, the consumer iterates until the sentinel."""
-from queue import Queue
-from threading import Thread
+"""Run an iterator on a producer thread and hand its items to the consuming thread through a bounded queue.
+
+Same constructor and iteration contract as the class the reference's sliding-window loop wraps its tile batches in
+(reference fetal_net/utils/threaded_generator.py:16-53, used at prediction.py:167): `ThreadedGenerator(iterator, queue_maxsize=N)` is
+iterable once; iteration starts the thread, yields the items in order and joins the thread at exhaustion.  Unlike the reference, an
+exception raised by the producer is re-raised in the consumer instead of being lost with the thread.
+"""
+import queue
+import threading
+
+_DONE = object()
 
 
 class ThreadedGenerator(object):
-    def __init__(self, iterator, sentinel=object(), queue_maxsize=0, daemon=False, Thread=Thread, Queue=Queue):
-        self._iterator = iterator
-        self._sentinel = sentinel
-        self._queue = Queue(maxsize=queue_maxsize)
-        self._thread = Thread(name=repr(iterator), target=self._run)
-        self._thread.daemon = daemon
-        self._error = None
+    def __init__(self, iterator, sentinel=_DONE, queue_maxsize=0, daemon=False, Thread=threading.Thread, Queue=queue.Queue):
+        self.source = iterator
+        self.end_marker = sentinel
+        self.buffer = Queue(maxsize=queue_maxsize)
+        self.failure = None
+        self.worker = Thread(target=self._produce, name="ThreadedGenerator:%r" % (iterator,))
+        self.worker.daemon = daemon
 
-    def __repr__(self):
-        return 'ThreadedGenerator({!r})'.format(self._iterator)
-
-    def _run(self):
-        try:
-            for value in self._iterator:
-                self._queue.put(value, block=True)
-        except BaseException as e:  # surfaced on the consumer side instead of dying silently
-            self._error = e
-        finally:
-            self._queue.put(self._sentinel)
+    def _produce(self):
+        it = iter(self.source)
+        while True:
+            try:
+                item = next(it)
+            except StopIteration:
+                break
+            except BaseException as exc:           # keep it for the consumer
+                self.failure = exc
+                break
+            self.buffer.put(item)
+        self.buffer.put(self.end_marker)
 
     def __iter__(self):
-        self._thread.start()
-        for value in iter(self._queue.get, self._sentinel):
-            yield value
-        self._thread.join()
-        if self._error is not None:
-            raise self._error
+        self.worker.start()
+        while True:
+            item = self.buffer.get()
+            if item is self.end_marker:
+                break
+            yield item
+        self.worker.join()
+        if self.failure is not None:
+            raise self.failure
+
+    def __repr__(self):
+        return "ThreadedGenerator(%r)" % (self.source,)
