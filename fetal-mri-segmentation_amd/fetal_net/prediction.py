@@ -57,9 +57,14 @@ def _geometry(model, data, patch_shape, overlap_factor):
     max_overlap = np.subtract(patch_shape, (1, 1, 1))
     overlap = min_overlap + (overlap_factor * (max_overlap - min_overlap)).astype(int)
     pad0 = _half_pads(np.subtract(patch_shape, prediction_shape))
-    data_0 = np.pad(data[0], pad0, mode='constant', constant_values=np.percentile(data[0], q=1))
+    # the reference pads with the 1st percentile unconditionally (prediction.py:138-146); with zero pad widths np.pad returns the data
+    # unchanged, so the percentile (a sort-sized pass over the whole volume, twice) is only computed when something is padded
+    data_0 = data[0]
+    if np.sum(pad0) > 0:
+        data_0 = np.pad(data_0, pad0, mode='constant', constant_values=np.percentile(data_0, q=1))
     pad_for_fit = _half_pads(np.maximum(np.subtract(patch_shape, data_0.shape), 0))
-    data_0 = np.pad(data_0, pad_for_fit, 'constant', constant_values=np.percentile(data_0, q=1))
+    if np.sum(pad_for_fit) > 0:
+        data_0 = np.pad(data_0, pad_for_fit, 'constant', constant_values=np.percentile(data_0, q=1))
     indices = get_set_of_patch_indices_full((0, 0, 0), np.subtract(data_0.shape, patch_shape), np.subtract(patch_shape, overlap))
     data_shape = list(np.asarray(data.shape[-3:]) + np.sum(pad_for_fit, -1))
     data_shape += [out_shape[1]] if is3d else [out_shape[-1]]
