@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""End-to-end training throughput THROUGH the reference API (`train_model` -> `fit_generator`) at BASELINE config 2, fed (a) by a host
+generator that yields float64 numpy batches like the reference's (one ready batch re-yielded: isolates the boundary cost: conversion,
+PCIe upload, per-batch metric read-back) and (b) by the device generator.  bench.py's headline has the batch resident in HBM."""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "fetal-mri-segmentation_amd"))
+import numpy as np
+import torch
+
+
+def main():
+    from bench_sampler import AUG, Vols
+    from fetal_net.device_generator import DeviceDataFile, device_data_generator
+    from fetal_net.metrics import dice_coefficient_loss
+    from fetal_net.model import unet_model_3d
+    patch, B, steps = (64, 128, 128), 4, 30
+    model = unet_model_3d(input_shape=(1,) + patch, depth=4, n_base_filters=32, initial_learning_rate=1e-4, loss_function=dice_coefficient_loss)
+    rs = np.random.RandomState(0)
+    xb = rs.randn(B, 1, *patch)                                     # float64, as the reference's generator yields
+    yb = (rs.rand(B, 1, *patch) > 0.7).astype(np.uint8)
+
+    def host_gen():
+        while True:
+            yield xb, yb
+
+    ddf = DeviceDataFile(Vols(6, (96, 192, 192)), patch)
+    dev_gen = device_data_generator(ddf, list(range(6)), batch_size=B, patch_shape=patch, augment=AUG, truth_index=0, truth_size=patch[2], is3d=True,
+                                    categorical=False, skip_blank=False)
+    out = {}
+    for name, g in (("host_float64_generator", host_gen()), ("device_generator", dev_gen)):
+        model.fit_generator(g, steps_per_epoch=5, epochs=1, verbose=0)          # warm-up
+        torch.cuda.synchronize()
+        t0 = time.time()
+        model.fit_generator(g, steps_per_epoch=steps, epochs=1, verbose=0)
+        torch.cuda.synchronize()
+        out[name + "_patches_per_s"] = steps * B / (time.time() - t0)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    main()
