@@ -235,6 +235,9 @@ k_conv_fwd_mfma(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__
             }
         }
 #endif
+        // planar (2-D slices): only the centre kd taps exist, so halo planes 0 and 5 (rows 0-179 and 900-1079) are never read: the
+        // DMA instructions that lie entirely inside them (16 rows each) are not issued
+        if (PL && (ph * 8 + wv < 11 || ph * 8 + wv >= 57)) return;
         if (ph * 8 + wv < H_INSTR) dma16(hp[ph], __builtin_amdgcn_readfirstlane(lds0 + hb * HALO_BYTES + (ph * 8 + wv) * 1024));
     };
 
