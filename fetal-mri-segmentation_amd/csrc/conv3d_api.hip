@@ -17,9 +17,9 @@ int conv3d_upcat_wgrad_mfma(const void*, int, const void*, int, const void*, flo
 int conv3d_fwd_mfma_ex(int, const void*, int, int, int, const void*, int, const void*, const float*, const void*, const void*, void*, int, int, int,
                        int, int, int, float, hipStream_t);
 
-bool conv3d_first_ok(int C0, int C1, int Cout, int D, int H, int W, int dtype, int up0);
-int conv3d_first_fwd(const void*, const void*, const float*, void*, int, int, int, int, int, int, float, hipStream_t);
-int conv3d_first_wgrad(const void*, const void*, float*, float*, int, int, int, int, int, hipStream_t);
+bool conv3d_first_ok(int C0, int C1, int Cout, int D, int H, int W, int dtype, int up0, int planar);
+int conv3d_first_fwd(const void*, int, int, const void*, const float*, void*, int, int, int, int, int, int, float, hipStream_t);
+int conv3d_first_wgrad(const void*, int, int, const void*, float*, float*, int, int, int, int, int, hipStream_t);
 
 static int check_common(const void* src0, int C0, int up0, int planar, const void* src1, int C1, int N, int D, int H, int W, int Cout) {
     if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || Cout <= 0 || C0 <= 0 || C1 < 0) return FMRI_E_SHAPE;
@@ -31,7 +31,7 @@ static int check_common(const void* src0, int C0, int up0, int planar, const voi
 extern "C" int fmri_conv3d_uses_mfma(int C0, int C1, int Cout, int D, int H, int W, int dtype) {
     // bit 0: forward/dgrad MFMA kernel, bit 1: wgrad MFMA kernel, bit 2: single-channel first-layer MFMA kernels
     return (conv3d_fwd_mfma_ok(C0, C1, Cout, D, H, W, dtype) ? 1 : 0) | (conv3d_wgrad_mfma_ok(C0, C1, Cout, D, H, W, dtype) ? 2 : 0) |
-           (conv3d_first_ok(C0, C1, Cout, D, H, W, dtype, 0) ? 4 : 0);
+           (conv3d_first_ok(C0, C1, Cout, D, H, W, dtype, 0, 0) ? 4 : 0);
 }
 
 extern "C" int fmri_conv3d_fwd(const void* src0, int C0, int up0, const void* src1, int C1, const void* w, const float* bias,
@@ -40,8 +40,8 @@ extern "C" int fmri_conv3d_fwd(const void* src0, int C0, int up0, const void* sr
     int rc = check_common(src0, C0, up0, planar, src1, C1, N, D, H, W, Cout);
     if (rc) return rc;
     if (dtype != FMRI_F32 && dtype != FMRI_BF16) return FMRI_E_DTYPE;
-    if (impl != FMRI_IMPL_GENERIC && !mask && !planar && conv3d_first_ok(C0, C1, Cout, D, H, W, dtype, up0))
-        return conv3d_first_fwd(src0, w, bias, y, N, D, H, W, Cout, act, alpha, as_stream(stream));
+    if (impl != FMRI_IMPL_GENERIC && !mask && conv3d_first_ok(C0, C1, Cout, D, H, W, dtype, up0, planar))
+        return conv3d_first_fwd(src0, C0, planar, w, bias, y, N, D, H, W, Cout, act, alpha, as_stream(stream));
     const bool can = conv3d_fwd_mfma_ok(C0, C1, Cout, D, H, W, dtype);
     if (impl == FMRI_IMPL_MFMA && !can) return FMRI_E_SHAPE;
     if (can && impl != FMRI_IMPL_GENERIC) {
@@ -65,8 +65,8 @@ extern "C" int fmri_conv3d_wgrad(const void* src0, int C0, int up0, const void* 
     if (rc) return rc;
     if (dtype != FMRI_F32 && dtype != FMRI_BF16) return FMRI_E_DTYPE;
     if (!dy || !dw) return FMRI_E_SHAPE;
-    if (impl != FMRI_IMPL_GENERIC && !planar && conv3d_first_ok(C0, C1, Cout, D, H, W, dtype, up0))
-        return conv3d_first_wgrad(src0, dy, dw, db, N, D, H, W, Cout, as_stream(stream));
+    if (impl != FMRI_IMPL_GENERIC && conv3d_first_ok(C0, C1, Cout, D, H, W, dtype, up0, planar))
+        return conv3d_first_wgrad(src0, C0, planar, dy, dw, db, N, D, H, W, Cout, as_stream(stream));
     const bool can = conv3d_wgrad_mfma_ok(C0, C1, Cout, D, H, W, dtype);
     if (impl == FMRI_IMPL_MFMA && !can) return FMRI_E_SHAPE;
     if (can && impl != FMRI_IMPL_GENERIC) {
@@ -78,7 +78,7 @@ extern "C" int fmri_conv3d_wgrad(const void* src0, int C0, int up0, const void* 
 
 extern "C" int64_t fmri_conv3d_wgrad_workspace_bytes(int C0, int C1, int Cout, int N, int D, int H, int W, int dtype, int planar) {
     if (!conv3d_wgrad_mfma_ok(C0, C1, Cout, D, H, W, dtype)) return 0;
-    if (!planar && conv3d_first_ok(C0, C1, Cout, D, H, W, dtype, 0)) return 0;
+    if (conv3d_first_ok(C0, C1, Cout, D, H, W, dtype, 0, planar)) return 0;
     return conv3d_wgrad_mfma_ws_bytes(C0, C1, Cout, N, D, H, W, planar);
 }
 

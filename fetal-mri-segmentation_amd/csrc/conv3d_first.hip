@@ -21,21 +21,32 @@ typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 // ---------------------------------------------------------------------------------------------------------- forward
 namespace ff {
 constexpr int TD = 4, TH = 16, TW = 32;                 // 2048 voxels per workgroup = 64 column tiles of 32 (one w-row each)
-constexpr int HD = TD + 2, HH = TH + 2, HW = TW + 2;    // 6 x 18 x 34 halo of bf16 scalars (7.3 KB)
+constexpr int HH = TH + 2, HW = TW + 2;                 // (6 x) 18 x 34 halo of bf16 scalars per input channel
 constexpr int NTHREADS = 256;
 }  // namespace ff
 
-__device__ __forceinline__ int tap_off(int tap, int HHs, int HWs) {
-    tap = tap > 26 ? 26 : tap;                            // taps 27..31 are zero-weighted padding: any in-tile address will do
-    const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
-    return (kd * HHs + kh) * HWs + kw;
+// The contraction index k enumerates (tap, input channel): k = tap * CIN + c, tap = kd*9 + kh*3 + kw (planar: kh*3 + kw, centre kd only).
+// Element offset of k inside a [hd][hh][hw][CIN] halo tile; k beyond the last real one is zero-weighted padding (any in-tile address).
+template <int CIN, bool PLANAR> __device__ __forceinline__ int k_off(int k, int HHs, int HWs) {
+    constexpr int K = (PLANAR ? 9 : 27) * CIN;
+    k = k >= K ? K - 1 : k;
+    const int tap = k / CIN, c = k % CIN;
+    const int kd = PLANAR ? 0 : tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+    return ((kd * HHs + kh) * HWs + kw) * CIN + c;
+}
+// index of (k, co) in the packed filter [27][Cout][CIN]
+template <int CIN, bool PLANAR> __device__ __forceinline__ int64_t k_widx(int k, int co, int Cout) {
+    const int tap = k / CIN, c = k % CIN;
+    return ((int64_t)((PLANAR ? 9 : 0) + tap) * Cout + co) * CIN + c;
 }
 
+template <int CIN, bool PLANAR>
 __global__ void __launch_bounds__(ff::NTHREADS)
-k_conv_first_fwd(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wt /*[27][Cout][1]*/, const float* __restrict__ bias,
+k_conv_first_fwd(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wt /*[27][Cout][CIN]*/, const float* __restrict__ bias,
                  bf16_t* __restrict__ y, int N, int D, int H, int W, int Cout, int act, float alpha) {
     using namespace ff;
-    __shared__ __attribute__((aligned(16))) bf16_t sx[HD * HH * HW];
+    constexpr int K = (PLANAR ? 9 : 27) * CIN, KS = (K + 15) / 16, HD = PLANAR ? TD : TD + 2, DOFF = PLANAR ? 0 : 1;
+    __shared__ __attribute__((aligned(16))) bf16_t sx[HD * HH * HW * CIN];
     int tile = blockIdx.x;
     const int twn = W / TW, thn = H / TH, tdn = D / TD;
     const int w0 = (tile % twn) * TW; tile /= twn;
@@ -44,32 +55,33 @@ k_conv_first_fwd(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wt /*[
     const int n = tile / tdn;
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6, r = lane & 31, hk = lane >> 5;
 
-    for (int i = t; i < HD * HH * HW; i += NTHREADS) {
-        const int hw_ = i % HW, q = i / HW, hh_ = q % HH, hd_ = q / HH;
-        const int gd = d0 - 1 + hd_, gh = h0 - 1 + hh_, gw = w0 - 1 + hw_;
+    for (int i = t; i < HD * HH * HW * CIN; i += NTHREADS) {
+        const int c = i % CIN, iv = i / CIN;
+        const int hw_ = iv % HW, q = iv / HW, hh_ = q % HH, hd_ = q / HH;
+        const int gd = d0 - DOFF + hd_, gh = h0 - 1 + hh_, gw = w0 - 1 + hw_;
         bf16_t v = 0;
         if ((unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W)
-            v = x[(((int64_t)n * D + gd) * H + gh) * W + gw];
+            v = x[((((int64_t)n * D + gd) * H + gh) * W + gw) * CIN + c];
         sx[i] = v;
     }
-    // per-lane tap offsets for the two k-steps (k = 16*ks + 8*hk + j)
-    int toff[2][8];
+    // per-lane element offsets for the k-steps (k = 16*ks + 8*hk + j)
+    int toff[KS][8];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
+    for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) toff[ks][j] = tap_off(16 * ks + 8 * hk + j, HH, HW);
+        for (int j = 0; j < 8; ++j) toff[ks][j] = k_off<CIN, PLANAR>(16 * ks + 8 * hk + j, HH, HW);
     __syncthreads();
 
     for (int cot = 0; cot < Cout / 32; ++cot) {
-        // A = W^T[co = r][tap], zero for tap >= 27
-        bf16x8_t a[2];
+        // A = W^T[co = r][k], zero for k >= K
+        bf16x8_t a[KS];
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+        for (int ks = 0; ks < KS; ++ks) {
             u16x8 u;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const int tap = 16 * ks + 8 * hk + j;
-                u[j] = tap < 27 ? wt[tap * Cout + cot * 32 + r] : (bf16_t)0;
+                const int k = 16 * ks + 8 * hk + j;
+                u[j] = k < K ? wt[k_widx<CIN, PLANAR>(k, cot * 32 + r, Cout)] : (bf16_t)0;
             }
             a[ks] = __builtin_bit_cast(bf16x8_t, u);
         }
@@ -82,12 +94,12 @@ k_conv_first_fwd(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wt /*[
         // 64 column tiles (d, h) pairs; each wave takes 16
         for (int ctile = wv; ctile < TD * TH; ctile += 4) {
             const int dl = ctile / TH, hl = ctile % TH;
-            const int base = (dl * HH + hl) * HW + r;
+            const int base = ((dl * HH + hl) * HW + r) * CIN;
             f32x16 acc;
 #pragma unroll
             for (int k = 0; k < 16; ++k) acc[k] = 0.f;
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
+            for (int ks = 0; ks < KS; ++ks) {
                 u16x8 u;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) u[j] = sx[base + toff[ks][j]];
@@ -113,28 +125,37 @@ k_conv_first_fwd(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wt /*[
 // ---------------------------------------------------------------------------------------------------------- weight gradient
 namespace fg {
 constexpr int TD = 2, TH = 8, TW = 32;                  // 512 voxels of dy per tile = 32 k-steps of 16 voxels
-constexpr int HD = TD + 2, HH = TH + 2, HW = TW + 2;    // x halo 4 x 10 x 34
+constexpr int HH = TH + 2, HW = TW + 2;                 // x halo (4 x) 10 x 34 per input channel
 constexpr int YVOX = TD * TH * TW;
 constexpr int NTHREADS = 256;
 }  // namespace fg
 
-// dw[tap][co] (Cin = 1) += sum_v dy[v][co] * x[v+tap];  db[co] += sum_v dy[v][co].  One 32-wide co tile per blockIdx.y.
+// dw[tap][co][c] += sum_v dy[v][co] * x[v+tap][c];  db[co] += sum_v dy[v][co].  One 32-wide co tile per blockIdx.y; the (tap, c)
+// pairs are the N dimension of the product (NCT column tiles of 32).
+template <int CIN, bool PLANAR>
 __global__ void __launch_bounds__(fg::NTHREADS)
 k_conv_first_wgrad(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy, float* __restrict__ dw, float* __restrict__ db,
                    int N, int D, int H, int W, int Cout) {
     using namespace fg;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[YVOX * 64 + HD * HH * HW * 2 + 16];
+    constexpr int K = (PLANAR ? 9 : 27) * CIN, NCT = (K + 31) / 32, HD = PLANAR ? TD : TD + 2, DOFF = PLANAR ? 0 : 1;
+    constexpr int XB = HD * HH * HW * CIN * 2;
+    constexpr int LB = (YVOX * 64 + XB + 16) > (NCT * 32 * 32 * 4 + 128 + 16) ? (YVOX * 64 + XB + 16) : (NCT * 32 * 32 * 4 + 128 + 16);
+    __shared__ __attribute__((aligned(16))) unsigned char lds[LB];
     unsigned char* const lds_y = lds;                                  // [voxel][32 co] 64-B rows
     bf16_t* const sx = reinterpret_cast<bf16_t*>(lds + YVOX * 64);     // halo scalars
     const int cot = blockIdx.y;
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6, r = lane & 31, hk = lane >> 5;
     const int twn = W / TW, thn = H / TH, tdn = D / TD;
     const int ntiles = N * tdn * thn * twn;
-    // B operand: lane r = tap, 8 consecutive voxels (k = 8*hk + j) along w
-    const int toff = tap_off(r, HH, HW) + 8 * hk;
-    f32x16 acc;
+    // B operand: lane r = column (tap, c) of column tile ct, 8 consecutive voxels (k = 8*hk + j) along w
+    int toff[NCT];
+    f32x16 acc[NCT];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) acc[k] = 0.f;
+    for (int ct = 0; ct < NCT; ++ct) {
+        toff[ct] = k_off<CIN, PLANAR>(ct * 32 + r, HH, HW) + 8 * hk * CIN;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc[ct][k] = 0.f;
+    }
     float bsum = 0.f;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         int q = tile;
@@ -155,12 +176,13 @@ k_conv_first_wgrad(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy, 
 #pragma unroll
             for (int k = 0; k < 8; ++k) *reinterpret_cast<uint4*>(lds_y + (t + k * NTHREADS) * 16) = v[k];
         }
-        for (int i = t; i < HD * HH * HW; i += NTHREADS) {
-            const int hw_ = i % HW, qq = i / HW, hh_ = qq % HH, hd_ = qq / HH;
-            const int gd = d0 - 1 + hd_, gh = h0 - 1 + hh_, gw = w0 - 1 + hw_;
+        for (int i = t; i < HD * HH * HW * CIN; i += NTHREADS) {
+            const int c = i % CIN, iv = i / CIN;
+            const int hw_ = iv % HW, qq = iv / HW, hh_ = qq % HH, hd_ = qq / HH;
+            const int gd = d0 - DOFF + hd_, gh = h0 - 1 + hh_, gw = w0 - 1 + hw_;
             bf16_t v = 0;
             if ((unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W)
-                v = x[(((int64_t)n * D + gd) * H + gh) * W + gw];
+                v = x[((((int64_t)n * D + gd) * H + gh) * W + gw) * CIN + c];
             sx[i] = v;
         }
         __syncthreads();
@@ -181,52 +203,75 @@ k_conv_first_wgrad(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy, 
 #pragma unroll
                 for (int j = 0; j < 8; ++j) bsum += bf2f(au[j]);
             }
-            u16x8 bu;
-            const int xb = (dl * HH + hl) * HW + 16 * wh + toff;
+            const int xb = ((dl * HH + hl) * HW + 16 * wh) * CIN;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) bu[j] = sx[xb + j];
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, au), __builtin_bit_cast(bf16x8_t, bu), acc, 0, 0, 0);
+            for (int ct = 0; ct < NCT; ++ct) {
+                u16x8 bu;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) bu[j] = sx[xb + toff[ct] + j * CIN];
+                acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, au), __builtin_bit_cast(bf16x8_t, bu), acc[ct], 0, 0, 0);
+            }
         }
         __syncthreads();
     }
-    // D rows = co, cols = tap: reduce the four waves in LDS, then ONE global atomic per (tap, co) and workgroup
-    float* const red = reinterpret_cast<float*>(lds);          // [32 tap][32 co] + [32] bias, tile buffers are dead now
-    for (int i = t; i < 32 * 32 + 32; i += NTHREADS) red[i] = 0.f;
+    // D rows = co, cols = (tap, c): reduce the four waves in LDS, then ONE global atomic per element and workgroup
+    float* const red = reinterpret_cast<float*>(lds);          // [NCT*32 columns][32 co] + [32] bias, tile buffers are dead now
+    for (int i = t; i < NCT * 1024 + 32; i += NTHREADS) red[i] = 0.f;
     __syncthreads();
 #pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
-        const int col = (reg & 3) + 8 * (reg >> 2) + 4 * hk;
-        atomicAdd(&red[r * 32 + col], acc[reg]);
-    }
+    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int col = (reg & 3) + 8 * (reg >> 2) + 4 * hk;
+            atomicAdd(&red[(ct * 32 + r) * 32 + col], acc[ct][reg]);
+        }
     if (db) {
         bsum += __shfl_down(bsum, 32);
-        if (hk == 0) atomicAdd(&red[1024 + r], bsum);
+        if (hk == 0) atomicAdd(&red[NCT * 1024 + r], bsum);
     }
     __syncthreads();
-    for (int i = t; i < 27 * 32; i += NTHREADS) atomicAdd(&dw[(i >> 5) * Cout + cot * 32 + (i & 31)], red[i]);
-    if (db && t < 32) atomicAdd(&db[cot * 32 + t], red[1024 + t]);
+    for (int i = t; i < K * 32; i += NTHREADS) atomicAdd(&dw[k_widx<CIN, PLANAR>(i >> 5, cot * 32 + (i & 31), Cout)], red[i]);
+    if (db && t < 32) atomicAdd(&db[cot * 32 + t], red[NCT * 1024 + t]);
 }
 
 }  // namespace
 
-bool conv3d_first_ok(int C0, int C1, int Cout, int D, int H, int W, int dtype, int up0) {
-    return dtype == FMRI_BF16 && C0 == 1 && C1 == 0 && !up0 && (Cout % 32) == 0 && (D % 4) == 0 && (H % 16) == 0 && (W % 32) == 0;
+// single-channel 3-D volumes, and the few-slice stacks of the 2-D models (reference config_utils.py:53-56: 5 slices by default)
+bool conv3d_first_ok(int C0, int C1, int Cout, int D, int H, int W, int dtype, int up0, int planar) {
+    if (dtype != FMRI_BF16 || C1 != 0 || up0 || (Cout % 32) || (D % 4) || (H % 16) || (W % 32)) return false;
+    return planar ? (C0 == 1 || C0 == 3 || C0 == 5 || C0 == 7) : C0 == 1;
 }
 
-int conv3d_first_fwd(const void* x, const void* w, const float* bias, void* y, int N, int D, int H, int W, int Cout, int act,
-                     float alpha, hipStream_t st) {
+#define FMRI_FIRST_DISPATCH(LAUNCH)                   \
+    do {                                              \
+        if (!planar) { LAUNCH(1, false); }            \
+        else if (C0 == 1) { LAUNCH(1, true); }        \
+        else if (C0 == 3) { LAUNCH(3, true); }        \
+        else if (C0 == 5) { LAUNCH(5, true); }        \
+        else { LAUNCH(7, true); }                     \
+    } while (0)
+
+int conv3d_first_fwd(const void* x, int C0, int planar, const void* w, const float* bias, void* y, int N, int D, int H, int W, int Cout,
+                     int act, float alpha, hipStream_t st) {
     const int ntile = N * (D / ff::TD) * (H / ff::TH) * (W / ff::TW);
-    k_conv_first_fwd<<<ntile, ff::NTHREADS, 0, st>>>((const bf16_t*)x, (const bf16_t*)w, bias, (bf16_t*)y, N, D, H, W, Cout, act, alpha);
+#define L_(CIN_, PL_) \
+    k_conv_first_fwd<CIN_, PL_><<<ntile, ff::NTHREADS, 0, st>>>((const bf16_t*)x, (const bf16_t*)w, bias, (bf16_t*)y, N, D, H, W, Cout, act, alpha)
+    FMRI_FIRST_DISPATCH(L_);
+#undef L_
     FMRI_LAUNCH_CHECK();
     return FMRI_OK;
 }
 
-int conv3d_first_wgrad(const void* x, const void* dy, float* dw, float* db, int N, int D, int H, int W, int Cout, hipStream_t st) {
+int conv3d_first_wgrad(const void* x, int C0, int planar, const void* dy, float* dw, float* db, int N, int D, int H, int W, int Cout,
+                       hipStream_t st) {
     const int ntiles = N * (D / fg::TD) * (H / fg::TH) * (W / fg::TW);
     int gx = 512 / (Cout / 32);
     if (gx > ntiles) gx = ntiles;
     if (gx < 1) gx = 1;
-    k_conv_first_wgrad<<<dim3(gx, Cout / 32), fg::NTHREADS, 0, st>>>((const bf16_t*)x, (const bf16_t*)dy, dw, db, N, D, H, W, Cout);
+#define L_(CIN_, PL_) \
+    k_conv_first_wgrad<CIN_, PL_><<<dim3(gx, Cout / 32), fg::NTHREADS, 0, st>>>((const bf16_t*)x, (const bf16_t*)dy, dw, db, N, D, H, W, Cout)
+    FMRI_FIRST_DISPATCH(L_);
+#undef L_
     FMRI_LAUNCH_CHECK();
     return FMRI_OK;
 }

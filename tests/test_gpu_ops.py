@@ -277,6 +277,11 @@ PLANAR_CASES = [
     ("planar_mfma", torch.bfloat16, 8, 16, 32, 64, False, 0, 64, 2),
     ("planar_mfma_dual_up", torch.bfloat16, 4, 16, 32, 64, True, 32, 64, 2),
     ("planar_mfma_32", torch.bfloat16, 4, 8, 16, 32, False, 0, 32, 2),
+    # first layer of the 2-D models: a stack of 5 (3, 7, 1) slices as channels; the (tap, channel) pairs are the MFMA k-dimension
+    ("planar_first_5", torch.bfloat16, 8, 32, 64, 5, False, 0, 32, 0),
+    ("planar_first_3", torch.bfloat16, 4, 16, 32, 3, False, 0, 64, 0),
+    ("planar_first_7", torch.bfloat16, 4, 16, 64, 7, False, 0, 32, 0),
+    ("planar_first_1", torch.bfloat16, 4, 32, 32, 1, False, 0, 32, 0),
 ]
 
 
