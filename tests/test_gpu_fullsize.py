@@ -69,6 +69,49 @@ def test_full_size_conv_linearity_and_wgrad_paths():
     assert _rel(dw_m, dw_g) <= 1e-4 and _rel(db_m, db_g) <= 1e-4
 
 
+def test_full_size_parity_form_equals_27_tap_kernels():
+    """dec0a at BASELINE size: the parity form (8 pre-summed 2x2x2 filters on the low-res tensor) against the 27-tap kernels that read
+    the up-sampled tensor, forward, both input gradients and the weight gradient, on small dyadic data (products and most partial sums
+    exact, so the two formulations may only differ by the one extra bf16 rounding of the up-sampled channels' partial sum)."""
+    from fmri_hip import ops
+    N, D, H, W, C0, C1, Cout = 1, 64, 128, 128, 128, 64, 64
+    assert ops.conv3d_upcat_ok(C0, C1, Cout, D, H, W, torch.bfloat16) == 3
+    g = torch.Generator().manual_seed(2)
+    bf = torch.bfloat16
+    x_low = (torch.randint(-4, 5, (N, D // 2, H // 2, W // 2, C0), generator=g).float() / 4).to(bf).cuda()
+    x_skip = (torch.randint(-4, 5, (N, D, H, W, C1), generator=g).float() / 4).to(bf).cuda()
+    w = (torch.randint(-2, 3, (27, Cout, C0 + C1), generator=g).float() / 8).cuda()
+    bias = (torch.randint(-4, 5, (Cout,), generator=g).float() / 4).cuda()
+    wf, wd = torch.empty((27, Cout, C0 + C1), dtype=bf, device="cuda"), torch.empty((27, C0 + C1, Cout), dtype=bf, device="cuda")
+    ops.pack_weights(w, wf, wd)
+    up_f, up_d = torch.empty((8, 8, Cout, C0), dtype=bf, device="cuda"), torch.empty((8, 8, C0, Cout), dtype=bf, device="cuda")
+    sk_f, sk_d = torch.empty((27, Cout, C1), dtype=bf, device="cuda"), torch.empty((27, C1, Cout), dtype=bf, device="cuda")
+    ops.conv3d_pack_up_weights(w, C0, C1, up_f, up_d, sk_f, sk_d)
+    y27, yp = torch.empty((N, D, H, W, Cout), dtype=bf, device="cuda"), torch.empty((N, D, H, W, Cout), dtype=bf, device="cuda")
+    ops.conv3d_fwd(x_low, x_skip, wf, bias, y27, up0=True, act=1)
+    ops.conv3d_upcat_fwd(x_low, x_skip, up_f, sk_f, bias, yp, act=1)
+    torch.cuda.synchronize()
+    assert _rel(yp.float(), y27.float()) <= 1e-2
+    dy = (torch.randint(-4, 5, (N, D, H, W, Cout), generator=g).float() / 4).to(bf).cuda()
+    cat = torch.empty((N, D, H, W, C0 + C1), dtype=bf, device="cuda")
+    dl27, dlp, dsp = torch.empty_like(x_low), torch.empty_like(x_low), torch.empty_like(x_skip)
+    ops.conv3d_dgrad(dy, wd, cat)
+    ops.upsample_bwd(cat, dl27, 0, xmask=x_low)
+    ops.conv3d_upcat_dgrad(dy, up_d, sk_d, x_low, None, dlp, dsp)
+    torch.cuda.synchronize()
+    # the 27-tap path rounds the full-resolution gradient to bf16 before the 2x2x2 reduction, the parity form does not
+    assert _rel(dlp.float(), dl27.float()) <= 2e-2
+    assert _rel(dsp.float(), cat[..., C0:].float()) <= 1e-2
+    Dsl = 16
+    dys, xls, xss = dy[:, :Dsl].contiguous(), x_low[:, :Dsl // 2].contiguous(), x_skip[:, :Dsl].contiguous()
+    dw27, dwp = torch.zeros((27, Cout, C0 + C1), device="cuda"), torch.zeros((27, Cout, C0 + C1), device="cuda")
+    db27, dbp = torch.zeros(Cout, device="cuda"), torch.zeros(Cout, device="cuda")
+    ops.conv3d_wgrad(xls, xss, dys, dw27, db27, up0=True)
+    ops.conv3d_upcat_wgrad(xls, xss, dys, dwp, dbp, torch.empty(64 * Cout * C0, device="cuda"))
+    torch.cuda.synchronize()
+    assert _rel(dwp, dw27) <= 1e-4 and _rel(dbp, db27) <= 1e-4
+
+
 def test_bench_contract_smoke():
     """bench.py runs end to end on one GPU and prints the driver's JSON contract (+ roofline with live HIP-event timing)."""
     import json
