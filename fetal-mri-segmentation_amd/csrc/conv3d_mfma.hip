@@ -522,202 +522,6 @@ k_conv_fwd_mfma(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__
 #endif
 }
 
-// slot swizzle for the 16x16x32 operand map (lane = 16*kgroup + column): conflict-free ds_read_b128 when the 16 rows are 4-aligned
-__device__ __forceinline__ int swz16(int row, int slot) { return row * 64 + ((slot ^ ((0 - (row >> 2)) & 3)) << 4); }
-
-template <int NT>  // NT = 32-wide output-channel tiles per workgroup (BN = 32*NT)
-__global__ void __launch_bounds__(fw::NTHREADS)
-k_conv_fwd_mfma16(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ bias, const bf16_t* __restrict__ mask,
-                bf16_t* __restrict__ y, int N, int D, int H, int W, int Cout, int act, float alpha) {
-    using namespace fw;
-    constexpr int BN = 32 * NT;
-    constexpr int FILT_BYTES = 3 * BN * 64;              // one (kd,kh) slab: 3 kw taps x BN rows x 64 B
-    constexpr int F_INSTR = FILT_BYTES / 1024;           // 12 or 6
-    constexpr int F_PER_WAVE = (F_INSTR + 7) / 8;        // 2 or 1 (short waves re-issue their first instruction)
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * HALO_BYTES + 2 * FILT_BYTES];
-
-    const int Cin = s.C0 + s.C1;
-    const int nch = Cin >> 5;
-    const int ncb = Cout / BN;
-    const int twn = W / TW, thn = H / TH, tdn = D / TD;
-    const int npairs = N * tdn * thn * twn * ncb;
-
-    const int t = threadIdx.x, lane = t & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int r = lane & 15, hk = lane >> 4;   // r = column (voxel) / row (cout) inside a 16-tile, hk = 8-channel k-group 0..3
-    const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr(lds));
-    const unsigned ldsf0 = lds0 + 2 * HALO_BYTES;
-
-    auto decode = [&](int pair, int ch) {
-        FwdItem it;
-        it.ch = ch;
-        it.co0 = (pair % ncb) * BN;
-        int q = pair / ncb;
-        it.w0 = (q % twn) * TW; q /= twn;
-        it.h0 = (q % thn) * TH; q /= thn;
-        it.d0 = (q % tdn) * TD;
-        it.n = q / tdn;
-        return it;
-    };
-
-    // ---- per-lane constants of the DMA address generation (hoisted: the phase loop only adds wave-uniform bases)
-    int f_soff[F_PER_WAVE];        // element offset of this lane's 16 B inside a filter slab's global image
-    unsigned f_doff[F_PER_WAVE];   // LDS byte offset of the wave-instruction inside a filter ring slot
-#pragma unroll
-    for (int k = 0; k < F_PER_WAVE; ++k) {
-        int instr = wv + 8 * k;
-        if (instr >= F_INSTR) instr = wv % F_INSTR;                // duplicate: keeps the per-wave DMA count uniform
-        const int i = instr * 64 + lane;
-        const int row = i >> 2, ps = i & 3;
-        const int ls = ps ^ ((0 - (row >> 2)) & 3);
-        f_soff[k] = ((row / BN) * Cout + (row % BN)) * Cin + ls * 8;
-        f_doff[k] = instr * 1024;
-    }
-    int h_pack[9];                 // halo piece ph: hd | hh<<4 | hw<<8 | ls<<13 | valid<<15
-    unsigned h_doff[9];
-#pragma unroll
-    for (int ph = 0; ph < 9; ++ph) {
-        int instr = ph * 8 + wv;
-        if (instr >= H_INSTR) instr -= 8;                          // duplicate of this wave's previous piece
-        const int i = instr * 64 + lane;
-        const int hv = i >> 2, ps = i & 3;
-        const int ls = ps ^ ((0 - (hv >> 2)) & 3);
-        const int hvc = hv < HVOX ? hv : 0;
-        const int hw_ = hvc % HW, hq = hvc / HW;
-        h_pack[ph] = (hq / HH) | ((hq % HH) << 4) | (hw_ << 8) | (ls << 13) | ((hv < HVOX ? 1 : 0) << 15);
-        h_doff[ph] = instr * 1024;
-    }
-    // filter slab of phase `ph` = (kd,kh) for item `it` into filter ring slot `fb`
-    auto issue_filter = [&](const FwdItem& it, int ph, int fb) {
-        const bf16_t* const base = wt + (((int64_t)ph * 3 * Cout + it.co0) * Cin + (it.ch << 5));
-#pragma unroll
-        for (int k = 0; k < F_PER_WAVE; ++k)
-            dma16(base + f_soff[k], __builtin_amdgcn_readfirstlane(ldsf0 + fb * FILT_BYTES + f_doff[k]));
-    };
-    // 1/9 of the halo tile of item `it` into halo ring slot `hb` (ph must be a compile-time constant at the call site)
-    auto issue_halo = [&](const FwdItem& it, int pk, unsigned doff, int hb) {
-        const int cc = it.ch << 5;
-        const bool from0 = cc < s.C0;
-        const bf16_t* sp = from0 ? s.p0 : s.p1;
-        const int sC = from0 ? s.C0 : s.C1;
-        const int coff = from0 ? cc : cc - s.C0;
-        const int sh = (from0 && s.up0) ? 1 : 0;
-        const int shd = sh & s.dsh;
-        const int sD = D >> shd, sH = H >> sh, sW = W >> sh;
-        const int gd = it.d0 - 1 + (pk & 15), gh = it.h0 - 1 + ((pk >> 4) & 15), gw = it.w0 - 1 + ((pk >> 8) & 31);
-        const int ls = (pk >> 13) & 3;
-        const bool ok = (pk >> 15) && (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W;
-        const int gdc = min(max(gd, 0), D - 1) >> shd, ghc = min(max(gh, 0), H - 1) >> sh, gwc = min(max(gw, 0), W - 1) >> sh;
-        const int off = ((gdc * sH + ghc) * sW + gwc) * sC + coff + ls * 8;      // inside one sample: < 2^31 elements
-        const bf16_t* real = sp + (int64_t)it.n * sD * sH * sW * sC + off;
-        const void* src = ok ? (const void*)real : (const void*)g_zero_page;
-        dma16(src, __builtin_amdgcn_readfirstlane(lds0 + hb * HALO_BYTES + doff));
-    };
-
-    constexpr int NCT = 2 * NT;                          // 16-wide output-channel tiles
-    f32x4 acc[4][NCT];                                   // [voxel row of 16][cout tile]
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int c = 0; c < NCT; ++c)
-#pragma unroll
-            for (int k = 0; k < 4; ++k) acc[j][c][k] = 0.f;
-
-    // per-lane halo index (before adding the tap offset) of this lane's voxel in the wave's two column tiles
-    int hv0[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int rt = 2 * wv + (j >> 1);                // 0..15 : d = rt>>2, h-pair = rt&3 ; j&1 = row of the pair
-        hv0[j] = ((rt >> 2) * HH + (2 * (rt & 3) + (j & 1))) * HW + r;
-    }
-    // filter fragment read offset inside a slab for k-step 0 (k-step 1 = same address with bit 5 flipped): rows kw*BN + c*32 + r
-    // keep the swizzle term of row r because kw*BN + c*32 is a multiple of 16
-    const int fa0 = swz16(r, hk);
-
-    int pair = blockIdx.x;
-    if (pair >= npairs) return;
-    FwdItem cur = decode(pair, 0);
-    // prologue: the whole halo of the first item and its first filter slab
-#pragma unroll
-    for (int ph = 0; ph < 9; ++ph) issue_halo(cur, h_pack[ph], h_doff[ph], 0);
-    issue_filter(cur, 0, 0);
-    int g = 0, hb = 0;
-    while (true) {
-        // the item after `cur` in this workgroup's stream
-        bool has_next = true;
-        FwdItem nxt = cur;
-        int npair = pair;
-        if (cur.ch + 1 < nch) nxt.ch = cur.ch + 1;
-        else {
-            npair = pair + gridDim.x;
-            has_next = npair < npairs;
-            if (has_next) nxt = decode(npair, 0);
-        }
-        const unsigned char* const lh = lds + hb * HALO_BYTES;
-        // keep the compiler from hoisting all 108 per-(phase,tap,row) fragment addresses out of the item loop (register spills)
-        asm volatile("" : "+v"(hv0[0]), "+v"(hv0[1]), "+v"(hv0[2]), "+v"(hv0[3]));
-#pragma unroll
-        for (int ph = 0; ph < 9; ++ph, ++g) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's DMA of the previous phase has landed
-            __builtin_amdgcn_s_barrier();                          // ... and everybody else's; previous phase fully read
-            if (ph < 8) issue_filter(cur, ph + 1, (g + 1) & 1);
-            else if (has_next) issue_filter(nxt, 0, (g + 1) & 1);
-            if (has_next) issue_halo(nxt, h_pack[ph], h_doff[ph], hb ^ 1);
-            const unsigned char* const lf = lds + 2 * HALO_BYTES + (g & 1) * FILT_BYTES;
-            const int hoff = ((ph / 3) * HH + (ph % 3)) * HW;
-#pragma unroll
-            for (int kw = 0; kw < 3; ++kw) {
-                bf16x8_t a[NCT], b[4];
-#pragma unroll
-                for (int c = 0; c < NCT; ++c) a[c] = *reinterpret_cast<const bf16x8_t*>(lf + fa0 + (kw * BN + c * 16) * 64);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const bf16x8_t*>(lh + swz16(hv0[j] + hoff + kw, hk));
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int c = 0; c < NCT; ++c)
-                        acc[j][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[c], b[j], acc[j][c], 0, 0, 0);
-            }
-        }
-        if (cur.ch == nch - 1) {
-            // ---- epilogue: D rows = output channel 4*hk + reg, D cols = voxel r
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int rt = 2 * wv + (j >> 1);
-                const int d = cur.d0 + (rt >> 2), h = cur.h0 + 2 * (rt & 3) + (j & 1), w = cur.w0 + r;
-                const int64_t vo = ((((int64_t)cur.n * D + d) * H + h) * W + w) * Cout + cur.co0;
-#pragma unroll
-                for (int c = 0; c < NCT; ++c) {
-                    const int cch = c * 16 + 4 * hk;
-                    float o[4];
-                    float4 bv4 = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (bias) bv4 = *reinterpret_cast<const float4*>(bias + cur.co0 + cch);
-                    const float bvv[4] = {bv4.x, bv4.y, bv4.z, bv4.w};
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        float v = acc[j][c][i] + bvv[i];
-                        if (act == FMRI_ACT_RELU) v = fmaxf(v, 0.f);
-                        else if (act == FMRI_ACT_LEAKY) v = v > 0.f ? v : alpha * v;
-                        o[i] = v;
-                        acc[j][c][i] = 0.f;
-                    }
-                    if (mask) {
-                        float m[4];
-                        ldv<bf16_t, 4>(mask + vo + cch, m);
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) if (!(m[i] > 0.f)) o[i] = 0.f;
-                    }
-                    stv<bf16_t, 4>(y + vo + cch, o);
-                }
-            }
-        }
-        if (!has_next) break;
-        cur = nxt;
-        pair = npair;
-        hb ^= 1;
-    }
-}
-
 // ======================================================================================================== weight gradient
 // One "unit" of work = one d-plane tile of 8 x 16 output voxels (8 k-steps of 16 voxels along w) for one kd.  A workgroup
 // (4 waves, 2 workgroups per CU) owns a (kd, 64-wide Cout block, CIB-wide Cin block) slice of dw, keeps its 9 taps x
@@ -1080,24 +884,6 @@ int conv3d_fwd_mfma_ex(int mode, const void* src0, int C0, int up0, int planar, 
             ncu = v;
         else
             ncu = 256;
-    }
-    static int use16 = -1;              // FMRI_FWD_MFMA=16 selects the v_mfma_f32_16x16x32_bf16 variant (A/B switch)
-    if (use16 < 0) {
-        const char* e = getenv("FMRI_FWD_MFMA");
-        use16 = (e && atoi(e) == 16) ? 1 : 0;
-    }
-    if (use16 && !planar && mode == 0 && !residual) {
-        if (Cout % 64 == 0) {
-            const int np = ntile * (Cout / 64);
-            k_conv_fwd_mfma16<2><<<np < ncu ? np : ncu, fw::NTHREADS, 0, st>>>(s, (const bf16_t*)w, bias, (const bf16_t*)mask, (bf16_t*)y,
-                                                                                  N, D, H, W, Cout, act, alpha);
-        } else {
-            const int np = ntile * (Cout / 32);
-            k_conv_fwd_mfma16<1><<<np < ncu ? np : ncu, fw::NTHREADS, 0, st>>>(s, (const bf16_t*)w, bias, (const bf16_t*)mask, (bf16_t*)y,
-                                                                                  N, D, H, W, Cout, act, alpha);
-        }
-        FMRI_LAUNCH_CHECK();
-        return FMRI_OK;
     }
 #define FMRI_LAUNCH_FWD(NT_, PL_, MODE_, RES_)                                                                             \
     do {                                                                                                                  \
