@@ -40,7 +40,7 @@ class LayerGraphEngine(object):
         self.by_name = OrderedDict((l.name, l) for l in self.layers)
         self.dtype, self.dev, self.training, self.dist = dtype, torch.device(device), training, dist_ctx
         self.planar = False
-        # bf16: every tensor carries its channels padded to a multiple of 64 (zero weights / zero activations in the padding) so that
+        # bf16: every tensor carries its channels padded to a multiple of 32 (zero weights / zero activations in the padding) so that
         # all convolutions - including the 16- and 32-channel levels, the stride-2 and the 1x1x1 ones - run on the MFMA kernels:
         # stride 2 = the stride-1 conv sampled at every second voxel, 1x1x1 = the centre tap of a 27-tap filter.  fp32 (parity mode)
         # keeps the exact-size tensors and the fp32 VALU kernels.  FMRI_GRAPH_PAD=0 switches the padding off.
@@ -142,7 +142,8 @@ class LayerGraphEngine(object):
             o["shape"] = self.shape[o["out"]]
 
     def _cp(self, c):
-        return ((c + 63) // 64) * 64 if self.pad else c
+        """physical channel count: the MFMA forward / input-gradient kernels tile channels by 32"""
+        return ((c + 31) // 32) * 32 if self.pad else c
 
     # ------------------------------------------------------------------------------------------------ parameters
     def _build_params(self, seed):
@@ -164,7 +165,7 @@ class LayerGraphEngine(object):
         self.P = torch.zeros(self.n_flat, dtype=torch.float32, device=self.dev)
         if self.training:
             self.G, self.M, self.V = torch.zeros_like(self.P), torch.zeros_like(self.P), torch.zeros_like(self.P)
-        self.Wf, self.Wd, self.Wup = {}, {}, {}
+        self.Wf, self.Wd, self.Wup, self._dy64_buf = {}, {}, {}, {}
         if self.pad:
             self._build_padded_params()
         else:
@@ -195,8 +196,9 @@ class LayerGraphEngine(object):
             self.bp[name] = torch.zeros(coutp, dtype=f32, device=dev)
             self.Wf[name] = torch.empty((27, coutp, cinp), dtype=self.dtype, device=dev)
             if self.training:
-                self.dWp[name] = torch.zeros((27, coutp, cinp), dtype=f32, device=dev)
-                self.dbp[name] = torch.zeros(coutp, dtype=f32, device=dev)
+                c64 = ((coutp + 63) // 64) * 64          # the weight-gradient kernel may be fed a dy zero-extended to 64 channels
+                self.dWp[name] = torch.zeros((27, c64, cinp), dtype=f32, device=dev)
+                self.dbp[name] = torch.zeros(c64, dtype=f32, device=dev)
                 if not self._is_input(op["ins"]):
                     self.Wd[name] = torch.empty((27, cinp, coutp), dtype=self.dtype, device=dev)
         # UpSampling3D -> Conv3D (reference isensee2017.py:101-104): parity form, 8 pre-summed 2x2x2 filters on the low-res tensor
@@ -483,10 +485,14 @@ class LayerGraphEngine(object):
                         dwp, dbp = self.dWp[name], self.dbp[name]
                         dwp.zero_()
                         dbp.zero_()
-                        if name in self.Wup and self.Wup[name]["wgrad"]:
+                        gw = g
+                        if g.shape[-1] % 64:
+                            # the MFMA weight-gradient kernel tiles Cout by 64: hand it a zero-extended copy of dy (the extra rows of dw stay 0)
+                            gw = self._dy64(g)
+                        if name in self.Wup and self.Wup[name]["wgrad"] and gw is g:
                             ops.conv3d_upcat_wgrad(s0, None, g, dwp, dbp, self.dwc_scratch)
                         else:
-                            ops.conv3d_wgrad(s0, s1, g, dwp, dbp, up0=o["up0"])
+                            ops.conv3d_wgrad(s0, s1, gw, dwp, dbp, up0=o["up0"])
                         taps = dwp if o["k"] == 3 else dwp[13:14]
                         dw += taps[:, :Lc["cout"]].index_select(2, self.cin_map[name])
                         db += dbp[:Lc["cout"]]
@@ -549,6 +555,16 @@ class LayerGraphEngine(object):
                 self._accum(src, lambda dst: ops.maxpool_bwd(self._t(src), g, dst, relu_mask=False))
         if self.dist is not None:
             self.dist.finish(self)
+
+    def _dy64(self, g):
+        C = g.shape[-1]
+        c64 = ((C + 63) // 64) * 64
+        key = tuple(g.shape[:-1]) + (c64,)
+        buf = self._dy64_buf.get(key)
+        if buf is None:
+            buf = self._dy64_buf[key] = torch.zeros(key, dtype=g.dtype, device=g.device)
+        buf[..., :C] = g
+        return buf
 
     def _slice_into(self, name, src, off):
         if name == self.input_name:
