@@ -39,13 +39,41 @@ def save_nifti(data, path, affine=None):
     return path
 
 
-def load_nifti(path):
+def load_nifti(path, return_affine=False, scaled=True):
+    """Read a single-file NIfTI-1 image (.nii / .nii.gz), either byte order.  With `scaled` the stored values are mapped through
+    scl_slope / scl_inter when a slope is set (what nibabel's get_fdata returns); otherwise the stored dtype is kept.
+    `return_affine`: also return the 4x4 voxel-to-world matrix (sform when sform_code > 0, else the pixdim scaling)."""
     opener = gzip.open if str(path).endswith(".gz") else open
     with opener(path, "rb") as f:
         raw = f.read()
-    dim = struct.unpack_from("<8h", raw, 40)
-    code = struct.unpack_from("<h", raw, 70)[0]
-    off = int(struct.unpack_from("<f", raw, 108)[0])
-    dt = {v[0]: k for k, v in _DT.items()}[code]
+    en = "<" if struct.unpack_from("<i", raw, 0)[0] == 348 else ">"
+    if struct.unpack_from(en + "i", raw, 0)[0] != 348:
+        raise ValueError("%s is not a NIfTI-1 file (sizeof_hdr != 348)" % path)
+    if raw[344:347] not in (b"n+1", b"ni1"):
+        raise ValueError("%s: unknown NIfTI magic %r" % (path, raw[344:348]))
+    if raw[344:347] == b"ni1":
+        raise ValueError("%s: two-file NIfTI (.hdr/.img) is not supported" % path)
+    dim = struct.unpack_from(en + "8h", raw, 40)
+    code = struct.unpack_from(en + "h", raw, 70)[0]
+    pixdim = struct.unpack_from(en + "8f", raw, 76)
+    off = int(struct.unpack_from(en + "f", raw, 108)[0])
+    slope, inter = struct.unpack_from(en + "2f", raw, 112)
+    by_code = {v[0]: k for k, v in _DT.items()}
+    if code not in by_code:
+        raise ValueError("%s: unsupported NIfTI datatype code %d" % (path, code))
+    dt = by_code[code].newbyteorder(en)
     shape = dim[1:1 + dim[0]]
-    return np.frombuffer(raw, dtype=dt, count=int(np.prod(shape)), offset=off).reshape(shape, order="F")
+    data = np.frombuffer(raw, dtype=dt, count=int(np.prod(shape)), offset=off).reshape(shape, order="F")
+    if scaled and slope not in (0.0, 1.0) or (scaled and slope != 0.0 and inter != 0.0):
+        data = data.astype(np.float64) * slope + inter
+    elif data.dtype.byteorder not in ("=", "|") and en == ">":
+        data = data.astype(data.dtype.newbyteorder("="))
+    if not return_affine:
+        return data
+    affine = np.eye(4)
+    if struct.unpack_from(en + "h", raw, 254)[0] > 0:
+        for r, o in enumerate((280, 296, 312)):
+            affine[r] = struct.unpack_from(en + "4f", raw, o)
+    else:
+        affine[0, 0], affine[1, 1], affine[2, 2] = pixdim[1:4]
+    return data, affine

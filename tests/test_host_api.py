@@ -176,3 +176,37 @@ def test_unsupported_topologies_fail_loudly():
         m.predict(np.zeros((1, 1, 16, 16, 16)))
     with pytest.raises(NotImplementedError):
         fmodel.isensee2017_model(input_shape=(32, 32, 5))
+
+
+def test_nifti_reader_big_endian_scaled_with_affine(tmp_path):
+    """a hand-built big-endian int16 NIfTI-1 with scl_slope / scl_inter and an sform: values, scaling and affine come back"""
+    import struct
+    from fetal_net.utils.nifti import load_nifti, save_nifti
+    vol = (np.arange(2 * 3 * 4, dtype=np.int16).reshape(2, 3, 4) - 7)
+    hdr = bytearray(348)
+    struct.pack_into(">i", hdr, 0, 348)
+    struct.pack_into(">8h", hdr, 40, 3, 2, 3, 4, 1, 1, 1, 1)
+    struct.pack_into(">h", hdr, 70, 4)
+    struct.pack_into(">h", hdr, 72, 16)
+    struct.pack_into(">8f", hdr, 76, 1.0, 0.5, 0.5, 2.0, 1.0, 1.0, 1.0, 1.0)
+    struct.pack_into(">f", hdr, 108, 352.0)
+    struct.pack_into(">2f", hdr, 112, 0.25, 10.0)
+    struct.pack_into(">h", hdr, 254, 1)
+    A = np.array([[0.5, 0, 0, -3.0], [0, 0.5, 0, 4.0], [0, 0, 2.0, 1.5], [0, 0, 0, 1]])
+    for r, o in enumerate((280, 296, 312)):
+        struct.pack_into(">4f", hdr, o, *A[r])
+    hdr[344:348] = b"n+1\x00"
+    path = tmp_path / "be.nii"
+    path.write_bytes(bytes(hdr) + b"\x00" * 4 + np.asfortranarray(vol.astype(">i2")).tobytes(order="F"))
+    data, aff = load_nifti(str(path), return_affine=True)
+    np.testing.assert_allclose(data, vol * 0.25 + 10.0)
+    np.testing.assert_allclose(aff, A)
+    assert np.array_equal(load_nifti(str(path), scaled=False), vol)
+    # files written by save_nifti carry slope 1: the stored dtype comes back untouched, with the identity affine
+    p2 = save_nifti(vol, str(tmp_path / "le.nii.gz"))
+    d2, a2 = load_nifti(p2, return_affine=True)
+    assert d2.dtype == np.int16 and np.array_equal(d2, vol) and np.array_equal(a2, np.eye(4))
+    bad = tmp_path / "bad.nii"
+    bad.write_bytes(b"\x00" * 400)
+    with pytest.raises(ValueError):
+        load_nifti(str(bad))
