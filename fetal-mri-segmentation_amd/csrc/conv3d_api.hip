@@ -7,6 +7,7 @@ int conv3d_wgrad_generic(const void*, int, int, int, const void*, int, const voi
                          hipStream_t);
 bool conv3d_fwd_mfma_ok(int C0, int C1, int Cout, int D, int H, int W, int dtype);
 bool conv3d_wgrad_mfma_ok(int C0, int C1, int Cout, int D, int H, int W, int dtype);
+bool conv3d_fwd_needs_cube(int D, int H, int W);
 int conv3d_fwd_mfma(const void*, int, int, int, const void*, int, const void*, const float*, const void*, void*, int, int, int, int, int, int,
                     float, hipStream_t);
 int conv3d_wgrad_mfma(const void*, int, int, int, const void*, int, const void*, float*, float*, int, int, int, int, int, void*, int64_t,
@@ -42,7 +43,7 @@ extern "C" int fmri_conv3d_fwd(const void* src0, int C0, int up0, const void* sr
     if (dtype != FMRI_F32 && dtype != FMRI_BF16) return FMRI_E_DTYPE;
     if (impl != FMRI_IMPL_GENERIC && !mask && conv3d_first_ok(C0, C1, Cout, D, H, W, dtype, up0, planar))
         return conv3d_first_fwd(src0, C0, planar, w, bias, y, N, D, H, W, Cout, act, alpha, as_stream(stream));
-    const bool can = conv3d_fwd_mfma_ok(C0, C1, Cout, D, H, W, dtype);
+    const bool can = conv3d_fwd_mfma_ok(C0, C1, Cout, D, H, W, dtype) && !(planar && conv3d_fwd_needs_cube(D, H, W));
     if (impl == FMRI_IMPL_MFMA && !can) return FMRI_E_SHAPE;
     if (can && impl != FMRI_IMPL_GENERIC) {
         if ((((uintptr_t)src0) | ((uintptr_t)src1) | ((uintptr_t)w) | ((uintptr_t)y) | ((uintptr_t)mask)) & 15) return FMRI_E_ALIGN;
@@ -133,6 +134,7 @@ extern "C" int fmri_conv3d_upcat_ok(int C0, int C1, int Cout, int D, int H, int 
     if ((D | H | W) & 1) return 0;
     if (C0 <= 0 || C1 < 0 || Cout * 8 > 4096) return 0;             // up-backward sends 8*Cout channels of dy through the zero page
     // C1 = 0: a convolution of a purely up-sampled tensor (reference isensee2017.py:101-104 create_up_sampling_module)
+    if (conv3d_fwd_needs_cube(D / 2, H / 2, W / 2) || conv3d_fwd_needs_cube(D, H, W)) return 0;      // the parity launches use the 4x8x16 tiling
     const bool fb = conv3d_fwd_mfma_ok(C0, 0, Cout, D / 2, H / 2, W / 2, dtype) && conv3d_fwd_mfma_ok(Cout, 0, C0, D / 2, H / 2, W / 2, dtype) &&
                     (C1 == 0 || (conv3d_fwd_mfma_ok(C1, 0, Cout, D, H, W, dtype) && conv3d_fwd_mfma_ok(Cout, 0, C1, D, H, W, dtype)));
     const bool wg_ = conv3d_wgrad_mfma_ok(C0, 0, Cout, D / 2, H / 2, W / 2, dtype) && (C1 == 0 || conv3d_wgrad_mfma_ok(C1, 0, Cout, D, H, W, dtype));

@@ -105,12 +105,19 @@ struct FwdItem {          // one (tile, Cout block, 32-channel chunk) unit of th
 //   2  "up-backward": gradient of that conv w.r.t. the low-res tensor = the same 2x2x2-tap structure over the space-to-depth view
 //      of dy: chunk -> (parity, 32-channel slice), halo rows are gathered from voxel 2g+p of dy, taps mirrored.
 // RES (MODE 0): the epilogue adds `residual` (same layout as y, may alias it) before bias + activation, in fp32.
-template <int NT, bool PL, int MODE, bool RES>  // NT = 32-wide output-channel tiles per workgroup (BN = 32*NT); PL = planar (kd = 1 taps only)
+// CUBE: the workgroup tile is 8 x 8 x 8 instead of 4 x 8 x 16 voxels (halo 10^3 = 1000 rows): the shape of the deepest levels of
+// deep models (e.g. 8^3 at level 4 of a 128^3 Isensee net), whose W is not a multiple of 16.  A 32-voxel column tile is then 4 h-rows
+// of 8 voxels; everything else is the same machinery.
+template <int NT, bool PL, int MODE, bool RES, bool CUBE = false>  // NT = 32-wide Cout tiles per workgroup (BN = 32*NT); PL = planar
 __global__ void __launch_bounds__(fw::NTHREADS)
 k_conv_fwd_mfma(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ bias, const bf16_t* __restrict__ mask,
                 const bf16_t* residual, bf16_t* y, int N, int D, int H, int W, int Cout, int act, float alpha) {
-    using namespace fw;
-    static_assert(!(PL && MODE != 0) && !(RES && MODE != 0), "unsupported combination");
+    constexpr int NTHREADS = fw::NTHREADS;
+    constexpr int TD = CUBE ? 8 : fw::TD, TH = CUBE ? 8 : fw::TH, TW = CUBE ? 8 : fw::TW;
+    constexpr int HD = TD + 2, HH = TH + 2, HW = TW + 2, HVOX = HD * HH * HW;
+    constexpr int H_INSTR = (HVOX * 4 + 63) / 64, HALO_BYTES = H_INSTR * 1024;
+    static_assert(!(PL && MODE != 0) && !(RES && MODE != 0) && !(CUBE && (PL || MODE != 0 || RES)), "unsupported combination");
+    (void)NTHREADS;
     constexpr bool PAR = MODE != 0;
     constexpr int BN = 32 * NT;
     constexpr int NKW = PAR ? 2 : 3;                     // kw taps per phase
@@ -255,12 +262,17 @@ k_conv_fwd_mfma(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__
     // Lane r of a 32-voxel column tile covers h-row (r>>4) and w = wl.  The second h-row is rotated by 2 (= HW mod 16) so that
     // the halo rows read by one ds_read_b128 lane group are distinct mod 16: with the plain map rows r and r+18 collided on
     // 2 of 16 lanes per group (rocprofv3: SQ_LDS_BANK_CONFLICT = 33 % of SQ_LDS_IDX_ACTIVE); the rotation makes it conflict-free.
-    const int wl = (r >> 4) ? (((r & 15) + 16 - (HW & 15)) & 15) : (r & 15);
+    // (CUBE: lane r covers h-row r>>3 of its tile's four and w = r&7; the rarely used variant lives with the bank conflicts)
+    const int wl = CUBE ? (r & 7) : ((r >> 4) ? (((r & 15) + 16 - (HW & 15)) & 15) : (r & 15));
+    // column tile rt (0..15) -> (d, first h-row) inside the workgroup tile, lane -> h-row inside the column tile
+    auto tile_d = [](int rt) { return CUBE ? rt >> 1 : rt >> 2; };
+    auto tile_h = [](int rt, int rr) { return CUBE ? 4 * (rt & 1) + (rr >> 3) : 2 * (rt & 3) + (rr >> 4); };
+    auto lane_w = [](int rr) { return CUBE ? (rr & 7) : ((rr >> 4) ? (((rr & 15) + 16 - (HW & 15)) & 15) : (rr & 15)); };
     int hv0[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        const int rt = 2 * wv + j;                       // 0..15 : d = rt>>2, h-pair = rt&3
-        hv0[j] = ((rt >> 2) * HH + (2 * (rt & 3) + (r >> 4))) * HW + wl;
+        const int rt = 2 * wv + j;
+        hv0[j] = (tile_d(rt) * HH + tile_h(rt, r)) * HW + wl;
     }
     // filter fragment read offset inside a slab for k-step 0 (k-step 1 = same address with bit 5 flipped): rows kw*BN + c*32 + r
     // keep the swizzle term of row r because kw*BN + c*32 is a multiple of 16
@@ -408,8 +420,7 @@ k_conv_fwd_mfma(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__
                     const int rr = kk * VPI + lane / LPV, q8 = lane % LPV;
                     const float4 a0 = *reinterpret_cast<const float4*>(stage + rr * (BN * 4) + ((((2 * q8) ^ rr) & (PPV - 1)) << 4));
                     const float4 a1 = *reinterpret_cast<const float4*>(stage + rr * (BN * 4) + ((((2 * q8 + 1) ^ rr) & (PPV - 1)) << 4));
-                    const int wq = (rr >> 4) ? (((rr & 15) + 16 - (HW & 15)) & 15) : (rr & 15);
-                    const int d = cur.d0 + (rt >> 2), h = cur.h0 + 2 * (rt & 3) + (rr >> 4), w = cur.w0 + wq;
+                    const int d = cur.d0 + tile_d(rt), h = cur.h0 + tile_h(rt, rr), w = cur.w0 + lane_w(rr);
                     const int64_t ao = ((((int64_t)cur.n * D + d) * H + h) * W + w) * Cout + cur.co0 + q8 * 8;
                     const uint4 r4 = *reinterpret_cast<const uint4*>(residual + ao);
                     float o[8] = {a0.x + __uint_as_float(r4.x << 16) + bq.x, a0.y + __uint_as_float(r4.x & 0xffff0000u) + bq.y,
@@ -486,8 +497,7 @@ k_conv_fwd_mfma(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__
                 const int vs = NT == 2 ? (v & 7) : ((v >> 2) & 3);
                 uint4 o4 = *reinterpret_cast<const uint4*>(stage + v * (BN * 2) + (((q ^ vs) & SWM) << 4));
                 const int rt = 2 * wv + (v >> 5), rr = v & 31;
-                const int wq = (rr >> 4) ? (((rr & 15) + 16 - (HW & 15)) & 15) : (rr & 15);
-                const int d = cur.d0 + (rt >> 2), h = cur.h0 + 2 * (rt & 3) + (rr >> 4), w = cur.w0 + wq;
+                const int d = cur.d0 + tile_d(rt), h = cur.h0 + tile_h(rt, rr), w = cur.w0 + lane_w(rr);
                 int64_t ao;
                 if constexpr (MODE == 1)     // parity class p of the [2D][2H][2W] output
                     ao = ((((int64_t)cur.n * 2 * D + 2 * d + (cur.par >> 2)) * 2 * H + 2 * h + ((cur.par >> 1) & 1)) * 2 * W + 2 * w + (cur.par & 1)) * Cout +
@@ -860,9 +870,11 @@ bool conv3d_fwd_mfma_ok(int C0, int C1, int Cout, int D, int H, int W, int dtype
     if (dtype != FMRI_BF16) return false;
     if ((C0 % 32) || (C1 % 32) || C0 + C1 < 32 || (Cout % 32)) return false;
     if (C0 + C1 > 4096) return false;                    // zero-page length (see g_zero_page)
-    if ((D % fw::TD) || (H % fw::TH) || (W % fw::TW)) return false;
+    if ((D % fw::TD) || (H % fw::TH) || (W % fw::TW)) return !((D % 8) || (H % 8) || (W % 8));     // 8x8x8 tiles (CUBE variant)
     return true;
 }
+// true when only the 8x8x8 tiling fits: plain 3-D convs only (no planar, parity-form or residual launches)
+bool conv3d_fwd_needs_cube(int D, int H, int W) { return (D % fw::TD) || (H % fw::TH) || (W % fw::TW); }
 bool conv3d_wgrad_mfma_ok(int C0, int C1, int Cout, int D, int H, int W, int dtype) {
     if (dtype != FMRI_BF16) return false;
     if ((C0 % 32) || (C1 % 32) || C0 + C1 < 32 || (Cout % 64)) return false;
@@ -876,7 +888,8 @@ int conv3d_fwd_mfma_ex(int mode, const void* src0, int C0, int up0, int planar, 
                        const void* mask, const void* residual, void* y, int N, int D, int H, int W, int Cout, int act, float alpha,
                        hipStream_t st) {
     SrcB s{(const bf16_t*)src0, (const bf16_t*)src1, C0, C1, up0, planar ? 0 : 1, planar};
-    const int ntile = N * (D / fw::TD) * (H / fw::TH) * (W / fw::TW);
+    const bool cube = (D % fw::TD) || (H % fw::TH) || (W % fw::TW);       // only the 8x8x8 tiling fits (conv3d_fwd_mfma_ok)
+    const int ntile = cube ? N * (D / 8) * (H / 8) * (W / 8) : N * (D / fw::TD) * (H / fw::TH) * (W / fw::TW);
     static int ncu = 0;                 // CU count of the current device, queried once (persistent grid = one workgroup per CU)
     if (ncu == 0) {
         int dev = 0, v = 0;
@@ -894,7 +907,17 @@ int conv3d_fwd_mfma_ex(int mode, const void* src0, int C0, int up0, int planar, 
     // 64-wide Cout blocks halve the halo traffic per MFMA, but a launch with fewer (tile, block) pairs than CUs (the 8x16x16 bottleneck
     // level) leaves CUs idle: 32-wide blocks double the pairs there
     const bool wide = Cout % 64 == 0 && (int64_t)ntile * (Cout / 64) * (mode == 1 ? 8 : 1) >= ncu;
-    if (mode == 1) {
+    if (cube) {
+        if (mode != 0 || residual || planar) return FMRI_E_SHAPE;
+        const int nt = wide ? 2 : 1;
+        const int np = ntile * (Cout / (32 * nt));
+        if (wide)
+            k_conv_fwd_mfma<2, false, 0, false, true><<<np < ncu ? np : ncu, fw::NTHREADS, 0, st>>>(
+                s, (const bf16_t*)w, bias, (const bf16_t*)mask, nullptr, (bf16_t*)y, N, D, H, W, Cout, act, alpha);
+        else
+            k_conv_fwd_mfma<1, false, 0, false, true><<<np < ncu ? np : ncu, fw::NTHREADS, 0, st>>>(
+                s, (const bf16_t*)w, bias, (const bf16_t*)mask, nullptr, (bf16_t*)y, N, D, H, W, Cout, act, alpha);
+    } else if (mode == 1) {
         if (wide) FMRI_LAUNCH_FWD(2, false, 1, false); else FMRI_LAUNCH_FWD(1, false, 1, false);
     } else if (mode == 2) {
         if (wide) FMRI_LAUNCH_FWD(2, false, 2, false); else FMRI_LAUNCH_FWD(1, false, 2, false);

@@ -40,6 +40,10 @@ CONV_CASES = [
     # 8 channel chunks on an all-boundary tile: the out-of-volume halo rows keep reading zeros as the source pointers advance
     ("mfma_deep_256", torch.bfloat16, 1, 4, 8, 16, 256, False, 0, 64, 2),
     ("mfma_dual_up_deep", torch.bfloat16, 1, 8, 16, 16, 128, True, 64, 96, 2),
+    # 8x8x8 workgroup tiles: volumes whose W is a multiple of 8 but not of 16 (deepest level of deep models)
+    ("mfma_cube_8", torch.bfloat16, 2, 8, 8, 8, 64, False, 0, 64, 2),
+    ("mfma_cube_multi", torch.bfloat16, 1, 16, 8, 24, 96, False, 0, 32, 2),
+    ("mfma_cube_dual_up", torch.bfloat16, 1, 8, 16, 8, 32, True, 32, 64, 2),
     ("first_layer_32", torch.bfloat16, 2, 4, 16, 32, 1, False, 0, 32, 0),
     ("first_layer_64_multi", torch.bfloat16, 1, 8, 32, 64, 1, False, 0, 64, 0),
 ]
@@ -80,8 +84,8 @@ def test_conv3d_fwd_noact_mask(ops, case):
 @pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
 def test_conv3d_wgrad(ops, case):
     name, dtype, N, D, H, W, C0, up0, C1, Cout, impl = case
-    if impl == 2 and Cout % 64:
-        pytest.skip("MFMA wgrad needs Cout % 64 == 0")
+    if impl == 2 and (Cout % 64 or W % 16):
+        pytest.skip("MFMA wgrad needs Cout % 64 == 0 and W % 16 == 0")
     s0 = (N, D // 2, H // 2, W // 2, C0) if up0 else (N, D, H, W, C0)
     src0 = rnd(s0, 9, dtype)
     src1 = rnd((N, D, H, W, C1), 10, dtype) if C1 else None
