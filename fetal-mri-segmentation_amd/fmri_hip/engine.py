@@ -162,10 +162,25 @@ class UNetEngine:
             self.Wf[name] = torch.empty((27, L["cout"], L["cin"]), dtype=self.dtype, device=dev)
             if self.training and name != first:
                 self.Wd[name] = torch.empty((27, L["cin"], L["cout"]), dtype=self.dtype, device=dev)
+        # Deconvolution3D(k = 2, s = 2) (reference unet.py:135): output voxel 2g+p = W[p] . x[g] + b, i.e. the parity form with ONE
+        # non-zero tap per parity class (low-res offset 0) - it rides the same MFMA kernels (fmri_conv3d_upcat_* with C1 = 0)
+        self.Wdc = {}
+        if not self.planar and self.dtype == torch.bfloat16:
+            for lvl, u in p.up.items():
+                L = self.layout[u["name"]]
+                D, H, W = p.level_dims(lvl)
+                if ops.conv3d_upcat_ok(L["cin"], 0, L["cout"], D, H, W, self.dtype) == 3:
+                    Wd_ = dict(up_f=torch.zeros((8, 8, L["cout"], L["cin"]), dtype=self.dtype, device=dev), up_d=None, dw27=None)
+                    if self.training:
+                        Wd_["up_d"] = torch.zeros((8, 8, L["cin"], L["cout"]), dtype=self.dtype, device=dev)
+                        Wd_["dw27"] = torch.zeros((27, L["cout"], L["cin"]), dtype=torch.float32, device=dev)   # never read
+                    self.Wdc[u["name"]] = Wd_
         self.dwc_scratch = None
-        if self.training and self.upcat_wgrad:
-            need = max(64 * self.layout[n]["cout"] * self.upcat[n][0] for n in self.upcat_wgrad)
-            self.dwc_scratch = torch.empty(need, dtype=torch.float32, device=dev)
+        need = [64 * self.layout[n]["cout"] * self.upcat[n][0] for n in self.upcat_wgrad] + \
+               [64 * self.layout[n]["cout"] * self.layout[n]["cin"] for n in self.Wdc]
+        if self.training and need:
+            self.dwc_scratch = torch.empty(max(need), dtype=torch.float32, device=dev)
+        self._par8 = torch.arange(8, device=dev)
         self.init_glorot(seed)
 
     def w_view(self, name, buf=None):
@@ -301,6 +316,12 @@ class UNetEngine:
             c0, c1 = self.upcat[name]
             ops.conv3d_pack_up_weights(self.w_view(name), c0, c1, W["up_f"], W["up_d"], W["sk_f"], W["sk_d"])
         for name, wt in self.Wt.items():
+            if name in self.Wdc:                          # parity p reads low-res offset 0 = combined tap 7 - p (mirrored: tap p)
+                Wd_, w8 = self.Wdc[name], self.w_view(name)
+                Wd_["up_f"][self._par8, 7 - self._par8] = w8.to(self.dtype)
+                if Wd_["up_d"] is not None:
+                    Wd_["up_d"][self._par8, self._par8] = w8.transpose(1, 2).to(self.dtype)
+                continue
             ops.cast(self.w_view(name), wt)
 
     # ------------------------------------------------------------------------------------------------ buffers
@@ -435,7 +456,10 @@ class UNetEngine:
             skip = A[p.enc[a["level"]][1]["name"]]
             if a["level"] in p.up:
                 u = p.up[a["level"]]
-                ops.deconv_fwd(h, self.Wt[u["name"]], self.b_view(u["name"]), A[u["name"]], planar=self.planar)
+                if u["name"] in self.Wdc:
+                    ops.conv3d_upcat_fwd(h, None, self.Wdc[u["name"]]["up_f"], None, self.b_view(u["name"]), A[u["name"]], act=ACT_NONE)
+                else:
+                    ops.deconv_fwd(h, self.Wt[u["name"]], self.b_view(u["name"]), A[u["name"]], planar=self.planar)
                 self._block_fwd(a, A[u["name"]], skip, False, bn_training)
             else:
                 self._block_fwd(a, h, skip, True, bn_training)
@@ -508,8 +532,17 @@ class UNetEngine:
                 u = p.up[ld]
                 self._block_bwd(a, A[u["name"]], skip, False)
                 ops.conv3d_dgrad(Gd[a["name"]], self.Wd[a["name"]], cat, planar=self.planar)
-                ops.deconv_bwd(A[low], self.Wt[u["name"]], cat, Gd[low], self.w_view(u["name"], self.G), self.b_view(u["name"], self.G),
-                               dy_off=0, xmask=self._mask_of(low), planar=self.planar)
+                if u["name"] in self.Wdc:
+                    Wd_ = self.Wdc[u["name"]]
+                    dyc = ops.slice_channels(cat, 0, Gd[u["name"]])          # the transposed conv's own slice of the concat gradient
+                    ops.conv3d_upcat_dgrad(dyc, Wd_["up_d"], None, self._mask_of(low), None, Gd[low], None)
+                    ops.conv3d_upcat_wgrad(A[low], None, dyc, Wd_["dw27"], self.b_view(u["name"], self.G), self.dwc_scratch)
+                    L = self.layout[u["name"]]
+                    dwc = self.dwc_scratch[:64 * L["cout"] * L["cin"]].view(8, 8, L["cout"], L["cin"])
+                    self.w_view(u["name"], self.G).add_(dwc[self._par8, 7 - self._par8])
+                else:
+                    ops.deconv_bwd(A[low], self.Wt[u["name"]], cat, Gd[low], self.w_view(u["name"], self.G), self.b_view(u["name"], self.G),
+                                   dy_off=0, xmask=self._mask_of(low), planar=self.planar)
                 self._grad_ready(u["name"])
             elif a["name"] in self.Wup:
                 self._block_bwd(a, A[low], skip, True)

@@ -393,3 +393,32 @@ def test_isensee_bf16_padded_engine(monkeypatch):
     xd = torch.from_numpy(x).cuda().reshape(N, *sp, 1).to(torch.bfloat16).contiguous()
     losses = [eb.metrics_from_sums(eb.train_step(xd, yd, 5e-3).cpu().numpy())["loss"] for _ in range(12)]
     assert min(losses[-4:]) < losses[0], losses
+
+
+def test_deconvolution_variant_bf16_mfma_path_vs_fp32():
+    """Deconvolution3D(k=2,s=2) up-convolution (reference unet.py:132-138 with deconvolution=True) in bf16 runs as the one-tap parity
+    form on the MFMA kernels; same weights and batch on the fp32 engine (VALU transposed-conv kernels): logits <= 3e-2 of their range,
+    every parameter gradient (the transposed conv's included) within 6e-2 in L2."""
+    from fmri_hip.engine import UNetEngine, UNetPlan
+    from oracle import unet_oracle as O
+    sp, N = (16, 32, 64), 2
+    res = {}
+    x, y = O.synthetic_batch((N, 1) + sp)
+    yd = torch.from_numpy(y).cuda().reshape(-1).contiguous()
+    for dt_ in (torch.float32, torch.bfloat16):
+        eng = UNetEngine(UNetPlan(1, sp, depth=2, n_base_filters=32, deconvolution=True), N, dtype=dt_, seed=7)
+        assert bool(eng.Wdc) == (dt_ == torch.bfloat16)
+        xd = torch.from_numpy(x).cuda().reshape(N, *sp, 1).to(dt_).contiguous()
+        eng.forward(xd)
+        eng.loss_forward(yd)
+        eng.backward(yd)
+        torch.cuda.synchronize()
+        res[dt_] = (eng.logits.cpu().numpy().copy(), eng.G.cpu().numpy().copy(), eng)
+    lf, gf, ef = res[torch.float32]
+    lb, gb, _ = res[torch.bfloat16]
+    assert np.abs(lb - lf).max() <= 3e-2 * np.abs(lf).max()
+    for name, L in ef.layout.items():
+        for key in ("w", "b"):
+            o, n = L[key]
+            e = np.linalg.norm(gb[o:o + n] - gf[o:o + n]) / (np.linalg.norm(gf[o:o + n]) + 1e-30)
+            assert e <= 6e-2, (name, key, e)
