@@ -49,6 +49,7 @@ __global__ void k_norm_reduce_v(const T* __restrict__ x, double* __restrict__ ws
 #pragma unroll
     for (int k = 0; k < VEC; ++k) s[k] = q[k] = 0.f;
     const T* base = x + (int64_t)g * V * C + cg * VEC;
+#pragma unroll 4
     for (int64_t v = v0 + vl; v < v1; v += VL) {
         float xv[VEC];
         ldv<T, VEC>(base + v * C, xv);
@@ -83,6 +84,7 @@ __global__ void k_norm_bwd_reduce_v(const T* __restrict__ x, const T* __restrict
         inv[k] = stats[((int64_t)gi * C + cg * VEC + k) * 3 + 1];
     }
     const int64_t base = (int64_t)g * V * C + cg * VEC;
+#pragma unroll 4
     for (int64_t v = v0 + vl; v < v1; v += VL) {
         float xv[VEC], yv[VEC], dv[VEC];
         ldv<T, VEC>(x + base + v * C, xv);
@@ -134,22 +136,38 @@ __global__ void k_zero_d(double* p, int n) {
     if (i < n) p[i] = 0.0;
 }
 
+// y = act((x - mean) * inv * gamma + beta).  A thread keeps its channel group for the whole grid-stride loop whenever the stride is a
+// multiple of C/VEC (always, for power-of-two channel counts), so the per-channel scale / shift live in registers and are only rebuilt
+// when the loop crosses into another instance (the four scalar loads per element they replace made the kernel instruction-bound).
 template <typename T, int VEC>
 __global__ void k_norm_apply(const T* __restrict__ x, const float* __restrict__ stats, const float* __restrict__ gamma,
                              const float* __restrict__ beta, T* __restrict__ y, int64_t V, int C, int per_instance, int act, float alpha,
                              int64_t total) {
     const int CG = C / VEC;
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const bool fixed = stride % CG == 0;
+    float sc[VEC], sh[VEC];
+    int have_g = -1, have_cg = -1;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += stride) {
         const int cg = (int)(i % CG);
         const int64_t v = i / CG;
         const int g = per_instance ? (int)(v / V) : 0;
+        if (g != have_g || cg != have_cg || !fixed) {
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) {
+                const int c = cg * VEC + k;
+                const float* st = stats + ((int64_t)g * C + c) * 3;
+                sc[k] = st[1] * gamma[c];
+                sh[k] = beta[c] - st[0] * sc[k];
+            }
+            have_g = g;
+            have_cg = cg;
+        }
         float xv[VEC], o[VEC];
         ldv<T, VEC>(x + v * C + cg * VEC, xv);
 #pragma unroll
         for (int k = 0; k < VEC; ++k) {
-            const int c = cg * VEC + k;
-            const float* st = stats + ((int64_t)g * C + c) * 3;
-            float z = (xv[k] - st[0]) * st[1] * gamma[c] + beta[c];
+            float z = fmaf(xv[k], sc[k], sh[k]);
             if (act == FMRI_ACT_RELU) z = fmaxf(z, 0.f);
             else if (act == FMRI_ACT_LEAKY) z = z > 0.f ? z : alpha * z;
             o[k] = z;
@@ -203,31 +221,45 @@ __global__ void k_norm_bwd_params(const double* __restrict__ ws, float* __restri
     dgamma[c] += (float)a;
     dbeta[c] += (float)b;
 }
-// dx = gamma * [ (dz - mean(dz)) * inv_s - xhat * mean(dz*xhat) * inv_sigma ]
+// dx = gamma * [ (dz - mean(dz)) * inv_s - xhat * mean(dz*xhat) * inv_sigma ]  =  a*dz + b*x + c  with per-(instance, channel)
+// coefficients a = gamma*inv, b = -gamma*inv*m2*invsig, c = -a*m1 - b*mean, kept in registers as in k_norm_apply
 template <typename T, int VEC>
 __global__ void k_norm_bwd_apply(const T* __restrict__ x, const T* __restrict__ y, const T* __restrict__ dy, const float* __restrict__ stats,
                                  const float* __restrict__ gamma, const double* __restrict__ ws, T* __restrict__ dx, int64_t V, int C,
                                  int per_instance, int act, float alpha, double M, int64_t total) {
     const int CG = C / VEC;
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const bool fixed = stride % CG == 0;
+    float ca[VEC], cb[VEC], cc[VEC];
+    int have_g = -1, have_cg = -1;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += stride) {
         const int cg = (int)(i % CG);
         const int64_t v = i / CG;
         const int g = per_instance ? (int)(v / V) : 0;
+        if (g != have_g || cg != have_cg || !fixed) {
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) {
+                const int c = cg * VEC + k;
+                const int64_t sc = (int64_t)g * C + c;
+                const float mean = stats[sc * 3], inv = stats[sc * 3 + 1], invsig = stats[sc * 3 + 2];
+                const float m1 = (float)(ws[sc * 2] / M), m2 = (float)(ws[sc * 2 + 1] / M);
+                ca[k] = gamma[c] * inv;
+                cb[k] = -gamma[c] * inv * m2 * invsig;
+                cc[k] = -ca[k] * m1 - cb[k] * mean;
+            }
+            have_g = g;
+            have_cg = cg;
+        }
         float xv[VEC], yv[VEC], dv[VEC], o[VEC];
         ldv<T, VEC>(x + v * C + cg * VEC, xv);
         ldv<T, VEC>(y + v * C + cg * VEC, yv);
         ldv<T, VEC>(dy + v * C + cg * VEC, dv);
 #pragma unroll
         for (int k = 0; k < VEC; ++k) {
-            const int c = cg * VEC + k;
-            const int64_t sc = (int64_t)g * C + c;
             float d = dv[k];
             if (act == FMRI_ACT_RELU) d = yv[k] > 0.f ? d : 0.f;
             else if (act == FMRI_ACT_LEAKY) d = yv[k] > 0.f ? d : alpha * d;
-            const float mean = stats[sc * 3], inv = stats[sc * 3 + 1], invsig = stats[sc * 3 + 2];
-            const float xh = (xv[k] - mean) * inv;
-            const float m1 = (float)(ws[sc * 2] / M), m2 = (float)(ws[sc * 2 + 1] / M);
-            o[k] = gamma[c] * ((d - m1) * inv - xh * m2 * invsig);
+            o[k] = fmaf(ca[k], d, fmaf(cb[k], xv[k], cc[k]));
         }
         stv<T, VEC>(dx + v * C + cg * VEC, o);
     }
