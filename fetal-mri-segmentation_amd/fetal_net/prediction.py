@@ -82,9 +82,10 @@ def patch_wise_prediction(model, data, patch_shape, overlap_factor=0, batch_size
                           prev_truth_index=None, prev_truth_size=None):
     """data (1,X,Y,Z) -> (X,Y,Z,C) float64 mean of all tiles covering each voxel."""
     is3d, pad0, pad_for_fit, data_0, indices, data_shape = _geometry(model, data, patch_shape, overlap_factor)
-    on_device = isinstance(model, Model) and is3d and truth_data is None and not permute and model._unsupported is None
+    on_device = isinstance(model, Model) and truth_data is None and not permute and model._unsupported is None and \
+        (is3d or getattr(model, "_input_layout", "") == "channels_last_2d")
     if on_device:
-        out, count_ok = _device_overlap_add(model, data_0, indices, patch_shape, batch_size, data_shape)
+        out, count_ok = _device_overlap_add(model, data_0, indices, patch_shape, batch_size, data_shape, is3d)
         assert count_ok, 'Found zeros in count'
         out = _unpad(out, pad_for_fit)
         assert np.array_equal(out.shape[:-1], data[0].shape), 'prediction shape wrong'
@@ -116,10 +117,11 @@ def patch_wise_prediction(model, data, patch_shape, overlap_factor=0, batch_size
     return predicted_output / predicted_count
 
 
-def _device_overlap_add(model, data_0, indices, patch_shape, batch_size, data_shape):
+def _device_overlap_add(model, data_0, indices, patch_shape, batch_size, data_shape, is3d=True):
     """Upload once, then per tile batch: gather -> network -> float64 overlap-add, all on the device.  The static buffers
     (volume, accumulators, tile batch, index list) and one captured hipGraph per distinct batch size are cached on the
-    model and re-used for every following volume of the same padded shape."""
+    model and re-used for every following volume of the same padded shape.  2-D models: a tile (px, py, slices) IS the
+    channels-last input of the network (the slice stack is the channel axis) and its output is one slice (px, py, 1)."""
     import torch
     from fmri_hip import ops
     patch = tuple(int(p) for p in patch_shape)
@@ -127,6 +129,10 @@ def _device_overlap_add(model, data_0, indices, patch_shape, batch_size, data_sh
     ashape = tuple(int(s) for s in data_shape)
     use_graph = os.environ.get("FMRI_HIPGRAPH", "1") == "1"
     n = len(indices)
+    if not is3d:
+        # 2-D: a tile is a 5-slice stack and the caller's batch (reference default 5) is far too small to fill the device - the MFMA
+        # kernels also want the slice count in multiples of 4.  The overlap-add does not depend on how tiles are grouped (float64 sums)
+        batch_size = max(batch_size, 64)
     sizes = sorted({min(batch_size, n - i) for i in range(0, n, batch_size)}, reverse=True)
     key = (vshape, ashape, patch, tuple(sizes), use_graph)
     st = model.__dict__.get("_tile_state")
@@ -136,14 +142,17 @@ def _device_overlap_add(model, data_0, indices, patch_shape, batch_size, data_sh
                   cnt=torch.zeros(ashape[:3], dtype=torch.int32, device="cuda"), per_b={})
         for B in sizes:
             eng = model.engine(B)
+            # 3-D: (B, px, py, pz, 1) = NDHWC with one channel; 2-D: (1, B, px, py, slices) = the planar layout, slices as channels
+            tshape = (B,) + patch + (1,) if is3d else (1, B) + patch
+            opatch = patch if is3d else (patch[0], patch[1], 1)
             pb = dict(idx=torch.zeros((B, 3), dtype=torch.int32, device="cuda"),
-                      tiles=torch.empty((B,) + patch + (1,), dtype=eng.dtype, device="cuda"), graph=None)
+                      tiles=torch.empty(tshape, dtype=eng.dtype, device="cuda"), graph=None)
 
-            def body(pb=pb, B=B):
+            def body(pb=pb, B=B, opatch=opatch):
                 e = model.engine(B)
                 ops.tile_gather(st["vol"], pb["idx"], patch, pb["tiles"])
                 e.predict(pb["tiles"])
-                ops.tile_scatter_accumulate(e.probs, pb["idx"], patch, st["acc"], st["cnt"])
+                ops.tile_scatter_accumulate(e.probs, pb["idx"], opatch, st["acc"], st["cnt"])
 
             pb["body"] = body
             if use_graph:

@@ -376,7 +376,10 @@ class UNetEngine:
         nvox0 = int(np.prod(self._dims(0)))
         self.logits = torch.empty((nvox0, p.n_labels), dtype=torch.float32, device=dev)
         self.probs = torch.empty_like(self.logits)
-        self.sums = torch.zeros(16, dtype=torch.float64, device=dev)
+        if getattr(self, "sums", None) is None:
+            # ONE tensor for the engine's lifetime: captured hipGraphs of other batch sizes keep its address (re-creating it per buffer
+            # set left them writing into freed memory, which the allocator then handed to the tile index list of the next volume)
+            self.sums = torch.zeros(16, dtype=torch.float64, device=dev)
         if not self.training:
             self.grad, self.dlogits, self.wgrad_ws = None, None, None
             return

@@ -228,3 +228,27 @@ def test_isensee_mask_weighted_loss(tmp_path):
     m1.save(path)
     m3 = load_old_model(path)
     assert getattr(m3.loss, "mask_weighted", False) and abs(m3.test_on_batch([x, masks], y)[0] - m1.test_on_batch([x, masks], y)[0]) <= 1e-5
+
+
+def test_2d_patch_wise_prediction_device_path_equals_host_tiling():
+    """2-D models: the device overlap-add loop (tile = slice stack = channels-last input, one output slice per tile) against the
+    reference-style host tiling around the same model (forced through a duck-typed proxy)"""
+    import fetal_net.model as fmodel
+    from fetal_net.prediction import patch_wise_prediction
+    # fp32 engine: the device loop regroups the tiles into larger batches, which in bf16 would also switch some layers between the
+    # VALU and MFMA kernels (1e-3 rounding differences); in fp32 both groupings run the same arithmetic
+    model = fmodel.unet_model_2d(input_shape=(32, 32, 5), depth=3, n_base_filters=8, compute_dtype="fp32")
+
+    class Proxy:                                   # not a fetal_net Model: patch_wise_prediction tiles on the host and calls .predict
+        output_shape = model.output_shape
+
+        @staticmethod
+        def predict(x):
+            return model.predict(x)
+
+    vol = np.random.RandomState(3).randn(1, 48, 40, 12)
+    for bs in (5, 7):
+        dev = patch_wise_prediction(model, vol, (32, 32, 5), overlap_factor=0.5, batch_size=bs)
+        host = patch_wise_prediction(Proxy(), vol, (32, 32, 5), overlap_factor=0.5, batch_size=bs)
+        assert dev.shape == host.shape == (48, 40, 12, 1)
+        np.testing.assert_allclose(dev, host, rtol=0, atol=2e-6)
