@@ -20,7 +20,7 @@ import numpy as np
 import torch
 
 from . import ops
-from ._lib import ACT_NONE, ACT_RELU, IMPL_AUTO
+from ._lib import lib, ACT_NONE, ACT_RELU, IMPL_AUTO
 
 
 class UNetPlan:
@@ -175,6 +175,22 @@ class UNetEngine:
                         Wd_["up_d"] = torch.zeros((8, 8, L["cin"], L["cout"]), dtype=self.dtype, device=dev)
                         Wd_["dw27"] = torch.zeros((27, L["cout"], L["cin"]), dtype=torch.float32, device=dev)   # never read
                     self.Wdc[u["name"]] = Wd_
+        # 2-D twin (Deconvolution2D, reference unet/unet.py get_up_convolution): the 4 taps are 4 independent 1x1 convs, run as ONE planar
+        # 3x3 MFMA conv to 4*Cout channels whose only non-zero tap is the centre one, followed by a depth-to-space copy
+        self.Wd2 = {}
+        if self.planar and self.dtype == torch.bfloat16:
+            for lvl, u in p.up.items():
+                L = self.layout[u["name"]]
+                _, S, H, W = (1,) + p.level_dims(lvl + 1, 4)                  # low-res dims (the slice count does not matter here)
+                if lib().fmri_conv3d_uses_mfma(L["cin"], 0, 4 * L["cout"], 4, H, W, 1) & 1:
+                    Wd_ = dict(w32=torch.zeros((27, 4 * L["cout"], L["cin"]), dtype=torch.float32, device=dev),
+                               wf=torch.empty((27, 4 * L["cout"], L["cin"]), dtype=self.dtype, device=dev), wd=None,
+                               b4=torch.zeros(4 * L["cout"], dtype=torch.float32, device=dev))
+                    if self.training:
+                        Wd_["wd"] = torch.empty((27, L["cin"], 4 * L["cout"]), dtype=self.dtype, device=dev)
+                        Wd_["dw"] = torch.zeros((27, 4 * L["cout"], L["cin"]), dtype=torch.float32, device=dev)
+                        Wd_["db"] = torch.zeros(4 * L["cout"], dtype=torch.float32, device=dev)
+                    self.Wd2[u["name"]] = Wd_
         self.dwc_scratch = None
         need = [64 * self.layout[n]["cout"] * self.upcat[n][0] for n in self.upcat_wgrad] + \
                [64 * self.layout[n]["cout"] * self.layout[n]["cin"] for n in self.Wdc]
@@ -316,6 +332,12 @@ class UNetEngine:
             c0, c1 = self.upcat[name]
             ops.conv3d_pack_up_weights(self.w_view(name), c0, c1, W["up_f"], W["up_d"], W["sk_f"], W["sk_d"])
         for name, wt in self.Wt.items():
+            if name in self.Wd2:
+                Wd_, L = self.Wd2[name], self.layout[name]
+                Wd_["w32"][13] = self.w_view(name)[:4].reshape(4 * L["cout"], L["cin"])
+                Wd_["b4"].copy_(self.b_view(name).repeat(4))
+                ops.pack_weights(Wd_["w32"], Wd_["wf"], Wd_["wd"])
+                continue
             if name in self.Wdc:                          # parity p reads low-res offset 0 = combined tap 7 - p (mirrored: tap p)
                 Wd_, w8 = self.Wdc[name], self.w_view(name)
                 Wd_["up_f"][self._par8, 7 - self._par8] = w8.to(self.dtype)
@@ -459,7 +481,12 @@ class UNetEngine:
             skip = A[p.enc[a["level"]][1]["name"]]
             if a["level"] in p.up:
                 u = p.up[a["level"]]
-                if u["name"] in self.Wdc:
+                if u["name"] in self.Wd2 and h.shape[1] % 4 == 0:
+                    Wd_ = self.Wd2[u["name"]]
+                    t4 = self._d2s_tmp(u["name"], h, Wd_)
+                    ops.conv3d_fwd(h, None, Wd_["wf"], Wd_["b4"], t4, act=ACT_NONE, planar=True)
+                    self._d2s_views(A[u["name"]], t4)[0].copy_(self._d2s_views(A[u["name"]], t4)[1])
+                elif u["name"] in self.Wdc:
                     ops.conv3d_upcat_fwd(h, None, self.Wdc[u["name"]]["up_f"], None, self.b_view(u["name"]), A[u["name"]], act=ACT_NONE)
                 else:
                     ops.deconv_fwd(h, self.Wt[u["name"]], self.b_view(u["name"]), A[u["name"]], planar=self.planar)
@@ -535,7 +562,19 @@ class UNetEngine:
                 u = p.up[ld]
                 self._block_bwd(a, A[u["name"]], skip, False)
                 ops.conv3d_dgrad(Gd[a["name"]], self.Wd[a["name"]], cat, planar=self.planar)
-                if u["name"] in self.Wdc:
+                if u["name"] in self.Wd2 and A[low].shape[1] % 4 == 0:
+                    Wd_, L = self.Wd2[u["name"]], self.layout[u["name"]]
+                    dyc = ops.slice_channels(cat, 0, Gd[u["name"]])
+                    t4 = self._d2s_tmp(u["name"], A[low], Wd_)
+                    yv, tv = self._d2s_views(dyc, t4)
+                    tv.copy_(yv)                                               # space-to-depth of the gradient
+                    ops.conv3d_dgrad(t4, Wd_["wd"], Gd[low], mask=self._mask_of(low), planar=True)
+                    Wd_["dw"].zero_()
+                    Wd_["db"].zero_()
+                    ops.conv3d_wgrad(A[low], None, t4, Wd_["dw"], Wd_["db"], planar=True)
+                    self.w_view(u["name"], self.G)[:4].add_(Wd_["dw"][13].view(4, L["cout"], L["cin"]))
+                    self.b_view(u["name"], self.G).add_(Wd_["db"].view(4, L["cout"]).sum(0))
+                elif u["name"] in self.Wdc:
                     Wd_ = self.Wdc[u["name"]]
                     dyc = ops.slice_channels(cat, 0, Gd[u["name"]])          # the transposed conv's own slice of the concat gradient
                     ops.conv3d_upcat_dgrad(dyc, Wd_["up_d"], None, self._mask_of(low), None, Gd[low], None)
@@ -571,6 +610,20 @@ class UNetEngine:
                 ops.conv3d_dgrad(Gd[ca["name"]], self.Wd[ca["name"]], Gd["pool_%d" % (ld - 1)], planar=self.planar)
         if self.dist is not None:
             self.dist.finish(self)
+
+    def _d2s_tmp(self, name, x_low, Wd_):
+        """(1, S, H, W, 4*Cout) scratch of the 2-D transposed conv for the current slice count"""
+        key = "t4_%d" % x_low.shape[1]
+        if key not in Wd_:
+            Wd_[key] = torch.empty(tuple(x_low.shape[:-1]) + (Wd_["b4"].numel(),), dtype=self.dtype, device=self.dev)
+        return Wd_[key]
+
+    @staticmethod
+    def _d2s_views(y, t4):
+        """matching 6-D views (S, H, ah, W, aw, Cout) of the full-resolution tensor y (1,S,2H,2W,Cout) and of t4 (1,S,H,W,4*Cout)"""
+        _, S, H, W, C4 = t4.shape
+        C = C4 // 4
+        return y.view(S, H, 2, W, 2, C), t4.view(S, H, W, 2, 2, C).permute(0, 1, 3, 2, 4, 5)
 
     def _dec_input_name(self, ld):
         """name of the activation that is up-sampled into decoder level ld"""

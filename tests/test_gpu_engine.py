@@ -422,3 +422,33 @@ def test_deconvolution_variant_bf16_mfma_path_vs_fp32():
             o, n = L[key]
             e = np.linalg.norm(gb[o:o + n] - gf[o:o + n]) / (np.linalg.norm(gf[o:o + n]) + 1e-30)
             assert e <= 6e-2, (name, key, e)
+
+
+def test_2d_deconvolution_variant_bf16_mfma_path_vs_fp32():
+    """Deconvolution2D(k=2,s=2) of the 2-D model in bf16 = one planar centre-tap MFMA conv to 4*Cout channels + depth-to-space copy; same
+    weights and batch on the fp32 engine (VALU transposed-conv kernels): logits and every parameter gradient agree to bf16 tolerance."""
+    from fmri_hip.engine import UNetEngine, UNetPlan
+    S, sp = 8, (32, 64)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn((1, S) + sp + (5,), generator=g)
+    y = (torch.rand((S * sp[0] * sp[1],), generator=g) > 0.6).to(torch.uint8).cuda()
+    res = {}
+    for dt_ in (torch.float32, torch.bfloat16):
+        eng = UNetEngine(UNetPlan(5, sp, depth=2, n_base_filters=32, ndim=2, deconvolution=True), S, dtype=dt_, seed=9)
+        assert bool(eng.Wd2) == (dt_ == torch.bfloat16)
+        eng.forward(x.cuda().to(dt_).contiguous())
+        eng.loss_forward(y)
+        eng.backward(y)
+        torch.cuda.synchronize()
+        res[dt_] = (eng.logits.cpu().numpy().copy(), eng.G.cpu().numpy().copy(), eng)
+    lf, gf, ef = res[torch.float32]
+    lb, gb, _ = res[torch.bfloat16]
+    assert np.abs(lb - lf).max() <= 3e-2 * np.abs(lf).max()
+    for name, L in ef.layout.items():
+        for key in ("w", "b"):
+            o, n = L[key]
+            ref = np.linalg.norm(gf[o:o + n])
+            if ref < 1e-12:
+                continue                      # the unused half (ad = 1 taps) of the transposed-conv filter in planar mode
+            e = np.linalg.norm(gb[o:o + n] - gf[o:o + n]) / ref
+            assert e <= 6e-2, (name, key, e)
