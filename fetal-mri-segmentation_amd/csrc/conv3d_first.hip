@@ -239,12 +239,15 @@ k_conv_first_wgrad(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy, 
 // single-channel 3-D volumes, and the few-slice stacks of the 2-D models (reference config_utils.py:53-56: 5 slices by default)
 bool conv3d_first_ok(int C0, int C1, int Cout, int D, int H, int W, int dtype, int up0, int planar) {
     if (dtype != FMRI_BF16 || C1 != 0 || up0 || (Cout % 32) || (D % 4) || (H % 16) || (W % 32)) return false;
-    return planar ? (C0 == 1 || C0 == 3 || C0 == 5 || C0 == 7) : C0 == 1;
+    return planar ? (C0 == 1 || C0 == 3 || C0 == 5 || C0 == 7) : (C0 >= 1 && C0 <= 4);     // 3-D: up to 4 modalities (BraTS-style inputs)
 }
 
 #define FMRI_FIRST_DISPATCH(LAUNCH)                   \
     do {                                              \
-        if (!planar) { LAUNCH(1, false); }            \
+        if (!planar && C0 == 1) { LAUNCH(1, false); }  \
+        else if (!planar && C0 == 2) { LAUNCH(2, false); } \
+        else if (!planar && C0 == 3) { LAUNCH(3, false); } \
+        else if (!planar) { LAUNCH(4, false); }       \
         else if (C0 == 1) { LAUNCH(1, true); }        \
         else if (C0 == 3) { LAUNCH(3, true); }        \
         else if (C0 == 5) { LAUNCH(5, true); }        \

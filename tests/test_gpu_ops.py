@@ -44,6 +44,8 @@ CONV_CASES = [
     ("mfma_cube_8", torch.bfloat16, 2, 8, 8, 8, 64, False, 0, 64, 2),
     ("mfma_cube_multi", torch.bfloat16, 1, 16, 8, 24, 96, False, 0, 32, 2),
     ("mfma_cube_dual_up", torch.bfloat16, 1, 8, 16, 8, 32, True, 32, 64, 2),
+    ("first_layer_4_modalities", torch.bfloat16, 1, 4, 16, 32, 4, False, 0, 32, 0),
+    ("first_layer_2_modalities", torch.bfloat16, 1, 8, 16, 32, 2, False, 0, 64, 0),
     ("first_layer_32", torch.bfloat16, 2, 4, 16, 32, 1, False, 0, 32, 0),
     ("first_layer_64_multi", torch.bfloat16, 1, 8, 32, 64, 1, False, 0, 64, 0),
 ]
