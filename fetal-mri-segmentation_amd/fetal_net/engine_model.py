@@ -342,11 +342,7 @@ class Model(object):
                 self._engine.load_keras_weights(self._pending_weights)
                 self._pending_weights = None
             if getattr(self, "_pending_opt", None) is not None:
-                m, v, t = self._pending_opt
-                self._engine.M.copy_(torch.from_numpy(m))
-                self._engine.V.copy_(torch.from_numpy(v))
-                self._engine.t = t
-                self._pending_opt = None
+                self._apply_optimizer_state(self._pending_opt)
             if dist_ctx is not None:
                 dist_ctx.broadcast_params(self._engine)
         self._engine.set_batch(batch)
@@ -547,46 +543,97 @@ class Model(object):
         else:
             self._pending_weights = OrderedDict((k, np.asarray(v)) for k, v in W.items())
 
-    def save_weights(self, path):
-        self.save(path, include_optimizer=False)
+    def get_optimizer_state(self):
+        """(m, v, iterations) with m / v as {'<layer>/<key>': ndarray in Keras layout}, or None before the first training step"""
+        eng = self._engine
+        if eng is None or not eng.training or eng.t == 0:
+            return getattr(self, "_pending_opt", None)
+        m = eng.flat_to_keras(eng.M.detach().cpu().numpy(), moving=False)
+        v = eng.flat_to_keras(eng.V.detach().cpu().numpy(), moving=False)
+        return m, v, int(eng.t)
 
-    def save(self, path, include_optimizer=True):
-        """Full-model checkpoint.  The reference writes Keras HDF5 (`.h5`, training.py:31-32); h5py is not available in this
-        stack, so the container is a numpy .npz written under the SAME file name (naming and resume-by-mtime keep working:
-        reference fetal/utils.py:42-43)."""
-        W = self.get_weights_dict()
-        arrays = {"w/" + k: v for k, v in W.items()}
-        meta = dict(format="fmri-npz-1", builder=self._builder, builder_kwargs=_jsonable(self._builder_kwargs),
+    def _apply_optimizer_state(self, state):
+        eng = self._engine
+        if eng is None or not eng.training:
+            self._pending_opt = state
+            return
+        import torch
+        m, v, t = state
+        Wz = eng.flat_to_keras(np.zeros(eng.n_flat, np.float32), moving=False)       # zeros for anything the state does not name
+        eng.M.copy_(torch.from_numpy(eng.keras_to_flat(dict(Wz, **m))))
+        eng.V.copy_(torch.from_numpy(eng.keras_to_flat(dict(Wz, **v))))
+        eng.t = int(t)
+        self._pending_opt = None
+
+    def save_weights(self, path):
+        self.save(path, include_optimizer=False, weights_only=True)
+
+    def _checkpoint_meta(self):
+        return dict(format="fmri-npz-1", builder=self._builder, builder_kwargs=_jsonable(self._builder_kwargs),
                     optimizer=self.optimizer.get_config() if self.optimizer else None,
                     loss=getattr(self.loss, "__name__", None),
                     metrics=[m if isinstance(m, str) else getattr(m, "__name__", str(m)) for m in self.metrics])
-        if include_optimizer and self._engine is not None and self._engine.training:
-            arrays["opt/m"] = self._engine.M.cpu().numpy()
-            arrays["opt/v"] = self._engine.V.cpu().numpy()
-            meta["opt_t"] = self._engine.t
-        arrays["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+
+    def save(self, path, include_optimizer=True, weights_only=False):
+        """Full-model checkpoint in the reference's container: a Keras 2.2 HDF5 file (reference training.py:31-32 via ModelCheckpoint;
+        layout restated in keras_h5.py) written through the system libhdf5.  Where no libhdf5 can be loaded the container is a numpy
+        .npz under the SAME file name (naming and resume-by-mtime keep working: reference fetal/utils.py:42-43); `load_weights` and
+        `load_old_model` tell the two apart by their magic bytes."""
+        from .utils import hdf5
         tmp = path + ".tmp"
+        if hdf5.available() and os.environ.get("FMRI_CHECKPOINT_FORMAT", "h5") != "npz":
+            from . import keras_h5
+            keras_h5.save_model(self, tmp, include_optimizer=include_optimizer, weights_only=weights_only,
+                                extra_meta=self._checkpoint_meta())
+            os.replace(tmp, path)
+            return
+        W = self.get_weights_dict()
+        arrays = {"w/" + k: v for k, v in W.items()}
+        meta = self._checkpoint_meta()
+        state = self.get_optimizer_state() if include_optimizer else None
+        if state is not None:
+            for k, a in state[0].items():
+                arrays["opt_m/" + k] = a
+            for k, a in state[1].items():
+                arrays["opt_v/" + k] = a
+            meta["opt_t"] = state[2]
+        arrays["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
         with open(tmp, "wb") as f:
             np.savez(f, **arrays)
         os.replace(tmp, path)
 
     def load_weights(self, path, by_name=False):
-        z = np.load(path, allow_pickle=False)
-        W = OrderedDict((k[2:], z[k]) for k in z.files if k.startswith("w/"))
-        self.set_weights_dict(W)
-        if "opt/m" in z.files:
-            t = int(json.loads(bytes(z["meta"]).decode()).get("opt_t", 0))
-            if self._engine is not None and self._engine.training:
-                import torch
-                self._engine.M.copy_(torch.from_numpy(z["opt/m"]))
-                self._engine.V.copy_(torch.from_numpy(z["opt/v"]))
-                self._engine.t = t
-            else:
-                self._pending_opt = (z["opt/m"], z["opt/v"], t)
+        from .utils import hdf5
+        if hdf5.is_hdf5(path):
+            from . import keras_h5
+            self.set_weights_dict(keras_h5.map_weights(self, keras_h5.read_weights(path)))
+            state = keras_h5.read_optimizer(path, self)
+        else:
+            z = np.load(path, allow_pickle=False)
+            self.set_weights_dict(OrderedDict((k[2:], z[k]) for k in z.files if k.startswith("w/")))
+            state = None
+            if any(k.startswith("opt_m/") for k in z.files):
+                t = int(json.loads(bytes(z["meta"]).decode()).get("opt_t", 0))
+                state = (OrderedDict((k[6:], z[k]) for k in z.files if k.startswith("opt_m/")),
+                         OrderedDict((k[6:], z[k]) for k in z.files if k.startswith("opt_v/")), t)
+        if state is not None:
+            self._apply_optimizer_state(state)
         return self
 
 
 def read_checkpoint_meta(path):
+    """the builder call recorded in a checkpoint: this stack's own record when present, else inferred from the Keras model_config"""
+    from .utils import hdf5
+    if hdf5.is_hdf5(path):
+        from . import keras_h5
+        mc, tc, own = keras_h5.read_configs(path)
+        if own is not None:
+            return own
+        if mc is None:
+            raise ValueError("%s is a weights-only HDF5 file (no model_config): build the model and call load_weights" % path)
+        name, kwargs = keras_h5.infer_builder(mc, tc)
+        opt = tc["optimizer_config"]["config"] if tc else None
+        return dict(format="keras-h5", builder=name, builder_kwargs=kwargs, optimizer=opt)
     z = np.load(path, allow_pickle=False)
     return json.loads(bytes(z["meta"]).decode())
 

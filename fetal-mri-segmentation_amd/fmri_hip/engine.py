@@ -245,8 +245,9 @@ class UNetEngine:
         W[f["name"] + "/bias"] = np.zeros(f["cout"], np.float32)
         self.load_keras_weights(W)
 
-    def load_keras_weights(self, W):
-        """W: {'<layer>/kernel': (kD,kH,kW,Cin,Cout) ndarray, '<layer>/bias': (Cout,)} in Keras layout."""
+    def keras_to_flat(self, W):
+        """W: {'<layer>/kernel': (kD,kH,kW,Cin,Cout) ndarray, '<layer>/bias': (Cout,), '<norm>/gamma' ...} in Keras layout -> the flat
+        fp32 parameter vector of this engine (also the layout of the Adam moments)."""
         host = np.zeros(self.n_flat, np.float32)
         for name, L in self.layout.items():
             k = np.asarray(W[name + "/kernel"], np.float32)
@@ -269,14 +270,18 @@ class UNetEngine:
             if L.get("norm"):
                 host[L["gamma"][0]:L["gamma"][0] + nb] = np.asarray(W[L["norm"] + "/gamma"], np.float32)
                 host[L["beta"][0]:L["beta"][0] + nb] = np.asarray(W[L["norm"] + "/beta"], np.float32)
-                if name in self.moving and (L["norm"] + "/moving_mean") in W:
-                    self.moving[name][0].copy_(torch.from_numpy(np.asarray(W[L["norm"] + "/moving_mean"], np.float32)))
-                    self.moving[name][1].copy_(torch.from_numpy(np.asarray(W[L["norm"] + "/moving_variance"], np.float32)))
-        self.P.copy_(torch.from_numpy(host))
+        return host
+
+    def load_keras_weights(self, W):
+        self.P.copy_(torch.from_numpy(self.keras_to_flat(W)))
+        for name, L in self.layout.items():
+            if L.get("norm") and name in self.moving and (L["norm"] + "/moving_mean") in W:
+                self.moving[name][0].copy_(torch.from_numpy(np.asarray(W[L["norm"] + "/moving_mean"], np.float32)))
+                self.moving[name][1].copy_(torch.from_numpy(np.asarray(W[L["norm"] + "/moving_variance"], np.float32)))
         self.refresh_weight_copies()
 
-    def export_keras_weights(self):
-        host = self.P.detach().cpu().numpy()
+    def flat_to_keras(self, host, moving=True):
+        """inverse of keras_to_flat for any vector in the parameter layout (weights, Adam m, Adam v)"""
         W = OrderedDict()
         order = [c["name"] for c in self.plan.convs_forward_order()] + [u["name"] for u in self.plan.up.values()] + [self.plan.final["name"]]
         for name in order:
@@ -297,10 +302,13 @@ class UNetEngine:
             if L.get("norm"):
                 W[L["norm"] + "/gamma"] = host[L["gamma"][0]:L["gamma"][0] + nb].copy()
                 W[L["norm"] + "/beta"] = host[L["beta"][0]:L["beta"][0] + nb].copy()
-                if name in self.moving:
+                if moving and name in self.moving:
                     mv = self.moving[name].cpu().numpy()
                     W[L["norm"] + "/moving_mean"], W[L["norm"] + "/moving_variance"] = mv[0].copy(), mv[1].copy()
         return W
+
+    def export_keras_weights(self):
+        return self.flat_to_keras(self.P.detach().cpu().numpy())
 
     def _upcat_layers(self):
         """decoder 'a' convs (UpSampling3D -> concatenate -> Conv3D, reference unet.py:132-138,61,102) that take the parity form:

@@ -250,7 +250,7 @@ class LayerGraphEngine(object):
                 W[l.name + "/beta"] = np.zeros(self.layout[l.name]["c"], np.float32)
         self.load_keras_weights(W)
 
-    def load_keras_weights(self, W):
+    def keras_to_flat(self, W):
         host = np.zeros(self.n_flat, np.float32)
         for name, Lc in self.layout.items():
             if Lc["kind"] == "conv":
@@ -264,11 +264,13 @@ class LayerGraphEngine(object):
                 for key in ("gamma", "beta"):
                     o, n = Lc[key]
                     host[o:o + n] = np.asarray(W[name + "/" + key], np.float32)
-        self.P.copy_(torch.from_numpy(host))
+        return host
+
+    def load_keras_weights(self, W):
+        self.P.copy_(torch.from_numpy(self.keras_to_flat(W)))
         self.refresh_weight_copies()
 
-    def export_keras_weights(self):
-        host = self.P.detach().cpu().numpy()
+    def flat_to_keras(self, host, moving=True):
         W = OrderedDict()
         for l in self.layers:
             name = l.name
@@ -283,6 +285,9 @@ class LayerGraphEngine(object):
                     o, n = self.layout[name][key]
                     W[name + "/" + key] = host[o:o + n].copy()
         return W
+
+    def export_keras_weights(self):
+        return self.flat_to_keras(self.P.detach().cpu().numpy())
 
     def refresh_weight_copies(self):
         if self.pad:

@@ -252,3 +252,46 @@ def test_2d_patch_wise_prediction_device_path_equals_host_tiling():
         host = patch_wise_prediction(Proxy(), vol, (32, 32, 5), overlap_factor=0.5, batch_size=bs)
         assert dev.shape == host.shape == (48, 40, 12, 1)
         np.testing.assert_allclose(dev, host, rtol=0, atol=2e-6)
+
+
+@pytest.mark.parametrize("variant", ["unet3d_bn_deconv", "unet2d_deconv", "isensee"])
+def test_hdf5_checkpoint_resumes_training_exactly(tmp_path, monkeypatch, variant):
+    """save() after 3 steps -> load_old_model() -> both models take 2 more identical steps: same losses, same weights, i.e. the
+    Keras-layout file carries weights, BatchNorm moving statistics, Adam moments and the step counter losslessly."""
+    from fetal_net.utils import hdf5
+    if not hdf5.available():
+        pytest.skip("no libhdf5 on this host")
+    monkeypatch.setenv("FMRI_DTYPE", "fp32")
+    import fetal_net.model as fmodel
+    from fetal_net.training import load_old_model
+    rng = np.random.RandomState(11)
+    if variant == "unet3d_bn_deconv":
+        model = fmodel.unet_model_3d(input_shape=(1, 8, 16, 16), depth=2, n_base_filters=8, deconvolution=True, batch_normalization=True,
+                                     initial_learning_rate=1e-2)
+        xs = [rng.standard_normal((2, 1, 8, 16, 16)) for _ in range(5)]
+        ys = [(rng.random_sample((2, 1, 8, 16, 16)) > 0.6).astype(np.uint8) for _ in range(5)]
+    elif variant == "unet2d_deconv":
+        model = fmodel.unet_model_2d(input_shape=(16, 16, 3), depth=2, n_base_filters=8, deconvolution=True, initial_learning_rate=1e-2)
+        xs = [rng.standard_normal((4, 16, 16, 3)) for _ in range(5)]
+        ys = [(rng.random_sample((4, 16, 16, 1)) > 0.6).astype(np.uint8) for _ in range(5)]
+    else:
+        model = fmodel.isensee2017_model_3d(input_shape=(1, 16, 16, 16), depth=3, n_base_filters=4, dropout_rate=0.0,
+                                            initial_learning_rate=1e-2)
+        xs = [rng.standard_normal((2, 1, 16, 16, 16)) for _ in range(5)]
+        ys = [(rng.random_sample((2, 1, 16, 16, 16)) > 0.6).astype(np.uint8) for _ in range(5)]
+    for i in range(3):
+        model.train_on_batch(xs[i], ys[i])
+    path = str(tmp_path / "ckpt.h5")
+    model.save(path)
+    assert hdf5.is_hdf5(path)
+    twin = load_old_model(path, verbose=False)
+    Wa, Wb = model.get_weights_dict(), twin.get_weights_dict()
+    assert set(Wa) == set(Wb) and all(np.array_equal(Wa[k], Wb[k]) for k in Wa)
+    for i in range(3, 5):
+        la = model.train_on_batch(xs[i], ys[i])
+        lb = twin.train_on_batch(xs[i], ys[i])
+        assert la[0] == pytest.approx(lb[0], abs=1e-5)
+    assert twin._engine.t == model._engine.t == 5
+    Wa, Wb = model.get_weights_dict(), twin.get_weights_dict()
+    for k in Wa:
+        np.testing.assert_allclose(Wb[k], Wa[k], atol=2e-5, err_msg=k)
