@@ -83,6 +83,19 @@ __device__ __forceinline__ void dma16_s(const void* sbase, unsigned voff, unsign
                  : "v"(voff), "s"(sbase), "s"(lds_dst)
                  : "memory");
 }
+// max of two non-NaN-critical floats as ONE v_max_f32 (fmaxf adds a canonicalising v_max x,x per operand)
+__device__ __forceinline__ float vmax(float a, float b) {
+    float o;
+    asm("v_max_f32 %0, %1, %2" : "=v"(o) : "v"(a), "v"(b));
+    return o;
+}
+// two floats -> one dword of bf16 (one v_cvt_pk_bf16_f32)
+__device__ __forceinline__ unsigned pack2bf(float a, float b) {
+    typedef __attribute__((ext_vector_type(2))) float f32x2;
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+    const f32x2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+}
 __device__ __forceinline__ unsigned lds_addr(const void* p) {
     return (unsigned)(size_t)(__attribute__((address_space(3))) const unsigned char*)p;
 }
@@ -249,14 +262,31 @@ k_conv_fwd_mfma(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__
     };
 
     f32x16 acc[2][NT];
-    float4 bv[NT][4];              // this lane's 4 x 4 bias values per 32-channel tile (fetched during the last chunk's first phase)
-    float4 bq = make_float4(0.f, 0.f, 0.f, 0.f), bq1 = bq;   // RES epilogue: bias of the 8 channels this lane finishes (line-major layout)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
+    // The accumulators of a tile START from its bias (MFMA D rows = output channel (reg&3) + 8*(reg>>2) + 4*hk), so the
+    // epilogue has no bias add and needs no bias registers during the phase loop; the next tile's values are fetched inside the
+    // epilogue, under the LDS transposition.  The activation is branch-free: act(v) = max(v, fma(v, act_s, +0)) with act_s = 0 (ReLU),
+    // alpha (LeakyReLU) or 1 (none) - per-element `if (act == ...)` compiled to ~500 scalar compare/branch pairs per tile.
+    const float act_s = act == FMRI_ACT_RELU ? 0.f : (act == FMRI_ACT_LEAKY ? alpha : 1.f);
+    auto load_bias = [&](int co0, float4 (&bv)[NT][4]) {
 #pragma unroll
         for (int c = 0; c < NT; ++c)
 #pragma unroll
-            for (int k = 0; k < 16; ++k) acc[j][c][k] = 0.f;
+            for (int gq = 0; gq < 4; ++gq)
+                bv[c][gq] = bias ? *reinterpret_cast<const float4*>(bias + co0 + c * 32 + 8 * gq + 4 * hk) : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    auto init_acc = [&](const float4 (&bv)[NT][4]) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int c = 0; c < NT; ++c)
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    acc[j][c][4 * gq] = bv[c][gq].x;
+                    acc[j][c][4 * gq + 1] = bv[c][gq].y;
+                    acc[j][c][4 * gq + 2] = bv[c][gq].z;
+                    acc[j][c][4 * gq + 3] = bv[c][gq].w;
+                }
+    };
 
     // per-lane halo index (before adding the tap offset) of this lane's voxel in the wave's two column tiles
     // Lane r of a 32-voxel column tile covers h-row (r>>4) and w = wl.  The second h-row is rotated by 2 (= HW mod 16) so that
@@ -281,6 +311,11 @@ k_conv_fwd_mfma(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__
     int pair = blockIdx.x;
     if (pair >= npairs) return;
     FwdItem cur = decode(pair, 0);
+    {
+        float4 bv0[NT][4];
+        load_bias(cur.co0, bv0);
+        init_acc(bv0);
+    }
     // prologue: the whole halo of the first item and its first filter slab
 #pragma unroll
     for (int ph = 0; ph < 9; ++ph) {
@@ -336,26 +371,6 @@ k_conv_fwd_mfma(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__
                 }
             };
             issue_dma();
-            if (RES && pl == 0 && cur.ch == nch - 1) {
-                bq = bias ? *reinterpret_cast<const float4*>(bias + cur.co0 + 8 * (lane % (BN / 8))) : make_float4(0.f, 0.f, 0.f, 0.f);
-                bq1 = bias ? *reinterpret_cast<const float4*>(bias + cur.co0 + 8 * (lane % (BN / 8)) + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-            if (!RES && pl == 0 && cur.ch == nch - 1) {
-                // the epilogue's bias, fetched a chunk ahead: 8 dependent L2 round trips inside the epilogue cost 23 % of the
-                // kernel at Cin = 32 (tools/prof_phases.py)
-                if (bias) {
-#pragma unroll
-                    for (int c = 0; c < NT; ++c)
-#pragma unroll
-                        for (int gq = 0; gq < 4; ++gq)
-                            bv[c][gq] = *reinterpret_cast<const float4*>(bias + cur.co0 + c * 32 + 8 * gq + 4 * hk);
-                } else {
-#pragma unroll
-                    for (int c = 0; c < NT; ++c)
-#pragma unroll
-                        for (int gq = 0; gq < 4; ++gq) bv[c][gq] = make_float4(0.f, 0.f, 0.f, 0.f);
-                }
-            }
             PROF_T(t3);
             const unsigned char* const lf = lds + 2 * HALO_BYTES + (g & 1) * FILT_BYTES;
             // halo row offset of this phase's (kd,kh) and of its kw taps.  Up modes: phase = (kd',kh') in {0,1}^2 shifted by the
@@ -400,8 +415,11 @@ k_conv_fwd_mfma(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__
             constexpr int PPV = BN / 4;                  // 16-byte fp32 pieces per voxel
             constexpr int LPV = BN / 8;                  // lanes per voxel
             constexpr int VPI = 64 / LPV;                // voxels per instruction
+            float4 bvn[NT][4];
+            load_bias(has_next ? nxt.co0 : cur.co0, bvn);
             __builtin_amdgcn_s_barrier();
             unsigned char* const stage = lds + hb * HALO_BYTES + wv * (32 * BN * 4);
+            const int64_t org = ((((int64_t)cur.n * D + cur.d0) * H + cur.h0) * W + cur.w0) * Cout + cur.co0;
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
 #pragma unroll
@@ -411,8 +429,6 @@ k_conv_fwd_mfma(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__
                         const int q = c * 8 + 2 * gq + hk;
                         *reinterpret_cast<float4*>(stage + r * (BN * 4) + (((q ^ r) & (PPV - 1)) << 4)) =
                             make_float4(acc[j][c][4 * gq], acc[j][c][4 * gq + 1], acc[j][c][4 * gq + 2], acc[j][c][4 * gq + 3]);
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) acc[j][c][4 * gq + i] = 0.f;
                     }
                 const int rt = 2 * wv + j;
 #pragma unroll
@@ -420,23 +436,18 @@ k_conv_fwd_mfma(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__
                     const int rr = kk * VPI + lane / LPV, q8 = lane % LPV;
                     const float4 a0 = *reinterpret_cast<const float4*>(stage + rr * (BN * 4) + ((((2 * q8) ^ rr) & (PPV - 1)) << 4));
                     const float4 a1 = *reinterpret_cast<const float4*>(stage + rr * (BN * 4) + ((((2 * q8 + 1) ^ rr) & (PPV - 1)) << 4));
-                    const int d = cur.d0 + tile_d(rt), h = cur.h0 + tile_h(rt, rr), w = cur.w0 + lane_w(rr);
-                    const int64_t ao = ((((int64_t)cur.n * D + d) * H + h) * W + w) * Cout + cur.co0 + q8 * 8;
+                    const int64_t ao = org + ((tile_d(rt) * H + tile_h(rt, rr)) * W + lane_w(rr)) * Cout + q8 * 8;
                     const uint4 r4 = *reinterpret_cast<const uint4*>(residual + ao);
-                    float o[8] = {a0.x + __uint_as_float(r4.x << 16) + bq.x, a0.y + __uint_as_float(r4.x & 0xffff0000u) + bq.y,
-                                  a0.z + __uint_as_float(r4.y << 16) + bq.z, a0.w + __uint_as_float(r4.y & 0xffff0000u) + bq.w,
-                                  a1.x + __uint_as_float(r4.z << 16) + bq1.x, a1.y + __uint_as_float(r4.z & 0xffff0000u) + bq1.y,
-                                  a1.z + __uint_as_float(r4.w << 16) + bq1.z, a1.w + __uint_as_float(r4.w & 0xffff0000u) + bq1.w};
+                    float o[8] = {a0.x + __uint_as_float(r4.x << 16), a0.y + __uint_as_float(r4.x & 0xffff0000u),
+                                  a0.z + __uint_as_float(r4.y << 16), a0.w + __uint_as_float(r4.y & 0xffff0000u),
+                                  a1.x + __uint_as_float(r4.z << 16), a1.y + __uint_as_float(r4.z & 0xffff0000u),
+                                  a1.z + __uint_as_float(r4.w << 16), a1.w + __uint_as_float(r4.w & 0xffff0000u)};
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        if (act == FMRI_ACT_RELU) o[i] = fmaxf(o[i], 0.f);
-                        else if (act == FMRI_ACT_LEAKY) o[i] = o[i] > 0.f ? o[i] : alpha * o[i];
-                    }
-                    *reinterpret_cast<uint4*>(y + ao) =
-                        make_uint4((unsigned)f2bf(o[0]) | ((unsigned)f2bf(o[1]) << 16), (unsigned)f2bf(o[2]) | ((unsigned)f2bf(o[3]) << 16),
-                                   (unsigned)f2bf(o[4]) | ((unsigned)f2bf(o[5]) << 16), (unsigned)f2bf(o[6]) | ((unsigned)f2bf(o[7]) << 16));
+                    for (int i = 0; i < 8; ++i) o[i] = vmax(o[i], __builtin_fmaf(o[i], act_s, 0.f));
+                    *reinterpret_cast<uint4*>(y + ao) = make_uint4(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]), pack2bf(o[4], o[5]), pack2bf(o[6], o[7]));
                 }
             }
+            init_acc(bvn);
         }
         if (!RES && cur.ch == nch - 1) {
             // ---- epilogue.  D rows = output channel (reg&3)+8*(reg>>2)+4*hk, D cols = voxel r: a lane owns 4-channel pieces of ONE
@@ -448,6 +459,8 @@ k_conv_fwd_mfma(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__
             constexpr int CPV = BN / 8;                  // 16-byte pieces per voxel
             constexpr int VPI = 64 / CPV;                // voxels per store instruction
             constexpr int SWM = NT == 2 ? 7 : 3;         // piece swizzle: row v keeps piece q at slot q ^ sw(v)
+            float4 bvn[NT][4];                           // bias of the next tile (lands while this one is packed)
+            load_bias(has_next ? nxt.co0 : cur.co0, bvn);
             __builtin_amdgcn_s_barrier();
             PROF_T(te2);
             unsigned char* const stage = lds + hb * HALO_BYTES + wv * (64 * BN * 2);
@@ -463,18 +476,14 @@ k_conv_fwd_mfma(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__
 #pragma unroll
                         for (int u = 0; u < 2; ++u) {
                             const int gq = 2 * pq + u;
-                            const float bvv[4] = {bv[c][gq].x, bv[c][gq].y, bv[c][gq].z, bv[c][gq].w};
                             float o[4];
 #pragma unroll
                             for (int i = 0; i < 4; ++i) {
-                                float vv = acc[j][c][4 * gq + i] + bvv[i];
-                                if (act == FMRI_ACT_RELU) vv = fmaxf(vv, 0.f);
-                                else if (act == FMRI_ACT_LEAKY) vv = vv > 0.f ? vv : alpha * vv;
-                                o[i] = vv;
-                                acc[j][c][4 * gq + i] = 0.f;
+                                const float vv = acc[j][c][4 * gq + i];
+                                o[i] = vmax(vv, __builtin_fmaf(vv, act_s, 0.f));
                             }
-                            pk[u][0] = (unsigned)f2bf(o[0]) | ((unsigned)f2bf(o[1]) << 16);
-                            pk[u][1] = (unsigned)f2bf(o[2]) | ((unsigned)f2bf(o[3]) << 16);
+                            pk[u][0] = pack2bf(o[0], o[1]);
+                            pk[u][1] = pack2bf(o[2], o[3]);
                         }
                         // half-wave exchange: lanes 0-31 end up with channels 16pq..16pq+7 of their voxel, lanes 32-63 with +8..+15
 #pragma unroll
@@ -489,6 +498,7 @@ k_conv_fwd_mfma(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__
                     }
                 }
             }
+            init_acc(bvn);
             PROF_T(te3);
             PROF_ADD(7, te0, te2); PROF_ADD(8, te2, te3);
 #pragma unroll
@@ -497,13 +507,16 @@ k_conv_fwd_mfma(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__
                 const int vs = NT == 2 ? (v & 7) : ((v >> 2) & 3);
                 uint4 o4 = *reinterpret_cast<const uint4*>(stage + v * (BN * 2) + (((q ^ vs) & SWM) << 4));
                 const int rt = 2 * wv + (v >> 5), rr = v & 31;
-                const int d = cur.d0 + tile_d(rt), h = cur.h0 + tile_h(rt, rr), w = cur.w0 + lane_w(rr);
+                // wave-uniform 64-bit tile origin + 32-bit offset inside the tile's bounding box
                 int64_t ao;
-                if constexpr (MODE == 1)     // parity class p of the [2D][2H][2W] output
-                    ao = ((((int64_t)cur.n * 2 * D + 2 * d + (cur.par >> 2)) * 2 * H + 2 * h + ((cur.par >> 1) & 1)) * 2 * W + 2 * w + (cur.par & 1)) * Cout +
-                         cur.co0 + q * 8;
-                else
-                    ao = ((((int64_t)cur.n * D + d) * H + h) * W + w) * Cout + cur.co0 + q * 8;
+                if constexpr (MODE == 1) {   // parity class p of the [2D][2H][2W] output
+                    const int64_t org = ((((int64_t)cur.n * 2 * D + 2 * cur.d0 + (cur.par >> 2)) * 2 * H + 2 * cur.h0 + ((cur.par >> 1) & 1)) * 2 * W +
+                                         2 * cur.w0 + (cur.par & 1)) * Cout + cur.co0;
+                    ao = org + ((2 * tile_d(rt) * 2 * H + 2 * tile_h(rt, rr)) * 2 * W + 2 * lane_w(rr)) * Cout + q * 8;
+                } else {
+                    const int64_t org = ((((int64_t)cur.n * D + cur.d0) * H + cur.h0) * W + cur.w0) * Cout + cur.co0;
+                    ao = org + ((tile_d(rt) * H + tile_h(rt, rr)) * W + lane_w(rr)) * Cout + q * 8;
+                }
                 if (mask) {
                     const uint4 m4 = *reinterpret_cast<const uint4*>(mask + ao);
                     const unsigned mm[4] = {m4.x, m4.y, m4.z, m4.w};
