@@ -14,6 +14,7 @@ MI355X layout decisions
   * every tensor is allocated once at build time (288 GB HBM: no re-computation, no allocator traffic in the step).
 """
 import math
+import os
 from collections import OrderedDict
 
 import numpy as np
@@ -96,6 +97,7 @@ class UNetEngine:
         self.planar = plan.ndim == 2      # 2-D: tensors are [1][slices][H][W][C], every op is planar (no coupling along D)
         self.dist = dist_ctx
         self.t = 0                       # Adam step counter
+        self._pack_stream, self._pack_event, self._pack_pending = None, None, False
         self.loss_kind, self.loss_param = 0, 1.0      # ops.LOSS_KINDS: 0 = dice_coefficient_loss
         self._bufsets = {}
         self._build_params(seed)
@@ -333,13 +335,43 @@ class UNetEngine:
                     self.upcat_wgrad.add(a["name"])
         return out
 
-    def refresh_weight_copies(self):
+    def refresh_weight_copies(self, overlap=False):
+        """compute-dtype images of the fp32 parameters (forward filters, tap-flipped transposed filters for the input gradients, parity
+        filters).  overlap=True (the optimizer step): only the first encoder level is repacked on the current stream; the other layers -
+        whose weights are the large ones and are first read a whole level later - are repacked on a side stream that `forward` joins
+        after level 0, i.e. under the first convolutions of the NEXT step instead of in front of them."""
+        early = set(c["name"] for c in self.plan.enc[0])
+        if overlap and self.dev.type == "cuda" and os.environ.get("FMRI_PACK_OVERLAP", "1") != "0":
+            if self._pack_stream is None:
+                self._pack_stream = torch.cuda.Stream(device=self.dev)
+                self._pack_event = torch.cuda.Event()
+            self._repack(lambda name: name in early)
+            main = torch.cuda.current_stream(self.dev)
+            self._pack_stream.wait_stream(main)
+            with torch.cuda.stream(self._pack_stream):
+                self._repack(lambda name: name not in early)
+                self._pack_event.record(self._pack_stream)
+            self._pack_pending = True
+            return
+        self._join_packs()
+        self._repack(lambda name: True)
+
+    def _join_packs(self):
+        if self._pack_pending:
+            torch.cuda.current_stream(self.dev).wait_event(self._pack_event)
+            self._pack_pending = False
+
+    def _repack(self, want):
         for name in self.Wf:
-            ops.pack_weights(self.w_view(name), self.Wf[name], self.Wd.get(name))
+            if want(name):
+                ops.pack_weights(self.w_view(name), self.Wf[name], self.Wd.get(name))
         for name, W in self.Wup.items():
-            c0, c1 = self.upcat[name]
-            ops.conv3d_pack_up_weights(self.w_view(name), c0, c1, W["up_f"], W["up_d"], W["sk_f"], W["sk_d"])
+            if want(name):
+                c0, c1 = self.upcat[name]
+                ops.conv3d_pack_up_weights(self.w_view(name), c0, c1, W["up_f"], W["up_d"], W["sk_f"], W["sk_d"])
         for name, wt in self.Wt.items():
+            if not want(name):
+                continue
             if name in self.Wd2:
                 Wd_, L = self.Wd2[name], self.layout[name]
                 Wd_["w32"][13] = self.w_view(name)[:4].reshape(4 * L["cout"], L["cin"])
@@ -482,6 +514,8 @@ class UNetEngine:
         for ld, lv in enumerate(p.enc):
             for c in lv:
                 h = self._block_fwd(c, h, None, False, bn_training)
+            if ld == 0:
+                self._join_packs()                          # the deeper layers' weight images were repacked on the side stream
             if ld < p.depth - 1:
                 h = ops.maxpool_fwd(h, A["pool_%d" % ld], planar=self.planar)
         for lv in p.dec:
@@ -652,7 +686,7 @@ class UNetEngine:
         self.t += 1
         lr_t = lr * math.sqrt(1.0 - beta2 ** self.t) / (1.0 - beta1 ** self.t)
         ops.adam_step(self.P, self.G, self.M, self.V, lr_t, beta1, beta2, eps, grad_scale)
-        self.refresh_weight_copies()
+        self.refresh_weight_copies(overlap=True)
 
     def train_step(self, x, y_true, lr, weight=None):
         """one full step: forward, Dice, backward, (all-reduce), Adam.  Returns the device tensor of metric sums."""
