@@ -13,7 +13,7 @@ int conv3d_fwd_mfma(const void*, int, int, int, const void*, int, const void*, c
 int conv3d_wgrad_mfma(const void*, int, int, int, const void*, int, const void*, float*, float*, int, int, int, int, int, void*, int64_t,
                       hipStream_t);
 int64_t conv3d_wgrad_mfma_ws_bytes(int C0, int C1, int Cout, int N, int D, int H, int W, int planar);
-int conv3d_upcat_wgrad_mfma(const void*, int, const void*, int, const void*, float*, float*, float*, int, int, int, int, int, void*, int64_t,
+int conv3d_upcat_wgrad_mfma(const void*, int, const void*, int, const void*, float*, float*, float*, int, int, int, int, int, int, void*, int64_t,
                             hipStream_t);
 int conv3d_fwd_mfma_ex(int, const void*, int, int, int, const void*, int, const void*, const float*, const void*, const void*, void*, int, int, int,
                        int, int, int, float, hipStream_t);
@@ -95,19 +95,29 @@ namespace {
 __device__ __forceinline__ int tap_class(int p, int k) { return p == 0 ? (k >= 1) : (k >= 2); }   // 3-tap index -> combined tap t'
 
 template <typename T>
-__global__ void k_pack_up_weights(const float* __restrict__ w, int C0, int C1, int Cout, T* __restrict__ up_f, T* __restrict__ up_d,
+__global__ void k_pack_up_weights(const float* __restrict__ w, int C0, int C1, int Cout, int planar, T* __restrict__ up_f, T* __restrict__ up_d,
                                   T* __restrict__ sk_f, T* __restrict__ sk_d) {
     const int Cin = C0 + C1;
-    const int64_t n_up = (int64_t)64 * Cout * C0, n_sk = (int64_t)27 * Cout * C1;
+    const int64_t n_up = (int64_t)(planar ? 16 : 64) * Cout * C0, n_sk = (int64_t)27 * Cout * C1;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_up + n_sk; i += (int64_t)gridDim.x * blockDim.x) {
         if (i < n_up) {
             const int c0 = (int)(i % C0);
             int64_t q = i / C0;
             const int co = (int)(q % Cout);
             q /= Cout;
+            float acc = 0.f;
+            if (planar) {                        // 2-D slices: parity (ph, pw), combined taps (kh', kw'), centre kd plane only
+                const int tw = (int)(q & 1), th = (int)((q >> 1) & 1), p = (int)(q >> 2);
+                const int ph = p >> 1, pw = p & 1;
+                for (int kh = 0; kh < 3; ++kh)
+                    for (int kw = 0; kw < 3; ++kw)
+                        if (tap_class(ph, kh) == th && tap_class(pw, kw) == tw) acc += w[((int64_t)(9 + kh * 3 + kw) * Cout + co) * Cin + c0];
+                if (up_f) up_f[i] = from_f<T>(acc);
+                if (up_d) up_d[(((int64_t)p * 2 + (1 - th)) * 2 + (1 - tw)) * C0 * Cout + (int64_t)c0 * Cout + co] = from_f<T>(acc);
+                continue;
+            }
             const int tw = (int)(q & 1), th = (int)((q >> 1) & 1), td = (int)((q >> 2) & 1), p = (int)(q >> 3);
             const int pd = p >> 2, ph = (p >> 1) & 1, pw = p & 1;
-            float acc = 0.f;
             for (int kd = 0; kd < 3; ++kd)
                 for (int kh = 0; kh < 3; ++kh)
                     for (int kw = 0; kw < 3; ++kw)
@@ -126,76 +136,120 @@ __global__ void k_pack_up_weights(const float* __restrict__ w, int C0, int C1, i
         }
     }
 }
-}  // namespace
 
-extern "C" int fmri_conv3d_upcat_ok(int C0, int C1, int Cout, int D, int H, int W, int dtype) {
-    // D,H,W = output (full-resolution) dims; both the low-res grid and the full grid must tile.  bit 0: forward + input gradients,
-    // bit 1: weight gradient
-    if ((D | H | W) & 1) return 0;
-    if (C0 <= 0 || C1 < 0 || Cout * 8 > 4096) return 0;             // up-backward sends 8*Cout channels of dy through the zero page
+// D,H,W = output (full-resolution) dims; planar: D = number of slices (not up-sampled).  bit 0: forward + input gradients, bit 1: weight gradient
+int upcat_ok(int C0, int C1, int Cout, int D, int H, int W, int dtype, int planar) {
+    if (((planar ? 0 : D) | H | W) & 1) return 0;
+    const int Dl = planar ? D : D / 2;
+    if (C0 <= 0 || C1 < 0 || Cout * (planar ? 4 : 8) > 4096) return 0;       // up-backward sends (classes x Cout) channels of dy through the zero page
     // C1 = 0: a convolution of a purely up-sampled tensor (reference isensee2017.py:101-104 create_up_sampling_module)
-    if (conv3d_fwd_needs_cube(D / 2, H / 2, W / 2) || conv3d_fwd_needs_cube(D, H, W)) return 0;      // the parity launches use the 4x8x16 tiling
-    const bool fb = conv3d_fwd_mfma_ok(C0, 0, Cout, D / 2, H / 2, W / 2, dtype) && conv3d_fwd_mfma_ok(Cout, 0, C0, D / 2, H / 2, W / 2, dtype) &&
+    if (conv3d_fwd_needs_cube(Dl, H / 2, W / 2) || conv3d_fwd_needs_cube(D, H, W)) return 0;      // the parity launches use the 4x8x16 tiling
+    const bool fb = conv3d_fwd_mfma_ok(C0, 0, Cout, Dl, H / 2, W / 2, dtype) && conv3d_fwd_mfma_ok(Cout, 0, C0, Dl, H / 2, W / 2, dtype) &&
                     (C1 == 0 || (conv3d_fwd_mfma_ok(C1, 0, Cout, D, H, W, dtype) && conv3d_fwd_mfma_ok(Cout, 0, C1, D, H, W, dtype)));
-    const bool wg_ = conv3d_wgrad_mfma_ok(C0, 0, Cout, D / 2, H / 2, W / 2, dtype) && (C1 == 0 || conv3d_wgrad_mfma_ok(C1, 0, Cout, D, H, W, dtype));
+    const bool wg_ = conv3d_wgrad_mfma_ok(C0, 0, Cout, Dl, H / 2, W / 2, dtype) && (C1 == 0 || conv3d_wgrad_mfma_ok(C1, 0, Cout, D, H, W, dtype));
     return (fb ? 1 : 0) | (fb && wg_ ? 2 : 0);
 }
 
-extern "C" int fmri_conv3d_pack_up_weights(const float* w, int C0, int C1, int Cout, void* w_up_fwd, void* w_up_dgrad, void* w_skip_fwd,
-                                           void* w_skip_dgrad, int dtype, fmri_stream_t stream) {
+int upcat_pack(const float* w, int C0, int C1, int Cout, void* w_up_fwd, void* w_up_dgrad, void* w_skip_fwd, void* w_skip_dgrad, int dtype,
+               int planar, fmri_stream_t stream) {
     if (!w || C0 <= 0 || C1 < 0 || Cout <= 0) return FMRI_E_SHAPE;
-    const int grid = grid_for((int64_t)64 * Cout * C0 + (int64_t)27 * Cout * C1, 256, 1024);
+    const int grid = grid_for((int64_t)(planar ? 16 : 64) * Cout * C0 + (int64_t)27 * Cout * C1, 256, 1024);
     if (dtype == FMRI_BF16)
-        k_pack_up_weights<bf16_t><<<grid, 256, 0, as_stream(stream)>>>(w, C0, C1, Cout, (bf16_t*)w_up_fwd, (bf16_t*)w_up_dgrad, (bf16_t*)w_skip_fwd,
-                                                                        (bf16_t*)w_skip_dgrad);
+        k_pack_up_weights<bf16_t><<<grid, 256, 0, as_stream(stream)>>>(w, C0, C1, Cout, planar, (bf16_t*)w_up_fwd, (bf16_t*)w_up_dgrad,
+                                                                        (bf16_t*)w_skip_fwd, (bf16_t*)w_skip_dgrad);
     else if (dtype == FMRI_F32)
-        k_pack_up_weights<float><<<grid, 256, 0, as_stream(stream)>>>(w, C0, C1, Cout, (float*)w_up_fwd, (float*)w_up_dgrad, (float*)w_skip_fwd,
-                                                                       (float*)w_skip_dgrad);
+        k_pack_up_weights<float><<<grid, 256, 0, as_stream(stream)>>>(w, C0, C1, Cout, planar, (float*)w_up_fwd, (float*)w_up_dgrad,
+                                                                       (float*)w_skip_fwd, (float*)w_skip_dgrad);
     else return FMRI_E_DTYPE;
     FMRI_LAUNCH_CHECK();
     return FMRI_OK;
 }
 
-extern "C" int fmri_conv3d_upcat_fwd(const void* src0_low, int C0, const void* src1, int C1, const void* w_up_fwd, const void* w_skip_fwd,
-                                     const float* bias, void* y, int N, int D, int H, int W, int Cout, int act, float alpha, int dtype,
-                                     fmri_stream_t stream) {
+int upcat_fwd(const void* src0_low, int C0, const void* src1, int C1, const void* w_up_fwd, const void* w_skip_fwd, const float* bias, void* y,
+              int N, int D, int H, int W, int Cout, int act, float alpha, int dtype, int planar, fmri_stream_t stream) {
     if (!src0_low || !w_up_fwd || !y || N <= 0 || (C1 > 0 && (!src1 || !w_skip_fwd))) return FMRI_E_SHAPE;
-    if (!(fmri_conv3d_upcat_ok(C0, C1, Cout, D, H, W, dtype) & 1)) return FMRI_E_SHAPE;
+    if (!(upcat_ok(C0, C1, Cout, D, H, W, dtype, planar) & 1)) return FMRI_E_SHAPE;
     if ((((uintptr_t)src0_low) | ((uintptr_t)src1) | ((uintptr_t)w_up_fwd) | ((uintptr_t)w_skip_fwd) | ((uintptr_t)y)) & 15) return FMRI_E_ALIGN;
+    const int Dl = planar ? D : D / 2;
     if (C1 == 0)        // nothing to add: the parity launch finishes the output itself
-        return conv3d_fwd_mfma_ex(1, src0_low, C0, 0, 0, nullptr, 0, w_up_fwd, bias, nullptr, nullptr, y, N, D / 2, H / 2, W / 2, Cout, act, alpha,
+        return conv3d_fwd_mfma_ex(1, src0_low, C0, 0, planar, nullptr, 0, w_up_fwd, bias, nullptr, nullptr, y, N, Dl, H / 2, W / 2, Cout, act, alpha,
                                   as_stream(stream));
     // 1. partial sums of the up-sampled channels, scattered by parity class into y
-    int rc = conv3d_fwd_mfma_ex(1, src0_low, C0, 0, 0, nullptr, 0, w_up_fwd, nullptr, nullptr, nullptr, y, N, D / 2, H / 2, W / 2, Cout,
+    int rc = conv3d_fwd_mfma_ex(1, src0_low, C0, 0, planar, nullptr, 0, w_up_fwd, nullptr, nullptr, nullptr, y, N, Dl, H / 2, W / 2, Cout,
                                 FMRI_ACT_NONE, 0.f, as_stream(stream));
     if (rc) return rc;
     // 2. plain conv over the skip channels; its epilogue adds the partial sums (in place), the bias, and applies the activation
-    return conv3d_fwd_mfma_ex(0, src1, C1, 0, 0, nullptr, 0, w_skip_fwd, bias, nullptr, y, y, N, D, H, W, Cout, act, alpha, as_stream(stream));
+    return conv3d_fwd_mfma_ex(0, src1, C1, 0, planar, nullptr, 0, w_skip_fwd, bias, nullptr, y, y, N, D, H, W, Cout, act, alpha, as_stream(stream));
 }
 
-extern "C" int fmri_conv3d_upcat_dgrad(const void* dy, int Cout, const void* w_up_dgrad, const void* w_skip_dgrad, const void* mask_low,
-                                       const void* mask_skip, void* dx_low, void* dx_skip, int N, int D, int H, int W, int C0, int C1, int dtype,
-                                       fmri_stream_t stream) {
+int upcat_dgrad(const void* dy, int Cout, const void* w_up_dgrad, const void* w_skip_dgrad, const void* mask_low, const void* mask_skip,
+                void* dx_low, void* dx_skip, int N, int D, int H, int W, int C0, int C1, int dtype, int planar, fmri_stream_t stream) {
     if (!dy || !w_up_dgrad || !dx_low || N <= 0 || (C1 > 0 && (!w_skip_dgrad || !dx_skip))) return FMRI_E_SHAPE;
-    if (!(fmri_conv3d_upcat_ok(C0, C1, Cout, D, H, W, dtype) & 1)) return FMRI_E_SHAPE;
+    if (!(upcat_ok(C0, C1, Cout, D, H, W, dtype, planar) & 1)) return FMRI_E_SHAPE;
     if ((((uintptr_t)dy) | ((uintptr_t)w_up_dgrad) | ((uintptr_t)w_skip_dgrad) | ((uintptr_t)dx_low) | ((uintptr_t)dx_skip) | ((uintptr_t)mask_low) |
          ((uintptr_t)mask_skip)) & 15)
         return FMRI_E_ALIGN;
-    // gradient of the low-res tensor: one launch over the space-to-depth view of dy (8 parity classes x Cout channels, mirrored taps)
-    int rc = conv3d_fwd_mfma_ex(2, dy, Cout, 0, 0, nullptr, 0, w_up_dgrad, nullptr, mask_low, nullptr, dx_low, N, D / 2, H / 2, W / 2, C0,
-                                FMRI_ACT_NONE, 0.f, as_stream(stream));
+    // gradient of the low-res tensor: one launch over the space-to-depth view of dy (parity classes x Cout channels, mirrored taps)
+    int rc = conv3d_fwd_mfma_ex(2, dy, Cout, 0, planar, nullptr, 0, w_up_dgrad, nullptr, mask_low, nullptr, dx_low, N, planar ? D : D / 2, H / 2,
+                                W / 2, C0, FMRI_ACT_NONE, 0.f, as_stream(stream));
     if (rc || C1 == 0) return rc;
     // gradient of the skip tensor: the plain tap-flipped transposed convolution restricted to the skip rows
-    return conv3d_fwd_mfma_ex(0, dy, Cout, 0, 0, nullptr, 0, w_skip_dgrad, nullptr, mask_skip, nullptr, dx_skip, N, D, H, W, C1, FMRI_ACT_NONE, 0.f,
-                              as_stream(stream));
+    return conv3d_fwd_mfma_ex(0, dy, Cout, 0, planar, nullptr, 0, w_skip_dgrad, nullptr, mask_skip, nullptr, dx_skip, N, D, H, W, C1, FMRI_ACT_NONE,
+                              0.f, as_stream(stream));
 }
 
+int upcat_wgrad(const void* src0_low, int C0, const void* src1, int C1, const void* dy, float* dw, float* db, float* dwc_scratch, int N, int D,
+                int H, int W, int Cout, int dtype, int planar, void* workspace, int64_t workspace_bytes, fmri_stream_t stream) {
+    if (!src0_low || !dy || !dw || !dwc_scratch || N <= 0 || (C1 > 0 && !src1)) return FMRI_E_SHAPE;
+    if (!(upcat_ok(C0, C1, Cout, D, H, W, dtype, planar) & 2)) return FMRI_E_SHAPE;
+    if ((((uintptr_t)src0_low) | ((uintptr_t)src1) | ((uintptr_t)dy)) & 15) return FMRI_E_ALIGN;
+    return conv3d_upcat_wgrad_mfma(src0_low, C0, src1, C1, dy, dw, db, dwc_scratch, N, D, H, W, Cout, planar, workspace, workspace_bytes,
+                                   as_stream(stream));
+}
+}  // namespace
+
+extern "C" int fmri_conv3d_upcat_ok(int C0, int C1, int Cout, int D, int H, int W, int dtype) { return upcat_ok(C0, C1, Cout, D, H, W, dtype, 0); }
+extern "C" int fmri_conv3d_pack_up_weights(const float* w, int C0, int C1, int Cout, void* w_up_fwd, void* w_up_dgrad, void* w_skip_fwd,
+                                           void* w_skip_dgrad, int dtype, fmri_stream_t stream) {
+    return upcat_pack(w, C0, C1, Cout, w_up_fwd, w_up_dgrad, w_skip_fwd, w_skip_dgrad, dtype, 0, stream);
+}
+extern "C" int fmri_conv3d_upcat_fwd(const void* src0_low, int C0, const void* src1, int C1, const void* w_up_fwd, const void* w_skip_fwd,
+                                     const float* bias, void* y, int N, int D, int H, int W, int Cout, int act, float alpha, int dtype,
+                                     fmri_stream_t stream) {
+    return upcat_fwd(src0_low, C0, src1, C1, w_up_fwd, w_skip_fwd, bias, y, N, D, H, W, Cout, act, alpha, dtype, 0, stream);
+}
+extern "C" int fmri_conv3d_upcat_dgrad(const void* dy, int Cout, const void* w_up_dgrad, const void* w_skip_dgrad, const void* mask_low,
+                                       const void* mask_skip, void* dx_low, void* dx_skip, int N, int D, int H, int W, int C0, int C1, int dtype,
+                                       fmri_stream_t stream) {
+    return upcat_dgrad(dy, Cout, w_up_dgrad, w_skip_dgrad, mask_low, mask_skip, dx_low, dx_skip, N, D, H, W, C0, C1, dtype, 0, stream);
+}
 extern "C" int fmri_conv3d_upcat_wgrad(const void* src0_low, int C0, const void* src1, int C1, const void* dy, float* dw, float* db,
                                        float* dwc_scratch, int N, int D, int H, int W, int Cout, int dtype, void* workspace,
                                        int64_t workspace_bytes, fmri_stream_t stream) {
-    if (!src0_low || !dy || !dw || !dwc_scratch || N <= 0 || (C1 > 0 && !src1)) return FMRI_E_SHAPE;
-    if (!(fmri_conv3d_upcat_ok(C0, C1, Cout, D, H, W, dtype) & 2)) return FMRI_E_SHAPE;
-    if ((((uintptr_t)src0_low) | ((uintptr_t)src1) | ((uintptr_t)dy)) & 15) return FMRI_E_ALIGN;
-    return conv3d_upcat_wgrad_mfma(src0_low, C0, src1, C1, dy, dw, db, dwc_scratch, N, D, H, W, Cout, workspace, workspace_bytes,
-                                   as_stream(stream));
+    return upcat_wgrad(src0_low, C0, src1, C1, dy, dw, db, dwc_scratch, N, D, H, W, Cout, dtype, 0, workspace, workspace_bytes, stream);
+}
+
+// 2-D twins (reference fetal_net/model/unet/unet.py:60-66: UpSampling2D -> concatenate -> Conv2D): S slices of H x W (output dims), tensors
+// [S][H][W][C] with the slices on the kernels' D axis, 4 parity classes (ph, pw) x 4 pre-summed taps instead of 9 taps on 4x the pixels.
+// Weight images: w_up_fwd [4][2][2][Cout][C0], w_up_dgrad [4][2][2][C0][Cout]; w / dw / the skip images keep the 27-tap layout whose
+// centre kd plane is the 3x3 kernel (as everywhere in the planar path); dwc_scratch: 16*Cout*C0 floats.
+extern "C" int fmri_conv2d_upcat_ok(int C0, int C1, int Cout, int S, int H, int W, int dtype) { return upcat_ok(C0, C1, Cout, S, H, W, dtype, 1); }
+extern "C" int fmri_conv2d_pack_up_weights(const float* w, int C0, int C1, int Cout, void* w_up_fwd, void* w_up_dgrad, void* w_skip_fwd,
+                                           void* w_skip_dgrad, int dtype, fmri_stream_t stream) {
+    return upcat_pack(w, C0, C1, Cout, w_up_fwd, w_up_dgrad, w_skip_fwd, w_skip_dgrad, dtype, 1, stream);
+}
+extern "C" int fmri_conv2d_upcat_fwd(const void* src0_low, int C0, const void* src1, int C1, const void* w_up_fwd, const void* w_skip_fwd,
+                                     const float* bias, void* y, int S, int H, int W, int Cout, int act, float alpha, int dtype,
+                                     fmri_stream_t stream) {
+    return upcat_fwd(src0_low, C0, src1, C1, w_up_fwd, w_skip_fwd, bias, y, 1, S, H, W, Cout, act, alpha, dtype, 1, stream);
+}
+extern "C" int fmri_conv2d_upcat_dgrad(const void* dy, int Cout, const void* w_up_dgrad, const void* w_skip_dgrad, const void* mask_low,
+                                       const void* mask_skip, void* dx_low, void* dx_skip, int S, int H, int W, int C0, int C1, int dtype,
+                                       fmri_stream_t stream) {
+    return upcat_dgrad(dy, Cout, w_up_dgrad, w_skip_dgrad, mask_low, mask_skip, dx_low, dx_skip, 1, S, H, W, C0, C1, dtype, 1, stream);
+}
+extern "C" int fmri_conv2d_upcat_wgrad(const void* src0_low, int C0, const void* src1, int C1, const void* dy, float* dw, float* db,
+                                       float* dwc_scratch, int S, int H, int W, int Cout, int dtype, void* workspace, int64_t workspace_bytes,
+                                       fmri_stream_t stream) {
+    return upcat_wgrad(src0_low, C0, src1, C1, dy, dw, db, dwc_scratch, 1, S, H, W, Cout, dtype, 1, workspace, workspace_bytes, stream);
 }

@@ -129,7 +129,7 @@ k_conv_fwd_mfma(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__
     constexpr int TD = CUBE ? 8 : fw::TD, TH = CUBE ? 8 : fw::TH, TW = CUBE ? 8 : fw::TW;
     constexpr int HD = TD + 2, HH = TH + 2, HW = TW + 2, HVOX = HD * HH * HW;
     constexpr int H_INSTR = (HVOX * 4 + 63) / 64, HALO_BYTES = H_INSTR * 1024;
-    static_assert(!(PL && MODE != 0) && !(RES && MODE != 0) && !(CUBE && (PL || MODE != 0 || RES)), "unsupported combination");
+    static_assert(!(RES && MODE != 0) && !(CUBE && (PL || MODE != 0 || RES)), "unsupported combination");
     (void)NTHREADS;
     constexpr bool PAR = MODE != 0;
     constexpr int BN = 32 * NT;
@@ -137,16 +137,17 @@ k_conv_fwd_mfma(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__
     constexpr int FILT_BYTES = 3 * BN * 64;              // ring slot: one (kd,kh) slab of up to 3 kw taps x BN rows x 64 B
     constexpr int F_INSTR = NKW * BN * 64 / 1024;        // DMA wave-instructions per slab: 12 / 6 (8 / 4 in the up modes)
     constexpr int F_PER_WAVE = (F_INSTR + 7) / 8;        // 2 or 1 (short waves re-issue their first instruction)
-    constexpr int NPH = PAR ? 4 : (PL ? 3 : 9);          // phases per chunk = (kd,kh) rows that exist
+    constexpr int NPAR = PL ? 4 : 8;                     // parity classes of the up modes (planar: (ph,pw) only)
+    constexpr int NPH = PAR ? (PL ? 2 : 4) : (PL ? 3 : 9);   // phases per chunk = (kd,kh) rows that exist
     constexpr int PH0 = PL ? 3 : 0;                      // first (kd,kh) row (planar: kd = 1)
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * HALO_BYTES + 2 * FILT_BYTES];
 
     const int Cin = s.C0 + s.C1;
     const int kpc = MODE == 2 ? (s.C0 >> 5) : 1;         // up-backward: chunks per parity class (s.C0 = channels of dy)
-    const int nch = MODE == 2 ? 8 * kpc : (Cin >> 5);
+    const int nch = MODE == 2 ? NPAR * kpc : (Cin >> 5);
     const int Krow = MODE == 2 ? s.C0 : Cin;             // k-extent of one filter row in global memory
     const int cbn = Cout / BN;
-    const int ncb = MODE == 1 ? 8 * cbn : cbn;
+    const int ncb = MODE == 1 ? NPAR * cbn : cbn;
     const int twn = W / TW, thn = H / TH, tdn = D / TD;
     const int npairs = N * tdn * thn * twn * ncb;
 
@@ -196,8 +197,8 @@ k_conv_fwd_mfma(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__
         int64_t slab;
         int koff;
         if constexpr (MODE == 0) { slab = PH0 + pl; koff = it.ch << 5; }
-        else if constexpr (MODE == 1) { slab = it.par * 4 + pl; koff = it.ch << 5; }
-        else { slab = (it.ch / kpc) * 4 + pl; koff = (it.ch % kpc) << 5; }
+        else if constexpr (MODE == 1) { slab = it.par * NPH + pl; koff = it.ch << 5; }
+        else { slab = (it.ch / kpc) * NPH + pl; koff = (it.ch % kpc) << 5; }
         const bf16_t* const base = wt + ((slab * NKW * Cout + it.co0) * Krow + koff);
 #pragma unroll
         for (int k = 0; k < F_PER_WAVE; ++k)
@@ -214,9 +215,10 @@ k_conv_fwd_mfma(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__
             const int gd = it.d0 - 1 + (pk & 15), gh = it.h0 - 1 + ((pk >> 4) & 15), gw = it.w0 - 1 + ((pk >> 8) & 31);
             const int ls = (pk >> 13) & 3;
             const bool ok = (pk >> 15) && (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W;
-            const int sd = 2 * min(max(gd, 0), D - 1) + (p >> 2), sh = 2 * min(max(gh, 0), H - 1) + ((p >> 1) & 1),
-                      sw = 2 * min(max(gw, 0), W - 1) + (p & 1);
-            const int64_t off = ((((int64_t)it.n * 2 * D + sd) * 2 * H + sh) * 2 * W + sw) * s.C0 + coff + ls * 8;
+            // planar: p = (ph, pw), the slice axis is not doubled
+            const int sd = PL ? min(max(gd, 0), D - 1) : 2 * min(max(gd, 0), D - 1) + (p >> 2);
+            const int sh = 2 * min(max(gh, 0), H - 1) + ((p >> 1) & 1), sw = 2 * min(max(gw, 0), W - 1) + (p & 1);
+            const int64_t off = ((((int64_t)it.n * (PL ? D : 2 * D) + sd) * 2 * H + sh) * 2 * W + sw) * s.C0 + coff + ls * 8;
             return ok ? s.p0 + off : (const bf16_t*)g_zero_page;
         }
         const int cc = it.ch << 5;
@@ -354,14 +356,15 @@ k_conv_fwd_mfma(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__
             PROF_T(t2);
             // DMA of the next phase (an LDS-DMA instruction costs its wave 100-180 cycles of issue here wherever it is placed:
             // staggering the two waves of a SIMD, or issuing mid-phase, measured the same or slower - tools/prof_phases.py)
-            const int HP0 = PAR ? (pl == 0 ? 0 : 1 + 2 * pl) : pl * (9 / NPH);     // the chunk's 9 halo pieces spread over its phases
-            const int HPN = PAR ? (pl == 0 ? 3 : 2) : 9 / NPH;
+            // the chunk's 9 halo pieces spread over its phases: 1 each (9 phases), 3 each (3), 3+2+2+2 (4), 5+4 (2)
+            const int HP0 = NPH == 4 ? (pl == 0 ? 0 : 1 + 2 * pl) : (NPH == 2 ? 5 * pl : pl * (9 / NPH));
+            const int HPN = NPH == 4 ? (pl == 0 ? 3 : 2) : (NPH == 2 ? 5 - pl : 9 / NPH);
             auto issue_dma = [&]() {
                 if (pl < NPH - 1) issue_filter(cur, pl + 1, (g + 1) & 1);
                 else if (has_next) issue_filter(nxt, 0, (g + 1) & 1);
                 if (has_next) {
 #pragma unroll
-                    for (int q = 0; q < 3; ++q) {
+                    for (int q = 0; q < 5; ++q) {
                         if (q < HPN) {
                             if (fresh) hp[HP0 + q] = halo_src(nxt, h_pack[HP0 + q]);
                             else hp[HP0 + q] += 32;
@@ -378,8 +381,9 @@ k_conv_fwd_mfma(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__
             int hoff, kw0 = 0;
             if constexpr (!PAR) hoff = (((PH0 + pl) / 3) * HH + ((PH0 + pl) % 3)) * HW;
             else {
-                const int p = MODE == 1 ? cur.par : 7 - cur.ch / kpc;
-                hoff = (((pl >> 1) + (p >> 2)) * HH + ((pl & 1) + ((p >> 1) & 1))) * HW;
+                const int p = MODE == 1 ? cur.par : (NPAR - 1) - cur.ch / kpc;
+                if constexpr (PL) hoff = (HH + pl + ((p >> 1) & 1)) * HW;           // centre plane; phase = kh'
+                else hoff = (((pl >> 1) + (p >> 2)) * HH + ((pl & 1) + ((p >> 1) & 1))) * HW;
                 kw0 = p & 1;
             }
 #pragma unroll
@@ -509,7 +513,11 @@ k_conv_fwd_mfma(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__
                 const int rt = 2 * wv + (v >> 5), rr = v & 31;
                 // wave-uniform 64-bit tile origin + 32-bit offset inside the tile's bounding box
                 int64_t ao;
-                if constexpr (MODE == 1) {   // parity class p of the [2D][2H][2W] output
+                if constexpr (MODE == 1 && PL) {   // parity class (ph, pw) of the [D][2H][2W] output
+                    const int64_t org = ((((int64_t)cur.n * D + cur.d0) * 2 * H + 2 * cur.h0 + ((cur.par >> 1) & 1)) * 2 * W + 2 * cur.w0 + (cur.par & 1)) * Cout +
+                                        cur.co0;
+                    ao = org + ((tile_d(rt) * 2 * H + 2 * tile_h(rt, rr)) * 2 * W + 2 * lane_w(rr)) * Cout + q * 8;
+                } else if constexpr (MODE == 1) {   // parity class p of the [2D][2H][2W] output
                     const int64_t org = ((((int64_t)cur.n * 2 * D + 2 * cur.d0 + (cur.par >> 2)) * 2 * H + 2 * cur.h0 + ((cur.par >> 1) & 1)) * 2 * W +
                                          2 * cur.w0 + (cur.par & 1)) * Cout + cur.co0;
                     ao = org + ((2 * tile_d(rt) * 2 * H + 2 * tile_h(rt, rr)) * 2 * W + 2 * lane_w(rr)) * Cout + q * 8;
@@ -613,18 +621,18 @@ k_conv_wgrad_mfma(SrcB s, const bf16_t* __restrict__ dy, float* __restrict__ dw,
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * STAGE_BYTES];
 
     const int Cin = s.C0 + s.C1;
-    const int ncib = Cin / CIB, ncob = (UPW ? 8 : 1) * (Cout / 64);
+    const int ncib = Cin / CIB, ncob = (UPW ? (s.planar ? 4 : 8) : 1) * (Cout / 64);
     // slab-major block order: the (kd, Cout block, Cin block) workgroups that read the SAME planes are adjacent in launch
     // order, so they run at the same time and share those planes in L2 / Infinity Cache instead of re-reading HBM
     // (measured with rocprofv3 FETCH_SIZE: combo-major order fetched 3.6x the algorithmic bytes)
-    const int ncombo = (UPW ? 2 : (s.planar ? 1 : 3)) * ncob * ncib;
+    const int ncombo = (s.planar ? 1 : (UPW ? 2 : 3)) * ncob * ncib;
     int combo = blockIdx.x % ncombo;
     const int slab = blockIdx.x / ncombo;
     const int cib = combo % ncib; combo /= ncib;
     const int cob = combo % ncob;
-    const int par = UPW ? cob / (Cout / 64) : 0;           // output parity class (pd, ph, pw) of this workgroup
+    const int par = UPW ? cob / (Cout / 64) : 0;           // output parity class (pd, ph, pw) of this workgroup; planar: (ph, pw)
     const int kdp = combo / ncob;                          // UPW: kd' in {0,1}
-    const int kd = UPW ? kdp + (par >> 2) : (s.planar ? 1 : kdp);   // planar (2-D slices): only the centre kd plane exists
+    const int kd = s.planar ? 1 : (UPW ? kdp + (par >> 2) : kdp);   // planar (2-D slices): only the centre kd plane exists
     const int co0 = (UPW ? cob % (Cout / 64) : cob) * 64, cc = cib * CIB;
 
     const bool from0 = cc < s.C0;
@@ -693,7 +701,8 @@ k_conv_wgrad_mfma(SrcB s, const bf16_t* __restrict__ dy, float* __restrict__ dw,
         const int gdc = min(max(gd, 0), D - 1) >> shd;
         const bf16_t* const xbase = sp + ((int64_t)n * sD + gdc) * sH * sW * sC + coff;
         const bf16_t* const ybase =
-            UPW ? dy + ((((int64_t)n * 2 * D + 2 * d + (par >> 2)) * 2 * H + 2 * h0 + ((par >> 1) & 1)) * 2 * W + 2 * w0 + (par & 1)) * Cout + co0
+            UPW ? (s.planar ? dy + ((((int64_t)n * D + d) * 2 * H + 2 * h0 + ((par >> 1) & 1)) * 2 * W + 2 * w0 + (par & 1)) * Cout + co0
+                            : dy + ((((int64_t)n * 2 * D + 2 * d + (par >> 2)) * 2 * H + 2 * h0 + ((par >> 1) & 1)) * 2 * W + 2 * w0 + (par & 1)) * Cout + co0)
                 : dy + ((((int64_t)n * D + d) * H + h0) * W + w0) * Cout + co0;
         const unsigned sbase = lds0 + buf * STAGE_BYTES;
 #pragma unroll
@@ -788,7 +797,7 @@ k_conv_wgrad_mfma(SrcB s, const bf16_t* __restrict__ dy, float* __restrict__ dw,
             for (int reg = 0; reg < 16; ++reg) {
                 const int co = co0 + ct * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * hk;
                 const int ci = cc + it * 32 + r;
-                atomicAdd(&dw[((int64_t)((par * 2 + kdp) * 4 + tap) * Cout + co) * Cin + ci], acc[tap][reg]);
+                atomicAdd(&dw[((int64_t)((s.planar ? par : par * 2 + kdp) * 4 + tap) * Cout + co) * Cin + ci], acc[tap][reg]);
             }
         }
     } else if (slab_ws) {
@@ -913,13 +922,13 @@ int conv3d_fwd_mfma_ex(int mode, const void* src0, int C0, int up0, int planar, 
     }
 #define FMRI_LAUNCH_FWD(NT_, PL_, MODE_, RES_)                                                                             \
     do {                                                                                                                  \
-        const int np = ntile * (Cout / (32 * NT_)) * (MODE_ == 1 ? 8 : 1);                                                \
+        const int np = ntile * (Cout / (32 * NT_)) * (MODE_ == 1 ? (PL_ ? 4 : 8) : 1);                                    \
         k_conv_fwd_mfma<NT_, PL_, MODE_, RES_><<<np < ncu ? np : ncu, fw::NTHREADS, 0, st>>>(                             \
             s, (const bf16_t*)w, bias, (const bf16_t*)mask, (const bf16_t*)residual, (bf16_t*)y, N, D, H, W, Cout, act, alpha); \
     } while (0)
     // 64-wide Cout blocks halve the halo traffic per MFMA, but a launch with fewer (tile, block) pairs than CUs (the 8x16x16 bottleneck
     // level) leaves CUs idle: 32-wide blocks double the pairs there
-    const bool wide = Cout % 64 == 0 && (int64_t)ntile * (Cout / 64) * (mode == 1 ? 8 : 1) >= ncu;
+    const bool wide = Cout % 64 == 0 && (int64_t)ntile * (Cout / 64) * (mode == 1 ? (planar ? 4 : 8) : 1) >= ncu;
     if (cube) {
         if (mode != 0 || residual || planar) return FMRI_E_SHAPE;
         const int nt = wide ? 2 : 1;
@@ -930,12 +939,17 @@ int conv3d_fwd_mfma_ex(int mode, const void* src0, int C0, int up0, int planar, 
         else
             k_conv_fwd_mfma<1, false, 0, false, true><<<np < ncu ? np : ncu, fw::NTHREADS, 0, st>>>(
                 s, (const bf16_t*)w, bias, (const bf16_t*)mask, nullptr, (bf16_t*)y, N, D, H, W, Cout, act, alpha);
+    } else if (mode == 1 && planar) {
+        if (wide) FMRI_LAUNCH_FWD(2, true, 1, false); else FMRI_LAUNCH_FWD(1, true, 1, false);
     } else if (mode == 1) {
         if (wide) FMRI_LAUNCH_FWD(2, false, 1, false); else FMRI_LAUNCH_FWD(1, false, 1, false);
+    } else if (mode == 2 && planar) {
+        if (wide) FMRI_LAUNCH_FWD(2, true, 2, false); else FMRI_LAUNCH_FWD(1, true, 2, false);
     } else if (mode == 2) {
         if (wide) FMRI_LAUNCH_FWD(2, false, 2, false); else FMRI_LAUNCH_FWD(1, false, 2, false);
+    } else if (residual && planar) {
+        if (wide) FMRI_LAUNCH_FWD(2, true, 0, true); else FMRI_LAUNCH_FWD(1, true, 0, true);
     } else if (residual) {
-        if (planar) return FMRI_E_SHAPE;
         if (wide) FMRI_LAUNCH_FWD(2, false, 0, true); else FMRI_LAUNCH_FWD(1, false, 0, true);
     } else if (wide) {
         if (planar) FMRI_LAUNCH_FWD(2, true, 0, false); else FMRI_LAUNCH_FWD(2, false, 0, false);
@@ -1023,18 +1037,27 @@ int conv3d_wgrad_mfma(const void* src0, int C0, int up0, int planar, const void*
 namespace {
 __device__ __forceinline__ int tap_class_w(int p, int k) { return p == 0 ? (k >= 1) : (k >= 2); }
 // dw[kd,kh,kw][co][c0] += sum over the 8 parity classes of dWc[p][class of the tap under p]
-__global__ void k_expand_up_wgrad(const float* __restrict__ dwc, float* __restrict__ dw, int Cout, int C0, int dw_ld) {
-    const int64_t total = (int64_t)27 * Cout * C0;
+__global__ void k_expand_up_wgrad(const float* __restrict__ dwc, float* __restrict__ dw, int Cout, int C0, int dw_ld, int planar) {
+    const int64_t total = (int64_t)(planar ? 9 : 27) * Cout * C0;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int c0 = (int)(i % C0);
         const int64_t q = i / C0;
-        const int co = (int)(q % Cout), t = (int)(q / Cout);
+        const int co = (int)(q % Cout);
+        const int t = (int)(q / Cout) + (planar ? 9 : 0);          // planar: the centre kd plane of the 27-tap image
         const int kd = t / 9, kh = (t / 3) % 3, kw = t % 3;
         float acc = 0.f;
+        if (planar) {                                              // dWc [4 (ph,pw)][2][2][Cout][C0]
 #pragma unroll
-        for (int p = 0; p < 8; ++p) {
-            const int cls = (tap_class_w(p >> 2, kd) * 2 + tap_class_w((p >> 1) & 1, kh)) * 2 + tap_class_w(p & 1, kw);
-            acc += dwc[((int64_t)(p * 8 + cls) * Cout + co) * C0 + c0];
+            for (int p = 0; p < 4; ++p) {
+                const int cls = tap_class_w(p >> 1, kh) * 2 + tap_class_w(p & 1, kw);
+                acc += dwc[((int64_t)(p * 4 + cls) * Cout + co) * C0 + c0];
+            }
+        } else {
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                const int cls = (tap_class_w(p >> 2, kd) * 2 + tap_class_w((p >> 1) & 1, kh)) * 2 + tap_class_w(p & 1, kw);
+                acc += dwc[((int64_t)(p * 8 + cls) * Cout + co) * C0 + c0];
+            }
         }
         dw[((int64_t)t * Cout + co) * dw_ld + c0] += acc;
     }
@@ -1042,15 +1065,15 @@ __global__ void k_expand_up_wgrad(const float* __restrict__ dwc, float* __restri
 }  // namespace
 
 int conv3d_upcat_wgrad_mfma(const void* src0_low, int C0, const void* src1, int C1, const void* dy, float* dw, float* db, float* dwc, int N,
-                            int D, int H, int W, int Cout, void* workspace, int64_t workspace_bytes, hipStream_t st) {
-    // D,H,W = output dims.  1. parity-filter gradients over the low-res grid
-    if (hipMemsetAsync(dwc, 0, (size_t)64 * Cout * C0 * sizeof(float), st) != hipSuccess) return FMRI_E_LAUNCH;
+                            int D, int H, int W, int Cout, int planar, void* workspace, int64_t workspace_bytes, hipStream_t st) {
+    // D,H,W = output dims (planar: D = slices, not doubled).  1. parity-filter gradients over the low-res grid
+    if (hipMemsetAsync(dwc, 0, (size_t)(planar ? 16 : 64) * Cout * C0 * sizeof(float), st) != hipSuccess) return FMRI_E_LAUNCH;
     {
-        SrcB s{(const bf16_t*)src0_low, nullptr, C0, 0, 0, 1, 0};
-        const int Dl = D / 2, Hl = H / 2, Wl = W / 2;
+        SrcB s{(const bf16_t*)src0_low, nullptr, C0, 0, 0, planar ? 0 : 1, planar};
+        const int Dl = planar ? D : D / 2, Hl = H / 2, Wl = W / 2;
         const bool wide = C0 % 64 == 0;
         const int CIB = wide ? 64 : 32;
-        const int combos = 2 * 8 * (Cout / 64) * (C0 / CIB);
+        const int combos = (planar ? 4 : 16) * (Cout / 64) * (C0 / CIB);
         const int nunits = N * Dl * (Hl / wg::TH) * (Wl / wg::TW);
         int nslab = (1536 + combos - 1) / combos;
         if (nslab > nunits) nslab = nunits;
@@ -1060,9 +1083,9 @@ int conv3d_upcat_wgrad_mfma(const void* src0_low, int C0, const void* src1, int 
         else k_conv_wgrad_mfma<1, true><<<combos * nslab, wg::NTHREADS, 0, st>>>(s, (const bf16_t*)dy, dwc, dbu, N, Dl, Hl, Wl, Cout, nslab, nullptr, C0);
     }
     // 2. fold them into the 27-tap gradient of the up-sampled input channels (columns [0, C0) of dw)
-    k_expand_up_wgrad<<<grid_for((int64_t)27 * Cout * C0, 256, 1024), 256, 0, st>>>(dwc, dw, Cout, C0, C0 + C1);
+    k_expand_up_wgrad<<<grid_for((int64_t)(planar ? 9 : 27) * Cout * C0, 256, 1024), 256, 0, st>>>(dwc, dw, Cout, C0, C0 + C1, planar);
     FMRI_LAUNCH_CHECK();
     if (C1 == 0) return FMRI_OK;
     // 3. the skip channels: plain weight gradient into columns [C0, C0+C1), bias gradient included
-    return conv3d_wgrad_mfma_ld(src1, C1, 0, 0, nullptr, 0, dy, dw + C0, C0 + C1, db, N, D, H, W, Cout, workspace, workspace_bytes, st);
+    return conv3d_wgrad_mfma_ld(src1, C1, 0, planar, nullptr, 0, dy, dw + C0, C0 + C1, db, N, D, H, W, Cout, workspace, workspace_bytes, st);
 }

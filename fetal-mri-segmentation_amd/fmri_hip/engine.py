@@ -154,13 +154,15 @@ class UNetEngine:
                 # up-sample + concat + conv in parity form (fmri_conv3d_upcat_*): pre-summed 2x2x2 filters per output parity for the
                 # up-sampled channels, plain 27-tap filters for the skip channels
                 c0, c1 = self.upcat[name]
-                W = dict(up_f=torch.empty((8, 8, L["cout"], c0), dtype=self.dtype, device=dev),
+                npar = 4 if self.planar else 8           # parity classes = pre-summed taps per class (2-D: (ph,pw) x 2x2 taps)
+                W = dict(up_f=torch.empty((npar, npar, L["cout"], c0), dtype=self.dtype, device=dev),
                          sk_f=torch.empty((27, L["cout"], c1), dtype=self.dtype, device=dev), up_d=None, sk_d=None)
                 if self.training:
-                    W["up_d"] = torch.empty((8, 8, c0, L["cout"]), dtype=self.dtype, device=dev)
+                    W["up_d"] = torch.empty((npar, npar, c0, L["cout"]), dtype=self.dtype, device=dev)
                     W["sk_d"] = torch.empty((27, c1, L["cout"]), dtype=self.dtype, device=dev)
                 self.Wup[name] = W
-                continue
+                if not self.planar:
+                    continue                             # 2-D keeps the 9-tap images too: batches whose slice count does not tile fall back
             self.Wf[name] = torch.empty((27, L["cout"], L["cin"]), dtype=self.dtype, device=dev)
             if self.training and name != first:
                 self.Wd[name] = torch.empty((27, L["cin"], L["cout"]), dtype=self.dtype, device=dev)
@@ -319,7 +321,7 @@ class UNetEngine:
         p = self.plan
         out = {}
         self.upcat_wgrad = set()                           # ... of which the weight gradient takes the parity form too
-        if self.planar or self.dtype != torch.bfloat16 or os.environ.get("FMRI_UPCAT", "1") == "0":
+        if self.dtype != torch.bfloat16 or os.environ.get("FMRI_UPCAT", "1") == "0":
             return out
         for lv in p.dec:
             a = lv[0]
@@ -327,13 +329,18 @@ class UNetEngine:
                 continue                                   # Deconvolution3D variant: the up-sampled tensor is materialised
             c1 = p.enc[a["level"]][1]["cout"]
             c0 = a["cin"] - c1
-            D, H, W = p.level_dims(a["level"])
-            ok = ops.conv3d_upcat_ok(c0, c1, a["cout"], D, H, W, self.dtype)
+            # 2-D: the slices ride the kernels' D axis; 4 of them (one tile) stand in for "a batch that tiles" (see _use_upcat)
+            D, H, W = p.level_dims(a["level"], 4) if self.planar else p.level_dims(a["level"])
+            ok = ops.conv3d_upcat_ok(c0, c1, a["cout"], D, H, W, self.dtype, planar=self.planar)
             if ok & 1:
                 out[a["name"]] = (c0, c1)
                 if ok & 2:
                     self.upcat_wgrad.add(a["name"])
         return out
+
+    def _use_upcat(self, name):
+        """parity form for this layer at the CURRENT batch size (2-D: the slice count must be a multiple of the 4-slice tile)"""
+        return name in self.Wup and (not self.planar or self.N % 4 == 0)
 
     def refresh_weight_copies(self, overlap=False):
         """compute-dtype images of the fp32 parameters (forward filters, tap-flipped transposed filters for the input gradients, parity
@@ -368,7 +375,7 @@ class UNetEngine:
         for name, W in self.Wup.items():
             if want(name):
                 c0, c1 = self.upcat[name]
-                ops.conv3d_pack_up_weights(self.w_view(name), c0, c1, W["up_f"], W["up_d"], W["sk_f"], W["sk_d"])
+                ops.conv3d_pack_up_weights(self.w_view(name), c0, c1, W["up_f"], W["up_d"], W["sk_f"], W["sk_d"], planar=self.planar)
         for name, wt in self.Wt.items():
             if not want(name):
                 continue
@@ -452,7 +459,7 @@ class UNetEngine:
             a = lv[0]
             # gradient of the concatenated conv input; the parity form writes the up-sampled part straight at low resolution,
             # so only the skip channels remain
-            ccat = self.upcat[a["name"]][1] if a["name"] in self.upcat else a["cin"]
+            ccat = self.upcat[a["name"]][1] if self._use_upcat(a["name"]) else a["cin"]
             Gd["cat_%d" % a["level"]] = torch.empty(self._dims(a["level"]) + (ccat,), dtype=dt, device=dev)
         self.dlogits = torch.empty_like(self.logits)
         # scratch for the slab flush of the MFMA weight-gradient kernel (max over the layers of this plan)
@@ -478,9 +485,9 @@ class UNetEngine:
         """one [conv -> (norm) -> ReLU] block (reference create_convolution_block, unet.py:89-115)"""
         name = c["name"]
         out, act = (self.pre[name], ACT_NONE) if c.get("norm") else (self.act[name], ACT_RELU)
-        if up0 and name in self.Wup:
+        if up0 and self._use_upcat(name):
             W = self.Wup[name]
-            ops.conv3d_upcat_fwd(src0, src1, W["up_f"], W["sk_f"], self.b_view(name), out, act=act)
+            ops.conv3d_upcat_fwd(src0, src1, W["up_f"], W["sk_f"], self.b_view(name), out, act=act, planar=self.planar)
         else:
             ops.conv3d_fwd(src0, src1, self.Wf[name], self.b_view(name), out, up0=up0, act=act, planar=self.planar)
         if not c.get("norm"):
@@ -566,8 +573,9 @@ class UNetEngine:
             ops.norm_act_bwd(self._as_samples(self.pre[name]), self._as_samples(self.act[name]), self._as_samples(g),
                              self.gb_view(name, "gamma"), self.nstats[name], self._as_samples(g), self.gb_view(name, "gamma", self.G),
                              self.gb_view(name, "beta", self.G), self.norm_ws, per, act=ACT_RELU)
-        if up0 and name in self.upcat_wgrad:
-            ops.conv3d_upcat_wgrad(src0, src1, g, self.w_view(name, self.G), self.b_view(name, self.G), self.dwc_scratch, workspace=self.wgrad_ws)
+        if up0 and name in self.upcat_wgrad and self._use_upcat(name):
+            ops.conv3d_upcat_wgrad(src0, src1, g, self.w_view(name, self.G), self.b_view(name, self.G), self.dwc_scratch, workspace=self.wgrad_ws,
+                                   planar=self.planar)
         else:
             ops.conv3d_wgrad(src0, src1, g, self.w_view(name, self.G), self.b_view(name, self.G), up0=up0, planar=self.planar,
                              workspace=self.wgrad_ws)
@@ -628,10 +636,10 @@ class UNetEngine:
                     ops.deconv_bwd(A[low], self.Wt[u["name"]], cat, Gd[low], self.w_view(u["name"], self.G), self.b_view(u["name"], self.G),
                                    dy_off=0, xmask=self._mask_of(low), planar=self.planar)
                 self._grad_ready(u["name"])
-            elif a["name"] in self.Wup:
+            elif self._use_upcat(a["name"]):
                 self._block_bwd(a, A[low], skip, True)
                 W = self.Wup[a["name"]]
-                ops.conv3d_upcat_dgrad(Gd[a["name"]], W["up_d"], W["sk_d"], self._mask_of(low), None, Gd[low], cat)
+                ops.conv3d_upcat_dgrad(Gd[a["name"]], W["up_d"], W["sk_d"], self._mask_of(low), None, Gd[low], cat, planar=self.planar)
             else:
                 self._block_bwd(a, A[low], skip, True)
                 ops.conv3d_dgrad(Gd[a["name"]], self.Wd[a["name"]], cat, planar=self.planar)

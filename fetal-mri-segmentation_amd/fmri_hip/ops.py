@@ -337,38 +337,58 @@ def noise_augment(x, stats, noise, kind, sigma):
 
 
 # ---------------------------------------------------------------------------------------------- up-sample + concat + conv, parity form
-def conv3d_upcat_ok(C0, C1, Cout, D, H, W, dtype):
-    """bit 0: forward / input gradients, bit 1: weight gradient"""
-    return int(lib().fmri_conv3d_upcat_ok(C0, C1, Cout, D, H, W, BF16 if dtype == torch.bfloat16 else F32))
+def conv3d_upcat_ok(C0, C1, Cout, D, H, W, dtype, planar=False):
+    """bit 0: forward / input gradients, bit 1: weight gradient.  planar: 2-D slices [1][S][H][W][C] (D = S is not up-sampled)"""
+    f = lib().fmri_conv2d_upcat_ok if planar else lib().fmri_conv3d_upcat_ok
+    return int(f(C0, C1, Cout, D, H, W, BF16 if dtype == torch.bfloat16 else F32))
 
 
-def conv3d_pack_up_weights(w, C0, C1, up_f=None, up_d=None, sk_f=None, sk_d=None):
+def conv3d_pack_up_weights(w, C0, C1, up_f=None, up_d=None, sk_f=None, sk_d=None, planar=False):
     _need_cuda(w, up_f, up_d, sk_f, sk_d)
     Cout = w.shape[1]
     ref = next(t for t in (up_f, up_d, sk_f, sk_d) if t is not None)
-    check(lib().fmri_conv3d_pack_up_weights(_p(w), C0, C1, Cout, _p(up_f), _p(up_d), _p(sk_f), _p(sk_d), dt(ref), _s()), "fmri_conv3d_pack_up_weights")
+    f = lib().fmri_conv2d_pack_up_weights if planar else lib().fmri_conv3d_pack_up_weights
+    check(f(_p(w), C0, C1, Cout, _p(up_f), _p(up_d), _p(sk_f), _p(sk_d), dt(ref), _s()), "fmri_conv%dd_pack_up_weights" % (2 if planar else 3))
 
 
-def conv3d_upcat_fwd(src0_low, src1, w_up_f, w_sk_f, bias, y, act=ACT_RELU, alpha=0.0):
+def conv3d_upcat_fwd(src0_low, src1, w_up_f, w_sk_f, bias, y, act=ACT_RELU, alpha=0.0, planar=False):
     _need_cuda(src0_low, src1, w_up_f, w_sk_f, bias, y)
     N, D, H, W, Cout = y.shape
-    check(lib().fmri_conv3d_upcat_fwd(_p(src0_low), src0_low.shape[-1], _p(src1), 0 if src1 is None else src1.shape[-1], _p(w_up_f), _p(w_sk_f), _p(bias), _p(y), N, D, H, W,
+    c0, c1 = src0_low.shape[-1], (0 if src1 is None else src1.shape[-1])
+    if planar:
+        assert N == 1
+        check(lib().fmri_conv2d_upcat_fwd(_p(src0_low), c0, _p(src1), c1, _p(w_up_f), _p(w_sk_f), _p(bias), _p(y), D, H, W, Cout, act, float(alpha),
+                                          dt(y), _s()), "fmri_conv2d_upcat_fwd")
+        return y
+    check(lib().fmri_conv3d_upcat_fwd(_p(src0_low), c0, _p(src1), c1, _p(w_up_f), _p(w_sk_f), _p(bias), _p(y), N, D, H, W,
                                       Cout, act, float(alpha), dt(y), _s()), "fmri_conv3d_upcat_fwd")
     return y
 
 
-def conv3d_upcat_dgrad(dy, w_up_d, w_sk_d, mask_low, mask_skip, dx_low, dx_skip):
+def conv3d_upcat_dgrad(dy, w_up_d, w_sk_d, mask_low, mask_skip, dx_low, dx_skip, planar=False):
     _need_cuda(dy, w_up_d, w_sk_d, mask_low, mask_skip, dx_low, dx_skip)
     N, D, H, W, Cout = dy.shape
+    c0, c1 = dx_low.shape[-1], (0 if dx_skip is None else dx_skip.shape[-1])
+    if planar:
+        assert N == 1
+        check(lib().fmri_conv2d_upcat_dgrad(_p(dy), Cout, _p(w_up_d), _p(w_sk_d), _p(mask_low), _p(mask_skip), _p(dx_low), _p(dx_skip), D, H, W,
+                                            c0, c1, dt(dy), _s()), "fmri_conv2d_upcat_dgrad")
+        return
     check(lib().fmri_conv3d_upcat_dgrad(_p(dy), Cout, _p(w_up_d), _p(w_sk_d), _p(mask_low), _p(mask_skip), _p(dx_low), _p(dx_skip), N, D, H, W,
-                                        dx_low.shape[-1], 0 if dx_skip is None else dx_skip.shape[-1], dt(dy), _s()), "fmri_conv3d_upcat_dgrad")
+                                        c0, c1, dt(dy), _s()), "fmri_conv3d_upcat_dgrad")
 
 
-def conv3d_upcat_wgrad(src0_low, src1, dy, dw, db, dwc_scratch, workspace=None):
+def conv3d_upcat_wgrad(src0_low, src1, dy, dw, db, dwc_scratch, workspace=None, planar=False):
     _need_cuda(src0_low, src1, dy, dw, db, dwc_scratch, workspace)
     N, D, H, W, Cout = dy.shape
     C0, C1 = src0_low.shape[-1], (0 if src1 is None else src1.shape[-1])
-    assert dwc_scratch.dtype == torch.float32 and dwc_scratch.numel() >= 64 * Cout * C0
+    assert dwc_scratch.dtype == torch.float32 and dwc_scratch.numel() >= (16 if planar else 64) * Cout * C0
+    nws = 0 if workspace is None else workspace.numel() * workspace.element_size()
+    if planar:
+        assert N == 1
+        check(lib().fmri_conv2d_upcat_wgrad(_p(src0_low), C0, _p(src1), C1, _p(dy), _p(dw), _p(db), _p(dwc_scratch), D, H, W, Cout, dt(dy),
+                                            _p(workspace), nws, _s()), "fmri_conv2d_upcat_wgrad")
+        return
     check(lib().fmri_conv3d_upcat_wgrad(_p(src0_low), C0, _p(src1), C1, _p(dy), _p(dw), _p(db), _p(dwc_scratch), N, D, H, W, Cout, dt(dy),
-                                        _p(workspace), 0 if workspace is None else workspace.numel() * workspace.element_size(), _s()),
+                                        _p(workspace), nws, _s()),
           "fmri_conv3d_upcat_wgrad")

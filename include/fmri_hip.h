@@ -96,6 +96,23 @@ int fmri_conv3d_upcat_wgrad(const void* src0_low, int C0, const void* src1, int 
                             float* dwc_scratch, int N, int D, int H, int W, int Cout, int dtype, void* workspace, int64_t workspace_bytes,
                             fmri_stream_t stream);
 
+/* ---- 2-D twins of the parity-form family (reference fetal_net/model/unet/unet.py:60-66 UpSampling2D -> concatenate -> Conv2D, the decoder
+ * of unet_model_2d).  Tensors are [S][H][W][C] (S slices, no coupling along S), dims below are OUTPUT dims; 4 parity classes (ph,pw) x 4
+ * pre-summed taps on the low-res [S][H/2][W/2][C0] tensor instead of 9 taps on 4x the pixels.  w / dw / w_skip_* keep the 27-tap layout of
+ * the planar path (the 3x3 kernel is the centre kd plane); w_up_fwd [4][2][2][Cout][C0], w_up_dgrad [4][2][2][C0][Cout];
+ * dwc_scratch: 16*Cout*C0 floats.  Argument meaning otherwise as the fmri_conv3d_upcat_* functions. */
+int fmri_conv2d_upcat_ok(int C0, int C1, int Cout, int S, int H, int W, int dtype);
+int fmri_conv2d_pack_up_weights(const float* w, int C0, int C1, int Cout, void* w_up_fwd, void* w_up_dgrad, void* w_skip_fwd,
+                                void* w_skip_dgrad, int dtype, fmri_stream_t stream);
+int fmri_conv2d_upcat_fwd(const void* src0_low, int C0, const void* src1, int C1, const void* w_up_fwd, const void* w_skip_fwd,
+                          const float* bias, void* y, int S, int H, int W, int Cout, int act, float alpha, int dtype, fmri_stream_t stream);
+int fmri_conv2d_upcat_dgrad(const void* dy, int Cout, const void* w_up_dgrad, const void* w_skip_dgrad, const void* mask_low,
+                            const void* mask_skip, void* dx_low, void* dx_skip, int S, int H, int W, int C0, int C1, int dtype,
+                            fmri_stream_t stream);
+int fmri_conv2d_upcat_wgrad(const void* src0_low, int C0, const void* src1, int C1, const void* dy, float* dw, float* db,
+                            float* dwc_scratch, int S, int H, int W, int Cout, int dtype, void* workspace, int64_t workspace_bytes,
+                            fmri_stream_t stream);
+
 /* fp32 master filter [27][Cout][Cin] -> w_fwd (dtype, same layout) and w_dgrad (dtype, [26-tap][Cin][Cout]).
  * Either destination may be NULL. */
 int fmri_conv3d_pack_weights(const float* w, void* w_fwd, void* w_dgrad, int Cout, int Cin, int dtype,

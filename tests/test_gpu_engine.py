@@ -165,6 +165,38 @@ def test_unet2d_fp32_and_bf16_vs_oracle():
             assert Wx[k].shape == W[k].shape
 
 
+@pytest.mark.parametrize("slices", [8, 6])
+def test_unet2d_parity_form_equals_9_tap_kernels(monkeypatch, slices):
+    """2-D decoder (UpSampling2D -> concatenate -> Conv2D, reference model/unet/unet.py:60-66): the parity form (4 classes x 2x2 taps on
+    the low-res slices, fmri_conv2d_upcat_*) against the engine that keeps the fused-upsample 9-tap kernels (FMRI_UPCAT=0) - same weights,
+    same batch: logits and every parameter gradient.  6 slices do not tile (4 per workgroup tile): the engine must fall back by itself."""
+    from fmri_hip.engine import UNetEngine, UNetPlan
+    X, Y, C = 32, 64, 3
+    plan = lambda: UNetPlan(C, (X, Y), depth=3, n_base_filters=32, ndim=2)
+    rs = np.random.RandomState(5)
+    x = torch.from_numpy(rs.randn(1, slices, X, Y, C).astype(np.float32)).cuda().to(torch.bfloat16)
+    y = torch.from_numpy((rs.rand(slices * X * Y) > 0.7).astype(np.uint8)).cuda()
+    monkeypatch.setenv("FMRI_UPCAT", "1")
+    a = UNetEngine(plan(), slices, dtype=torch.bfloat16, seed=9)
+    assert len(a.Wup) == 2 and a._use_upcat(next(iter(a.Wup))) == (slices % 4 == 0)
+    monkeypatch.setenv("FMRI_UPCAT", "0")
+    b = UNetEngine(plan(), slices, dtype=torch.bfloat16, seed=9)
+    assert not b.Wup
+    out = []
+    for eng in (a, b):
+        eng.forward(x)
+        eng.loss_forward(y)
+        eng.backward(y)
+        torch.cuda.synchronize()
+        out.append((eng.logits.float().cpu().numpy().copy(), eng.G.cpu().numpy().copy()))
+    assert _rel(out[0][0], out[1][0]) <= (2e-2 if slices % 4 == 0 else 0.0)
+    for name, L in a.layout.items():
+        o, n = L["w"]
+        ga, gb = out[0][1][o:o + n], out[1][1][o:o + n]
+        e = np.linalg.norm(ga - gb) / (np.linalg.norm(gb) + 1e-30)
+        assert e <= (6e-2 if slices % 4 == 0 else 1e-6), (name, e)
+
+
 @pytest.mark.parametrize("norm,deconv", [("batch", True), ("instance", False), ("batch", False), (None, True)])
 def test_unet3d_norm_and_deconv_variants_fp32(norm, deconv):
     """the optional pieces of create_convolution_block / get_up_convolution (reference unet.py:103-111,135): BatchNormalization,

@@ -613,6 +613,77 @@ def test_upcat_without_skip_channels(ops):
     assert_close(db, b64.grad, 2e-3, 2e-3, what="db")
 
 
+UPCAT2D_CASES = [
+    # name, S (slices), H, W (output dims), C0 (up-sampled), C1 (skip), Cout
+    ("one_tile", 4, 16, 32, 64, 32, 64),
+    ("multi_tile", 8, 32, 64, 128, 64, 64),
+    ("narrow_cout", 4, 32, 32, 64, 64, 96),
+    ("deep", 4, 16, 32, 256, 128, 128),
+    ("no_skip", 4, 16, 32, 64, 0, 64),
+]
+
+
+@pytest.mark.parametrize("case", UPCAT2D_CASES, ids=[c[0] for c in UPCAT2D_CASES])
+def test_upcat_2d_fwd_dgrad_wgrad(ops, case):
+    """fmri_conv2d_upcat_* (4 parity classes x 4 pre-summed taps per slice) against conv3x3(concat(nearest_up2(x_low), x_skip)) per slice
+    and its fp64 autograd gradients (reference model/unet/unet.py:60-66).  Tensors [1][S][H][W][C]; the 3x3 kernel is the centre kd plane
+    of the 27-tap weight image, the other planes are poisoned to prove they are never read."""
+    name, S, H, W, C0, C1, Cout = case
+    dtype = torch.bfloat16
+    ok = ops.conv3d_upcat_ok(C0, C1, Cout, S, H, W, dtype, planar=True)
+    assert ok & 1
+    x_low = rnd((1, S, H // 2, W // 2, C0), 21, dtype)
+    x_skip = rnd((1, S, H, W, C1), 22, dtype) if C1 else None
+    w = rnd((27, Cout, C0 + C1), 23, dtype, scale=0.05).float().contiguous()
+    w[:9] = 1e4
+    w[18:] = -1e4
+    bias = rnd((Cout,), 24, torch.float32)
+    up_f = torch.empty((4, 4, Cout, C0), device="cuda", dtype=dtype)
+    up_d = torch.empty((4, 4, C0, Cout), device="cuda", dtype=dtype)
+    sk_f = torch.empty((27, Cout, C1), device="cuda", dtype=dtype) if C1 else None
+    sk_d = torch.empty((27, C1, Cout), device="cuda", dtype=dtype) if C1 else None
+    ops.conv3d_pack_up_weights(w, C0, C1, up_f, up_d, sk_f, sk_d, planar=True)
+    y = torch.full((1, S, H, W, Cout), float("nan"), dtype=dtype, device="cuda")
+    ops.conv3d_upcat_fwd(x_low, x_skip, up_f, sk_f, bias, y, act=1, planar=True)
+    torch.cuda.synchronize()
+
+    def ref_pre(xl, xs, kern, b):
+        up = xl[0].permute(0, 3, 1, 2)                                            # [S][C0][h][w]
+        up = up.repeat_interleave(2, dim=2).repeat_interleave(2, dim=3)
+        inp = up if xs is None else torch.cat([up, xs[0].permute(0, 3, 1, 2)], dim=1)
+        return F.conv2d(inp, kern, b, padding=1)                                  # [S][Cout][H][W]
+
+    xl = f64(x_low).requires_grad_(True)
+    xs = f64(x_skip).requires_grad_(True) if C1 else None
+    kern = f64(w)[9:18].reshape(3, 3, Cout, C0 + C1).permute(2, 3, 0, 1).contiguous().requires_grad_(True)
+    b64 = f64(bias).requires_grad_(True)
+    pre = ref_pre(xl, xs, kern, b64)
+    ref = F.relu(pre).permute(0, 2, 3, 1).unsqueeze(0)
+    assert_close(y, ref, 1.5e-2, 1.5e-2, what=name + " fwd")
+    dy = rnd((1, S, H, W, Cout), 25, dtype)
+    m_low = rnd((1, S, H // 2, W // 2, C0), 26, dtype).clamp_min(0)
+    m_skip = rnd((1, S, H, W, C1), 27, dtype).clamp_min(0) if C1 else None
+    dx_low = torch.full_like(x_low, float("nan"))
+    dx_skip = torch.full_like(x_skip, float("nan")) if C1 else None
+    ops.conv3d_upcat_dgrad(dy, up_d, sk_d, m_low, m_skip, dx_low, dx_skip, planar=True)
+    torch.cuda.synchronize()
+    pre.backward(f64(dy)[0].permute(0, 3, 1, 2))
+    assert_close(dx_low, xl.grad * (f64(m_low) > 0), 1.5e-2, 1.5e-2, what=name + " dx_low")
+    if C1:
+        assert_close(dx_skip, xs.grad * (f64(m_skip) > 0), 1e-2, 1e-2, what=name + " dx_skip")
+    if ok & 2:
+        dw = torch.zeros((27, Cout, C0 + C1), device="cuda")
+        db = torch.zeros(Cout, device="cuda")
+        ops.conv3d_upcat_wgrad(x_low, x_skip, dy, dw, db, torch.empty(16 * Cout * C0, device="cuda"), planar=True)
+        torch.cuda.synchronize()
+        ref_dw = kern.grad.permute(2, 3, 0, 1).reshape(9, Cout, C0 + C1)
+        assert_close(dw[9:18], ref_dw, 2e-3, 2e-3, what=name + " dw")
+        assert float(dw[:9].abs().max()) == 0.0 and float(dw[18:].abs().max()) == 0.0
+        assert_close(db, b64.grad, 2e-3, 2e-3, what=name + " db")
+    else:
+        assert Cout % 64                                                          # the weight-gradient kernel tiles Cout by 64
+
+
 def test_weighted_cross_entropy_loss_value_and_gradient(ops):
     """fmri_sigmoid_dice_fwd_weighted / _loss_bwd_weighted = Dice + w * mean(exp(-mask/sigma) * BCE) (reference metrics.py:66-76,89-95)
     against the metrics oracle's dice_and_xent with a weight mask, value and finite-difference-free analytic gradient (torch fp64)."""
