@@ -753,8 +753,7 @@ k_conv_wgrad_mfma(SrcB s, const bf16_t* __restrict__ dy, float* __restrict__ dw,
                 const unsigned char* pa = sb + pre_y + ks8 * TW * 128;
                 s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)pa);
                 s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(pa + 4 * 128));
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { af[j] = v0[j]; af[4 + j] = v1[j]; }
+                af = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);      // plain concatenation: no element-wise copies
             }
             const bf16x8_t a = __builtin_bit_cast(bf16x8_t, af);                     // A[co][k = voxel]
             if (do_bias) {
@@ -767,9 +766,7 @@ k_conv_wgrad_mfma(SrcB s, const bf16_t* __restrict__ dy, float* __restrict__ dw,
                 const unsigned char* pb = sb + pre_x[c & 3] + (c >> 2) * 4 * XROWB;
                 s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)pb);
                 s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(pb + 4 * XROWB));
-                s16x8 bfv;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { bfv[j] = v0[j]; bfv[4 + j] = v1[j]; }
+                const s16x8 bfv = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
                 acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bf16x8_t, bfv), acc[tap], 0, 0, 0);   // B[k = voxel][ci]
             }
         }
