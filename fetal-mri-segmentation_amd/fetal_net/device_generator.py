@@ -7,6 +7,9 @@ is: the reference's random draws on the host (same order, same generators => sam
 fmri_affine_sample launch for the image (trilinear, cval = volume minimum) and one for the labels (nearest, cval = 0) straight
 into the batch tensors, then the elementwise intensity passes.  The generator yields torch CUDA tensors in the reference's logical
 layouts ((N,1,X,Y,Z) / (N,X,Y,C) float32 images, uint8 labels); Model.train_on_batch / fit_generator take them as they are.
+A data file with a non-empty `mask` array (the distance masks of the mask-weighted loss, reference generator.py:18-21) makes the generator
+yield ([x, masks], y) like the reference's convert_data (generator.py:397-401): the mask patch is sampled like the labels (nearest, outside
+= 0, same transformation) at the label slices.  As in the reference the masks are NOT padded with the volumes.
 
 `device_data_generator` keeps the keyword arguments of the reference's `data_generator` (generator.py:222-225).
 Applied augmenters: flip, scale, iso_scale, rotate, translate, contrast, intensity_multiplication, gaussian_noise, speckle_noise.
@@ -34,7 +37,9 @@ class DeviceDataFile(object):
         root = data_file.root
         n = len(root.data)
         self.indices = list(range(n)) if indices is None else list(indices)
-        self.data, self.truth, self.min, self.max = {}, {}, {}, {}
+        self.data, self.truth, self.min, self.max, self.mask = {}, {}, {}, {}, None
+        if hasattr(root, "mask") and root.mask is not None and len(root.mask):
+            self.mask = {}
         self.subject_ids = [s for s in root.subject_ids] if hasattr(root, "subject_ids") else None
         out_shape = [patch_shape[0] // ds, patch_shape[1] // ds, 1]
         padding = np.ceil(np.subtract(patch_shape, out_shape) / 2).astype(int)
@@ -53,10 +58,26 @@ class DeviceDataFile(object):
             self.data[i] = torch.from_numpy(np.ascontiguousarray(d, dtype=np.float32)).to(device)
             self.truth[i] = torch.from_numpy(np.ascontiguousarray(t).astype(np.uint8)).to(device)
             self.min[i], self.max[i] = dmin, dmax
+            if self.mask is not None:
+                self.mask[i] = torch.from_numpy(np.ascontiguousarray(np.asarray(root.mask[i]), dtype=np.float32)).to(device)
         self.device = device
+        self._mask_edge = {}
+
+    def mask_for_crops(self, i):
+        """the mask as the reference's un-augmented path sees it: a crop that runs past the (unpadded) mask is completed with edge values
+        (reference utils/patches.py:66-90), so the volume is grown with replicated borders up to the padded label volume's extent"""
+        if i not in self._mask_edge:
+            import torch
+            m = self.mask[i]
+            grow = [max(int(t) - int(s), 0) for t, s in zip(self.truth[i].shape, m.shape)]
+            if any(grow):
+                m = torch.nn.functional.pad(m[None, None], (0, grow[2], 0, grow[1], 0, grow[0]), mode="replicate")[0, 0].contiguous()
+            self._mask_edge[i] = m
+        return self._mask_edge[i]
 
     def nbytes(self):
-        return sum(v.numel() * 4 for v in self.data.values()) + sum(v.numel() for v in self.truth.values())
+        return sum(v.numel() * 4 for v in self.data.values()) + sum(v.numel() for v in self.truth.values()) + \
+            sum(v.numel() * 4 for v in (self.mask or {}).values())
 
 
 def random_list_generator(index_list):
@@ -93,8 +114,9 @@ class _Sampler(object):
                     raise NotImplementedError(msg)
                 warnings.warn(msg)
 
-    def sample_into(self, index, x_slot, y_slot):
-        """x_slot: float32 view (X, Y, n_chan) of the batch tensor; y_slot: uint8 view (X, Y, truth_size)"""
+    def sample_into(self, index, x_slot, y_slot, m_slot=None):
+        """x_slot: float32 view (X, Y, n_chan) of the batch tensor; y_slot: uint8 view (X, Y, truth_size); m_slot: float32 view
+        (X, Y, truth_size) for the distance mask, when the data file has masks"""
         ops, ddf = self.ops, self.ddf
         data, truth = ddf.data[index], ddf.truth[index]
         ps = self.patch_shape
@@ -106,12 +128,21 @@ class _Sampler(object):
                                  rotate_factor=p["rotate_factor"], translate_factor=p["translate_factor"])
             _, At = distort_image(truth, np.eye(4), flip_axis=p["flip_axis"], scale_factor=p["scale_factor"],
                                   rotate_factor=p["rotate_factor"], translate_factor=p["translate_factor"])
+            Am = None
+            if m_slot is not None:
+                _, Am = distort_image(ddf.mask[index], np.eye(4), flip_axis=p["flip_axis"], scale_factor=p["scale_factor"],
+                                      rotate_factor=p["rotate_factor"], translate_factor=p["translate_factor"])
         else:
-            p, A, At = None, np.eye(4), np.eye(4)
+            p, A, At, Am = None, np.eye(4), np.eye(4), np.eye(4)
         # image: trilinear, outside = the volume's minimum; labels: nearest, outside = 0 (identity affine = the plain crop)
         ops.affine_sample(data, A, corner, ps, x_slot, order=1, cval=ddf.min[index], out_ld=self.n_chan)
         ops.affine_sample(truth, At, (corner[0], corner[1], zt), (ps[0], ps[1], self.truth_size), y_slot, order=0, cval=0.0,
                           out_ld=self.truth_size)
+        if m_slot is not None:
+            # augmented: outside the mask = 0 (interpolate_affine_range, cval 0); plain crop: edge values
+            src = ddf.mask[index] if p is not None else ddf.mask_for_crops(index)
+            ops.affine_sample(src, Am, (corner[0], corner[1], zt), (ps[0], ps[1], self.truth_size), m_slot, order=0, cval=0.0,
+                              out_ld=self.truth_size)
         img = x_slot if self.n_chan == ps[2] else None
         if p is not None:
             need_intensity = p["contrast"] is not None or p["intensity_multiplication"] != 1 or p["apply_speckle_noise"] or p["apply_gaussian_noise"]
@@ -157,10 +188,11 @@ def device_data_generator(data_file, index_list, batch_size=1, n_labels=1, label
     while True:
         x = torch.empty((batch_size, ps[0], ps[1], sampler.n_chan), device=ddf.device, dtype=torch.float32)
         y = torch.empty((batch_size, ps[0], ps[1], truth_size), device=ddf.device, dtype=torch.uint8)
+        m = torch.empty((batch_size, ps[0], ps[1], truth_size), device=ddf.device, dtype=torch.float32) if ddf.mask is not None else None
         filled = 0
         while filled < batch_size:
             index = next(index_generator)
-            sampler.sample_into(index, x[filled], y[filled])
+            sampler.sample_into(index, x[filled], y[filled], None if m is None else m[filled])
             if drop_easy_patches:
                 truth_mean = float(y[filled][16:-16, 16:-16, :].float().mean().item())
                 if 1 - np.abs(truth_mean - 0.5) < np.random.random():
@@ -172,6 +204,7 @@ def device_data_generator(data_file, index_list, batch_size=1, n_labels=1, label
         if categorical:
             yy = torch.stack([1 - y, y], dim=-1).float()           # keras.utils.to_categorical(y, 2)
         if is3d:
-            yield x.unsqueeze(1), yy.unsqueeze(1)
+            xo, yo, mo = x.unsqueeze(1), yy.unsqueeze(1), (None if m is None else m.unsqueeze(1))
         else:
-            yield x, yy
+            xo, yo, mo = x, yy, m
+        yield (xo if mo is None else [xo, mo]), yo

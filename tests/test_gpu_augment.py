@@ -124,9 +124,10 @@ class _Root:
 
 
 class FakeDataFile:
-    def __init__(self, vols, truths):
+    def __init__(self, vols, truths, masks=None):
         self.root = _Root()
         self.root.data, self.root.truth = vols, truths
+        self.root.mask = masks if masks is not None else []
         self.root.subject_ids = [("s%d" % i).encode() for i in range(len(vols))]
 
 
@@ -137,13 +138,21 @@ def test_device_generator_reproduces_the_reference_batches(gold):
     for c in meta["generator_cases"]:
         vols, truths = synth_volumes(c["seed"], [tuple(s) for s in c["shapes"]])
         kw = dict(c["kwargs"])
+        masks = None
+        if c.get("masks"):          # distance masks of the mask-weighted loss -> ([x, masks], y) batches
+            masks = [scipy.ndimage.distance_transform_edt(1 - t) + scipy.ndimage.distance_transform_edt(t) for t in truths]
         np.random.seed(c["seed"])
         random.seed(c["seed"])
-        g = device_data_generator(FakeDataFile(vols, truths), list(range(len(vols))), patch_shape=tuple(c["patch"]),
+        g = device_data_generator(FakeDataFile(vols, truths, masks), list(range(len(vols))), patch_shape=tuple(c["patch"]),
                                   shuffle_index_list=False, **kw)
         for b in range(c["n_batches"]):
             x, y = next(g)
             torch.cuda.synchronize()
+            if masks is not None:
+                x, m = x
+                gm = arr["%s_m%d" % (c["name"], b)]
+                assert m.is_cuda and tuple(m.shape) == gm.shape, c["name"]
+                np.testing.assert_allclose(m.cpu().numpy(), gm, rtol=0, atol=1e-6, err_msg=c["name"] + " mask")
             gx, gy = arr["%s_x%d" % (c["name"], b)], arr["%s_y%d" % (c["name"], b)]
             assert tuple(x.shape) == gx.shape and tuple(y.shape) == gy.shape, c["name"]
             assert x.is_cuda and y.is_cuda
