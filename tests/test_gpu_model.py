@@ -298,3 +298,29 @@ def test_hdf5_checkpoint_resumes_training_exactly(tmp_path, monkeypatch, variant
         if normed and k.endswith("/bias") and not k.startswith("conv3d_transpose"):
             continue        # a bias in front of a normalisation has a zero gradient: Adam turns its rounding noise into +-lr steps
         np.testing.assert_allclose(Wb[k], Wa[k], atol=1e-4, err_msg=k)
+
+
+def test_two_stage_pipeline_on_device_models(monkeypatch):
+    """fetal_net.pipeline.predict_volume with two engine-backed models (reference prod/predict_nifti2.py:98-160): both stages run through
+    the device tile loop; the second stage equals a direct patch-wise prediction of the normalised ROI pasted into zeros."""
+    monkeypatch.setenv("FMRI_DTYPE", "fp32")
+    import fetal_net.model as fmodel
+    from fetal_net.pipeline import predict_volume
+    from fetal_net.prediction import patch_wise_prediction
+    rs = np.random.RandomState(4)
+    vol = rs.randn(40, 40, 20) * 50 + 100
+    m1 = fmodel.unet_model_3d(input_shape=(1, 16, 16, 8), depth=2, n_base_filters=8)
+    m2 = fmodel.unet_model_3d(input_shape=(1, 32, 32, 16), depth=2, n_base_filters=8)
+    W = m1.get_weights_dict()
+    final = [k for k in W if k.endswith("/bias")][-1]
+    W[final] = W[final] + 3.0                                  # stage 1 says "foreground" everywhere: the ROI is the whole volume
+    m1.set_weights_dict(W)
+    cfg1 = {"patch_shape": [16, 16], "patch_depth": 8}
+    cfg2 = {"patch_shape": [32, 32], "patch_depth": 16}
+    n1, n2 = {"mean": 100.0, "std": 50.0}, {"mean": 90.0, "std": 40.0}
+    out = predict_volume(vol, m1, cfg1, overlap_factor=0.5, norm_params=n1, model2=m2, config2=cfg2, norm_params2=n2)
+    assert out["prediction"].squeeze().shape == vol.shape and out["mask"].all()
+    direct = patch_wise_prediction(model=m2, data=((vol - 90.0) / 40.0)[None], overlap_factor=0.5, patch_shape=[32, 32, 16]).squeeze()
+    assert out["prediction_roi"].shape == vol.shape
+    np.testing.assert_allclose(out["prediction_roi"], direct, atol=1e-6)
+    assert 0.0 < float(out["prediction_roi"].min()) and float(out["prediction_roi"].max()) < 1.0
