@@ -46,10 +46,16 @@ class DataParallel:
         if g.is_cuda:
             if self._comm is None:
                 self._comm = torch.cuda.Stream(device=g.device)
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream())
+            # the bucket's gradients may come from several streams (the engine runs the conv weight gradients on their own stream)
+            streams = [torch.cuda.current_stream()] + [st for st in getattr(eng, "grad_streams", lambda: [])() if st != torch.cuda.current_stream()]
+            events = []
+            for st in streams:
+                ev = torch.cuda.Event()
+                ev.record(st)
+                events.append(ev)
             with torch.cuda.stream(self._comm):
-                self._comm.wait_event(ev)
+                for ev in events:
+                    self._comm.wait_event(ev)
                 dist.all_reduce(g, group=self.group)
         else:
             dist.all_reduce(g, group=self.group)

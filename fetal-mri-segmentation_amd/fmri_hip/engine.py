@@ -98,6 +98,8 @@ class UNetEngine:
         self.dist = dist_ctx
         self.t = 0                       # Adam step counter
         self._pack_stream, self._pack_event, self._pack_pending = None, None, False
+        self._wg_stream = (torch.cuda.Stream(device=self.dev) if (training and self.dev.type == "cuda" and os.environ.get("FMRI_WGRAD_STREAM", "1") != "0")
+                           else None)
         self.loss_kind, self.loss_param = 0, 1.0      # ops.LOSS_KINDS: 0 = dice_coefficient_loss
         self._bufsets = {}
         self._build_params(seed)
@@ -573,13 +575,23 @@ class UNetEngine:
             ops.norm_act_bwd(self._as_samples(self.pre[name]), self._as_samples(self.act[name]), self._as_samples(g),
                              self.gb_view(name, "gamma"), self.nstats[name], self._as_samples(g), self.gb_view(name, "gamma", self.G),
                              self.gb_view(name, "beta", self.G), self.norm_ws, per, act=ACT_RELU)
-        if up0 and name in self.upcat_wgrad and self._use_upcat(name):
-            ops.conv3d_upcat_wgrad(src0, src1, g, self.w_view(name, self.G), self.b_view(name, self.G), self.dwc_scratch, workspace=self.wgrad_ws,
-                                   planar=self.planar)
-        else:
-            ops.conv3d_wgrad(src0, src1, g, self.w_view(name, self.G), self.b_view(name, self.G), up0=up0, planar=self.planar,
-                             workspace=self.wgrad_ws)
-        self._grad_ready(name)
+        def wgrad():
+            if up0 and name in self.upcat_wgrad and self._use_upcat(name):
+                ops.conv3d_upcat_wgrad(src0, src1, g, self.w_view(name, self.G), self.b_view(name, self.G), self.dwc_scratch,
+                                       workspace=self.wgrad_ws, planar=self.planar)
+            else:
+                ops.conv3d_wgrad(src0, src1, g, self.w_view(name, self.G), self.b_view(name, self.G), up0=up0, planar=self.planar,
+                                 workspace=self.wgrad_ws)
+            self._grad_ready(name)
+
+        if self._wg_stream is None:
+            wgrad()
+            return
+        # the weight gradients are off the critical path of the backward pass (nothing reads them before the optimizer step): they run on
+        # their own stream, behind the event "dL/d(conv output) is final", next to the input-gradient chain of the main stream
+        self._wg_stream.wait_stream(torch.cuda.current_stream(self.dev))
+        with torch.cuda.stream(self._wg_stream):
+            wgrad()
 
     def _mask_of(self, name):
         """ReLU mask tensor a consumer applies to the gradient of `name`'s output, or None when the block is normalised (its
@@ -591,6 +603,7 @@ class UNetEngine:
     def backward(self, y_true, grad_scale=1.0, weight=None):
         p, A, Gd = self.plan, self.act, self.grad
         normed = p.norm is not None
+        self._main_stream = torch.cuda.current_stream(self.dev) if self.dev.type == "cuda" else None
         self.G.zero_()
         ops.sigmoid_loss_bwd(self.probs, y_true, self.sums, self.dlogits, self.loss_kind, self.loss_param, smooth=1.0, grad_scale=grad_scale,
                              weight=weight)
@@ -658,6 +671,8 @@ class UNetEngine:
             self._block_bwd(ca, xin, None, False)
             if ld > 0:
                 ops.conv3d_dgrad(Gd[ca["name"]], self.Wd[ca["name"]], Gd["pool_%d" % (ld - 1)], planar=self.planar)
+        if self._wg_stream is not None:
+            torch.cuda.current_stream(self.dev).wait_stream(self._wg_stream)
         if self.dist is not None:
             self.dist.finish(self)
 
@@ -684,6 +699,10 @@ class UNetEngine:
             if lv[0]["level"] == ld + 1:
                 return lv[1]["name"]
         raise KeyError(ld)
+
+    def grad_streams(self):
+        """streams that enqueue parameter-gradient kernels during backward (a gradient bucket is complete when all of them got there)"""
+        return [st for st in (getattr(self, "_main_stream", None), self._wg_stream) if st is not None]
 
     def _grad_ready(self, name):
         if self.dist is not None:

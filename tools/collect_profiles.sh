@@ -10,10 +10,14 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o stats -- python3 "$ROOT/bench.py" --steps 10 --warmup 3 --no-cpu-baseline > "$OUT/stats.log" 2>&1
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch" -o fetch -- python3 "$ROOT/bench.py" --steps 1 --warmup 1 --no-cpu-baseline > "$OUT/pmc_fetch.log" 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_write" -o write -- python3 "$ROOT/bench.py" --steps 1 --warmup 1 --no-cpu-baseline > "$OUT/pmc_write.log" 2>&1
+# default command: the weight-gradient kernels run on a second stream, concurrently with the input-gradient chain (durations overlap)
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o stats -- python3 "$ROOT/bench.py" --steps 10 --warmup 3 --no-cpu-baseline --no-exclusive-pass > "$OUT/stats.log" 2>&1
+# one stream: exclusive kernel durations (what bench.py reports as roofline_exclusive)
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_serial" -o stats -- python3 "$ROOT/bench.py" --steps 10 --warmup 3 --no-cpu-baseline --serialize-streams > "$OUT/stats_serial.log" 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch" -o fetch -- python3 "$ROOT/bench.py" --steps 1 --warmup 1 --no-cpu-baseline --serialize-streams > "$OUT/pmc_fetch.log" 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_write" -o write -- python3 "$ROOT/bench.py" --steps 1 --warmup 1 --no-cpu-baseline --serialize-streams > "$OUT/pmc_write.log" 2>&1
 cd "$ROOT"
 python3 tools/pmc_aggregate.py "$OUT" 2 > "$OUT/pmc_traffic_per_step.json"
-find "$OUT" -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} "$OUT/kernel_stats.csv"
+find "$OUT/stats" -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} "$OUT/kernel_stats.csv"
+find "$OUT/stats_serial" -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} "$OUT/kernel_stats_serial.csv"
 ls -la "$OUT"
