@@ -47,6 +47,8 @@ class LayerGraphEngine(object):
         import os
         self.pad = dtype == torch.bfloat16 and os.environ.get("FMRI_GRAPH_PAD", "1") != "0"
         self.t = 0
+        self._wg_stream = (torch.cuda.Stream(device=self.dev) if (training and self.dev.type == "cuda" and os.environ.get("FMRI_WGRAD_STREAM", "1") != "0")
+                           else None)
         self._fixed_drop = None
         self.loss_kind, self.loss_param = 0, 1.0
         self.sums = torch.zeros(16, dtype=torch.float64, device=self.dev)
@@ -452,7 +454,11 @@ class LayerGraphEngine(object):
             write(self.tmp[name])
             ops.add(self.Gt[name], self.tmp[name], self.Gt[name])
 
+    def grad_streams(self):
+        return [st for st in (getattr(self, "_main_stream", None), self._wg_stream) if st is not None]
+
     def backward(self, y_true, grad_scale=1.0, weight=None):
+        self._main_stream = torch.cuda.current_stream(self.dev) if self.dev.type == "cuda" else None
         self.G.zero_()
         self._has_grad = set()
         if self.dist is not None:
@@ -485,24 +491,33 @@ class LayerGraphEngine(object):
                 if self.pad or (o["k"] == 3 and o["s"] == 1):
                     s0 = self._t(ins[0])
                     s1 = self._t(ins[1]) if len(ins) > 1 else None
-                    if self.pad:
-                        Lc = self.layout[name]
-                        dwp, dbp = self.dWp[name], self.dbp[name]
-                        dwp.zero_()
-                        dbp.zero_()
-                        gw = g
-                        if g.shape[-1] % 64:
-                            # the MFMA weight-gradient kernel tiles Cout by 64: hand it a zero-extended copy of dy (the extra rows of dw stay 0)
-                            gw = self._dy64(g)
-                        if name in self.Wup and self.Wup[name]["wgrad"] and gw is g:
-                            ops.conv3d_upcat_wgrad(s0, None, g, dwp, dbp, self.dwc_scratch)
+
+                    def wgrad(o=o, name=name, g=g, s0=s0, s1=s1, dw=dw, db=db):
+                        if self.pad:
+                            Lc = self.layout[name]
+                            dwp, dbp = self.dWp[name], self.dbp[name]
+                            dwp.zero_()
+                            dbp.zero_()
+                            gw = g
+                            if g.shape[-1] % 64:
+                                # the MFMA weight-gradient kernel tiles Cout by 64: hand it a zero-extended copy of dy (the extra rows of dw stay 0)
+                                gw = self._dy64(g)
+                            if name in self.Wup and self.Wup[name]["wgrad"] and gw is g:
+                                ops.conv3d_upcat_wgrad(s0, None, g, dwp, dbp, self.dwc_scratch)
+                            else:
+                                ops.conv3d_wgrad(s0, s1, gw, dwp, dbp, up0=o["up0"])
+                            taps = dwp if o["k"] == 3 else dwp[13:14]
+                            dw += taps[:, :Lc["cout"]].index_select(2, self.cin_map[name])
+                            db += dbp[:Lc["cout"]]
                         else:
-                            ops.conv3d_wgrad(s0, s1, gw, dwp, dbp, up0=o["up0"])
-                        taps = dwp if o["k"] == 3 else dwp[13:14]
-                        dw += taps[:, :Lc["cout"]].index_select(2, self.cin_map[name])
-                        db += dbp[:Lc["cout"]]
-                    else:
-                        ops.conv3d_wgrad(s0, s1, g, dw, db, up0=o["up0"])
+                            ops.conv3d_wgrad(s0, s1, g, dw, db, up0=o["up0"])
+
+                    if self._wg_stream is None:
+                        wgrad()
+                    else:          # weight gradients beside the input-gradient chain (see UNetEngine._block_bwd)
+                        self._wg_stream.wait_stream(torch.cuda.current_stream(self.dev))
+                        with torch.cuda.stream(self._wg_stream):
+                            wgrad()
                     if name in self.Wup and self.training:
                         self._accum(ins[0], lambda dst: ops.conv3d_upcat_dgrad(g, self.Wup[name]["up_d"], None, None, None, dst, None))
                     elif name in self.Wd:
@@ -558,6 +573,8 @@ class LayerGraphEngine(object):
             elif kind == "maxpool":
                 src = o["ins"][0]
                 self._accum(src, lambda dst: ops.maxpool_bwd(self._t(src), g, dst, relu_mask=False))
+        if self._wg_stream is not None:
+            torch.cuda.current_stream(self.dev).wait_stream(self._wg_stream)
         if self.dist is not None:
             self.dist.finish(self)
 
