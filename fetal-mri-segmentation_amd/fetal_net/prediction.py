@@ -133,6 +133,12 @@ def _device_overlap_add(model, data_0, indices, patch_shape, batch_size, data_sh
         # 2-D: a tile is a 5-slice stack and the caller's batch (reference default 5) is far too small to fill the device - the MFMA
         # kernels also want the slice count in multiples of 4.  The overlap-add does not depend on how tiles are grouped (float64 sums)
         batch_size = max(batch_size, 64)
+    else:
+        # 3-D: the caller's batch (reference default 5) leaves a 1-tile remainder on the usual 36-tile volume and every forward pass pays its
+        # kernel tails; tiles are grouped by at least 12 and the groups are evened out (36 -> 3 x 12: device loop 52.4 -> 50.4 ms).  As above
+        # the result does not depend on the grouping.
+        groups = -(-n // max(batch_size, 12))
+        batch_size = -(-n // groups)
     sizes = sorted({min(batch_size, n - i) for i in range(0, n, batch_size)}, reverse=True)
     key = (vshape, ashape, patch, tuple(sizes), use_graph)
     st = model.__dict__.get("_tile_state")
