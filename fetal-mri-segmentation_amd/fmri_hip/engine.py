@@ -97,7 +97,7 @@ class UNetEngine:
         self.planar = plan.ndim == 2      # 2-D: tensors are [1][slices][H][W][C], every op is planar (no coupling along D)
         self.dist = dist_ctx
         self.t = 0                       # Adam step counter
-        self._pack_stream, self._pack_event, self._pack_pending = None, None, False
+        self._pack_stream, self._pack_event, self._pack_event_dec, self._pack_pending = None, None, None, 0
         self._wg_stream = (torch.cuda.Stream(device=self.dev) if (training and self.dev.type == "cuda" and os.environ.get("FMRI_WGRAD_STREAM", "1") != "0")
                            else None)
         self.loss_kind, self.loss_param = 0, 1.0      # ops.LOSS_KINDS: 0 = dice_coefficient_loss
@@ -353,22 +353,30 @@ class UNetEngine:
         if overlap and self.dev.type == "cuda" and os.environ.get("FMRI_PACK_OVERLAP", "1") != "0":
             if self._pack_stream is None:
                 self._pack_stream = torch.cuda.Stream(device=self.dev)
-                self._pack_event = torch.cuda.Event()
+                self._pack_event, self._pack_event_dec = torch.cuda.Event(), torch.cuda.Event()
             self._repack(lambda name: name in early)
             main = torch.cuda.current_stream(self.dev)
             self._pack_stream.wait_stream(main)
+            enc = set(c["name"] for lv in self.plan.enc for c in lv) - early
             with torch.cuda.stream(self._pack_stream):
-                self._repack(lambda name: name not in early)
+                # in order of first use: the encoder's images (joined after level 0), then the decoder's (joined in front of the decoder)
+                self._repack(lambda name: name in enc)
                 self._pack_event.record(self._pack_stream)
-            self._pack_pending = True
+                self._repack(lambda name: name not in early and name not in enc)
+                self._pack_event_dec.record(self._pack_stream)
+            self._pack_pending = 2
             return
         self._join_packs()
         self._repack(lambda name: True)
 
-    def _join_packs(self):
-        if self._pack_pending:
+    def _join_packs(self, decoder=True):
+        """make the current stream wait for the side-stream repack: the encoder's images, or (decoder=True) all of them"""
+        if self._pack_pending == 2:
             torch.cuda.current_stream(self.dev).wait_event(self._pack_event)
-            self._pack_pending = False
+            self._pack_pending = 1
+        if decoder and self._pack_pending == 1:
+            torch.cuda.current_stream(self.dev).wait_event(self._pack_event_dec)
+            self._pack_pending = 0
 
     def _repack(self, want):
         for name in self.Wf:
@@ -524,9 +532,10 @@ class UNetEngine:
             for c in lv:
                 h = self._block_fwd(c, h, None, False, bn_training)
             if ld == 0:
-                self._join_packs()                          # the deeper layers' weight images were repacked on the side stream
+                self._join_packs(decoder=False)             # the deeper layers' weight images were repacked on the side stream
             if ld < p.depth - 1:
                 h = ops.maxpool_fwd(h, A["pool_%d" % ld], planar=self.planar)
+        self._join_packs()
         for lv in p.dec:
             a, b = lv
             skip = A[p.enc[a["level"]][1]["name"]]
