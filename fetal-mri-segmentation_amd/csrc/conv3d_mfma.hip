@@ -553,6 +553,444 @@ k_conv_fwd_mfma(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__
 #endif
 }
 
+// ============================================================================================ forward / dgrad, warp-specialised
+// Same tiling, LDS rings and phase protocol as k_conv_fwd_mfma, with the eight waves split into two roles:
+//   waves 0-3 (consumers, one per SIMD): nothing but fragment reads + MFMAs + the epilogue.  Each owns FOUR 32-voxel column tiles (one
+//              d-plane of the 4 x 8 x 16 tile) x NT Cout tiles, so a (kw, k-step) needs NT + 4 ds_read_b128 for 4*NT MFMAs: 0.75 KB of LDS
+//              reads per MFMA instead of 1 KB.  At 1 KB per MFMA the four SIMDs ask for exactly the LDS peak (4 MFMAs x 1 KB per 32 cycles =
+//              128 B/clk), i.e. the 2 x 2 kernel is LDS-bound and MFMA-bound at once and every LDS-DMA write or bank conflict costs time;
+//   waves 4-7 (producers, one per SIMD): all LDS-DMA (filter slabs, halo pieces), its address arithmetic and the counted waits.  Their issue
+//              stalls (100-180 cycles per instruction) no longer sit in front of the MFMAs of the same wave.
+// One s_barrier per phase hands both rings over exactly as before (a producer waits for its own DMA before it arrives).
+template <int NT, bool PL, int MODE, bool RES>
+__global__ void __launch_bounds__(fw::NTHREADS)
+k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ bias, const bf16_t* __restrict__ mask,
+              const bf16_t* residual, bf16_t* y, int N, int D, int H, int W, int Cout, int act, float alpha) {
+    constexpr int TD = fw::TD, TH = fw::TH, TW = fw::TW;
+    constexpr int HD = TD + 2, HH = TH + 2, HW = TW + 2, HVOX = HD * HH * HW;
+    constexpr int H_INSTR = (HVOX * 4 + 63) / 64, HALO_BYTES = H_INSTR * 1024;
+    static_assert(!(RES && MODE != 0), "unsupported combination");
+    constexpr bool PAR = MODE != 0;
+    constexpr int BN = 32 * NT;
+    constexpr int NKW = PAR ? 2 : 3;
+    constexpr int FILT_BYTES = 3 * BN * 64;
+    constexpr int F_INSTR = NKW * BN * 64 / 1024;        // 12 / 6 (8 / 4 in the up modes)
+    constexpr int DW = 4;                                // DMA (producer) waves = MFMA (consumer) waves
+    constexpr int JT = 4;                                // column tiles per consumer wave
+    constexpr int F_PER_WAVE = (F_INSTR + DW - 1) / DW;  // 3 / 2 (2 / 1)
+    constexpr int NPIECE = (H_INSTR + DW - 1) / DW;      // 17 halo DMA instructions per producer wave and chunk
+    constexpr int NPAR = PL ? 4 : 8;
+    constexpr int NPH = PAR ? (PL ? 2 : 4) : (PL ? 3 : 9);
+    constexpr int PH0 = PL ? 3 : 0;
+    static_assert(4 * 32 * JT * BN * 2 <= HALO_BYTES && 4 * 32 * BN * 4 <= HALO_BYTES, "epilogue staging must fit the consumed halo slot");
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * HALO_BYTES + 2 * FILT_BYTES];
+
+    const int Cin = s.C0 + s.C1;
+    const int kpc = MODE == 2 ? (s.C0 >> 5) : 1;
+    const int nch = MODE == 2 ? NPAR * kpc : (Cin >> 5);
+    const int Krow = MODE == 2 ? s.C0 : Cin;
+    const int cbn = Cout / BN;
+    const int ncb = MODE == 1 ? NPAR * cbn : cbn;
+    const int twn = W / TW, thn = H / TH, tdn = D / TD;
+    const int npairs = N * tdn * thn * twn * ncb;
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int r = lane & 31, hk = lane >> 5;
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr(lds));
+    const unsigned ldsf0 = lds0 + 2 * HALO_BYTES;
+
+    auto decode = [&](int pair, int ch) {
+        FwdItem it;
+        it.ch = ch;
+        const int cb = pair % ncb;
+        it.par = MODE == 1 ? cb / cbn : 0;
+        it.co0 = (MODE == 1 ? cb % cbn : cb) * BN;
+        int q = pair / ncb;
+        it.w0 = (q % twn) * TW; q /= twn;
+        it.h0 = (q % thn) * TH; q /= thn;
+        it.d0 = (q % tdn) * TD;
+        it.n = q / tdn;
+        return it;
+    };
+    int pair = blockIdx.x;
+    if (pair >= npairs) return;
+    FwdItem cur = decode(pair, 0);
+    int g = 0, hb = 0;
+
+    if (wv >= DW) {
+        // ------------------------------------------------------------------------------------------------------------ producer
+        const int dwv = wv - DW;
+        unsigned f_voff[F_PER_WAVE];
+#pragma unroll
+        for (int k = 0; k < F_PER_WAVE; ++k) {
+            const int instr = (dwv + DW * k) % F_INSTR;
+            const int i = instr * 64 + lane;
+            const int row = i >> 2, ps = i & 3;
+            const int ls = ps ^ ((row >> 2) & 3);
+            f_voff[k] = (unsigned)(((row / BN) * Cout + (row % BN)) * Krow + ls * 8) * 2u;
+        }
+        int h_pack[NPIECE];            // halo piece ph: hd | hh<<4 | hw<<8 | ls<<13 | valid<<15
+#pragma unroll
+        for (int ph = 0; ph < NPIECE; ++ph) {
+            const int i = (ph * DW + dwv) * 64 + lane;
+            const int hv = i >> 2, ps = i & 3;
+            const int ls = ps ^ ((hv >> 2) & 3);
+            const int hvc = hv < HVOX ? hv : 0;
+            const int hw_ = hvc % HW, hq = hvc / HW;
+            h_pack[ph] = (hq / HH) | ((hq % HH) << 4) | (hw_ << 8) | (ls << 13) | ((hv < HVOX ? 1 : 0) << 15);
+        }
+        auto issue_filter = [&](const FwdItem& it, int pl, int fb) {
+            int64_t slab;
+            int koff;
+            if constexpr (MODE == 0) { slab = PH0 + pl; koff = it.ch << 5; }
+            else if constexpr (MODE == 1) { slab = it.par * NPH + pl; koff = it.ch << 5; }
+            else { slab = (it.ch / kpc) * NPH + pl; koff = (it.ch % kpc) << 5; }
+            const bf16_t* const base = wt + ((slab * NKW * Cout + it.co0) * Krow + koff);
+#pragma unroll
+            for (int k = 0; k < F_PER_WAVE; ++k)
+                if (k == 0 || dwv + DW * k < F_INSTR)
+                    dma16_s(base, f_voff[k], __builtin_amdgcn_readfirstlane(ldsf0 + fb * FILT_BYTES + ((dwv + DW * k) % F_INSTR) * 1024));
+        };
+        const bf16_t* hp[NPIECE];
+        auto halo_src = [&](const FwdItem& it, int pk) -> const bf16_t* {
+            const int gd = it.d0 - 1 + (pk & 15), gh = it.h0 - 1 + ((pk >> 4) & 15), gw = it.w0 - 1 + ((pk >> 8) & 31);
+            const int ls = (pk >> 13) & 3;
+            const bool ok = (pk >> 15) && (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W;
+            if constexpr (MODE == 2) {
+                const int p = it.ch / kpc, coff = (it.ch % kpc) << 5;
+                const int sd = PL ? min(max(gd, 0), D - 1) : 2 * min(max(gd, 0), D - 1) + (p >> 2);
+                const int sh = 2 * min(max(gh, 0), H - 1) + ((p >> 1) & 1), sw = 2 * min(max(gw, 0), W - 1) + (p & 1);
+                const int64_t off = ((((int64_t)it.n * (PL ? D : 2 * D) + sd) * 2 * H + sh) * 2 * W + sw) * s.C0 + coff + ls * 8;
+                return ok ? s.p0 + off : (const bf16_t*)g_zero_page;
+            } else {
+                const int cc = it.ch << 5;
+                const bool from0 = cc < s.C0;
+                const bf16_t* sp = from0 ? s.p0 : s.p1;
+                const int sC = from0 ? s.C0 : s.C1;
+                const int coff = from0 ? cc : cc - s.C0;
+                const int sh = (from0 && s.up0) ? 1 : 0;
+                const int shd = sh & s.dsh;
+                const int sD = D >> shd, sH = H >> sh, sW = W >> sh;
+                const int gdc = min(max(gd, 0), D - 1) >> shd, ghc = min(max(gh, 0), H - 1) >> sh, gwc = min(max(gw, 0), W - 1) >> sh;
+                const int off = ((gdc * sH + ghc) * sW + gwc) * sC + coff + ls * 8;
+                const bf16_t* real = sp + (int64_t)it.n * sD * sH * sW * sC + off;
+                return ok ? real : (const bf16_t*)g_zero_page;
+            }
+        };
+        static_assert(NPIECE * DW == H_INSTR, "every producer wave issues exactly NPIECE halo instructions per chunk (counted waits)");
+        auto issue_halo = [&](int ph, int slot) {
+            const int instr = ph * DW + dwv;
+            // planar: halo planes 0 and 5 are never read - their instructions copy zeros instead of fetching the neighbour slices (they are
+            // still issued: the counted s_waitcnt below needs the same instruction count in every wave)
+            const bool dead = PL && (instr < 11 || instr >= 57);
+            dma16(dead ? (const void*)g_zero_page : (const void*)hp[ph], __builtin_amdgcn_readfirstlane(lds0 + slot * HALO_BYTES + instr * 1024));
+        };
+        // Halo pieces of the NEXT chunk issued in phase pl: spread over the first NPH-1 phases (all of them when a chunk has one phase
+        // only... it has at least two), so that the last phase's wait - everything landed - finds them a phase old.
+        auto pieces_from = [](int pl) { return pl >= NPH - 1 ? NPIECE : pl * NPIECE / (NPH - 1); };
+        auto wait_newer = [](int n) {      // wait until at most n of this wave's DMA instructions are in flight (n folds to a constant)
+            switch (n) {
+                case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+                case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+                case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+                case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+                case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+                case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+                case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+                case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+                case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+                case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+                default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+            }
+        };
+#pragma unroll
+        for (int ph = 0; ph < NPIECE; ++ph) {
+            hp[ph] = halo_src(cur, h_pack[ph]);
+            issue_halo(ph, 0);
+        }
+        issue_filter(cur, 0, 0);
+        while (true) {
+            bool has_next = true;
+            FwdItem nxt = cur;
+            int npair = pair;
+            if (cur.ch + 1 < nch) nxt.ch = cur.ch + 1;
+            else {
+                npair = pair + gridDim.x;
+                has_next = npair < npairs;
+                if (has_next) nxt = decode(npair, 0);
+            }
+            const bool fresh = MODE == 2 ? (nxt.ch % kpc == 0) : (nxt.ch == 0 || (nxt.ch << 5) == s.C0);
+#pragma unroll
+            for (int pl = 0; pl < NPH; ++pl, ++g) {
+                // This phase's filter slab was issued one phase ago, FOLLOWED by that phase's halo pieces (which belong to the next chunk):
+                // wait for the slab only and leave those pieces in flight - a full vmcnt(0) here exposes the memory latency of every piece
+                // in every phase (measured: the producer chain issue + latency, not the MFMAs, set the phase time).  The first phase of a
+                // chunk needs its whole halo: everything must have landed, and the youngest piece is a phase old by then.
+                if (pl == 0) wait_newer(0);
+                else wait_newer(has_next ? pieces_from(pl) - pieces_from(pl - 1) : 0);
+                __builtin_amdgcn_s_barrier();                          // everybody's has landed; the previous phase is fully read
+                if (pl < NPH - 1) issue_filter(cur, pl + 1, (g + 1) & 1);
+                else if (has_next) issue_filter(nxt, 0, (g + 1) & 1);
+                if (has_next) {
+                    const int HP0 = pieces_from(pl), HPN = pieces_from(pl + 1) - HP0;
+#pragma unroll
+                    for (int q = 0; q < NPIECE; ++q) {
+                        if (q < HPN) {
+                            if (fresh) hp[HP0 + q] = halo_src(nxt, h_pack[HP0 + q]);
+                            else hp[HP0 + q] += 32;
+                            issue_halo(HP0 + q, hb ^ 1);
+                        }
+                    }
+                }
+            }
+            if (cur.ch == nch - 1) __builtin_amdgcn_s_barrier();       // the consumers' epilogue barrier
+            if (!has_next) break;
+            cur = nxt;
+            pair = npair;
+            hb ^= 1;
+        }
+        return;
+    }
+
+    // ---------------------------------------------------------------------------------------------------------------- consumer
+    const int cw = wv;
+    f32x16 acc[JT][NT];
+    const float act_s = act == FMRI_ACT_RELU ? 0.f : (act == FMRI_ACT_LEAKY ? alpha : 1.f);
+    auto load_bias = [&](int co0, float4 (&bv)[NT][4]) {
+#pragma unroll
+        for (int c = 0; c < NT; ++c)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq)
+                bv[c][gq] = bias ? *reinterpret_cast<const float4*>(bias + co0 + c * 32 + 8 * gq + 4 * hk) : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    auto init_acc = [&](const float4 (&bv)[NT][4]) {
+#pragma unroll
+        for (int j = 0; j < JT; ++j)
+#pragma unroll
+            for (int c = 0; c < NT; ++c)
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    acc[j][c][4 * gq] = bv[c][gq].x;
+                    acc[j][c][4 * gq + 1] = bv[c][gq].y;
+                    acc[j][c][4 * gq + 2] = bv[c][gq].z;
+                    acc[j][c][4 * gq + 3] = bv[c][gq].w;
+                }
+    };
+    // lane r of a column tile: h-row r>>4, w rotated by HW mod 16 on the second row (conflict-free ds_read_b128 groups, see k_conv_fwd_mfma)
+    auto tile_d = [](int rt) { return rt >> 2; };
+    auto tile_h = [](int rt, int rr) { return 2 * (rt & 3) + (rr >> 4); };
+    auto lane_w = [](int rr) { return (rr >> 4) ? (((rr & 15) + 16 - (HW & 15)) & 15) : (rr & 15); };
+    int hv0[JT];
+#pragma unroll
+    for (int j = 0; j < JT; ++j) {
+        const int rt = JT * cw + j;
+        hv0[j] = (tile_d(rt) * HH + tile_h(rt, r)) * HW + lane_w(r);
+    }
+    const int fa[2] = {swz64(r, hk), swz64(r, hk) ^ 32};
+    {
+        float4 bv0[NT][4];
+        load_bias(cur.co0, bv0);
+        init_acc(bv0);
+    }
+#ifdef FMRI_PROF
+    unsigned long long cprof[12] = {};
+    PROF_T(ck0);
+#endif
+    while (true) {
+        bool has_next = true;
+        FwdItem nxt = cur;
+        int npair = pair;
+        if (cur.ch + 1 < nch) nxt.ch = cur.ch + 1;
+        else {
+            npair = pair + gridDim.x;
+            has_next = npair < npairs;
+            if (has_next) nxt = decode(npair, 0);
+        }
+        const unsigned char* const lh = lds + hb * HALO_BYTES;
+#pragma unroll
+        for (int j = 0; j < JT; ++j) asm volatile("" : "+v"(hv0[j]));
+#pragma unroll
+        for (int pl = 0; pl < NPH; ++pl, ++g) {
+            PROF_T(c0);
+            __builtin_amdgcn_s_barrier();
+            PROF_T(c1);
+            const unsigned char* const lf = lds + 2 * HALO_BYTES + (g & 1) * FILT_BYTES;
+            int hoff, kw0 = 0;
+            if constexpr (!PAR) hoff = (((PH0 + pl) / 3) * HH + ((PH0 + pl) % 3)) * HW;
+            else {
+                const int p = MODE == 1 ? cur.par : (NPAR - 1) - cur.ch / kpc;
+                if constexpr (PL) hoff = (HH + pl + ((p >> 1) & 1)) * HW;
+                else hoff = (((pl >> 1) + (p >> 2)) * HH + ((pl & 1) + ((p >> 1) & 1))) * HW;
+                kw0 = p & 1;
+            }
+            // One wave per SIMD feeds the MFMA pipe alone: the fragments of step st+1 (a (kw, k-step) pair) are requested before the MFMAs
+            // of step st are issued, into the other half of a double register set, so that the LDS latency runs under 4*NT MFMAs
+            // (left to the compiler the reads were issued right in front of their MFMAs: 43 instead of 32 cycles per MFMA).
+            constexpr int NST = NKW * 2;
+            bf16x8_t fa_[2][NT], fb_[2][JT];
+            auto load_a = [&](int st, int buf) {
+                const int kw = st >> 1, ks = st & 1;
+#pragma unroll
+                for (int c = 0; c < NT; ++c)
+                    fa_[buf][c] = *reinterpret_cast<const bf16x8_t*>(lf + fa[ks] + (kw * BN + c * 32) * 64);
+            };
+            auto load_b = [&](int st, int buf, int j) {
+                const int kw = st >> 1, ks = st & 1;
+                fb_[buf][j] = *reinterpret_cast<const bf16x8_t*>(lh + (swz64(hv0[j] + hoff + kw + kw0, hk) ^ (ks << 5)));
+            };
+            load_a(0, 0);
+#pragma unroll
+            for (int j = 0; j < JT; ++j) load_b(0, 0, j);
+#pragma unroll
+            for (int st = 0; st < NST; ++st) {
+                // the requests of step st+1 are threaded between the MFMAs of step st: address arithmetic and ds_reads issue in the shadow of
+                // the MFMA that was just started instead of in a block of their own
+                if (st + 1 < NST) load_a(st + 1, (st + 1) & 1);
+#pragma unroll
+                for (int j = 0; j < JT; ++j) {
+#pragma unroll
+                    for (int c = 0; c < NT; ++c)
+                        acc[j][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_[st & 1][c], fb_[st & 1][j], acc[j][c], 0, 0, 0);
+                    if (st + 1 < NST) load_b(st + 1, (st + 1) & 1, j);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            PROF_T(c2);
+#ifdef FMRI_PROF
+            cprof[1] += c1 - c0; cprof[3] += c2 - c1; cprof[6] += 1;
+#endif
+        }
+        PROF_T(ce0);
+        if (RES && cur.ch == nch - 1) {
+            // y = act(acc + residual): fp32 transposition through LDS, one 32-voxel column tile at a time (wave-private 8 KiB)
+            constexpr int PPV = BN / 4, LPV = BN / 8, VPI = 64 / LPV;
+            float4 bvn[NT][4];
+            load_bias(has_next ? nxt.co0 : cur.co0, bvn);
+            __builtin_amdgcn_s_barrier();
+            unsigned char* const stage = lds + hb * HALO_BYTES + cw * (32 * BN * 4);
+            const int64_t org = ((((int64_t)cur.n * D + cur.d0) * H + cur.h0) * W + cur.w0) * Cout + cur.co0;
+#pragma unroll
+            for (int j = 0; j < JT; ++j) {
+#pragma unroll
+                for (int c = 0; c < NT; ++c)
+#pragma unroll
+                    for (int gq = 0; gq < 4; ++gq) {
+                        const int q = c * 8 + 2 * gq + hk;
+                        *reinterpret_cast<float4*>(stage + r * (BN * 4) + (((q ^ r) & (PPV - 1)) << 4)) =
+                            make_float4(acc[j][c][4 * gq], acc[j][c][4 * gq + 1], acc[j][c][4 * gq + 2], acc[j][c][4 * gq + 3]);
+                    }
+                const int rt = JT * cw + j;
+#pragma unroll
+                for (int kk = 0; kk < 32 / VPI; ++kk) {
+                    const int rr = kk * VPI + lane / LPV, q8 = lane % LPV;
+                    const float4 a0 = *reinterpret_cast<const float4*>(stage + rr * (BN * 4) + ((((2 * q8) ^ rr) & (PPV - 1)) << 4));
+                    const float4 a1 = *reinterpret_cast<const float4*>(stage + rr * (BN * 4) + ((((2 * q8 + 1) ^ rr) & (PPV - 1)) << 4));
+                    const int64_t ao = org + ((tile_d(rt) * H + tile_h(rt, rr)) * W + lane_w(rr)) * Cout + q8 * 8;
+                    const uint4 r4 = *reinterpret_cast<const uint4*>(residual + ao);
+                    float o[8] = {a0.x + __uint_as_float(r4.x << 16), a0.y + __uint_as_float(r4.x & 0xffff0000u),
+                                  a0.z + __uint_as_float(r4.y << 16), a0.w + __uint_as_float(r4.y & 0xffff0000u),
+                                  a1.x + __uint_as_float(r4.z << 16), a1.y + __uint_as_float(r4.z & 0xffff0000u),
+                                  a1.z + __uint_as_float(r4.w << 16), a1.w + __uint_as_float(r4.w & 0xffff0000u)};
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) o[i] = vmax(o[i], __builtin_fmaf(o[i], act_s, 0.f));
+                    *reinterpret_cast<uint4*>(y + ao) = make_uint4(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]), pack2bf(o[4], o[5]), pack2bf(o[6], o[7]));
+                }
+            }
+            init_acc(bvn);
+        }
+        if (!RES && cur.ch == nch - 1) {
+            // bias is in the accumulators; activation, bf16, half-wave exchange, wave-private LDS transposition (16 KiB per consumer wave of
+            // the consumed halo slot), line-major stores
+            constexpr int CPV = BN / 8;                  // 16-byte pieces per voxel
+            constexpr int VPI = 64 / CPV;                // voxels per store instruction
+            constexpr int SWM = NT == 2 ? 7 : 3;
+            float4 bvn[NT][4];
+            load_bias(has_next ? nxt.co0 : cur.co0, bvn);
+            __builtin_amdgcn_s_barrier();
+            unsigned char* const stage = lds + hb * HALO_BYTES + cw * (32 * JT * BN * 2);
+#pragma unroll
+            for (int j = 0; j < JT; ++j) {
+                const int v = j * 32 + r;
+                const int vs = NT == 2 ? (v & 7) : ((v >> 2) & 3);
+#pragma unroll
+                for (int c = 0; c < NT; ++c) {
+#pragma unroll
+                    for (int pq = 0; pq < 2; ++pq) {
+                        unsigned pk[2][2];
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            const int gq = 2 * pq + u;
+                            float o[4];
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                const float vv = acc[j][c][4 * gq + i];
+                                o[i] = vmax(vv, __builtin_fmaf(vv, act_s, 0.f));
+                            }
+                            pk[u][0] = pack2bf(o[0], o[1]);
+                            pk[u][1] = pack2bf(o[2], o[3]);
+                        }
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            auto sw = __builtin_amdgcn_permlane32_swap(pk[0][q], pk[1][q], false, false);
+                            pk[0][q] = sw[0];
+                            pk[1][q] = sw[1];
+                        }
+                        const int q = c * 4 + pq * 2 + hk;
+                        *reinterpret_cast<uint4*>(stage + v * (BN * 2) + (((q ^ vs) & SWM) << 4)) =
+                            make_uint4(pk[0][0], pk[0][1], pk[1][0], pk[1][1]);
+                    }
+                }
+            }
+            init_acc(bvn);
+#pragma unroll
+            for (int kk = 0; kk < (32 * JT) / VPI; ++kk) {
+                const int v = kk * VPI + lane / CPV, q = lane % CPV;
+                const int vs = NT == 2 ? (v & 7) : ((v >> 2) & 3);
+                uint4 o4 = *reinterpret_cast<const uint4*>(stage + v * (BN * 2) + (((q ^ vs) & SWM) << 4));
+                const int rt = JT * cw + (v >> 5), rr = v & 31;
+                int64_t ao;
+                if constexpr (MODE == 1 && PL) {
+                    const int64_t org = ((((int64_t)cur.n * D + cur.d0) * 2 * H + 2 * cur.h0 + ((cur.par >> 1) & 1)) * 2 * W + 2 * cur.w0 + (cur.par & 1)) * Cout +
+                                        cur.co0;
+                    ao = org + ((tile_d(rt) * 2 * H + 2 * tile_h(rt, rr)) * 2 * W + 2 * lane_w(rr)) * Cout + q * 8;
+                } else if constexpr (MODE == 1) {
+                    const int64_t org = ((((int64_t)cur.n * 2 * D + 2 * cur.d0 + (cur.par >> 2)) * 2 * H + 2 * cur.h0 + ((cur.par >> 1) & 1)) * 2 * W +
+                                         2 * cur.w0 + (cur.par & 1)) * Cout + cur.co0;
+                    ao = org + ((2 * tile_d(rt) * 2 * H + 2 * tile_h(rt, rr)) * 2 * W + 2 * lane_w(rr)) * Cout + q * 8;
+                } else {
+                    const int64_t org = ((((int64_t)cur.n * D + cur.d0) * H + cur.h0) * W + cur.w0) * Cout + cur.co0;
+                    ao = org + ((tile_d(rt) * H + tile_h(rt, rr)) * W + lane_w(rr)) * Cout + q * 8;
+                }
+                if (mask) {
+                    const uint4 m4 = *reinterpret_cast<const uint4*>(mask + ao);
+                    const unsigned mm[4] = {m4.x, m4.y, m4.z, m4.w};
+                    unsigned* const oo = reinterpret_cast<unsigned*>(&o4);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        if (!(__uint_as_float(mm[i] << 16) > 0.f)) oo[i] &= 0xffff0000u;
+                        if (!(__uint_as_float(mm[i] & 0xffff0000u) > 0.f)) oo[i] &= 0x0000ffffu;
+                    }
+                }
+                *reinterpret_cast<uint4*>(y + ao) = o4;
+            }
+        }
+#ifdef FMRI_PROF
+        { PROF_T(ce1); cprof[4] += ce1 - ce0; }
+#endif
+        if (!has_next) break;
+        cur = nxt;
+        pair = npair;
+        hb ^= 1;
+    }
+#ifdef FMRI_PROF
+    PROF_T(ck1);
+    cprof[5] = ck1 - ck0;
+    if (lane == 0)
+        for (int i = 0; i < 12; ++i) atomicAdd(&g_prof[i], cprof[i]);
+#endif
+}
+
 // ======================================================================================================== weight gradient
 // One "unit" of work = one d-plane tile of 8 x 16 output voxels (8 k-steps of 16 voxels along w) for one kd.  A workgroup
 // (4 waves, 2 workgroups per CU) owns a (kd, 64-wide Cout block, CIB-wide Cin block) slice of dw, keeps its 9 taps x
@@ -917,11 +1355,21 @@ int conv3d_fwd_mfma_ex(int mode, const void* src0, int C0, int up0, int planar, 
         else
             ncu = 256;
     }
+    // FMRI_FWD_WS=0: the symmetric kernel (every wave issues DMA and MFMAs) instead of the warp-specialised one
+    static int use_ws = -1;
+    if (use_ws < 0) {
+        const char* e = getenv("FMRI_FWD_WS");
+        use_ws = e ? atoi(e) : 1;
+    }
 #define FMRI_LAUNCH_FWD(NT_, PL_, MODE_, RES_)                                                                             \
     do {                                                                                                                  \
         const int np = ntile * (Cout / (32 * NT_)) * (MODE_ == 1 ? (PL_ ? 4 : 8) : 1);                                    \
-        k_conv_fwd_mfma<NT_, PL_, MODE_, RES_><<<np < ncu ? np : ncu, fw::NTHREADS, 0, st>>>(                             \
-            s, (const bf16_t*)w, bias, (const bf16_t*)mask, (const bf16_t*)residual, (bf16_t*)y, N, D, H, W, Cout, act, alpha); \
+        if (use_ws && !(PL_))   /* planar: 17 halo pieces in 2 phases make the producers the bottleneck - symmetric kernel */ \
+            k_conv_fwd_ws<NT_, PL_, MODE_, RES_><<<np < ncu ? np : ncu, fw::NTHREADS, 0, st>>>(                           \
+                s, (const bf16_t*)w, bias, (const bf16_t*)mask, (const bf16_t*)residual, (bf16_t*)y, N, D, H, W, Cout, act, alpha); \
+        else                                                                                                              \
+            k_conv_fwd_mfma<NT_, PL_, MODE_, RES_><<<np < ncu ? np : ncu, fw::NTHREADS, 0, st>>>(                         \
+                s, (const bf16_t*)w, bias, (const bf16_t*)mask, (const bf16_t*)residual, (bf16_t*)y, N, D, H, W, Cout, act, alpha); \
     } while (0)
     // 64-wide Cout blocks halve the halo traffic per MFMA, but a launch with fewer (tile, block) pairs than CUs (the 8x16x16 bottleneck
     // level) leaves CUs idle: 32-wide blocks double the pairs there
