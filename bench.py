@@ -305,7 +305,7 @@ def main():
             ach = flops / (t_ms * 1e-3) / 1e12
             r = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS,
                  "note": note,
-                 "traffic": pmc_traffic("k_conv_fwd_mfma" if dom == "conv_fwd_mfma" else "k_conv_wgrad_mfma"),
+                 "traffic": pmc_traffic("k_conv_fwd_" if dom == "conv_fwd_mfma" else "k_conv_wgrad_mfma"),   # k_conv_fwd_ws<..> and k_conv_fwd_mfma<..>
                  "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, separate passes, FETCH_SIZE x2 corrected)",
                  "algorithmic_flop_per_launch": flops / max(launches, 1), "launches_per_step": launches,
                  "avg_launch_ms": t_ms / max(launches, 1)}

@@ -618,6 +618,49 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
     FwdItem cur = decode(pair, 0);
     int g = 0, hb = 0;
 
+    // Plain epilogue, second half: the tile's 512 voxels x BN channels sit in the consumed halo slot as bf16, voxel-major (written by the
+    // consumers); ALL eight waves - the producers have nothing else to do at this point - read them back line-major and store 64 voxels each
+    // (8 or 4 lanes per voxel write its 128 or 64 contiguous bytes), with the optional ReLU mask of the producer of the tensor.
+    auto tile_d = [](int rt) { return rt >> 2; };
+    auto tile_h = [](int rt, int rr) { return 2 * (rt & 3) + (rr >> 4); };
+    auto lane_w = [](int rr) { return (rr >> 4) ? (((rr & 15) + 16 - (HW & 15)) & 15) : (rr & 15); };
+    auto store_share = [&](const FwdItem& it, int slot) {
+        constexpr int CPV = BN / 8;                  // 16-byte pieces per voxel
+        constexpr int VPI = 64 / CPV;                // voxels per store instruction
+        constexpr int SWM = NT == 2 ? 7 : 3;
+        const unsigned char* const stage = lds + slot * HALO_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < CPV; ++kk) {
+            const int v = wv * 64 + kk * VPI + lane / CPV, q = lane % CPV;       // tile-wide voxel index: column tile v >> 5, lane v & 31
+            const int vs = NT == 2 ? (v & 7) : ((v >> 2) & 3);
+            uint4 o4 = *reinterpret_cast<const uint4*>(stage + v * (BN * 2) + (((q ^ vs) & SWM) << 4));
+            const int rt = v >> 5, rr = v & 31;
+            int64_t ao;
+            if constexpr (MODE == 1 && PL) {
+                const int64_t org = ((((int64_t)it.n * D + it.d0) * 2 * H + 2 * it.h0 + ((it.par >> 1) & 1)) * 2 * W + 2 * it.w0 + (it.par & 1)) * Cout + it.co0;
+                ao = org + ((tile_d(rt) * 2 * H + 2 * tile_h(rt, rr)) * 2 * W + 2 * lane_w(rr)) * Cout + q * 8;
+            } else if constexpr (MODE == 1) {
+                const int64_t org = ((((int64_t)it.n * 2 * D + 2 * it.d0 + (it.par >> 2)) * 2 * H + 2 * it.h0 + ((it.par >> 1) & 1)) * 2 * W +
+                                     2 * it.w0 + (it.par & 1)) * Cout + it.co0;
+                ao = org + ((2 * tile_d(rt) * 2 * H + 2 * tile_h(rt, rr)) * 2 * W + 2 * lane_w(rr)) * Cout + q * 8;
+            } else {
+                const int64_t org = ((((int64_t)it.n * D + it.d0) * H + it.h0) * W + it.w0) * Cout + it.co0;
+                ao = org + ((tile_d(rt) * H + tile_h(rt, rr)) * W + lane_w(rr)) * Cout + q * 8;
+            }
+            if (mask) {
+                const uint4 m4 = *reinterpret_cast<const uint4*>(mask + ao);
+                const unsigned mm[4] = {m4.x, m4.y, m4.z, m4.w};
+                unsigned* const oo = reinterpret_cast<unsigned*>(&o4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (!(__uint_as_float(mm[i] << 16) > 0.f)) oo[i] &= 0xffff0000u;
+                    if (!(__uint_as_float(mm[i] & 0xffff0000u) > 0.f)) oo[i] &= 0x0000ffffu;
+                }
+            }
+            *reinterpret_cast<uint4*>(y + ao) = o4;
+        }
+    };
+
     if (wv >= DW) {
         // ------------------------------------------------------------------------------------------------------------ producer
         const int dwv = wv - DW;
@@ -744,7 +787,13 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
                     }
                 }
             }
-            if (cur.ch == nch - 1) __builtin_amdgcn_s_barrier();       // the consumers' epilogue barrier
+            if (cur.ch == nch - 1) {
+                __builtin_amdgcn_s_barrier();                          // the halo slot is fully read: the consumers stage the tile in it
+                if constexpr (!RES) {
+                    __builtin_amdgcn_s_barrier();                      // staged
+                    store_share(cur, hb);
+                }
+            }
             if (!has_next) break;
             cur = nxt;
             pair = npair;
@@ -778,9 +827,6 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
                 }
     };
     // lane r of a column tile: h-row r>>4, w rotated by HW mod 16 on the second row (conflict-free ds_read_b128 groups, see k_conv_fwd_mfma)
-    auto tile_d = [](int rt) { return rt >> 2; };
-    auto tile_h = [](int rt, int rr) { return 2 * (rt & 3) + (rr >> 4); };
-    auto lane_w = [](int rr) { return (rr >> 4) ? (((rr & 15) + 16 - (HW & 15)) & 15) : (rr & 15); };
     int hv0[JT];
 #pragma unroll
     for (int j = 0; j < JT; ++j) {
@@ -943,37 +989,8 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
                 }
             }
             init_acc(bvn);
-#pragma unroll
-            for (int kk = 0; kk < (32 * JT) / VPI; ++kk) {
-                const int v = kk * VPI + lane / CPV, q = lane % CPV;
-                const int vs = NT == 2 ? (v & 7) : ((v >> 2) & 3);
-                uint4 o4 = *reinterpret_cast<const uint4*>(stage + v * (BN * 2) + (((q ^ vs) & SWM) << 4));
-                const int rt = JT * cw + (v >> 5), rr = v & 31;
-                int64_t ao;
-                if constexpr (MODE == 1 && PL) {
-                    const int64_t org = ((((int64_t)cur.n * D + cur.d0) * 2 * H + 2 * cur.h0 + ((cur.par >> 1) & 1)) * 2 * W + 2 * cur.w0 + (cur.par & 1)) * Cout +
-                                        cur.co0;
-                    ao = org + ((tile_d(rt) * 2 * H + 2 * tile_h(rt, rr)) * 2 * W + 2 * lane_w(rr)) * Cout + q * 8;
-                } else if constexpr (MODE == 1) {
-                    const int64_t org = ((((int64_t)cur.n * 2 * D + 2 * cur.d0 + (cur.par >> 2)) * 2 * H + 2 * cur.h0 + ((cur.par >> 1) & 1)) * 2 * W +
-                                         2 * cur.w0 + (cur.par & 1)) * Cout + cur.co0;
-                    ao = org + ((2 * tile_d(rt) * 2 * H + 2 * tile_h(rt, rr)) * 2 * W + 2 * lane_w(rr)) * Cout + q * 8;
-                } else {
-                    const int64_t org = ((((int64_t)cur.n * D + cur.d0) * H + cur.h0) * W + cur.w0) * Cout + cur.co0;
-                    ao = org + ((tile_d(rt) * H + tile_h(rt, rr)) * W + lane_w(rr)) * Cout + q * 8;
-                }
-                if (mask) {
-                    const uint4 m4 = *reinterpret_cast<const uint4*>(mask + ao);
-                    const unsigned mm[4] = {m4.x, m4.y, m4.z, m4.w};
-                    unsigned* const oo = reinterpret_cast<unsigned*>(&o4);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        if (!(__uint_as_float(mm[i] << 16) > 0.f)) oo[i] &= 0xffff0000u;
-                        if (!(__uint_as_float(mm[i] & 0xffff0000u) > 0.f)) oo[i] &= 0x0000ffffu;
-                    }
-                }
-                *reinterpret_cast<uint4*>(y + ao) = o4;
-            }
+            __builtin_amdgcn_s_barrier();                              // the whole tile is staged: all eight waves store it
+            store_share(cur, hb);
         }
 #ifdef FMRI_PROF
         { PROF_T(ce1); cprof[4] += ce1 - ce0; }
