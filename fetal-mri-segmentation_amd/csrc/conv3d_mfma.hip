@@ -578,7 +578,10 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
     constexpr int DW = 4;                                // DMA (producer) waves = MFMA (consumer) waves
     constexpr int JT = 4;                                // column tiles per consumer wave
     constexpr int F_PER_WAVE = (F_INSTR + DW - 1) / DW;  // 3 / 2 (2 / 1)
-    constexpr int NPIECE = (H_INSTR + DW - 1) / DW;      // 17 halo DMA instructions per producer wave and chunk
+    // halo DMA instructions per producer wave and chunk.  Planar (2-D slices): halo planes 0 and 5 are never read, only the instructions
+    // 11..56 that touch planes 1-4 are issued (46 -> 12 per wave, the last two are zero copies so that every wave issues the same number)
+    constexpr int H_I0 = PL ? 11 : 0, H_I1 = PL ? 57 : H_INSTR;
+    constexpr int NPIECE = (H_I1 - H_I0 + DW - 1) / DW;  // 17 (12)
     constexpr int NPAR = PL ? 4 : 8;
     constexpr int NPH = PAR ? (PL ? 2 : 4) : (PL ? 3 : 9);
     constexpr int PH0 = PL ? 3 : 0;
@@ -676,7 +679,7 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
         int h_pack[NPIECE];            // halo piece ph: hd | hh<<4 | hw<<8 | ls<<13 | valid<<15
 #pragma unroll
         for (int ph = 0; ph < NPIECE; ++ph) {
-            const int i = (ph * DW + dwv) * 64 + lane;
+            const int i = (H_I0 + ph * DW + dwv) * 64 + lane;
             const int hv = i >> 2, ps = i & 3;
             const int ls = ps ^ ((hv >> 2) & 3);
             const int hvc = hv < HVOX ? hv : 0;
@@ -721,12 +724,12 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
                 return ok ? real : (const bf16_t*)g_zero_page;
             }
         };
-        static_assert(NPIECE * DW == H_INSTR, "every producer wave issues exactly NPIECE halo instructions per chunk (counted waits)");
+        static_assert(NPIECE * DW >= H_I1 - H_I0 && NPIECE * DW - (H_I1 - H_I0) < DW, "piece map");
         auto issue_halo = [&](int ph, int slot) {
-            const int instr = ph * DW + dwv;
-            // planar: halo planes 0 and 5 are never read - their instructions copy zeros instead of fetching the neighbour slices (they are
-            // still issued: the counted s_waitcnt below needs the same instruction count in every wave)
-            const bool dead = PL && (instr < 11 || instr >= 57);
+            const int instr = H_I0 + ph * DW + dwv;
+            // every wave issues exactly NPIECE instructions per chunk (the counted s_waitcnt below relies on it): the few past the last live
+            // instruction copy zeros into the dead rows behind it
+            const bool dead = instr >= H_I1;
             dma16(dead ? (const void*)g_zero_page : (const void*)hp[ph], __builtin_amdgcn_readfirstlane(lds0 + slot * HALO_BYTES + instr * 1024));
         };
         // Halo pieces of the NEXT chunk issued in phase pl: spread over the first NPH-1 phases (all of them when a chunk has one phase
@@ -1381,7 +1384,7 @@ int conv3d_fwd_mfma_ex(int mode, const void* src0, int C0, int up0, int planar, 
 #define FMRI_LAUNCH_FWD(NT_, PL_, MODE_, RES_)                                                                             \
     do {                                                                                                                  \
         const int np = ntile * (Cout / (32 * NT_)) * (MODE_ == 1 ? (PL_ ? 4 : 8) : 1);                                    \
-        if (use_ws && !(PL_))   /* planar: 17 halo pieces in 2 phases make the producers the bottleneck - symmetric kernel */ \
+        if (use_ws && (!(PL_) || use_ws > 1))   /* planar: the producers are the bottleneck - symmetric kernel */ \
             k_conv_fwd_ws<NT_, PL_, MODE_, RES_><<<np < ncu ? np : ncu, fw::NTHREADS, 0, st>>>(                           \
                 s, (const bf16_t*)w, bias, (const bf16_t*)mask, (const bf16_t*)residual, (bf16_t*)y, N, D, H, W, Cout, act, alpha); \
         else                                                                                                              \
