@@ -338,26 +338,43 @@ k_conv1x1_bwd_v2(const T* __restrict__ x, const float* __restrict__ w, const flo
         for (int k = 0; k < 8; ++k) { wr[l][k] = l < L ? w[l * C + sub * 8 + k] : 0.f; aw[l][k] = 0.f; }
     }
     const int64_t vpb = blockDim.x / LPV;
-    for (int64_t v = blockIdx.x * vpb + threadIdx.x / LPV; v < nvox; v += (int64_t)gridDim.x * vpb) {
-        float xv[8], gx[8];
-        ldv<T, 8>(x + v * C + sub * 8, xv);
+    const int64_t stride = (int64_t)gridDim.x * vpb;
+    // four voxels per trip: their loads are issued together (HBM-bound kernel: one dependent load per trip left the memory pipe half empty)
+    for (int64_t v0 = blockIdx.x * vpb + threadIdx.x / LPV; v0 < nvox; v0 += 4 * stride) {
+        float xv[4][8];
+        float gl[4][4];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) gx[k] = 0.f;
+        for (int u = 0; u < 4; ++u) {
+            const int64_t v = v0 + u * stride;
+            if (v < nvox) {
+                ldv<T, 8>(x + v * C + sub * 8, xv[u]);
 #pragma unroll
-        for (int l = 0; l < 4; ++l) {
-            if (l < L) {
-                const float g = dl[v * L + l];
-                ab[l] += g;
-#pragma unroll
-                for (int k = 0; k < 8; ++k) { gx[k] = fmaf(g, wr[l][k], gx[k]); aw[l][k] = fmaf(g, xv[k], aw[l][k]); }
+                for (int l = 0; l < 4; ++l) gl[u][l] = l < L ? dl[v * L + l] : 0.f;
             }
         }
-        if (dx) {
-            if (relu_mask) {
 #pragma unroll
-                for (int k = 0; k < 8; ++k) if (!(xv[k] > 0.f)) gx[k] = 0.f;
+        for (int u = 0; u < 4; ++u) {
+            const int64_t v = v0 + u * stride;
+            if (v >= nvox) break;
+            float gx[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) gx[k] = 0.f;
+#pragma unroll
+            for (int l = 0; l < 4; ++l) {
+                if (l < L) {
+                    const float g = gl[u][l];
+                    ab[l] += g;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) { gx[k] = fmaf(g, wr[l][k], gx[k]); aw[l][k] = fmaf(g, xv[u][k], aw[l][k]); }
+                }
             }
-            stv<T, 8>(dx + v * C + sub * 8, gx);
+            if (dx) {
+                if (relu_mask) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) if (!(xv[u][k] > 0.f)) gx[k] = 0.f;
+                }
+                stv<T, 8>(dx + v * C + sub * 8, gx);
+            }
         }
     }
     for (int l = 0; l < L; ++l) {
@@ -431,7 +448,7 @@ extern "C" int fmri_conv1x1_bwd(const void* x, const float* w, const float* dlog
     hipStream_t s = as_stream(stream);
     size_t sh = (size_t)L * (2 * C + 1) * 4;
     if (int lpv = lpv_of(C, L)) {
-        int g2 = grid_for(nvox * lpv, 256, 256 * 4);
+        int g2 = grid_for(nvox * lpv, 256, 256 * 16);
         size_t sh2 = (size_t)L * (C + 1) * 4;
         if (dtype == FMRI_F32) { LAUNCH_LPV(k_conv1x1_bwd_v2, float, lpv, g2, sh2, s, (const float*)x, w, dlogits, (float*)dx, dw, db, nvox, C, L, relu_mask) }
         else if (dtype == FMRI_BF16) { LAUNCH_LPV(k_conv1x1_bwd_v2, bf16_t, lpv, g2, sh2, s, (const bf16_t*)x, w, dlogits, (bf16_t*)dx, dw, db, nvox, C, L, relu_mask) }
