@@ -846,6 +846,7 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
     unsigned long long cprof[12] = {};
     PROF_T(ck0);
 #endif
+    bf16x8_t fa_[2][NT], fb_[2][JT];           // double-buffered filter / halo fragments (live across the phases of a tile)
     while (true) {
         bool has_next = true;
         FwdItem nxt = cur;
@@ -856,52 +857,73 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
             has_next = npair < npairs;
             if (has_next) nxt = decode(npair, 0);
         }
-        const unsigned char* const lh = lds + hb * HALO_BYTES;
 #pragma unroll
         for (int j = 0; j < JT; ++j) asm volatile("" : "+v"(hv0[j]));
+        // (halo slot, halo row offset of the (kd,kh) row, first kw) of phase `pl` of item `it` whose halo sits in slot `slot`
+        auto phase_hoff = [&](const FwdItem& it, int pl, int& kw0) {
+            kw0 = 0;
+            if constexpr (!PAR) return (((PH0 + pl) / 3) * HH + ((PH0 + pl) % 3)) * HW;
+            else {
+                const int p = MODE == 1 ? it.par : (NPAR - 1) - it.ch / kpc;
+                kw0 = p & 1;
+                if constexpr (PL) return (HH + pl + ((p >> 1) & 1)) * HW;
+                else return (((pl >> 1) + (p >> 2)) * HH + ((pl & 1) + ((p >> 1) & 1))) * HW;
+            }
+        };
+        constexpr int NST = NKW * 2;
+        // One wave per SIMD feeds the MFMA pipe alone: the fragments of step st+1 (a (kw, k-step) pair) are requested before the MFMAs of
+        // step st are issued, into the other half of a double register set, threaded between those MFMAs (left to the compiler the reads
+        // sat right in front of their MFMAs).  The pipeline runs ACROSS the phase barrier inside a tile: once the fragments of a phase's
+        // last step are in registers this wave is done reading the rings, so it passes the next phase's barrier BEFORE issuing that step's
+        // MFMAs and requests the next phase's first fragments under them - only the first phase of a tile starts with an exposed LDS latency.
+        auto load_a = [&](const unsigned char* lfp, int st, int buf) {
+            const int kw = st >> 1, ks = st & 1;
+#pragma unroll
+            for (int c = 0; c < NT; ++c) fa_[buf][c] = *reinterpret_cast<const bf16x8_t*>(lfp + fa[ks] + (kw * BN + c * 32) * 64);
+        };
+        auto load_b = [&](const unsigned char* lhp, int hoffp, int kw0p, int st, int buf, int j) {
+            const int kw = st >> 1, ks = st & 1;
+            fb_[buf][j] = *reinterpret_cast<const bf16x8_t*>(lhp + (swz64(hv0[j] + hoffp + kw + kw0p, hk) ^ (ks << 5)));
+        };
 #pragma unroll
         for (int pl = 0; pl < NPH; ++pl, ++g) {
             PROF_T(c0);
-            __builtin_amdgcn_s_barrier();
-            PROF_T(c1);
+            const unsigned char* const lh = lds + hb * HALO_BYTES;
             const unsigned char* const lf = lds + 2 * HALO_BYTES + (g & 1) * FILT_BYTES;
-            int hoff, kw0 = 0;
-            if constexpr (!PAR) hoff = (((PH0 + pl) / 3) * HH + ((PH0 + pl) % 3)) * HW;
-            else {
-                const int p = MODE == 1 ? cur.par : (NPAR - 1) - cur.ch / kpc;
-                if constexpr (PL) hoff = (HH + pl + ((p >> 1) & 1)) * HW;
-                else hoff = (((pl >> 1) + (p >> 2)) * HH + ((pl & 1) + ((p >> 1) & 1))) * HW;
-                kw0 = p & 1;
+            int kw0;
+            const int hoff = phase_hoff(cur, pl, kw0);
+            if (pl == 0 && cur.ch == 0) {          // first phase of a tile: nothing was primed across the epilogue
+                __builtin_amdgcn_s_barrier();
+                load_a(lf, 0, 0);
+#pragma unroll
+                for (int j = 0; j < JT; ++j) load_b(lh, hoff, kw0, 0, 0, j);
             }
-            // One wave per SIMD feeds the MFMA pipe alone: the fragments of step st+1 (a (kw, k-step) pair) are requested before the MFMAs
-            // of step st are issued, into the other half of a double register set, so that the LDS latency runs under 4*NT MFMAs
-            // (left to the compiler the reads were issued right in front of their MFMAs: 43 instead of 32 cycles per MFMA).
-            constexpr int NST = NKW * 2;
-            bf16x8_t fa_[2][NT], fb_[2][JT];
-            auto load_a = [&](int st, int buf) {
-                const int kw = st >> 1, ks = st & 1;
-#pragma unroll
-                for (int c = 0; c < NT; ++c)
-                    fa_[buf][c] = *reinterpret_cast<const bf16x8_t*>(lf + fa[ks] + (kw * BN + c * 32) * 64);
-            };
-            auto load_b = [&](int st, int buf, int j) {
-                const int kw = st >> 1, ks = st & 1;
-                fb_[buf][j] = *reinterpret_cast<const bf16x8_t*>(lh + (swz64(hv0[j] + hoff + kw + kw0, hk) ^ (ks << 5)));
-            };
-            load_a(0, 0);
-#pragma unroll
-            for (int j = 0; j < JT; ++j) load_b(0, 0, j);
+            PROF_T(c1);
 #pragma unroll
             for (int st = 0; st < NST; ++st) {
-                // the requests of step st+1 are threaded between the MFMAs of step st: address arithmetic and ds_reads issue in the shadow of
-                // the MFMA that was just started instead of in a block of their own
-                if (st + 1 < NST) load_a(st + 1, (st + 1) & 1);
+                const bool last = st + 1 == NST;
+                // a next phase of the SAME tile follows (same chunk, or the next chunk of this tile in the other halo slot)
+                const bool chain = last && (pl + 1 < NPH || cur.ch + 1 < nch);
+                const unsigned char* lfn = lf;
+                const unsigned char* lhn = lh;
+                int hoffn = hoff, kw0n = kw0, stn = st + 1;
+                if (last) {
+                    stn = 0;
+                    lfn = lds + 2 * HALO_BYTES + ((g + 1) & 1) * FILT_BYTES;
+                    if (pl + 1 < NPH) hoffn = phase_hoff(cur, pl + 1, kw0n);
+                    else { hoffn = phase_hoff(nxt, 0, kw0n); lhn = lds + (hb ^ 1) * HALO_BYTES; }
+                }
+                if (chain) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this phase's last fragments are in registers: done with the rings
+                    __builtin_amdgcn_s_barrier();                          // = the next phase's barrier
+                }
+                if (!last || chain) load_a(lfn, stn, stn & 1);
 #pragma unroll
                 for (int j = 0; j < JT; ++j) {
 #pragma unroll
                     for (int c = 0; c < NT; ++c)
                         acc[j][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_[st & 1][c], fb_[st & 1][j], acc[j][c], 0, 0, 0);
-                    if (st + 1 < NST) load_b(st + 1, (st + 1) & 1, j);
+                    if (!last || chain) load_b(lhn, hoffn, kw0n, stn, stn & 1, j);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
