@@ -978,7 +978,9 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
             constexpr int SWM = NT == 2 ? 7 : 3;
             float4 bvn[NT][4];
             load_bias(has_next ? nxt.co0 : cur.co0, bvn);
+            PROF_T(e0);
             __builtin_amdgcn_s_barrier();
+            PROF_T(e1);
             unsigned char* const stage = lds + hb * HALO_BYTES + cw * (32 * JT * BN * 2);
 #pragma unroll
             for (int j = 0; j < JT; ++j) {
@@ -1013,9 +1015,15 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
                     }
                 }
             }
+            PROF_T(e2);
             init_acc(bvn);
             __builtin_amdgcn_s_barrier();                              // the whole tile is staged: all eight waves store it
+            PROF_T(e3);
             store_share(cur, hb);
+            PROF_T(e4);
+#ifdef FMRI_PROF
+            cprof[7] += e1 - e0; cprof[8] += e2 - e1; cprof[9] += e3 - e2; cprof[10] += e4 - e3;
+#endif
         }
 #ifdef FMRI_PROF
         { PROF_T(ce1); cprof[4] += ce1 - ce0; }

@@ -35,6 +35,9 @@ for name, C0, up0, C1, Cout, D, H, W in LAYERS:
     tot = max(p[5], 1)
     sec = [p[i] / tot * 100 for i in range(4)]
     ep = p[4] / tot * 100
-    epd = "(barrier %.1f, bias+pack+lds-write %.1f, lds-read+store %.1f)" % (p[7] / tot * 100, p[8] / tot * 100, (p[4] - p[7] - p[8]) / tot * 100)
+    if p[10]:      # warp-specialised kernel: barrier 1 | pack + stage | barrier 2 | read back + store
+        epd = "(barrier %.1f, pack+stage %.1f, barrier %.1f, store %.1f)" % tuple(p[i] / tot * 100 for i in (7, 8, 9, 10))
+    else:
+        epd = "(barrier %.1f, bias+pack+lds-write %.1f, lds-read+store %.1f)" % (p[7] / tot * 100, p[8] / tot * 100, (p[4] - p[7] - p[8]) / tot * 100)
     print("%-7s cyc/phase %6.0f | dma-wait %5.1f%%  barrier %5.1f%%  dma-issue %5.1f%%  mfma-loop %5.1f%%  epilogue %5.1f%% %s  other %5.1f%%"
           % (name, tot / max(p[6], 1), sec[0], sec[1], sec[2], sec[3], ep, epd, 100 - sum(sec) - ep))
