@@ -49,3 +49,65 @@ def test_rccl_single_rank_bucketed_allreduce(tmp_path):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, str(f)], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0 and "RCCL_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+
+
+TWO_RANK = textwrap.dedent("""
+    import os, sys
+    sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "fetal-mri-segmentation_amd"))
+    import numpy as np, torch, torch.distributed as dist
+    from fmri_hip.engine import UNetEngine, UNetPlan
+    from fmri_hip.dist import DataParallel
+    rank, world, out_dir = int(sys.argv[1]), 2, sys.argv[2]
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = sys.argv[3]
+    torch.cuda.set_device(0)                                   # both ranks share the one GPU of the box: gloo carries the collectives
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sp = (8, 16, 32)
+    rs = np.random.RandomState(7)
+    X = rs.randn(4, *sp, 1).astype(np.float32)                 # global batch of 4 patches; rank r trains on patches 2r, 2r+1
+    Y = (rs.rand(4, *sp) > 0.6).astype(np.uint8)
+    xd = torch.from_numpy(X[2 * rank:2 * rank + 2]).cuda().contiguous()
+    yd = torch.from_numpy(Y[2 * rank:2 * rank + 2]).cuda().reshape(-1).contiguous()
+    ctx = DataParallel(world, rank, bucket_bytes=64 << 10)
+    eng = UNetEngine(UNetPlan(1, sp, depth=2, n_base_filters=8), 2, dtype=torch.float32, dist_ctx=ctx, seed=5 + rank)   # different seeds:
+    ctx.broadcast_params(eng)                                                                                            # rank 0's weights win
+    losses = []
+    for _ in range(3):
+        s = eng.train_step(xd, yd, 1e-2)
+        losses.append(eng.metrics_from_sums(s.cpu().numpy())["dice_coefficient"])
+    torch.cuda.synchronize()
+    np.savez(os.path.join(out_dir, "rank%%d.npz" %% rank), P=eng.P.cpu().numpy(), dice=np.array(losses), buckets=len(ctx.launched))
+    if rank == 0:                                             # the same three steps on ONE engine with the whole global batch
+        ref = UNetEngine(UNetPlan(1, sp, depth=2, n_base_filters=8), 4, dtype=torch.float32, seed=5)
+        xa = torch.from_numpy(X).cuda().contiguous(); ya = torch.from_numpy(Y).cuda().reshape(-1).contiguous()
+        rl = []
+        for _ in range(3):
+            s = ref.train_step(xa, ya, 1e-2)
+            rl.append(ref.metrics_from_sums(s.cpu().numpy())["dice_coefficient"])
+        np.savez(os.path.join(out_dir, "ref.npz"), P=ref.P.cpu().numpy(), dice=np.array(rl))
+    dist.barrier()
+    dist.destroy_process_group()
+    print("RANK_OK", rank)
+""") % (ROOT, ROOT)
+
+
+def test_two_ranks_equal_one_engine_on_the_global_batch(tmp_path):
+    """Two processes (both on the box's one GPU, gloo for the collectives) train data-parallel on halves of a global batch of 4 with the
+    exact global-batch Dice (summed sums, summed gradients): after three steps every rank holds the same parameters, and they equal
+    one engine stepping on all 4 patches (fp32; tolerance = summation order of atomics and of the all-reduce).  Exercises the real engine's
+    two-stream backward together with the bucketed all-reduce, which the 1-rank RCCL test cannot (its reductions are identities)."""
+    import numpy as np
+    f = tmp_path / "two_rank.py"
+    f.write_text(TWO_RANK)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", FMRI_DTYPE="fp32")
+    port = str(29600 + os.getpid() % 300)
+    procs = [subprocess.Popen([sys.executable, str(f), str(r), str(tmp_path), port], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
+             for r in range(2)]
+    outs = [p.communicate(timeout=900) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0 and "RANK_OK" in so, (so[-1500:], se[-3000:])
+    r0, r1, ref = (np.load(str(tmp_path / n)) for n in ("rank0.npz", "rank1.npz", "ref.npz"))
+    assert int(r0["buckets"]) >= 2
+    np.testing.assert_allclose(r0["P"], r1["P"], rtol=0, atol=1e-7)                       # ranks stay in lock-step
+    np.testing.assert_allclose(r0["dice"], ref["dice"], rtol=0, atol=2e-5)                # the global-batch Dice, not a per-rank one
+    np.testing.assert_allclose(r0["dice"], r1["dice"], rtol=0, atol=1e-9)
+    assert float(np.abs(r0["P"] - ref["P"]).max()) <= 2e-4                                # 3 Adam steps at lr 1e-2
