@@ -1224,13 +1224,11 @@ k_conv_wgrad_mfma(SrcB s, const bf16_t* __restrict__ dy, float* __restrict__ dw,
     if (u < nunits) issue(u, 0);
     for (; u < nunits; u += nslab, buf ^= 1) {
         const bool more = (u + nslab) < nunits;
-        if (more) {
-            issue(u + nslab, buf ^ 1);
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_WAVE) : "memory");   // this unit's DMA (older) has landed
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
+        // ONE barrier per unit: "my DMA for this unit has landed" + "everybody is done reading the other ring slot" (a wave gets here only
+        // after its MFMAs on it) - then the next unit's DMA goes into that slot and runs under this unit's MFMAs
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        if (more) issue(u + nslab, buf ^ 1);
         const unsigned char* const sb = lds + buf * STAGE_BYTES;
 #pragma unroll
         for (int ks8 = 0; ks8 < 8; ++ks8) {
@@ -1258,8 +1256,7 @@ k_conv_wgrad_mfma(SrcB s, const bf16_t* __restrict__ dy, float* __restrict__ dw,
                 acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bf16x8_t, bfv), acc[tap], 0, 0, 0);   // B[k = voxel][ci]
             }
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                                                 // ring slot `buf` may be refilled
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                            // fragments in registers before this wave reports "done reading"
     }
     };
     if constexpr (UPW) {
