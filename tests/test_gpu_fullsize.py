@@ -129,3 +129,68 @@ def test_bench_contract_smoke():
     assert j["n_gpus"] == 1 and j["steps"] == 2 and j["dtype"] == "bf16" and j["value"] > 10
     r = j["roofline"]
     assert r["bound"] == "mfma" and 0 < r["frac"] < 1 and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+
+
+WS_SCRIPT = r"""
+import os, sys
+sys.path.insert(0, os.path.join(%r, "fetal-mri-segmentation_amd"))
+import numpy as np, torch
+from fmri_hip import ops
+out = {}
+g = torch.Generator().manual_seed(1)
+def rnd(shape, scale=1.0):
+    return (torch.randn(shape, generator=g) * scale).cuda().to(torch.bfloat16)
+cases = [  # N, D, H, W, C0, C1, Cout, up0, mask
+    (1, 4, 8, 16, 32, 0, 32, 0, 0), (2, 8, 16, 32, 64, 0, 64, 0, 1), (1, 8, 16, 16, 96, 32, 96, 0, 0), (1, 8, 16, 32, 128, 64, 64, 1, 0),
+    (3, 4, 24, 48, 64, 64, 128, 0, 1), (1, 12, 8, 16, 256, 0, 160, 0, 0), (5, 4, 8, 16, 32, 0, 64, 0, 0),
+]
+for i, (N, D, H, W, C0, C1, Cout, up0, msk) in enumerate(cases):
+    s0 = (N, D // 2, H // 2, W // 2, C0) if up0 else (N, D, H, W, C0)
+    x0, x1 = rnd(s0), (rnd((N, D, H, W, C1)) if C1 else None)
+    w = rnd((27, Cout, C0 + C1), 0.05)
+    b = torch.randn(Cout, generator=g).cuda()
+    y = torch.empty((N, D, H, W, Cout), device="cuda", dtype=torch.bfloat16)
+    ops.conv3d_fwd(x0, x1, w, b, y, up0=bool(up0), act=1)
+    out["fwd%%d" %% i] = y.view(torch.int16).cpu().numpy()
+    if not up0 and not C1:
+        wd = rnd((27, C0, Cout), 0.05)
+        dy = rnd((N, D, H, W, Cout))
+        dx = torch.empty((N, D, H, W, C0), device="cuda", dtype=torch.bfloat16)
+        ops.conv3d_dgrad(dy, wd, dx, mask=(rnd((N, D, H, W, C0)) if msk else None))
+        out["dgrad%%d" %% i] = dx.view(torch.int16).cpu().numpy()
+# parity form (MODE 1 + residual epilogue, MODE 2)
+N, D, H, W, C0, C1, Cout = 2, 8, 16, 32, 128, 64, 64
+xl, xs = rnd((N, D // 2, H // 2, W // 2, C0)), rnd((N, D, H, W, C1))
+w = rnd((27, Cout, C0 + C1), 0.05).float().contiguous()
+up_f = torch.empty((8, 8, Cout, C0), device="cuda", dtype=torch.bfloat16); up_d = torch.empty((8, 8, C0, Cout), device="cuda", dtype=torch.bfloat16)
+sk_f = torch.empty((27, Cout, C1), device="cuda", dtype=torch.bfloat16); sk_d = torch.empty((27, C1, Cout), device="cuda", dtype=torch.bfloat16)
+ops.conv3d_pack_up_weights(w, C0, C1, up_f, up_d, sk_f, sk_d)
+y = torch.empty((N, D, H, W, Cout), device="cuda", dtype=torch.bfloat16)
+ops.conv3d_upcat_fwd(xl, xs, up_f, sk_f, torch.randn(Cout, generator=g).cuda(), y, act=1)
+dy = rnd((N, D, H, W, Cout)); dxl, dxs = torch.empty_like(xl), torch.empty_like(xs)
+ops.conv3d_upcat_dgrad(dy, up_d, sk_d, rnd(tuple(xl.shape)), None, dxl, dxs)
+torch.cuda.synchronize()
+out["up_fwd"], out["up_dxl"], out["up_dxs"] = (t.view(torch.int16).cpu().numpy() for t in (y, dxl, dxs))
+np.savez(sys.argv[1], **out)
+print("DONE")
+"""
+
+
+def test_warp_specialised_kernel_is_bit_identical_to_the_symmetric_one(tmp_path):
+    """k_conv_fwd_ws (4 MFMA waves + 4 LDS-DMA waves) against k_conv_fwd_mfma (FMRI_FWD_WS=0) on the same seeded inputs: both accumulate
+    every output in the same (chunk, (kd,kh), kw, k-step) order, so forward, input gradients (with and without mask), dual-source /
+    fused-upsample reads and the parity-form launches must agree BIT FOR BIT - any race in the producer/consumer hand-over shows up here."""
+    import subprocess, sys, os
+    import numpy as np
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    f = tmp_path / "ws.py"
+    f.write_text(WS_SCRIPT % root)
+    outs = []
+    for ws in ("1", "0"):
+        o = str(tmp_path / ("out%s.npz" % ws))
+        r = subprocess.run([sys.executable, str(f), o], capture_output=True, text=True, timeout=600, env=dict(os.environ, FMRI_FWD_WS=ws))
+        assert r.returncode == 0 and "DONE" in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])
+        outs.append(np.load(o))
+    assert set(outs[0].files) == set(outs[1].files) and len(outs[0].files) >= 13
+    for k in outs[0].files:
+        assert np.array_equal(outs[0][k], outs[1][k]), k
