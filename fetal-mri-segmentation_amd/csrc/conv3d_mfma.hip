@@ -103,6 +103,14 @@ __device__ __forceinline__ unsigned lds_addr(const void* p) {
 // 16-byte slot swizzle for 64-byte rows: 4 consecutive rows x 4 slots cover a 256-B bank row exactly once per slot index
 __device__ __forceinline__ int swz64(int row, int slot) { return row * 64 + ((slot ^ ((row >> 2) & 3)) << 4); }
 
+// XCD-aware workgroup numbering: the hardware deals consecutive workgroup ids round-robin over the 8 XCDs (each with its own L2), so ids that
+// should share cached data - the (kd, Cout, Cin) workgroups reading the same planes, the Cout blocks / neighbouring tiles of one input tile -
+// are renumbered such that each XCD owns a contiguous range of logical ids.
+__device__ __forceinline__ int xcd_logical_id(int b, int nb) {
+    const int full = nb & ~7;
+    return b < full ? (b & 7) * (full >> 3) + (b >> 3) : b;
+}
+
 struct FwdItem {          // one (tile, Cout block, 32-channel chunk) unit of the persistent stream
     int n, d0, h0, w0, co0, ch, par;
 };
@@ -310,7 +318,7 @@ k_conv_fwd_mfma(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__
     // keep the swizzle term of row r because kw*BN + c*32 is a multiple of 16
     const int fa[2] = {swz64(r, hk), swz64(r, hk) ^ 32};
 
-    int pair = blockIdx.x;
+    int pair = xcd_logical_id(blockIdx.x, gridDim.x);            // neighbouring (tile, Cout block) pairs on one XCD / L2
     if (pair >= npairs) return;
     FwdItem cur = decode(pair, 0);
     {
@@ -616,7 +624,7 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
         it.n = q / tdn;
         return it;
     };
-    int pair = blockIdx.x;
+    int pair = xcd_logical_id(blockIdx.x, gridDim.x);            // neighbouring (tile, Cout block) pairs on one XCD / L2
     if (pair >= npairs) return;
     FwdItem cur = decode(pair, 0);
     int g = 0, hb = 0;
@@ -1114,8 +1122,9 @@ k_conv_wgrad_mfma(SrcB s, const bf16_t* __restrict__ dy, float* __restrict__ dw,
     // order, so they run at the same time and share those planes in L2 / Infinity Cache instead of re-reading HBM
     // (measured with rocprofv3 FETCH_SIZE: combo-major order fetched 3.6x the algorithmic bytes)
     const int ncombo = (s.planar ? 1 : (UPW ? 2 : 3)) * ncob * ncib;
-    int combo = blockIdx.x % ncombo;
-    const int slab = blockIdx.x / ncombo;
+    const int wg_id = xcd_logical_id(blockIdx.x, gridDim.x);      // workgroups of one slab (same planes) on one XCD / L2
+    int combo = wg_id % ncombo;
+    const int slab = wg_id / ncombo;
     const int cib = combo % ncib; combo /= ncib;
     const int cob = combo % ncob;
     const int par = UPW ? cob / (Cout / 64) : 0;           // output parity class (pd, ph, pw) of this workgroup; planar: (ph, pw)
@@ -1221,14 +1230,22 @@ k_conv_wgrad_mfma(SrcB s, const bf16_t* __restrict__ dy, float* __restrict__ dw,
     constexpr int PH_ = decltype(PHc)::value, PW_ = decltype(PWc)::value;
     int u = slab;
     int buf = 0;
+#ifdef FMRI_PROF
+    unsigned long long wprof[12] = {};
+    PROF_T(wk0);
+#endif
     if (u < nunits) issue(u, 0);
     for (; u < nunits; u += nslab, buf ^= 1) {
         const bool more = (u + nslab) < nunits;
+        PROF_T(w0);
         // ONE barrier per unit: "my DMA for this unit has landed" + "everybody is done reading the other ring slot" (a wave gets here only
         // after its MFMAs on it) - then the next unit's DMA goes into that slot and runs under this unit's MFMAs
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        PROF_T(w1);
         __builtin_amdgcn_s_barrier();
+        PROF_T(w2);
         if (more) issue(u + nslab, buf ^ 1);
+        PROF_T(w3);
         const unsigned char* const sb = lds + buf * STAGE_BYTES;
 #pragma unroll
         for (int ks8 = 0; ks8 < 8; ++ks8) {
@@ -1257,7 +1274,14 @@ k_conv_wgrad_mfma(SrcB s, const bf16_t* __restrict__ dy, float* __restrict__ dw,
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                            // fragments in registers before this wave reports "done reading"
+#ifdef FMRI_PROF
+        { PROF_T(w4); wprof[0] += w1 - w0; wprof[1] += w2 - w1; wprof[2] += w3 - w2; wprof[3] += w4 - w3; wprof[6] += 1; }
+#endif
     }
+#ifdef FMRI_PROF
+    { PROF_T(wk1); wprof[5] = wk1 - wk0; }
+    if (lane == 0) for (int i = 0; i < 7; ++i) atomicAdd(&g_prof[i], wprof[i]);
+#endif
     };
     if constexpr (UPW) {
         switch (par & 3) {
@@ -1284,7 +1308,7 @@ k_conv_wgrad_mfma(SrcB s, const bf16_t* __restrict__ dy, float* __restrict__ dw,
         }
     } else if (slab_ws) {
         constexpr int KSP = (CI_T == 2) ? 1 : 2;          // Cin-block 32: the two k-step halves keep separate slabs
-        float* const my = slab_ws + ((int64_t)blockIdx.x * KSP + ksl) * (9 * 64 * CIB);
+        float* const my = slab_ws + ((int64_t)wg_id * KSP + ksl) * (9 * 64 * CIB);
 #pragma unroll
         for (int tap = 0; tap < NACC; ++tap) {
 #pragma unroll
