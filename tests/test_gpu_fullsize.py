@@ -194,3 +194,27 @@ def test_warp_specialised_kernel_is_bit_identical_to_the_symmetric_one(tmp_path)
     assert set(outs[0].files) == set(outs[1].files) and len(outs[0].files) >= 13
     for k in outs[0].files:
         assert np.array_equal(outs[0][k], outs[1][k]), k
+
+
+def test_bench_contract_line(tmp_path):
+    """`python bench.py --steps 3 --warmup 1` prints ONE JSON line with the driver's contract keys, the two roofline objects of the
+    two-stream step and a cpu-free run when asked (the CPU baseline itself takes ~25 s and is exercised by the default bench run)."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+              "roofline", "roofline_exclusive", "step_mfma_frac", "kernel_ms_per_step"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["unit"] == "patches/s" and d["dtype"] == "bf16" and d["scaling"] == "weak"
+    assert d["vs_baseline"] is None and "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] - 4 * 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]
+    for ro in (d["roofline"], d["roofline_exclusive"]):
+        assert ro["bound"] == "mfma" and ro["peak"] == 2500.0 and ro["unit"] == "TFLOP/s" and abs(ro["frac"] - ro["achieved"] / ro["peak"]) < 1e-12
+        assert ro["launches_per_step"] == 32 and ro["avg_launch_ms"] > 0
+    assert d["roofline_exclusive"]["frac"] > d["roofline"]["frac"]          # exclusive kernel time < the bracket inside the two-stream region
+    assert 0.3 < d["step_mfma_frac"] < 1.0
