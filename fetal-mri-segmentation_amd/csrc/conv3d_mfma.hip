@@ -1188,11 +1188,14 @@ k_conv_wgrad_mfma(SrcB s, const bf16_t* __restrict__ dy, float* __restrict__ dw,
     }
     const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr(lds));
     auto issue = [&](int u, int buf) {
+        // unit index = column (n, h-tile, w-tile) x D + d: d runs fastest, and a workgroup walks a CONTIGUOUS run of units, i.e. up a column.
+        // The three kd workgroups of a slab then read x planes d-1, d, d+1 at step d and d, d+1, d+2 at the next: two of the three planes (and
+        // the dy plane all three share) were fetched a step ago by a neighbour on the same XCD, so they come out of L2 instead of HBM.
         int q = u;
+        const int d = q % D; q /= D;
         const int w0 = (q % twn) * TW; q /= twn;
-        const int h0 = (q % thn) * TH; q /= thn;
-        const int d = q % D;
-        const int n = q / D;
+        const int h0 = (q % thn) * TH;
+        const int n = q / thn;
         const int gd = d + kd - 1;
         const bool dok = (unsigned)gd < (unsigned)D;
         const int gdc = min(max(gd, 0), D - 1) >> shd;
@@ -1228,15 +1231,17 @@ k_conv_wgrad_mfma(SrcB s, const bf16_t* __restrict__ dy, float* __restrict__ dw,
     // the unit loop, instantiated per (ph, pw) in the up mode so that every fragment row constant stays compile-time
     auto run = [&](auto PHc, auto PWc) {
     constexpr int PH_ = decltype(PHc)::value, PW_ = decltype(PWc)::value;
-    int u = slab;
+    const int per = (nunits + nslab - 1) / nslab;          // contiguous run of units per slab
+    int u = slab * per;
+    const int u_end = min(nunits, u + per);
     int buf = 0;
 #ifdef FMRI_PROF
     unsigned long long wprof[12] = {};
     PROF_T(wk0);
 #endif
-    if (u < nunits) issue(u, 0);
-    for (; u < nunits; u += nslab, buf ^= 1) {
-        const bool more = (u + nslab) < nunits;
+    if (u < u_end) issue(u, 0);
+    for (; u < u_end; ++u, buf ^= 1) {
+        const bool more = (u + 1) < u_end;
         PROF_T(w0);
         // ONE barrier per unit: "my DMA for this unit has landed" + "everybody is done reading the other ring slot" (a wave gets here only
         // after its MFMAs on it) - then the next unit's DMA goes into that slot and runs under this unit's MFMAs
@@ -1244,7 +1249,7 @@ k_conv_wgrad_mfma(SrcB s, const bf16_t* __restrict__ dy, float* __restrict__ dw,
         PROF_T(w1);
         __builtin_amdgcn_s_barrier();
         PROF_T(w2);
-        if (more) issue(u + nslab, buf ^ 1);
+        if (more) issue(u + 1, buf ^ 1);
         PROF_T(w3);
         const unsigned char* const sb = lds + buf * STAGE_BYTES;
 #pragma unroll
