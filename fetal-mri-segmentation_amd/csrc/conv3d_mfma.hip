@@ -1098,8 +1098,11 @@ __device__ __forceinline__ bf16x8_t tr_frag(const unsigned char* base, int row0,
 // dims), the Cout blocks enumerate (parity, 64-channel block), only kd in {pd, pd+1} gets workgroups and only the 4 (kh,kw) taps
 // {ph,ph+1} x {pw,pw+1} are accumulated; the dy tile is gathered from the parity-p voxels of the [2D][2H][2W] gradient.
 // Result layout [8 p][2][2][2][Cout][C0] fp32 (atomics), expanded into the 27-tap gradient by k_expand_up_wgrad.
-template <int CI_T, bool UPW>  // CI_T = 32-wide input-channel tiles per workgroup (1 or 2); output-channel block is always 64
-__global__ void __launch_bounds__(wg::NTHREADS, 2)
+// WS: warp-specialised variant - eight waves, ONE workgroup per CU: waves 0-3 (one per SIMD) read fragments and issue MFMAs exactly as the
+// four waves of the plain kernel do, waves 4-7 issue all LDS-DMA (tools/prof_wgrad.py: a wave of the plain kernel spends 35-50 % of its time
+// issuing its ten DMA instructions per unit, wherever they are placed).
+template <int CI_T, bool UPW, bool WS = false>  // CI_T = 32-wide input-channel tiles per workgroup (1 or 2); output-channel block is always 64
+__global__ void __launch_bounds__(WS ? 512 : wg::NTHREADS, WS ? 1 : 2)
 k_conv_wgrad_mfma(SrcB s, const bf16_t* __restrict__ dy, float* __restrict__ dw, float* __restrict__ db, int N, int D, int H,
                   int W, int Cout, int nslab, float* __restrict__ slab_ws, int dw_ld) {
     using namespace wg;
@@ -1114,7 +1117,8 @@ k_conv_wgrad_mfma(SrcB s, const bf16_t* __restrict__ dy, float* __restrict__ dw,
     constexpr int X_BYTES = X_INSTR * 1024;
     constexpr int Y_BYTES = Y_INSTR * 1024;
     constexpr int STAGE_BYTES = X_BYTES + Y_BYTES;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * STAGE_BYTES];
+    constexpr int NSTAGE = WS ? 3 : 2;                   // WS: the producers run TWO units ahead (one workgroup per CU leaves the LDS for it)
+    __shared__ __attribute__((aligned(16))) unsigned char lds[NSTAGE * STAGE_BYTES];
 
     const int Cin = s.C0 + s.C1;
     const int ncib = Cin / CIB, ncob = (UPW ? (s.planar ? 4 : 8) : 1) * (Cout / 64);
@@ -1141,7 +1145,9 @@ k_conv_wgrad_mfma(SrcB s, const bf16_t* __restrict__ dy, float* __restrict__ dw,
     const int sD = D >> shd, sH = H >> sh, sW = W >> sh;
 
     const int t = threadIdx.x, lane = t & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wv_all = __builtin_amdgcn_readfirstlane(t >> 6);
+    const bool producer = WS && wv_all >= 4;
+    const int wv = wv_all & 3;                             // index among the four waves of this wave's role
     const int r = lane & 31, hk = lane >> 5;
     const int ct = wv & 1;
     const int it = (CI_T == 2) ? (wv >> 1) : 0;
@@ -1239,19 +1245,71 @@ k_conv_wgrad_mfma(SrcB s, const bf16_t* __restrict__ dy, float* __restrict__ dw,
     unsigned long long wprof[12] = {};
     PROF_T(wk0);
 #endif
-    if (u < u_end) issue(u, 0);
-    for (; u < u_end; ++u, buf ^= 1) {
+    if (u < u_end && (!WS || producer)) issue(u, 0);
+    if (WS && producer && u + 1 < u_end) issue(u + 1, 1);
+    for (; u < u_end; ++u, buf = (buf + 1 == NSTAGE ? 0 : buf + 1)) {
         const bool more = (u + 1) < u_end;
         PROF_T(w0);
-        // ONE barrier per unit: "my DMA for this unit has landed" + "everybody is done reading the other ring slot" (a wave gets here only
-        // after its MFMAs on it) - then the next unit's DMA goes into that slot and runs under this unit's MFMAs
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // ONE barrier per unit: "my DMA for this unit has landed" + "everybody is done reading the ring slot of the previous unit" (a wave
+        // gets here only after its MFMAs on it) - then that slot is refilled: with the unit after this one (plain kernel, 2 slots) or the
+        // one after that (WS, 3 slots: the wait below leaves the youngest unit's DMA in flight)
+        if (WS) {
+            if (producer) {
+                if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_WAVE) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         PROF_T(w1);
         __builtin_amdgcn_s_barrier();
         PROF_T(w2);
-        if (more) issue(u + 1, buf ^ 1);
+        if (WS) {
+            if (producer && u + 2 < u_end) issue(u + 2, buf == 0 ? 2 : buf - 1);          // = (buf + 2) % 3: the slot of the previous unit
+        } else if (more) issue(u + 1, buf ^ 1);
         PROF_T(w3);
+        if (producer) continue;
         const unsigned char* const sb = lds + buf * STAGE_BYTES;
+        if constexpr (WS && CI_T == 2) {
+            // One consumer wave per SIMD: nobody else hides the latency of the transposing reads, so the fragments run two MFMAs ahead of
+            // their use (3-deep x-fragment ring, double dy fragment), threaded between the MFMAs.
+            typedef __attribute__((ext_vector_type(8))) short s16x8;
+            constexpr int NS = 8 * NACC;
+            auto row_of = [&](int st) {
+                const int ks8 = st / NACC, tap = st % NACC;
+                return UPW ? (ks8 + (tap >> 1) + PH_) * XW + (tap & 1) + PW_ : (ks8 + tap / 3) * XW + (tap % 3);
+            };
+            auto load_bf = [&](int st) {
+                const int c = row_of(st);
+                const unsigned char* pb = sb + pre_x[c & 3] + (c >> 2) * 4 * XROWB;
+                s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)pb);
+                s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(pb + 4 * XROWB));
+                return __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
+            };
+            auto load_af = [&](int ks8) {
+                const unsigned char* pa = sb + pre_y + ks8 * TW * 128;
+                s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)pa);
+                s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(pa + 4 * 128));
+                return __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
+            };
+            s16x8 af2[2], bf3[3];
+            af2[0] = load_af(0);
+            bf3[0] = load_bf(0);
+            bf3[1] = load_bf(1);
+#pragma unroll
+            for (int st = 0; st < NS; ++st) {
+                const int ks8 = st / NACC, tap = st % NACC;
+                if (st + 2 < NS) bf3[(st + 2) % 3] = load_bf(st + 2);
+                if (tap == NACC - 3 && ks8 + 1 < 8) af2[(ks8 + 1) & 1] = load_af(ks8 + 1);
+                if (do_bias && tap == 0) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) bsum += bf2f((unsigned short)af2[ks8 & 1][j]);
+                }
+                acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, af2[ks8 & 1]), __builtin_bit_cast(bf16x8_t, bf3[st % 3]),
+                                                                  acc[tap], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else
 #pragma unroll
         for (int ks8 = 0; ks8 < 8; ++ks8) {
             if (CI_T == 1 && (ks8 & 1) != ksl) continue;              // Cin-block 32: the two wave pairs split the k-steps
@@ -1298,6 +1356,7 @@ k_conv_wgrad_mfma(SrcB s, const bf16_t* __restrict__ dy, float* __restrict__ dw,
     } else {
         run(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
     }
+    if (producer) return;
     // ---- flush: D rows = co, cols = ci (128-B contiguous per half-wave).  With a workspace: plain stores of this workgroup's partial
     // slab [9][64][CIB] (summed per element by k_wgrad_reduce: deterministic, ~5x the atomic rate); without: fp32 atomics into dw.
     if constexpr (UPW) {
@@ -1537,7 +1596,19 @@ int conv3d_wgrad_mfma_ld(const void* src0, int C0, int up0, int planar, const vo
     int CIB, combos, nslab;
     wgrad_plan(C0, C1, Cout, N, D, H, W, planar, use_ws, CIB, combos, nslab);
     float* ws = use_ws ? (float*)workspace : nullptr;
-    if (CIB == 64) k_conv_wgrad_mfma<2, false><<<combos * nslab, wg::NTHREADS, 0, st>>>(s, (const bf16_t*)dy, dw, db, N, D, H, W, Cout, nslab, ws, dw_ld);
+    // Warp-specialised variant (8 waves, one workgroup per CU, 3-slot ring with the producers two units ahead): alone it is 2-5 % faster on
+    // the layers with >= 0.3 TFLOP and a few % slower on the small ones, but inside the two-stream training step the whole-CU workgroups
+    // interleave worse with the forward-type kernels of the other stream (-0.7 % per step) - kept as an option, off by default.
+    // FMRI_WGRAD_WS = 1 always / 2 by size.
+    static int wg_ws = -2;
+    if (wg_ws == -2) {
+        const char* e = getenv("FMRI_WGRAD_WS");
+        wg_ws = e ? atoi(e) : 0;
+    }
+    if (wg_ws == 1 || (wg_ws == 2 && flops_ >= 0.3e12)) {
+        if (CIB == 64) k_conv_wgrad_mfma<2, false, true><<<combos * nslab, 512, 0, st>>>(s, (const bf16_t*)dy, dw, db, N, D, H, W, Cout, nslab, ws, dw_ld);
+        else k_conv_wgrad_mfma<1, false, true><<<combos * nslab, 512, 0, st>>>(s, (const bf16_t*)dy, dw, db, N, D, H, W, Cout, nslab, ws, dw_ld);
+    } else if (CIB == 64) k_conv_wgrad_mfma<2, false><<<combos * nslab, wg::NTHREADS, 0, st>>>(s, (const bf16_t*)dy, dw, db, N, D, H, W, Cout, nslab, ws, dw_ld);
     else k_conv_wgrad_mfma<1, false><<<combos * nslab, wg::NTHREADS, 0, st>>>(s, (const bf16_t*)dy, dw, db, N, D, H, W, Cout, nslab, ws, dw_ld);
     if (use_ws) {
         const int ncob = Cout / 64, ncib = Cin / CIB;
@@ -1600,7 +1671,11 @@ int conv3d_upcat_wgrad_mfma(const void* src0_low, int C0, const void* src1, int 
         if (nslab > nunits) nslab = nunits;
         if (nslab < 1) nslab = 1;
         float* const dbu = C1 == 0 ? db : nullptr;         // with skip channels the plain launch below produces the bias gradient
-        if (wide) k_conv_wgrad_mfma<2, true><<<combos * nslab, wg::NTHREADS, 0, st>>>(s, (const bf16_t*)dy, dwc, dbu, N, Dl, Hl, Wl, Cout, nslab, nullptr, C0);
+        const char* e = getenv("FMRI_WGRAD_WS");
+        const int ws_mode = e ? atoi(e) : 0;
+        const bool ws_up = wide && (ws_mode == 1 || (ws_mode == 2 && 2.0 * 8 * 8 * (double)C0 * Cout * N * Dl * Hl * Wl >= 0.3e12));
+        if (ws_up) k_conv_wgrad_mfma<2, true, true><<<combos * nslab, 512, 0, st>>>(s, (const bf16_t*)dy, dwc, dbu, N, Dl, Hl, Wl, Cout, nslab, nullptr, C0);
+        else if (wide) k_conv_wgrad_mfma<2, true><<<combos * nslab, wg::NTHREADS, 0, st>>>(s, (const bf16_t*)dy, dwc, dbu, N, Dl, Hl, Wl, Cout, nslab, nullptr, C0);
         else k_conv_wgrad_mfma<1, true><<<combos * nslab, wg::NTHREADS, 0, st>>>(s, (const bf16_t*)dy, dwc, dbu, N, Dl, Hl, Wl, Cout, nslab, nullptr, C0);
     }
     // 2. fold them into the 27-tap gradient of the up-sampled input channels (columns [0, C0) of dw)
