@@ -149,3 +149,20 @@ def test_isensee_oracle_runs_and_trains():
         r = I.loss_and_grads(spec, W, x, y)
         opt.step(W, r["grads"])
     assert r["loss"] < l0
+
+
+def test_oracle_reproduces_its_committed_cfg1_fixture():
+    """tests/golden/oracle_cfg1_golden.npz (made by make_oracle_fixture.py): the seeded configs[0] forward of the oracle - inputs, weights,
+    logits and Dice - has not drifted"""
+    import importlib.util
+    import os
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    spec = importlib.util.spec_from_file_location("make_oracle_fixture", os.path.join(here, "make_oracle_fixture.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    gold = np.load(os.path.join(here, "oracle_cfg1_golden.npz"))
+    now = mod.compute()
+    assert float(now["x_sum"]) == float(gold["x_sum"]) and int(now["y_sum"]) == int(gold["y_sum"])
+    np.testing.assert_array_equal(now["w_first"], gold["w_first"])
+    np.testing.assert_allclose(now["logits"], gold["logits"], rtol=0, atol=1e-6)
+    assert abs(float(now["dice"]) - float(gold["dice"])) <= 1e-9
