@@ -75,6 +75,29 @@ def test_cfg1_fp32_forward_backward_adam():
         assert _rel(Wm[k], W[k]) <= 2e-3, k
 
 
+def test_cfg1_fp32_logits_against_the_committed_oracle_fixture():
+    """the same configs[0] forward against tests/golden/oracle_cfg1_golden.npz (committed output of the oracle, make_oracle_fixture.py):
+    logits <= 1e-3 relative, Dice <= 1e-4 - the north-star tolerances - without running the oracle"""
+    import os
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_cfg1_golden.npz"))
+    from fmri_hip.engine import UNetEngine, UNetPlan
+    from oracle import unet_oracle as O
+    spec = O.Spec((1, 16, 64, 64), depth=3, n_base_filters=8)
+    W = spec.init_weights(42)                                  # the fixture's weights: glorot_uniform seed 42, zero biases
+    eng = UNetEngine(UNetPlan(1, (16, 64, 64), depth=3, n_base_filters=8), 1, dtype=torch.float32)
+    eng.load_keras_weights(W)
+    x, y = O.synthetic_batch((1, 1, 16, 64, 64))               # input data only (seeds 1234 / 1235); the oracle's forward is not run
+    assert float(x.sum()) == float(gold["x_sum"]) and int(y.sum()) == int(gold["y_sum"])
+    np.testing.assert_array_equal(W[sorted(W)[0]].astype(np.float32).ravel()[:16], gold["w_first"])
+    xd, yd = _dev_inputs(eng, x, y)
+    eng.forward(xd)
+    sums = eng.loss_forward(yd)
+    torch.cuda.synchronize()
+    logits = eng.logits.cpu().numpy().reshape(gold["logits"].shape)
+    assert _rel(logits, gold["logits"]) <= 1e-3
+    assert abs(eng.metrics_from_sums(sums.cpu().numpy())["dice_coefficient"] - float(gold["dice"])) <= 1e-4
+
+
 def test_depth4_base32_bf16_small_patch():
     """BASELINE config-2 topology (depth 4 / 32 filters, MFMA kernels) on a small 1x8x16x32... patch vs the oracle."""
     from oracle import unet_oracle as O
