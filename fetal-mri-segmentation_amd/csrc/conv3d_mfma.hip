@@ -172,6 +172,20 @@ k_conv_fwd_mfma(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__
         it.par = MODE == 1 ? cb / cbn : 0;
         it.co0 = (MODE == 1 ? cb % cbn : cb) * BN;
         int q = pair / ncb;
+        // tiles are numbered in compact 2 (d) x 4 (h) x 4 (w) blocks when the grid allows it: the ~32 consecutive pairs an XCD works on at any
+        // time then share their halo planes / rows / columns in its L2 instead of being a one-tile-thick row of the volume
+        if (((twn | thn) & 3) == 0 && (tdn & 1) == 0) {
+            const int in = q & 31;
+            int blk = q >> 5;
+            const int nbw = twn >> 2, nbh = thn >> 2, nbd = tdn >> 1;
+            const int bw_ = blk % nbw; blk /= nbw;
+            const int bh_ = blk % nbh; blk /= nbh;
+            it.w0 = (bw_ * 4 + (in & 3)) * TW;
+            it.h0 = (bh_ * 4 + ((in >> 2) & 3)) * TH;
+            it.d0 = ((blk % nbd) * 2 + (in >> 4)) * TD;
+            it.n = blk / nbd;
+            return it;
+        }
         it.w0 = (q % twn) * TW; q /= twn;
         it.h0 = (q % thn) * TH; q /= thn;
         it.d0 = (q % tdn) * TD;
@@ -618,6 +632,20 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
         it.par = MODE == 1 ? cb / cbn : 0;
         it.co0 = (MODE == 1 ? cb % cbn : cb) * BN;
         int q = pair / ncb;
+        // tiles are numbered in compact 2 (d) x 4 (h) x 4 (w) blocks when the grid allows it: the ~32 consecutive pairs an XCD works on at any
+        // time then share their halo planes / rows / columns in its L2 instead of being a one-tile-thick row of the volume
+        if (((twn | thn) & 3) == 0 && (tdn & 1) == 0) {
+            const int in = q & 31;
+            int blk = q >> 5;
+            const int nbw = twn >> 2, nbh = thn >> 2, nbd = tdn >> 1;
+            const int bw_ = blk % nbw; blk /= nbw;
+            const int bh_ = blk % nbh; blk /= nbh;
+            it.w0 = (bw_ * 4 + (in & 3)) * TW;
+            it.h0 = (bh_ * 4 + ((in >> 2) & 3)) * TH;
+            it.d0 = ((blk % nbd) * 2 + (in >> 4)) * TD;
+            it.n = blk / nbd;
+            return it;
+        }
         it.w0 = (q % twn) * TW; q /= twn;
         it.h0 = (q % thn) * TH; q /= thn;
         it.d0 = (q % tdn) * TD;
