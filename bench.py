@@ -3,7 +3,12 @@
 depth-4 / 32-base-filter U-Net (BASELINE.json configs[1]; reference fetal_net/model/unet3d/unet.py:17-86 defaults), batch 4
 per GPU, synthetic data resident in HBM, random-init (glorot) weights.
 
-  python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, one rank per GPU)
+  python bench.py --gpus N --steps K --warmup W
+
+N > 1: one rank per GPU over RCCL.  Under a launcher (torch.distributed.run sets RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*) this
+process IS one rank; started bare (`python bench.py --gpus 8`) it becomes a parent that starts the N ranks as child processes - before
+anything touches the GPU - relays rank 0's JSON line and exits non-zero when any rank fails.  A rank whose WORLD_SIZE differs from
+--gpus refuses to run (a single-GPU number can no longer be labelled as a scaling run).
 
 Prints ONE JSON line on rank 0.  Besides the driver contract it carries
   "roofline"     for the dominant kernel (live HIP-event timing of every conv launch in the timed steps), and
@@ -67,6 +72,7 @@ class LaunchTimer:
 
     def __init__(self):
         self.rec = {}
+        self.detail = {}
         self.on = False
 
     def wrap(self, ops_mod, fn_name, label_fn, launches=1):
@@ -80,13 +86,20 @@ class LaunchTimer:
             e0.record()
             r = orig(*a, **k)
             e1.record()
-            self.rec.setdefault(label_fn(*a, **k), []).append((e0, e1, launches))
+            lab = label_fn(*a, **k)
+            fam, detail = lab if isinstance(lab, tuple) else (lab, None)
+            self.rec.setdefault(fam, []).append((e0, e1, launches))
+            if detail is not None:                      # per-layer view: (pass, C0, C1, Cout, D) identifies a conv of the plan
+                self.detail.setdefault(detail, []).append((e0, e1))
             return r
 
         setattr(ops_mod, fn_name, wrapped)
 
     def totals_ms(self):
         return {k: (sum(a.elapsed_time(b) for a, b, _ in v), sum(n for _, _, n in v)) for k, v in self.rec.items()}
+
+    def detail_ms(self):
+        return {k: (sum(a.elapsed_time(b) for a, b in v), len(v)) for k, v in self.detail.items()}
 
 
 def synthetic_batch(shape, seed_x=1234, seed_y=1235, fg=0.30):
@@ -141,21 +154,157 @@ def cpu_baseline(budget_s=25.0):
                       "Keras/TF not installed" % (n, best, cands, ncpu)}
 
 
+TRAFFIC_PROFILE = os.path.join("profiles", "r02_pmc_traffic_per_step.json")
+
+
+def kernel_source_hash():
+    """sha256 over the kernel sources the library is built from (csrc/*.hip, common.h, the public header).  A profile under profiles/
+    carries the hash of the tree it was collected on; the GPU box has no .git, so THIS is what bench.py can check at run time (the
+    profile also records `git rev-parse HEAD` for the reader)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "fetal-mri-segmentation_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h")) + [os.path.join(ROOT, "include", "fmri_hip.h")]):
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic(kernel_key):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/r01_pmc_traffic_per_step.json:
-    FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs of this same bench; FETCH_SIZE doubled per the gfx950 note in
-    MI355X_MICROARCH.md §HBM).  None when the file is missing."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic_per_step.json")
+    """(HBM bytes per launch of the dominant kernel, stamp) from the committed rocprofv3 PMC passes (TRAFFIC_PROFILE: FETCH_SIZE and
+    WRITE_SIZE collected in separate --pmc runs of this same bench by tools/collect_profiles.sh; FETCH_SIZE doubled per the gfx950 note
+    in MI355X_MICROARCH.md, HBM section).  The bytes are None when the file is missing OR was collected on other kernel sources than the
+    ones in this tree (stamp["kernel_source_hash"] != kernel_source_hash()): a stale profile is not reported."""
+    path = os.path.join(ROOT, TRAFFIC_PROFILE)
+    stamp = {"file": TRAFFIC_PROFILE, "head": None, "kernel_source_hash": None, "current_kernel_source_hash": kernel_source_hash(), "fresh": False}
     if not os.path.exists(path):
-        return None
+        return None, stamp
     with open(path) as f:
         d = json.load(f)
+    meta = d.get("_meta", {})
+    stamp["head"], stamp["kernel_source_hash"] = meta.get("git_head"), meta.get("kernel_source_hash")
+    stamp["fresh"] = stamp["kernel_source_hash"] == stamp["current_kernel_source_hash"]
+    if not stamp["fresh"]:
+        return None, stamp
     tot_b, calls = 0.0, 0
     for k, v in d.items():
         if k.startswith(kernel_key):
             tot_b += (2.0 * v["fetch_kb"] + v["write_kb"]) * 1024.0
             calls += v["calls"]
-    return (tot_b / calls) if calls else None
+    return ((tot_b / calls) if calls else None), stamp
+
+
+def per_layer_table(eng, detail_ms, steps):
+    """every 3x3x3 conv of the plan x (fwd, dgrad, wgrad): exclusive ms per launch, algorithmic TFLOP/s / 2.5 PF, algorithmic
+    GB/s / 8 TB/s (bytes = |X| + |Y| + |W| in bf16, each tensor once: the pass reads two and writes one)."""
+    p, N = eng.plan, eng.N
+    first = p.enc[0][0]["name"]
+    rows = []
+    for c in p.convs_forward_order():
+        D, H, W = p.level_dims(c["level"])
+        vox = N * D * H * W
+        fl = 2.0 * 27 * c["cin"] * c["cout"] * vox
+        by = 2.0 * (vox * c["cin"] + vox * c["cout"] + 27 * c["cin"] * c["cout"])
+        for ps in ("fwd", "dgrad", "wgrad"):
+            if ps == "dgrad" and c["name"] == first:
+                continue
+            t = detail_ms.get((ps, c["cin"], c["cout"], D))
+            if t is None:
+                continue
+            ms = t[0] / max(t[1], 1)
+            rows.append({"layer": c["name"], "level": c["level"], "cin": c["cin"], "cout": c["cout"], "pass": ps, "ms": round(ms, 4),
+                         "gflop": round(fl / 1e9, 1), "tflops": round(fl / (ms * 1e-3) / 1e12, 1),
+                         "mfma_frac": round(fl / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
+                         "algorithmic_mb": round(by / 1e6, 1), "gbs": round(by / (ms * 1e-3) / 1e9, 1),
+                         "hbm_frac": round(by / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                         "meets_40pct_hbm": bool(by / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS >= 0.40),
+                         "parity_form": c["name"] in getattr(eng, "upcat", {})})
+    tot_ms = sum(r["ms"] for r in rows)
+    tot_fl = sum(r["gflop"] for r in rows)
+    tot_by = sum(r["algorithmic_mb"] for r in rows)
+    return {"rows": rows, "total": {"ms": round(tot_ms, 3), "gflop": round(tot_fl, 1), "mfma_frac": round(tot_fl / tot_ms / PEAK_BF16_TFLOPS, 4) if tot_ms else None,
+                                    "algorithmic_mb": round(tot_by, 1), "hbm_frac": round(tot_by / tot_ms / PEAK_HBM_GBS, 4) if tot_ms else None},
+            "note": "exclusive (one-stream) HIP-event time per launch, mean over %d steps; the network-level 40 %% HBM target is above the "
+                    "MFMA ceiling (23.9 %%, SURVEY 0/8d)" % steps}
+
+
+def launch_ranks(n, argv):
+    """Parent of a bare `bench.py --gpus N`: N children, one per GPU, each a rank of a 127.0.0.1 rendezvous.  The parent never touches
+    the GPU (a process that has initialised HIP must not fork/exec workers on this pool).  Returns the exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL between processes needs it on this driver
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0)))
+    rc = 0
+    pending = set(range(n))
+    while pending:
+        for r in sorted(pending):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            pending.discard(r)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                sys.stderr.write("bench.py: rank %d exited with code %d - stopping the other ranks\n" % (r, code))
+                for q in pending:                              # a dead rank leaves the others inside a collective
+                    procs[q].terminate()
+        if pending:
+            time.sleep(0.05)
+    out = procs[0].stdout.read() if procs[0].stdout else ""
+    line = None
+    for ln in out.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            sys.stderr.write(ln + "\n")
+    if rc == 0 and line is None:
+        sys.stderr.write("bench.py: rank 0 printed no result line\n")
+        rc = 1
+    if line is not None and rc == 0:
+        print(line)
+    return rc
+
+
+def selftest_cpu(a, rank, world):
+    """Launcher / rendezvous / result-line plumbing on the CPU (`--selftest-cpu`, used by tests/test_bench_launcher.py): the ranks form a
+    gloo group and all-reduce a small gradient-like buffer per "step"; nothing is measured and the line says so."""
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        assert dist.get_world_size() == a.gpus
+    g = torch.full((1 << 16,), float(rank + 1))
+    t0 = time.perf_counter()
+    for _ in range(a.warmup + a.steps):
+        h = g.clone()
+        if world > 1:
+            dist.all_reduce(h)
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    assert float(h[0]) == world * (world + 1) / 2.0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+        ranks = dist.get_world_size()
+        dist.destroy_process_group()
+    else:
+        ranks = 1
+    if rank == 0:
+        print(json.dumps({"metric": "launcher self-test (CPU, gloo) - not a measurement", "value": a.batch * world * a.steps / dt,
+                          "unit": "patches/s", "n_gpus": world, "collective_ranks": ranks, "steps": a.steps, "warmup": a.warmup,
+                          "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                          "dtype": "f32", "data": "selftest", "config": {"workload": "selftest", "global_batch": a.batch * world,
+                                                                           "parallelism": "dp%d" % world}}))
 
 
 def main():
@@ -170,17 +319,37 @@ def main():
                     help="skip the second (single-stream) pass that measures exclusive kernel durations (used when profiling the timed region alone)")
     ap.add_argument("--serialize-streams", action="store_true",
                     help="run the conv weight gradients on the main stream (no concurrent kernels): per-kernel durations become exclusive")
+    ap.add_argument("--per-layer", default=None, metavar="JSON",
+                    help="also write the per-layer table (every 3x3x3 conv x fwd/dgrad/wgrad: exclusive ms, TFLOP/s / 2.5 PF, algorithmic "
+                         "GB/s / 8 TB/s; SURVEY 8d) to this file")
+    ap.add_argument("--selftest-cpu", action="store_true", help="exercise the N-rank launcher on the CPU (gloo); measures nothing")
     a = ap.parse_args()
+    if a.gpus < 1:
+        ap.error("--gpus must be >= 1")
+
+    if a.gpus > 1 and "RANK" not in os.environ:
+        # bare multi-GPU invocation: become the parent of N ranks BEFORE anything initialises the GPU
+        if not a.selftest_cpu and torch.cuda.device_count() < a.gpus:          # device_count() alone does not initialise HIP
+            sys.stderr.write("bench.py: --gpus %d but only %d device(s) visible\n" % (a.gpus, torch.cuda.device_count()))
+            sys.exit(2)
+        sys.exit(launch_ranks(a.gpus, sys.argv[1:]))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        sys.stderr.write("bench.py: --gpus %d but the launcher set WORLD_SIZE=%d\n" % (a.gpus, world))
+        sys.exit(2)
+    if a.selftest_cpu:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        return selftest_cpu(a, rank, world)
     torch.cuda.set_device(local_rank)
     dctx = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world)
+        assert dist.get_world_size() == a.gpus, (dist.get_world_size(), a.gpus)
         from fmri_hip.dist import DataParallel
         dctx = DataParallel(world, rank)
 
@@ -201,33 +370,48 @@ def main():
 
     timer = LaunchTimer()
     if not a.no_launch_timing:
+        # detail key = (pass, Cin of the conv, Cout of the conv, D of its output): unique per conv of the plan
         def lab_fwd(src0, src1, w, bias, y_, *aa, **kk):
             c0, c1 = src0.shape[-1], (0 if src1 is None else src1.shape[-1])
+            key = ("fwd", c0 + c1, y_.shape[-1], y_.shape[1])
             if c0 == 1 and c1 == 0:
-                return "conv_first_fwd"
-            return ("conv_fwd_mfma" if (c0 % 32 == 0 and c1 % 32 == 0 and y_.shape[-1] % 32 == 0) else "conv_fwd_generic")
+                return "conv_first_fwd", key
+            return ("conv_fwd_mfma" if (c0 % 32 == 0 and c1 % 32 == 0 and y_.shape[-1] % 32 == 0) else "conv_fwd_generic"), key
 
         def lab_dgrad(dy, wd, dx, *aa, **kk):
-            return "conv_fwd_mfma" if (dy.shape[-1] % 32 == 0 and dx.shape[-1] % 32 == 0) else "conv_fwd_generic"
+            key = ("dgrad", dx.shape[-1], dy.shape[-1], dy.shape[1])
+            return ("conv_fwd_mfma" if (dy.shape[-1] % 32 == 0 and dx.shape[-1] % 32 == 0) else "conv_fwd_generic"), key
 
         def lab_wgrad(src0, src1, dy, dw, db, *aa, **kk):
             c0, c1 = src0.shape[-1], (0 if src1 is None else src1.shape[-1])
+            key = ("wgrad", c0 + c1, dy.shape[-1], dy.shape[1])
             if c0 == 1 and c1 == 0:
-                return "conv_first_wgrad"
-            return ("conv_wgrad_mfma" if (c0 % 32 == 0 and c1 % 32 == 0 and dy.shape[-1] % 64 == 0) else "conv_wgrad_generic")
+                return "conv_first_wgrad", key
+            return ("conv_wgrad_mfma" if (c0 % 32 == 0 and c1 % 32 == 0 and dy.shape[-1] % 64 == 0) else "conv_wgrad_generic"), key
+
+        def lab_up_fwd(x_low, skip, w_up, w_sk, bias, y_, *aa, **kk):
+            return "conv_fwd_mfma", ("fwd", x_low.shape[-1] + (0 if skip is None else skip.shape[-1]), y_.shape[-1], y_.shape[1])
+
+        def lab_up_dgrad(dy, *aa, **kk):
+            # the parity-form input gradient covers BOTH halves of the concat (low-res tensor + skip tensor) and the up-sampling gradient
+            dlow, dskip = aa[4], aa[5]
+            return "conv_fwd_mfma", ("dgrad", dlow.shape[-1] + (0 if dskip is None else dskip.shape[-1]), dy.shape[-1], dy.shape[1])
+
+        def lab_up_wgrad(x_low, skip, dy, *aa, **kk):
+            return "conv_wgrad_mfma", ("wgrad", x_low.shape[-1] + (0 if skip is None else skip.shape[-1]), dy.shape[-1], dy.shape[1])
 
         timer.wrap(ops, "conv3d_fwd", lab_fwd)
         timer.wrap(ops, "conv3d_dgrad", lab_dgrad)
         timer.wrap(ops, "conv3d_wgrad", lab_wgrad)
-        timer.wrap(ops, "conv3d_upcat_fwd", lambda *aa, **kk: "conv_fwd_mfma", launches=2)
-        timer.wrap(ops, "conv3d_upcat_dgrad", lambda *aa, **kk: "conv_fwd_mfma", launches=2)
+        timer.wrap(ops, "conv3d_upcat_fwd", lab_up_fwd, launches=2)
+        timer.wrap(ops, "conv3d_upcat_dgrad", lab_up_dgrad, launches=2)
         # the optimizer step repacks the deep layers' weight images on a side stream, under the next step's first convolutions: their event
         # brackets measure a concurrent span, not a cost on the step's critical path
         def lab_pack(*aa, **kk):
             return "pack_weights" if torch.cuda.current_stream() == torch.cuda.default_stream() else "pack_weights_side_stream_overlapped"
 
         timer.wrap(ops, "conv3d_pack_up_weights", lab_pack)
-        timer.wrap(ops, "conv3d_upcat_wgrad", lambda *aa, **kk: "conv_wgrad_mfma", launches=2)
+        timer.wrap(ops, "conv3d_upcat_wgrad", lab_up_wgrad, launches=2)
         timer.wrap(ops, "pack_weights", lab_pack)
         for nm in ("maxpool_fwd", "maxpool_bwd", "upsample_bwd", "conv1x1_fwd", "conv1x1_bwd", "sigmoid_dice_fwd",
                    "sigmoid_dice_bwd", "adam_step"):
@@ -258,6 +442,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     tot_timed = timer.totals_ms()
+    detail = timer.detail_ms()          # exclusive only when everything ran on one stream (replaced by the second pass below otherwise)
     tot_excl = None
     if not a.no_launch_timing and not a.no_exclusive_pass and eng._wg_stream is not None:
         # The engine runs the weight-gradient kernels on a second stream, concurrently with the input-gradient chain: inside the timed
@@ -268,15 +453,20 @@ def main():
         for _ in range(2):
             eng.train_step(xd, yd, lr)
         torch.cuda.synchronize()
-        timer.rec = {}
+        timer.rec, timer.detail = {}, {}
         timer.on = True
         for _ in range(a.steps):
             eng.train_step(xd, yd, lr)
         torch.cuda.synchronize()
         timer.on = False
         tot_excl = timer.totals_ms()
+        detail = timer.detail_ms()
         eng._wg_stream = keep
 
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
     if rank != 0:
         return
     ms = dt / a.steps * 1e3
@@ -284,6 +474,7 @@ def main():
     m = eng.metrics_from_sums(sums.cpu().numpy())
     out = {
         "metric": "3D patches/sec (64x128x128, bf16) fwd+bwd", "value": value, "unit": "patches/s", "n_gpus": world,
+        "collective_ranks": (dctx.world if dctx is not None else 1),
         "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {"workload": "configs[1]: depth-4 3D U-Net, 32 base filters, bf16, batch %dx1x64x128x128 per GPU, "
@@ -303,10 +494,12 @@ def main():
             flops = (fl["fwd_mfma"] + fl["dgrad_mfma"]) if dom == "conv_fwd_mfma" else fl["wgrad_mfma"]
             t_ms, launches = per_step[dom]
             ach = flops / (t_ms * 1e-3) / 1e12
+            traffic, stamp = pmc_traffic("k_conv_fwd_" if dom == "conv_fwd_mfma" else "k_conv_wgrad")   # every instantiation of the family
             r = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS,
                  "note": note,
-                 "traffic": pmc_traffic("k_conv_fwd_" if dom == "conv_fwd_mfma" else "k_conv_wgrad_mfma"),   # k_conv_fwd_ws<..> and k_conv_fwd_mfma<..>
-                 "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, separate passes, FETCH_SIZE x2 corrected)",
+                 "traffic": traffic, "traffic_profile": stamp,
+                 "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, separate passes, FETCH_SIZE x2 corrected); null when the committed "
+                                 "profile was collected on other kernel sources",
                  "algorithmic_flop_per_launch": flops / max(launches, 1), "launches_per_step": launches,
                  "avg_launch_ms": t_ms / max(launches, 1)}
             if dom == "conv_fwd_mfma":
@@ -341,6 +534,13 @@ def main():
                 out["roofline_exclusive"]["other"] = rox
         # step-level figure that does not depend on how kernels overlap: all conv FLOPs of a step / the step time
         out["step_mfma_frac"] = (fl["fwd_mfma"] + fl["dgrad_mfma"] + fl["wgrad_mfma"]) / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS
+    if a.per_layer and not a.no_launch_timing:
+        tab = per_layer_table(eng, detail, a.steps)
+        tab["exclusive"] = bool(tot_excl is not None or a.serialize_streams or eng._wg_stream is None)
+        tab["kernel_source_hash"] = kernel_source_hash()
+        with open(a.per_layer, "w") as f:
+            json.dump(tab, f, indent=1)
+        out["per_layer_total"] = tab["total"]
     if world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
     print(json.dumps(out))

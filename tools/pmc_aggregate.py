@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Per-kernel HBM traffic per training step from two rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE, one counter per pass).
 
-usage: pmc_aggregate.py <dir with pmc_fetch/ and pmc_write/> <steps profiled (warmup + timed)>
+usage: pmc_aggregate.py <dir with pmc_fetch/ and pmc_write/> <steps profiled (warmup + timed)> [git head] [kernel source hash]
+The two optional stamps land under "_meta"; bench.py reports roofline.traffic from the file only while the hash matches its tree.
 Both counters are in KiB-like units of 1 KB per the guide's table; on gfx950 FETCH_SIZE under-reports wide streaming reads by 2x
 (/opt/skills/guides/MI355X_MICROARCH.md, HBM section), so hbm_mb_corrected = (2 * fetch_kb + write_kb) * 1024 / 1e6."""
 import csv
@@ -30,7 +31,8 @@ def load(d, counter):
 def main():
     root, steps = sys.argv[1], int(sys.argv[2])
     fe, wr = load(os.path.join(root, "pmc_fetch"), "FETCH_SIZE"), load(os.path.join(root, "pmc_write"), "WRITE_SIZE")
-    res = {}
+    res = {"_meta": {"git_head": sys.argv[3] if len(sys.argv) > 3 else None,
+                     "kernel_source_hash": sys.argv[4] if len(sys.argv) > 4 else None, "steps_profiled": steps}}
     for k in fe:
         calls = fe[k][0] / steps
         f, w = fe[k][1] / steps, wr.get(k, [0, 0.0])[1] / steps
