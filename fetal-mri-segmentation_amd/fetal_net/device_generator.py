@@ -202,7 +202,10 @@ def device_data_generator(data_file, index_list, batch_size=1, n_labels=1, label
             filled += 1
         yy = y
         if categorical:
-            yy = torch.stack([1 - y, y], dim=-1).float()           # keras.utils.to_categorical(y, 2)
+            # keras.utils.to_categorical(y, 2) (reference generator.py:390-391): a trailing axis of size 1 is dropped before the one-hot
+            # axis is appended - (N,X,Y,1) -> (N,X,Y,2), (N,X,Y,T>1) -> (N,X,Y,T,2) - float32
+            yc = y.squeeze(-1) if y.shape[-1] == 1 else y
+            yy = torch.stack([1 - yc, yc], dim=-1).float()
         if is3d:
             xo, yo, mo = x.unsqueeze(1), yy.unsqueeze(1), (None if m is None else m.unsqueeze(1))
         else:

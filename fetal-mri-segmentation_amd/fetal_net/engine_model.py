@@ -607,7 +607,14 @@ class Model(object):
         if hdf5.is_hdf5(path):
             from . import keras_h5
             self.set_weights_dict(keras_h5.map_weights(self, keras_h5.read_weights(path)))
-            state = keras_h5.read_optimizer(path, self)
+            try:
+                state = keras_h5.read_optimizer(path, self)
+            except ValueError as e:
+                # Keras (saving.py load_model): "Error in loading the saved optimizer state. As a result, your model is starting with a
+                # freshly initialized optimizer." - a warning, never a failed load_weights
+                import warnings
+                warnings.warn("optimizer state of %s not restored (%s): the optimizer starts fresh" % (path, e))
+                state = None
         else:
             z = np.load(path, allow_pickle=False)
             self.set_weights_dict(OrderedDict((k[2:], z[k]) for k in z.files if k.startswith("w/")))

@@ -214,12 +214,19 @@ def save_model(model, path, include_optimizer=True, weights_only=False, extra_me
             m, v, t = state
             og = f.create_group("optimizer_weights")
             keys = trainable_keys(model)
-            names = ["Adam/iterations:0"] + ["training/Adam/m_%s:0" % k for k in keys] + ["training/Adam/v_%s:0" % k for k in keys]
-            _set_list_attr(og, "weight_names", [n.encode() for n in names])
+            # Keras 2.2.x Adam.weights = [iterations] + ms + vs + vhats (keras/optimizers.py Adam.get_updates): the slots are anonymous
+            # K.zeros variables ("training/Adam/Variable[_k]:0", numbered in creation order m, v, vhat, m, v, vhat ... per parameter), and
+            # with amsgrad=False every vhat is a K.zeros(1) placeholder that is still saved.  Keras restores them BY POSITION
+            # (optimizer.set_weights), so the count - 1 + 3n - is what has to be right for a file written here to resume there.
+            n = len(keys)
+            var = lambda i: "training/Adam/Variable%s:0" % ("" if i == 0 else "_%d" % i)
+            names = ["Adam/iterations:0"] + [var(3 * i) for i in range(n)] + [var(3 * i + 1) for i in range(n)] + [var(3 * i + 2) for i in range(n)]
+            _set_list_attr(og, "weight_names", [n_.encode() for n_ in names])
             og.create_dataset(names[0], data=np.int64(t)).close()
-            for prefix, src in (("m", m), ("v", v)):
-                for k in keys:
-                    og.create_dataset("training/Adam/%s_%s:0" % (prefix, k), data=np.asarray(src[k], np.float32)).close()
+            for i, k in enumerate(keys):
+                og.create_dataset(names[1 + i], data=np.asarray(m[k], np.float32)).close()
+                og.create_dataset(names[1 + n + i], data=np.asarray(v[k], np.float32)).close()
+                og.create_dataset(names[1 + 2 * n + i], data=np.zeros((1,), np.float32)).close()
             og.close()
 
 
@@ -276,11 +283,25 @@ def read_optimizer(path, model):
         arrays = [np.asarray(og[n][()]) for n in names]
         og.close()
     keys = trainable_keys(model)
-    if len(arrays) != 1 + 2 * len(keys):
-        raise ValueError("optimizer_weights holds %d arrays, expected 1 + 2 x %d (Adam)" % (len(arrays), len(keys)))
-    t = int(arrays[0])
-    m = OrderedDict(zip(keys, arrays[1:1 + len(keys)]))
-    v = OrderedDict(zip(keys, arrays[1 + len(keys):]))
+    n = len(keys)
+    short = [nm.rsplit("/", 1)[-1].split(":")[0] for nm in names]
+    if all(("m_" + k) in short and ("v_" + k) in short for k in keys):
+        # files of this package's first format: slots named after their parameter
+        at = dict(zip(short, arrays))
+        it = [a for nm, a in zip(short, arrays) if nm == "iterations"]
+        return (OrderedDict((k, at["m_" + k]) for k in keys), OrderedDict((k, at["v_" + k]) for k in keys), int(it[0]) if it else 0)
+    # Keras layout, by position: [iterations] + ms + vs (+ one shape-(1,) vhat placeholder per parameter when amsgrad=False, or
+    # parameter-shaped vhats when amsgrad=True - ignored either way: this engine's Adam has no amsgrad)
+    if len(arrays) not in (1 + 2 * n, 1 + 3 * n):
+        raise ValueError("optimizer_weights holds %d arrays, expected 1 + 2 x %d or 1 + 3 x %d (Keras Adam)" % (len(arrays), n, n))
+    t = int(np.asarray(arrays[0]).reshape(-1)[0])
+    m = OrderedDict(zip(keys, arrays[1:1 + n]))
+    v = OrderedDict(zip(keys, arrays[1 + n:1 + 2 * n]))
+    shapes = weight_shapes(model)
+    for k in keys:
+        for slot, a in (("m", m[k]), ("v", v[k])):
+            if tuple(a.shape) != tuple(shapes[k]):
+                raise ValueError("optimizer slot %s of %s has shape %s, the parameter has %s" % (slot, k, tuple(a.shape), tuple(shapes[k])))
     return m, v, t
 
 

@@ -178,6 +178,13 @@ def _device_overlap_add(model, data_0, indices, patch_shape, batch_size, data_sh
     st["acc"].zero_()
     st["cnt"].zero_()
     idx_all = torch.from_numpy(np.ascontiguousarray(indices, dtype=np.int32)).cuda()
+    # A captured graph holds no dependency on the engine's weight-repack side stream (it was captured after a warm-up that had already
+    # joined it), but an optimizer step since then may have left a repack of the deeper layers' filter images in flight there: make THIS
+    # stream wait for it before any replay reads those images.
+    for B in sizes:
+        join = getattr(model.engine(B), "_join_packs", None)
+        if join is not None:
+            join()
     for i in range(0, n, batch_size):
         bidx = idx_all[i:i + batch_size]
         pb = st["per_b"][int(bidx.shape[0])]
@@ -215,9 +222,9 @@ def predict_with_permutations(model, data):
 
 
 def flip_it(data_, axes):
-    for ax in axes:
-        data_ = np.flip(data_, ax)
-    return data_
+    """mirror along every axis in `axes` (an involution: applying it twice restores the input)"""
+    axes = tuple(int(a) for a in axes)
+    return np.flip(data_, axis=axes) if axes else data_
 
 
 def predict_flips(data, model, overlap_factor, config):
@@ -233,34 +240,54 @@ def predict_flips(data, model, overlap_factor, config):
     return predictions
 
 
+class _TTAVariant:
+    """One random test-time variant of a volume: intensity window, mirror axes, optional x/y swap, in-plane rotation angle.
+    `draw` consumes numpy's global RNG in the order the reference's loop does (two window draws, the angle, three mirror coins, the
+    swap coin: reference prediction.py:34-42) - a seeded run therefore produces the reference's variants (tests/golden/augment_golden.*)."""
+    __slots__ = ("lo", "hi", "angle", "mirror", "swap")
+
+    @classmethod
+    def draw(cls, vmin, vmax, jitter=0.10, max_angle=30):
+        v = cls()
+        span = vmax - vmin
+        v.lo = vmin + jitter * np.random.uniform(-1, 1) * span
+        v.hi = vmax + jitter * np.random.uniform(-1, 1) * span
+        v.angle = np.random.uniform(-max_angle, max_angle)
+        v.mirror = tuple(np.flatnonzero(np.random.choice([True, False], size=3)))
+        v.swap = bool(np.random.choice([True, False]))
+        return v
+
+    def forward(self, vol):
+        """volume -> variant: window, mirror, swap, rotate (quadratic spline, shape kept)"""
+        from scipy import ndimage
+        out = flip_it(contrast_augment(vol, self.lo, self.hi), self.mirror)
+        if self.swap:
+            out = np.swapaxes(out, 0, 1)
+        return ndimage.rotate(out, self.angle, order=2, reshape=False)
+
+    def inverse(self, pred):
+        """prediction of the variant -> frame of the original volume.  The back-rotation keeps scipy's defaults (cubic spline,
+        reshape=True), as the reference's does - the result can be larger than the input when angle != 0."""
+        from scipy import ndimage
+        out = ndimage.rotate(pred, -self.angle)
+        if self.swap:
+            out = np.swapaxes(out, 0, 1)
+        return flip_it(out, self.mirror)
+
+
 def predict_augment(data, model, overlap_factor, patch_shape, num_augments=32):
-    """Contrast / flip / transpose / in-plane rotation variants of the volume, each predicted patch-wise on the device and mapped
-    back (reference prediction.py:25-62; same numpy draws in the same order).  The volume-sized spline rotations stay on the
-    host (scipy), as in the reference.  Like the reference, the back-rotation uses scipy's default reshape=True, so stacking
-    succeeds only when all predictions end up with one shape (num_augments = 1, or equal angles)."""
-    from scipy import ndimage
-    data_max, data_min = data.max(), data.min()
-    data = data.squeeze()
-    predictions = []
+    """Random intensity / mirror / swap / rotation variants of the volume (reference prediction.py:25-62), each predicted patch-wise on
+    the device tile loop and mapped back; the volume-sized spline rotations stay on the host (scipy), as in the reference.  Like the
+    reference, stacking succeeds only when all back-rotated predictions end up with one shape (num_augments = 1, or equal angles)."""
+    vmin, vmax = data.min(), data.max()
+    vol = data.squeeze()
+    out = []
     for _ in range(num_augments):
-        val_range = data_max - data_min
-        contrast_min_val = data_min + 0.10 * np.random.uniform(-1, 1) * val_range
-        contrast_max_val = data_max + 0.10 * np.random.uniform(-1, 1) * val_range
-        curr = contrast_augment(data, contrast_min_val, contrast_max_val)
-        rotate_factor = np.random.uniform(-30, 30)
-        to_flip = np.arange(0, 3)[np.random.choice([True, False], size=3)]
-        to_transpose = np.random.choice([True, False])
-        curr = flip_it(curr, to_flip)
-        if to_transpose:
-            curr = curr.transpose([1, 0, 2])
-        curr = ndimage.rotate(curr, rotate_factor, order=2, reshape=False)
-        pred = patch_wise_prediction(model=model, data=curr[np.newaxis, ...], overlap_factor=overlap_factor,
+        variant = _TTAVariant.draw(vmin, vmax)
+        pred = patch_wise_prediction(model=model, data=variant.forward(vol)[np.newaxis], overlap_factor=overlap_factor,
                                      patch_shape=patch_shape).squeeze()
-        pred = ndimage.rotate(pred, -rotate_factor)
-        if to_transpose:
-            pred = pred.transpose([1, 0, 2])
-        predictions.append(flip_it(pred, to_flip).squeeze())
-    return np.stack(predictions, axis=0)
+        out.append(variant.inverse(pred).squeeze())
+    return np.stack(out, axis=0)
 
 
 def run_validation_case(data_index, output_dir, model, data_file, training_modalities, patch_shape, overlap_factor=0,
@@ -306,18 +333,17 @@ def run_validation_cases(validation_keys_file, model_file, training_modalities, 
     if own:
         import tables
         data_file = tables.open_file(hdf5_file, "r")
-    file_names = []
+    has_ids = 'subject_ids' in data_file.root
+
+    def case_dir(index):
+        label = data_file.root.subject_ids[index].decode('utf-8') if has_ids else "validation_case_{}".format(index)
+        return os.path.join(output_dir, label)
+
     try:
-        for index in validation_indices:
-            if 'subject_ids' in data_file.root:
-                case_directory = os.path.join(output_dir, data_file.root.subject_ids[index].decode('utf-8'))
-            else:
-                case_directory = os.path.join(output_dir, "validation_case_{}".format(index))
-            file_names.append(run_validation_case(data_index=index, output_dir=case_directory, model=model, data_file=data_file,
-                                                  training_modalities=training_modalities, overlap_factor=overlap_factor,
-                                                  permute=permute, patch_shape=patch_shape, prev_truth_index=prev_truth_index,
-                                                  prev_truth_size=prev_truth_size, use_augmentations=use_augmentations))
+        return [run_validation_case(data_index=i, output_dir=case_dir(i), model=model, data_file=data_file,
+                                    training_modalities=training_modalities, overlap_factor=overlap_factor, permute=permute,
+                                    patch_shape=patch_shape, prev_truth_index=prev_truth_index, prev_truth_size=prev_truth_size,
+                                    use_augmentations=use_augmentations) for i in validation_indices]
     finally:
         if own:
             data_file.close()
-    return file_names

@@ -1,30 +1,21 @@
-"""Patch extraction helpers on the live prediction path (reference fetal_net/utils/patches.py:57-91)."""
+"""Host-side tile extraction for the sliding-window path when the model is a foreign object (the device path gathers its tiles with
+fmri_tile_gather).  Same contract as the reference helper of the same name (fetal_net/utils/patches.py:57-91): a corner-indexed patch of
+the last three axes, parts that fall outside the volume replicate the nearest edge voxel."""
 import numpy as np
 
 
 def get_patch_from_3d_data(data, patch_shape, patch_index):
-    """corner-indexed patch of the last three axes; out-of-range parts replicate the edge."""
-    patch_index = np.asarray(patch_index, dtype=np.int16)
-    patch_shape = np.asarray(patch_shape)
-    image_shape = data.shape[-3:]
-    if np.any(patch_index < 0) or np.any((patch_index + patch_shape) > image_shape):
-        data, patch_index = fix_out_of_bound_patch_attempt(data, patch_shape, patch_index)
-    i, s = patch_index, patch_shape
-    return data[..., i[0]:i[0] + s[0], i[1]:i[1] + s[1], i[2]:i[2] + s[2]]
-
-
-def fix_out_of_bound_patch_attempt(data, patch_shape, patch_index, ndim=3):
-    image_shape = np.asarray(data.shape[-ndim:])
-    pad_before = np.abs((patch_index < 0) * patch_index)
-    pad_after = np.abs(((patch_index + patch_shape) > image_shape) * ((patch_index + patch_shape) - image_shape))
-    pad_args = np.stack([pad_before, pad_after], axis=1).tolist()
-    pad_args = [[0, 0]] * (data.ndim - len(pad_args)) + pad_args
-    return np.pad(data, pad_args, mode="edge"), patch_index + pad_before
-
-
-def get_random_nd_index(index_max):
-    return tuple([np.random.choice(index_max[index] + 1) for index in range(len(index_max))])
+    """Clamped-index gather: per axis the wanted coordinates corner .. corner + size - 1 are clipped into [0, dim - 1] - exactly what an
+    edge-mode pad followed by a slice produces, without building the padded volume.  Leading axes (channels) are kept.  Always a copy."""
+    data = np.asarray(data)
+    dims = data.shape[-3:]
+    coords = [np.clip(np.arange(int(c), int(c) + int(n)), 0, d - 1) for c, n, d in zip(patch_index, patch_shape, dims)]
+    if len(coords) != 3:
+        raise ValueError("patch_index / patch_shape must address the last three axes")
+    return data[(Ellipsis,) + np.ix_(*coords)]
 
 
 def get_random_patch_index(image_shape, patch_shape):
-    return get_random_nd_index(np.subtract(image_shape, patch_shape))
+    """uniform random corner such that the patch lies inside the image; one np.random.choice draw per axis (the draw order is part of the
+    seeded-generator contract, tests/golden/augment_golden.*)"""
+    return tuple(int(np.random.choice(int(i) - int(p) + 1)) for i, p in zip(image_shape, patch_shape))

@@ -728,7 +728,9 @@ class UNetEngine:
         """one full step: forward, Dice, backward, (all-reduce), Adam.  Returns the device tensor of metric sums."""
         self.forward(x)
         self.loss_forward(y_true, weight)
-        self.backward(y_true, weight=weight)
+        # data parallel: with the global-batch Dice sums the ranks' gradients are summed (scale 1); with per-rank losses
+        # (global_dice=False) the all-reduce sum is turned into the mean by scaling each rank's loss gradient by 1/world
+        self.backward(y_true, grad_scale=(self.dist.grad_scale if self.dist is not None else 1.0), weight=weight)
         self.adam_step(lr)
         return self.sums
 

@@ -605,7 +605,7 @@ class LayerGraphEngine(object):
     def train_step(self, x, y_true, lr, weight=None):
         self.forward(x)
         self.loss_forward(y_true, weight)
-        self.backward(y_true, weight=weight)
+        self.backward(y_true, grad_scale=(self.dist.grad_scale if getattr(self, "dist", None) is not None else 1.0), weight=weight)
         self.adam_step(lr)
         return self.sums
 

@@ -67,7 +67,8 @@ TWO_RANK = textwrap.dedent("""
     Y = (rs.rand(4, *sp) > 0.6).astype(np.uint8)
     xd = torch.from_numpy(X[2 * rank:2 * rank + 2]).cuda().contiguous()
     yd = torch.from_numpy(Y[2 * rank:2 * rank + 2]).cuda().reshape(-1).contiguous()
-    ctx = DataParallel(world, rank, bucket_bytes=64 << 10)
+    local = len(sys.argv) > 4 and sys.argv[4] == "local"      # per-rank Dice losses, gradients AVERAGED (DataParallel.grad_scale = 1/world)
+    ctx = DataParallel(world, rank, bucket_bytes=64 << 10, global_dice=not local)
     eng = UNetEngine(UNetPlan(1, sp, depth=2, n_base_filters=8), 2, dtype=torch.float32, dist_ctx=ctx, seed=5 + rank)   # different seeds:
     ctx.broadcast_params(eng)                                                                                            # rank 0's weights win
     losses = []
@@ -76,7 +77,22 @@ TWO_RANK = textwrap.dedent("""
         losses.append(eng.metrics_from_sums(s.cpu().numpy())["dice_coefficient"])
     torch.cuda.synchronize()
     np.savez(os.path.join(out_dir, "rank%%d.npz" %% rank), P=eng.P.cpu().numpy(), dice=np.array(losses), buckets=len(ctx.launched))
-    if rank == 0:                                             # the same three steps on ONE engine with the whole global batch
+    if rank == 0 and local:
+        # reference for the averaged mode: ONE engine, per step the gradients of the two halves' own Dice losses, averaged by hand
+        ref = UNetEngine(UNetPlan(1, sp, depth=2, n_base_filters=8), 2, dtype=torch.float32, seed=5)
+        halves = [(torch.from_numpy(X[2 * r:2 * r + 2]).cuda().contiguous(), torch.from_numpy(Y[2 * r:2 * r + 2]).cuda().reshape(-1).contiguous())
+                  for r in range(2)]
+        for _ in range(3):
+            gs = []
+            for xh, yh in halves:
+                ref.forward(xh); ref.loss_forward(yh); ref.backward(yh)
+                torch.cuda.synchronize()
+                gs.append(ref.G.clone())
+            ref.G.copy_(0.5 * (gs[0] + gs[1]))
+            ref.adam_step(1e-2)
+        torch.cuda.synchronize()
+        np.savez(os.path.join(out_dir, "ref.npz"), P=ref.P.cpu().numpy(), dice=np.array(losses))
+    elif rank == 0:                                           # the same three steps on ONE engine with the whole global batch
         ref = UNetEngine(UNetPlan(1, sp, depth=2, n_base_filters=8), 4, dtype=torch.float32, seed=5)
         xa = torch.from_numpy(X).cuda().contiguous(); ya = torch.from_numpy(Y).cuda().reshape(-1).contiguous()
         rl = []
@@ -111,3 +127,22 @@ def test_two_ranks_equal_one_engine_on_the_global_batch(tmp_path):
     np.testing.assert_allclose(r0["dice"], ref["dice"], rtol=0, atol=2e-5)                # the global-batch Dice, not a per-rank one
     np.testing.assert_allclose(r0["dice"], r1["dice"], rtol=0, atol=1e-9)
     assert float(np.abs(r0["P"] - ref["P"]).max()) <= 2e-4                                # 3 Adam steps at lr 1e-2
+
+
+def test_two_ranks_with_per_rank_losses_average_their_gradients(tmp_path):
+    """global_dice=False: every rank back-propagates ITS OWN Dice loss and the all-reduce must yield the MEAN gradient (ADVICE r1:
+    grad_scale = 1/world was never passed on, so the sum was applied).  Reference: one engine, the two halves' gradients averaged by hand."""
+    import numpy as np
+    f = tmp_path / "two_rank.py"
+    f.write_text(TWO_RANK)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", FMRI_DTYPE="fp32")
+    port = str(29900 + os.getpid() % 90)
+    procs = [subprocess.Popen([sys.executable, str(f), str(r), str(tmp_path), port, "local"], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                              text=True, env=env) for r in range(2)]
+    outs = [p.communicate(timeout=900) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0 and "RANK_OK" in so, (so[-1500:], se[-3000:])
+    r0, r1, ref = (np.load(str(tmp_path / n)) for n in ("rank0.npz", "rank1.npz", "ref.npz"))
+    np.testing.assert_allclose(r0["P"], r1["P"], rtol=0, atol=1e-7)
+    assert float(np.abs(r0["P"] - ref["P"]).max()) <= 2e-4
+    assert float(np.abs(r0["dice"] - r1["dice"]).max()) > 1e-6        # the ranks really saw different (local) losses

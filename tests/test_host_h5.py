@@ -182,12 +182,75 @@ def test_optimizer_state_round_trip(tmp_path):
     model.save(path)
     with hdf5.File(path) as f:
         names = [bytes(n).decode() for n in f["optimizer_weights"].attrs["weight_names"]]
-        assert len(names) == 1 + 2 * len(keys) and names[0] == "Adam/iterations:0"
+        # Keras 2.2.x Adam: [iterations] + ms + vs + one shape-(1,) vhat placeholder per parameter (amsgrad=False), anonymous slot names
+        n = len(keys)
+        assert len(names) == 1 + 3 * n and names[0] == "Adam/iterations:0"
+        assert names[1] == "training/Adam/Variable:0" and names[1 + n] == "training/Adam/Variable_1:0" and names[1 + 2 * n] == "training/Adam/Variable_2:0"
         assert f["optimizer_weights"][names[0]][()].dtype == np.int64
+        assert all(f["optimizer_weights"][nm][()].shape == (1,) for nm in names[1 + 2 * n:])
     m2, v2, t2 = keras_h5.read_optimizer(path, model)
     assert t2 == 123 and all(np.array_equal(m2[k], m[k]) and np.array_equal(v2[k], v[k]) for k in keys)
     model.save(str(tmp_path / "noopt.h5"), include_optimizer=False)
     assert keras_h5.read_optimizer(str(tmp_path / "noopt.h5"), model) is None
+
+
+def _write_keras224_style_file(path, model, W, m, v, t, vhats=True, bad_count=False):
+    """a file laid out the way keras 2.2.4 `model.save()` lays it out (keras/engine/saving.py _serialize_model + optimizers.Adam):
+    written with the raw binding, not with this package's writer."""
+    from fetal_net import keras_h5
+    keys = keras_h5.trainable_keys(model)
+    with hdf5.File(path, "w") as f:
+        f.attrs["keras_version"] = b"2.2.4"
+        f.attrs["backend"] = b"tensorflow"
+        f.attrs["model_config"] = json.dumps(keras_h5.model_config(model)).encode()
+        f.attrs["training_config"] = json.dumps(keras_h5.training_config(model)).encode()
+        g = f.create_group("model_weights")
+        keras_h5.write_weights_group(g, model, W)
+        g.close()
+        og = f.create_group("optimizer_weights")
+        n = len(keys)
+        names = ["Adam/iterations:0"]
+        slots = [np.int64(t)]
+        var = lambda i: "training/Adam/Variable%s:0" % ("" if i == 0 else "_%d" % i)
+        names += [var(3 * i) for i in range(n)] + [var(3 * i + 1) for i in range(n)]
+        slots += [m[k] for k in keys] + [v[k] for k in keys]
+        if vhats:
+            names += [var(3 * i + 2) for i in range(n)]
+            slots += [np.zeros((1,), np.float32) for _ in keys]
+        if bad_count:
+            names, slots = names[:-3], slots[:-3]
+        og.attrs["weight_names"] = np.asarray([nm.encode() for nm in names], dtype="S")
+        for nm, a in zip(names, slots):
+            og.create_dataset(nm, data=a).close()
+        og.close()
+
+
+def test_keras_224_checkpoint_layout_opens_with_load_old_model(tmp_path):
+    """a ModelCheckpoint file of the reference carries 1 + 3n optimizer arrays (vhat placeholders); it must open with
+    load_old_model alone and restore m, v, iterations; an unreadable optimizer group is a warning, not a failed load"""
+    import fetal_net.model as models
+    from fetal_net import keras_h5
+    from fetal_net.training import load_old_model
+    model = models.unet_model_3d(input_shape=(1, 8, 16, 16), depth=2, n_base_filters=4)
+    W = _random_weights(model)
+    model.set_weights_dict(W)
+    keys, shapes = keras_h5.trainable_keys(model), keras_h5.weight_shapes(model)
+    rng = np.random.RandomState(9)
+    m = dict((k, rng.standard_normal(shapes[k]).astype(np.float32)) for k in keys)
+    v = dict((k, rng.random_sample(shapes[k]).astype(np.float32)) for k in keys)
+    for vhats in (True, False):
+        path = str(tmp_path / ("k224_%d.h5" % vhats))
+        _write_keras224_style_file(path, model, W, m, v, 77, vhats=vhats)
+        m2, v2, t2 = keras_h5.read_optimizer(path, model)
+        assert t2 == 77 and all(np.array_equal(m2[k], m[k]) and np.array_equal(v2[k], v[k]) for k in keys)
+        got = load_old_model(path, verbose=False)
+        assert all(np.array_equal(got.get_weights_dict()[k], W[k]) for k in W)
+        assert got._pending_opt is not None and got._pending_opt[2] == 77
+    bad = str(tmp_path / "bad.h5")
+    _write_keras224_style_file(bad, model, W, m, v, 5, bad_count=True)
+    with pytest.warns(UserWarning, match="optimizer state"):
+        got = load_old_model(bad, verbose=False)
+    assert all(np.array_equal(got.get_weights_dict()[k], W[k]) for k in W)
 
 
 def test_npz_container_still_loads(tmp_path, monkeypatch):
