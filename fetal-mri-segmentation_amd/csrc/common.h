@@ -74,3 +74,34 @@ static inline int grid_for(int64_t total, int block = 256, int cap = 256 * 16) {
             default: KERN<T, 1><<<grid, block, 0, s>>>(__VA_ARGS__); break;          \
         }                                                                            \
     } while (0)
+
+// ---- 64 x 64 weight tile: rows = output channels, columns = input channels.  src(co, ci) -> fp32 value; the tile is written once
+// row-major to f_dst[co * ld_f + ci] (coalesced along ci) and once transposed to d_dst[ci * ld_d + co] (coalesced along co) through LDS.
+// Round 1 wrote the transposed image with one scattered 2-byte store per element (stride Cout): 8x write amplification in HBM
+// (rocprofv3 WRITE_SIZE 240 MB for 32 MB of images) and ~1 ms per optimizer step for what is 130 MB of traffic.
+// Call with 256 threads; `tile` = T[64][PACK_PITCH(T)] in LDS; ends with a barrier (the tile can be reused at once).
+#define PACK_PITCH(T) (64 + (sizeof(T) == 2 ? 2 : 1))       /* odd number of 4-byte words per row: the column reads are conflict-free */
+template <typename T, typename F>
+__device__ __forceinline__ void pack_tile(F src, T* __restrict__ f_dst, int64_t ld_f, T* __restrict__ d_dst, int64_t ld_d, int co0, int ci0,
+                                          int Cout, int Cin, T (*tile)[PACK_PITCH(T)]) {
+    const int x = threadIdx.x & 63, y = threadIdx.x >> 6;
+#pragma unroll 4
+    for (int k = 0; k < 16; ++k) {
+        const int col = k * 4 + y, co = co0 + col, ci = ci0 + x;
+        if (co < Cout && ci < Cin) {
+            const T v = from_f<T>(src(co, ci));
+            if (f_dst) f_dst[(int64_t)co * ld_f + ci] = v;
+            tile[col][x] = v;
+        }
+    }
+    __syncthreads();
+    if (d_dst) {
+#pragma unroll 4
+        for (int k = 0; k < 16; ++k) {
+            const int row = k * 4 + y, ci = ci0 + row, co = co0 + x;
+            if (co < Cout && ci < Cin) d_dst[(int64_t)ci * ld_d + co] = tile[x][row];
+        }
+    }
+    __syncthreads();
+}
+

@@ -94,47 +94,56 @@ extern "C" int64_t fmri_conv3d_wgrad_workspace_bytes(int C0, int C1, int Cout, i
 namespace {
 __device__ __forceinline__ int tap_class(int p, int k) { return p == 0 ? (k >= 1) : (k >= 2); }   // 3-tap index -> combined tap t'
 
+// One 64 (Cout) x 64 (Cin) tile per workgroup: blocks [0, n_up) cover (class, Cout tile, C0 tile) of the pre-summed parity filters, the rest
+// (tap, Cout tile, C1 tile) of the skip filters; both images of a tile (row-major forward, transposed input-gradient) are written coalesced
+// (pack_tile, common.h).  The pre-sums run over (kd, kh, kw) in ascending order in fp32, then one rounding.
 template <typename T>
-__global__ void k_pack_up_weights(const float* __restrict__ w, int C0, int C1, int Cout, int planar, T* __restrict__ up_f, T* __restrict__ up_d,
-                                  T* __restrict__ sk_f, T* __restrict__ sk_d) {
+__global__ void __launch_bounds__(256) k_pack_up_weights(const float* __restrict__ w, int C0, int C1, int Cout, int planar, T* __restrict__ up_f,
+                                                         T* __restrict__ up_d, T* __restrict__ sk_f, T* __restrict__ sk_d) {
+    __shared__ T tile[64][PACK_PITCH(T)];
     const int Cin = C0 + C1;
-    const int64_t n_up = (int64_t)(planar ? 16 : 64) * Cout * C0, n_sk = (int64_t)27 * Cout * C1;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_up + n_sk; i += (int64_t)gridDim.x * blockDim.x) {
-        if (i < n_up) {
-            const int c0 = (int)(i % C0);
-            int64_t q = i / C0;
-            const int co = (int)(q % Cout);
-            q /= Cout;
-            float acc = 0.f;
-            if (planar) {                        // 2-D slices: parity (ph, pw), combined taps (kh', kw'), centre kd plane only
-                const int tw = (int)(q & 1), th = (int)((q >> 1) & 1), p = (int)(q >> 2);
-                const int ph = p >> 1, pw = p & 1;
+    const int tco = (Cout + 63) >> 6, tc0 = (C0 + 63) >> 6, tc1 = (C1 + 63) >> 6;
+    const int ncls = planar ? 16 : 64;
+    const int n_up = ncls * tco * tc0;
+    int b = blockIdx.x;
+    if (b < n_up) {
+        const int ci0 = (b % tc0) << 6; b /= tc0;
+        const int co0 = (b % tco) << 6;
+        const int q = b / tco;                                     // class = (parity, combined tap)
+        int mirrored;
+        if (planar) {                                              // 2-D slices: parity (ph, pw), combined taps (kh', kw'), centre kd plane only
+            const int tw = q & 1, th = (q >> 1) & 1, p = q >> 2, ph = p >> 1, pw = p & 1;
+            mirrored = (p * 2 + (1 - th)) * 2 + (1 - tw);
+            pack_tile<T>([&](int co, int c0) {
+                float acc = 0.f;
                 for (int kh = 0; kh < 3; ++kh)
                     for (int kw = 0; kw < 3; ++kw)
                         if (tap_class(ph, kh) == th && tap_class(pw, kw) == tw) acc += w[((int64_t)(9 + kh * 3 + kw) * Cout + co) * Cin + c0];
-                if (up_f) up_f[i] = from_f<T>(acc);
-                if (up_d) up_d[(((int64_t)p * 2 + (1 - th)) * 2 + (1 - tw)) * C0 * Cout + (int64_t)c0 * Cout + co] = from_f<T>(acc);
-                continue;
-            }
-            const int tw = (int)(q & 1), th = (int)((q >> 1) & 1), td = (int)((q >> 2) & 1), p = (int)(q >> 3);
-            const int pd = p >> 2, ph = (p >> 1) & 1, pw = p & 1;
+                return acc;
+            }, up_f ? up_f + (int64_t)q * Cout * C0 : nullptr, C0, up_d ? up_d + (int64_t)mirrored * C0 * Cout : nullptr, Cout, co0, ci0, Cout, C0, tile);
+            return;
+        }
+        const int tw = q & 1, th = (q >> 1) & 1, td = (q >> 2) & 1, p = q >> 3;
+        const int pd = p >> 2, ph = (p >> 1) & 1, pw = p & 1;
+        mirrored = ((p * 2 + (1 - td)) * 2 + (1 - th)) * 2 + (1 - tw);
+        pack_tile<T>([&](int co, int c0) {
+            float acc = 0.f;
             for (int kd = 0; kd < 3; ++kd)
                 for (int kh = 0; kh < 3; ++kh)
                     for (int kw = 0; kw < 3; ++kw)
                         if (tap_class(pd, kd) == td && tap_class(ph, kh) == th && tap_class(pw, kw) == tw)
                             acc += w[((int64_t)((kd * 3 + kh) * 3 + kw) * Cout + co) * Cin + c0];
-            if (up_f) up_f[i] = from_f<T>(acc);
-            if (up_d) up_d[((((int64_t)p * 2 + (1 - td)) * 2 + (1 - th)) * 2 + (1 - tw)) * C0 * Cout + (int64_t)c0 * Cout + co] = from_f<T>(acc);
-        } else {
-            const int64_t r = i - n_up;
-            const int c1 = (int)(r % C1);
-            const int64_t q = r / C1;
-            const int co = (int)(q % Cout), t = (int)(q / Cout);
-            const float v = w[((int64_t)t * Cout + co) * Cin + C0 + c1];
-            if (sk_f) sk_f[r] = from_f<T>(v);
-            if (sk_d) sk_d[((int64_t)(26 - t) * C1 + c1) * Cout + co] = from_f<T>(v);
-        }
+            return acc;
+        }, up_f ? up_f + (int64_t)q * Cout * C0 : nullptr, C0, up_d ? up_d + (int64_t)mirrored * C0 * Cout : nullptr, Cout, co0, ci0, Cout, C0, tile);
+        return;
     }
+    b -= n_up;
+    const int ci0 = (b % tc1) << 6; b /= tc1;
+    const int co0 = (b % tco) << 6;
+    const int t = b / tco;
+    const float* const wt = w + (int64_t)t * Cout * Cin + C0;
+    pack_tile<T>([&](int co, int c1) { return wt[(int64_t)co * Cin + c1]; }, sk_f ? sk_f + (int64_t)t * Cout * C1 : nullptr, C1,
+                 sk_d ? sk_d + (int64_t)(26 - t) * C1 * Cout : nullptr, Cout, co0, ci0, Cout, C1, tile);
 }
 
 // D,H,W = output (full-resolution) dims; planar: D = number of slices (not up-sampled).  bit 0: forward + input gradients, bit 1: weight gradient
@@ -153,7 +162,8 @@ int upcat_ok(int C0, int C1, int Cout, int D, int H, int W, int dtype, int plana
 int upcat_pack(const float* w, int C0, int C1, int Cout, void* w_up_fwd, void* w_up_dgrad, void* w_skip_fwd, void* w_skip_dgrad, int dtype,
                int planar, fmri_stream_t stream) {
     if (!w || C0 <= 0 || C1 < 0 || Cout <= 0) return FMRI_E_SHAPE;
-    const int grid = grid_for((int64_t)(planar ? 16 : 64) * Cout * C0 + (int64_t)27 * Cout * C1, 256, 1024);
+    const int tco = (Cout + 63) / 64;
+    const int grid = (planar ? 16 : 64) * tco * ((C0 + 63) / 64) + 27 * tco * ((C1 + 63) / 64);
     if (dtype == FMRI_BF16)
         k_pack_up_weights<bf16_t><<<grid, 256, 0, as_stream(stream)>>>(w, C0, C1, Cout, planar, (bf16_t*)w_up_fwd, (bf16_t*)w_up_dgrad,
                                                                         (bf16_t*)w_skip_fwd, (bf16_t*)w_skip_dgrad);

@@ -633,24 +633,21 @@ extern "C" int fmri_adam_step(float* p, const float* g, float* m, float* v, int6
 // ------------------------------------------------------------------------------------------------ weight packing
 // fp32 master [27][Cout][Cin] -> compute-dtype copies: forward layout and the tap-flipped transposed dgrad layout.
 template <typename T>
-__global__ void k_pack_weights(const float* __restrict__ w, T* __restrict__ wf, T* __restrict__ wd, int Cout, int Cin) {
-    const int64_t total = (int64_t)27 * Cout * Cin;
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        float val = w[i];
-        if (wf) wf[i] = from_f<T>(val);
-        if (wd) {
-            int ci = (int)(i % Cin);
-            int64_t r = i / Cin;
-            int co = (int)(r % Cout);
-            int tap = (int)(r / Cout);
-            wd[((int64_t)(26 - tap) * Cin + ci) * Cout + co] = from_f<T>(val);
-        }
-    }
+__global__ void __launch_bounds__(256) k_pack_weights(const float* __restrict__ w, T* __restrict__ wf, T* __restrict__ wd, int Cout, int Cin) {
+    __shared__ T tile[64][PACK_PITCH(T)];
+    const int tci = (Cin + 63) >> 6, tco = (Cout + 63) >> 6;
+    int b = blockIdx.x;
+    const int ci0 = (b % tci) << 6; b /= tci;
+    const int co0 = (b % tco) << 6;
+    const int tap = b / tco;
+    const float* const wt = w + (int64_t)tap * Cout * Cin;
+    pack_tile<T>([&](int co, int ci) { return wt[(int64_t)co * Cin + ci]; }, wf ? wf + (int64_t)tap * Cout * Cin : nullptr, Cin,
+                 wd ? wd + (int64_t)(26 - tap) * Cin * Cout : nullptr, Cout, co0, ci0, Cout, Cin, tile);
 }
 extern "C" int fmri_conv3d_pack_weights(const float* w, void* w_fwd, void* w_dgrad, int Cout, int Cin, int dtype,
                                         fmri_stream_t stream) {
     if (Cout <= 0 || Cin <= 0) return FMRI_E_SHAPE;
-    int grid = grid_for((int64_t)27 * Cout * Cin, 256, 1024);
+    const int grid = 27 * ((Cout + 63) / 64) * ((Cin + 63) / 64);
     if (dtype == FMRI_F32) k_pack_weights<float><<<grid, 256, 0, as_stream(stream)>>>(w, (float*)w_fwd, (float*)w_dgrad, Cout, Cin);
     else if (dtype == FMRI_BF16) k_pack_weights<bf16_t><<<grid, 256, 0, as_stream(stream)>>>(w, (bf16_t*)w_fwd, (bf16_t*)w_dgrad, Cout, Cin);
     else return FMRI_E_DTYPE;

@@ -9,6 +9,8 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
+from gpu_util import bar          # noqa: E402  (limit = <= 2x the error measured on MI355X; FMRI_MEASURE=1 records instead of asserting)
+
 
 def _setup(spatial, depth, base, N, dtype, seed=42):
     from fmri_hip.engine import UNetEngine, UNetPlan
@@ -109,9 +111,9 @@ def test_depth4_base32_bf16_small_patch():
     eng.backward(yd)
     torch.cuda.synchronize()
     logits = eng.logits.cpu().numpy().reshape(ref["logits"].shape)
-    assert _rel(logits, ref["logits"]) <= 3e-2      # bf16 storage of 14 stacked conv outputs
+    bar("d4b32_small.logits_rel", _rel(logits, ref["logits"]), 1.7e-2)      # measured 8.5e-3;      # bf16 storage of 14 stacked conv outputs
     m = eng.metrics_from_sums(sums.cpu().numpy())
-    assert abs(m["dice_coefficient"] - ref["dice"]) <= 2e-3
+    bar("d4b32_small.dice_abs", abs(m["dice_coefficient"] - ref["dice"]), 1e-5)      # measured 4.2e-6
     worst = 0.0
     for name, L in eng.layout.items():
         gk = ref["grads"][name + "/kernel"]
@@ -121,8 +123,7 @@ def test_depth4_base32_bf16_small_patch():
             mine = eng.w_view(name, eng.G).cpu().numpy().T.reshape(gk.shape)
         e = np.linalg.norm(mine.astype(np.float64) - gk) / (np.linalg.norm(gk) + 1e-30)
         worst = max(worst, e)
-        assert e <= 6e-2, (name, e)
-    print("bf16 worst relative L2 gradient error", worst)
+    bar("d4b32_small.grad_l2_rel", worst, 4.8e-2)                                     # measured 2.4e-2
 
 
 def test_bf16_matches_fp32_engine_on_gpu():
@@ -136,7 +137,7 @@ def test_bf16_matches_fp32_engine_on_gpu():
     e32.forward(x32)
     e16.forward(x16)
     torch.cuda.synchronize()
-    assert _rel(e16.logits.cpu().numpy(), e32.logits.cpu().numpy()) <= 3e-2
+    bar("bf16_vs_fp32_engine.logits_rel", _rel(e16.logits.cpu().numpy(), e32.logits.cpu().numpy()), 1.3e-2)      # measured 6.2e-3
 
 
 def test_training_loss_decreases_bf16():
@@ -154,7 +155,7 @@ def test_unet2d_fp32_and_bf16_vs_oracle():
     from fmri_hip.engine import UNetEngine, UNetPlan
     from oracle import unet_oracle as O
     N, X, Y, C = 4, 32, 64, 5
-    for dtype, base, tol_l, tol_d, tol_g in ((torch.float32, 8, 1e-3, 1e-4, 2e-3), (torch.bfloat16, 32, 3e-2, 2e-3, 1e-1)):   # bf16: first-layer gradient passes through 13 bf16-stored tensors
+    for dtype, base, tol_l, tol_d, tol_g in ((torch.float32, 8, 1e-5, 1e-7, 1e-5), (torch.bfloat16, 32, 2.2e-2, 2.2e-5, 1e-1)):   # bf16: first-layer gradient passes through 13 bf16-stored tensors
         spec = O.Spec((X, Y, C), ndim=2, depth=3, n_base_filters=base)
         W = spec.init_weights(11)
         rs = np.random.RandomState(3)
@@ -170,8 +171,9 @@ def test_unet2d_fp32_and_bf16_vs_oracle():
         eng.backward(yd)
         torch.cuda.synchronize()
         logits = eng.logits.cpu().numpy().reshape(ref["logits"].shape)
-        assert _rel(logits, ref["logits"]) <= tol_l, dtype
-        assert abs(eng.metrics_from_sums(sums.cpu().numpy())["dice_coefficient"] - ref["dice"]) <= tol_d
+        tag = "unet2d.%s." % ("f32" if dtype == torch.float32 else "bf16")
+        bar(tag + "logits_rel", _rel(logits, ref["logits"]), tol_l)
+        bar(tag + "dice_abs", abs(eng.metrics_from_sums(sums.cpu().numpy())["dice_coefficient"] - ref["dice"]), tol_d)
         Wg = {}
         for name, L in eng.layout.items():
             gk = ref["grads"][name + "/kernel"]
@@ -182,7 +184,7 @@ def test_unet2d_fp32_and_bf16_vs_oracle():
             else:
                 mine = eng.w_view(name, eng.G).cpu().numpy().T.reshape(gk.shape)
             e = np.linalg.norm(mine.astype(np.float64) - gk) / (np.linalg.norm(gk) + 1e-30)
-            assert e <= tol_g, (str(dtype), name, e)
+            bar(tag + "grad_l2_rel", e, tol_g)
         Wx = eng.export_keras_weights()
         for k in W:
             assert Wx[k].shape == W[k].shape
@@ -212,7 +214,7 @@ def test_unet2d_parity_form_equals_9_tap_kernels(monkeypatch, slices):
         eng.backward(y)
         torch.cuda.synchronize()
         out.append((eng.logits.float().cpu().numpy().copy(), eng.G.cpu().numpy().copy()))
-    assert _rel(out[0][0], out[1][0]) <= (2e-2 if slices % 4 == 0 else 0.0)
+    bar("unet2d_parity_vs_9tap.logits_rel_s%d" % slices, _rel(out[0][0], out[1][0]), (8.2e-3 if slices % 4 == 0 else 0.0))      # measured 4.1e-3
     for name, L in a.layout.items():
         o, n = L["w"]
         ga, gb = out[0][1][o:o + n], out[1][1][o:o + n]
@@ -425,8 +427,9 @@ def test_isensee_bf16_padded_engine(monkeypatch):
     lb, db, gb, eb = res["pad"]
     ln, dn, gn, _ = res["nopad"]
     rng = np.abs(lf).max()
-    assert np.abs(lb - lf).max() <= 3e-2 * rng and np.abs(lb - ln).max() <= 3e-2 * rng
-    assert abs(db - df) <= 2e-3 and abs(db - dn) <= 2e-3
+    bar("isensee_bf16.logits_rel_vs_f32", np.abs(lb - lf).max() / rng, 3e-2)
+    bar("isensee_bf16.logits_rel_pad_vs_nopad", np.abs(lb - ln).max() / rng, 1.9e-2)      # measured 9.2e-3
+    bar("isensee_bf16.dice_abs", max(abs(db - df), abs(db - dn)), 4e-5)                  # measured 1.8e-5
     normed = {op["name"] for op in ef.ops if op["kind"] == "conv" and any(o2["kind"] == "norm" and o2["ins"][0] == op["out"] for o2 in ef.ops)}
     for name, L in ef.layout.items():
         keys = ("w", "b") if L["kind"] == "conv" else ("gamma", "beta")
@@ -435,8 +438,8 @@ def test_isensee_bf16_padded_engine(monkeypatch):
                 continue          # the bias of a conv that feeds a normalisation has an exactly zero gradient: only rounding noise to compare
             o, n = L[key]
             ref = np.linalg.norm(gf[o:o + n]) + 1e-30
-            assert np.linalg.norm(gb[o:o + n] - gf[o:o + n]) / ref <= 0.35, (name, key, "padded bf16 vs fp32")
-            assert np.linalg.norm(gb[o:o + n] - gn[o:o + n]) / ref <= 0.35, (name, key, "padded vs exact-size bf16")
+            bar("isensee_bf16.grad_l2_rel_vs_f32", np.linalg.norm(gb[o:o + n] - gf[o:o + n]) / ref, 0.35)
+            bar("isensee_bf16.grad_l2_rel_pad_vs_nopad", np.linalg.norm(gb[o:o + n] - gn[o:o + n]) / ref, 0.27)      # measured 0.13
     # the padding never leaks: channels beyond the logical count are exactly zero in every activation
     for name, t in eb.T.items():
         c = eb.clog[name]
@@ -471,12 +474,12 @@ def test_deconvolution_variant_bf16_mfma_path_vs_fp32():
         res[dt_] = (eng.logits.cpu().numpy().copy(), eng.G.cpu().numpy().copy(), eng)
     lf, gf, ef = res[torch.float32]
     lb, gb, _ = res[torch.bfloat16]
-    assert np.abs(lb - lf).max() <= 3e-2 * np.abs(lf).max()
+    bar("deconv3d_bf16.logits_rel", np.abs(lb - lf).max() / np.abs(lf).max(), 1.1e-2)      # measured 5.3e-3
     for name, L in ef.layout.items():
         for key in ("w", "b"):
             o, n = L[key]
             e = np.linalg.norm(gb[o:o + n] - gf[o:o + n]) / (np.linalg.norm(gf[o:o + n]) + 1e-30)
-            assert e <= 6e-2, (name, key, e)
+            bar("deconv3d_bf16.grad_l2_rel", e, 4.2e-2)                                          # measured 2.1e-2
 
 
 def test_2d_deconvolution_variant_bf16_mfma_path_vs_fp32():
@@ -498,7 +501,7 @@ def test_2d_deconvolution_variant_bf16_mfma_path_vs_fp32():
         res[dt_] = (eng.logits.cpu().numpy().copy(), eng.G.cpu().numpy().copy(), eng)
     lf, gf, ef = res[torch.float32]
     lb, gb, _ = res[torch.bfloat16]
-    assert np.abs(lb - lf).max() <= 3e-2 * np.abs(lf).max()
+    bar("deconv2d_bf16.logits_rel", np.abs(lb - lf).max() / np.abs(lf).max(), 1.7e-2)      # measured 8.1e-3
     for name, L in ef.layout.items():
         for key in ("w", "b"):
             o, n = L[key]
@@ -506,4 +509,4 @@ def test_2d_deconvolution_variant_bf16_mfma_path_vs_fp32():
             if ref < 1e-12:
                 continue                      # the unused half (ad = 1 taps) of the transposed-conv filter in planar mode
             e = np.linalg.norm(gb[o:o + n] - gf[o:o + n]) / ref
-            assert e <= 6e-2, (name, key, e)
+            bar("deconv2d_bf16.grad_l2_rel", e, 8e-2)                                            # measured 5.1e-2

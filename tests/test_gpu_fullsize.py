@@ -7,6 +7,8 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
+from gpu_util import bar          # noqa: E402
+
 
 def _rel(a, b):
     a, b = a.double(), b.double()
@@ -27,9 +29,9 @@ def test_full_size_bf16_vs_fp32_paths_and_dice():
     s16 = e16.loss_forward(y).cpu().numpy().copy()
     s32 = e32.loss_forward(y).cpu().numpy().copy()
     torch.cuda.synchronize()
-    assert _rel(e16.logits, e32.logits) <= 3e-2
+    bar("fullsize_fwd_n1.logits_rel_bf16_vs_f32", _rel(e16.logits, e32.logits), 1.25e-2)      # measured 6.1e-3
     d16, d32 = e16.metrics_from_sums(s16), e32.metrics_from_sums(s32)
-    assert abs(d16["dice_coefficient"] - d32["dice_coefficient"]) <= 2e-3
+    bar("fullsize_fwd_n1.dice_abs", abs(d16["dice_coefficient"] - d32["dice_coefficient"]), 5e-6)      # measured 2.3e-6
     assert s16[7] == s32[7] == np.prod(spatial)                      # every voxel counted once
     assert s16[1] == s32[1] == float(y.sum().item())                 # sum(y) is exact in both
     # forward is deterministic (no atomics on the forward path)
@@ -55,7 +57,8 @@ def test_full_size_conv_linearity_and_wgrad_paths():
                    act=0, impl=IMPL_MFMA)
     torch.cuda.synchronize()
     # small dyadic inputs: every product and partial sum is exact in fp32, sums stay below the bf16 exact-integer range / 32
-    assert _rel(ys.float(), ya.float() + yb.float()) <= 1e-2
+    # (the sums are exact in fp32; what remains is bf16(a + b) against bf16(a) + bf16(b): one rounding step of the larger magnitudes)
+    bar("fullsize_linearity.rel", _rel(ys.float(), ya.float() + yb.float()), 7.8e-3)      # measured 3.8e-3 (= 2^-8: one bf16 rounding step)
     # weight gradient: MFMA path == generic fp32-FMA path on the same bf16 data (a 16-plane slab keeps the generic kernel short)
     Dsl = 16
     dy = (torch.randint(-4, 5, (N, Dsl, H, W, Cout), generator=g).float() / 4).to(torch.bfloat16).cuda()
@@ -91,7 +94,7 @@ def test_full_size_parity_form_equals_27_tap_kernels():
     ops.conv3d_fwd(x_low, x_skip, wf, bias, y27, up0=True, act=1)
     ops.conv3d_upcat_fwd(x_low, x_skip, up_f, sk_f, bias, yp, act=1)
     torch.cuda.synchronize()
-    assert _rel(yp.float(), y27.float()) <= 1e-2
+    bar("fullsize_parity_vs_27tap.fwd_rel", _rel(yp.float(), y27.float()), 1e-2)
     dy = (torch.randint(-4, 5, (N, D, H, W, Cout), generator=g).float() / 4).to(bf).cuda()
     cat = torch.empty((N, D, H, W, C0 + C1), dtype=bf, device="cuda")
     dl27, dlp, dsp = torch.empty_like(x_low), torch.empty_like(x_low), torch.empty_like(x_skip)
@@ -100,8 +103,8 @@ def test_full_size_parity_form_equals_27_tap_kernels():
     ops.conv3d_upcat_dgrad(dy, up_d, sk_d, x_low, None, dlp, dsp)
     torch.cuda.synchronize()
     # the 27-tap path rounds the full-resolution gradient to bf16 before the 2x2x2 reduction, the parity form does not
-    assert _rel(dlp.float(), dl27.float()) <= 2e-2
-    assert _rel(dsp.float(), cat[..., C0:].float()) <= 1e-2
+    bar("fullsize_parity_vs_27tap.dlow_rel", _rel(dlp.float(), dl27.float()), 1.4e-2)      # measured 7.1e-3
+    bar("fullsize_parity_vs_27tap.dskip_rel", _rel(dsp.float(), cat[..., C0:].float()), 0.0)      # same taps, same order: identical
     Dsl = 16
     dys, xls, xss = dy[:, :Dsl].contiguous(), x_low[:, :Dsl // 2].contiguous(), x_skip[:, :Dsl].contiguous()
     dw27, dwp = torch.zeros((27, Cout, C0 + C1), device="cuda"), torch.zeros((27, Cout, C0 + C1), device="cuda")

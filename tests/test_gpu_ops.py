@@ -1,8 +1,11 @@
 """GPU parity of each C-ABI kernel against torch-CPU fp64 restatements (checker).  Run with -m gpu on an MI355X.
 
-Tolerances: fp32 mode 1e-5 relative (plain fmaf chains, only summation order differs); bf16 mode: inputs are rounded to
-bf16 first and the checker uses those rounded inputs in fp64, so the remaining error is the bf16 rounding of the stored
-output (2^-9 relative) plus fp32 accumulation order -> 1e-2.
+Tolerances (each <= 2-5x the error measured on MI355X with FMRI_MEASURE=1, profiles/r02_tolerance_use.json): |got - ref| <=
+atol * max|ref| + rtol * |ref|.  fp32 mode: plain fmaf chains, only the summation order differs (measured ~3e-7) -> 2e-6.  bf16 mode:
+the inputs are bf16 and the checker uses them in fp64, so what remains is ONE rounding of the stored output - bf16 keeps 8 significant
+bits, i.e. up to 2^-8 = 3.9e-3 relative - plus the fp32 accumulation order (~2e-5 of the largest output): rtol 5e-3, atol 1e-4.  One
+dropped (tap, channel) product at Cin = 32 is ~3 % of an output's sigma: 100x outside these bars.  Weight gradients are fp32 sums of
+exact bf16 products (measured 4e-7) -> 2e-6.
 """
 import numpy as np
 import pytest
@@ -14,7 +17,9 @@ from gpu_util import (assert_close, f64, keras_kernel_from_packed, planar_kernel
 
 pytestmark = pytest.mark.gpu
 
-TOL = {torch.float32: (1e-5, 1e-5), torch.bfloat16: (1e-2, 1e-2)}
+TOL = {torch.float32: (2e-6, 2e-6), torch.bfloat16: (5e-3, 1e-4)}
+WG_TOL = {torch.float32: (1e-5, 2e-6), torch.bfloat16: (2e-6, 2e-6)}      # weight / bias gradients (fp32 outputs)
+PARITY_TOL = (6e-3, 6e-3)      # parity form: the up-sampled channels' partial sum is stored as bf16 once more (2^-8 of a partial that may exceed the result)
 
 
 @pytest.fixture(scope="module")
@@ -109,13 +114,13 @@ def test_conv3d_wgrad(ops, case):
             outs.append(dw2)
         torch.cuda.synchronize()
         assert torch.equal(outs[0], outs[1])
-        assert_close(outs[0], dw, 1e-5, 1e-5, what=name + " slab vs atomic")
+        assert_close(outs[0], dw, 1e-6, 1e-6, what=name + " slab vs atomic")
     x = ref_concat_input(f64(src0), None if src1 is None else f64(src1), up0)
     wk = torch.zeros((Cout, C0 + C1, 3, 3, 3), dtype=torch.float64, requires_grad=True)
     out = F.conv3d(x, wk, None, padding=1)
     out.backward(to_ncdhw(f64(dy)))
     ref = wk.grad.permute(2, 3, 4, 0, 1).reshape(27, Cout, C0 + C1)
-    rt = (1e-4, 1e-5) if dtype == torch.float32 else (2e-3, 2e-3)
+    rt = WG_TOL[dtype]
     assert_close(dw, ref, *rt, what=name + " dw")
     assert_close(db, f64(dy).sum(dim=(0, 1, 2, 3)), *rt, what=name + " db")
 
@@ -160,7 +165,7 @@ def test_maxpool_fwd_bwd(ops, dtype, C):
     torch.cuda.synchronize()
     yr.backward(to_ncdhw(f64(dy)))
     ref = (to_ndhwc(xr.grad) + f64(add)[..., 8:]) * (f64(x) > 0)
-    assert_close(dx, ref, 1e-6 if dtype == torch.float32 else 1e-2, 1e-6 if dtype == torch.float32 else 4e-3, what="maxpool_bwd")
+    assert_close(dx, ref, 1e-6 if dtype == torch.float32 else 5e-3, 1e-6 if dtype == torch.float32 else 1e-3, what="maxpool_bwd")
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
@@ -315,7 +320,7 @@ def test_planar_conv_fwd_dgrad_wgrad(ops, case):
         wk = torch.zeros((Cout, C0 + C1, 3, 3, 3), dtype=torch.float64, requires_grad=True)
         F.conv3d(x, wk, None, padding=1).backward(to_ncdhw(f64(dy)))
         refg = planar_kernel(wk.grad).permute(2, 3, 4, 0, 1).reshape(27, Cout, C0 + C1)
-        rt = (1e-4, 1e-5) if dtype == torch.float32 else (2e-3, 2e-3)
+        rt = WG_TOL[dtype]
         assert_close(dw, refg, *rt, what=name + " dw")
         assert_close(db, f64(dy).sum(dim=(0, 1, 2, 3)), *rt, what=name + " db")
     # input gradient through the packed transposed copy
@@ -348,7 +353,7 @@ def test_planar_pool_and_upsample(ops, dtype):
     torch.cuda.synchronize()
     yr.backward(f64(dy)[0].permute(0, 3, 1, 2))
     ref = xr.grad.permute(0, 2, 3, 1) * (f64(x)[0] > 0)
-    assert_close(dx[0], ref, 1e-6 if dtype == torch.float32 else 1e-2, 1e-6 if dtype == torch.float32 else 4e-3, what="planar maxpool bwd")
+    assert_close(dx[0], ref, 1e-6 if dtype == torch.float32 else 5e-3, 1e-6 if dtype == torch.float32 else 1e-3, what="planar maxpool bwd")
     g = rnd((1, S, H, W, C), 22, dtype)
     lo = torch.empty((1, S, H // 2, W // 2, C), dtype=dtype, device="cuda")
     ops.upsample_bwd(g, lo, planar=True)
@@ -381,7 +386,7 @@ def test_norm_act_fwd_bwd(ops, dtype, mode, act):
     z = O._instancenorm(xr, gr, br) if per else O._batchnorm_train(xr, gr, br)
     yr = F.relu(z) if act == 1 else F.leaky_relu(z, alpha)
     torch.cuda.synchronize()
-    tol = (1e-4, 1e-5) if dtype == torch.float32 else (1e-2, 1e-2)
+    tol = (1e-4, 1e-5) if dtype == torch.float32 else (5e-3, 2e-4)
     assert_close(y, to_ndhwc(yr.detach()), *tol, what="norm fwd")
     dy = rnd((N, D, H, W, C), 83, dtype)
     # the backward reads the STORED y (bf16-rounded in bf16 mode) for act': mirror that in the checker
@@ -391,7 +396,7 @@ def test_norm_act_fwd_bwd(ops, dtype, mode, act):
     ops.norm_act_bwd(x, y, dy, gamma, stats, dx, dg, db, ws, per, act=act, alpha=alpha)
     torch.cuda.synchronize()
     yr.backward(to_ncdhw(f64(dy)))
-    tolb = (2e-4, 2e-5) if dtype == torch.float32 else (2e-2, 2e-2)
+    tolb = (2e-4, 2e-5) if dtype == torch.float32 else (6e-3, 2e-3)
     assert_close(dx, to_ndhwc(xr.grad), *tolb, what="norm dx")
     assert_close(dg, gr.grad, *tolb, what="norm dgamma")
     assert_close(db, br.grad, *tolb, what="norm dbeta")
@@ -427,10 +432,11 @@ def test_deconv_k2s2_fwd_bwd(ops, dtype, planar):
     ops.deconv_bwd(x, w, dyfull, dx, dw, dbg, dy_off=4, xmask=x, planar=planar)
     torch.cuda.synchronize()
     yr.backward(to_ncdhw(f64(dyfull)[..., 4:]))
-    tolb = (1e-4, 1e-5) if dtype == torch.float32 else (1e-2, 1e-2)
+    tolb = (1e-4, 1e-5) if dtype == torch.float32 else (5e-3, 1e-4)
+    tolw = (1e-4, 1e-5) if dtype == torch.float32 else (2e-5, 2e-5)
     assert_close(dx, to_ndhwc(xr.grad) * (f64(x) > 0), *tolb, what="deconv dx")
-    assert_close(dw[:nt], wr.grad[:nt], *tolb, what="deconv dw")
-    assert_close(dbg, br.grad, *tolb, what="deconv db")
+    assert_close(dw[:nt], wr.grad[:nt], *tolw, what="deconv dw")
+    assert_close(dbg, br.grad, *tolw, what="deconv db")
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
@@ -462,10 +468,11 @@ def test_conv_direct_fwd_bwd(ops, dtype, k, s, dims):
     ops.conv_direct_bwd(x, w, dy, dx, dw, db, k, s)
     torch.cuda.synchronize()
     yr.backward(to_ncdhw(f64(dy)))
-    tolb = (1e-4, 1e-5) if dtype == torch.float32 else (1e-2, 1e-2)
+    tolb = (1e-4, 1e-5) if dtype == torch.float32 else (5e-3, 1e-4)
+    tolw = (1e-4, 1e-5) if dtype == torch.float32 else (2e-5, 2e-5)
     assert_close(dx, to_ndhwc(xr.grad), *tolb, what="direct dx")
-    assert_close(dw, wr.grad, *tolb, what="direct dw")
-    assert_close(db, br.grad, *tolb, what="direct db")
+    assert_close(dw, wr.grad, *tolw, what="direct dw")
+    assert_close(db, br.grad, *tolw, what="direct db")
 
 
 def test_add_and_channel_scale(ops):
@@ -527,7 +534,7 @@ UPCAT_CASES = [
 def test_upcat_fwd_and_dgrad(ops, case):
     """fmri_conv3d_upcat_fwd / _dgrad (8 parity classes x 8 pre-summed taps on the low-res tensor) against the plain definition
     conv3x3x3(concat(nearest_up2(x_low), x_skip)) and its autograd gradients in fp64.  Inputs and master weights are bf16-exact;
-    the parity form rounds the pre-summed weights and the up-sampled channels' partial sum to bf16 once more, hence 1.5e-2."""
+    the parity form rounds the pre-summed weights and the up-sampled channels' partial sum to bf16 once more, hence PARITY_TOL."""
     name, N, D, H, W, C0, C1, Cout = case
     dtype = torch.bfloat16
     assert ops.conv3d_upcat_ok(C0, C1, Cout, D, H, W, dtype) & 1
@@ -549,12 +556,12 @@ def test_upcat_fwd_and_dgrad(ops, case):
     inp = ref_concat_input(xl, xs, True)
     pre = F.conv3d(inp, keras_kernel_from_packed(f64(w)), f64(bias), padding=1)
     ref = to_ndhwc(F.relu(pre))
-    assert_close(y, ref, 1.5e-2, 1.5e-2, what=name + " fwd")
+    assert_close(y, ref, *PARITY_TOL, what=name + " fwd")
     # the existing fused-upsample kernel computes the same thing with 27 taps: the two device paths agree as well
     wf = w.to(dtype)
     y2 = torch.empty_like(y)
     ops.conv3d_fwd(x_low, x_skip, wf, bias, y2, up0=True, act=1)
-    assert_close(y, f64(y2), 1.5e-2, 1.5e-2, what=name + " fwd vs 27-tap kernel")
+    assert_close(y, f64(y2), *PARITY_TOL, what=name + " fwd vs 27-tap kernel")
     # gradients w.r.t. both inputs for a random dy, with the producers' ReLU masks
     dy = rnd((N, D, H, W, Cout), 5, dtype)
     m_low = rnd((N, D // 2, H // 2, W // 2, C0), 6, dtype).clamp_min(0)
@@ -564,8 +571,8 @@ def test_upcat_fwd_and_dgrad(ops, case):
     ops.conv3d_upcat_dgrad(dy, up_d, sk_d, m_low, m_skip, dx_low, dx_skip)
     torch.cuda.synchronize()
     pre.backward(to_ncdhw(f64(dy)))
-    assert_close(dx_low, xl.grad * (f64(m_low) > 0), 1.5e-2, 1.5e-2, what=name + " dx_low")
-    assert_close(dx_skip, xs.grad * (f64(m_skip) > 0), 1e-2, 1e-2, what=name + " dx_skip")
+    assert_close(dx_low, xl.grad * (f64(m_low) > 0), *PARITY_TOL, what=name + " dx_low")
+    assert_close(dx_skip, xs.grad * (f64(m_skip) > 0), *TOL[torch.bfloat16], what=name + " dx_skip")
     # weight / bias gradient: parity form vs autograd of the plain definition (fp32 accumulation of bf16 products: 2e-3)
     if ops.conv3d_upcat_ok(C0, C1, Cout, D, H, W, dtype) & 2:
         dw = torch.zeros((27, Cout, C0 + C1), device="cuda")
@@ -577,8 +584,8 @@ def test_upcat_fwd_and_dgrad(ops, case):
         pre2 = F.conv3d(ref_concat_input(f64(x_low), f64(x_skip), True), kern, f64(bias), padding=1)
         pre2.backward(to_ncdhw(f64(dy)))
         ref_dw = kern.grad.permute(2, 3, 4, 0, 1).reshape(27, Cout, C0 + C1)
-        assert_close(dw, ref_dw, 2e-3, 2e-3, what=name + " dw")
-        assert_close(db, f64(dy).sum(dim=(0, 1, 2, 3)), 2e-3, 2e-3, what=name + " db")
+        assert_close(dw, ref_dw, 4e-6, 4e-6, what=name + " dw")
+        assert_close(db, f64(dy).sum(dim=(0, 1, 2, 3)), 4e-6, 4e-6, what=name + " db")
 
 
 def test_upcat_without_skip_channels(ops):
@@ -600,7 +607,7 @@ def test_upcat_without_skip_channels(ops):
     kern = keras_kernel_from_packed(f64(w)).requires_grad_(True)
     b64 = f64(bias).requires_grad_(True)
     pre = F.conv3d(ref_concat_input(xl, None, True), kern, b64, padding=1)
-    assert_close(y, to_ndhwc(F.leaky_relu(pre, 0.3)), 1.5e-2, 1.5e-2, what="fwd")
+    assert_close(y, to_ndhwc(F.leaky_relu(pre, 0.3)), *PARITY_TOL, what="fwd")
     dy = rnd((N, D, H, W, Cout), 14, dtype)
     dx_low = torch.full_like(x_low, float("nan"))
     ops.conv3d_upcat_dgrad(dy, up_d, None, None, None, dx_low, None)
@@ -608,9 +615,9 @@ def test_upcat_without_skip_channels(ops):
     ops.conv3d_upcat_wgrad(x_low, None, dy, dw, db, torch.empty(64 * Cout * C0, device="cuda"))
     torch.cuda.synchronize()
     pre.backward(to_ncdhw(f64(dy)))
-    assert_close(dx_low, xl.grad, 1.5e-2, 1.5e-2, what="dx_low")
-    assert_close(dw, kern.grad.permute(2, 3, 4, 0, 1).reshape(27, Cout, C0), 2e-3, 2e-3, what="dw")
-    assert_close(db, b64.grad, 2e-3, 2e-3, what="db")
+    assert_close(dx_low, xl.grad, *PARITY_TOL, what="dx_low")
+    assert_close(dw, kern.grad.permute(2, 3, 4, 0, 1).reshape(27, Cout, C0), 4e-6, 4e-6, what="dw")
+    assert_close(db, b64.grad, 4e-6, 4e-6, what="db")
 
 
 UPCAT2D_CASES = [
@@ -659,7 +666,7 @@ def test_upcat_2d_fwd_dgrad_wgrad(ops, case):
     b64 = f64(bias).requires_grad_(True)
     pre = ref_pre(xl, xs, kern, b64)
     ref = F.relu(pre).permute(0, 2, 3, 1).unsqueeze(0)
-    assert_close(y, ref, 1.5e-2, 1.5e-2, what=name + " fwd")
+    assert_close(y, ref, *PARITY_TOL, what=name + " fwd")
     dy = rnd((1, S, H, W, Cout), 25, dtype)
     m_low = rnd((1, S, H // 2, W // 2, C0), 26, dtype).clamp_min(0)
     m_skip = rnd((1, S, H, W, C1), 27, dtype).clamp_min(0) if C1 else None
@@ -668,18 +675,18 @@ def test_upcat_2d_fwd_dgrad_wgrad(ops, case):
     ops.conv3d_upcat_dgrad(dy, up_d, sk_d, m_low, m_skip, dx_low, dx_skip, planar=True)
     torch.cuda.synchronize()
     pre.backward(f64(dy)[0].permute(0, 3, 1, 2))
-    assert_close(dx_low, xl.grad * (f64(m_low) > 0), 1.5e-2, 1.5e-2, what=name + " dx_low")
+    assert_close(dx_low, xl.grad * (f64(m_low) > 0), *PARITY_TOL, what=name + " dx_low")
     if C1:
-        assert_close(dx_skip, xs.grad * (f64(m_skip) > 0), 1e-2, 1e-2, what=name + " dx_skip")
+        assert_close(dx_skip, xs.grad * (f64(m_skip) > 0), *TOL[torch.bfloat16], what=name + " dx_skip")
     if ok & 2:
         dw = torch.zeros((27, Cout, C0 + C1), device="cuda")
         db = torch.zeros(Cout, device="cuda")
         ops.conv3d_upcat_wgrad(x_low, x_skip, dy, dw, db, torch.empty(16 * Cout * C0, device="cuda"), planar=True)
         torch.cuda.synchronize()
         ref_dw = kern.grad.permute(2, 3, 0, 1).reshape(9, Cout, C0 + C1)
-        assert_close(dw[9:18], ref_dw, 2e-3, 2e-3, what=name + " dw")
+        assert_close(dw[9:18], ref_dw, 4e-6, 4e-6, what=name + " dw")
         assert float(dw[:9].abs().max()) == 0.0 and float(dw[18:].abs().max()) == 0.0
-        assert_close(db, b64.grad, 2e-3, 2e-3, what=name + " db")
+        assert_close(db, b64.grad, 4e-6, 4e-6, what=name + " db")
     else:
         assert Cout % 64                                                          # the weight-gradient kernel tiles Cout by 64
 
