@@ -400,7 +400,11 @@ def main():
         def lab_up_wgrad(x_low, skip, dy, *aa, **kk):
             return "conv_wgrad_mfma", ("wgrad", x_low.shape[-1] + (0 if skip is None else skip.shape[-1]), dy.shape[-1], dy.shape[1])
 
+        def lab_tail(src0, w, bias, y_, *aa, **kk):      # conv block whose epilogue also pools / computes the final 1x1x1 conv
+            return "conv_fwd_mfma", ("fwd", src0.shape[-1], y_.shape[-1], y_.shape[1])
+
         timer.wrap(ops, "conv3d_fwd", lab_fwd)
+        timer.wrap(ops, "conv3d_fwd_tail", lab_tail)
         timer.wrap(ops, "conv3d_dgrad", lab_dgrad)
         timer.wrap(ops, "conv3d_wgrad", lab_wgrad)
         timer.wrap(ops, "conv3d_upcat_fwd", lab_up_fwd, launches=2)

@@ -18,6 +18,10 @@ int conv3d_upcat_wgrad_mfma(const void*, int, const void*, int, const void*, flo
 int conv3d_fwd_mfma_ex(int, const void*, int, int, int, const void*, int, const void*, const float*, const void*, const void*, void*, int, int, int,
                        int, int, int, float, hipStream_t);
 
+int conv3d_fwd_tail_ok(int C0, int Cout, int N, int D, int H, int W, int dtype);
+int conv3d_fwd_mfma_tail(const void*, int, const void*, const float*, void*, void*, const float*, const float*, float*, int, int, int, int, int, int,
+                         float, hipStream_t);
+
 bool conv3d_first_ok(int C0, int C1, int Cout, int D, int H, int W, int dtype, int up0, int planar);
 int conv3d_first_fwd(const void*, int, int, const void*, const float*, void*, int, int, int, int, int, int, float, hipStream_t);
 int conv3d_first_wgrad(const void*, int, int, const void*, float*, float*, int, int, int, int, int, hipStream_t);
@@ -50,6 +54,22 @@ extern "C" int fmri_conv3d_fwd(const void* src0, int C0, int up0, const void* sr
         return conv3d_fwd_mfma(src0, C0, up0, planar, src1, C1, w, bias, mask, y, N, D, H, W, Cout, act, alpha, as_stream(stream));
     }
     return conv3d_fwd_generic(src0, C0, up0, planar, src1, C1, w, bias, mask, y, N, D, H, W, Cout, act, alpha, dtype, as_stream(stream));
+}
+
+extern "C" int fmri_conv3d_fwd_tail_ok(int C0, int Cout, int N, int D, int H, int W, int dtype) {
+    if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || C0 <= 0 || Cout <= 0) return 0;
+    return conv3d_fwd_tail_ok(C0, Cout, N, D, H, W, dtype);
+}
+
+extern "C" int fmri_conv3d_fwd_tail(const void* src0, int C0, const void* w, const float* bias, void* y, void* y_pool, const float* w1,
+                                    const float* b1, float* logits, int N, int D, int H, int W, int Cout, int act, float alpha, int dtype,
+                                    fmri_stream_t stream) {
+    int rc = check_common(src0, C0, 0, 0, nullptr, 0, N, D, H, W, Cout);
+    if (rc) return rc;
+    if (dtype != FMRI_BF16) return FMRI_E_DTYPE;
+    if (!w || !y || (!y_pool && !logits)) return FMRI_E_SHAPE;
+    if ((((uintptr_t)src0) | ((uintptr_t)w) | ((uintptr_t)y) | ((uintptr_t)y_pool) | ((uintptr_t)w1)) & 15) return FMRI_E_ALIGN;
+    return conv3d_fwd_mfma_tail(src0, C0, w, bias, y, y_pool, w1, b1, logits, N, D, H, W, Cout, act, alpha, as_stream(stream));
 }
 
 extern "C" int fmri_conv3d_dgrad(const void* dy, int Cout, const void* w_dgrad, const void* mask, void* dx, int N, int D, int H,

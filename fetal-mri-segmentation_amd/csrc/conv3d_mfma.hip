@@ -115,6 +115,17 @@ struct FwdItem {          // one (tile, Cout block, 32-channel chunk) unit of th
     int n, d0, h0, w0, co0, ch, par;
 };
 
+// Optional extra outputs of a plain (MODE 0, no residual) warp-specialised launch, produced from the tile while it sits in LDS as bf16
+// - i.e. from exactly the values that are stored to y - so that the HBM-bound consumers of y need no pass of their own:
+//   pool    [N][D/2][H/2][W/2][Cout]   2x2x2 max of y            (MaxPooling3D behind an encoder block, reference unet.py:51)
+//   logits  [N*D*H*W] fp32             sum_c w1[c] * y[v][c] + b1  (final Conv3D(1, (1,1,1)), reference unet.py:68); needs Cout == BN
+struct FwdTail {
+    bf16_t* pool;
+    const float* w1;
+    const float* b1;
+    float* logits;
+};
+
 // MODE selects what the 3x3x3 machinery computes:
 //   0  the plain convolution (forward, and dgrad with tap-flipped transposed weights);
 //   1  "up-forward": the conv of a nearest x2 up-sampled source WITHOUT the redundant taps.  Output voxel 2g+p (p = parity in
@@ -587,7 +598,7 @@ k_conv_fwd_mfma(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__
 template <int NT, bool PL, int MODE, bool RES>
 __global__ void __launch_bounds__(fw::NTHREADS)
 k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ bias, const bf16_t* __restrict__ mask,
-              const bf16_t* residual, bf16_t* y, int N, int D, int H, int W, int Cout, int act, float alpha) {
+              const bf16_t* residual, bf16_t* y, int N, int D, int H, int W, int Cout, int act, float alpha, FwdTail tail) {
     constexpr int TD = fw::TD, TH = fw::TH, TW = fw::TW;
     constexpr int HD = TD + 2, HH = TH + 2, HW = TW + 2, HVOX = HD * HH * HW;
     constexpr int H_INSTR = (HVOX * 4 + 63) / 64, HALO_BYTES = H_INSTR * 1024;
@@ -697,6 +708,58 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
                 }
             }
             *reinterpret_cast<uint4*>(y + ao) = o4;
+            if constexpr (MODE == 0 && !RES) {
+                if (tail.logits) {
+                    // final 1x1x1 conv to one label: the CPV lanes of a voxel hold its BN (= Cout) channels, 8 each
+                    const float4 wa = *reinterpret_cast<const float4*>(tail.w1 + q * 8), wb = *reinterpret_cast<const float4*>(tail.w1 + q * 8 + 4);
+                    float part = __uint_as_float(o4.x << 16) * wa.x;
+                    part = __builtin_fmaf(__uint_as_float(o4.x & 0xffff0000u), wa.y, part);
+                    part = __builtin_fmaf(__uint_as_float(o4.y << 16), wa.z, part);
+                    part = __builtin_fmaf(__uint_as_float(o4.y & 0xffff0000u), wa.w, part);
+                    part = __builtin_fmaf(__uint_as_float(o4.z << 16), wb.x, part);
+                    part = __builtin_fmaf(__uint_as_float(o4.z & 0xffff0000u), wb.y, part);
+                    part = __builtin_fmaf(__uint_as_float(o4.w << 16), wb.z, part);
+                    part = __builtin_fmaf(__uint_as_float(o4.w & 0xffff0000u), wb.w, part);
+#pragma unroll
+                    for (int m = 1; m < CPV; m <<= 1) part += __shfl_xor(part, m);
+                    if (q == 0)
+                        tail.logits[(((int64_t)it.n * D + it.d0 + tile_d(rt)) * H + it.h0 + tile_h(rt, rr)) * W + it.w0 + lane_w(rr)] = part + tail.b1[0];
+                }
+            }
+        }
+        if constexpr (MODE == 0 && !RES) {
+            if (tail.pool) {
+                // 2x2x2 max pooling of the staged tile: 2 x 4 x 8 pooled voxels x CPV 16-byte pieces, one per thread
+                const int idx = wv * 64 + lane;
+                if (idx < 64 * CPV) {
+                    const int pv = idx / CPV, q = idx % CPV;
+                    const int pd = pv >> 5, ph = (pv >> 3) & 3, pw = pv & 7;
+                    float mx[8];
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) {
+                        const int d = 2 * pd + (c >> 2), h = 2 * ph + ((c >> 1) & 1), w = 2 * pw + (c & 1);
+                        // inverse of (tile_d, tile_h, lane_w): column tile rt = d*4 + h/2, lane rr = (h&1)*16 + (w rotated by HW mod 16 on odd rows)
+                        const int v = (d * 4 + (h >> 1)) * 32 + ((h & 1) ? 16 + ((w + (HW & 15)) & 15) : w);
+                        const int vs = NT == 2 ? (v & 7) : ((v >> 2) & 3);
+                        const uint4 p4 = *reinterpret_cast<const uint4*>(stage + v * (BN * 2) + (((q ^ vs) & SWM) << 4));
+                        const unsigned pp[4] = {p4.x, p4.y, p4.z, p4.w};
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const float lo = __uint_as_float(pp[i] << 16), hi = __uint_as_float(pp[i] & 0xffff0000u);
+                            mx[2 * i] = c == 0 ? lo : vmax(mx[2 * i], lo);
+                            mx[2 * i + 1] = c == 0 ? hi : vmax(mx[2 * i + 1], hi);
+                        }
+                    }
+                    uint4 o;
+                    o.x = (__float_as_uint(mx[0]) >> 16) | (__float_as_uint(mx[1]) & 0xffff0000u);
+                    o.y = (__float_as_uint(mx[2]) >> 16) | (__float_as_uint(mx[3]) & 0xffff0000u);
+                    o.z = (__float_as_uint(mx[4]) >> 16) | (__float_as_uint(mx[5]) & 0xffff0000u);
+                    o.w = (__float_as_uint(mx[6]) >> 16) | (__float_as_uint(mx[7]) & 0xffff0000u);
+                    const int64_t po = ((((int64_t)it.n * (D >> 1) + (it.d0 >> 1) + pd) * (H >> 1) + (it.h0 >> 1) + ph) * (W >> 1) + (it.w0 >> 1) + pw) * Cout +
+                                       it.co0 + q * 8;
+                    *reinterpret_cast<uint4*>(tail.pool + po) = o;
+                }
+            }
         }
     };
 
@@ -1504,13 +1567,8 @@ bool conv3d_wgrad_mfma_ok(int C0, int C1, int Cout, int D, int H, int W, int dty
 
 // mode 0: plain conv (residual != nullptr selects the RES epilogue); 1: up-forward (src0 = LOW-res tensor, D/H/W = low-res dims,
 // y = [2D][2H][2W] partial sums); 2: up-backward (src0 = dy [2D][2H][2W][C0], y = gradient of the low-res tensor)
-int conv3d_fwd_mfma_ex(int mode, const void* src0, int C0, int up0, int planar, const void* src1, int C1, const void* w, const float* bias,
-                       const void* mask, const void* residual, void* y, int N, int D, int H, int W, int Cout, int act, float alpha,
-                       hipStream_t st) {
-    SrcB s{(const bf16_t*)src0, (const bf16_t*)src1, C0, C1, up0, planar ? 0 : 1, planar};
-    const bool cube = (D % fw::TD) || (H % fw::TH) || (W % fw::TW);       // only the 8x8x8 tiling fits (conv3d_fwd_mfma_ok)
-    const int ntile = cube ? N * (D / 8) * (H / 8) * (W / 8) : N * (D / fw::TD) * (H / fw::TH) * (W / fw::TW);
-    static int ncu = 0;                 // CU count of the current device, queried once (persistent grid = one workgroup per CU)
+static int fwd_cu_count() {             // CU count of the current device, queried once (persistent grid = one workgroup per CU)
+    static int ncu = 0;
     if (ncu == 0) {
         int dev = 0, v = 0;
         if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
@@ -1518,25 +1576,41 @@ int conv3d_fwd_mfma_ex(int mode, const void* src0, int C0, int up0, int planar, 
         else
             ncu = 256;
     }
-    // FMRI_FWD_WS=0: the symmetric kernel (every wave issues DMA and MFMAs) instead of the warp-specialised one
+    return ncu;
+}
+static int fwd_use_ws() {               // FMRI_FWD_WS=0: the symmetric kernel (every wave issues DMA and MFMAs) instead of the warp-specialised one
     static int use_ws = -1;
     if (use_ws < 0) {
         const char* e = getenv("FMRI_FWD_WS");
         use_ws = e ? atoi(e) : 1;
     }
+    return use_ws;
+}
+static bool fwd_wide(int mode, int planar, int ntile, int Cout) {
+    // 64-wide Cout blocks halve the halo traffic per MFMA, but a launch with fewer (tile, block) pairs than CUs (the 8x16x16 bottleneck
+    // level) leaves CUs idle: 32-wide blocks double the pairs there
+    return Cout % 64 == 0 && (int64_t)ntile * (Cout / 64) * (mode == 1 ? (planar ? 4 : 8) : 1) >= fwd_cu_count();
+}
+
+static int conv3d_fwd_mfma_launch(int mode, const void* src0, int C0, int up0, int planar, const void* src1, int C1, const void* w,
+                                  const float* bias, const void* mask, const void* residual, void* y, int N, int D, int H, int W, int Cout,
+                                  int act, float alpha, FwdTail tail, hipStream_t st) {
+    SrcB s{(const bf16_t*)src0, (const bf16_t*)src1, C0, C1, up0, planar ? 0 : 1, planar};
+    const bool cube = (D % fw::TD) || (H % fw::TH) || (W % fw::TW);       // only the 8x8x8 tiling fits (conv3d_fwd_mfma_ok)
+    const int ntile = cube ? N * (D / 8) * (H / 8) * (W / 8) : N * (D / fw::TD) * (H / fw::TH) * (W / fw::TW);
+    const int ncu = fwd_cu_count();
+    const int use_ws = fwd_use_ws();
 #define FMRI_LAUNCH_FWD(NT_, PL_, MODE_, RES_)                                                                             \
     do {                                                                                                                  \
         const int np = ntile * (Cout / (32 * NT_)) * (MODE_ == 1 ? (PL_ ? 4 : 8) : 1);                                    \
         if (use_ws && (!(PL_) || use_ws > 1))   /* planar: the producers are the bottleneck - symmetric kernel */ \
             k_conv_fwd_ws<NT_, PL_, MODE_, RES_><<<np < ncu ? np : ncu, fw::NTHREADS, 0, st>>>(                           \
-                s, (const bf16_t*)w, bias, (const bf16_t*)mask, (const bf16_t*)residual, (bf16_t*)y, N, D, H, W, Cout, act, alpha); \
+                s, (const bf16_t*)w, bias, (const bf16_t*)mask, (const bf16_t*)residual, (bf16_t*)y, N, D, H, W, Cout, act, alpha, tail); \
         else                                                                                                              \
             k_conv_fwd_mfma<NT_, PL_, MODE_, RES_><<<np < ncu ? np : ncu, fw::NTHREADS, 0, st>>>(                         \
                 s, (const bf16_t*)w, bias, (const bf16_t*)mask, (const bf16_t*)residual, (bf16_t*)y, N, D, H, W, Cout, act, alpha); \
     } while (0)
-    // 64-wide Cout blocks halve the halo traffic per MFMA, but a launch with fewer (tile, block) pairs than CUs (the 8x16x16 bottleneck
-    // level) leaves CUs idle: 32-wide blocks double the pairs there
-    const bool wide = Cout % 64 == 0 && (int64_t)ntile * (Cout / 64) * (mode == 1 ? (planar ? 4 : 8) : 1) >= ncu;
+    const bool wide = fwd_wide(mode, planar, ntile, Cout);
     if (cube) {
         if (mode != 0 || residual || planar) return FMRI_E_SHAPE;
         const int nt = wide ? 2 : 1;
@@ -1567,6 +1641,27 @@ int conv3d_fwd_mfma_ex(int mode, const void* src0, int C0, int up0, int planar, 
 #undef FMRI_LAUNCH_FWD
     FMRI_LAUNCH_CHECK();
     return FMRI_OK;
+}
+int conv3d_fwd_mfma_ex(int mode, const void* src0, int C0, int up0, int planar, const void* src1, int C1, const void* w, const float* bias,
+                       const void* mask, const void* residual, void* y, int N, int D, int H, int W, int Cout, int act, float alpha,
+                       hipStream_t st) {
+    return conv3d_fwd_mfma_launch(mode, src0, C0, up0, planar, src1, C1, w, bias, mask, residual, y, N, D, H, W, Cout, act, alpha,
+                                  FwdTail{nullptr, nullptr, nullptr, nullptr}, st);
+}
+// bit 0: the 2x2x2 max-pooled copy can be produced by the conv's epilogue, bit 1: the final 1x1x1 conv to one label can (plain 3-D
+// warp-specialised launch on the 4x8x16 tiling; the logits need the voxel's whole channel range in one workgroup: Cout == block width)
+int conv3d_fwd_tail_ok(int C0, int Cout, int N, int D, int H, int W, int dtype) {
+    if (!conv3d_fwd_mfma_ok(C0, 0, Cout, D, H, W, dtype) || conv3d_fwd_needs_cube(D, H, W) || fwd_use_ws() == 0) return 0;
+    const int ntile = N * (D / fw::TD) * (H / fw::TH) * (W / fw::TW);
+    const int bn = fwd_wide(0, 0, ntile, Cout) ? 64 : 32;
+    return 1 | (Cout == bn ? 2 : 0);
+}
+int conv3d_fwd_mfma_tail(const void* src0, int C0, const void* w, const float* bias, void* y, void* pool, const float* w1, const float* b1,
+                         float* logits, int N, int D, int H, int W, int Cout, int act, float alpha, hipStream_t st) {
+    const int ok = conv3d_fwd_tail_ok(C0, Cout, N, D, H, W, FMRI_BF16);
+    if ((pool && !(ok & 1)) || (logits && (!(ok & 2) || !w1 || !b1))) return FMRI_E_SHAPE;
+    return conv3d_fwd_mfma_launch(0, src0, C0, 0, 0, nullptr, 0, w, bias, nullptr, nullptr, y, N, D, H, W, Cout, act, alpha,
+                                  FwdTail{(bf16_t*)pool, w1, b1, logits}, st);
 }
 int conv3d_fwd_mfma(const void* src0, int C0, int up0, int planar, const void* src1, int C1, const void* w, const float* bias,
                     const void* mask, void* y, int N, int D, int H, int W, int Cout, int act, float alpha, hipStream_t st) {

@@ -491,10 +491,26 @@ class UNetEngine:
         """view [N][D][H][W][C] as [samples][voxels...][C] for the normalisation kernels (2-D: slices are the samples)"""
         return t.reshape((t.shape[1],) + tuple(t.shape[2:])) if self.planar else t
 
-    def _block_fwd(self, c, src0, src1, up0, bn_training):
-        """one [conv -> (norm) -> ReLU] block (reference create_convolution_block, unet.py:89-115)"""
+    def _tail_ok(self, c):
+        """what the epilogue of conv block `c` can produce besides its output (ops.conv3d_fwd_tail_ok bits): only plain single-source
+        3-D blocks without a normalisation layer (the consumer then reads the block's OUTPUT); FMRI_TAIL_FUSE=0 switches it off (A/B)"""
+        if c.get("norm") or self.planar or self.dtype != torch.bfloat16 or os.environ.get("FMRI_TAIL_FUSE", "1") == "0":
+            return 0
+        d = self._dims(c["level"])
+        return ops.conv3d_fwd_tail_ok(c["cin"], c["cout"], d[0], d[1], d[2], d[3], self.dtype)
+
+    def _block_fwd(self, c, src0, src1, up0, bn_training, pool=None, final=None):
+        """one [conv -> (norm) -> ReLU] block (reference create_convolution_block, unet.py:89-115).  pool: tensor that receives
+        MaxPooling3D(2) of the block's output; final: the final 1x1x1 conv descriptor whose logits the epilogue computes - both only
+        when _tail_ok(c) says so (the caller checks)."""
         name = c["name"]
         out, act = (self.pre[name], ACT_NONE) if c.get("norm") else (self.act[name], ACT_RELU)
+        if pool is not None or final is not None:
+            w1 = self.w_view(final["name"]).reshape(-1) if final is not None else None
+            ops.conv3d_fwd_tail(src0, self.Wf[name], self.b_view(name), out, pool=pool, w1=w1,
+                                b1=self.b_view(final["name"]) if final is not None else None,
+                                logits=self.logits.reshape(-1) if final is not None else None, act=act)
+            return self.act[name]
         if up0 and self._use_upcat(name):
             W = self.Wup[name]
             ops.conv3d_upcat_fwd(src0, src1, W["up_f"], W["sk_f"], self.b_view(name), out, act=act, planar=self.planar)
@@ -529,12 +545,14 @@ class UNetEngine:
         self.x_in = x
         h = x
         for ld, lv in enumerate(p.enc):
-            for c in lv:
-                h = self._block_fwd(c, h, None, False, bn_training)
+            h = self._block_fwd(lv[0], h, None, False, bn_training)
+            # MaxPooling3D behind the level's second block comes out of that conv's epilogue when the kernel can do it
+            fuse_pool = ld < p.depth - 1 and (self._tail_ok(lv[1]) & 1)
+            h = self._block_fwd(lv[1], h, None, False, bn_training, pool=A["pool_%d" % ld] if fuse_pool else None)
             if ld == 0:
                 self._join_packs(decoder=False)             # the deeper layers' weight images were repacked on the side stream
             if ld < p.depth - 1:
-                h = ops.maxpool_fwd(h, A["pool_%d" % ld], planar=self.planar)
+                h = A["pool_%d" % ld] if fuse_pool else ops.maxpool_fwd(h, A["pool_%d" % ld], planar=self.planar)
         self._join_packs()
         for lv in p.dec:
             a, b = lv
@@ -553,9 +571,12 @@ class UNetEngine:
                 self._block_fwd(a, A[u["name"]], skip, False, bn_training)
             else:
                 self._block_fwd(a, h, skip, True, bn_training)
-            h = self._block_fwd(b, A[a["name"]], None, False, bn_training)
+            # the last block also produces the logits of the final 1x1x1 conv (one label) in its epilogue when the kernel can do it
+            fuse_final = lv is p.dec[-1] and p.n_labels == 1 and (self._tail_ok(b) & 2)
+            h = self._block_fwd(b, A[a["name"]], None, False, bn_training, final=p.final if fuse_final else None)
         f = p.final
-        ops.conv1x1_fwd(h, self.w_view(f["name"]), self.b_view(f["name"]), self.logits)
+        if not (p.dec and fuse_final):
+            ops.conv1x1_fwd(h, self.w_view(f["name"]), self.b_view(f["name"]), self.logits)
         return self.logits
 
     def loss_forward(self, y_true, weight=None):

@@ -52,6 +52,17 @@ int fmri_conv3d_fwd(const void* src0, int C0, int up0, const void* src1, int C1,
                     const void* mask, void* y, int N, int D, int H, int W, int Cout, int act, float alpha, int dtype,
                     int impl, int planar, fmri_stream_t stream);
 
+/* ---- Conv3D block with its HBM-bound consumer folded into the epilogue (bf16 MFMA path only; single full-resolution source).
+ * The tile of y is still in LDS when it is stored; from those same bf16 values the kernel can also produce
+ *   y_pool [N][D/2][H/2][W/2][Cout]  = MaxPooling3D(2) of y            (reference unet3d/unet.py:51 behind the encoder block :45-50)
+ *   logits [N*D*H*W] fp32            = Conv3D(1, (1,1,1))(y) = sum_c w1[c]*y[v][c] + b1[0]   (reference unet.py:68, n_labels = 1)
+ * so that neither fmri_maxpool3d_2x_fwd nor fmri_conv1x1_fwd has to read y back.  Either output may be NULL (not both).
+ * fmri_conv3d_fwd_tail_ok: bit 0 = y_pool available, bit 1 = logits available for this shape (host-side query, no GPU needed). */
+int fmri_conv3d_fwd_tail_ok(int C0, int Cout, int N, int D, int H, int W, int dtype);
+int fmri_conv3d_fwd_tail(const void* src0, int C0, const void* w, const float* bias, void* y, void* y_pool, const float* w1,
+                         const float* b1, float* logits, int N, int D, int H, int W, int Cout, int act, float alpha, int dtype,
+                         fmri_stream_t stream);
+
 /* ---- Conv3DBackpropInputV2 (autodiff of unet.py:102): dx = conv(dy, w_dgrad) * (mask > 0).
  * w_dgrad [27][Cin][Cout] is the tap-flipped, transposed copy made by fmri_conv3d_pack_weights. */
 int fmri_conv3d_dgrad(const void* dy, int Cout, const void* w_dgrad, const void* mask, void* dx, int N, int D, int H,

@@ -717,3 +717,80 @@ def test_weighted_cross_entropy_loss_value_and_gradient(ops):
     want = MO.dice_and_xent(t.numpy(), p.detach().numpy(), xent_weight=0.7, weight_mask=w64.numpy()) if hasattr(MO, "dice_and_xent") else float(loss)
     assert abs(got - float(loss)) <= 1e-5 and abs(got - float(want)) <= 1e-5
     assert_close(dl, z.grad, 1e-4, 1e-5, what="weighted dice+xent gradient")
+
+
+TAIL_CASES = [
+    # name, N, D, H, W, C0, Cout, expected ok bits (on a 256-CU device)
+    ("narrow_32", 1, 8, 16, 32, 32, 32, 3),          # 32-wide Cout block == Cout: pool + logits
+    ("few_tiles_64", 2, 8, 16, 32, 32, 64, 1),       # fewer (tile, 64-block) pairs than CUs -> 32-wide blocks: no single block sees all 64 channels
+    ("wide_64", 2, 16, 64, 64, 32, 64, 3),           # the shape class of the network's last block (64-wide block == Cout)
+    ("wide_128_pool", 1, 16, 64, 128, 64, 128, 1),   # two 64-blocks per voxel: pool only
+]
+
+
+@pytest.mark.parametrize("case", TAIL_CASES, ids=[c[0] for c in TAIL_CASES])
+def test_conv3d_fwd_tail(ops, case):
+    """fmri_conv3d_fwd_tail: the conv block's epilogue also writes MaxPooling3D(2)(y) and the final 1x1x1 conv's logits from the tile
+    in LDS.  y must be BIT-identical to fmri_conv3d_fwd, the pooled tensor to fmri_maxpool3d_2x_fwd(y) (same bf16 values, max is
+    exact), the logits equal fmri_conv1x1_fwd(y) up to fp32 summation order; all three are checked against fp64 as well
+    (reference unet3d/unet.py:45-51, :68)."""
+    name, N, D, H, W, C0, Cout, bits = case
+    bf = torch.bfloat16
+    ok = ops.conv3d_fwd_tail_ok(C0, Cout, N, D, H, W, bf)
+    if torch.cuda.get_device_properties(0).multi_processor_count == 256:
+        assert ok == bits, (name, ok)
+    x = rnd((N, D, H, W, C0), 21, bf)
+    w = rnd((27, Cout, C0), 22, bf, scale=0.1)
+    bias = rnd((Cout,), 23, torch.float32, scale=0.3)
+    w1 = rnd((Cout,), 24, torch.float32, scale=0.2)
+    b1 = rnd((1,), 25, torch.float32)
+    y0 = torch.empty((N, D, H, W, Cout), dtype=bf, device="cuda")
+    ops.conv3d_fwd(x, None, w, bias, y0, act=1)
+    p0 = torch.empty((N, D // 2, H // 2, W // 2, Cout), dtype=bf, device="cuda")
+    ops.maxpool_fwd(y0, p0)
+    l0 = torch.empty((N * D * H * W, 1), dtype=torch.float32, device="cuda")
+    ops.conv1x1_fwd(y0, w1.reshape(1, Cout), b1, l0)
+    y = torch.full_like(y0, float("nan"))
+    pool = torch.full_like(p0, float("nan")) if ok & 1 else None
+    logits = torch.full((N * D * H * W,), float("nan"), dtype=torch.float32, device="cuda") if ok & 2 else None
+    assert ok & 1
+    ops.conv3d_fwd_tail(x, w, bias, y, pool=pool, w1=w1 if ok & 2 else None, b1=b1 if ok & 2 else None, logits=logits, act=1)
+    torch.cuda.synchronize()
+    assert torch.equal(y.view(torch.int16), y0.view(torch.int16))
+    assert torch.equal(pool.view(torch.int16), p0.view(torch.int16))
+    ref = ref_conv_fwd(f64(x), None, False, f64(w), f64(bias), 1)
+    assert_close(y, ref, *TOL[bf], what=name + " tail y")
+    if ok & 2:
+        assert_close(logits.reshape(-1, 1), l0, 2e-6, 2e-6, what=name + " tail logits vs conv1x1 kernel")
+        assert_close(logits, ((f64(y) @ f64(w1)) + f64(b1)).reshape(-1), 2e-6, 2e-6, what=name + " tail logits vs fp64")
+    else:
+        with pytest.raises(RuntimeError):
+            ops.conv3d_fwd_tail(x, w, bias, y, w1=w1, b1=b1, logits=torch.empty(N * D * H * W, dtype=torch.float32, device="cuda"))
+
+
+def test_engine_tail_fusion_equals_separate_kernels(monkeypatch):
+    """the engine with the pooling / final-conv tails fused into the conv epilogues (default) against FMRI_TAIL_FUSE=0: identical
+    activations and pooled tensors, logits equal to fp32 summation order, same Dice, gradients equal to atomics order"""
+    from fmri_hip.engine import UNetEngine, UNetPlan
+    sp, N = (16, 64, 64), 2
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn((N,) + sp + (1,), generator=g).cuda().to(torch.bfloat16)
+    yv = (torch.rand((N * sp[0] * sp[1] * sp[2],), generator=g) > 0.7).to(torch.uint8).cuda()
+    out = {}
+    for fuse in ("1", "0"):
+        monkeypatch.setenv("FMRI_TAIL_FUSE", fuse)
+        eng = UNetEngine(UNetPlan(1, sp, depth=3, n_base_filters=32), N, dtype=torch.bfloat16, seed=11)
+        if fuse == "1":
+            assert eng._tail_ok(eng.plan.enc[0][1]) & 1 and eng._tail_ok(eng.plan.dec[-1][1]) & 2
+        eng.forward(x)
+        s = eng.loss_forward(yv).cpu().numpy().copy()
+        eng.backward(yv)
+        torch.cuda.synchronize()
+        out[fuse] = (eng.logits.clone(), {k: v.clone() for k, v in eng.act.items()}, s, eng.G.clone())
+    la, aa, sa, ga = out["1"]
+    lb, ab, sb, gb = out["0"]
+    for k in aa:
+        assert torch.equal(aa[k].view(torch.int16), ab[k].view(torch.int16)), k
+    assert_close(la, lb, 2e-6, 2e-6, what="fused logits")
+    assert abs(sa[0] - sb[0]) <= 1e-6 * abs(sb[0]) and sa[7] == sb[7]
+    assert float((ga - gb).abs().max()) <= 1e-4 * float(gb.abs().max())
