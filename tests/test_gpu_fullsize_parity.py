@@ -381,3 +381,47 @@ def test_cfg4_full_volume_sliding_window(monkeypatch, graph, golden_dir):
     const = patch_wise_prediction(model=model, data=data, patch_shape=patch, overlap_factor=0.5, batch_size=5)
     s = 1.0 / (1.0 + np.exp(-0.75))
     assert float(np.abs(const - s).max()) <= 1e-6
+
+
+KD_SCRIPT = r"""
+import os, sys
+sys.path.insert(0, os.path.join(%r, "fetal-mri-segmentation_amd"))
+import numpy as np, torch
+from fmri_hip import ops
+g = torch.Generator().manual_seed(5)
+def dyadic(shape, lo, hi, den, density=1.0):
+    t = torch.randint(lo, hi + 1, shape, generator=g).float() / den
+    return t * (torch.rand(shape, generator=g) < density).float() if density < 1.0 else t
+out = {}
+# (a) runs that cross column boundaries (5 units per workgroup on columns of 4 planes), dual source; (b) fused x2 up-sampled source
+for tag, (N, D, H, W, C0, C1, Cout, up0) in dict(cols=(5, 4, 128, 128, 64, 0, 64, 0), dual=(1, 8, 32, 64, 64, 64, 128, 0), up=(1, 8, 32, 64, 128, 64, 64, 1)).items():
+    s0 = (N, D // 2, H // 2, W // 2, C0) if up0 else (N, D, H, W, C0)
+    x0, x1 = dyadic(s0, -4, 4, 4), (dyadic((N, D, H, W, C1), -4, 4, 4) if C1 else None)
+    dy = dyadic((N, D, H, W, Cout), -2, 2, 2, density=1.0 / 16)
+    dw, db = torch.zeros((27, Cout, C0 + C1), device="cuda"), torch.zeros(Cout, device="cuda")
+    ops.conv3d_wgrad(x0.to(torch.bfloat16).cuda(), None if x1 is None else x1.to(torch.bfloat16).cuda(), dy.to(torch.bfloat16).cuda(), dw, db, up0=bool(up0))
+    torch.cuda.synchronize()
+    out[tag + "_dw"], out[tag + "_db"] = dw.cpu().numpy(), db.cpu().numpy()
+np.savez(sys.argv[1], **out)
+print("DONE")
+"""
+
+
+def test_kd_sharing_weight_gradient_kernel_is_exact(tmp_path):
+    """the opt-in kd-sharing weight-gradient kernel (FMRI_WGRAD_KD=2: one workgroup per (64 Cout, 64 Cin) block walks columns of d-planes
+    for all 27 taps through a 4-slot x-plane ring) against the default kernel on dyadic data whose sums are exact in fp32 in any order:
+    the two must agree BIT FOR BIT - runs that cross column boundaries, a dual source, a fused up-sampled source"""
+    import subprocess
+    import sys
+    f = tmp_path / "kd.py"
+    f.write_text(KD_SCRIPT % ROOT)
+    res = []
+    for mode in ("2", "0"):
+        o = str(tmp_path / ("kd%s.npz" % mode))
+        r = subprocess.run([sys.executable, str(f), o], capture_output=True, text=True, timeout=900, env=dict(os.environ, FMRI_WGRAD_KD=mode))
+        assert r.returncode == 0 and "DONE" in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])
+        res.append(np.load(o))
+    assert len(res[0].files) == 6
+    for k in res[0].files:
+        assert float(np.abs(res[0][k]).max()) > 0
+        assert np.array_equal(res[0][k], res[1][k]), k
