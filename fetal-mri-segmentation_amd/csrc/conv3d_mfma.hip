@@ -1549,17 +1549,11 @@ __device__ __forceinline__ void wk_compute(const unsigned char* lds, const int (
         load_a(ks8, av);
         if constexpr (G == 3) {
             if (do_bias) {
-                // bias gradient = sum of the dy fragment: v_dot2_f32_bf16 with a (1, 1) operand - four instructions per fragment, no temporaries
-                typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
-                typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+                // bias gradient = sum of the dy fragments (this group has 32 registers to spare)
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const u32x4 d4 = __builtin_bit_cast(u32x4, av[h]);
+                for (int h = 0; h < 2; ++h)
 #pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        bsum[h] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, d4[q]), __builtin_bit_cast(bf16x2_t, 0x3f803f80u), bsum[h],
-                                                                  false);
-                }
+                    for (int q = 0; q < 8; ++q) bsum[h] += bf2f((unsigned short)av[h][q]);
             }
         }
 #pragma unroll

@@ -8,6 +8,7 @@ namespace {
 
 struct Geo {
     int N, D, H, W, Do, Ho, Wo, Cin, Cout, k, s, pd, ph, pw;   // p* = zeros in front of each axis
+    int planar;       // 2-D slices stacked along D: only the centre kd plane of the filter exists, D is neither padded nor strided
 };
 
 __device__ __forceinline__ void out_coords(int64_t v, const Geo& g, int& n, int& d, int& h, int& w) {
@@ -27,7 +28,8 @@ __global__ void k_direct_fwd(const T* __restrict__ x, const T* __restrict__ wt, 
         out_coords(i / g.Cout, g, n, d, h, w);
         float acc = bias ? bias[co] : 0.f;
         for (int kd = 0; kd < g.k; ++kd) {
-            const int id = d * g.s + kd - g.pd;
+            if (g.planar && kd != g.k / 2) continue;
+            const int id = g.planar ? d : d * g.s + kd - g.pd;
             if ((unsigned)id >= (unsigned)g.D) continue;
             for (int kh = 0; kh < g.k; ++kh) {
                 const int ih = h * g.s + kh - g.ph;
@@ -60,15 +62,17 @@ __global__ void k_direct_dgrad(const T* __restrict__ dy, const T* __restrict__ w
         const int n = (int)(v / g.D);
         float acc = 0.f;
         for (int kd = 0; kd < g.k; ++kd) {
+            if (g.planar && kd != g.k / 2) continue;
             const int td = id + g.pd - kd;
-            if (td < 0 || (td % g.s) || td / g.s >= g.Do) continue;
+            if (!g.planar && (td < 0 || (td % g.s) || td / g.s >= g.Do)) continue;
+            const int od = g.planar ? id : td / g.s;
             for (int kh = 0; kh < g.k; ++kh) {
                 const int th = ih + g.ph - kh;
                 if (th < 0 || (th % g.s) || th / g.s >= g.Ho) continue;
                 for (int kw = 0; kw < g.k; ++kw) {
                     const int tw = iw + g.pw - kw;
                     if (tw < 0 || (tw % g.s) || tw / g.s >= g.Wo) continue;
-                    const T* gp = dy + ((((int64_t)n * g.Do + td / g.s) * g.Ho + th / g.s) * g.Wo + tw / g.s) * g.Cout;
+                    const T* gp = dy + ((((int64_t)n * g.Do + od) * g.Ho + th / g.s) * g.Wo + tw / g.s) * g.Cout;
                     const T* wp = wt + (int64_t)((kd * g.k + kh) * g.k + kw) * g.Cout * g.Cin + ci;
                     for (int co = 0; co < g.Cout; ++co) acc = fmaf(to_f<T>(gp[co]), to_f<T>(wp[(int64_t)co * g.Cin]), acc);
                 }
@@ -84,6 +88,8 @@ __global__ void k_direct_wgrad(const T* __restrict__ x, const T* __restrict__ dy
                                int nsplit) {
     const int tap = blockIdx.x, co = blockIdx.y, sp = blockIdx.z;
     const int kd = tap / (g.k * g.k), kh = (tap / g.k) % g.k, kw = tap % g.k;
+    if (g.planar && kd != g.k / 2) return;                      // dead filter planes of the 2-D slices: their gradient stays zero
+    const int tap_b = g.planar ? (g.k / 2) * g.k * g.k : 0;     // the tap whose workgroups also sum the bias gradient
     const int64_t nout = (int64_t)g.N * g.Do * g.Ho * g.Wo;
     const int64_t v0 = nout * sp / nsplit, v1 = nout * (sp + 1) / nsplit;
     float bsum = 0.f;
@@ -94,14 +100,14 @@ __global__ void k_direct_wgrad(const T* __restrict__ x, const T* __restrict__ dy
             int n, d, h, w;
             out_coords(v, g, n, d, h, w);
             const float gv = to_f<T>(dy[v * g.Cout + co]);
-            if (ci0 == 0 && threadIdx.x == 0 && tap == 0) bsum += gv;
-            const int id = d * g.s + kd - g.pd, ih = h * g.s + kh - g.ph, iw = w * g.s + kw - g.pw;
+            if (ci0 == 0 && threadIdx.x == 0 && tap == tap_b) bsum += gv;
+            const int id = g.planar ? d : d * g.s + kd - g.pd, ih = h * g.s + kh - g.ph, iw = w * g.s + kw - g.pw;
             if ((unsigned)id >= (unsigned)g.D || (unsigned)ih >= (unsigned)g.H || (unsigned)iw >= (unsigned)g.W) continue;
             if (ci < g.Cin) acc = fmaf(gv, to_f<T>(x[((((int64_t)n * g.D + id) * g.H + ih) * g.W + iw) * g.Cin + ci]), acc);
         }
         if (ci < g.Cin) atomicAdd(&dw[((int64_t)tap * g.Cout + co) * g.Cin + ci], acc);
     }
-    if (db && threadIdx.x == 0 && tap == 0) atomicAdd(&db[co], bsum);
+    if (db && threadIdx.x == 0 && tap == tap_b) atomicAdd(&db[co], bsum);
 }
 
 template <typename T>
@@ -149,15 +155,16 @@ bool make_geo(Geo& g, int N, int D, int H, int W, int Cin, int Cout, int k, int 
     g.N = N; g.D = D; g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout; g.k = k; g.s = s;
     g.Do = planar ? D : (D + s - 1) / s; g.Ho = (H + s - 1) / s; g.Wo = (W + s - 1) / s;
     g.pd = planar ? 0 : pad_before(D); g.ph = pad_before(H); g.pw = pad_before(W);
-    return !planar;      // planar strided / 1x1 variants are not needed by any reference builder
+    g.planar = planar ? 1 : 0;
+    return true;
 }
 
 }  // namespace
 
-extern "C" int fmri_conv3d_direct_fwd(const void* x, const void* w, const float* bias, void* y, int N, int D, int H, int W, int Cin,
-                                      int Cout, int ksize, int stride, int act, float alpha, int dtype, fmri_stream_t stream) {
+static int direct_fwd(const void* x, const void* w, const float* bias, void* y, int N, int D, int H, int W, int Cin, int Cout, int ksize,
+                      int stride, int act, float alpha, int dtype, int planar, fmri_stream_t stream) {
     Geo g;
-    if (!make_geo(g, N, D, H, W, Cin, Cout, ksize, stride, 0)) return FMRI_E_SHAPE;
+    if (!make_geo(g, N, D, H, W, Cin, Cout, ksize, stride, planar)) return FMRI_E_SHAPE;
     const int grid = grid_for((int64_t)N * g.Do * g.Ho * g.Wo * Cout, 256, 16384);
     hipStream_t s = as_stream(stream);
     if (dtype == FMRI_F32) k_direct_fwd<float><<<grid, 256, 0, s>>>((const float*)x, (const float*)w, bias, (float*)y, g, act, alpha);
@@ -167,10 +174,10 @@ extern "C" int fmri_conv3d_direct_fwd(const void* x, const void* w, const float*
     return FMRI_OK;
 }
 
-extern "C" int fmri_conv3d_direct_bwd(const void* x, const void* w, const void* dy, void* dx, float* dw, float* db, int N, int D, int H,
-                                      int W, int Cin, int Cout, int ksize, int stride, int dtype, fmri_stream_t stream) {
+static int direct_bwd(const void* x, const void* w, const void* dy, void* dx, float* dw, float* db, int N, int D, int H, int W, int Cin,
+                      int Cout, int ksize, int stride, int dtype, int planar, fmri_stream_t stream) {
     Geo g;
-    if (!make_geo(g, N, D, H, W, Cin, Cout, ksize, stride, 0)) return FMRI_E_SHAPE;
+    if (!make_geo(g, N, D, H, W, Cin, Cout, ksize, stride, planar)) return FMRI_E_SHAPE;
     hipStream_t s = as_stream(stream);
     const int grid = grid_for((int64_t)N * D * H * W * Cin, 256, 16384);
     const int nsplit = 32;
@@ -185,6 +192,25 @@ extern "C" int fmri_conv3d_direct_bwd(const void* x, const void* w, const void* 
     } else return FMRI_E_DTYPE;
     FMRI_LAUNCH_CHECK();
     return FMRI_OK;
+}
+
+extern "C" int fmri_conv3d_direct_fwd(const void* x, const void* w, const float* bias, void* y, int N, int D, int H, int W, int Cin,
+                                      int Cout, int ksize, int stride, int act, float alpha, int dtype, fmri_stream_t stream) {
+    return direct_fwd(x, w, bias, y, N, D, H, W, Cin, Cout, ksize, stride, act, alpha, dtype, 0, stream);
+}
+extern "C" int fmri_conv3d_direct_bwd(const void* x, const void* w, const void* dy, void* dx, float* dw, float* db, int N, int D, int H,
+                                      int W, int Cin, int Cout, int ksize, int stride, int dtype, fmri_stream_t stream) {
+    return direct_bwd(x, w, dy, dx, dw, db, N, D, H, W, Cin, Cout, ksize, stride, dtype, 0, stream);
+}
+// 2-D twins (reference model/unet/isensee.py:49 strides=(2,2), :96 kernel=(1,1), :59 heads): S slices stacked along D, untouched by the
+// stride; the filter image keeps the 27-tap (or 1-tap) layout with the 2-D kernel in its centre kd plane
+extern "C" int fmri_conv2d_direct_fwd(const void* x, const void* w, const float* bias, void* y, int S, int H, int W, int Cin, int Cout,
+                                      int ksize, int stride, int act, float alpha, int dtype, fmri_stream_t stream) {
+    return direct_fwd(x, w, bias, y, 1, S, H, W, Cin, Cout, ksize, stride, act, alpha, dtype, 1, stream);
+}
+extern "C" int fmri_conv2d_direct_bwd(const void* x, const void* w, const void* dy, void* dx, float* dw, float* db, int S, int H, int W,
+                                      int Cin, int Cout, int ksize, int stride, int dtype, fmri_stream_t stream) {
+    return direct_bwd(x, w, dy, dx, dw, db, 1, S, H, W, Cin, Cout, ksize, stride, dtype, 1, stream);
 }
 
 extern "C" int fmri_add(const void* a, const void* b, void* y, int64_t n, int dtype, fmri_stream_t stream) {

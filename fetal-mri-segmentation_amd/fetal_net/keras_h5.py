@@ -335,14 +335,20 @@ def infer_builder(mc, tc=None):
         kw["initial_learning_rate"] = float(tc["optimizer_config"]["config"]["lr"])
         kw["loss_function"] = {"__callable__": tc["loss"]} if isinstance(tc["loss"], str) else None
     if "Add" in cls or "LeakyReLU" in cls:
-        if "Conv2D" in cls:
-            raise NotImplementedError("2-D Isensee model (isensee2017_model) is not built in this package")
         drops = [l for l in layers if l["class_name"].startswith("SpatialDropout")]
         heads = [l for l in convs if all(int(k) == 1 for k in l["config"]["kernel_size"]) and
                  not _followed_by_norm(l["name"], layers)]
         kw.update(n_base_filters=int(convs[0]["config"]["filters"]), depth=len(drops),
                   dropout_rate=float(drops[0]["config"]["rate"]) if drops else 0.0, n_segmentation_levels=len(heads),
                   n_labels=int(heads[0]["config"]["filters"]))
+        if "Conv2D" in cls:
+            # 2-D twin: only the heads that reach the output are in the file; more than one means they were summed (summation=True).
+            # With summation=False the file cannot tell how many (dead) heads the builder created - their count only shows in the layer
+            # numbering: the head conv2d_K of level 0 is the (3*depth + 3*(depth-1) + created_heads)-th convolution
+            last = int(heads[-1]["name"].rsplit("_", 1)[1])
+            depth = len(drops)
+            kw.update(summation=len(heads) > 1, n_segmentation_levels=(len(heads) if len(heads) > 1 else max(1, last - (6 * depth - 3))))
+            return "isensee2017_model", kw
         if len(inputs) > 1:
             kw["mask_shape"] = tuple(int(v) for v in inputs[1]["config"]["batch_input_shape"][1:])
         return "isensee2017_model_3d", kw

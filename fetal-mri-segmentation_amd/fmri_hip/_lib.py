@@ -47,6 +47,8 @@ SIGNATURES = {
     "fmri_deconv3d_k2s2_bwd": [p, p, p, i32, i32, p, p, p, p, i32, i32, i32, i32, i32, i32, i32, i32, p],
     "fmri_conv3d_direct_fwd": [p, p, p, p, i32, i32, i32, i32, i32, i32, i32, i32, i32, f32, i32, p],
     "fmri_conv3d_direct_bwd": [p, p, p, p, p, p, i32, i32, i32, i32, i32, i32, i32, i32, i32, p],
+    "fmri_conv2d_direct_fwd": [p, p, p, p, i32, i32, i32, i32, i32, i32, i32, i32, f32, i32, p],
+    "fmri_conv2d_direct_bwd": [p, p, p, p, p, p, i32, i32, i32, i32, i32, i32, i32, i32, p],
     "fmri_add": [p, p, p, i64, i32, p],
     "fmri_act_bwd": [p, p, p, i32, f32, i64, i32, p],
     "fmri_slice_channels": [p, i32, i32, p, i32, i64, i32, i32, p],

@@ -1,9 +1,12 @@
 """Generic executor for a recorded Keras-style layer graph (fetal_net.model.graph.Graph) on the C ABI.
 
 The hand-scheduled `UNetEngine` stays the path of the headline U-Net; this interpreter runs any graph made of the layer
-classes the reference's 3-D builders emit — Conv3D (3x3x3 stride 1|2, 1x1x1), InstanceNormalization / BatchNormalization,
+classes the reference's builders emit — Conv3D (3x3x3 stride 1|2, 1x1x1), InstanceNormalization / BatchNormalization,
 LeakyReLU / Activation('relu'|'sigmoid'), MaxPooling3D, UpSampling3D, Concatenate, Add, SpatialDropout3D — i.e. the Isensee
-model of reference fetal_net/model/unet3d/isensee2017.py:15-111 (and, for cross-checking, unet_model_3d).
+model of reference fetal_net/model/unet3d/isensee2017.py:15-111 (and, for cross-checking, unet_model_3d) — and their 2-D twins
+(Conv2D, UpSampling2D, SpatialDropout2D, MaxPooling2D between two Permute layers: reference fetal_net/model/unet/isensee.py:14-105).
+2-D graphs run PLANAR: the batch of slices (N,X,Y,C) is one tensor [1][N][X][Y][C], every kernel gets planar = 1 (no coupling along
+the slice axis, pooling / up-sampling / stride in X and Y only), a 2-D filter is the centre kd plane of a 27-tap image.
 
 Compile-time fusions (nothing of the fused kind is ever materialised):
   * UpSampling3D -> Conv3D(3x3x3)          => conv reads its source through the fused nearest x2 (up0)
@@ -27,7 +30,7 @@ LEAKY_ALPHA = 0.3      # keras.layers.LeakyReLU default (reference isensee2017.p
 
 class _Dims(object):
     def __init__(self, spatial, n_labels):
-        self.spatial, self.n_labels, self.ndim = tuple(spatial), n_labels, 3
+        self.spatial, self.n_labels, self.ndim = tuple(spatial), n_labels, len(spatial)
 
     def level_dims(self, level, slices=1):
         return tuple(s >> level for s in self.spatial)
@@ -39,7 +42,8 @@ class LayerGraphEngine(object):
         self.layers = list(layers)
         self.by_name = OrderedDict((l.name, l) for l in self.layers)
         self.dtype, self.dev, self.training, self.dist = dtype, torch.device(device), training, dist_ctx
-        self.planar = False
+        self.planar = any(l.class_name == "Conv2D" for l in self.layers)      # 2-D graph: slices ride the kernels' D axis
+        self.nd = 2 if self.planar else 3
         # bf16: every tensor carries its channels padded to a multiple of 32 (zero weights / zero activations in the padding) so that
         # all convolutions - including the 16- and 32-channel levels, the stride-2 and the 1x1x1 ones - run on the MFMA kernels:
         # stride 2 = the stride-1 conv sampled at every second voxel, 1x1x1 = the centre tap of a 27-tap filter.  fp32 (parity mode)
@@ -60,23 +64,42 @@ class LayerGraphEngine(object):
     # ------------------------------------------------------------------------------------------------ compile
     def _compile(self):
         L = self.layers
-        consumers = {l.name: [] for l in L}
-        for l in L:
-            for i in l.inbound:
-                consumers[i].append(l.name)
-        self.consumers = consumers
         absorbed = set()          # layers that never get a tensor of their own
         self.ops = []             # dicts: kind, out, ins, + params
-        self.alias = {}           # layer name -> tensor name that holds its value
-        out_layer = L[-1]
+        nd = self.nd
+        CONV, UPS, DROP, POOL = "Conv%dD" % nd, "UpSampling%dD" % nd, "SpatialDropout%dD" % nd, "MaxPooling%dD" % nd
+        k3, s1 = (3,) * nd, (1,) * nd
+        self.input_name = L[0].name
+        # Permute layers (the 2-D builders wrap a channels-first graph in two of them) own no tensor: the engine's tensors are
+        # channels-last throughout, a Permute is just another name for its source
+        self.alias = {}           # layer name -> name of the layer whose tensor holds its value
+        for l in L:
+            if l.class_name == "Permute":
+                self.alias[l.name] = self.alias.get(l.inbound[0], l.inbound[0])
+                absorbed.add(l.name)
+        res = lambda n: self.alias.get(n, n)
+        consumers = {l.name: [] for l in L}
+        for l in L:
+            if l.class_name == "Permute":
+                continue
+            for i in l.inbound:
+                consumers[res(i)].append(l.name)
+        self.consumers = consumers
+        inb = {l.name: [res(i) for i in l.inbound] for l in L}
+        out_layer = L[-1] if L[-1].class_name != "Permute" else self.by_name[L[-1].inbound[0]]
         if not (out_layer.class_name == "Activation" and out_layer.config.get("activation") == "sigmoid"):
             raise NotImplementedError("the graph must end in Activation('sigmoid')")
-        self.logits_src = out_layer.inbound[0]
-        self.input_name = L[0].name
-        in_shape = L[0].output_shape                      # (None, C, X, Y, Z)
-        self.in_channels = in_shape[1]
-        self.plan = _Dims(in_shape[2:], out_layer.output_shape[1])
-        self.shape = {l.name: (l.output_shape[1],) + tuple(l.output_shape[2:]) for l in L}   # (C, D, H, W)
+        self.logits_src = inb[out_layer.name][0]
+        in_shape = L[0].output_shape                      # 3-D: (None, C, X, Y, Z); 2-D: (None, X, Y, C) channels-last
+        if self.planar:
+            self.in_channels = in_shape[-1]
+            self.plan = _Dims(in_shape[1:3], out_layer.output_shape[1])
+        else:
+            self.in_channels = in_shape[1]
+            self.plan = _Dims(in_shape[2:], out_layer.output_shape[1])
+        self.shape = {l.name: (l.output_shape[1],) + tuple(l.output_shape[2:]) for l in L if l.class_name != "Permute"}   # (C, spatial...)
+        if self.planar:
+            self.shape[self.input_name] = (self.in_channels,) + tuple(in_shape[1:3])
         self.convs, self.norms = OrderedDict(), OrderedDict()
 
         def single_consumer(name, cls=None):
@@ -86,9 +109,9 @@ class LayerGraphEngine(object):
         # producers that a later 3x3x3 stride-1 conv reads through (fused up-sampling / concatenation): decided up front because
         # they precede their consumer in the layer list
         for l in L:
-            if l.class_name == "Conv3D" and tuple(l.config["kernel_size"]) == (3, 3, 3) and tuple(l.config.get("strides") or (1, 1, 1)) == (1, 1, 1):
-                src = self.by_name[l.inbound[0]]
-                if src.class_name == "UpSampling3D" and single_consumer(src.name):
+            if l.class_name == CONV and tuple(l.config["kernel_size"]) == k3 and tuple(l.config.get("strides") or s1) == s1:
+                src = self.by_name[inb[l.name][0]]
+                if src.class_name == UPS and single_consumer(src.name):
                     absorbed.add(src.name)
                 elif src.class_name == "Concatenate" and len(src.inbound) == 2 and single_consumer(src.name):
                     absorbed.add(src.name)
@@ -98,17 +121,17 @@ class LayerGraphEngine(object):
             cn = l.class_name
             if cn == "InputLayer":
                 continue
-            if cn == "Conv3D":
-                k, s = tuple(l.config["kernel_size"]), tuple(l.config.get("strides") or (1, 1, 1))
-                src = self.by_name[l.inbound[0]]
-                op = dict(kind="conv", name=l.name, out=l.name, k=k[0], s=s[0], act=ACT_NONE, up0=False, ins=[l.inbound[0]])
-                if k == (3, 3, 3) and s == (1, 1, 1):
-                    if src.class_name == "UpSampling3D" and single_consumer(src.name):
+            if cn == CONV:
+                k, s = tuple(l.config["kernel_size"]), tuple(l.config.get("strides") or s1)
+                src = self.by_name[inb[l.name][0]]
+                op = dict(kind="conv", name=l.name, out=l.name, k=k[0], s=s[0], act=ACT_NONE, up0=False, ins=[inb[l.name][0]])
+                if k == k3 and s == s1:
+                    if src.class_name == UPS and single_consumer(src.name):
                         absorbed.add(src.name)
-                        op["ins"], op["up0"] = [src.inbound[0]], True
+                        op["ins"], op["up0"] = [inb[src.name][0]], True
                     elif src.class_name == "Concatenate" and len(src.inbound) == 2 and single_consumer(src.name):
                         absorbed.add(src.name)
-                        op["ins"] = list(src.inbound)
+                        op["ins"] = list(inb[src.name])
                 nxt = self.by_name[consumers[l.name][0]] if single_consumer(l.name) else None
                 if nxt is not None and nxt.class_name == "Activation" and nxt.config.get("activation") == "relu":
                     absorbed.add(nxt.name)
@@ -116,7 +139,7 @@ class LayerGraphEngine(object):
                 self.convs[l.name] = op
                 self.ops.append(op)
             elif cn in ("InstanceNormalization", "BatchNormalization"):
-                op = dict(kind="norm", name=l.name, out=l.name, ins=[l.inbound[0]], instance=(cn == "InstanceNormalization"), act=ACT_NONE)
+                op = dict(kind="norm", name=l.name, out=l.name, ins=[inb[l.name][0]], instance=(cn == "InstanceNormalization"), act=ACT_NONE)
                 nxt = self.by_name[consumers[l.name][0]] if single_consumer(l.name) else None
                 if nxt is not None and (nxt.class_name == "LeakyReLU" or (nxt.class_name == "Activation" and nxt.config.get("activation") == "relu")):
                     absorbed.add(nxt.name)
@@ -124,15 +147,15 @@ class LayerGraphEngine(object):
                 self.norms[l.name] = op
                 self.ops.append(op)
             elif cn == "Add":
-                self.ops.append(dict(kind="add", out=l.name, ins=list(l.inbound)))
-            elif cn == "SpatialDropout3D":
-                self.ops.append(dict(kind="dropout", out=l.name, ins=[l.inbound[0]], rate=float(l.config.get("rate", 0.0))))
-            elif cn == "UpSampling3D":
-                self.ops.append(dict(kind="upsample", out=l.name, ins=[l.inbound[0]]))
-            elif cn == "MaxPooling3D":
-                self.ops.append(dict(kind="maxpool", out=l.name, ins=[l.inbound[0]]))
+                self.ops.append(dict(kind="add", out=l.name, ins=list(inb[l.name])))
+            elif cn == DROP:
+                self.ops.append(dict(kind="dropout", out=l.name, ins=[inb[l.name][0]], rate=float(l.config.get("rate", 0.0))))
+            elif cn == UPS:
+                self.ops.append(dict(kind="upsample", out=l.name, ins=[inb[l.name][0]]))
+            elif cn == POOL:
+                self.ops.append(dict(kind="maxpool", out=l.name, ins=[inb[l.name][0]]))
             elif cn == "Concatenate":
-                raise NotImplementedError("Concatenate is only supported in front of a 3x3x3 Conv3D (layer %s)" % l.name)
+                raise NotImplementedError("Concatenate is only supported in front of a 3x3(x3) convolution (layer %s)" % l.name)
             else:
                 raise NotImplementedError("layer class %s (%s) is not executable on the engine yet" % (cn, l.name))
         self.clog = {n: sh[0] for n, sh in self.shape.items()}          # logical channel counts
@@ -206,7 +229,7 @@ class LayerGraphEngine(object):
         # UpSampling3D -> Conv3D (reference isensee2017.py:101-104): parity form, 8 pre-summed 2x2x2 filters on the low-res tensor
         self.Wup, self.dwc_scratch = {}, None
         for name, op in self.convs.items():
-            if op["up0"] and len(op["ins"]) == 1 and op["s"] == 1 and op["k"] == 3:
+            if op["up0"] and len(op["ins"]) == 1 and op["s"] == 1 and op["k"] == 3 and not self.planar:     # (2-D: fused-upsample 9-tap kernels)
                 coutp, cinp = self.shape[name][0], self.Wp32[name].shape[2]
                 ok = ops.conv3d_upcat_ok(cinp, 0, coutp, *self.shape[name][1:], self.dtype)
                 if ok & 1:
@@ -244,8 +267,8 @@ class LayerGraphEngine(object):
             if l.name in self.convs:
                 Lc = self.layout[l.name]
                 k = Lc["k"]
-                lim = math.sqrt(6.0 / (k ** 3 * (Lc["cin"] + Lc["cout"])))
-                W[l.name + "/kernel"] = rs.uniform(-lim, lim, size=(k, k, k, Lc["cin"], Lc["cout"])).astype(np.float32)
+                lim = math.sqrt(6.0 / (k ** self.nd * (Lc["cin"] + Lc["cout"])))
+                W[l.name + "/kernel"] = rs.uniform(-lim, lim, size=(k,) * self.nd + (Lc["cin"], Lc["cout"])).astype(np.float32)
                 W[l.name + "/bias"] = np.zeros(Lc["cout"], np.float32)
             elif l.name in self.norms:
                 W[l.name + "/gamma"] = np.ones(self.layout[l.name]["c"], np.float32)
@@ -257,7 +280,11 @@ class LayerGraphEngine(object):
         for name, Lc in self.layout.items():
             if Lc["kind"] == "conv":
                 k = np.asarray(W[name + "/kernel"], np.float32)
-                assert k.shape == (Lc["k"],) * 3 + (Lc["cin"], Lc["cout"]), (name, k.shape)
+                assert k.shape == (Lc["k"],) * self.nd + (Lc["cin"], Lc["cout"]), (name, k.shape)
+                if self.nd == 2:                          # (kh,kw,Cin,Cout) -> centre kd plane of the k^3 image (k = 1: the single tap)
+                    k3 = np.zeros((Lc["k"],) * 3 + (Lc["cin"], Lc["cout"]), np.float32)
+                    k3[Lc["k"] // 2] = k
+                    k = k3
                 o, n = Lc["w"]
                 host[o:o + n] = k.transpose(0, 1, 2, 4, 3).reshape(-1)
                 ob, nb = Lc["b"]
@@ -279,7 +306,8 @@ class LayerGraphEngine(object):
             if name in self.convs:
                 Lc = self.layout[name]
                 o, n = Lc["w"]
-                W[name + "/kernel"] = host[o:o + n].reshape((Lc["k"],) * 3 + (Lc["cout"], Lc["cin"])).transpose(0, 1, 2, 4, 3).copy()
+                k = host[o:o + n].reshape((Lc["k"],) * 3 + (Lc["cout"], Lc["cin"])).transpose(0, 1, 2, 4, 3)
+                W[name + "/kernel"] = (k[Lc["k"] // 2] if self.nd == 2 else k).copy()
                 ob, nb = Lc["b"]
                 W[name + "/bias"] = host[ob:ob + nb].copy()
             elif name in self.norms:
@@ -321,7 +349,7 @@ class LayerGraphEngine(object):
             T, pre, stats = {}, {}, {}
             for o in self.ops:
                 C, sp = o["shape"][0], tuple(o["shape"][1:])
-                T[o["out"]] = torch.empty((N,) + sp + (C,), dtype=self.dtype, device=self.dev)
+                T[o["out"]] = torch.empty(self._lead(N) + sp + (C,), dtype=self.dtype, device=self.dev)
                 if o["kind"] == "conv" and o["out"] != o["name"]:
                     pass
                 if o["kind"] == "norm":
@@ -335,7 +363,7 @@ class LayerGraphEngine(object):
                 for o in self.ops:
                     if o["kind"] == "conv" and o["s"] == 2:
                         sp_in = tuple(self.shape[o["ins"][0]][1:])
-                        full[o["name"]] = torch.empty((N,) + sp_in + (o["shape"][0],), dtype=self.dtype, device=self.dev)
+                        full[o["name"]] = torch.empty(self._lead(N) + sp_in + (o["shape"][0],), dtype=self.dtype, device=self.dev)
                         if self.training:
                             gfull[o["name"]] = torch.zeros_like(full[o["name"]])
             cmax = max([self.shape[n][0] for n in self.norms] + [1])
@@ -354,10 +382,24 @@ class LayerGraphEngine(object):
     def _t(self, name):
         return self.x_in if name == self.input_name else self.T[name]
 
+    def _lead(self, N):
+        """leading dims of an activation: 3-D (N,) + (D,H,W); 2-D planar (1, N) + (H,W) - the slices are the kernels' D axis"""
+        return (1, N) if self.planar else (N,)
+
+    def _smp(self, t):
+        """[samples][voxels...][C] view for the per-sample kernels (instance norm, spatial dropout): 2-D slices are the samples"""
+        return t.reshape(tuple(t.shape[1:])) if self.planar else t
+
+    def _s2(self, t, offs):
+        """every second voxel of a stride-1 result (stride-2 conv in the channel-padded mode); planar: H and W only"""
+        if self.planar:
+            return t[:, :, offs[0]::2, offs[1]::2, :]
+        return t[:, offs[0]::2, offs[1]::2, offs[2]::2, :]
+
     # ------------------------------------------------------------------------------------------------ forward
     def forward(self, x, bn_training=None):
         training = self.training if bn_training is None else bn_training
-        assert tuple(x.shape) == (self.N,) + self.plan.spatial + (self.in_channels,), x.shape
+        assert tuple(x.shape) == self._lead(self.N) + self.plan.spatial + (self.in_channels,), x.shape
         self.x_in = x
         for o in self.ops:
             kind = o["kind"]
@@ -370,24 +412,23 @@ class LayerGraphEngine(object):
                     if name in self.Wup:
                         ops.conv3d_upcat_fwd(s0, None, self.Wup[name]["up_f"], None, self.bp[name], out, act=o["act"], alpha=LEAKY_ALPHA)
                     elif o["s"] == 1:
-                        ops.conv3d_fwd(s0, s1, self.Wf[name], self.bp[name], out, up0=o["up0"], act=o["act"])
+                        ops.conv3d_fwd(s0, s1, self.Wf[name], self.bp[name], out, up0=o["up0"], act=o["act"], planar=self.planar)
                     else:
                         fl = self.full[name]
-                        ops.conv3d_fwd(s0, s1, self.Wf[name], self.bp[name], fl, up0=o["up0"], act=o["act"])
-                        od, oh, ow = self._s2_offsets(fl)
-                        out.copy_(fl[:, od::2, oh::2, ow::2, :])
+                        ops.conv3d_fwd(s0, s1, self.Wf[name], self.bp[name], fl, up0=o["up0"], act=o["act"], planar=self.planar)
+                        out.copy_(self._s2(fl, self._s2_offsets(fl)))
                     continue
                 bias = self._v(name, "b")
                 if o["k"] == 3 and o["s"] == 1:
                     s0 = self._t(o["ins"][0])
                     s1 = self._t(o["ins"][1]) if len(o["ins"]) > 1 else None
-                    ops.conv3d_fwd(s0, s1, self.Wf[name], bias, out, up0=o["up0"], act=o["act"])
+                    ops.conv3d_fwd(s0, s1, self.Wf[name], bias, out, up0=o["up0"], act=o["act"], planar=self.planar)
                 else:
-                    ops.conv_direct_fwd(self._t(o["ins"][0]), self.Wf[name], bias, out, o["k"], o["s"], act=o["act"])
+                    ops.conv_direct_fwd(self._t(o["ins"][0]), self.Wf[name], bias, out, o["k"], o["s"], act=o["act"], planar=self.planar)
             elif kind == "norm":
                 name = o["name"]
                 gam, bet = (self.gp[name], self.betap[name]) if self.pad else (self._v(name, "gamma"), self._v(name, "beta"))
-                ops.norm_act_fwd(self._t(o["ins"][0]), gam, bet, out, self.stats[name], self.norm_ws,
+                ops.norm_act_fwd(self._smp(self._t(o["ins"][0])), gam, bet, self._smp(out), self.stats[name], self.norm_ws,
                                  1 if o["instance"] else 0, eps=1e-3, eps_on_std=o["instance"], act=o["act"], alpha=LEAKY_ALPHA)
             elif kind == "add":
                 ops.add(self._t(o["ins"][0]), self._t(o["ins"][1]), out)
@@ -402,14 +443,14 @@ class LayerGraphEngine(object):
                     else:                                   # whole channels of a sample are dropped, survivors scaled by 1/(1-p)
                         sc = (torch.rand((self.N, src.shape[-1]), device=self.dev) < keep).float() / keep
                     self.drop[o["out"]] = sc
-                    ops.channel_scale(src, sc, out)
+                    ops.channel_scale(self._smp(src), sc, self._smp(out))
                 else:
                     self.drop[o["out"]] = None
                     ops.cast(src, out)                      # identity copy keeps the tensor table simple
             elif kind == "upsample":
-                ops.upsample_fwd(self._t(o["ins"][0]), out)
+                ops.upsample_fwd(self._t(o["ins"][0]), out, planar=self.planar)
             elif kind == "maxpool":
-                ops.maxpool_fwd(self._t(o["ins"][0]), out)
+                ops.maxpool_fwd(self._t(o["ins"][0]), out, planar=self.planar)
         src = self.T[self.logits_src]
         if src.shape[-1] != self.plan.n_labels:                # channel-padded: the logits are the first n_labels channels
             self.logits.copy_(src.reshape(-1, src.shape[-1])[:, :self.plan.n_labels])
@@ -417,11 +458,10 @@ class LayerGraphEngine(object):
             ops.cast(src.reshape(-1), self.logits.reshape(-1))
         return self.logits
 
-    @staticmethod
-    def _s2_offsets(full):
+    def _s2_offsets(self, full):
         """TF 'same' padding with stride 2 reads x[2o + k - pad_before]; pad_before = 0 for even sizes (output o = stride-1 'same'
         result at 2o+1), 1 for odd sizes (at 2o)"""
-        return tuple(1 if d % 2 == 0 else 0 for d in full.shape[1:4])
+        return tuple(1 if d % 2 == 0 else 0 for d in (full.shape[2:4] if self.planar else full.shape[1:4]))
 
     def set_dropout_masks(self, masks):
         """testing hook: fix the SpatialDropout3D masks ({layer name: [N,C] fp32 tensor}) instead of drawing them"""
@@ -485,8 +525,7 @@ class LayerGraphEngine(object):
                 ins = o["ins"]
                 if self.pad and o["s"] == 2:                 # gradient of "sample every second voxel": scatter into the stride-1 grid
                     gf = self.gfull[name]
-                    od, oh, ow = self._s2_offsets(gf)
-                    gf[:, od::2, oh::2, ow::2, :] = g        # the other voxels stay zero (zeroed at allocation, never written)
+                    self._s2(gf, self._s2_offsets(gf)).copy_(g)      # the other voxels stay zero (zeroed at allocation, never written)
                     g = gf
                 if self.pad or (o["k"] == 3 and o["s"] == 1):
                     s0 = self._t(ins[0])
@@ -505,12 +544,12 @@ class LayerGraphEngine(object):
                             if name in self.Wup and self.Wup[name]["wgrad"] and gw is g:
                                 ops.conv3d_upcat_wgrad(s0, None, g, dwp, dbp, self.dwc_scratch)
                             else:
-                                ops.conv3d_wgrad(s0, s1, gw, dwp, dbp, up0=o["up0"])
+                                ops.conv3d_wgrad(s0, s1, gw, dwp, dbp, up0=o["up0"], planar=self.planar)
                             taps = dwp if o["k"] == 3 else dwp[13:14]
                             dw += taps[:, :Lc["cout"]].index_select(2, self.cin_map[name])
                             db += dbp[:Lc["cout"]]
                         else:
-                            ops.conv3d_wgrad(s0, s1, g, dw, db, up0=o["up0"])
+                            ops.conv3d_wgrad(s0, s1, g, dw, db, up0=o["up0"], planar=self.planar)
 
                     if self._wg_stream is None:
                         wgrad()
@@ -522,27 +561,25 @@ class LayerGraphEngine(object):
                         self._accum(ins[0], lambda dst: ops.conv3d_upcat_dgrad(g, self.Wup[name]["up_d"], None, None, None, dst, None))
                     elif name in self.Wd:
                         if len(ins) == 1 and not o["up0"]:
-                            self._accum(ins[0], lambda dst: ops.conv3d_dgrad(g, self.Wd[name], dst))
+                            self._accum(ins[0], lambda dst: ops.conv3d_dgrad(g, self.Wd[name], dst, planar=self.planar))
                         else:
                             cin = self.Wd[name].shape[1]           # physical (channel-padded) width of the concatenated input
                             if name not in self.cat:
                                 self.cat[name] = torch.empty(tuple(g.shape[:-1]) + (cin,), dtype=self.dtype, device=self.dev)
                             cat = self.cat[name]
-                            ops.conv3d_dgrad(g, self.Wd[name], cat)
+                            ops.conv3d_dgrad(g, self.Wd[name], cat, planar=self.planar)
                             c0 = self.shape[ins[0]][0] if ins[0] != self.input_name else self.in_channels
                             if o["up0"]:
-                                self._accum(ins[0], lambda dst: ops.upsample_bwd(cat, dst, dy_off=0))
+                                self._accum(ins[0], lambda dst: ops.upsample_bwd(cat, dst, dy_off=0, planar=self.planar))
                             else:
                                 self._slice_into(ins[0], cat, 0)
                             if len(ins) > 1:
                                 self._slice_into(ins[1], cat, c0)
                 else:
                     x = self._t(ins[0])
-                    if ins[0] == self.input_name:
-                        ops.conv_direct_bwd(x, self.Wf[name], g, None, dw, db, o["k"], o["s"])
-                    else:
-                        ops.conv_direct_bwd(x, self.Wf[name], g, None, dw, db, o["k"], o["s"])
-                        self._accum(ins[0], lambda dst: ops.conv_direct_bwd(x, self.Wf[name], g, dst, None, None, o["k"], o["s"]))
+                    ops.conv_direct_bwd(x, self.Wf[name], g, None, dw, db, o["k"], o["s"], planar=self.planar)
+                    if ins[0] != self.input_name:
+                        self._accum(ins[0], lambda dst: ops.conv_direct_bwd(x, self.Wf[name], g, dst, None, None, o["k"], o["s"], planar=self.planar))
             elif kind == "norm":
                 name = o["name"]
                 src = o["ins"][0]
@@ -551,13 +588,15 @@ class LayerGraphEngine(object):
                     dg, dbt = self.dgp[name], self.dbetap[name]
                     dg.zero_()
                     dbt.zero_()
-                    self._accum(src, lambda dst: ops.norm_act_bwd(self._t(src), self.T[out], g, self.gp[name], self.stats[name], dst, dg, dbt,
-                                                                  self.norm_ws, 1 if o["instance"] else 0, act=o["act"], alpha=LEAKY_ALPHA))
+                    self._accum(src, lambda dst: ops.norm_act_bwd(self._smp(self._t(src)), self._smp(self.T[out]), self._smp(g), self.gp[name],
+                                                                  self.stats[name], self._smp(dst), dg, dbt, self.norm_ws,
+                                                                  1 if o["instance"] else 0, act=o["act"], alpha=LEAKY_ALPHA))
                     self._v(name, "gamma", self.G).add_(dg[:c])
                     self._v(name, "beta", self.G).add_(dbt[:c])
                     continue
-                self._accum(src, lambda dst: ops.norm_act_bwd(self._t(src), self.T[out], g, self._v(name, "gamma"), self.stats[name], dst,
-                                                              self._v(name, "gamma", self.G), self._v(name, "beta", self.G), self.norm_ws,
+                self._accum(src, lambda dst: ops.norm_act_bwd(self._smp(self._t(src)), self._smp(self.T[out]), self._smp(g), self._v(name, "gamma"),
+                                                              self.stats[name], self._smp(dst), self._v(name, "gamma", self.G),
+                                                              self._v(name, "beta", self.G), self.norm_ws,
                                                               1 if o["instance"] else 0, act=o["act"], alpha=LEAKY_ALPHA))
             elif kind == "add":
                 for i in o["ins"]:
@@ -567,12 +606,12 @@ class LayerGraphEngine(object):
                 if sc is None:
                     self._slice_into(o["ins"][0], g, 0)
                 else:
-                    self._accum(o["ins"][0], lambda dst: ops.channel_scale(g, sc, dst))
+                    self._accum(o["ins"][0], lambda dst: ops.channel_scale(self._smp(g), sc, self._smp(dst)))
             elif kind == "upsample":
-                self._accum(o["ins"][0], lambda dst: ops.upsample_bwd(g, dst, dy_off=0))
+                self._accum(o["ins"][0], lambda dst: ops.upsample_bwd(g, dst, dy_off=0, planar=self.planar))
             elif kind == "maxpool":
                 src = o["ins"][0]
-                self._accum(src, lambda dst: ops.maxpool_bwd(self._t(src), g, dst, relu_mask=False))
+                self._accum(src, lambda dst: ops.maxpool_bwd(self._t(src), g, dst, relu_mask=False, planar=self.planar))
         if self._wg_stream is not None:
             torch.cuda.current_stream(self.dev).wait_stream(self._wg_stream)
         if self.dist is not None:

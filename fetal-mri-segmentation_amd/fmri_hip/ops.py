@@ -228,20 +228,31 @@ def deconv_bwd(x, w, dy, dx, dw, db, dy_off=0, xmask=None, planar=False):
                                        Cout, dt(x), int(planar), _s()), "fmri_deconv3d_k2s2_bwd")
 
 
-def conv_direct_fwd(x, w, bias, y, ksize, stride, act=ACT_NONE, alpha=0.0):
-    """x [N,D,H,W,Cin], w [k^3,Cout,Cin] (compute dtype), y [N,ceil(D/s),ceil(H/s),ceil(W/s),Cout]"""
+def conv_direct_fwd(x, w, bias, y, ksize, stride, act=ACT_NONE, alpha=0.0, planar=False):
+    """x [N,D,H,W,Cin], w [k^3,Cout,Cin] (compute dtype), y [N,ceil(D/s),ceil(H/s),ceil(W/s),Cout]; planar: x [1,S,H,W,Cin] 2-D slices,
+    the stride applies to H and W only"""
     _need_cuda(x, w, bias, y)
     N, D, H, W, Cin = x.shape
     Cout = w.shape[1]
+    if planar:
+        assert N == 1
+        check(lib().fmri_conv2d_direct_fwd(_p(x), _p(w), _p(bias), _p(y), D, H, W, Cin, Cout, ksize, stride, act, float(alpha), dt(x), _s()),
+              "fmri_conv2d_direct_fwd")
+        return y
     check(lib().fmri_conv3d_direct_fwd(_p(x), _p(w), _p(bias), _p(y), N, D, H, W, Cin, Cout, ksize, stride, act, float(alpha), dt(x), _s()),
           "fmri_conv3d_direct_fwd")
     return y
 
 
-def conv_direct_bwd(x, w, dy, dx, dw, db, ksize, stride):
+def conv_direct_bwd(x, w, dy, dx, dw, db, ksize, stride, planar=False):
     _need_cuda(x, w, dy, dx, dw, db)
     N, D, H, W, Cin = x.shape
     Cout = w.shape[1]
+    if planar:
+        assert N == 1
+        check(lib().fmri_conv2d_direct_bwd(_p(x), _p(w), _p(dy), _p(dx), _p(dw), _p(db), D, H, W, Cin, Cout, ksize, stride, dt(x), _s()),
+              "fmri_conv2d_direct_bwd")
+        return
     check(lib().fmri_conv3d_direct_bwd(_p(x), _p(w), _p(dy), _p(dx), _p(dw), _p(db), N, D, H, W, Cin, Cout, ksize, stride, dt(x), _s()),
           "fmri_conv3d_direct_bwd")
 

@@ -206,6 +206,13 @@ int fmri_conv3d_direct_fwd(const void* x, const void* w, const float* bias, void
 /* dx (optional) = input gradient; dw [k^3][Cout][Cin], db [Cout] fp32 ACCUMULATED (optional). */
 int fmri_conv3d_direct_bwd(const void* x, const void* w, const void* dy, void* dx, float* dw, float* db, int N, int D, int H, int W,
                            int Cin, int Cout, int ksize, int stride, int dtype, fmri_stream_t stream);
+/* 2-D twins — reference model/unet/isensee.py:49 (strides=(2,2)), :96 (kernel=(1,1)), :59 (segmentation heads): x [1][S][H][W][Cin] =
+ * S slices stacked along the planar axis, which the stride leaves alone; y [1][S][ceil(H/s)][ceil(W/s)][Cout].  The filter image keeps
+ * the k^3 layout with the 2-D kernel in its centre kd plane; the other planes are never read and their gradient is never written. */
+int fmri_conv2d_direct_fwd(const void* x, const void* w, const float* bias, void* y, int S, int H, int W, int Cin, int Cout, int ksize,
+                           int stride, int act, float alpha, int dtype, fmri_stream_t stream);
+int fmri_conv2d_direct_bwd(const void* x, const void* w, const void* dy, void* dx, float* dw, float* db, int S, int H, int W, int Cin,
+                           int Cout, int ksize, int stride, int dtype, fmri_stream_t stream);
 /* y = a + b (residual Add, reference isensee2017.py:55; gradient fan-in of multiply-consumed tensors) */
 int fmri_add(const void* a, const void* b, void* y, int64_t n, int dtype, fmri_stream_t stream);
 /* dx = dy * act'(y): ReluGrad / LeakyRelu gradient from the stored post-activation tensor (dx may alias dy) */

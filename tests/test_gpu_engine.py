@@ -510,3 +510,129 @@ def test_2d_deconvolution_variant_bf16_mfma_path_vs_fp32():
                 continue                      # the unused half (ad = 1 taps) of the transposed-conv filter in planar mode
             e = np.linalg.norm(gb[o:o + n] - gf[o:o + n]) / ref
             bar("deconv2d_bf16.grad_l2_rel", e, 8e-2)                                            # measured 5.1e-2
+
+
+@pytest.mark.parametrize("summation", [False, True])
+def test_isensee2d_graph_engine_fp32_vs_oracle(summation):
+    """2-D Isensee (reference fetal_net/model/unet/isensee.py:14-105: Conv2D blocks with InstanceNormalization + LeakyReLU, stride-2
+    in-convs, SpatialDropout2D with fixed masks, UpSampling2D, 1x1 localisation convs and heads; heads summed only with summation=True)
+    on the layer-graph engine in PLANAR mode - the batch of slices is one [1][N][X][Y][C] tensor, 2-D filters are the centre plane of
+    27-tap images - against the torch-CPU restatement: logits <= 1e-3 relative, Dice <= 1e-4, every parameter gradient; the dead kd
+    planes of every 3x3 filter gradient stay exactly zero."""
+    import fetal_net.model as fmodel
+    from fmri_hip.graph_engine import LayerGraphEngine
+    from oracle import isensee_oracle as I
+    N, X, Y, C = 4, 32, 32, 3
+    kw = dict(input_shape=(X, Y, C), depth=3, n_base_filters=4, n_segmentation_levels=2, dropout_rate=0.3, summation=summation)
+    model = fmodel.isensee2017_model(**kw)
+    spec = I.IsenseeSpec(ndim=2, **kw)
+    rs = np.random.RandomState(12)
+    x = rs.randn(N, X, Y, C).astype(np.float32)
+    y = (rs.rand(N, X, Y, 1) > 0.7).astype(np.uint8)
+    masks = {lv: ((rs.rand(N, spec.levels[lv]["filters"]) < 0.7).astype(np.float64) / 0.7) for lv in range(3)}
+    W = spec.init_weights(23)
+    r2 = np.random.RandomState(5)
+    for k in W:
+        if k.endswith(("/bias", "/beta")):
+            W[k] = (r2.randn(*W[k].shape) * 0.05).astype(np.float32)
+        if k.endswith("/gamma"):
+            W[k] = (1.0 + r2.randn(*W[k].shape) * 0.1).astype(np.float32)
+    ref = I.loss_and_grads(spec, W, x, y, dropout_masks=masks)
+    eng = LayerGraphEngine(model.layers, N, dtype=torch.float32)
+    assert eng.planar and eng.nd == 2
+    eng.load_keras_weights(W)
+    eng.set_dropout_masks({"spatial_dropout2d_%d" % (lv + 1): torch.tensor(masks[lv], dtype=torch.float32).cuda() for lv in range(3)})
+    xd = torch.from_numpy(x).cuda().unsqueeze(0).contiguous()
+    yd = torch.from_numpy(y).cuda().reshape(-1).contiguous()
+    eng.forward(xd)
+    sums = eng.loss_forward(yd)
+    eng.backward(yd)
+    torch.cuda.synchronize()
+    logits = eng.logits.cpu().numpy().reshape(ref["logits"].shape)
+    assert _rel(logits, ref["logits"]) <= 1e-3
+    assert abs(eng.metrics_from_sums(sums.cpu().numpy())["dice_coefficient"] - ref["dice"]) <= 1e-4
+    assert len(eng.layout) * 2 == len(ref["grads"])
+    for name, L in eng.layout.items():
+        if L["kind"] == "conv":
+            g3 = eng.w_view(name, eng.G).cpu().numpy().reshape((L["k"],) * 3 + (L["cout"], L["cin"])).transpose(0, 1, 2, 4, 3)
+            if L["k"] == 3:
+                assert float(np.abs(g3[0]).max()) == 0.0 and float(np.abs(g3[2]).max()) == 0.0, name
+            for key, mine in (("kernel", g3[L["k"] // 2]), ("bias", eng._v(name, "b", eng.G).cpu().numpy())):
+                gk = ref["grads"][name + "/" + key]
+                if key == "bias" and float(np.abs(gk).max()) < 1e-9:
+                    continue                  # the bias of a conv in front of a normalisation: exactly zero gradient, only noise to compare
+                e = np.linalg.norm(mine - gk) / (np.linalg.norm(gk) + 1e-30)
+                assert e <= 5e-3, (name, key, e)
+        else:
+            for key in ("gamma", "beta"):
+                gk = ref["grads"][name + "/" + key]
+                e = np.linalg.norm(eng._v(name, key, eng.G).cpu().numpy() - gk) / (np.linalg.norm(gk) + 1e-30)
+                assert e <= 5e-3, (name, key, e)
+    # weights survive the Keras round trip in their 2-D shapes
+    Wx = eng.export_keras_weights()
+    assert set(Wx) == set(W) and all(Wx[k].shape == W[k].shape and np.array_equal(Wx[k], W[k]) for k in W)
+    # a few optimiser steps with random dropout reduce the loss; inference runs
+    eng.set_dropout_masks(None)
+    torch.manual_seed(0)
+    losses = [eng.metrics_from_sums(eng.train_step(xd, yd, 5e-3).cpu().numpy())["loss"] for _ in range(20)]
+    assert min(losses[-5:]) < losses[0], losses
+    eng.predict(xd)
+    torch.cuda.synchronize()
+    assert torch.isfinite(eng.probs).all()
+
+
+def test_isensee2d_bf16_engine_vs_fp32_and_model_surface(tmp_path, monkeypatch):
+    """2-D Isensee in bf16 (channels padded to 32, every conv - stride 2 and 1x1 included - on the planar MFMA kernels where the shape
+    tiles, generic kernels elsewhere) against the fp32 engine on the same weights / slices / dropout masks, then through the Keras-style
+    surface: fit_generator on (N,X,Y,C) batches, predict, save and load_old_model from the file alone."""
+    import fetal_net.model as fmodel
+    from fetal_net.training import load_old_model
+    from fmri_hip.graph_engine import LayerGraphEngine
+    from oracle import isensee_oracle as I
+    N, X, Y, C = 8, 64, 64, 5
+    kw = dict(input_shape=(X, Y, C), depth=3, n_base_filters=16, n_segmentation_levels=2, dropout_rate=0.3)
+    model = fmodel.isensee2017_model(**kw)
+    spec = I.IsenseeSpec(ndim=2, **kw)
+    W = spec.init_weights(4)
+    rs = np.random.RandomState(2)
+    x = rs.randn(N, X, Y, C).astype(np.float32)
+    y = (rs.rand(N, X, Y, 1) > 0.7).astype(np.uint8)
+    masks = {"spatial_dropout2d_%d" % (lv + 1): torch.tensor((rs.rand(N, spec.levels[lv]["filters"]) < 0.7).astype(np.float32) / 0.7).cuda()
+             for lv in range(3)}
+    yd = torch.from_numpy(y).cuda().reshape(-1).contiguous()
+    res = {}
+    for dt_ in (torch.float32, torch.bfloat16):
+        eng = LayerGraphEngine(model.layers, N, dtype=dt_)
+        eng.load_keras_weights(W)
+        eng.set_dropout_masks(masks)
+        eng.forward(torch.from_numpy(x).cuda().unsqueeze(0).to(dt_).contiguous())
+        s = eng.loss_forward(yd).cpu().numpy().copy()
+        eng.backward(yd)
+        torch.cuda.synchronize()
+        res[dt_] = (eng.logits.cpu().numpy().copy(), eng.metrics_from_sums(s)["dice_coefficient"], eng.G.cpu().numpy().copy(), eng.layout)
+    lf, df, gf, layout = res[torch.float32]
+    lb, db, gb, _ = res[torch.bfloat16]
+    bar("isensee2d_bf16.logits_rel_vs_f32", np.abs(lb - lf).max() / np.abs(lf).max(), 3e-2)
+    bar("isensee2d_bf16.dice_abs", abs(db - df), 1e-4)
+    for name, L in layout.items():
+        for key in (("w",) if L["kind"] == "conv" else ("gamma", "beta")):
+            o, n = L[key]
+            bar("isensee2d_bf16.grad_l2_rel_vs_f32", np.linalg.norm(gb[o:o + n] - gf[o:o + n]) / (np.linalg.norm(gf[o:o + n]) + 1e-30), 0.35)
+    # Keras-style surface
+    monkeypatch.setenv("FMRI_DTYPE", "bf16")
+    m = fmodel.isensee2017_model(**kw)
+    m.set_weights_dict(W)
+
+    def gen():
+        while True:
+            yield x, y
+
+    hist = m.fit_generator(generator=gen(), steps_per_epoch=4, epochs=2, validation_data=gen(), validation_steps=1, verbose=0)
+    assert len(hist.history["loss"]) == 2 and np.isfinite(hist.history["val_loss"]).all()
+    p = m.predict(x)
+    assert p.shape == (N, X, Y, 1) and np.isfinite(p).all() and 0.0 <= p.min() and p.max() <= 1.0
+    path = str(tmp_path / "isensee2d-epoch01-loss-0.100-acc0.900.h5")
+    m.save(path)
+    again = load_old_model(path, verbose=False)
+    assert [l.name for l in again.layers] == [l.name for l in m.layers]
+    np.testing.assert_allclose(again.predict(x), p, atol=1e-6)

@@ -51,6 +51,62 @@ def test_builder_graph_matches_reference(topo, case, fn, kw):
     assert getattr(model.loss, "__name__") == gold["compile"]["loss"]
 
 
+@pytest.mark.parametrize("case,kw", [
+    ("isensee2d_d3", dict(input_shape=(32, 32, 3), depth=3, n_base_filters=8, n_segmentation_levels=2)),
+    ("isensee2d_slices5", dict(input_shape=(128, 128, 5))),
+    ("isensee2d_summation", dict(input_shape=(64, 64, 5), depth=4, n_base_filters=8, summation=True, loss_function=FM.dice_and_xent)),
+])
+def test_isensee2d_builder_matches_reference(topo, case, kw):
+    """2-D Isensee (reference model/unet/isensee.py:14-105).  The fixture records every layer the reference builder CREATES; with
+    summation=False the deeper segmentation heads are created but reach no output, so a Keras Model drops them: `model.layers` must be
+    the recorded graph restricted to what the output depends on, under the recorded names (the dead heads still advance conv2d_N)."""
+    model = fmodel.isensee2017_model(**kw)
+    gold = topo[case]
+    assert [l.name for l in model._created_layers] == [l["name"] for l in gold["layers"]]
+    by = {l["name"]: l for l in gold["layers"]}
+    keep, stack = set(), [gold["layers"][-1]["name"]]
+    while stack:
+        n = stack.pop()
+        if n not in keep:
+            keep.add(n)
+            stack.extend(by[n]["inputs"])
+    live = [l for l in gold["layers"] if l["name"] in keep]
+    assert (len(live) < len(gold["layers"])) == (not kw.get("summation", False))
+    assert [l.name for l in model.layers] == [l["name"] for l in live]
+    for mine, ref in zip(model.layers, live):
+        assert list(mine.output_shape) == ref["output_shape"], mine.name
+        assert mine.inbound == ref["inputs"], mine.name
+        assert mine.class_name == ref["class"], mine.name
+    assert list(model.output_shape) == gold["output_shape"]
+    assert model.optimizer.lr == gold["compile"]["optimizer"]["lr"]
+    assert model.metrics_names[1:] == gold["compile"]["metrics"]
+    assert getattr(model.loss, "__name__") == gold["compile"]["loss"]
+    # the oracle twin owns exactly the model's weights
+    from fetal_net import keras_h5
+    from oracle import isensee_oracle as I
+    okw = {k: v for k, v in kw.items() if k != "loss_function"}
+    okw.setdefault("n_segmentation_levels", 3)
+    W = I.IsenseeSpec(ndim=2, **okw).init_weights(1)
+    shapes = keras_h5.weight_shapes(model)
+    assert list(shapes) and set(shapes) == set(W) and all(tuple(W[k].shape) == tuple(shapes[k]) for k in W)
+    assert model.count_params() == sum(int(v.size) for v in W.values())
+
+
+def test_isensee2d_checkpoint_header_round_trip(tmp_path):
+    """model_config of a saved 2-D Isensee file is enough to rebuild the builder call (load_old_model without a config)"""
+    from fetal_net import keras_h5
+    for kw in (dict(input_shape=(32, 32, 3), depth=3, n_base_filters=8, n_segmentation_levels=2),
+               dict(input_shape=(32, 32, 3), depth=3, n_base_filters=8, n_segmentation_levels=2, summation=True)):
+        model = fmodel.isensee2017_model(**kw)
+        name, got = keras_h5.infer_builder(keras_h5.model_config(model), keras_h5.training_config(model))
+        assert name == "isensee2017_model"
+        for k in ("input_shape", "depth", "n_base_filters", "n_segmentation_levels"):
+            assert tuple(np.atleast_1d(got[k])) == tuple(np.atleast_1d(kw[k])), k
+        assert got["summation"] == kw.get("summation", False)
+        again = fmodel.isensee2017_model(**{k: v for k, v in got.items() if k != "loss_function"})
+        assert [l.name for l in again.layers] == [l.name for l in model.layers]
+
+
 def test_train_fetal_call_signature(topo):
     # exactly how reference fetal/train_fetal.py:33-39 calls a builder (unknown kwargs are swallowed)
     m = fmodel.unet_model_3d(input_shape=[1, 32, 32, 16], initial_learning_rate=1e-4,
@@ -174,8 +230,9 @@ def test_unsupported_topologies_fail_loudly():
     m = fmodel.unet_model_3d(input_shape=(1, 16, 16, 16), depth=2, activation_name="softmax")
     with pytest.raises(NotImplementedError):
         m.predict(np.zeros((1, 1, 16, 16, 16)))
+    m2 = fmodel.isensee2017_model(input_shape=(32, 32, 5), activation_name="softmax")      # built, but not runnable on the engine
     with pytest.raises(NotImplementedError):
-        fmodel.isensee2017_model(input_shape=(32, 32, 5))
+        m2.predict(np.zeros((1, 32, 32, 5)))
 
 
 def test_nifti_reader_big_endian_scaled_with_affine(tmp_path):
