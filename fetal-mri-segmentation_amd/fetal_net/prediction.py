@@ -319,8 +319,8 @@ def run_validation_case(data_index, output_dir, model, data_file, training_modal
 def run_validation_cases(validation_keys_file, model_file, training_modalities, hdf5_file, patch_shape, output_dir=".",
                          overlap_factor=0, permute=False, prev_truth_index=None, prev_truth_size=None, use_augmentations=False,
                          data_file=None, model=None):
-    """reference prediction.py:333-351.  `hdf5_file` is opened with PyTables when that is installed; callers may instead
-    pass an already opened duck-typed `data_file` (and a `model`)."""
+    """reference prediction.py:333-351.  `hdf5_file` is opened with `fetal_net.data.open_data_file` (plain-layout files through libhdf5,
+    PyTables files through PyTables when installed); callers may instead pass an already opened duck-typed `data_file` (and a `model`)."""
     import glob
     import pickle
     from .training import load_old_model
@@ -331,8 +331,8 @@ def run_validation_cases(validation_keys_file, model_file, training_modalities, 
         model = load_old_model(max(candidates, key=os.path.getmtime))      # newest checkpoint (reference fetal/utils.py:42-43)
     own = data_file is None
     if own:
-        import tables
-        data_file = tables.open_file(hdf5_file, "r")
+        from .data import open_data_file
+        data_file = open_data_file(hdf5_file, "r")
     has_ids = 'subject_ids' in data_file.root
 
     def case_dir(index):

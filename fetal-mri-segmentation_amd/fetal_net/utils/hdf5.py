@@ -380,14 +380,28 @@ class Group(object):
         if "/" in name.strip("/"):
             parent = self.create_group(name.rsplit("/", 1)[0])
             parent.close()
-        t = _native_of(arr.dtype)
+        own_type = False
+        if arr.dtype.kind == "U":
+            arr = np.char.encode(arr, "utf8")
+        if arr.dtype.kind == "S":                                      # fixed-length, NUL-padded byte strings (numpy 'S'; PyTables / h5py layout)
+            arr = _c_order(arr)
+            t = _check(L.H5Tcopy(_g("H5T_C_S1_g")), "H5Tcopy")
+            L.H5Tset_size(t, max(arr.dtype.itemsize, 1))
+            L.H5Tset_strpad(t, 1)                                      # H5T_STR_NULLPAD
+            own_type = True
+        else:
+            t = _native_of(arr.dtype)
         space = _space_of(arr.shape)
         did = L.H5Dcreate2(self.id, name.encode(), t, space, 0, 0, 0)
         if did < 0:
             L.H5Sclose(space)
+            if own_type:
+                L.H5Tclose(t)
             raise OSError("HDF5: cannot create dataset %r in %s (name already in use?)" % (name, self.name))
         rc = L.H5Dwrite(did, t, 0, 0, 0, arr.ctypes.data_as(C.c_void_p)) if arr.size else 0
         L.H5Sclose(space)
+        if own_type:
+            L.H5Tclose(t)
         if rc < 0:
             L.H5Dclose(did)
             raise OSError("HDF5: H5Dwrite(%s) failed" % name)
