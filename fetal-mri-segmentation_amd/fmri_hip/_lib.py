@@ -49,6 +49,10 @@ SIGNATURES = {
     "fmri_conv3d_direct_bwd": [p, p, p, p, p, p, i32, i32, i32, i32, i32, i32, i32, i32, i32, p],
     "fmri_conv2d_direct_fwd": [p, p, p, p, i32, i32, i32, i32, i32, i32, i32, i32, f32, i32, p],
     "fmri_conv2d_direct_bwd": [p, p, p, p, p, p, i32, i32, i32, i32, i32, i32, i32, i32, p],
+    "fmri_correlate1d_f64": [p, p, i32, i32, i32, i32, p, i32, p],
+    "fmri_threshold_f64": [p, p, i64, C.c_double, p],
+    "fmri_fill_holes_step": [p, p, p, i32, i32, i32, i32, i32, p, p],
+    "fmri_largest_component_step": [p, p, p, p, p, i32, i32, i32, i32, i32, p, p],
     "fmri_add": [p, p, p, i64, i32, p],
     "fmri_act_bwd": [p, p, p, i32, f32, i64, i32, p],
     "fmri_slice_channels": [p, i32, i32, p, i32, i64, i32, i32, p],

@@ -423,3 +423,77 @@ def conv3d_upcat_wgrad(src0_low, src1, dy, dw, db, dwc_scratch, workspace=None, 
     check(lib().fmri_conv3d_upcat_wgrad(_p(src0_low), C0, _p(src1), C1, _p(dy), _p(dw), _p(db), _p(dwc_scratch), N, D, H, W, Cout, dt(dy),
                                         _p(workspace), nws, _s()),
           "fmri_conv3d_upcat_wgrad")
+
+
+# ---------------------------------------------------------------------------------------------------- post-processing (fetal_net.postprocess)
+def gaussian_filter_f64(vol, sigma, truncate=4.0):
+    """scipy.ndimage.gaussian_filter(vol, sigma) (order 0, mode 'reflect') of a float64 device volume [X,Y,Z]: three separable passes with
+    scipy's own weights and summation order - bit-identical to the host result"""
+    import numpy as np
+    _need_cuda(vol)
+    assert vol.dtype == torch.float64 and vol.dim() == 3
+    X, Y, Z = vol.shape
+    sig = [float(sigma)] * 3 if np.isscalar(sigma) else [float(v) for v in sigma]
+    a, b = vol, None
+    for axis, sd in enumerate(sig):
+        if sd <= 1e-15:                                       # scipy skips an axis whose sigma is ~0
+            continue
+        radius = int(truncate * sd + 0.5)
+        x = np.arange(-radius, radius + 1)
+        phi = np.exp(-0.5 / (sd * sd) * x ** 2)               # scipy.ndimage._filters._gaussian_kernel1d, order 0
+        w = torch.from_numpy(phi / phi.sum()).cuda()
+        b = torch.empty_like(vol)
+        check(lib().fmri_correlate1d_f64(_p(a), _p(b), X, Y, Z, axis, _p(w), radius, _s()), "fmri_correlate1d_f64")
+        a = b
+    return a if a is not vol else vol.clone()
+
+
+def threshold_f64(vol, thr):
+    _need_cuda(vol)
+    out = torch.empty(vol.shape, dtype=torch.uint8, device=vol.device)
+    check(lib().fmri_threshold_f64(_p(vol), _p(out), vol.numel(), float(thr), _s()), "fmri_threshold_f64")
+    return out
+
+
+def _until_stable(step, sweeps=16, limit=100000):
+    """run `step(sweeps, changed)` until a batch of sweeps changes nothing (one 4-byte read-back per batch)"""
+    changed = torch.zeros(1, dtype=torch.int32, device="cuda")
+    done = 0
+    while done < limit:
+        changed.zero_()
+        step(sweeps, changed)
+        done += sweeps
+        if int(changed.item()) == 0:
+            return done
+    raise RuntimeError("label propagation did not converge")
+
+
+def binary_fill_holes_u8(mask):
+    """scipy.ndimage.binary_fill_holes (default 6-connectivity) of a uint8 0/1 device volume"""
+    _need_cuda(mask)
+    assert mask.dtype == torch.uint8 and mask.dim() == 3
+    X, Y, Z = mask.shape
+    reached, out = torch.empty_like(mask), torch.empty_like(mask)
+    L = lib()
+    check(L.fmri_fill_holes_step(_p(mask), _p(reached), 0, X, Y, Z, 0, 0, 0, _s()), "fmri_fill_holes_step")
+    _until_stable(lambda n, ch: check(L.fmri_fill_holes_step(_p(mask), _p(reached), 0, X, Y, Z, 1, n, _p(ch), _s()), "fmri_fill_holes_step"))
+    check(L.fmri_fill_holes_step(_p(mask), _p(reached), _p(out), X, Y, Z, 2, 0, 0, _s()), "fmri_fill_holes_step")
+    return out
+
+
+def largest_component_u8(mask):
+    """mask of the largest 6-connected component (scipy.ndimage.label + argmax of the sizes; all zero when there is no foreground)"""
+    _need_cuda(mask)
+    assert mask.dtype == torch.uint8 and mask.dim() == 3
+    X, Y, Z = mask.shape
+    n = mask.numel()
+    labels = torch.empty(n, dtype=torch.int32, device=mask.device)
+    counts = torch.empty(n + 1, dtype=torch.int32, device=mask.device)
+    best = torch.empty(1, dtype=torch.int64, device=mask.device)
+    out = torch.empty_like(mask)
+    L = lib()
+    check(L.fmri_largest_component_step(_p(mask), _p(labels), 0, 0, 0, X, Y, Z, 0, 0, 0, _s()), "fmri_largest_component_step")
+    _until_stable(lambda k, ch: check(L.fmri_largest_component_step(0, _p(labels), 0, 0, 0, X, Y, Z, 1, k, _p(ch), _s()),
+                                      "fmri_largest_component_step"), sweeps=8)
+    check(L.fmri_largest_component_step(0, _p(labels), _p(counts), _p(best), _p(out), X, Y, Z, 2, 0, 0, _s()), "fmri_largest_component_step")
+    return out

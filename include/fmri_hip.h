@@ -263,6 +263,22 @@ int fmri_noise_augment(void* x, int64_t n, int dtype, const float* stats, const 
 /* ---- plumbing: dtype casts used around the boundary (fp32 <-> bf16), n elements */
 int fmri_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, fmri_stream_t stream);
 
+/* ---- post-processing of a predicted probability volume [X][Y][Z] (reference fetal_net/postprocess.py:7-19, used by
+ * prod/predict_nifti2.py:77-95): scipy.ndimage.gaussian_filter -> "> threshold" -> binary_fill_holes -> largest connected component.
+ * fmri_correlate1d_f64: one axis of the separable gaussian, mode 'reflect', weights [2*radius+1] fp64 on the device (the caller computes
+ *   them as scipy does); sums in scipy's order, so three calls (axis 0, 1, 2) reproduce gaussian_filter bit for bit.  src != dst.
+ * fmri_fill_holes_step / fmri_largest_component_step: phase 0 = initialise, phase 1 = `sweeps` propagation sweeps (6-connectivity;
+ *   *changed, a device int the caller zeroes, is set while the region still grows: repeat phase 1 until it stays 0), phase 2 = write the
+ *   result mask (uint8 0/1).  Largest component: ties go to the component whose first voxel comes first in C order (scipy's numbering);
+ *   counts = int32 [X*Y*Z + 1] scratch, best = 8-byte scratch. */
+int fmri_correlate1d_f64(const double* src, double* dst, int X, int Y, int Z, int axis, const double* weights, int radius,
+                         fmri_stream_t stream);
+int fmri_threshold_f64(const double* src, uint8_t* dst, int64_t n, double threshold, fmri_stream_t stream);
+int fmri_fill_holes_step(const uint8_t* mask, uint8_t* reached, uint8_t* out, int X, int Y, int Z, int phase, int sweeps, int* changed,
+                         fmri_stream_t stream);
+int fmri_largest_component_step(const uint8_t* mask, int32_t* labels, int32_t* counts, unsigned long long* best, uint8_t* out, int X, int Y,
+                                int Z, int phase, int sweeps, int* changed, fmri_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
