@@ -1284,15 +1284,40 @@ k_conv_wgrad_mfma(SrcB s, const bf16_t* __restrict__ dy, float* __restrict__ dw,
         y_doff[j] = X_BYTES + instr * 1024;
     }
     const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr(lds));
-    auto issue = [&](int u, int buf) {
-        // unit index = column (n, h-tile, w-tile) x D + d: d runs fastest, and a workgroup walks a CONTIGUOUS run of units, i.e. up a column.
-        // The three kd workgroups of a slab then read x planes d-1, d, d+1 at step d and d, d+1, d+2 at the next: two of the three planes (and
-        // the dy plane all three share) were fetched a step ago by a neighbour on the same XCD, so they come out of L2 instead of HBM.
+    // ---- DMA address generation.  A workgroup issues the units of its run strictly in order, so the issue side keeps a CURSOR (n, h0, w0, d)
+    // that is advanced by one unit per call - no divisions in the loop - and everything that only depends on the column (n, h0, w0): the
+    // per-lane element offset of each x piece inside a plane and whether that halo row lies inside the volume, is worked out once per
+    // column.  Per unit what is left is two scalar 64-bit bases and, per DMA instruction, one 64-bit add and a select.  (Round 1 redid the
+    // whole decode - six divisions by run-time values, ~25 VALU instructions per piece - at every unit: tools/prof_wgrad.py showed a wave
+    // spending 40-50 % of its time between the barrier and its first MFMA.)
+    // unit index = column (n, h-tile, w-tile) x D + d: d runs fastest, and a workgroup walks a CONTIGUOUS run of units, i.e. up a column.
+    // The three kd workgroups of a slab then read x planes d-1, d, d+1 at step d and d, d+1, d+2 at the next: two of the three planes (and
+    // the dy plane all three share) were fetched a step ago by a neighbour on the same XCD, so they come out of L2 instead of HBM.
+    int ic_n = 0, ic_h0 = 0, ic_w0 = 0, ic_d = 0;
+    int x_off[XPW];                // element offset of this lane's 16 bytes inside an x plane of the cursor's column
+    unsigned x_ok = 0;             // bit j: piece j of this lane lies inside the volume in h and w
+    auto col_setup = [&]() {
+        x_ok = 0;
+#pragma unroll
+        for (int j = 0; j < XPW; ++j) {
+            const int pk = x_pack[j];
+            const int gh = ic_h0 - 1 + (pk & 15), gw = ic_w0 - 1 + ((pk >> 4) & 31);
+            const bool ok = (pk >> 12) && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W;
+            const int ghc = min(max(gh, 0), H - 1) >> sh, gwc = min(max(gw, 0), W - 1) >> sh;
+            x_off[j] = (ghc * sW + gwc) * sC + ((pk >> 9) & 7) * 8;
+            x_ok |= (ok ? 1u : 0u) << j;
+        }
+    };
+    auto cursor_set = [&](int u) {
         int q = u;
-        const int d = q % D; q /= D;
-        const int w0 = (q % twn) * TW; q /= twn;
-        const int h0 = (q % thn) * TH;
-        const int n = q / thn;
+        ic_d = q % D; q /= D;
+        ic_w0 = (q % twn) * TW; q /= twn;
+        ic_h0 = (q % thn) * TH;
+        ic_n = q / thn;
+        col_setup();
+    };
+    auto issue = [&](int buf) {
+        const int n = ic_n, h0 = ic_h0, w0 = ic_w0, d = ic_d;
         const int gd = d + kd - 1;
         const bool dok = (unsigned)gd < (unsigned)D;
         const int gdc = min(max(gd, 0), D - 1) >> shd;
@@ -1302,17 +1327,23 @@ k_conv_wgrad_mfma(SrcB s, const bf16_t* __restrict__ dy, float* __restrict__ dw,
                             : dy + ((((int64_t)n * 2 * D + 2 * d + (par >> 2)) * 2 * H + 2 * h0 + ((par >> 1) & 1)) * 2 * W + 2 * w0 + (par & 1)) * Cout + co0)
                 : dy + ((((int64_t)n * D + d) * H + h0) * W + w0) * Cout + co0;
         const unsigned sbase = lds0 + buf * STAGE_BYTES;
+        const unsigned okm = dok ? x_ok : 0u;
 #pragma unroll
-        for (int j = 0; j < XPW; ++j) {
-            const int pk = x_pack[j];
-            const int gh = h0 - 1 + (pk & 15), gw = w0 - 1 + ((pk >> 4) & 31);
-            const bool ok = dok && (pk >> 12) && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W;
-            const int ghc = min(max(gh, 0), H - 1) >> sh, gwc = min(max(gw, 0), W - 1) >> sh;
-            const bf16_t* real = xbase + ((ghc * sW + gwc) * sC + ((pk >> 9) & 7) * 8);
-            dma16(ok ? (const void*)real : (const void*)g_zero_page, __builtin_amdgcn_readfirstlane(sbase + x_doff[j]));
-        }
+        for (int j = 0; j < XPW; ++j)
+            dma16(((okm >> j) & 1) ? (const void*)(xbase + x_off[j]) : (const void*)g_zero_page, __builtin_amdgcn_readfirstlane(sbase + x_doff[j]));
 #pragma unroll
         for (int j = 0; j < YPW; ++j) dma16(ybase + y_soff[j], __builtin_amdgcn_readfirstlane(sbase + y_doff[j]));
+        // advance the cursor: up the column, then on to the next column of the run
+        if (++ic_d == D) {
+            ic_d = 0;
+            ic_w0 += TW;
+            if (ic_w0 == W) {
+                ic_w0 = 0;
+                ic_h0 += TH;
+                if (ic_h0 == H) { ic_h0 = 0; ++ic_n; }
+            }
+            col_setup();
+        }
     };
 
     // ---- per-lane constants of the transposing fragment reads.  A row index is (lane part) + (wave-uniform constant c);
@@ -1336,8 +1367,11 @@ k_conv_wgrad_mfma(SrcB s, const bf16_t* __restrict__ dy, float* __restrict__ dw,
     unsigned long long wprof[12] = {};
     PROF_T(wk0);
 #endif
-    if (u < u_end && (!WS || producer)) issue(u, 0);
-    if (WS && producer && u + 1 < u_end) issue(u + 1, 1);
+    if (u < u_end && (!WS || producer)) {
+        cursor_set(u);
+        issue(0);
+    }
+    if (WS && producer && u + 1 < u_end) issue(1);
     for (; u < u_end; ++u, buf = (buf + 1 == NSTAGE ? 0 : buf + 1)) {
         const bool more = (u + 1) < u_end;
         PROF_T(w0);
@@ -1356,8 +1390,8 @@ k_conv_wgrad_mfma(SrcB s, const bf16_t* __restrict__ dy, float* __restrict__ dw,
         __builtin_amdgcn_s_barrier();
         PROF_T(w2);
         if (WS) {
-            if (producer && u + 2 < u_end) issue(u + 2, buf == 0 ? 2 : buf - 1);          // = (buf + 2) % 3: the slot of the previous unit
-        } else if (more) issue(u + 1, buf ^ 1);
+            if (producer && u + 2 < u_end) issue(buf == 0 ? 2 : buf - 1);                 // = (buf + 2) % 3: the slot of the previous unit
+        } else if (more) issue(buf ^ 1);
         PROF_T(w3);
         if (producer) continue;
         const unsigned char* const sb = lds + buf * STAGE_BYTES;

@@ -7,6 +7,7 @@ engine and overlap-added in float64 on the device (fmri_tile_scatter_accumulate 
 tile-batch size replays gather -> network -> scatter.  Any other object with `.output_shape` / `.predict(ndarray)` (the
 reference's duck-typing contract) is driven through the same geometry with host-side tiles.
 """
+import gc
 import itertools
 import os
 
@@ -169,8 +170,19 @@ def _device_overlap_add(model, data_0, indices, patch_shape, batch_size, data_sh
                 torch.cuda.current_stream().wait_stream(side)
                 torch.cuda.synchronize()
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
-                    body()
+                # No cyclic garbage collection while the stream is capturing: a collector run that happens to free an old CUDAGraph /
+                # stream / event (the per-batch closures above sit in reference cycles, so earlier tile states die by the cycle
+                # collector, at an arbitrary allocation) destroys HIP objects mid-capture, which HIP refuses - and a failing destructor
+                # aborts the process.  Collect now, outside the capture, and keep the collector off until the capture has ended.
+                gc_was_on = gc.isenabled()
+                gc.collect()
+                gc.disable()
+                try:
+                    with torch.cuda.graph(g):
+                        body()
+                finally:
+                    if gc_was_on:
+                        gc.enable()
                 pb["graph"] = g
             st["per_b"][B] = pb
         model.__dict__["_tile_state"] = st
