@@ -1524,42 +1524,47 @@ k_conv_wgrad_mfma(SrcB s, const bf16_t* __restrict__ dy, float* __restrict__ dw,
 }
 
 // ============================================================================================ weight gradient, kd-sharing form
-// EXPERIMENTAL, off by default (FMRI_WGRAD_KD=1|2 enables it): measured 8-25 % SLOWER than k_conv_wgrad_mfma on MI355X, see DESIGN.md.
 // The kernel above gives every (kd, Cout block, Cin block) its own workgroup, so each x plane and each dy plane is staged by three
-// workgroups (rocprofv3: 1.78x the algorithmic HBM bytes, 135 B of LDS-DMA per MFMA) and a wave reads one x fragment per MFMA (1.11 KB
-// of LDS reads per MFMA).  Here ONE workgroup (8 waves, one per CU) owns a (64 Cout, 64 Cin) block for ALL 27 taps and walks up a column
-// of d-plane tiles with
-//   * a 4-slot ring of x planes (d-1, d, d+1 in use, d+2 in flight) and a 2-slot ring of dy planes: one new x plane + one dy plane per
-//     step feed 3 x 288 MFMAs - a third of the DMA per MFMA, and every plane is fetched once per (Cout, Cin) block pair;
-//   * wave = (Cin half, tap group of 7 | 7 | 7 | 6) holding 64 (Cout) x 32 (Cin) accumulators per tap: an x fragment serves TWO MFMAs
-//     (both Cout halves), 0.64 KB of LDS reads per MFMA.
-// What it costs: 14 accumulator tiles = 224 of the 256 registers two waves per SIMD leave a wave.  The fragment pipeline is squeezed to
-// one x fragment ahead (an LDS wait every second MFMA) and hipcc still spills ~30 registers per unit; with ONE barrier domain per CU
-// nothing overlaps a unit's hand-over, whereas two independent 4-wave workgroups of the kernel above cover each other's.  Bit-identical
-// results (exact tests at full size pass); variants tried on the same skeleton and dropped: 12 waves = (kd, Cout half, Cin half) with 144
-// accumulator registers under the 168-register budget of three waves per SIMD (spills inside the MFMA loop, 3x slower), and a
-// (32 Cout, 64 Cin) block with 112 accumulator registers and a 5-deep fragment ring (no spills, still 4-7 % slower on dec0b / dec1b):
-// the DMA instruction stream is NOT what limits the weight gradient.
-namespace wk {
-constexpr int NTHREADS = 512;
-constexpr int X_INSTR = 23, Y_INSTR = 16;              // DMA wave-instructions per x plane (180 rows x 128 B + pad) / dy plane (128 x 128 B)
-constexpr int XS_BYTES = X_INSTR * 1024, YS_BYTES = Y_INSTR * 1024;
-constexpr int NXS = 4, NYS = 2;
-constexpr int LDS_BYTES = NXS * XS_BYTES + NYS * YS_BYTES;     // 126,976
-}  // namespace wk
+// workgroups: 135 B of LDS-DMA per MFMA, and tools/prof_wgrad.py shows its waves waiting for planes they requested a whole unit earlier
+// (~20 MB of DMA requests in flight chip-wide): the weight gradient is bound by its LDS-DMA stream.  Here a workgroup owns a (Cout, Cin)
+// block for ALL 27 taps and walks up a column of d-plane tiles with a 4-slot ring of x planes (d-1, d, d+1 in use, d+2 in flight) and a
+// 2-slot ring of dy planes: one new x plane + one dy plane per step feed all three kd.  wave = tap group of 7 | 7 | 7 | 6 taps.
+//   BLK = 32: (32 Cout, 32 Cin) block, 4 waves, TWO workgroups per CU (64 KiB of LDS each) - two independent barrier domains, as in the
+//             kernel above; 112 accumulator registers per wave leave room for a 4-deep fragment ring.  19.5 KB of DMA per 216 MFMAs =
+//             90 B per MFMA (-33 %).
+//   BLK = 64: (64 Cout, 64 Cin) block, 8 waves = (Cin half, tap group), ONE workgroup per CU; an x fragment serves two MFMAs (both Cout
+//             halves: 0.64 KB of LDS reads per MFMA) and the DMA drops to 45 B per MFMA - but 224 of a wave's 256 registers are accumulators:
+//             the fragment pipeline is one read deep, hipcc spills ~30 registers per unit, and a single barrier domain per CU overlaps nothing.
+//             Measured 8-25 % SLOWER than the per-kd kernel; kept for the record (FMRI_WGRAD_KD_BLK=64).
+// Flush: fp32 atomics (128 contiguous bytes per half-wave).  Bit-identical sums on exactly representable data (tests).
+template <int BLK>
+struct WkCfg {
+    static constexpr int NW = BLK == 64 ? 8 : 4;                 // waves per workgroup (all of them issue DMA)
+    static constexpr int NH = BLK == 64 ? 2 : 1;                 // Cout halves (32 channels each) per wave
+    static constexpr int ROWB = BLK * 2;                          // bytes per x / dy row in LDS
+    static constexpr int RS = ROWB / 16;                          // 16-byte slots per row
+    static constexpr int X_INSTR = (wg::XROWS * RS + 63) / 64;    // DMA wave-instructions per x plane: 23 / 12
+    static constexpr int Y_INSTR = wg::YROWS * RS / 64;           // ... per dy plane: 16 / 8
+    static constexpr int XS_BYTES = X_INSTR * 1024, YS_BYTES = Y_INSTR * 1024;
+    static constexpr int NXS = 4, NYS = 2;
+    static constexpr int LDS_BYTES = NXS * XS_BYTES + NYS * YS_BYTES;      // 126,976 / 65,536
+    static constexpr int PF = BLK == 64 ? 1 : 3;                  // x fragments in flight ahead of their MFMAs
+    static constexpr int XPW = (X_INSTR + NW - 1) / NW, YPW = (Y_INSTR + NW - 1) / NW;
+};
 
-template <int G>   // tap group: taps 7G .. 7G + NTAP - 1 of the 27
+template <int BLK, int G>   // tap group: taps 7G .. 7G + NTAP - 1 of the 27
 __device__ __forceinline__ void wk_compute(const unsigned char* lds, const int (&xb)[3], int yb, const int (&pre_x)[4], int pre_y,
-                                           f32x16 (&acc)[G == 3 ? 6 : 7][2], float (&bsum)[2], bool do_bias) {
-    constexpr int NTAP = G == 3 ? 6 : 7, T0 = 7 * G;
+                                           f32x16 (&acc)[G == 3 ? 6 : 7][WkCfg<BLK>::NH], float (&bsum)[2], bool do_bias) {
+    typedef WkCfg<BLK> K;
+    constexpr int NTAP = G == 3 ? 6 : 7, T0 = 7 * G, NH = K::NH, ROWB = K::ROWB;
     typedef __attribute__((ext_vector_type(8))) short s16x8;
-    auto load_a = [&](int ks8, s16x8 (&av)[2]) {
+    auto load_a = [&](int ks8, s16x8 (&av)[NH]) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < NH; ++h) {
             // the second Cout half sits 4 slots further: bit 6 of the in-row offset
-            const unsigned char* p0 = lds + yb + (h ? (pre_y ^ 64) : pre_y) + ks8 * wg::TW * 128;
+            const unsigned char* p0 = lds + yb + (h ? (pre_y ^ 64) : pre_y) + ks8 * wg::TW * ROWB;
             s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p0);
-            s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p0 + 4 * 128));
+            s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p0 + 4 * ROWB));
             av[h] = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
         }
     };
@@ -1568,24 +1573,25 @@ __device__ __forceinline__ void wk_compute(const unsigned char* lds, const int (
     auto load_b = [&](int st) {
         const int ks8 = st / NTAP, t = T0 + st % NTAP, kd = t / 9, kh = (t / 3) % 3, kw = t % 3;
         const int c = (ks8 + kh) * wg::XW + kw;
-        const unsigned char* pb = lds + xb[kd] + pre_x[c & 3] + (c >> 2) * 4 * 128;
+        const unsigned char* pb = lds + xb[kd] + pre_x[c & 3] + (c >> 2) * 4 * ROWB;
         s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)pb);
-        s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(pb + 4 * 128));
+        s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(pb + 4 * ROWB));
         return __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
     };
-    // Fixed register budget: the dy fragments of a k-step are single-buffered, the x fragments run one step ahead of their MFMAs in a
-    // 2-deep register ring; sched_barrier keeps the compiler from hoisting more reads (left alone it spills > 3,000 registers).
-    constexpr int NS = 8 * NTAP;
-    s16x8 av[2], b[2];
-    b[0] = load_b(0);
+    // Fixed register budget: the dy fragments of a k-step are single-buffered, the x fragments run PF steps ahead of their MFMAs in a
+    // register ring; sched_barrier keeps the compiler from hoisting more reads (left alone it spills thousands of registers at BLK = 64).
+    constexpr int NS = 8 * NTAP, PF = K::PF, RING = PF + 1;
+    s16x8 av[NH], b[RING];
+#pragma unroll
+    for (int q = 0; q < PF; ++q) b[q] = load_b(q);
 #pragma unroll
     for (int ks8 = 0; ks8 < 8; ++ks8) {
         load_a(ks8, av);
         if constexpr (G == 3) {
             if (do_bias) {
-                // bias gradient = sum of the dy fragments (this group has 32 registers to spare)
+                // bias gradient = sum of the dy fragments (the 6-tap group has registers to spare)
 #pragma unroll
-                for (int h = 0; h < 2; ++h)
+                for (int h = 0; h < NH; ++h)
 #pragma unroll
                     for (int q = 0; q < 8; ++q) bsum[h] += bf2f((unsigned short)av[h][q]);
             }
@@ -1593,10 +1599,10 @@ __device__ __forceinline__ void wk_compute(const unsigned char* lds, const int (
 #pragma unroll
         for (int j = 0; j < NTAP; ++j) {
             const int st = ks8 * NTAP + j;
-            if (st + 1 < NS) b[(st + 1) & 1] = load_b(st + 1);
-            const bf16x8_t bb = __builtin_bit_cast(bf16x8_t, b[st & 1]);
+            if (st + PF < NS) b[(st + PF) % RING] = load_b(st + PF);
+            const bf16x8_t bb = __builtin_bit_cast(bf16x8_t, b[st % RING]);
 #pragma unroll
-            for (int h = 0; h < 2; ++h)
+            for (int h = 0; h < NH; ++h)
                 acc[j][h] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, av[h]), bb, acc[j][h], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -1612,20 +1618,19 @@ struct WkArgs {
 };
 
 // everything a wave does, instantiated per tap group so that the accumulators are one fixed register set for the kernel's lifetime
-template <int G>
+template <int BLK, int G>
 __device__ __forceinline__ void wk_run(const WkArgs& a, unsigned char* lds, int wv, int lane) {
-    using namespace wk;
-    constexpr int NTAP = G == 3 ? 6 : 7;
-    constexpr int NW = 8;                                  // waves per workgroup (all of them issue DMA)
+    typedef WkCfg<BLK> K;
+    constexpr int NTAP = G == 3 ? 6 : 7, NW = K::NW, NH = K::NH, ROWB = K::ROWB, RS = K::RS;
     const SrcB& s = a.s;
     const int N = a.N, D = a.D, H = a.H, W = a.W, Cout = a.Cout;
     const int Cin = s.C0 + s.C1;
-    const int ncib = Cin / 64, ncob = Cout / 64;
+    const int ncib = Cin / BLK, ncob = Cout / BLK;
     const int ncombo = ncob * ncib;
     const int wg_id = xcd_logical_id(blockIdx.x, gridDim.x);      // the (Cout, Cin) blocks of one slab (same planes) on one XCD / L2
     const int combo = wg_id % ncombo, slab = wg_id / ncombo;
     const int cib = combo % ncib, cob = combo / ncib;
-    const int co0 = cob * 64, cc = cib * 64;
+    const int co0 = cob * BLK, cc = cib * BLK;
 
     const bool from0 = cc < s.C0;
     const bf16_t* sp = from0 ? s.p0 : s.p1;
@@ -1636,15 +1641,15 @@ __device__ __forceinline__ void wk_run(const WkArgs& a, unsigned char* lds, int 
     const int sD = D >> shd, sH = H >> sh, sW = W >> sh;
 
     const int r = lane & 31, hk = lane >> 5;
-    const int it = wv >> 2;                                // Cin half; waves g and g + 4 share a SIMD
-    // bias gradient = sum over the dy fragments: in the 6-tap group (it has registers to spare) of Cin half 0
+    const int it = BLK == 64 ? (wv >> 2) : 0;              // Cin half (BLK = 64: waves g and g + 4 share a SIMD)
+    // bias gradient = sum over the dy fragments: in the 6-tap group (it has registers to spare) of Cin half 0 / Cin block 0
     const bool do_bias = G == 3 && (a.db != nullptr) && cib == 0 && it == 0;
 
-    f32x16 acc[NTAP][2];
+    f32x16 acc[NTAP][NH];
 #pragma unroll
     for (int q = 0; q < NTAP; ++q)
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
+        for (int h = 0; h < NH; ++h)
 #pragma unroll
             for (int k = 0; k < 16; ++k) acc[q][h][k] = 0.f;
     float bsum[2] = {0.f, 0.f};
@@ -1653,54 +1658,59 @@ __device__ __forceinline__ void wk_run(const WkArgs& a, unsigned char* lds, int 
     const int nunits = N * D * thn * twn;
     const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr(lds));
 
-    // ---- DMA: a unit's 39 wave-instructions (23 for an x plane, 16 for a dy plane) are dealt round-robin over the NW waves.
-    // plane `gd` (may lie outside the volume: zeros) of column (n, h0, w0) into x slot `slot`.
-    // (`ln` = the lane id behind an empty asm: the per-lane address pieces are recomputed at every call - a few dozen VALU instructions -
-    // instead of being hoisted out of the unit loop into ~20 long-lived registers the accumulators leave no room for)
-    auto issue_x = [&](int n, int h0, int w0, int gd, int slot) {
-        int ln = lane;
-        asm volatile("" : "+v"(ln));
+    // ---- DMA.  A unit's wave-instructions (X_INSTR for an x plane, Y_INSTR for a dy plane) are dealt round-robin over the NW waves.  The
+    // issue side keeps a cursor (cn, ch0, cw0) of the column being issued and, per column, the lane constants of its pieces: element offset
+    // inside a plane and whether that halo row lies inside the volume (bit j of x_ok); per plane what is left is a scalar base, one 64-bit add
+    // and a select per instruction.
+    int cn = 0, ch0 = 0, cw0 = 0;
+    int x_off[K::XPW], y_off[K::YPW];
+    unsigned x_ok = 0;
+    auto col_setup = [&](int n, int h0, int w0) {
+        cn = n; ch0 = h0; cw0 = w0;
+        x_ok = 0;
+#pragma unroll
+        for (int k = 0; k < K::XPW; ++k) {
+            const int id = wv + NW * k;
+            const int i = id * 64 + lane;
+            const int row = i / RS, ps = i % RS;
+            const int ls = RS == 8 ? (ps ^ (((row >> 1) & 1) << 2)) : ps;       // 128-byte rows flip their halves on row bit 1 (wg_slot_off)
+            const int xh = row / wg::XW, xw = row % wg::XW;
+            const int gh = h0 - 1 + xh, gw = w0 - 1 + xw;
+            const bool ok = id < K::X_INSTR && row < wg::XROWS && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W;
+            const int ghc = min(max(gh, 0), H - 1) >> sh, gwc = min(max(gw, 0), W - 1) >> sh;
+            x_off[k] = (ghc * sW + gwc) * sC + ls * 8;
+            x_ok |= (ok ? 1u : 0u) << k;
+        }
+#pragma unroll
+        for (int k = 0; k < K::YPW; ++k) {
+            const int id = (NW - 1 - wv) + NW * k;            // dealt from the other end: the waves with one x instruction fewer go first
+            const int i = id * 64 + lane;
+            const int row = i / RS, ps = i % RS;
+            const int ls = RS == 8 ? (ps ^ (((row >> 1) & 1) << 2)) : ps;
+            y_off[k] = ((row >> 4) * W + (row & 15)) * Cout + ls * 8;
+        }
+    };
+    // plane `gd` (may lie outside the volume: zeros) of the cursor's column into x slot `slot`
+    auto issue_x = [&](int gd, int slot) {
         const bool dok = (unsigned)gd < (unsigned)D;
         const int gdc = min(max(gd, 0), D - 1) >> shd;
-        const bf16_t* const xbase = sp + ((int64_t)n * sD + gdc) * sH * sW * sC + coff;
+        const bf16_t* const xbase = sp + ((int64_t)cn * sD + gdc) * sH * sW * sC + coff;
+        const unsigned okm = dok ? x_ok : 0u;
 #pragma unroll
-        for (int k = 0; k < (X_INSTR + NW - 1) / NW; ++k) {
+        for (int k = 0; k < K::XPW; ++k) {
             const int id = wv + NW * k;
-            if (id < X_INSTR) {
-                const int i = id * 64 + ln;
-                const int row = i >> 3, ps = i & 7;
-                const int ls = ps ^ (((row >> 1) & 1) << 2);
-                const int xh = row / wg::XW, xw = row % wg::XW;
-                const int gh = h0 - 1 + xh, gw = w0 - 1 + xw;
-                const bool ok = dok && row < wg::XROWS && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W;
-                const int ghc = min(max(gh, 0), H - 1) >> sh, gwc = min(max(gw, 0), W - 1) >> sh;
-                const bf16_t* real = xbase + ((ghc * sW + gwc) * sC + ls * 8);
-                dma16(ok ? (const void*)real : (const void*)g_zero_page, __builtin_amdgcn_readfirstlane(lds0 + slot * XS_BYTES + id * 1024));
-            }
+            if (id < K::X_INSTR)
+                dma16(((okm >> k) & 1) ? (const void*)(xbase + x_off[k]) : (const void*)g_zero_page,
+                      __builtin_amdgcn_readfirstlane(lds0 + slot * K::XS_BYTES + id * 1024));
         }
     };
-    auto issue_y = [&](int n, int h0, int w0, int d, int ybuf) {
-        int ln = lane;
-        asm volatile("" : "+v"(ln));
-        const bf16_t* const ybase = a.dy + ((((int64_t)n * D + d) * H + h0) * W + w0) * Cout + co0;
+    auto issue_y = [&](int d, int ybuf) {
+        const bf16_t* const ybase = a.dy + ((((int64_t)cn * D + d) * H + ch0) * W + cw0) * Cout + co0;
 #pragma unroll
-        for (int k = 0; k < (Y_INSTR + NW - 1) / NW; ++k) {
-            const int id = (NW - 1 - wv) + NW * k;           // dealt from the other end: the waves with one x instruction fewer go first
-            if (id < Y_INSTR) {
-                const int i = id * 64 + ln;
-                const int row = i >> 3, ps = i & 7;
-                const int ls = ps ^ (((row >> 1) & 1) << 2);
-                dma16(ybase + (((row >> 4) * W + (row & 15)) * Cout + ls * 8),
-                      __builtin_amdgcn_readfirstlane(lds0 + NXS * XS_BYTES + ybuf * YS_BYTES + id * 1024));
-            }
+        for (int k = 0; k < K::YPW; ++k) {
+            const int id = (NW - 1 - wv) + NW * k;
+            if (id < K::Y_INSTR) dma16(ybase + y_off[k], __builtin_amdgcn_readfirstlane(lds0 + K::NXS * K::XS_BYTES + ybuf * K::YS_BYTES + id * 1024));
         }
-    };
-    auto decode = [&](int u, int& n, int& h0, int& w0, int& d) {
-        int q = u;
-        d = q % D; q /= D;
-        w0 = (q % twn) * wg::TW; q /= twn;
-        h0 = (q % thn) * wg::TH;
-        n = q / thn;
     };
 
     // ---- per-lane constants of the transposing fragment reads (see k_conv_wgrad_mfma)
@@ -1709,46 +1719,55 @@ __device__ __forceinline__ void wk_run(const WkArgs& a, unsigned char* lds, int 
     const int lslot_x = it * 4 + 2 * (gq & 1) + (pp >> 1), lslot_y = 2 * (gq & 1) + (pp >> 1);
     int pre_x[4];
 #pragma unroll
-    for (int m = 0; m < 4; ++m) pre_x[m] = wg_slot_off<128>(lrow + m, lslot_x) + (pp & 1) * 8;
-    const int pre_y = wg_slot_off<128>(lrow, lslot_y) + (pp & 1) * 8;
+    for (int m = 0; m < 4; ++m) pre_x[m] = wg_slot_off<ROWB>(lrow + m, lslot_x) + (pp & 1) * 8;
+    const int pre_y = wg_slot_off<ROWB>(lrow, lslot_y) + (pp & 1) * 8;
 
     const int per = (nunits + a.nslab - 1) / a.nslab;
     int u = slab * per;
     const int u_end = min(nunits, u + per);
     if (u < u_end) {
-        int n, h0, w0, d;
-        decode(u, n, h0, w0, d);
-        issue_x(n, h0, w0, d - 1, 0);
-        issue_x(n, h0, w0, d, 1);
-        issue_x(n, h0, w0, d + 1, 2);
-        issue_y(n, h0, w0, d, 0);
+        int d;
+        {
+            int q = u;
+            d = q % D; q /= D;
+            const int w0 = (q % twn) * wg::TW; q /= twn;
+            col_setup(q / thn, (q % thn) * wg::TH, w0);
+        }
+        issue_x(d - 1, 0);
+        issue_x(d, 1);
+        issue_x(d + 1, 2);
+        issue_y(d, 0);
         int xs = 2, yb = 0;                              // ring slot of the newest x plane (kd = 2) of the current unit; dy slot
         for (; u < u_end; ++u) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                // this unit's planes have landed everywhere; the previous unit is fully read
-            bool fresh = false;
-            int nn = 0, nh0 = 0, nw0 = 0, nd = 0;
             const bool more = u + 1 < u_end;
+            const bool fresh = more && d + 1 == D;       // the next unit starts a new column: it needs three new planes, one slot is free
             if (more) {
-                decode(u + 1, nn, nh0, nw0, nd);
-                fresh = nd == 0;                         // the next unit starts a new column: it needs three new planes, one slot is free
-                issue_x(nn, nh0, nw0, fresh ? nd - 1 : nd + 1, (xs + 1) & 3);
-                issue_y(nn, nh0, nw0, nd, yb ^ 1);
+                if (fresh) {                             // advance the cursor to the next column of the run
+                    int w0 = cw0 + wg::TW, h0 = ch0, n = cn;
+                    if (w0 == W) { w0 = 0; h0 += wg::TH; if (h0 == H) { h0 = 0; ++n; } }
+                    col_setup(n, h0, w0);
+                    d = -1;
+                }
+                issue_x(fresh ? -1 : d + 2, (xs + 1) & 3);
+                issue_y(d + 1, yb ^ 1);
             }
-            int xb[3] = {((xs + 2) & 3) * XS_BYTES, ((xs + 3) & 3) * XS_BYTES, xs * XS_BYTES};
+            int xb[3] = {((xs + 2) & 3) * K::XS_BYTES, ((xs + 3) & 3) * K::XS_BYTES, xs * K::XS_BYTES};
 #pragma unroll
             for (int k = 0; k < 3; ++k) asm volatile("" : "+s"(xb[k]));       // slot bases stay scalar: base + lane offset is added per read
-            wk_compute<G>(lds, xb, NXS * XS_BYTES + yb * YS_BYTES, pre_x, pre_y, acc, bsum, do_bias);
+            wk_compute<BLK, G>(lds, xb, K::NXS * K::XS_BYTES + yb * K::YS_BYTES, pre_x, pre_y, acc, bsum, do_bias);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (more && fresh) {
+            if (fresh) {
                 __builtin_amdgcn_s_barrier();            // everybody is done with the old column's planes: its other two slots are free
-                issue_x(nn, nh0, nw0, nd, (xs + 2) & 3);
-                issue_x(nn, nh0, nw0, nd + 1, (xs + 3) & 3);
+                issue_x(0, (xs + 2) & 3);
+                issue_x(1, (xs + 3) & 3);
                 xs = (xs + 3) & 3;
             } else {
                 xs = (xs + 1) & 3;
             }
             yb ^= 1;
+            ++d;
         }
     }
     // ---- flush: D rows = co, cols = ci; fp32 atomics, 128 contiguous bytes per half-wave
@@ -1756,7 +1775,7 @@ __device__ __forceinline__ void wk_run(const WkArgs& a, unsigned char* lds, int 
     for (int j = 0; j < NTAP; ++j) {
         const int tap = 7 * G + j;
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
+        for (int h = 0; h < NH; ++h)
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
                 const int co = co0 + h * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * hk;
@@ -1766,7 +1785,7 @@ __device__ __forceinline__ void wk_run(const WkArgs& a, unsigned char* lds, int 
     }
     if (do_bias) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < NH; ++h) {
             float b = bsum[h];
             b += __shfl_down(b, 32);
             if (hk == 0) atomicAdd(&a.db[co0 + h * 32 + r], b);
@@ -1774,15 +1793,16 @@ __device__ __forceinline__ void wk_run(const WkArgs& a, unsigned char* lds, int 
     }
 }
 
-__global__ void __launch_bounds__(wk::NTHREADS, 1) k_conv_wgrad_kd(WkArgs a) {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[wk::LDS_BYTES];
+template <int BLK>
+__global__ void __launch_bounds__(WkCfg<BLK>::NW * 64, BLK == 64 ? 1 : 2) k_conv_wgrad_kd(WkArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[WkCfg<BLK>::LDS_BYTES];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     switch (wv & 3) {                                     // tap group
-        case 0: wk_run<0>(a, lds, wv, lane); break;
-        case 1: wk_run<1>(a, lds, wv, lane); break;
-        case 2: wk_run<2>(a, lds, wv, lane); break;
-        default: wk_run<3>(a, lds, wv, lane); break;
+        case 0: wk_run<BLK, 0>(a, lds, wv, lane); break;
+        case 1: wk_run<BLK, 1>(a, lds, wv, lane); break;
+        case 2: wk_run<BLK, 2>(a, lds, wv, lane); break;
+        default: wk_run<BLK, 3>(a, lds, wv, lane); break;
     }
 }
 
@@ -2013,20 +2033,35 @@ int conv3d_wgrad_mfma_ld(const void* src0, int C0, int up0, int planar, const vo
     const double flops_ = 2.0 * (planar ? 9 : 27) * (double)(C0 + C1) * Cout * (double)N * D * H * W;
     const bool use_ws = workspace != nullptr && workspace_bytes >= conv3d_wgrad_mfma_ws_bytes(C0, C1, Cout, N, D, H, W, planar) &&
                         (force_slab == 1 || flops_ < 0.3e12);
-    // kd-sharing kernel (one workgroup per (64 Cout, 64 Cin) block walks columns for all 27 taps): EXPERIMENTAL, slower than the kernel
-    // below on MI355X (see its header) - FMRI_WGRAD_KD=1 uses it for the large layers, =2 wherever the shape allows, default 0 = off.
-    static int kd_mode = -1;
+    // kd-sharing kernels (a workgroup owns a (Cout, Cin) block for all 27 taps and walks columns; see k_conv_wgrad_kd).  Measured per layer
+    // (profiles/r02_wgrad_kd_sharing_ab.log): the 4-wave form wins where the per-kd kernel has to fall back to 32-wide Cin blocks (enc0b
+    // 32 -> 64 at full resolution: -17 %), is level with it on the 64- and 128-channel layers (0 ... -5 %) and loses on the fused-upsample
+    // launches.  FMRI_WGRAD_KD: 0 = off, 1 (default) = the layers with a 32-wide Cin block and >= 0.1 TFLOP, 2 = wherever the shape allows;
+    // FMRI_WGRAD_KD_BLK = 32 (4-wave workgroups, two per CU) | 64 (8-wave workgroup, one per CU: slower, kept for the record).
+    static int kd_mode = -1, kd_blk = 32;
     if (kd_mode < 0) {
         const char* e = getenv("FMRI_WGRAD_KD");
-        kd_mode = e ? atoi(e) : 0;
+        kd_mode = e ? atoi(e) : 1;
+        const char* f = getenv("FMRI_WGRAD_KD_BLK");
+        kd_blk = (f && atoi(f) == 64) ? 64 : 32;
     }
-    if (kd_mode && !planar && !use_ws && (C0 % 64 == 0) && (C1 % 64 == 0) && (kd_mode == 2 || flops_ >= 0.3e12)) {
-        const int combos_kd = (Cout / 64) * (Cin / 64);
+    const bool narrow = (C0 % 64) || (C1 % 64);
+    if (kd_mode && !planar && !use_ws && (!up0 || kd_mode == 2) && (C0 % kd_blk == 0) && (C1 % kd_blk == 0) && (Cout % kd_blk == 0) &&
+        (kd_mode == 2 || (narrow && kd_blk == 32 && flops_ >= 0.1e12))) {
+        const int combos_kd = (Cout / kd_blk) * (Cin / kd_blk);
         const int nunits = N * D * (H / wg::TH) * (W / wg::TW);
-        int nsl = (2 * fwd_cu_count() + combos_kd - 1) / combos_kd;
+        static int kd_wgs = -1;
+        if (kd_wgs < 0) {
+            const char* e = getenv("FMRI_WGRAD_KD_WGS");
+            kd_wgs = e ? atoi(e) : 0;
+        }
+        const int target = kd_wgs > 0 ? kd_wgs : (kd_blk == 64 ? 2 : 4) * fwd_cu_count();
+        int nsl = (target + combos_kd - 1) / combos_kd;
         if (nsl > nunits) nsl = nunits;
         if (nsl < 1) nsl = 1;
-        k_conv_wgrad_kd<<<combos_kd * nsl, wk::NTHREADS, 0, st>>>(WkArgs{s, (const bf16_t*)dy, dw, db, N, D, H, W, Cout, nsl, dw_ld});
+        const WkArgs wa{s, (const bf16_t*)dy, dw, db, N, D, H, W, Cout, nsl, dw_ld};
+        if (kd_blk == 64) k_conv_wgrad_kd<64><<<combos_kd * nsl, 512, 0, st>>>(wa);
+        else k_conv_wgrad_kd<32><<<combos_kd * nsl, 256, 0, st>>>(wa);
         FMRI_LAUNCH_CHECK();
         return FMRI_OK;
     }

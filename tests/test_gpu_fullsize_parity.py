@@ -407,21 +407,23 @@ print("DONE")
 """
 
 
-def test_kd_sharing_weight_gradient_kernel_is_exact(tmp_path):
-    """the opt-in kd-sharing weight-gradient kernel (FMRI_WGRAD_KD=2: one workgroup per (64 Cout, 64 Cin) block walks columns of d-planes
-    for all 27 taps through a 4-slot x-plane ring) against the default kernel on dyadic data whose sums are exact in fp32 in any order:
-    the two must agree BIT FOR BIT - runs that cross column boundaries, a dual source, a fused up-sampled source"""
+def test_kd_sharing_weight_gradient_kernels_are_exact(tmp_path):
+    """the kd-sharing weight-gradient kernels (one workgroup per (Cout, Cin) block walks columns of d-planes for all 27 taps through a 4-slot
+    x-plane ring; FMRI_WGRAD_KD=2 forces them wherever the shape allows: the 4-wave / 32-block form that is the default for narrow layers, and
+    the 8-wave / 64-block form) against the per-kd kernel (FMRI_WGRAD_KD=0) on dyadic data whose sums are exact in fp32 in any order: all three
+    must agree BIT FOR BIT - runs that cross column boundaries, a dual source, a fused up-sampled source"""
     import subprocess
     import sys
     f = tmp_path / "kd.py"
     f.write_text(KD_SCRIPT % ROOT)
     res = []
-    for mode in ("2", "0"):
-        o = str(tmp_path / ("kd%s.npz" % mode))
-        r = subprocess.run([sys.executable, str(f), o], capture_output=True, text=True, timeout=900, env=dict(os.environ, FMRI_WGRAD_KD=mode))
-        assert r.returncode == 0 and "DONE" in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])
+    for tag, env in (("kd32", dict(FMRI_WGRAD_KD="2")), ("kd64", dict(FMRI_WGRAD_KD="2", FMRI_WGRAD_KD_BLK="64")), ("perkd", dict(FMRI_WGRAD_KD="0"))):
+        o = str(tmp_path / (tag + ".npz"))
+        r = subprocess.run([sys.executable, str(f), o], capture_output=True, text=True, timeout=900, env=dict(os.environ, **env))
+        assert r.returncode == 0 and "DONE" in r.stdout, (tag, r.stdout[-1000:], r.stderr[-3000:])
         res.append(np.load(o))
     assert len(res[0].files) == 6
     for k in res[0].files:
-        assert float(np.abs(res[0][k]).max()) > 0
-        assert np.array_equal(res[0][k], res[1][k]), k
+        assert float(np.abs(res[2][k]).max()) > 0
+        assert np.array_equal(res[0][k], res[2][k]), ("kd32", k)
+        assert np.array_equal(res[1][k], res[2][k]), ("kd64", k)
