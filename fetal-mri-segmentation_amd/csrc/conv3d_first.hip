@@ -106,6 +106,11 @@ k_conv_first_fwd(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wt /*[
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks], __builtin_bit_cast(bf16x8_t, u), acc, 0, 0, 0);
             }
             const int64_t vo = ((((int64_t)n * D + d0 + dl) * H + h0 + hl) * W + w0 + r) * Cout + cot * 32;
+            // D rows = channel (reg&3) + 8*(reg>>2) + 4*hk of voxel r: a lane owns 4-channel (8-byte) pieces, and storing those directly wrote
+            // a quarter of a 32-byte sector per lane (1.8 TB/s in round 1).  A half-wave exchange (v_permlane32_swap) gives every lane 8
+            // consecutive channels of voxel (lane & 31): two 16-byte stores per lane, each instruction filling whole 32-byte sectors of 32
+            // consecutive voxel rows.
+            unsigned pk[4][2];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 float o[4];
@@ -116,7 +121,19 @@ k_conv_first_fwd(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wt /*[
                     else if (act == FMRI_ACT_LEAKY) v = v > 0.f ? v : alpha * v;
                     o[i] = v;
                 }
-                stv<bf16_t, 4>(y + vo + 8 * g + 4 * hk, o);
+                pk[g][0] = (unsigned)f2bf(o[0]) | ((unsigned)f2bf(o[1]) << 16);
+                pk[g][1] = (unsigned)f2bf(o[2]) | ((unsigned)f2bf(o[3]) << 16);
+            }
+#pragma unroll
+            for (int pq = 0; pq < 2; ++pq) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    auto sw = __builtin_amdgcn_permlane32_swap(pk[2 * pq][q], pk[2 * pq + 1][q], false, false);
+                    pk[2 * pq][q] = sw[0];
+                    pk[2 * pq + 1][q] = sw[1];
+                }
+                // lanes 0-31 now hold channels 16pq .. 16pq+7 of voxel r, lanes 32-63 channels 16pq+8 .. 16pq+15 of the same voxel
+                *reinterpret_cast<uint4*>(y + vo + (2 * pq + hk) * 8) = make_uint4(pk[2 * pq][0], pk[2 * pq][1], pk[2 * pq + 1][0], pk[2 * pq + 1][1]);
             }
         }
     }
