@@ -244,6 +244,11 @@ def launch_ranks(n, argv):
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL between processes needs it on this driver
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0)))
+    # rank 0's stdout is drained by a thread while the ranks run (a full pipe would block rank 0 inside a collective the others wait in)
+    import threading
+    captured = []
+    reader = threading.Thread(target=lambda: captured.extend(procs[0].stdout.readlines()), daemon=True)
+    reader.start()
     rc = 0
     pending = set(range(n))
     while pending:
@@ -259,12 +264,13 @@ def launch_ranks(n, argv):
                     procs[q].terminate()
         if pending:
             time.sleep(0.05)
-    out = procs[0].stdout.read() if procs[0].stdout else ""
+    reader.join(timeout=10)
     line = None
-    for ln in out.splitlines():
+    for ln in captured:
+        ln = ln.rstrip("\n")
         if ln.startswith("{") and '"metric"' in ln:
             line = ln
-        else:
+        elif ln:
             sys.stderr.write(ln + "\n")
     if rc == 0 and line is None:
         sys.stderr.write("bench.py: rank 0 printed no result line\n")

@@ -496,8 +496,12 @@ class UNetEngine:
         3-D blocks without a normalisation layer (the consumer then reads the block's OUTPUT); FMRI_TAIL_FUSE=0 switches it off (A/B)"""
         if c.get("norm") or self.planar or self.dtype != torch.bfloat16 or os.environ.get("FMRI_TAIL_FUSE", "1") == "0":
             return 0
-        d = self._dims(c["level"])
-        return ops.conv3d_fwd_tail_ok(c["cin"], c["cout"], d[0], d[1], d[2], d[3], self.dtype)
+        key = (c["name"], self.N)
+        cache = self.__dict__.setdefault("_tail_cache", {})
+        if key not in cache:                                   # a host-side query per (layer, batch size), not per step
+            d = self._dims(c["level"])
+            cache[key] = ops.conv3d_fwd_tail_ok(c["cin"], c["cout"], d[0], d[1], d[2], d[3], self.dtype)
+        return cache[key]
 
     def _block_fwd(self, c, src0, src1, up0, bn_training, pool=None, final=None):
         """one [conv -> (norm) -> ReLU] block (reference create_convolution_block, unet.py:89-115).  pool: tensor that receives
