@@ -1,0 +1,30 @@
+"""`python -m fetal.experiments.train_adv --config_dir <dir>`: adversarial training of the segmentation model against the PatchGAN
+discriminator (reference fetal/experiments/train_adv.py:127-291), both networks on the MI355X engines.  Config keys beyond the training
+ones: dis_model_name (discriminator_image_3d), dis_loss, gen_steps, dis_steps, gd_loss_ratio."""
+import os
+
+
+def main(overwrite=False, config=None):
+    from fetal.config_utils import get_config
+    from fetal.utils import create_data_file
+    from fetal_net.adversarial import train_adversarial
+    from fetal_net.data import open_data_file
+    from fetal_net.generator import get_training_and_validation_generators
+    from ._common import build_models, config_with_defaults, generator_kwargs
+    config = config_with_defaults(config if config is not None else get_config())
+    if overwrite or not os.path.exists(config["data_file"]):
+        create_data_file(config)
+    data_file_opened = open_data_file(config["data_file"])
+    gen_model, dis_model = build_models(config, overwrite)
+    train_generator, validation_generator, n_train_steps, n_validation_steps = get_training_and_validation_generators(
+        data_file_opened, **generator_kwargs(config, overwrite))
+    try:
+        return train_adversarial(config, gen_model, dis_model, train_generator, validation_generator, n_train_steps, n_validation_steps)
+    finally:
+        data_file_opened.close()
+
+
+if __name__ == "__main__":
+    from fetal.config_utils import get_config
+    cfg = get_config()
+    main(overwrite=cfg["overwrite"], config=cfg)

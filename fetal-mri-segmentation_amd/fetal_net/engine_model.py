@@ -452,6 +452,23 @@ class Model(object):
         logs = self._batch_logs(sums.cpu().numpy())
         return [logs[k] for k in self.metrics_names]
 
+    def evaluate(self, x, y, batch_size=None, verbose=0):
+        """Keras `model.evaluate(x, y, batch_size)`: batch-size-weighted means of test_on_batch (reference fetal/experiments/train_adv.py:253-262)"""
+        n, bs = _batch_len(x), int(batch_size or 32)
+        outs, sizes = [], []
+        for i in range(0, n, bs):
+            xs = [a[i:i + bs] for a in x] if isinstance(x, (list, tuple)) else x[i:i + bs]
+            outs.append(self.test_on_batch(xs, y[i:i + bs]))
+            sizes.append(_batch_len(xs))
+        return [float(np.average([o[k] for o in outs], weights=sizes)) for k in range(len(outs[0]))]
+
+    def to_json(self, **kw):
+        """the Keras model_config document of the recorded layer graph (reference fetal/experiments/train_adv.py:269-270)"""
+        from . import keras_h5
+        doc = keras_h5.model_config(self)
+        doc.update(keras_version=keras_h5.KERAS_VERSION, backend=keras_h5.BACKEND)
+        return json.dumps(doc, **kw)
+
     def evaluate_generator(self, generator, steps, max_queue_size=10, workers=1, use_multiprocessing=False, verbose=0):
         get, stop = _prefetch(generator, max_queue_size)
         outs, sizes = [], []

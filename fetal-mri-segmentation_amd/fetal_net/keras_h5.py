@@ -32,7 +32,7 @@ _ATTR_LIMIT = 64512                       # keras/engine/saving.py HDF5_OBJECT_H
 
 _WEIGHT_KEYS = {"Conv3D": ("kernel", "bias"), "Conv2D": ("kernel", "bias"), "Conv3DTranspose": ("kernel", "bias"),
                 "Conv2DTranspose": ("kernel", "bias"), "BatchNormalization": ("gamma", "beta", "moving_mean", "moving_variance"),
-                "InstanceNormalization": ("gamma", "beta")}
+                "InstanceNormalization": ("gamma", "beta"), "Dense": ("kernel", "bias")}
 _NON_TRAINABLE = ("moving_mean", "moving_variance")
 
 
@@ -56,6 +56,8 @@ def weight_shapes(model):
         for k in keys:
             if k != "kernel":
                 out["%s/%s" % (l.name, k)] = (c,)
+            elif l.class_name == "Dense":
+                out["%s/kernel" % l.name] = (c_in, c)
             elif l.class_name.endswith("Transpose"):
                 out["%s/kernel" % l.name] = tuple(int(v) for v in l.config["kernel_size"]) + (c, c_in)
             else:
@@ -120,6 +122,17 @@ def layer_config(layer, model):
         return dict(base, dims=[int(v) for v in c["dims"]])
     if cls.startswith("SpatialDropout"):
         return dict(base, rate=float(c["rate"]), noise_shape=None, seed=None)
+    if cls in ("AveragePooling3D", "AveragePooling2D"):
+        p = [int(v) for v in c["pool_size"]]
+        return dict(base, pool_size=p, padding="valid", strides=p, data_format=_data_format(model))
+    if cls in ("GlobalAveragePooling3D", "GlobalAveragePooling2D"):
+        return dict(base, data_format=_data_format(model))
+    if cls == "Dense":
+        # Dense(128, activation=LeakyReLU()) (reference all_dis_3d.py:42): Keras serialises a layer instance used as an activation by its
+        # class name, which its own deserialiser cannot resolve without custom_objects={'LeakyReLU': ...}
+        act = {None: "linear", "leaky_relu": "LeakyReLU"}.get(c.get("activation"), c.get("activation"))
+        return dict(base, units=int(c["units"]), activation=act, use_bias=True, kernel_initializer=_GLOROT, bias_initializer=_init("Zeros"),
+                    kernel_regularizer=None, bias_regularizer=None, activity_regularizer=None, kernel_constraint=None, bias_constraint=None)
     raise TypeError("no Keras config for layer class %s" % cls)
 
 

@@ -28,7 +28,11 @@ class Graph(object):
 
     def conv(self, x, filters, kernel, strides=None, padding="valid"):
         nd = len(kernel)
+        if isinstance(strides, int):
+            strides = (strides,) * nd
         strides = tuple(strides or (1,) * nd)
+        if len(strides) != nd:          # keras.utils.conv_utils.normalize_tuple
+            raise ValueError('The `strides` argument must be a tuple of %d integers. Received: %s' % (nd, str(strides)))
         sp = [(-(-d // s) if padding == "same" else (d - k) // s + 1) for d, s, k in zip(x.shape[2:], strides, kernel)]
         params = int(filters * x.shape[1] * _prod(kernel) + filters)
         return self._add("conv%dd" % nd, "Conv%dD" % nd, (None, filters) + tuple(sp), [x], filters=filters, kernel_size=tuple(kernel),
@@ -57,6 +61,24 @@ class Graph(object):
         nd = len(size)
         return self._add("max_pooling%dd" % nd, "MaxPooling%dD" % nd, x.shape[:2] + tuple(d // p for d, p in zip(x.shape[2:], size)), [x],
                          pool_size=tuple(size))
+
+    def avg_pool(self, x, size):
+        nd = len(size)
+        return self._add("average_pooling%dd" % nd, "AveragePooling%dD" % nd, x.shape[:2] + tuple(d // p for d, p in zip(x.shape[2:], size)), [x],
+                         pool_size=tuple(size))
+
+    def global_avg_pool(self, x):
+        nd = len(x.shape) - 2
+        return self._add("global_average_pooling%dd" % nd, "GlobalAveragePooling%dD" % nd, (None, x.shape[1]), [x])
+
+    def dense(self, x, units, activation=None):
+        """activation: None | 'sigmoid' | 'leaky_relu' (a keras.layers.LeakyReLU() instance handed to Dense: the instance takes a
+        leaky_re_lu_<n> name from the counter although it never becomes a node of the graph)"""
+        alpha = None
+        if activation == "leaky_relu":
+            self._name("leaky_re_lu")
+            alpha = 0.3
+        return self._add("dense", "Dense", (None, units), [x], units=units, activation=activation, alpha=alpha, params=int(x.shape[1] * units + units))
 
     def up_sample(self, x, size):
         nd = len(size)

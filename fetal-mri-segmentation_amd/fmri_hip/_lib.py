@@ -78,6 +78,16 @@ SIGNATURES = {
     "fmri_minmax": [p, i64, i32, p, p],
     "fmri_rescale_intensity": [p, i64, i32, p, i32, f32, f32, f32, p],
     "fmri_noise_augment": [p, i64, i32, p, p, i32, f32, p],
+    "fmri_avgpool3d_2x_fwd": [p, p, i32, i32, i32, i32, i32, i32, i32, p],
+    "fmri_avgpool3d_2x_bwd": [p, p, i32, i32, i32, i32, i32, i32, i32, p],
+    "fmri_global_avgpool_fwd": [p, p, i32, i64, i32, i32, p],
+    "fmri_global_avgpool_bwd": [p, p, i32, i64, i32, i32, p],
+    "fmri_dense_fwd": [p, p, p, p, i32, i32, i32, i32, f32, p],
+    "fmri_dense_bwd": [p, p, p, p, p, p, p, i32, i32, i32, i32, f32, p],
+    "fmri_sigmoid_bce_fwd": [p, p, p, p, i64, p],
+    "fmri_sigmoid_bce_bwd": [p, p, p, i64, f32, p],
+    "fmri_sigmoid_chain": [p, p, i32, i32, p, i64, f32, i32, i32, p],
+    "fmri_discriminator_input": [p, i32, p, i32, i32, p, i32, i32, i64, i32, p],
 }
 
 _lib = None

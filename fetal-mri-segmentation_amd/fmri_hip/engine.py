@@ -634,13 +634,19 @@ class UNetEngine:
             return None
         return self.act.get(name)
 
-    def backward(self, y_true, grad_scale=1.0, weight=None):
+    def backward(self, y_true, grad_scale=1.0, weight=None, dprobs=None, dprobs_scale=1.0, seg_loss=True):
+        """`dprobs` ([..., ld >= n_labels], optional): a gradient that arrives on the probabilities from outside - the adversarial term of
+        reference fetal/experiments/train_adv.py:177-180 (the frozen discriminator's input gradient); `seg_loss=False` leaves only that
+        term (the unlabelled pass of train_semi.py:176-183)."""
         p, A, Gd = self.plan, self.act, self.grad
         normed = p.norm is not None
         self._main_stream = torch.cuda.current_stream(self.dev) if self.dev.type == "cuda" else None
         self.G.zero_()
-        ops.sigmoid_loss_bwd(self.probs, y_true, self.sums, self.dlogits, self.loss_kind, self.loss_param, smooth=1.0, grad_scale=grad_scale,
-                             weight=weight)
+        if seg_loss:
+            ops.sigmoid_loss_bwd(self.probs, y_true, self.sums, self.dlogits, self.loss_kind, self.loss_param, smooth=1.0, grad_scale=grad_scale,
+                                 weight=weight)
+        if dprobs is not None:
+            ops.sigmoid_chain(self.probs, dprobs, self.dlogits, scale=dprobs_scale, accumulate=seg_loss)
         f = p.final
         last = p.dec[-1][1] if p.dec else p.enc[-1][1]
         ops.conv1x1_bwd(A[last["name"]], self.w_view(f["name"]), self.dlogits, Gd[last["name"]], self.w_view(f["name"], self.G),

@@ -5,6 +5,10 @@ classes the reference's builders emit — Conv3D (3x3x3 stride 1|2, 1x1x1), Inst
 LeakyReLU / Activation('relu'|'sigmoid'), MaxPooling3D, UpSampling3D, Concatenate, Add, SpatialDropout3D — i.e. the Isensee
 model of reference fetal_net/model/unet3d/isensee2017.py:15-111 (and, for cross-checking, unet_model_3d) — and their 2-D twins
 (Conv2D, UpSampling2D, SpatialDropout2D, MaxPooling2D between two Permute layers: reference fetal_net/model/unet/isensee.py:14-105).
+A graph may also end in Dense(1, 'sigmoid') on a GlobalAveragePooling3D (the PatchGAN discriminator of reference
+fetal_net/model/discriminator/all_dis_3d.py:11-72: + AveragePooling3D, Dense, anisotropic strides (2, 2, 1)); its loss is the binary
+cross-entropy on float targets, and with `input_grad=True` the backward pass also delivers dL/d(input) - what the generator of the
+adversarial experiments is trained with (reference fetal/experiments/train_adv.py:165-180).
 2-D graphs run PLANAR: the batch of slices (N,X,Y,C) is one tensor [1][N][X][Y][C], every kernel gets planar = 1 (no coupling along
 the slice axis, pooling / up-sampling / stride in X and Y only), a 2-D filter is the centre kd plane of a 27-tap image.
 
@@ -37,8 +41,10 @@ class _Dims(object):
 
 
 class LayerGraphEngine(object):
-    def __init__(self, layers, batch, dtype=torch.bfloat16, device="cuda", seed=42, training=True, dist_ctx=None):
+    def __init__(self, layers, batch, dtype=torch.bfloat16, device="cuda", seed=42, training=True, dist_ctx=None, input_grad=False):
         lib()
+        self.input_grad = bool(input_grad)      # keep dL/d(input) (channel-padded in bf16 mode: the caller hands over cp(C) channels)
+        self.beta1 = 0.9
         self.layers = list(layers)
         self.by_name = OrderedDict((l.name, l) for l in self.layers)
         self.dtype, self.dev, self.training, self.dist = dtype, torch.device(device), training, dist_ctx
@@ -87,9 +93,11 @@ class LayerGraphEngine(object):
         self.consumers = consumers
         inb = {l.name: [res(i) for i in l.inbound] for l in L}
         out_layer = L[-1] if L[-1].class_name != "Permute" else self.by_name[L[-1].inbound[0]]
-        if not (out_layer.class_name == "Activation" and out_layer.config.get("activation") == "sigmoid"):
-            raise NotImplementedError("the graph must end in Activation('sigmoid')")
-        self.logits_src = inb[out_layer.name][0]
+        self.head = "dense" if (out_layer.class_name == "Dense" and out_layer.config.get("activation") == "sigmoid") else "seg"
+        if self.head == "seg" and not (out_layer.class_name == "Activation" and out_layer.config.get("activation") == "sigmoid"):
+            raise NotImplementedError("the graph must end in Activation('sigmoid') or Dense(n, 'sigmoid')")
+        # seg head: the sigmoid layer owns no tensor, its source holds the logits; dense head: the Dense op writes the logits itself
+        self.logits_src = inb[out_layer.name][0] if self.head == "seg" else out_layer.name
         in_shape = L[0].output_shape                      # 3-D: (None, C, X, Y, Z); 2-D: (None, X, Y, C) channels-last
         if self.planar:
             self.in_channels = in_shape[-1]
@@ -98,6 +106,7 @@ class LayerGraphEngine(object):
             self.in_channels = in_shape[1]
             self.plan = _Dims(in_shape[2:], out_layer.output_shape[1])
         self.shape = {l.name: (l.output_shape[1],) + tuple(l.output_shape[2:]) for l in L if l.class_name != "Permute"}   # (C, spatial...)
+        self.flat = set(l.name for l in L if l.class_name in ("GlobalAveragePooling%dD" % nd, "Dense"))   # fp32 [N, C] tensors
         if self.planar:
             self.shape[self.input_name] = (self.in_channels,) + tuple(in_shape[1:3])
         self.convs, self.norms = OrderedDict(), OrderedDict()
@@ -115,8 +124,10 @@ class LayerGraphEngine(object):
                     absorbed.add(src.name)
                 elif src.class_name == "Concatenate" and len(src.inbound) == 2 and single_consumer(src.name):
                     absorbed.add(src.name)
+        APOOL, GAP = "AveragePooling%dD" % nd, "GlobalAveragePooling%dD" % nd
+        self.denses = OrderedDict()
         for l in L:
-            if l.name in absorbed or l is out_layer:
+            if l.name in absorbed or (l is out_layer and self.head == "seg"):
                 continue
             cn = l.class_name
             if cn == "InputLayer":
@@ -124,7 +135,15 @@ class LayerGraphEngine(object):
             if cn == CONV:
                 k, s = tuple(l.config["kernel_size"]), tuple(l.config.get("strides") or s1)
                 src = self.by_name[inb[l.name][0]]
-                op = dict(kind="conv", name=l.name, out=l.name, k=k[0], s=s[0], act=ACT_NONE, up0=False, ins=[inb[l.name][0]])
+                if len(set(k)) != 1 or not set(s) <= {1, 2}:
+                    raise NotImplementedError("convolution %s: kernel %s strides %s" % (l.name, k, s))
+                # strides other than 1: in the channel-padded mode, and for anisotropic strides such as the discriminator's (2, 2, 1),
+                # the convolution runs at stride 1 and every second voxel along the strided axes is kept (`sub`)
+                sub = s if (s != s1 and (self.pad or len(set(s)) != 1)) else None
+                if sub is not None and k != k3:
+                    raise NotImplementedError("strided %s convolution %s" % (k, l.name))
+                op = dict(kind="conv", name=l.name, out=l.name, k=k[0], s=(1 if sub is not None else s[0]), sub=sub, act=ACT_NONE, up0=False,
+                          ins=[inb[l.name][0]])
                 if k == k3 and s == s1:
                     if src.class_name == UPS and single_consumer(src.name):
                         absorbed.add(src.name)
@@ -154,6 +173,20 @@ class LayerGraphEngine(object):
                 self.ops.append(dict(kind="upsample", out=l.name, ins=[inb[l.name][0]]))
             elif cn == POOL:
                 self.ops.append(dict(kind="maxpool", out=l.name, ins=[inb[l.name][0]]))
+            elif cn == APOOL:
+                if tuple(l.config.get("pool_size")) != (2,) * nd:
+                    raise NotImplementedError("AveragePooling with pool_size %s" % (l.config.get("pool_size"),))
+                self.ops.append(dict(kind="avgpool", out=l.name, ins=[inb[l.name][0]]))
+            elif cn == GAP:
+                self.ops.append(dict(kind="gap", out=l.name, ins=[inb[l.name][0]]))
+            elif cn == "Dense":
+                a = l.config.get("activation")
+                if a not in (None, "leaky_relu", "relu") and not (l is out_layer and a == "sigmoid"):
+                    raise NotImplementedError("Dense activation %r (%s)" % (a, l.name))
+                op = dict(kind="dense", name=l.name, out=l.name, ins=[inb[l.name][0]], units=int(l.config["units"]),
+                          act={None: ACT_NONE, "sigmoid": ACT_NONE, "relu": ACT_RELU, "leaky_relu": ACT_LEAKY}[a])
+                self.denses[l.name] = op
+                self.ops.append(op)
             elif cn == "Concatenate":
                 raise NotImplementedError("Concatenate is only supported in front of a 3x3(x3) convolution (layer %s)" % l.name)
             else:
@@ -161,7 +194,9 @@ class LayerGraphEngine(object):
         self.clog = {n: sh[0] for n, sh in self.shape.items()}          # logical channel counts
         if self.pad:
             for n, sh in self.shape.items():
-                if n != self.input_name:
+                if n in self.flat and self.by_name[n].class_name == "Dense":
+                    continue                                  # dense outputs keep their logical width (fp32, no MFMA tiling)
+                if n != self.input_name or self.input_grad:
                     self.shape[n] = (self._cp(sh[0]),) + tuple(sh[1:])
         for o in self.ops:                                   # shapes of op outputs follow the layer whose name they carry
             o["shape"] = self.shape[o["out"]]
@@ -186,6 +221,11 @@ class LayerGraphEngine(object):
             off = (off + 3) & ~3
             self.layout[name] = dict(kind="norm", gamma=(off, c), beta=(off + ((c + 3) & ~3), c), c=c)
             off = off + ((c + 3) & ~3) + c
+        for name, op in self.denses.items():
+            K, M = self.clog[op["ins"][0]], op["units"]
+            off = (off + 3) & ~3
+            self.layout[name] = dict(kind="dense", w=(off, K * M), b=((off + K * M + 3) & ~3, M), K=K, M=M)
+            off = ((off + K * M + 3) & ~3) + M
         self.n_flat = (off + 3) & ~3
         self.P = torch.zeros(self.n_flat, dtype=torch.float32, device=self.dev)
         if self.training:
@@ -214,7 +254,7 @@ class LayerGraphEngine(object):
             for i in op["ins"]:
                 c = self.clog[i]
                 idx += list(range(base, base + c))
-                base += c if i == self.input_name else self.shape[i][0]
+                base += self.shape[i][0] if (i != self.input_name or self.input_grad) else c
             cinp = base
             self.cin_map[name] = torch.tensor(idx, dtype=torch.long, device=dev)
             self.Wp32[name] = torch.zeros((27, coutp, cinp), dtype=f32, device=dev)
@@ -249,7 +289,8 @@ class LayerGraphEngine(object):
                 self.dbetap[name] = torch.zeros(cp, dtype=f32, device=dev)
 
     def _is_input(self, ins):
-        return len(ins) == 1 and ins[0] == self.input_name
+        """a conv that reads the graph's input needs no input-gradient filters - unless the caller wants dL/d(input)"""
+        return len(ins) == 1 and ins[0] == self.input_name and not self.input_grad
 
     def _v(self, name, which, buf=None):
         buf = self.P if buf is None else buf
@@ -273,6 +314,11 @@ class LayerGraphEngine(object):
             elif l.name in self.norms:
                 W[l.name + "/gamma"] = np.ones(self.layout[l.name]["c"], np.float32)
                 W[l.name + "/beta"] = np.zeros(self.layout[l.name]["c"], np.float32)
+            elif l.name in self.denses:
+                Lc = self.layout[l.name]
+                lim = math.sqrt(6.0 / (Lc["K"] + Lc["M"]))
+                W[l.name + "/kernel"] = rs.uniform(-lim, lim, size=(Lc["K"], Lc["M"])).astype(np.float32)
+                W[l.name + "/bias"] = np.zeros(Lc["M"], np.float32)
         self.load_keras_weights(W)
 
     def keras_to_flat(self, W):
@@ -287,6 +333,13 @@ class LayerGraphEngine(object):
                     k = k3
                 o, n = Lc["w"]
                 host[o:o + n] = k.transpose(0, 1, 2, 4, 3).reshape(-1)
+                ob, nb = Lc["b"]
+                host[ob:ob + nb] = np.asarray(W[name + "/bias"], np.float32)
+            elif Lc["kind"] == "dense":
+                k = np.asarray(W[name + "/kernel"], np.float32)
+                assert k.shape == (Lc["K"], Lc["M"]), (name, k.shape)
+                o, n = Lc["w"]
+                host[o:o + n] = k.reshape(-1)
                 ob, nb = Lc["b"]
                 host[ob:ob + nb] = np.asarray(W[name + "/bias"], np.float32)
             else:
@@ -314,6 +367,12 @@ class LayerGraphEngine(object):
                 for key in ("gamma", "beta"):
                     o, n = self.layout[name][key]
                     W[name + "/" + key] = host[o:o + n].copy()
+            elif name in self.denses:
+                Lc = self.layout[name]
+                o, n = Lc["w"]
+                W[name + "/kernel"] = host[o:o + n].reshape(Lc["K"], Lc["M"]).copy()
+                ob, nb = Lc["b"]
+                W[name + "/bias"] = host[ob:ob + nb].copy()
         return W
 
     def export_keras_weights(self):
@@ -349,35 +408,39 @@ class LayerGraphEngine(object):
             T, pre, stats = {}, {}, {}
             for o in self.ops:
                 C, sp = o["shape"][0], tuple(o["shape"][1:])
+                if o["out"] in self.flat:                   # GlobalAveragePooling / Dense outputs: fp32 [samples][C]
+                    T[o["out"]] = torch.zeros((N, C), dtype=torch.float32, device=self.dev)
+                    continue
                 T[o["out"]] = torch.empty(self._lead(N) + sp + (C,), dtype=self.dtype, device=self.dev)
-                if o["kind"] == "conv" and o["out"] != o["name"]:
-                    pass
                 if o["kind"] == "norm":
                     stats[o["name"]] = torch.zeros((N if o["instance"] else 1, C, 3), dtype=torch.float32, device=self.dev)
             Gd, tmp = {}, {}
             if self.training:
                 for name, t in T.items():
                     Gd[name] = torch.empty_like(t)
+                if self.input_grad:
+                    Gd[self.input_name] = torch.empty(self._lead(N) + tuple(self.shape[self.input_name][1:]) + (self.shape[self.input_name][0],),
+                                                      dtype=self.dtype, device=self.dev)
             full, gfull = {}, {}
-            if self.pad:                                  # stride-2 convs: the stride-1 result at the input resolution (and its gradient)
-                for o in self.ops:
-                    if o["kind"] == "conv" and o["s"] == 2:
-                        sp_in = tuple(self.shape[o["ins"][0]][1:])
-                        full[o["name"]] = torch.empty(self._lead(N) + sp_in + (o["shape"][0],), dtype=self.dtype, device=self.dev)
-                        if self.training:
-                            gfull[o["name"]] = torch.zeros_like(full[o["name"]])
+            for o in self.ops:                            # strided convs run as `sub`: the stride-1 result at the input resolution (+ gradient)
+                if o["kind"] == "conv" and o["sub"] is not None:
+                    sp_in = tuple(self.shape[o["ins"][0]][1:])
+                    full[o["name"]] = torch.empty(self._lead(N) + sp_in + (o["shape"][0],), dtype=self.dtype, device=self.dev)
+                    if self.training:
+                        gfull[o["name"]] = torch.zeros_like(full[o["name"]])
             cmax = max([self.shape[n][0] for n in self.norms] + [1])
-            nvox = N * int(np.prod(self.plan.spatial))
+            nvox = N * int(np.prod(self.plan.spatial)) if self.head == "seg" else N
             Lb = self.plan.n_labels
             self._bufsets[N] = dict(T=T, G=Gd, tmp=tmp, stats=stats, ws=torch.zeros((N, cmax, 2), dtype=torch.float64, device=self.dev),
                                     logits=torch.empty((nvox, Lb), dtype=torch.float32, device=self.dev),
                                     probs=torch.empty((nvox, Lb), dtype=torch.float32, device=self.dev),
                                     dlogits=torch.empty((nvox, Lb), dtype=torch.float32, device=self.dev),
-                                    dummy_y=torch.zeros(nvox * Lb, dtype=torch.uint8, device=self.dev), drop={}, cat={}, full=full, gfull=gfull)
+                                    dummy_y=torch.zeros(nvox * Lb, dtype=torch.uint8, device=self.dev), drop={}, cat={}, full=full, gfull=gfull,
+                                    dense_in={})
         b = self._bufsets[N]
         self.N, self.T, self.Gt, self.tmp, self.stats, self.norm_ws = N, b["T"], b["G"], b["tmp"], b["stats"], b["ws"]
         self.logits, self.probs, self.dlogits, self._dummy_y, self.drop, self.cat = b["logits"], b["probs"], b["dlogits"], b["dummy_y"], b["drop"], b["cat"]
-        self.full, self.gfull = b["full"], b["gfull"]
+        self.full, self.gfull, self.dense_in = b["full"], b["gfull"], b["dense_in"]
 
     def _t(self, name):
         return self.x_in if name == self.input_name else self.T[name]
@@ -390,41 +453,43 @@ class LayerGraphEngine(object):
         """[samples][voxels...][C] view for the per-sample kernels (instance norm, spatial dropout): 2-D slices are the samples"""
         return t.reshape(tuple(t.shape[1:])) if self.planar else t
 
-    def _s2(self, t, offs):
-        """every second voxel of a stride-1 result (stride-2 conv in the channel-padded mode); planar: H and W only"""
-        if self.planar:
-            return t[:, :, offs[0]::2, offs[1]::2, :]
-        return t[:, offs[0]::2, offs[1]::2, offs[2]::2, :]
+    def _sub(self, t, strides):
+        """the voxels of a stride-1 'same' result that a strided 'same' convolution computes.  TF pads pad_before = 0 for an even size
+        (output o = the stride-1 result at 2o + 1) and 1 for an odd one (at 2o); axes with stride 1 are kept whole."""
+        first = 2 if self.planar else 1
+        sl = [slice(None)] * t.dim()
+        for a, st in enumerate(strides):
+            if st == 2:
+                sl[first + a] = slice(1 if t.shape[first + a] % 2 == 0 else 0, None, 2)
+        return t[tuple(sl)]
 
     # ------------------------------------------------------------------------------------------------ forward
     def forward(self, x, bn_training=None):
         training = self.training if bn_training is None else bn_training
-        assert tuple(x.shape) == self._lead(self.N) + self.plan.spatial + (self.in_channels,), x.shape
+        assert tuple(x.shape) == self._lead(self.N) + self.plan.spatial + (self.shape[self.input_name][0],), x.shape
         self.x_in = x
         for o in self.ops:
             kind = o["kind"]
             out = self.T[o["out"]]
             if kind == "conv":
                 name = o["name"]
+                dst = out if o["sub"] is None else self.full[name]
                 if self.pad:
                     s0 = self._t(o["ins"][0])
                     s1 = self._t(o["ins"][1]) if len(o["ins"]) > 1 else None
                     if name in self.Wup:
                         ops.conv3d_upcat_fwd(s0, None, self.Wup[name]["up_f"], None, self.bp[name], out, act=o["act"], alpha=LEAKY_ALPHA)
-                    elif o["s"] == 1:
-                        ops.conv3d_fwd(s0, s1, self.Wf[name], self.bp[name], out, up0=o["up0"], act=o["act"], planar=self.planar)
                     else:
-                        fl = self.full[name]
-                        ops.conv3d_fwd(s0, s1, self.Wf[name], self.bp[name], fl, up0=o["up0"], act=o["act"], planar=self.planar)
-                        out.copy_(self._s2(fl, self._s2_offsets(fl)))
-                    continue
-                bias = self._v(name, "b")
-                if o["k"] == 3 and o["s"] == 1:
+                        ops.conv3d_fwd(s0, s1, self.Wf[name], self.bp[name], dst, up0=o["up0"], act=o["act"], planar=self.planar)
+                elif o["k"] == 3 and o["s"] == 1:
                     s0 = self._t(o["ins"][0])
                     s1 = self._t(o["ins"][1]) if len(o["ins"]) > 1 else None
-                    ops.conv3d_fwd(s0, s1, self.Wf[name], bias, out, up0=o["up0"], act=o["act"], planar=self.planar)
+                    ops.conv3d_fwd(s0, s1, self.Wf[name], self._v(name, "b"), dst, up0=o["up0"], act=o["act"], planar=self.planar)
                 else:
-                    ops.conv_direct_fwd(self._t(o["ins"][0]), self.Wf[name], bias, out, o["k"], o["s"], act=o["act"], planar=self.planar)
+                    ops.conv_direct_fwd(self._t(o["ins"][0]), self.Wf[name], self._v(name, "b"), out, o["k"], o["s"], act=o["act"],
+                                        planar=self.planar)
+                if o["sub"] is not None:
+                    out.copy_(self._sub(dst, o["sub"]))
             elif kind == "norm":
                 name = o["name"]
                 gam, bet = (self.gp[name], self.betap[name]) if self.pad else (self._v(name, "gamma"), self._v(name, "beta"))
@@ -451,6 +516,14 @@ class LayerGraphEngine(object):
                 ops.upsample_fwd(self._t(o["ins"][0]), out, planar=self.planar)
             elif kind == "maxpool":
                 ops.maxpool_fwd(self._t(o["ins"][0]), out, planar=self.planar)
+            elif kind == "avgpool":
+                ops.avgpool_fwd(self._t(o["ins"][0]), out, planar=self.planar)
+            elif kind == "gap":
+                ops.global_avgpool_fwd(self._smp(self._t(o["ins"][0])), out)
+            elif kind == "dense":
+                name = o["name"]
+                ops.dense_fwd(self._dense_x(o), self._v(name, "w").view(self.layout[name]["K"], o["units"]), self._v(name, "b"), out,
+                              act=o["act"], alpha=LEAKY_ALPHA)
         src = self.T[self.logits_src]
         if src.shape[-1] != self.plan.n_labels:                # channel-padded: the logits are the first n_labels channels
             self.logits.copy_(src.reshape(-1, src.shape[-1])[:, :self.plan.n_labels])
@@ -458,10 +531,16 @@ class LayerGraphEngine(object):
             ops.cast(src.reshape(-1), self.logits.reshape(-1))
         return self.logits
 
-    def _s2_offsets(self, full):
-        """TF 'same' padding with stride 2 reads x[2o + k - pad_before]; pad_before = 0 for even sizes (output o = stride-1 'same'
-        result at 2o+1), 1 for odd sizes (at 2o)"""
-        return tuple(1 if d % 2 == 0 else 0 for d in (full.shape[2:4] if self.planar else full.shape[1:4]))
+    def _dense_x(self, o):
+        """the Dense layer's input [N, K] fp32: its source tensor, or the logical channels of a channel-padded one"""
+        src, K = self.T[o["ins"][0]], self.layout[o["name"]]["K"]
+        if src.shape[1] == K:
+            return src
+        buf = self.dense_in.get(o["name"])
+        if buf is None:
+            buf = self.dense_in[o["name"]] = torch.empty((src.shape[0], K), dtype=torch.float32, device=self.dev)
+        buf.copy_(src[:, :K])
+        return buf
 
     def set_dropout_masks(self, masks):
         """testing hook: fix the SpatialDropout3D masks ({layer name: [N,C] fp32 tensor}) instead of drawing them"""
@@ -474,6 +553,13 @@ class LayerGraphEngine(object):
             self.dist.all_reduce_sums(self.sums)
         return self.sums
 
+    def bce_forward(self, target):
+        """dense head: probs = sigmoid(logits); sums = [sum of binary cross-entropy terms, sum |p - t|, n] (loss = [0] / [2], mae = [1] / [2])"""
+        assert self.head == "dense"
+        self.sums.zero_()
+        ops.sigmoid_bce_fwd(self.logits.reshape(-1), target.reshape(-1), self.probs.reshape(-1), self.sums)
+        return self.sums
+
     def predict(self, x):
         self.forward(x, bn_training=False)
         self.sums.zero_()
@@ -483,7 +569,7 @@ class LayerGraphEngine(object):
     # ------------------------------------------------------------------------------------------------ backward
     def _accum(self, name, write):
         """route a gradient contribution for tensor `name`: write(dst) fills dst; the first contribution writes G directly"""
-        if name == self.input_name:
+        if name == self.input_name and not self.input_grad:
             return
         if name not in self._has_grad:
             write(self.Gt[name])
@@ -497,14 +583,25 @@ class LayerGraphEngine(object):
     def grad_streams(self):
         return [st for st in (getattr(self, "_main_stream", None), self._wg_stream) if st is not None]
 
-    def backward(self, y_true, grad_scale=1.0, weight=None):
+    def backward(self, y_true, grad_scale=1.0, weight=None, dprobs=None, dprobs_scale=1.0, seg_loss=True, params=True):
+        """seg head: y_true = uint8 labels; `dprobs` (optional, [..., ld >= n_labels]) is an extra gradient that arrives on the probabilities
+        (the adversarial term of reference train_adv.py:177-180), `seg_loss=False` leaves only that term (train_semi.py:176-183).
+        dense head: y_true = float targets, the loss is their mean binary cross-entropy times grad_scale.
+        params=False: only the input gradient is wanted (the frozen discriminator inside the combined model)."""
         self._main_stream = torch.cuda.current_stream(self.dev) if self.dev.type == "cuda" else None
         self.G.zero_()
         self._has_grad = set()
-        if self.dist is not None:
+        self._params = params
+        if self.dist is not None and params:
             self.dist.begin()
-        ops.sigmoid_loss_bwd(self.probs, y_true, self.sums, self.dlogits, self.loss_kind, self.loss_param, smooth=1.0, grad_scale=grad_scale,
-                             weight=weight)
+        if self.head == "dense":
+            ops.sigmoid_bce_bwd(self.probs.reshape(-1), y_true.reshape(-1), self.dlogits.reshape(-1), grad_scale / self.probs.numel())
+        else:
+            if seg_loss:
+                ops.sigmoid_loss_bwd(self.probs, y_true, self.sums, self.dlogits, self.loss_kind, self.loss_param, smooth=1.0, grad_scale=grad_scale,
+                                     weight=weight)
+            if dprobs is not None:
+                ops.sigmoid_chain(self.probs, dprobs, self.dlogits, scale=dprobs_scale, accumulate=seg_loss)
         gsrc = self.Gt[self.logits_src]
         if gsrc.shape[-1] != self.plan.n_labels:
             gsrc.zero_()
@@ -523,9 +620,9 @@ class LayerGraphEngine(object):
                     ops.act_bwd(self.T[out], g, g, o["act"], LEAKY_ALPHA)
                 dw, db = self.w_view(name, self.G), self._v(name, "b", self.G)
                 ins = o["ins"]
-                if self.pad and o["s"] == 2:                 # gradient of "sample every second voxel": scatter into the stride-1 grid
+                if o["sub"] is not None:                     # gradient of "sample every second voxel": scatter into the stride-1 grid
                     gf = self.gfull[name]
-                    self._s2(gf, self._s2_offsets(gf)).copy_(g)      # the other voxels stay zero (zeroed at allocation, never written)
+                    self._sub(gf, o["sub"]).copy_(g)             # the other voxels stay zero (zeroed at allocation, never written)
                     g = gf
                 if self.pad or (o["k"] == 3 and o["s"] == 1):
                     s0 = self._t(ins[0])
@@ -551,7 +648,9 @@ class LayerGraphEngine(object):
                         else:
                             ops.conv3d_wgrad(s0, s1, g, dw, db, up0=o["up0"], planar=self.planar)
 
-                    if self._wg_stream is None:
+                    if not params:
+                        pass
+                    elif self._wg_stream is None:
                         wgrad()
                     else:          # weight gradients beside the input-gradient chain (see UNetEngine._block_bwd)
                         self._wg_stream.wait_stream(torch.cuda.current_stream(self.dev))
@@ -568,7 +667,7 @@ class LayerGraphEngine(object):
                                 self.cat[name] = torch.empty(tuple(g.shape[:-1]) + (cin,), dtype=self.dtype, device=self.dev)
                             cat = self.cat[name]
                             ops.conv3d_dgrad(g, self.Wd[name], cat, planar=self.planar)
-                            c0 = self.shape[ins[0]][0] if ins[0] != self.input_name else self.in_channels
+                            c0 = self.shape[ins[0]][0]
                             if o["up0"]:
                                 self._accum(ins[0], lambda dst: ops.upsample_bwd(cat, dst, dy_off=0, planar=self.planar))
                             else:
@@ -577,8 +676,9 @@ class LayerGraphEngine(object):
                                 self._slice_into(ins[1], cat, c0)
                 else:
                     x = self._t(ins[0])
-                    ops.conv_direct_bwd(x, self.Wf[name], g, None, dw, db, o["k"], o["s"], planar=self.planar)
-                    if ins[0] != self.input_name:
+                    if params:
+                        ops.conv_direct_bwd(x, self.Wf[name], g, None, dw, db, o["k"], o["s"], planar=self.planar)
+                    if ins[0] != self.input_name or self.input_grad:
                         self._accum(ins[0], lambda dst: ops.conv_direct_bwd(x, self.Wf[name], g, dst, None, None, o["k"], o["s"], planar=self.planar))
             elif kind == "norm":
                 name = o["name"]
@@ -591,8 +691,9 @@ class LayerGraphEngine(object):
                     self._accum(src, lambda dst: ops.norm_act_bwd(self._smp(self._t(src)), self._smp(self.T[out]), self._smp(g), self.gp[name],
                                                                   self.stats[name], self._smp(dst), dg, dbt, self.norm_ws,
                                                                   1 if o["instance"] else 0, act=o["act"], alpha=LEAKY_ALPHA))
-                    self._v(name, "gamma", self.G).add_(dg[:c])
-                    self._v(name, "beta", self.G).add_(dbt[:c])
+                    if params:
+                        self._v(name, "gamma", self.G).add_(dg[:c])
+                        self._v(name, "beta", self.G).add_(dbt[:c])
                     continue
                 self._accum(src, lambda dst: ops.norm_act_bwd(self._smp(self._t(src)), self._smp(self.T[out]), self._smp(g), self._v(name, "gamma"),
                                                               self.stats[name], self._smp(dst), self._v(name, "gamma", self.G),
@@ -612,10 +713,34 @@ class LayerGraphEngine(object):
             elif kind == "maxpool":
                 src = o["ins"][0]
                 self._accum(src, lambda dst: ops.maxpool_bwd(self._t(src), g, dst, relu_mask=False, planar=self.planar))
+            elif kind == "avgpool":
+                self._accum(o["ins"][0], lambda dst: ops.avgpool_bwd(g, dst, planar=self.planar))
+            elif kind == "gap":
+                self._accum(o["ins"][0], lambda dst: ops.global_avgpool_bwd(g, self._smp(dst)))
+            elif kind == "dense":
+                name = o["name"]
+                Lc = self.layout[name]
+                x, w = self._dense_x(o), self._v(name, "w").view(Lc["K"], Lc["M"])
+                dw = self._v(name, "w", self.G).view(Lc["K"], Lc["M"]) if params else None
+                db = self._v(name, "b", self.G) if params else None
+
+                def write(dst, o=o, x=x, w=w, dw=dw, db=db, g=g):
+                    if dst.shape[1] == x.shape[1]:
+                        ops.dense_bwd(x, w, self.T[o["out"]], g, dst, dw, db, act=o["act"], alpha=LEAKY_ALPHA)
+                    else:                                       # channel-padded source: the padding receives a zero gradient
+                        dx = torch.empty_like(x)
+                        ops.dense_bwd(x, w, self.T[o["out"]], g, dx, dw, db, act=o["act"], alpha=LEAKY_ALPHA)
+                        dst.zero_()
+                        dst[:, :x.shape[1]] = dx
+                self._accum(o["ins"][0], write)
         if self._wg_stream is not None:
             torch.cuda.current_stream(self.dev).wait_stream(self._wg_stream)
-        if self.dist is not None:
+        if self.dist is not None and params:
             self.dist.finish(self)
+
+    def input_gradient(self):
+        """dL/d(input) of the last backward pass (engines built with input_grad=True): same layout as the input"""
+        return self.Gt[self.input_name]
 
     def _dy64(self, g):
         C = g.shape[-1]
@@ -628,14 +753,15 @@ class LayerGraphEngine(object):
         return buf
 
     def _slice_into(self, name, src, off):
-        if name == self.input_name:
+        if name == self.input_name and not self.input_grad:
             return
         first = name not in self._has_grad
         ops.slice_channels(src, off, self.Gt[name], accumulate=not first)
         self._has_grad.add(name)
 
     # ------------------------------------------------------------------------------------------------ optimizer
-    def adam_step(self, lr, beta1=0.9, beta2=0.999, eps=1e-7, grad_scale=1.0):
+    def adam_step(self, lr, beta1=None, beta2=0.999, eps=1e-7, grad_scale=1.0):
+        beta1 = self.beta1 if beta1 is None else beta1
         self.t += 1
         lr_t = lr * math.sqrt(1.0 - beta2 ** self.t) / (1.0 - beta1 ** self.t)
         ops.adam_step(self.P, self.G, self.M, self.V, lr_t, beta1, beta2, eps, grad_scale)

@@ -497,3 +497,92 @@ def largest_component_u8(mask):
                                       "fmri_largest_component_step"), sweeps=8)
     check(L.fmri_largest_component_step(0, _p(labels), _p(counts), _p(best), _p(out), X, Y, Z, 2, 0, 0, _s()), "fmri_largest_component_step")
     return out
+
+
+# ---------------------------------------------------------------------------------------------------- discriminator head (discriminator.hip)
+def avgpool_fwd(x, y, planar=False):
+    """x [N,D,H,W,C] -> y [N,D//2,H//2,W//2,C] (planar: [N,D,H//2,W//2,C]); AveragePooling3D() / AveragePooling2D()"""
+    _need_cuda(x, y)
+    N, D, H, W, Cc = x.shape
+    assert tuple(y.shape) == (N, D if planar else D // 2, H // 2, W // 2, Cc), (x.shape, y.shape)
+    check(lib().fmri_avgpool3d_2x_fwd(_p(x), _p(y), N, D, H, W, Cc, dt(x), int(planar), _s()), "fmri_avgpool3d_2x_fwd")
+    return y
+
+
+def avgpool_bwd(dy, dx, planar=False):
+    _need_cuda(dy, dx)
+    N, D, H, W, Cc = dx.shape
+    assert tuple(dy.shape) == (N, D if planar else D // 2, H // 2, W // 2, Cc), (dx.shape, dy.shape)
+    check(lib().fmri_avgpool3d_2x_bwd(_p(dy), _p(dx), N, D, H, W, Cc, dt(dx), int(planar), _s()), "fmri_avgpool3d_2x_bwd")
+    return dx
+
+
+def global_avgpool_fwd(x, y):
+    """x [N, ..., C] -> y [N, C] fp32"""
+    _need_cuda(x, y)
+    N, Cc = x.shape[0], x.shape[-1]
+    assert y.dtype == torch.float32 and tuple(y.shape) == (N, Cc)
+    check(lib().fmri_global_avgpool_fwd(_p(x), _p(y), N, x.numel() // (N * Cc), Cc, dt(x), _s()), "fmri_global_avgpool_fwd")
+    return y
+
+
+def global_avgpool_bwd(dy, dx):
+    _need_cuda(dy, dx)
+    N, Cc = dx.shape[0], dx.shape[-1]
+    assert dy.dtype == torch.float32 and tuple(dy.shape) == (N, Cc)
+    check(lib().fmri_global_avgpool_bwd(_p(dy), _p(dx), N, dx.numel() // (N * Cc), Cc, dt(dx), _s()), "fmri_global_avgpool_bwd")
+    return dx
+
+
+def dense_fwd(x, w, b, y, act=ACT_NONE, alpha=0.0):
+    """x [N,K] fp32, w [K,M] (Keras kernel), b [M] -> y [N,M] fp32"""
+    _need_cuda(x, w, b, y)
+    N, K = x.shape
+    M = w.shape[1]
+    assert w.shape[0] == K and tuple(y.shape) == (N, M) and all(t.dtype == torch.float32 for t in (x, w, y))
+    check(lib().fmri_dense_fwd(_p(x), _p(w), _p(b), _p(y), N, K, M, act, float(alpha), _s()), "fmri_dense_fwd")
+    return y
+
+
+def dense_bwd(x, w, y, dy, dx, dw, db, act=ACT_NONE, alpha=0.0):
+    """dw / db accumulate, dx is written; any of the three may be None"""
+    _need_cuda(x, w, y, dy, dx, dw, db)
+    N, K = x.shape
+    M = w.shape[1]
+    check(lib().fmri_dense_bwd(_p(x), _p(w), _p(y), _p(dy), _p(dx), _p(dw), _p(db), N, K, M, act, float(alpha), _s()), "fmri_dense_bwd")
+
+
+def sigmoid_bce_fwd(logits, target, probs, sums):
+    """sums (fp64, >= 3) += [sum of Keras binary_crossentropy terms, sum |p - t|, n]"""
+    _need_cuda(logits, target, probs, sums)
+    assert target.dtype == torch.float32 and logits.dtype == torch.float32 and sums.dtype == torch.float64
+    check(lib().fmri_sigmoid_bce_fwd(_p(logits), _p(target), _p(probs), _p(sums), logits.numel(), _s()), "fmri_sigmoid_bce_fwd")
+    return probs
+
+
+def sigmoid_bce_bwd(probs, target, dlogits, scale):
+    _need_cuda(probs, target, dlogits)
+    check(lib().fmri_sigmoid_bce_bwd(_p(probs), _p(target), _p(dlogits), probs.numel(), float(scale), _s()), "fmri_sigmoid_bce_bwd")
+    return dlogits
+
+
+def sigmoid_chain(probs, dprobs, dlogits, scale=1.0, accumulate=False):
+    """dlogits [nvox, L] (+)= scale * dprobs[..., :L] * p * (1 - p); dprobs [..., ld] is the discriminator's input gradient"""
+    _need_cuda(probs, dprobs, dlogits)
+    nvox, L = probs.shape
+    ld = dprobs.shape[-1]
+    assert dprobs.numel() == nvox * ld and dlogits.shape == probs.shape
+    check(lib().fmri_sigmoid_chain(_p(probs), _p(dprobs), ld, L, _p(dlogits), nvox, float(scale), int(accumulate), dt(dprobs), _s()),
+          "fmri_sigmoid_chain")
+    return dlogits
+
+
+def discriminator_input(probs, x, out, merge=False):
+    """out [..., ld] = [probs, x, 0...] or, merge, the mul-merge maps [x * probs, x * (1 - probs), 0...] (train_adv.py:92-95)"""
+    _need_cuda(probs, x, out)
+    nvox, L = probs.shape
+    Cc = x.shape[-1]
+    assert x.numel() == nvox * Cc and out.numel() == nvox * out.shape[-1]
+    check(lib().fmri_discriminator_input(_p(probs), L, _p(x), Cc, dt(x), _p(out), out.shape[-1], dt(out), nvox, int(merge), _s()),
+          "fmri_discriminator_input")
+    return out

@@ -279,6 +279,35 @@ int fmri_fill_holes_step(const uint8_t* mask, uint8_t* reached, uint8_t* out, in
 int fmri_largest_component_step(const uint8_t* mask, int32_t* labels, int32_t* counts, unsigned long long* best, uint8_t* out, int X, int Y,
                                 int Z, int phase, int sweeps, int* changed, fmri_stream_t stream);
 
+/* ---- PatchGAN discriminator head and the adversarial coupling.  Reference
+ * fetal_net/model/discriminator/all_dis_3d.py:11-72 (conv blocks of the segmentation path's layer kinds + AveragePooling3D,
+ * GlobalAveragePooling3D, Dense(128, LeakyReLU) x fc_layers, Dense(1, 'sigmoid'), loss binary_crossentropy, metric 'mae') and
+ * fetal/experiments/train_adv.py:92-125, :165-180 (discriminator inputs; generator trained through the frozen discriminator).
+ * fmri_avgpool3d_2x: x [N][D][H][W][C] -> y [N][D/2][H/2][W/2][C] ('valid': floor, an odd trailing plane is ignored / gets a zero
+ *   gradient); planar: window 1x2x2.  D,H,W are the INPUT dims in both directions.
+ * fmri_global_avgpool: x [N][V][C] (dtype) <-> y [N][C] fp32.
+ * fmri_dense: y[n][m] = act(b[m] + sum_k x[n][k] * w[k][m]), w the Keras kernel [K][M]; bwd takes the OUTPUT y for the activation's
+ *   derivative, ACCUMULATES into dw / db (nullable) and writes dx (nullable).
+ * fmri_sigmoid_bce: probs = sigmoid(logits); sums[0] += sum_i BCE_i with Keras' clip of p to [1e-7, 1-1e-7], sums[1] += sum |p - t|,
+ *   sums[2] += n (the caller zeroes sums); bwd: dlogits = scale * (p - t), 0 where the clip is active.  target is a FLOAT (soft labels).
+ * fmri_sigmoid_chain: dlogits (=|+=) scale * dprobs[v * ld + l] * p * (1 - p) for the generator's probs [nvox][n_labels] (fp32);
+ *   dprobs (dtype) = the leading channels of the discriminator's input gradient.
+ * fmri_discriminator_input: out [nvox][out_ld] (zero-filled past the used channels) = merge ? [x * s, x * (1 - s)] (mul_merge_maps,
+ *   numpy channel broadcasting: C == 1, n_labels == 1 or C == n_labels) : [s, x] (Concatenate(axis=1)([segs, inputs])), s = probs fp32. */
+int fmri_avgpool3d_2x_fwd(const void* x, void* y, int N, int D, int H, int W, int C, int dtype, int planar, fmri_stream_t stream);
+int fmri_avgpool3d_2x_bwd(const void* dy, void* dx, int N, int D, int H, int W, int C, int dtype, int planar, fmri_stream_t stream);
+int fmri_global_avgpool_fwd(const void* x, float* y, int N, int64_t V, int C, int dtype, fmri_stream_t stream);
+int fmri_global_avgpool_bwd(const float* dy, void* dx, int N, int64_t V, int C, int dtype, fmri_stream_t stream);
+int fmri_dense_fwd(const float* x, const float* w, const float* b, float* y, int N, int K, int M, int act, float alpha, fmri_stream_t stream);
+int fmri_dense_bwd(const float* x, const float* w, const float* y, const float* dy, float* dx, float* dw, float* db, int N, int K, int M,
+                   int act, float alpha, fmri_stream_t stream);
+int fmri_sigmoid_bce_fwd(const float* logits, const float* target, float* probs, double* sums, int64_t n, fmri_stream_t stream);
+int fmri_sigmoid_bce_bwd(const float* probs, const float* target, float* dlogits, int64_t n, float scale, fmri_stream_t stream);
+int fmri_sigmoid_chain(const float* probs, const void* dprobs, int dprobs_ld, int n_labels, float* dlogits, int64_t nvox, float scale,
+                       int accumulate, int dtype, fmri_stream_t stream);
+int fmri_discriminator_input(const float* probs, int n_labels, const void* x, int C, int x_dtype, void* out, int out_ld, int out_dtype,
+                             int64_t nvox, int merge, fmri_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

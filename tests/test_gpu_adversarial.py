@@ -1,0 +1,395 @@
+"""-m gpu: the discriminator's kernels, the discriminator engine and the generator step through the frozen discriminator against the
+CPU oracle (oracle/discriminator_oracle.py); SURVEY.md §8f row 4, reference fetal_net/model/discriminator/all_dis_3d.py and
+fetal/experiments/train_adv.py / train_semi.py."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from gpu_util import assert_close, bar, f64, rnd          # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+DT = [torch.float32, torch.bfloat16]
+TOL = {torch.float32: (2e-6, 2e-6), torch.bfloat16: (5e-3, 1e-4)}       # bf16: one rounding of the result (2^-8)
+
+
+def _ops():
+    from fmri_hip import ops
+    return ops
+
+
+# ------------------------------------------------------------------------------------------------------------------ kernels
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("shape,planar", [((2, 4, 6, 8, 16), False), ((1, 5, 7, 6, 3), False), ((3, 2, 2, 2, 32), False),
+                                          ((1, 5, 8, 6, 8), True), ((1, 3, 5, 7, 4), True)])
+def test_average_pooling_forward_backward(dtype, shape, planar):
+    ops = _ops()
+    N, D, H, W, C = shape
+    x = rnd(shape, 1, dtype)
+    out_shape = (N, D if planar else D // 2, H // 2, W // 2, C)
+    y = torch.empty(out_shape, dtype=dtype, device="cuda")
+    ops.avgpool_fwd(x, y, planar=planar)
+    xr = f64(x).permute(0, 4, 1, 2, 3).requires_grad_(True)
+    yr = F.avg_pool3d(xr, (1, 2, 2) if planar else 2)
+    assert_close(y, yr.detach().permute(0, 2, 3, 4, 1), *TOL[dtype], what="avgpool fwd %s" % (shape,))
+    dy = rnd(out_shape, 2, dtype)
+    dx = torch.full(shape, float("nan"), dtype=dtype, device="cuda")
+    ops.avgpool_bwd(dy, dx, planar=planar)
+    yr.backward(f64(dy).permute(0, 4, 1, 2, 3))
+    assert_close(dx, xr.grad.permute(0, 2, 3, 4, 1), *TOL[dtype], what="avgpool bwd %s" % (shape,))     # odd trailing planes: exactly 0
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("shape", [(2, 2, 2, 1, 128), (3, 5, 4, 3, 7), (1, 16, 16, 8, 96)])
+def test_global_average_pooling_forward_backward(dtype, shape):
+    ops = _ops()
+    x = rnd(shape, 3, dtype)
+    N, C = shape[0], shape[-1]
+    y = torch.empty((N, C), dtype=torch.float32, device="cuda")
+    ops.global_avgpool_fwd(x, y)
+    assert_close(y, f64(x).mean(dim=(1, 2, 3)), 2e-6, 2e-6, what="gap fwd")          # fp32 accumulation of the stored values
+    dy = rnd((N, C), 4, torch.float32)
+    dx = torch.empty(shape, dtype=dtype, device="cuda")
+    ops.global_avgpool_bwd(dy, dx)
+    V = shape[1] * shape[2] * shape[3]
+    assert_close(dx, (f64(dy) / V)[:, None, None, None, :].expand(shape), *TOL[dtype], what="gap bwd")
+
+
+@pytest.mark.parametrize("N,K,M,act", [(4, 128, 128, 2), (6, 64, 1, 0), (1, 7, 5, 1), (16, 128, 1, 0)])
+def test_dense_forward_backward(N, K, M, act):
+    ops = _ops()
+    x, w, b = rnd((N, K), 5, torch.float32), rnd((K, M), 6, torch.float32, 0.2), rnd((M,), 7, torch.float32, 0.1)
+    y = torch.empty((N, M), dtype=torch.float32, device="cuda")
+    ops.dense_fwd(x, w, b, y, act=act, alpha=0.3)
+    xr, wr, br = f64(x).requires_grad_(True), f64(w).requires_grad_(True), f64(b).requires_grad_(True)
+    z = xr @ wr + br
+    yr = {0: z, 1: F.relu(z), 2: F.leaky_relu(z, 0.3)}[act]
+    assert_close(y, yr.detach(), 2e-6, 2e-6, what="dense fwd")
+    dy = rnd((N, M), 8, torch.float32)
+    dx = torch.empty_like(x)
+    dw, db = torch.ones_like(w), torch.ones_like(b)                  # accumulate: start from 1
+    ops.dense_bwd(x, w, y, dy, dx, dw, db, act=act, alpha=0.3)
+    yr.backward(f64(dy))
+    assert_close(dx, xr.grad, 2e-6, 2e-6, what="dense dx")
+    assert_close(dw, wr.grad + 1, 2e-6, 2e-6, what="dense dw")
+    assert_close(db, br.grad + 1, 2e-6, 2e-6, what="dense db")
+    ops.dense_bwd(x, w, y, dy, None, None, None, act=act, alpha=0.3)        # every output is optional
+
+
+def test_sigmoid_bce_forward_backward_with_soft_labels_and_clipping():
+    ops = _ops()
+    from oracle.discriminator_oracle import keras_bce
+    z = torch.tensor([-30.0, -3.0, -0.2, 0.0, 0.7, 4.0, 30.0, 1.5], device="cuda")          # +-30: sigmoid saturates past Keras' clip
+    t = torch.tensor([0.05, 0.0, 0.93, 1.0, 0.98, 0.02, 0.95, 0.5], device="cuda")
+    p, sums = torch.empty_like(z), torch.zeros(16, dtype=torch.float64, device="cuda")
+    ops.sigmoid_bce_fwd(z, t, p, sums)
+    pr = torch.sigmoid(f64(z))
+    assert_close(p, pr, 2e-6, 2e-6, what="bce probs")
+    s = sums.cpu().numpy()
+    assert s[2] == 8
+    p32 = torch.sigmoid(z.cpu())                                  # the clip acts on the fp32 probability with fp32 bounds, as in Keras / TF
+    pc = torch.clamp(p32, float(np.float32(1e-7)), float(np.float32(1 - 1e-7))).double()
+    ref = float(-(f64(t) * torch.log(pc) + (1 - f64(t)) * torch.log(1 - pc)).sum())
+    assert abs(ref / 8 - float(keras_bce(p32.double(), f64(t)))) < 2e-3 * ref / 8          # the fp64 oracle differs only in the saturated terms
+    bar("bce.loss_rel", abs(s[0] - ref) / ref, 2e-7)
+    bar("bce.mae_rel", abs(s[1] - float((p32.double() - f64(t)).abs().sum())) / s[1], 6e-8)
+    dl = torch.empty_like(z)
+    ops.sigmoid_bce_bwd(p, t, dl, 0.125 * 10.0)
+    exp = 1.25 * (p32.double() - f64(t))
+    exp[0] = 0.0                                                  # p < 1e-7 and p > 1 - 1e-7: clip_by_value passes no gradient
+    exp[6] = 0.0
+    assert float(p32[0]) < 1e-7 and float(p32[6]) > 1 - 1e-7
+    assert_close(dl, exp, 2e-6, 2e-6, what="bce dlogits")
+    ops.sigmoid_bce_fwd(z, t, p, sums)                            # sums accumulate until the caller zeroes them
+    assert sums.cpu().numpy()[2] == 16
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("L,ld", [(1, 32), (2, 5), (1, 1)])
+def test_sigmoid_chain(dtype, L, ld):
+    ops = _ops()
+    nvox = 1000
+    probs = torch.sigmoid(rnd((nvox, L), 9, torch.float32))
+    dprobs = rnd((nvox, ld), 10, dtype)
+    dl = rnd((nvox, L), 11, torch.float32)
+    dl0 = dl.clone()
+    ops.sigmoid_chain(probs, dprobs, dl, scale=2.5, accumulate=True)
+    exp = f64(dl0) + 2.5 * f64(dprobs)[:, :L] * f64(probs) * (1 - f64(probs))
+    assert_close(dl, exp, 2e-6, 2e-6, what="chain accumulate")
+    ops.sigmoid_chain(probs, dprobs, dl, scale=1.0, accumulate=False)
+    assert_close(dl, f64(dprobs)[:, :L] * f64(probs) * (1 - f64(probs)), 2e-6, 2e-6, what="chain write")
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_discriminator_input_assembly(dtype):
+    ops = _ops()
+    from fetal_net.adversarial import mul_merge_maps
+    N, sp = 2, (4, 6, 3)
+    for L, C, ld in ((1, 1, 32), (1, 1, 2), (2, 1, 7), (1, 3, 8)):
+        nvox = N * int(np.prod(sp))
+        probs = torch.sigmoid(rnd((nvox, L), 12, torch.float32))
+        x = rnd((N,) + sp + (C,), 13, dtype)
+        out = torch.full((N,) + sp + (ld,), float("nan"), dtype=dtype, device="cuda")
+        ops.discriminator_input(probs, x, out, merge=False)
+        exp = torch.zeros((nvox, ld), dtype=torch.float64)
+        exp[:, :L] = f64(probs)
+        exp[:, L:L + C] = f64(x).reshape(nvox, C)
+        assert_close(out.reshape(nvox, ld), exp, *TOL[dtype], what="concat input L%d C%d" % (L, C))
+        if 2 * max(L, C) <= ld:
+            ops.discriminator_input(probs, x, out, merge=True)
+            r = f64(x).reshape(N, *sp, C).permute(0, 4, 1, 2, 3).numpy()
+            s = f64(probs).reshape(N, *sp, L).permute(0, 4, 1, 2, 3).numpy()
+            mm = torch.from_numpy(mul_merge_maps(r, s)).permute(0, 2, 3, 4, 1).reshape(nvox, -1)       # the reference's numpy form
+            exp = torch.zeros((nvox, ld), dtype=torch.float64)
+            exp[:, :mm.shape[1]] = mm
+            assert_close(out.reshape(nvox, ld), exp, *TOL[dtype], what="mul-merge input L%d C%d" % (L, C))
+
+
+# ------------------------------------------------------------------------------------------------------------------ discriminator engine
+def _perturb(W, seed=5):
+    r2 = np.random.RandomState(seed)
+    for k in W:
+        if k.endswith(("/bias", "/beta")):
+            W[k] = (r2.randn(*W[k].shape) * 0.05).astype(np.float32)
+        if k.endswith("/gamma"):
+            W[k] = (1.0 + r2.randn(*W[k].shape) * 0.1).astype(np.float32)
+    return W
+
+
+def _dis_setup(input_shape, N, depth, base, rate=0.3, seed=31):
+    import fetal_net.model as fmodel
+    from oracle import discriminator_oracle as DO
+    model = fmodel.discriminator_image_3d(input_shape=input_shape, n_base_filters=base, depth=depth, dropout_rate=rate)
+    spec = DO.DiscriminatorSpec(input_shape, base, depth, rate)
+    W = _perturb(spec.init_weights(seed))
+    rs = np.random.RandomState(8)
+    x = rs.randn(N, *input_shape)
+    t = np.clip(rs.uniform(0.9, 1.0, size=(N, 1)), 0, 1)
+    t[N // 2:] = 1 - t[N // 2:]
+    masks = {b["level"]: (rs.rand(N, b["cout"]) < 1 - rate).astype(np.float64) / (1 - rate) for b in spec.blocks}
+    return model, spec, W, x, t, masks
+
+
+def _engine_masks(masks, dtype=torch.float32):
+    return {"spatial_dropout3d_%d" % (lv + 1): torch.tensor(m, dtype=torch.float32).cuda() for lv, m in masks.items()}
+
+
+def _keras_grads(eng):
+    """{'<layer>/<key>': gradient in Keras layout} from the engine's flat gradient buffer"""
+    return eng.flat_to_keras(eng.G.detach().cpu().numpy())
+
+
+def _dev_x(eng, x, dtype):
+    t = torch.from_numpy(np.ascontiguousarray(x)).permute(0, 2, 3, 4, 1).float()
+    cp = eng.shape[eng.input_name][0]
+    if cp != t.shape[-1]:
+        t = F.pad(t, (0, cp - t.shape[-1]))
+    return t.to(dtype).cuda().contiguous()
+
+
+@pytest.mark.parametrize("input_shape,depth,base", [((2, 16, 16, 8), 3, 4), ((3, 32, 16, 8), 4, 8), ((2, 18, 14, 6), 2, 4)])
+def test_discriminator_engine_fp32_vs_oracle(input_shape, depth, base):
+    """forward (strides (2,2,1) with TF 'same' padding, also on odd extents), loss, metric, every parameter gradient and the input
+    gradient of the discriminator against the oracle, with fixed SpatialDropout3D masks"""
+    from fmri_hip.graph_engine import LayerGraphEngine
+    from oracle import discriminator_oracle as DO
+    N = 4
+    model, spec, W, x, t, masks = _dis_setup(input_shape, N, depth, base)
+    loss, mae, p, grads = DO.discriminator_step(spec, W, x, t, dropout_masks={k: torch.tensor(v) for k, v in masks.items()})
+    eng = LayerGraphEngine(model.layers, N, dtype=torch.float32, input_grad=True)
+    assert eng.head == "dense" and not eng.pad
+    eng.load_keras_weights(W)
+    eng.set_dropout_masks(_engine_masks(masks))
+    td = torch.from_numpy(t.astype(np.float32)).cuda().reshape(-1)
+    eng.forward(_dev_x(eng, x, torch.float32))
+    sums = eng.bce_forward(td).cpu().numpy()
+    eng.backward(td)
+    torch.cuda.synchronize()
+    assert_close(eng.probs.reshape(N, 1), p, 3e-7, 3e-7, what="dis probs")
+    bar("dis_fp32.loss_rel", abs(sums[0] / sums[2] - loss) / loss, 2e-7)
+    bar("dis_fp32.mae_rel", abs(sums[1] / sums[2] - mae) / mae, 1e-7)
+    G = _keras_grads(eng)
+    assert set(G) == set(grads)
+    for k, g in grads.items():
+        ref = g.numpy()
+        if k.endswith("/bias") and k.startswith("conv3d"):
+            continue          # a conv bias in front of an instance normalisation has an exactly zero gradient: only rounding noise
+        bar("dis_fp32.grad_l2_rel", np.linalg.norm(G[k] - ref) / (np.linalg.norm(ref) + 1e-30), 2e-5)
+    # input gradient: the same backward pass, against autograd on the oracle (weights fixed)
+    _, gin = DO.adversarial_term(spec, W, x[:, :1], x[:, 1:], t, dropout_masks={k: torch.tensor(v) for k, v in masks.items()})
+    mine = eng.input_gradient().permute(0, 4, 1, 2, 3)[:, :1]
+    bar("dis_fp32.input_grad_l2_rel", float(torch.linalg.norm(f64(mine) - gin) / torch.linalg.norm(gin)), 2.5e-6)
+    # params=False leaves the input gradient unchanged
+    before = eng.input_gradient().clone()
+    eng.backward(td, params=False)
+    torch.cuda.synchronize()
+    assert torch.equal(before, eng.input_gradient())
+
+
+def test_discriminator_bf16_padded_engine_vs_fp32_engine(monkeypatch):
+    """bf16: channels padded to 32 (the 2-channel input included), every convolution on the MFMA kernels, the (2,2,1) stride as a sampled
+    stride-1 convolution.  Same weights / masks on three engines: fp32 (VALU kernels, the one checked against the oracle above), exact-size
+    bf16 (FMRI_GRAPH_PAD=0, VALU kernels) and padded bf16.  Activations agree to < 1 %; the parameter gradients of the convolutional part
+    carry the bf16 noise of this head amplified: GlobalAveragePooling hands back a gradient that is constant over the voxels of a channel
+    (up to the LeakyReLU slope), and the instance normalisation's backward projection removes most of it, so the bf16 rounding of the
+    stored gradient is divided by a small residual.  The two bf16 engines (independent roundings) differ from fp32 by the same amount,
+    which is what marks it as storage noise and not a kernel error; the dense layers (fp32 throughout) agree to 1 %."""
+    from fmri_hip.graph_engine import LayerGraphEngine
+    N, input_shape = 4, (2, 32, 32, 16)
+    model, spec, W, x, t, masks = _dis_setup(input_shape, N, 4, 8)
+    td = torch.from_numpy(t.astype(np.float32)).cuda().reshape(-1)
+    res = {}
+    for tag, dt_, pad in (("f32", torch.float32, "1"), ("pad", torch.bfloat16, "1"), ("nopad", torch.bfloat16, "0")):
+        monkeypatch.setenv("FMRI_GRAPH_PAD", pad)
+        eng = LayerGraphEngine(model.layers, N, dtype=dt_, input_grad=True)
+        assert eng.pad == (tag == "pad")
+        eng.load_keras_weights(W)
+        eng.set_dropout_masks(_engine_masks(masks))
+        eng.forward(_dev_x(eng, x, dt_))
+        s = eng.bce_forward(td).cpu().numpy()
+        eng.backward(td)
+        torch.cuda.synchronize()
+        res[tag] = (eng, s, _keras_grads(eng), eng.input_gradient().float()[..., :2].cpu().numpy().copy(), eng.logits.cpu().numpy().copy())
+    eb = res["pad"][0]
+    assert eb.shape[eb.input_name][0] == 32
+    for tag in ("pad", "nopad"):
+        bar("dis_bf16.logits_abs", np.abs(res[tag][4] - res["f32"][4]).max(), 1e-3)
+        bar("dis_bf16.loss_rel", abs(res[tag][1][0] - res["f32"][1][0]) / res["f32"][1][0], 1.8e-4)
+        for k, gf in res["f32"][2].items():
+            if k.endswith("/bias") and k.startswith("conv3d"):
+                continue          # exactly zero gradient in front of an instance normalisation
+            e = np.linalg.norm(res[tag][2][k] - gf) / (np.linalg.norm(gf) + 1e-30)
+            bar("dis_bf16.dense_grad_l2_rel_vs_f32" if k.startswith("dense") else "dis_bf16.conv_grad_l2_rel_vs_f32", e,
+                2.4e-2 if k.startswith("dense") else 0.6)
+        bar("dis_bf16.input_grad_l2_rel_vs_f32", np.linalg.norm(res[tag][3] - res["f32"][3]) / np.linalg.norm(res["f32"][3]), 0.38)
+    for k, gf in res["f32"][2].items():
+        if not (k.endswith("/bias") and k.startswith("conv3d")):
+            bar("dis_bf16.grad_l2_rel_pad_vs_nopad", np.linalg.norm(res["pad"][2][k] - res["nopad"][2][k]) / (np.linalg.norm(gf) + 1e-30), 0.25)
+    # the padding never leaks
+    for name, tt in eb.T.items():
+        c = eb.clog[name]
+        if tt.shape[-1] > c:
+            assert float(tt[..., c:].abs().max()) == 0.0, name
+
+
+def test_discriminator_model_learns_and_round_trips(tmp_path):
+    """DiscriminatorModel surface: train_on_batch on a separable task drives the loss down (Adam beta_1 = 0.5), predict / evaluate agree,
+    weights and optimizer state survive save() -> load_weights()"""
+    import fetal_net.model as fmodel
+    torch.manual_seed(0)
+    kw = dict(input_shape=[2, 32, 32, 8], n_base_filters=8, depth=3, dropout_rate=0.1, initial_learning_rate=2e-3)
+    model = fmodel.discriminator_image_3d(**kw)
+    rs = np.random.RandomState(0)
+    N = 8
+    x = rs.randn(N, 2, 32, 32, 8).astype(np.float32)
+    x[N // 2:, 0] += 1.5 * np.sign(rs.randn(N // 2, 32, 32, 8))          # "fake" half: a different texture in channel 0
+    y = np.concatenate([np.full((N // 2, 1), 0.95), np.full((N // 2, 1), 0.05)]).astype(np.float32)
+    hist = [model.train_on_batch(x, y) for _ in range(40)]
+    assert model.metrics_names == ["loss", "mean_absolute_error"]
+    assert np.mean([h[0] for h in hist[-5:]]) < 0.6 * hist[0][0], hist[::8]
+    ev = model.evaluate(x, y, batch_size=4)
+    p = model.predict(x)
+    assert p.shape == (N, 1)
+    np.testing.assert_allclose(ev[1], np.abs(p - y).mean(), rtol=1e-4)
+    path = str(tmp_path / "dis.h5")
+    model.save(path)
+    twin = fmodel.discriminator_image_3d(**kw)
+    twin.load_weights(path)
+    np.testing.assert_allclose(twin.predict(x), p, rtol=0, atol=1e-6)
+    assert twin._engine.t == model._engine.t == 40
+    np.testing.assert_array_equal(twin._engine.M.cpu().numpy(), model._engine.M.cpu().numpy())
+    doc = model.to_json()
+    assert '"GlobalAveragePooling3D"' in doc and '"Dense"' in doc
+
+
+# ------------------------------------------------------------------------------------------------------------------ generator through D
+def _gen_setup(sp, N):
+    import fetal_net.model as fmodel
+    from oracle import unet_oracle as O
+    gen = fmodel.unet_model_3d(input_shape=(1,) + sp, depth=2, n_base_filters=8, compute_dtype="fp32")
+    gspec = O.Spec((1,) + sp, depth=2, n_base_filters=8)
+    Wg = gspec.init_weights(4)
+    x, y = O.synthetic_batch((N, 1) + sp)
+    return gen, gspec, Wg, x, y
+
+
+@pytest.mark.parametrize("mode", ["adv", "semi"])
+def test_generator_step_through_frozen_discriminator_vs_oracle(mode):
+    """CombinedModel.train_on_batch: the three reported losses and every generator gradient of
+    seg_loss + gd_loss_ratio * BCE(D(concat([G(x), x])), valid) against autograd through both oracle networks; the discriminator's
+    parameters do not move, the generator's do."""
+    import fetal_net.model as fmodel
+    from fetal_net.adversarial import CombinedModel
+    from oracle import discriminator_oracle as DO, unet_oracle as O
+    sp, N, ratio = (16, 16, 8), 2, 10.0
+    gen, gspec, Wg, x, y = _gen_setup(sp, N)
+    dis = fmodel.discriminator_image_3d(input_shape=[2] + list(sp), n_base_filters=4, depth=3, dropout_rate=0.0, compute_dtype="fp32")
+    dspec = DO.DiscriminatorSpec((2,) + sp, 4, 3, 0.0)
+    Wd = _perturb(dspec.init_weights(7))
+    gen.set_weights_dict(Wg)
+    dis.set_weights_dict(Wd)
+    rs = np.random.RandomState(3)
+    valid = np.clip(rs.uniform(0.9, 1.0, size=(N, 1)), 0, 1)
+    x_semi = rs.randn(*x.shape).astype(np.float32) if mode == "semi" else None
+    ref = DO.combined_loss_and_grads(lambda Wt, xt: O.forward(gspec, Wt, xt)[1], Wg, dspec, Wd, x, y, valid, ratio, x_semi=x_semi)
+    comb = CombinedModel(gen, dis, gd_loss_ratio=ratio, lr=0.0, mode=mode)          # lr 0: gradients stay inspectable, weights fixed
+    out = comb.train_on_batch(x if mode == "adv" else [x, x_semi], [valid, y] if mode == "adv" else [y, valid])
+    names = comb.metrics_names
+    assert names == (["loss", "dis_loss", "seg_loss"] if mode == "adv" else ["loss", "seg_real_loss", "dis_loss"])
+    got = dict(zip(names, out))
+    bar("combined.total_rel", abs(got["loss"] - ref["total"]) / abs(ref["total"]), 1e-7)
+    bar("combined.dis_loss_rel", abs(got["dis_loss"] - ref["dis_loss"]) / ref["dis_loss"], 1e-7)
+    bar("combined.seg_loss_rel", abs(got[names[2] if mode == "adv" else names[1]] - ref["seg_loss"]) / abs(ref["seg_loss"]), 1e-8)
+    eg = gen._engine
+    G = eg.flat_to_keras(eg.G.detach().cpu().numpy()) if hasattr(eg, "flat_to_keras") else None
+    for k, g in ref["grads"].items():
+        bar("combined.grad_l2_rel", np.linalg.norm(G[k] - g) / (np.linalg.norm(g) + 1e-30), 2.5e-6)
+    # the adversarial term really contributes: without it the gradient is a different one
+    plain = O.loss_and_grads(gspec, Wg, x, y)["grads"]
+    k0 = "conv3d_1/kernel"
+    assert np.linalg.norm(ref["grads"][k0] - plain[k0]) > 0.05 * np.linalg.norm(plain[k0])
+    # frozen discriminator: bit-identical parameters after generator steps with a real learning rate; the generator moves
+    Pd, Pg = dis._engine.P.clone(), eg.P.clone()
+    comb.optimizer.lr = 1e-3
+    comb.train_on_batch(x if mode == "adv" else [x, x_semi], [valid, y] if mode == "adv" else [y, valid])
+    torch.cuda.synchronize()
+    assert torch.equal(Pd, dis._engine.P) and not torch.equal(Pg, eg.P)
+
+
+@pytest.mark.parametrize("dis_dtype", [None, "fp32"])
+def test_adversarial_loop_runs_and_checkpoints(tmp_path, dis_dtype):
+    """train_adversarial (the epoch loop of train_adv.py:213-287) on synthetic generators, bf16 generator with a bf16 or an fp32
+    discriminator: finite histories, the generator checkpoint g_<epoch>_<loss>.{json,h5} appears, the scheduler drives both learning rates"""
+    import fetal_net.model as fmodel
+    from fetal_net.adversarial import train_adversarial
+    from oracle import unet_oracle as O
+    sp, N = (32, 32, 16), 2
+    gen = fmodel.unet_model_3d(input_shape=(1,) + sp, depth=2, n_base_filters=16, initial_learning_rate=1e-3)
+    dis = fmodel.discriminator_image_3d(input_shape=[2] + list(sp), n_base_filters=8, depth=3, initial_learning_rate=1e-3,
+                                        **({"compute_dtype": dis_dtype} if dis_dtype else {}))
+    x, y = O.synthetic_batch((N, 1) + sp)
+
+    def batches():
+        while True:
+            yield x, y
+
+    np.random.seed(0)
+    torch.manual_seed(0)
+    cfg = dict(gd_loss_ratio=10, dis_steps=1, gen_steps=1, initial_learning_rate=1e-3, patience=1, learning_rate_drop=0.5, n_epochs=3,
+               batch_size=N, validation_batch_size=N, base_dir=str(tmp_path))
+    hist = train_adversarial(cfg, gen, dis, batches(), batches(), n_train_steps=4, n_validation_steps=1, verbose=0)
+    assert len(hist) == 3
+    for rec in hist:
+        assert all(np.isfinite(v) for k, v in rec.items() if isinstance(v, float)), rec
+    assert hist[0]["saved"] is not None and os.path.exists(hist[0]["saved"] + ".h5") and os.path.exists(hist[0]["saved"] + ".json")
+    assert hist[-1]["val_g_loss"] < hist[0]["val_g_loss"] + 0.05          # the segmentation does not fall apart under the adversary
+    assert dis.optimizer.lr == hist[-1]["lr"] or dis.optimizer.lr == hist[-1]["lr"] * 0.5
+    # semi-supervised variant: an unlabelled stream feeds the adversarial term
+    hist2 = train_adversarial(dict(cfg, n_epochs=1, base_dir=None), gen, dis, batches(), batches(), n_train_steps=2, n_validation_steps=1,
+                              semi_generator=batches(), verbose=0)
+    assert np.isfinite(hist2[0]["g_loss"]) and "g_seg_real_loss" in hist2[0]

@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Time the three steps of the adversarial loop at the benchmark's patch size (reference fetal/experiments/train_adv.py:229-248):
+the discriminator step on 2N samples, the generator step through the frozen discriminator on N, and the plain generator step.
+    python tools/bench_adversarial.py [--dis-dtype bf16|fp32] [--batch 4] [--steps 10]"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "fetal-mri-segmentation_amd"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--dis-dtype", default="bf16")
+    ap.add_argument("--batch", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--patch", type=int, nargs=3, default=[64, 128, 128])
+    a = ap.parse_args()
+    import torch
+    import fetal_net.model as fmodel
+    from fetal_net.adversarial import CombinedModel, input2discriminator, input2gan
+    sp, N = tuple(a.patch), a.batch
+    gen = fmodel.unet_model_3d(input_shape=(1,) + sp)
+    dis = fmodel.discriminator_image_3d(input_shape=[2] + list(sp), compute_dtype=a.dis_dtype)
+    comb = CombinedModel(gen, dis, gd_loss_ratio=10, lr=1e-4)
+    rs = np.random.RandomState(0)
+    x = torch.from_numpy(rs.randn(N, 1, *sp).astype(np.float32)).cuda()
+    y = torch.from_numpy((rs.rand(N, 1, *sp) > 0.7).astype(np.uint8)).cuda()
+    d_x = torch.from_numpy(rs.randn(2 * N, 2, *sp).astype(np.float32)).cuda()
+    d_y = np.concatenate([np.full((N, 1), 0.95), np.full((N, 1), 0.05)]).astype(np.float32)
+    valid = np.full((N, 1), 0.95, np.float32)
+
+    def timed(fn, label):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            fn()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) * 1e3 / a.steps
+        print("%-46s %8.2f ms" % (label, ms), flush=True)
+        return ms
+
+    print("patch %s  N = %d  generator bf16  discriminator %s (%d parameters)" % (sp, N, a.dis_dtype, dis.count_params()))
+    t_d = timed(lambda: dis.train_on_batch(d_x, d_y), "discriminator step (2N samples)")
+    t_c = timed(lambda: comb.train_on_batch(x, [valid, y]), "generator step through frozen discriminator")
+    t_g = timed(lambda: gen.train_on_batch(x, y), "plain generator step")
+    print("one round (dis_steps = gen_steps = 1, inputs resident): %.2f ms = %.1f patches/s" % (t_d + t_c, N / (t_d + t_c) * 1e3))
+    print("adversarial term on top of the plain step: %.2f ms" % (t_c - t_g))
+
+
+if __name__ == "__main__":
+    main()
