@@ -1081,39 +1081,49 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
             __builtin_amdgcn_s_barrier();
             PROF_T(e1);
             unsigned char* const stage = lds + hb * HALO_BYTES + cw * (32 * JT * BN * 2);
+            // the activation is a launch constant: none (every input-gradient launch) costs nothing, ReLU one v_max per value, LeakyReLU two
+            // operations - the general max(v, alpha * v) form for all three spent 256 VALU instructions per tile and wave on the identity
+            auto stage_tile = [&](auto act_tag) {
+                constexpr int ACT = decltype(act_tag)::value;
 #pragma unroll
-            for (int j = 0; j < JT; ++j) {
-                const int v = j * 32 + r;
-                const int vs = NT == 2 ? (v & 7) : ((v >> 2) & 3);
+                for (int j = 0; j < JT; ++j) {
+                    const int v = j * 32 + r;
+                    const int vs = NT == 2 ? (v & 7) : ((v >> 2) & 3);
 #pragma unroll
-                for (int c = 0; c < NT; ++c) {
+                    for (int c = 0; c < NT; ++c) {
 #pragma unroll
-                    for (int pq = 0; pq < 2; ++pq) {
-                        unsigned pk[2][2];
+                        for (int pq = 0; pq < 2; ++pq) {
+                            unsigned pk[2][2];
 #pragma unroll
-                        for (int u = 0; u < 2; ++u) {
-                            const int gq = 2 * pq + u;
-                            float o[4];
+                            for (int u = 0; u < 2; ++u) {
+                                const int gq = 2 * pq + u;
+                                float o[4];
 #pragma unroll
-                            for (int i = 0; i < 4; ++i) {
-                                const float vv = acc[j][c][4 * gq + i];
-                                o[i] = vmax(vv, __builtin_fmaf(vv, act_s, 0.f));
+                                for (int i = 0; i < 4; ++i) {
+                                    const float vv = acc[j][c][4 * gq + i];
+                                    if constexpr (ACT == FMRI_ACT_NONE) o[i] = vv;
+                                    else if constexpr (ACT == FMRI_ACT_RELU) o[i] = vmax(vv, 0.f);
+                                    else o[i] = vmax(vv, __builtin_fmaf(vv, act_s, 0.f));
+                                }
+                                pk[u][0] = pack2bf(o[0], o[1]);
+                                pk[u][1] = pack2bf(o[2], o[3]);
                             }
-                            pk[u][0] = pack2bf(o[0], o[1]);
-                            pk[u][1] = pack2bf(o[2], o[3]);
-                        }
 #pragma unroll
-                        for (int q = 0; q < 2; ++q) {
-                            auto sw = __builtin_amdgcn_permlane32_swap(pk[0][q], pk[1][q], false, false);
-                            pk[0][q] = sw[0];
-                            pk[1][q] = sw[1];
+                            for (int q = 0; q < 2; ++q) {
+                                auto sw = __builtin_amdgcn_permlane32_swap(pk[0][q], pk[1][q], false, false);
+                                pk[0][q] = sw[0];
+                                pk[1][q] = sw[1];
+                            }
+                            const int q = c * 4 + pq * 2 + hk;
+                            *reinterpret_cast<uint4*>(stage + v * (BN * 2) + (((q ^ vs) & SWM) << 4)) =
+                                make_uint4(pk[0][0], pk[0][1], pk[1][0], pk[1][1]);
                         }
-                        const int q = c * 4 + pq * 2 + hk;
-                        *reinterpret_cast<uint4*>(stage + v * (BN * 2) + (((q ^ vs) & SWM) << 4)) =
-                            make_uint4(pk[0][0], pk[0][1], pk[1][0], pk[1][1]);
                     }
                 }
-            }
+            };
+            if (act == FMRI_ACT_NONE) stage_tile(std::integral_constant<int, FMRI_ACT_NONE>{});
+            else if (act == FMRI_ACT_RELU) stage_tile(std::integral_constant<int, FMRI_ACT_RELU>{});
+            else stage_tile(std::integral_constant<int, FMRI_ACT_LEAKY>{});
             PROF_T(e2);
             init_acc(bvn);
             __builtin_amdgcn_s_barrier();                              // the whole tile is staged: all eight waves store it

@@ -261,7 +261,7 @@ def loss_and_grads(spec, W, x, y, dtype=torch.float64):
     loss = -dice                                             # reference metrics.py:31-32
     loss.backward()
     grads = OrderedDict((k, v.grad.detach().numpy().copy()) for k, v in Wt.items())
-    return dict(loss=float(loss), dice=float(dice), logits=logits.detach().numpy(), probs=probs.detach().numpy(),
+    return dict(loss=float(loss.detach()), dice=float(dice.detach()), logits=logits.detach().numpy(), probs=probs.detach().numpy(),
                 grads=grads)
 
 
