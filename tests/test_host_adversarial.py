@@ -169,3 +169,28 @@ def test_oracle_discriminator_gradients_are_consistent():
     probs = rs.rand(2, 1, 16, 16, 4)
     val, g = DO.adversarial_term(spec, W, probs, x[:, :1], np.array([[1.0], [0.9]]))
     assert g.shape == (2, 1, 16, 16, 4) and np.isfinite(val) and float(g.abs().max()) > 0
+
+
+def test_experiment_scripts_call_the_reference_generators_with_accepted_keywords(golden_dir):
+    """fetal/experiments/_common.generator_kwargs hands get_training_and_validation_generators exactly keywords the reference function
+    takes (fixture: its argument names, parsed from the reference source), and the semi-supervised stream swaps augment for val_augment
+    as reference train_semi.py:215-240 does"""
+    from fetal.experiments import _common as C
+    with open(os.path.join(golden_dir, "signatures_golden.json")) as f:
+        sig = json.load(f)["get_training_and_validation_generators"]
+    keys = ["batch_size", "validation_split", "validation_file", "training_file", "test_file", "n_labels", "labels", "patch_shape", "patch_depth",
+            "validation_batch_size", "augment", "skip_blank_train", "skip_blank_val", "truth_index", "truth_size", "prev_truth_index",
+            "prev_truth_size", "truth_downsample", "truth_crop", "patches_per_epoch", "categorical", "3D", "drop_easy_patches_train",
+            "drop_easy_patches_val"]
+    cfg = {k: i for i, k in enumerate(keys)}
+    cfg["patch_shape"] = [64, 64]
+    kw = C.generator_kwargs(cfg, overwrite=False)
+    assert set(kw) <= set(sig["args"]) - {"data_file"}, set(kw) - set(sig["args"])
+    assert kw["patch_shape"] == (64, 64, cfg["patch_depth"]) and kw["is3d"] == cfg["3D"] and kw["data_split"] == cfg["validation_split"]
+    semi = C.generator_kwargs(cfg, overwrite=True, val_augment=cfg["augment"])
+    semi.pop("augment")
+    assert set(semi) <= set(sig["args"]) and "val_augment" in semi and semi["overwrite"] is True
+    d = C.config_with_defaults({"dis_model_name": "discriminator_image"})
+    assert d["dis_model_name"] == "discriminator_image_3d" and d["gd_loss_ratio"] == 10 and d["dis_steps"] == d["gen_steps"] == 1
+    import fetal_net.model as fmodel
+    assert callable(getattr(fmodel, d["dis_model_name"]))
