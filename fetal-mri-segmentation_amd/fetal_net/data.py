@@ -4,8 +4,10 @@ The reference keeps its volumes in a PyTables file: three VLArrays of pickled nu
 plus `/subject_ids`, and everything downstream only uses `data_file.root.<name>[i]`, `len(data_file.root.data)`,
 `'subject_ids' in data_file.root` and `.close()`.  `open_data_file` returns an object with exactly that surface for
 
-  * a PyTables file, through `tables` when it is installed (the reference's own environment), and
-  * the PLAIN layout below, through this package's ctypes binding of libhdf5 - no PyTables, no blosc plug-in needed:
+  * a PyTables file as the reference writes it: through `tables` when that is installed (read-write), otherwise read-only through
+    `PyTablesDataFile` - libhdf5 over ctypes, the blosc chunk filter decoded by fetal_net/utils/blosc.py, the rows unpickled; pinned
+    by a file written with the reference's own functions under PyTables 3.6.1 (tests/golden/pytables_data_golden.h5), and
+  * the PLAIN layout below, through the same binding - no filter at all:
         /            attribute fmri_data_file = 1, n_samples
         /data/s<i>   one dataset per sample (any float dtype; the reference stores float64), /truth/s<i> (uint8), /mask/s<i> (optional)
         /subject_ids fixed-length byte strings (optional)
@@ -97,6 +99,76 @@ class PlainDataFile(object):
         return False
 
 
+class _Pickled(object):
+    """`root.data`-like sequence over a VLArray whose rows are pickles (PyTables ObjectAtom)"""
+
+    def __init__(self, rows):
+        self._rows = rows
+
+    def __len__(self):
+        return len(self._rows)
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[j] for j in range(*i.indices(len(self)))]
+        import warnings
+        with warnings.catch_warnings():                      # pickles of older numpy versions name numpy.core.*: still loadable, noisily
+            warnings.simplefilter("ignore", DeprecationWarning)
+            return pickle.loads(self._rows[i])
+
+    def __iter__(self):
+        return (self[i] for i in range(len(self)))
+
+
+class PyTablesDataFile(object):
+    """read-only view of a reference data file (reference data.py:11-17, :33-38, :65-66) without PyTables: `/data`, `/truth`, `/mask` are
+    1-D datasets of variable-length bytes (one pickled array per subject) whose chunks carry the blosc filter, `/subject_ids` a plain
+    string array.  An empty `/mask` (data.py:36-38 appends masks only when the subject has one) reads as a zero-length sequence."""
+
+    def __init__(self, filename):
+        from .utils import hdf5
+        self.filename = filename
+        self._f = hdf5.File(filename, "r")
+        self._sets = []
+        names = []
+        try:
+            for k in ("data", "truth", "mask"):
+                if k in self._f:
+                    d = self._f[k]
+                    if not isinstance(d, hdf5.VLenBytes):
+                        d.close()
+                        raise ValueError("%s:/%s is not a VLArray of pickled rows" % (filename, k))
+                    self._sets.append(d)
+                    names.append(k)
+            if "data" not in names or "truth" not in names:
+                raise ValueError("%s has no /data and /truth VLArrays: not a reference data file" % filename)
+        except Exception:
+            self.close()
+            raise
+        self.root = _Root(names + (["subject_ids"] if "subject_ids" in self._f else []))
+        for k, d in zip(names, self._sets):
+            setattr(self.root, k, _Pickled(d))
+        if "subject_ids" in self._f:
+            d = self._f["subject_ids"]
+            self.root.subject_ids = [bytes(v) for v in np.atleast_1d(np.asarray(d[()]))]
+            d.close()
+
+    def close(self):
+        for d in self._sets:
+            d.close()
+        self._sets = []
+        if self._f is not None:
+            self._f.close()
+            self._f = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+        return False
+
+
 def is_plain_data_file(filename):
     from .utils import hdf5
     if not hdf5.is_hdf5(filename):
@@ -106,7 +178,8 @@ def is_plain_data_file(filename):
 
 
 def open_data_file(filename, readwrite="r"):
-    """reference data.py:77-78.  Plain-layout files open through libhdf5; anything else is handed to PyTables."""
+    """reference data.py:77-78.  Plain-layout files open through libhdf5; a PyTables file goes to PyTables where that is installed and
+    to the built-in read-only reader where it is not."""
     if is_plain_data_file(filename):
         if readwrite != "r":
             raise ValueError("plain data files are read-only here; rewrite them with write_plain_data_file")
@@ -114,9 +187,9 @@ def open_data_file(filename, readwrite="r"):
     try:
         import tables
     except ImportError:
-        raise ImportError("%s is a PyTables data file and PyTables is not installed here: convert it once with "
-                          "`python tools/convert_data_file.py %s out.h5` in an environment that has PyTables "
-                          "(the blosc filter of reference data.py:13 is not part of plain libhdf5)" % (filename, filename))
+        if readwrite != "r":
+            raise ImportError("%s: writing a PyTables data file needs PyTables (reading does not)" % filename)
+        return PyTablesDataFile(filename)
     return tables.open_file(filename, readwrite)
 
 

@@ -11,8 +11,13 @@ module binds it with ctypes.  The surface imitates the few h5py idioms Keras' sa
     with File(path) as f:
         f.attrs["layer_names"]; f["conv3d_1"]["conv3d_1/kernel:0"][()]; list(f.keys())
 
-Everything raises (OSError / KeyError / TypeError); nothing is silently skipped.  Compression filters, chunking, references and
-compound types are not handled - Keras files use none of them.
+Everything raises (OSError / KeyError / TypeError); nothing is silently skipped.  Chunking, references and compound types are not
+written - Keras files use none of them.
+
+For the reference's DATA files (PyTables VLArrays of pickled arrays behind the blosc filter, reference fetal_net/data.py:11-17) there
+is a read path: `VLenBytes` reads the rows of a variable-length uint8 dataset, and `register_blosc_filter()` gives libhdf5 a decoder
+for filter 32001 (a ctypes callback into fetal_net/utils/blosc.py) so that the library can expand the chunks that hold the rows'
+heap references.
 """
 import ctypes as C
 import ctypes.util
@@ -96,6 +101,10 @@ def lib():
         "H5Aget_space": (hid_t, [hid_t]), "H5Aget_type": (hid_t, [hid_t]),
         "H5Aopen_by_idx": (hid_t, [hid_t, C.c_char_p, C.c_int, C.c_int, hsize_t, hid_t, hid_t]),
         "H5Aget_name": (C.c_ssize_t, [hid_t, C.c_size_t, C.c_char_p]),
+        "H5Tvlen_create": (hid_t, [hid_t]), "H5Tget_super": (hid_t, [hid_t]),
+        "H5Sselect_hyperslab": (C.c_int, [hid_t, C.c_int, C.POINTER(hsize_t), C.POINTER(hsize_t), C.POINTER(hsize_t), C.POINTER(hsize_t)]),
+        "H5Zregister": (C.c_int, [C.c_void_p]), "H5Zfilter_avail": (C.c_int, [C.c_int]),
+        "H5allocate_memory": (C.c_void_p, [C.c_size_t, C.c_int]), "H5free_memory": (C.c_int, [C.c_void_p]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(h, name)
@@ -117,7 +126,7 @@ def _check(v, what):
     return v
 
 
-_H5T_INTEGER, _H5T_FLOAT, _H5T_STRING = 0, 1, 3
+_H5T_INTEGER, _H5T_FLOAT, _H5T_STRING, _H5T_VLEN = 0, 1, 3, 9
 _H5I_GROUP, _H5I_DATASET = 2, 5
 _NATIVE = {"f4": "H5T_NATIVE_FLOAT_g", "f8": "H5T_NATIVE_DOUBLE_g", "i1": "H5T_NATIVE_INT8_g", "u1": "H5T_NATIVE_UINT8_g",
            "i2": "H5T_NATIVE_INT16_g", "u2": "H5T_NATIVE_UINT16_g", "i4": "H5T_NATIVE_INT32_g", "u4": "H5T_NATIVE_UINT32_g",
@@ -309,6 +318,113 @@ class Dataset(object):
             pass
 
 
+# ------------------------------------------------------------------------------------------------------------ blosc filter, VL rows
+BLOSC_FILTER_ID = 32001
+_H5Z_FLAG_REVERSE = 0x0100
+_H5Z_FUNC = C.CFUNCTYPE(C.c_size_t, C.c_uint, C.c_size_t, C.POINTER(C.c_uint), C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_void_p))
+
+
+class _H5ZClass2(C.Structure):
+    _fields_ = [("version", C.c_int), ("id", C.c_int), ("encoder_present", C.c_uint), ("decoder_present", C.c_uint), ("name", C.c_char_p),
+                ("can_apply", C.c_void_p), ("set_local", C.c_void_p), ("filter", _H5Z_FUNC)]
+
+
+_filter_keepalive = []
+
+
+def _blosc_filter(flags, cd_nelmts, cd_values, nbytes, buf_size, buf):
+    """H5Z_func_t: decode only.  Returns the number of valid bytes in the new buffer, 0 on failure (HDF5's convention)."""
+    try:
+        if not (flags & _H5Z_FLAG_REVERSE):
+            return 0                                        # writing through the blosc filter is not provided
+        from . import blosc
+        L = lib()
+        plain = blosc.decompress(C.string_at(buf[0], nbytes))
+        out = L.H5allocate_memory(max(len(plain), 1), 0)
+        if not out:
+            return 0
+        C.memmove(out, plain, len(plain))
+        L.H5free_memory(buf[0])
+        buf[0] = out
+        buf_size[0] = len(plain)
+        return len(plain)
+    except Exception:
+        return 0
+
+
+def register_blosc_filter():
+    """make filter 32001 ('blosc', the one PyTables registers) known to this process's libhdf5 unless a plug-in already provides it"""
+    L = lib()
+    if _filter_keepalive or L.H5Zfilter_avail(BLOSC_FILTER_ID) > 0:
+        return
+    fn = _H5Z_FUNC(_blosc_filter)
+    cls = _H5ZClass2(1, BLOSC_FILTER_ID, 0, 1, b"blosc", None, None, fn)
+    _filter_keepalive.extend([fn, cls])
+    _check(L.H5Zregister(C.byref(cls)), "H5Zregister(blosc)")
+
+
+class _HVL(C.Structure):
+    _fields_ = [("len", C.c_size_t), ("p", C.c_void_p)]
+
+
+class VLenBytes(object):
+    """rows of a 1-D dataset of H5T_VLEN { uint8 } - PyTables' VLArray with an ObjectAtom keeps one pickle per row this way"""
+
+    def __init__(self, did, name):
+        self.id, self.name = did, name
+        self.attrs = Attributes(self)
+        L = lib()
+        space = L.H5Dget_space(did)
+        self.shape = _shape_of(space)
+        L.H5Sclose(space)
+        ftype = L.H5Dget_type(did)
+        base = L.H5Tget_super(ftype)
+        ok = len(self.shape) == 1 and L.H5Tget_class(base) == _H5T_INTEGER and L.H5Tget_size(base) == 1
+        L.H5Tclose(base)
+        L.H5Tclose(ftype)
+        if not ok:
+            self.close()
+            raise TypeError("%s: only 1-D variable-length byte datasets are supported" % name)
+
+    def __len__(self):
+        return self.shape[0]
+
+    def __getitem__(self, i):
+        i = int(i)
+        if i < 0:
+            i += self.shape[0]
+        if not 0 <= i < self.shape[0]:
+            raise IndexError(i)
+        L = lib()
+        register_blosc_filter()
+        mem = _check(L.H5Tvlen_create(_g("H5T_NATIVE_UINT8_g")), "H5Tvlen_create")
+        fspace = L.H5Dget_space(self.id)
+        one = (hsize_t * 1)(1)
+        mspace = _check(L.H5Screate_simple(1, one, None), "H5Screate_simple")
+        try:
+            _check(L.H5Sselect_hyperslab(fspace, 0, (hsize_t * 1)(i), None, one, None), "H5Sselect_hyperslab")
+            row = _HVL()
+            _check(L.H5Dread(self.id, mem, mspace, fspace, 0, C.byref(row)), "H5Dread(%s[%d]) - is the chunk filter available?" % (self.name, i))
+            data = C.string_at(row.p, row.len) if row.len else b""
+            L.H5Dvlen_reclaim(mem, mspace, 0, C.byref(row))
+        finally:
+            L.H5Sclose(mspace)
+            L.H5Sclose(fspace)
+            L.H5Tclose(mem)
+        return data
+
+    def close(self):
+        if self.id is not None:
+            lib().H5Dclose(self.id)
+            self.id = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Group(object):
     def __init__(self, gid, name, owns=True):
         self.id, self.name, self._owns = gid, name, owns
@@ -349,7 +465,11 @@ class Group(object):
         if kind == _H5I_GROUP:
             return Group(_check(L.H5Gopen2(self.id, name.encode(), 0), "H5Gopen2"), full)
         if kind == _H5I_DATASET:
-            return Dataset(_check(L.H5Dopen2(self.id, name.encode(), 0), "H5Dopen2"), full)
+            did = _check(L.H5Dopen2(self.id, name.encode(), 0), "H5Dopen2")
+            ftype = L.H5Dget_type(did)
+            vlen = L.H5Tget_class(ftype) == _H5T_VLEN
+            L.H5Tclose(ftype)
+            return VLenBytes(did, full) if vlen else Dataset(did, full)
         raise TypeError("%s is neither a group nor a dataset" % full)
 
     def create_group(self, name):

@@ -56,7 +56,7 @@ def test_foreign_hdf5_is_not_mistaken_for_a_data_file(tmp_path):
     try:
         import tables  # noqa: F401
     except ImportError:
-        with pytest.raises(ImportError, match="convert_data_file"):
+        with pytest.raises(ValueError, match="not a reference data file"):
             D.open_data_file(p)
 
 
@@ -114,3 +114,88 @@ def test_norm_params_json(tmp_path):
     assert D.load_norm_params(str(tmp_path)) == (12.5, [3.0, 4.0])
     D.save_norm_params(str(tmp_path), None, None)                # normalize=False in the reference: both null
     assert D.load_norm_params(str(tmp_path)) == (None, None)
+
+
+# ---------------------------------------------------------------------------------------------- reference PyTables files, natively
+def test_blosc_decoder_against_frames_of_the_c_library(golden_dir):
+    """42 frames compressed by c-blosc 1.20.1 itself (through PyTables' filter: typesizes 1-8, byte shuffle on / off, levels 1 / 5 / 9,
+    single- and multi-block buffers with a short last block, the 16-byte-record chunk of a VLArray) decode to their plain contents"""
+    from fetal_net.utils import blosc
+    z = np.load(os.path.join(golden_dir, "blosc_frames_golden.npz"))
+    frames = [k for k in z.files if k.startswith("frame_")]
+    assert len(frames) == 42
+    seen = set()
+    for k in frames:
+        name = k[len("frame_"):].rsplit("_s", 1)[0]
+        frame = z[k].tobytes()
+        assert blosc.decompress(frame) == z["plain_" + name].tobytes(), k
+        seen.add((frame[2] & 1, frame[3], int.from_bytes(frame[4:8], "little") > int.from_bytes(frame[8:12], "little")))
+    assert {s[0] for s in seen} == {0, 1} and {s[1] for s in seen} >= {1, 2, 4, 8} and any(s[2] for s in seen)
+    # malformed input raises instead of returning garbage
+    good = z["frame_ramp_i4_s1_l5"].tobytes()
+    with pytest.raises(blosc.BloscError):
+        blosc.decompress(good[:40])
+    with pytest.raises(blosc.BloscError):
+        blosc.decompress(bytes([good[0], good[1], good[2] | (1 << 5)]) + good[3:])         # lz4 codec bits
+    with pytest.raises(blosc.BloscError):
+        blosc.decompress(bytes([3]) + good[1:])                                            # unknown container version
+    stored = bytes([2, 1, 0x2, 1]) + (5).to_bytes(4, "little") + (5).to_bytes(4, "little") + (21).to_bytes(4, "little") + b"hello"
+    assert blosc.decompress(stored) == b"hello"                                             # memcpy'd frame
+
+
+def test_reference_pytables_data_file_opens_without_pytables(golden_dir, tmp_path):
+    """tests/golden/pytables_data_golden.h5 was written by the reference's own create_data_file / add_data_to_storage (data.py:11-38)
+    under PyTables 3.6.1: VLArrays of pickled arrays behind blosc level 5.  The built-in reader returns every row exactly."""
+    from fetal_net.data import PyTablesDataFile, is_plain_data_file, open_data_file
+    path = os.path.join(golden_dir, "pytables_data_golden.h5")
+    z = np.load(os.path.join(golden_dir, "pytables_data_golden.npz"))
+    assert not is_plain_data_file(path)
+    f = open_data_file(path)
+    try:
+        import tables  # noqa: F401
+    except ImportError:
+        assert isinstance(f, PyTablesDataFile)
+    assert len(f.root.data) == len(f.root.truth) == len(f.root.mask) == 3
+    assert "subject_ids" in f.root and "data" in f.root and "nothing" not in f.root
+    assert [bytes(s) for s in f.root.subject_ids] == [bytes(s) for s in z["subject_ids"]]
+    for i in range(3):
+        for k in ("data", "truth", "mask"):
+            got, want = getattr(f.root, k)[i], z["%s_%d" % (k, i)]
+            assert got.dtype == want.dtype and got.shape == want.shape and np.array_equal(got, want), (k, i)
+    assert f.root.data[-1].shape == (6, 6, 5) and len(f.root.data[0:2]) == 2
+    with pytest.raises(IndexError):
+        f.root.data[3]
+    f.close()
+    with pytest.raises(ImportError):
+        try:
+            import tables  # noqa: F401
+            raise ImportError("PyTables present: the write path is PyTables' own")
+        except ImportError:
+            open_data_file(path, "a")
+    # the converter runs without PyTables too and its output is the plain layout with the same content
+    import subprocess
+    import sys
+    out = str(tmp_path / "plain.h5")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call([sys.executable, os.path.join(root, "tools", "convert_data_file.py"), path, out])
+    assert is_plain_data_file(out)
+    g = open_data_file(out)
+    for i in range(3):
+        for k in ("data", "truth", "mask"):
+            assert np.array_equal(getattr(g.root, k)[i], z["%s_%d" % (k, i)])
+    assert [bytes(s) for s in g.root.subject_ids] == [bytes(s) for s in z["subject_ids"]]
+    g.close()
+
+
+def test_device_side_consumers_accept_the_native_reader(golden_dir):
+    """what the generators do with a data file (reference generator.py:158-190, :246-275): length, per-subject arrays, split lists"""
+    from fetal_net.data import get_validation_split, open_data_file
+    f = open_data_file(os.path.join(golden_dir, "pytables_data_golden.h5"))
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        tr, va, te = get_validation_split(f, training_file=os.path.join(d, "tr.pkl"), validation_file=os.path.join(d, "va.pkl"),
+                                          test_file=os.path.join(d, "te.pkl"), data_split=0.67)
+    assert sorted(tr + va + te) == [0, 1, 2]
+    vol, lab = f.root.data[tr[0]], f.root.truth[tr[0]]
+    assert vol.shape == lab.shape and vol.dtype == np.float64 and lab.dtype == np.uint8
+    f.close()
