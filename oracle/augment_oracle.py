@@ -14,9 +14,12 @@ Follows:
   reference fetal_net/generator.py:13-57,222-328,385-401  DataFileDummy, pad_samples, data_generator, add_data, extract_patch, convert_data
   reference fetal_net/augment.py:380-471  permutation keys, permute_data, reverse_permute_data
   reference fetal_net/prediction.py:19-85,354-367  flip_it, predict_augment, predict_flips, predict, predict_with_permutations
-Third-party behaviour restated (libraries absent here: parity unpinned for these three): skimage.exposure.rescale_intensity
-(in_range=(lo,hi), out_range='image'), skimage.util.random_noise modes 'gaussian' / 'speckle' (clip to [0,1]), sklearn-style
-MinMaxScaler over the whole array (reference utils.py:116-313).
+Third-party behaviour restated (libraries absent from the main interpreter): skimage.exposure.rescale_intensity (in_range=(lo,hi),
+out_range='image'), skimage.util.random_noise modes 'gaussian' / 'speckle' / 'poisson' (clip to [0,1]), skimage.filters.gaussian, the
+sklearn-style MinMaxScaler over the whole array (reference utils.py:116-313).  PINNED: tests/golden/skimage_golden.npz holds outputs of
+the reference's own contrast_augment / add_gaussian_noise / add_speckle_noise / shot_noise / apply_gaussian_filter run over
+scikit-image 0.18.3 and scikit-learn 0.24.2 (generator tests/golden/make_skimage_fixture.py, run under the container's conda
+interpreter); tests/test_oracle_augment.py checks every restatement below against them.
 """
 import itertools
 import random
@@ -96,6 +99,27 @@ def add_gaussian_noise(data, sigma, noise):
 def add_speckle_noise(data, sigma, noise):
     s, scale, mn = _minmax01(np.asarray(data, dtype=np.float64))
     return (np.clip(s + s * (noise * sigma), 0.0, 1.0) - mn) / scale
+
+
+def shot_noise(data, poisson=None):
+    """reference augment.py:87-94: min-max to [0,1], quantise to 1023 levels, skimage random_noise('poisson', clip=True), undo the scaling.
+    skimage: vals = 2 ** ceil(log2(number of distinct values)); out = poisson(image * vals) / vals.  `poisson(lam)` defaults to numpy's
+    global generator, which is what skimage draws from."""
+    s, scale, mn = _minmax01(np.asarray(data, dtype=np.float64))
+    q = np.floor(s * 1023) / 1023
+    vals = 2 ** np.ceil(np.log2(len(np.unique(q))))
+    draw = (poisson or np.random.poisson)(q * vals) / float(vals)
+    return (np.clip(draw, 0.0, 1.0) - mn) / scale
+
+
+def apply_gaussian_filter(data, sigma):
+    """reference augment.py:113-114 = skimage.filters.gaussian(data, sigma): scipy's gaussian_filter with mode 'nearest', truncate 4; a 3-D
+    array whose last axis has length 3 is taken for an RGB image by skimage (multichannel guess): no smoothing along that axis"""
+    data = np.asarray(data, dtype=np.float64)
+    sig = [sigma] * data.ndim
+    if data.ndim == 3 and data.shape[-1] == 3:
+        sig[-1] = 0
+    return ndimage.gaussian_filter(data, sig, mode="nearest", truncate=4.0)
 
 
 # ------------------------------------------------------------------------------------------------ augment_data

@@ -116,3 +116,69 @@ def test_tta(gold):
     for seed in meta["tta"]["augment_seeds"]:
         np.random.seed(seed)
         np.testing.assert_allclose(A.predict_augment(pw, vol, num_augments=1), arr["tta_augment_%d" % seed], rtol=0, atol=1e-10)
+
+
+# ------------------------------------------------------------------------------------------------ scikit-image / scikit-learn pins
+def _sk(golden_dir):
+    import os
+    return np.load(os.path.join(golden_dir, "skimage_golden.npz"))
+
+
+def _cases(z, prefix):
+    n = 0
+    while "%s_%d" % (prefix, n) in z.files:
+        key = "%s_%d" % (prefix, n)
+        yield key, z["in_" + str(z[key + "_in"])], z[key + "_args"], z[key]
+        n += 1
+
+
+def test_contrast_augment_matches_skimage_rescale_intensity(golden_dir):
+    """reference contrast_augment over scikit-image 0.18.3 (the fixture) vs the restatement, incl. a window outside the data range, an
+    all-negative volume and a nearly empty window"""
+    z = _sk(golden_dir)
+    seen = 0
+    for key, vol, (lo, hi), want in _cases(z, "contrast"):
+        got = A.contrast_augment(vol, lo, hi)
+        assert np.abs(got - want).max() <= 1e-12 * max(1.0, np.abs(want).max()), key
+        seen += 1
+    assert seen == 5
+
+
+def test_noise_augmentations_match_skimage_random_noise(golden_dir):
+    """add_gaussian_noise / add_speckle_noise: the fixture was drawn from numpy's global generator seeded right before the call; skimage
+    draws normal(0, sqrt(sigma^2), shape) once, which the legacy RandomState of any numpy reproduces"""
+    z = _sk(golden_dir)
+    for kind, fn in (("gaussian", A.add_gaussian_noise), ("speckle", A.add_speckle_noise)):
+        seen = 0
+        for key, vol, (sigma, seed), want in _cases(z, kind):
+            draw = np.random.RandomState(int(seed)).normal(0.0, (sigma ** 2) ** 0.5, vol.shape)
+            got = fn(vol, sigma, draw / sigma)
+            assert np.abs(got - want).max() <= 1e-12 * max(1.0, np.abs(want).max()), key
+            seen += 1
+        assert seen == 4
+
+
+def test_shot_noise_matches_skimage_poisson(golden_dir):
+    z = _sk(golden_dir)
+    seen = 0
+    for key, vol, (seed,), want in _cases(z, "shot"):
+        rs = np.random.RandomState(int(seed))
+        got = A.shot_noise(vol, poisson=rs.poisson)
+        assert np.abs(got - want).max() <= 1e-12 * max(1.0, np.abs(want).max()), key
+        seen += 1
+    assert seen == 3
+
+
+def test_gaussian_filter_matches_skimage_filters_gaussian(golden_dir):
+    z = _sk(golden_dir)
+    seen = 0
+    for key, vol, (sigma,), want in _cases(z, "gfilter"):
+        got = A.apply_gaussian_filter(vol, sigma)
+        assert np.abs(got - want).max() <= 1e-12 * max(1.0, np.abs(want).max()), key
+        seen += 1
+    assert seen == 5
+    # skimage's RGB guess: a 3-D array with 3 planes along the last axis is not smoothed along it
+    vol = np.random.RandomState(0).rand(6, 5, 3)
+    got = A.apply_gaussian_filter(vol, 1.0)
+    from scipy import ndimage
+    assert np.allclose(got, ndimage.gaussian_filter(vol, [1.0, 1.0, 0.0], mode="nearest", truncate=4.0))
