@@ -117,7 +117,54 @@ __global__ void k_noise(T* __restrict__ x, int64_t n, const float* __restrict__ 
     }
 }
 
+// shot noise (reference augment.py:87-94): MinMaxScaler((0,1)) -> floor(x * 1023) / 1023 -> skimage random_noise('poisson', clip=True) ->
+// inverse scaling.  skimage: vals = 2 ** ceil(log2(number of distinct values)); out = poisson(image * vals) / vals.  Three passes:
+//   phase 0  mark which of the 1024 quantisation levels occur                               (present[1024], zeroed by the caller)
+//   phase 1  rates[t] = q[t] * vals  - the caller draws Poisson(rates) (torch.poisson; the draws are the only random part)
+//   phase 2  x[t] = (clip(draws[t] / vals, 0, 1) - mn) / scale
+__device__ __forceinline__ float shot_vals(const int* __restrict__ present) {
+    int cnt = 0;
+    for (int i = 0; i < 1024; ++i) cnt += present[i] != 0;
+    int v = 1;
+    while (v < cnt) v <<= 1;                       // 2 ** ceil(log2(cnt))
+    return (float)v;
+}
+template <typename T>
+__global__ void k_shot_noise(T* __restrict__ x, int64_t n, const float* __restrict__ stats, int* __restrict__ present, float* __restrict__ rates,
+                             const float* __restrict__ draws, int phase) {
+    const float dmin = stats[0], rng = stats[1] - stats[0];
+    const float scale = 1.f / (rng != 0.f ? rng : 1.f), mn = -dmin * scale;
+    __shared__ float vals_s;
+    if (phase > 0) {
+        if (threadIdx.x == 0) vals_s = shot_vals(present);
+        __syncthreads();
+    }
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
+        if (phase == 2) {
+            const float s = fminf(fmaxf(draws[t] / vals_s, 0.f), 1.f);
+            x[t] = from_f<T>((s - mn) / scale);
+            continue;
+        }
+        const float s = fminf(fmaxf(to_f<T>(x[t]) * scale + mn, 0.f), 1.f);
+        const float level = floorf(s * 1023.f);
+        if (phase == 0) present[(int)level] = 1;
+        else rates[t] = level / 1023.f * vals_s;
+    }
+}
+
 }  // namespace
+
+extern "C" int fmri_shot_noise_step(void* x, int64_t n, int dtype, const float* stats, int* present, float* rates, const float* draws, int phase,
+                                    fmri_stream_t stream) {
+    if (n < 1 || phase < 0 || phase > 2 || !x || !stats || !present || (phase == 1 && !rates) || (phase == 2 && !draws)) return FMRI_E_SHAPE;
+    hipStream_t st = as_stream(stream);
+    const int grid = grid_for(n);
+    if (dtype == FMRI_F32) k_shot_noise<float><<<grid, 256, 0, st>>>((float*)x, n, stats, present, rates, draws, phase);
+    else if (dtype == FMRI_BF16) k_shot_noise<bf16_t><<<grid, 256, 0, st>>>((bf16_t*)x, n, stats, present, rates, draws, phase);
+    else return FMRI_E_DTYPE;
+    FMRI_LAUNCH_CHECK();
+    return FMRI_OK;
+}
 
 extern "C" int fmri_affine_sample(const void* vol, int vol_dtype, int X, int Y, int Z, const double* affine, int x0, int y0, int z0, int nx,
                                   int ny, int nz, int order, float cval, void* out, int out_dtype, int out_ld, fmri_stream_t stream) {

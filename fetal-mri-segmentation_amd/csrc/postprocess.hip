@@ -17,22 +17,27 @@ __device__ __forceinline__ int reflect_idx(int i, int n) {          // scipy mod
     return i;
 }
 
-__global__ void k_correlate1d_sym(const double* __restrict__ src, double* __restrict__ dst, int X, int Y, int Z, int axis,
+// T = double: the post-processing volume (bit-identical to scipy).  T = float: a training patch (skimage.filters.gaussian of the
+// augmentation chain, reference augment.py:113-114): the same sums in fp64, the result rounded once to the patch's fp32.
+// NEAREST = scipy mode 'nearest' (a a a a | a b c d | d d d d), what skimage.filters.gaussian passes; else 'reflect'.
+template <typename T, bool NEAREST>
+__global__ void k_correlate1d_sym(const T* __restrict__ src, T* __restrict__ dst, int X, int Y, int Z, int axis,
                                   const double* __restrict__ w, int radius) {
 #pragma clang fp contract(off)      // separately rounded multiply and add: scipy's C loop is compiled without fused operations
     const int64_t total = (int64_t)X * Y * Z;
     const int n = axis == 0 ? X : (axis == 1 ? Y : Z);
     const int64_t stride = axis == 0 ? (int64_t)Y * Z : (axis == 1 ? Z : 1);
+    auto at = [&](int i) { return NEAREST ? min(max(i, 0), n - 1) : reflect_idx(i, n); };
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
         const int z = (int)(t % Z);
         const int64_t q = t / Z;
         const int y = (int)(q % Y), x = (int)(q / Y);
         const int l = axis == 0 ? x : (axis == 1 ? y : z);
         const int64_t base = t - (int64_t)l * stride;
-        double acc = src[t] * w[radius];
+        double acc = (double)src[t] * w[radius];
         for (int jj = -radius; jj < 0; ++jj)
-            acc += (src[base + (int64_t)reflect_idx(l + jj, n) * stride] + src[base + (int64_t)reflect_idx(l - jj, n) * stride]) * w[jj + radius];
-        dst[t] = acc;
+            acc += ((double)src[base + (int64_t)at(l + jj) * stride] + (double)src[base + (int64_t)at(l - jj) * stride]) * w[jj + radius];
+        dst[t] = (T)acc;
     }
 }
 
@@ -138,7 +143,17 @@ __global__ void k_cc_select(const int32_t* __restrict__ lab, const unsigned long
 extern "C" int fmri_correlate1d_f64(const double* src, double* dst, int X, int Y, int Z, int axis, const double* weights, int radius,
                                     fmri_stream_t stream) {
     if (!src || !dst || !weights || src == dst || X <= 0 || Y <= 0 || Z <= 0 || axis < 0 || axis > 2 || radius < 0) return FMRI_E_SHAPE;
-    k_correlate1d_sym<<<grid_for((int64_t)X * Y * Z, 256, 8192), 256, 0, as_stream(stream)>>>(src, dst, X, Y, Z, axis, weights, radius);
+    k_correlate1d_sym<double, false><<<grid_for((int64_t)X * Y * Z, 256, 8192), 256, 0, as_stream(stream)>>>(src, dst, X, Y, Z, axis, weights, radius);
+    FMRI_LAUNCH_CHECK();
+    return FMRI_OK;
+}
+extern "C" int fmri_correlate1d_f32(const float* src, float* dst, int X, int Y, int Z, int axis, const double* weights, int radius, int mode,
+                                    fmri_stream_t stream) {
+    if (!src || !dst || !weights || src == dst || X <= 0 || Y <= 0 || Z <= 0 || axis < 0 || axis > 2 || radius < 0 || (mode != 0 && mode != 1))
+        return FMRI_E_SHAPE;
+    const int grid = grid_for((int64_t)X * Y * Z, 256, 8192);
+    if (mode == 1) k_correlate1d_sym<float, true><<<grid, 256, 0, as_stream(stream)>>>(src, dst, X, Y, Z, axis, weights, radius);
+    else k_correlate1d_sym<float, false><<<grid, 256, 0, as_stream(stream)>>>(src, dst, X, Y, Z, axis, weights, radius);
     FMRI_LAUNCH_CHECK();
     return FMRI_OK;
 }

@@ -12,10 +12,11 @@ yield ([x, masks], y) like the reference's convert_data (generator.py:397-401): 
 = 0, same transformation) at the label slices.  As in the reference the masks are NOT padded with the volumes.
 
 `device_data_generator` keeps the keyword arguments of the reference's `data_generator` (generator.py:222-225).
-Applied augmenters: flip, scale, iso_scale, rotate, translate, contrast, intensity_multiplication, gaussian_noise, speckle_noise.
-Not applied (their random draws are still consumed so that the affine part stays aligned with a seeded reference run):
-poisson_noise, gaussian_filter, piecewise_affine, elastic_transform, coarse_dropout - a warning is issued once, or
-NotImplementedError with strict=True.  The noise fields come from a torch device generator (`noise_seed`), not numpy.
+Applied augmenters: flip, scale, iso_scale, rotate, translate, contrast, intensity_multiplication, gaussian_filter (skimage.filters.gaussian),
+poisson_noise (the reference's shot_noise), speckle_noise, gaussian_noise - in the reference's order (augment.py:348-367).
+Not applied (their random draws are still consumed so that the affine part stays aligned with a seeded reference run): imgaug's
+piecewise_affine, elastic_transform, coarse_dropout - a warning is issued once, or NotImplementedError with strict=True.  The noise
+fields (normal and Poisson draws) come from a torch device generator (`noise_seed`), not numpy.
 """
 import random
 import warnings
@@ -24,7 +25,7 @@ import numpy as np
 
 from .augment import distort_image, draw_augment_parameters
 
-_UNSUPPORTED = ("poisson_noise", "gaussian_filter", "piecewise_affine", "elastic_transform", "coarse_dropout")
+_UNSUPPORTED = ("piecewise_affine", "elastic_transform", "coarse_dropout")        # imgaug's augmenters
 
 
 class DeviceDataFile(object):
@@ -106,8 +107,7 @@ class _Sampler(object):
         self.gen = torch.Generator(device=ddf.device)
         self.gen.manual_seed(noise_seed)
         if augment is not None:
-            bad = [k for k in _UNSUPPORTED if augment.get(k) is not None and not (k == "gaussian_filter" and augment[k]["prob"] <= 0)
-                   and not (k == "elastic_transform" and augment[k]["alpha"] <= 0)]
+            bad = [k for k in _UNSUPPORTED if augment.get(k) is not None and not (k == "elastic_transform" and augment[k]["alpha"] <= 0)]
             if bad:
                 msg = "augmenters not applied on the device path: %s" % ", ".join(bad)
                 if strict:
@@ -145,7 +145,8 @@ class _Sampler(object):
                               out_ld=self.truth_size)
         img = x_slot if self.n_chan == ps[2] else None
         if p is not None:
-            need_intensity = p["contrast"] is not None or p["intensity_multiplication"] != 1 or p["apply_speckle_noise"] or p["apply_gaussian_noise"]
+            need_intensity = (p["contrast"] is not None or p["intensity_multiplication"] != 1 or p["apply_speckle_noise"] or p["apply_gaussian_noise"]
+                              or p["apply_gaussian_filter"] or p["apply_poisson_noise"])
             if need_intensity:
                 if img is None:                            # image channels interleaved with the previous-slice truth: work on a copy
                     img = x_slot[..., :ps[2]].contiguous()
@@ -153,6 +154,14 @@ class _Sampler(object):
                     ops.minmax(img, self.stats)
                     lo, hi = p["contrast"] if p["contrast"] is not None else (0.0, 0.0)
                     ops.rescale_intensity(img, self.stats, p["contrast"] is not None, lo, hi, p["intensity_multiplication"])
+                # order of reference augment.py:354-367: gaussian filter, shot (poisson) noise, speckle, gaussian noise
+                if p["apply_gaussian_filter"]:
+                    smooth = ops.gaussian_filter_f32(img, p["gaussian_sigma"])
+                    if smooth is not img:
+                        img.copy_(smooth)
+                if p["apply_poisson_noise"]:
+                    ops.minmax(img, self.stats)
+                    ops.shot_noise(img, self.stats, generator=self.gen)
                 for flag, key, kind in (("apply_speckle_noise", "speckle_noise", 1), ("apply_gaussian_noise", "gaussian_noise", 0)):
                     if p[flag]:
                         ops.minmax(img, self.stats)

@@ -586,3 +586,45 @@ def discriminator_input(probs, x, out, merge=False):
     check(lib().fmri_discriminator_input(_p(probs), L, _p(x), Cc, dt(x), _p(out), out.shape[-1], dt(out), nvox, int(merge), _s()),
           "fmri_discriminator_input")
     return out
+
+
+# ---------------------------------------------------------------------------------------------------- augmenters of the skimage family
+def gaussian_filter_f32(patch, sigma, truncate=4.0, mode="nearest"):
+    """skimage.filters.gaussian(patch, sigma) of an fp32 device patch [X,Y,Z] (reference augment.py:113-114): scipy's weights, mode
+    'nearest'; a patch with 3 planes along the last axis is not smoothed along it (skimage takes it for an RGB image).  Returns a new
+    tensor (or `patch` itself when every sigma is ~0)."""
+    import numpy as np
+    _need_cuda(patch)
+    assert patch.dtype == torch.float32 and patch.dim() == 3
+    X, Y, Z = patch.shape
+    sig = [float(sigma)] * 3
+    if Z == 3:
+        sig[2] = 0.0
+    a = patch
+    for axis, sd in enumerate(sig):
+        if sd <= 1e-15:
+            continue
+        radius = int(truncate * sd + 0.5)
+        x = np.arange(-radius, radius + 1)
+        phi = np.exp(-0.5 / (sd * sd) * x ** 2)
+        w = torch.from_numpy(phi / phi.sum()).to(patch.device)
+        b = torch.empty_like(patch)
+        check(lib().fmri_correlate1d_f32(_p(a), _p(b), X, Y, Z, axis, _p(w), radius, 1 if mode == "nearest" else 0, _s()), "fmri_correlate1d_f32")
+        a = b
+    return a
+
+
+def shot_noise(x, stats, generator=None, draws_fn=None):
+    """reference augment.py:87-94 in place on `x` (fp32 / bf16 device tensor); `stats` = minmax(x) taken before the call.  The Poisson
+    draws come from torch's device generator (`draws_fn(rates)` overrides them: tests feed the oracle's own draws)."""
+    _need_cuda(x, stats)
+    n = x.numel()
+    present = torch.zeros(1024, dtype=torch.int32, device=x.device)
+    rates = torch.empty(n, dtype=torch.float32, device=x.device)
+    L = lib()
+    check(L.fmri_shot_noise_step(_p(x), n, _dt_any(x), _p(stats), _p(present), 0, 0, 0, _s()), "fmri_shot_noise_step(0)")
+    check(L.fmri_shot_noise_step(_p(x), n, _dt_any(x), _p(stats), _p(present), _p(rates), 0, 1, _s()), "fmri_shot_noise_step(1)")
+    draws = draws_fn(rates) if draws_fn is not None else torch.poisson(rates, generator=generator)
+    draws = draws.to(torch.float32).contiguous()
+    check(L.fmri_shot_noise_step(_p(x), n, _dt_any(x), _p(stats), _p(present), 0, _p(draws), 2, _s()), "fmri_shot_noise_step(2)")
+    return rates

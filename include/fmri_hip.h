@@ -259,6 +259,16 @@ int fmri_rescale_intensity(void* x, int64_t n, int dtype, const float* stats, in
  * (reference augment.py:99-110).  noise: n fp32 N(0,1) draws on the device; stats = fmri_minmax of x before the call. In place. */
 int fmri_noise_augment(void* x, int64_t n, int dtype, const float* stats, const float* noise, int kind, float sigma,
                        fmri_stream_t stream);
+/* shot noise (reference augment.py:87-94): MinMaxScaler((0,1)) -> floor(x * 1023) / 1023 -> skimage random_noise('poisson', clip=True) ->
+ * inverse scaling, in three phases around the caller's Poisson draw: 0 = mark the occupied quantisation levels in present (int32 [1024],
+ * zeroed by the caller); 1 = rates[t] = q[t] * vals with vals = 2 ** ceil(log2(number of occupied levels)) (skimage's rule); 2 = x[t] from
+ * draws[t] ~ Poisson(rates[t]) (fp32, device).  stats = fmri_minmax of x before phase 0. */
+int fmri_shot_noise_step(void* x, int64_t n, int dtype, const float* stats, int* present, float* rates, const float* draws, int phase,
+                         fmri_stream_t stream);
+/* one axis of skimage.filters.gaussian on an fp32 patch [X][Y][Z] (reference augment.py:113-114): weights fp64 [2*radius+1] on the device,
+ * sums in fp64 in scipy's order, result rounded to fp32; mode 0 = 'reflect', 1 = 'nearest' (skimage's default).  src != dst. */
+int fmri_correlate1d_f32(const float* src, float* dst, int X, int Y, int Z, int axis, const double* weights, int radius, int mode,
+                         fmri_stream_t stream);
 
 /* ---- plumbing: dtype casts used around the boundary (fp32 <-> bf16), n elements */
 int fmri_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, fmri_stream_t stream);

@@ -158,3 +158,103 @@ def test_device_generator_reproduces_the_reference_batches(gold):
             assert x.is_cuda and y.is_cuda
             np.testing.assert_array_equal(y.cpu().numpy(), gy, err_msg=c["name"])
             np.testing.assert_allclose(x.cpu().numpy(), gx, rtol=0, atol=2e-5, err_msg=c["name"])
+
+
+# ------------------------------------------------------------------------------------------------ gaussian filter, shot noise (skimage family)
+def test_gaussian_filter_augmentation_vs_the_reference_outputs(ops, golden_dir):
+    """fmri_correlate1d_f32 (mode 'nearest', fp64 sums, fp32 storage) x 3 axes against what the reference's apply_gaussian_filter returned
+    over scikit-image 0.18.3 (tests/golden/skimage_golden.npz): one fp32 rounding of input and output"""
+    z = np.load(os.path.join(golden_dir, "skimage_golden.npz"))
+    n = 0
+    while "gfilter_%d" % n in z.files:
+        vol, sigma, want = z["in_" + str(z["gfilter_%d_in" % n])], float(z["gfilter_%d_args" % n][0]), z["gfilter_%d" % n]
+        t = torch.from_numpy(vol.astype(np.float32)).cuda()
+        got = ops.gaussian_filter_f32(t, sigma).cpu().numpy().astype(np.float64)
+        scale = max(np.abs(want).max(), 1e-30)
+        assert np.abs(got - want).max() <= 3e-7 * scale, (n, np.abs(got - want).max() / scale)
+        n += 1
+    assert n == 5
+    # a larger patch, a radius beyond the extent of an axis (sigma 2.5 -> radius 10 on an 8-long axis), the RGB rule of skimage
+    rs = np.random.RandomState(4)
+    for shape, sigma in (((40, 24, 8), 2.5), ((16, 16, 3), 1.2), ((9, 7, 5), 0.4)):
+        vol = rs.randn(*shape).astype(np.float32)
+        got = ops.gaussian_filter_f32(torch.from_numpy(vol).cuda(), sigma).cpu().numpy()
+        want = OA.apply_gaussian_filter(vol.astype(np.float64), sigma)
+        assert np.abs(got - want).max() <= 3e-7 * np.abs(want).max(), shape
+
+
+def test_shot_noise_vs_oracle_with_the_same_poisson_draws(ops):
+    """the deterministic frame of the reference's shot_noise (min-max scaling, 1023-level quantisation, skimage's power-of-two `vals`,
+    clip, inverse scaling) with the device's rates handed to numpy's Poisson generator - the oracle consumes the very same draws"""
+    rs = np.random.RandomState(9)
+    for shape, gen in (((12, 10, 6), lambda: rs.randn(12, 10, 6) * 40 + 100), ((8, 8, 4), lambda: np.round(rs.rand(8, 8, 4) * 5) / 5)):
+        x = gen().astype(np.float32)
+        t = torch.from_numpy(x.copy()).cuda()
+        stats = torch.empty(2, device="cuda")
+        ops.minmax(t, stats)
+        seen = {}
+
+        def draws_fn(rates):
+            lam = rates.cpu().numpy().astype(np.float64)
+            seen["lam"] = lam
+            seen["draw"] = np.random.RandomState(21).poisson(lam)
+            return torch.from_numpy(seen["draw"].astype(np.float32)).cuda()
+
+        ops.shot_noise(t, stats, draws_fn=draws_fn)
+        got = t.cpu().numpy().astype(np.float64)
+        # oracle on the fp32 values, fed the same draws; its rates must agree with the device's except where fp32 rounding moves a
+        # value across a quantisation boundary (none in these volumes)
+        want_rates = {}
+        want = OA.shot_noise(x.astype(np.float64), poisson=lambda lam: (want_rates.setdefault("lam", lam), seen["draw"].reshape(lam.shape))[1])
+        lam_dev, lam_ref = seen["lam"].reshape(x.shape), want_rates["lam"]
+        off = np.abs(lam_dev - lam_ref) > 1e-3 * max(lam_ref.max(), 1.0)
+        assert off.mean() <= 2e-3, off.mean()
+        scale = np.abs(want).max()
+        assert np.abs(got - want).max() <= 2e-6 * scale
+        # skimage's rule for the number of levels: a power of two >= the number of distinct quantised values
+        levels = len(np.unique(np.floor(np.clip((x.astype(np.float64) - x.min()) / (x.max() - x.min()), 0, 1) * 1023)))
+        vals = 2 ** int(np.ceil(np.log2(levels)))
+        assert abs(lam_dev.max() - vals) <= 1e-3 * vals                 # the maximum (scaled value 1.0) has rate exactly vals
+
+
+def test_shot_noise_device_draws_are_poisson(ops):
+    """with torch's device generator: mean and variance of the scaled draws match the Poisson law (statistical check, fixed seed)"""
+    x = torch.linspace(0.0, 1.0, 1024, device="cuda").repeat(256).contiguous()          # all 1024 levels occupied -> vals = 1024
+    stats = torch.empty(2, device="cuda")
+    ops.minmax(x, stats)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(5)
+    ref = x.clone()
+    rates = ops.shot_noise(x, stats, generator=g)
+    torch.cuda.synchronize()
+    assert abs(float(rates.max()) - 1024.0) < 1e-2
+    sel = (ref > 0.45) & (ref < 0.55)
+    lam = rates[sel].double()
+    d = (x[sel] * 1024.0).double()                          # the draws themselves (the band is far from the clip at 1.0)
+    assert abs(float((d - lam).mean())) < 0.01 * float(lam.mean())
+    assert abs(float(((d - lam) ** 2).mean()) / float(lam.mean()) - 1.0) < 0.05                   # Poisson: variance == mean
+    assert float(x.min()) >= 0.0 and float(x.max()) <= 1.0
+
+
+def test_device_generator_applies_gaussian_filter_and_poisson_noise():
+    """the two augmenters in the generator: always-on configuration smooths the patch (lower high-frequency energy than the plain patch
+    of the same seed) and the labels are untouched; no 'not applied' warning is raised for them any more"""
+    import warnings
+    from fetal_net.device_generator import device_data_generator
+    vols, truths = synth_volumes(3, [(40, 40, 24)])
+    df = FakeDataFile(vols, truths)
+    outs = {}
+    for tag, aug in (("plain", {"flip": [0, 0, 0]}), ("aug", {"flip": [0, 0, 0], "gaussian_filter": {"prob": 1.0, "max_sigma": 1.5}, "poisson_noise": 1.0})):
+        np.random.seed(2)
+        random.seed(2)
+        with warnings.catch_warnings():
+            warnings.simplefilter("error")
+            gen = device_data_generator(df, [0], batch_size=1, augment=aug, patch_shape=(16, 16, 8), skip_blank=False, categorical=False,
+                                        is3d=True, truth_index=0, truth_size=8, shuffle_index_list=False)
+            x, y = next(gen)
+        outs[tag] = (x.float().cpu().numpy(), y.cpu().numpy())
+    (xp, yp), (xa, ya) = outs["plain"], outs["aug"]
+    assert xp.shape == xa.shape and np.isfinite(xa).all()
+    rough = lambda a: np.abs(np.diff(a, axis=2)).mean()
+    assert not np.allclose(xp, xa)
+    assert xa.min() >= xp.min() - 1e-3 * abs(xp.min()) - 1e-3 and xa.max() <= xp.max() + 1e-3 * abs(xp.max()) + 1e-3      # smoothing + clipped noise stay in range
