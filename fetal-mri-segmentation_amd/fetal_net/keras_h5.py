@@ -13,8 +13,10 @@ LAYOUT of keras/engine/saving.py (Keras 2.2.x - the version the reference's API 
 A weights-only file (`save_weights`) is the /model_weights group placed at the root.
 
 Writing: the files are meant to open in Keras 2.2 (`load_model(..., custom_objects=...)`, `load_weights`) - the layer configs below
-carry every key the Keras layer constructors serialise.  PARITY UNPINNED: no Keras / h5py exists here to read a file back with, the
-structure is checked with the HDF5 tools (h5dump) and by round trip only.
+carry every key the Keras layer constructors serialise.  Pinned at the h5py level (Keras' own HDF5 layer): a file written by h5py through
+Keras 2.2.4's saving call sequence is read here (tests/golden/keras_like_golden.h5, make_keras_h5_fixture.py), and files written here are
+read by h5py through Keras' loading call sequence (tests/keras_h5_read_like_keras.py) - both run under the container's conda
+interpreter, the only one with h5py.  Keras itself exists nowhere in this image: its call sequences and JSON configs are restated.
 Reading: weights are matched to the model's weighted layers BY ORDER (what Keras' `load_weights` does when `by_name=False`), so files
 whose auto-numbered names differ (conv3d_15 ...) load too; `infer_builder` recovers the builder call from `model_config`, so a
 reference-trained `.h5` opens with `load_old_model(path)` alone.

@@ -279,3 +279,76 @@ def test_h5dump_reads_the_file(tmp_path):
     out = subprocess.run([tool, "-H", path], capture_output=True, text=True, timeout=60)
     assert out.returncode == 0
     assert 'GROUP "model_weights"' in out.stdout and 'DATASET "kernel:0"' in out.stdout and "H5T_IEEE_F32LE" in out.stdout
+
+
+# ---------------------------------------------------------------------------------------------- pinned against h5py (Keras' own HDF5 layer)
+CONDA_PY = "/opt/conda/bin/python3.9"          # the container's stray interpreter: the only one with h5py (no Keras anywhere)
+
+
+def test_h5py_written_keras_style_file_loads(golden_dir):
+    """tests/golden/keras_like_golden.h5 was written by h5py 3.3.0 through Keras 2.2.4's saving call sequence (restated in
+    make_keras_h5_fixture.py): variable-length ASCII scalars, fixed-length string lists, nested dataset names, an int64 scalar.  The
+    reader recovers the builder, every weight and the Adam state; load_old_model opens it with no other information."""
+    import fetal_net.model as models
+    from fetal_net import keras_h5
+    from fetal_net.training import load_old_model
+    path = os.path.join(golden_dir, "keras_like_golden.h5")
+    z = np.load(os.path.join(golden_dir, "keras_like_golden.npz"))
+    kw = json.loads(bytes(z["builder_kwargs"]).decode())
+    with hdf5.File(path) as f:
+        assert bytes(f.attrs["keras_version"]) == b"2.2.4" and bytes(f.attrs["backend"]) == b"tensorflow"
+        assert json.loads(bytes(f.attrs["model_config"]).decode())["class_name"] == "Model"
+    meta = __import__("fetal_net.engine_model", fromlist=["x"]).read_checkpoint_meta(path)
+    assert meta["builder"] == "unet_model_3d" and tuple(meta["builder_kwargs"]["input_shape"]) == tuple(kw["input_shape"])
+    assert meta["builder_kwargs"]["depth"] == kw["depth"] and meta["builder_kwargs"]["n_base_filters"] == kw["n_base_filters"]
+    model = models.unet_model_3d(**kw)
+    W = keras_h5.map_weights(model, keras_h5.read_weights(path))
+    want = {k[2:]: z[k] for k in z.files if k.startswith("w/")}
+    assert set(W) == set(want) and all(np.array_equal(W[k], want[k]) for k in want)
+    m, v, t = keras_h5.read_optimizer(path, model)
+    assert t == int(z["iterations"])
+    for k in keras_h5.trainable_keys(model):
+        assert np.array_equal(m[k], z["m/" + k]) and np.array_equal(v[k], z["v/" + k])
+    reopened = load_old_model(path)
+    got = reopened.get_weights_dict()
+    assert all(np.array_equal(got[k], want[k]) for k in want)
+    assert reopened.get_optimizer_state()[2] == int(z["iterations"])
+
+
+@pytest.mark.skipif(not os.path.exists(CONDA_PY), reason="needs the container's conda interpreter (h5py)")
+def test_keras_style_h5py_reader_reads_our_checkpoints(tmp_path):
+    """the mirror image: files written by keras_h5.save_model, read by h5py through Keras 2.2.4's LOADING call sequence
+    (tests/keras_h5_read_like_keras.py, run under the conda interpreter): layer names, every weight, the optimizer slots by position"""
+    import fetal_net.model as models
+    from fetal_net import keras_h5
+    for builder, kw in (("unet_model_3d", dict(input_shape=(1, 8, 16, 16), depth=2, n_base_filters=4, batch_normalization=True)),
+                        ("isensee2017_model_3d", dict(input_shape=(1, 16, 16, 16), depth=3, n_base_filters=4, n_segmentation_levels=2))):
+        model = getattr(models, builder)(**kw)
+        W = _random_weights(model)
+        model.set_weights_dict(W)
+        keys = keras_h5.trainable_keys(model)
+        shapes = keras_h5.weight_shapes(model)
+        rng = np.random.RandomState(3)
+        m = dict((k, rng.standard_normal(shapes[k]).astype(np.float32)) for k in keys)
+        v = dict((k, rng.random_sample(shapes[k]).astype(np.float32)) for k in keys)
+        model._pending_opt = (m, v, 41)
+        path, out = str(tmp_path / (builder + ".h5")), str(tmp_path / (builder + ".npz"))
+        model.save(path)
+        script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "keras_h5_read_like_keras.py")
+        env = {k: v_ for k, v_ in os.environ.items() if not k.startswith("PYTHON")}
+        subprocess.run([CONDA_PY, "-W", "ignore", script, path, out], check=True, env=env, cwd=str(tmp_path))
+        z = np.load(out)
+        assert str(z["keras_version"]) == "2.2.4" and str(z["backend"]) == "tensorflow" and str(z["optimizer_class"]) == "Adam"
+        assert list(z["layer_names"]) == [l.name for l in model.layers] == list(z["config_layer_names"])
+        assert list(z["layer_classes"]) == [l.class_name for l in model.layers]
+        for k, a in W.items():
+            if k.rsplit("/", 1)[1] in ("moving_mean", "moving_variance") and ("w/%s:0" % k) not in z.files:
+                continue
+            assert np.array_equal(z["w/%s:0" % k], a), k
+        n = len(keys)
+        names = list(z["opt_names"])
+        assert len(names) == 1 + 3 * n and names[0] == "Adam/iterations:0"
+        assert int(z["opt/0000"]) == 41 and z["opt/0000"].dtype == np.int64
+        for i, k in enumerate(keys):
+            assert np.array_equal(z["opt/%04d" % (1 + i)], m[k]) and np.array_equal(z["opt/%04d" % (1 + n + i)], v[k])
+            assert z["opt/%04d" % (1 + 2 * n + i)].shape == (1,)
