@@ -393,3 +393,40 @@ def test_adversarial_loop_runs_and_checkpoints(tmp_path, dis_dtype):
     hist2 = train_adversarial(dict(cfg, n_epochs=1, base_dir=None), gen, dis, batches(), batches(), n_train_steps=2, n_validation_steps=1,
                               semi_generator=batches(), verbose=0)
     assert np.isfinite(hist2[0]["g_loss"]) and "g_seg_real_loss" in hist2[0]
+
+
+def test_discriminator_entry_points_reject_bad_arguments():
+    """error behaviour of the new C-ABI functions: shape / dtype errors come back as codes (raised by the binding), nothing is launched"""
+    from fmri_hip import ops
+    from fmri_hip._lib import FmriError, lib
+    L = lib()
+    x = torch.zeros((1, 1, 1, 4, 8), device="cuda")
+    from fmri_hip._lib import check as chk
+    with pytest.raises(FmriError):
+        chk(L.fmri_avgpool3d_2x_fwd(x.data_ptr(), x.data_ptr(), 1, 1, 1, 4, 8, 0, 0, 0), "fmri_avgpool3d_2x_fwd")       # D = 1 cannot be pooled in 3-D
+    assert L.fmri_avgpool3d_2x_fwd(x.data_ptr(), x.data_ptr(), 1, 2, 2, 2, 8, 7, 0, 0) != 0                # unknown dtype
+    assert L.fmri_global_avgpool_fwd(0, x.data_ptr(), 1, 4, 8, 0, 0) != 0                                  # null source
+    assert L.fmri_dense_fwd(x.data_ptr(), x.data_ptr(), 0, x.data_ptr(), 0, 4, 4, 0, 0.0, 0) != 0          # N = 0
+    assert L.fmri_sigmoid_chain(x.data_ptr(), x.data_ptr(), 1, 2, x.data_ptr(), 4, 1.0, 0, 0, 0) != 0      # row stride < n_labels
+    assert L.fmri_discriminator_input(x.data_ptr(), 2, x.data_ptr(), 3, 0, x.data_ptr(), 8, 0, 4, 1, 0) != 0   # mul-merge of 2 labels x 3 channels
+    assert L.fmri_discriminator_input(x.data_ptr(), 1, x.data_ptr(), 1, 0, x.data_ptr(), 1, 0, 4, 0, 0) != 0   # output narrower than [s, x]
+    assert L.fmri_sigmoid_bce_fwd(x.data_ptr(), x.data_ptr(), x.data_ptr(), 0, 4, 0) != 0                   # no sums buffer
+    assert L.fmri_shot_noise_step(x.data_ptr(), 4, 0, x.data_ptr(), x.data_ptr(), 0, 0, 1, 0) != 0          # phase 1 without a rates buffer
+    assert L.fmri_correlate1d_f32(x.data_ptr(), x.data_ptr(), 1, 4, 8, 2, x.data_ptr(), 1, 1, 0) != 0       # in-place is refused
+    torch.cuda.synchronize()
+    # the layer-graph engine refuses what it cannot run instead of approximating it
+    import fetal_net.model as fmodel
+    from fetal_net.model.graph import Graph
+    from fmri_hip.graph_engine import LayerGraphEngine
+    g = Graph()
+    h = g.input((2, 8, 8, 8))
+    h = g.conv(h, 4, (3, 3, 3), strides=(3, 1, 1), padding="same")
+    h = g.global_avg_pool(h)
+    g.dense(h, 1, activation="sigmoid")
+    with pytest.raises(NotImplementedError):
+        LayerGraphEngine(g.layers, 1, dtype=torch.float32)
+    g = Graph()
+    h = g.global_avg_pool(g.avg_pool(g.input((2, 8, 8, 8)), (4, 4, 4)))
+    g.dense(h, 1, activation="sigmoid")
+    with pytest.raises(NotImplementedError):
+        LayerGraphEngine(g.layers, 1, dtype=torch.float32)
