@@ -5,13 +5,15 @@ import os
 
 
 def main(overwrite=False, config=None):
-    from fetal.config_utils import get_config
     from fetal.utils import create_data_file
     from fetal_net.adversarial import train_adversarial
     from fetal_net.data import open_data_file
     from fetal_net.generator import get_training_and_validation_generators
     from ._common import build_models, config_with_defaults, generator_kwargs
-    config = config_with_defaults(config if config is not None else get_config())
+    if config is None:
+        from fetal.config_utils import get_config
+        config = get_config()
+    config = config_with_defaults(config)
     if overwrite or not os.path.exists(config["data_file"]):
         create_data_file(config)
     data_file_opened = open_data_file(config["data_file"])

@@ -75,9 +75,64 @@ def _soft_labels(n, d_out_shape):
     return np.clip(np.random.uniform(0.9, 1.0, size=[n] + list(d_out_shape)[1:]), a_min=0, a_max=1)
 
 
-def input2discriminator(real_patches, real_segs, fake_segs, d_out_shape, mul_merge=True, fake_patches=None):
+class EngineLayout(object):
+    """a discriminator batch already in the engine's layout ([2N][X][Y][Z][channels padded], device): passes through `_to_device_x`"""
+
+    def __init__(self, tensor):
+        self.tensor = tensor
+        self.shape = tuple(tensor.shape)
+
+    def __getitem__(self, key):                                  # batch slices (Model.evaluate)
+        return EngineLayout(self.tensor[key].contiguous())
+
+
+def _input2discriminator_device(real_patches, real_segs, fake_segs, d_out_shape, mul_merge, fake_patches, dis_model):
+    """device tensors in (fetal_net.device_generator batches, Model.predict of a CUDA tensor): the batch is assembled in HBM by
+    fmri_discriminator_input straight into the discriminator's engine layout.  The host generators are consumed in the reference's order
+    (noise decision, labels); the noise FIELD itself comes from torch's device generator."""
+    import torch
+    from fmri_hip import ops
+    if dis_model is None:
+        raise TypeError("device batches need dis_model=... (the discriminator's engine layout is where they are assembled)")
+    n = int(real_patches.shape[0])
+    eng = dis_model.engine(2 * n)
+    cp, dt_ = eng.shape[eng.input_name][0], eng.dtype
+    sp = tuple(real_patches.shape[2:])
+    nvox = n * int(np.prod(sp))
+
+    def vox_major(t, dtype):                                    # (N, C, X, Y, Z) -> [nvox][C]
+        t = t.to(dtype)
+        return (t.reshape(n, *sp, 1) if t.shape[1] == 1 else t.permute(0, 2, 3, 4, 1)).reshape(nvox, -1).contiguous()
+
+    segs = vox_major(real_segs, torch.float32)
+    if np.random.choice([True, False]):                         # add_noise_to_segs
+        gen = getattr(dis_model, "_noise_gen", None)
+        if gen is None:
+            gen = dis_model._noise_gen = torch.Generator(device=segs.device)
+            gen.manual_seed(0)
+        segs = segs + torch.randn(segs.shape, device=segs.device, generator=gen) * 0.025
+        segs = (segs * (1.0 + torch.randn(segs.shape, device=segs.device, generator=gen) * 0.025)).clamp_(0.0, 1.0)
+    out = torch.empty((2 * n,) + sp + (cp,), dtype=dt_, device=segs.device)
+    xr = vox_major(real_patches, torch.float32)
+    xf = xr if fake_patches is None else vox_major(fake_patches, torch.float32)
+    ops.discriminator_input(segs, xr, out[:n], merge=bool(mul_merge))
+    ops.discriminator_input(vox_major(fake_segs, torch.float32), xf, out[n:], merge=bool(mul_merge))
+    if not mul_merge:
+        # the reference's concatenation form puts the patches first ([x, s], train_adv.py:102-104); the kernel writes [s, x]
+        L = segs.shape[1]
+        C = xr.shape[1]
+        out[..., :L + C] = torch.cat((out[..., L:L + C], out[..., :L]), dim=-1)
+    d_y = _soft_labels(2 * n, d_out_shape)
+    d_y[n:, ...] = 1 - d_y[n:, ...]
+    return EngineLayout(out), d_y
+
+
+def input2discriminator(real_patches, real_segs, fake_segs, d_out_shape, mul_merge=True, fake_patches=None, dis_model=None):
     """(d_x, d_y): the real pairs first, the generated ones after; labels ~U(0.9, 1) for real, 1 - U(0.9, 1) for fake
-    (reference train_adv.py:97-115; train_semi.py:98-114 pairs the generated maps with their own unlabelled patches: `fake_patches`)"""
+    (reference train_adv.py:97-115; train_semi.py:98-114 pairs the generated maps with their own unlabelled patches: `fake_patches`).
+    CUDA tensors (with `dis_model`) are assembled on the device, see _input2discriminator_device."""
+    if _is_device_tensor(real_patches):
+        return _input2discriminator_device(real_patches, real_segs, fake_segs, d_out_shape, mul_merge, fake_patches, dis_model)
     fake_patches = real_patches if fake_patches is None else fake_patches
     if mul_merge:
         real = mul_merge_maps(real_patches, add_noise_to_segs(real_segs))
@@ -146,6 +201,8 @@ class DiscriminatorModel(Model):
     def _to_device_x(self, x):
         """(N, C, X, Y, Z) -> [N][X][Y][Z][Cp]: channels last, zero-extended to the engine's physical channel count"""
         import torch
+        if isinstance(x, EngineLayout):
+            return x.tensor
         t = x if _is_device_tensor(x) else torch.from_numpy(np.ascontiguousarray(np.asarray(x), dtype=np.float32)).cuda(non_blocking=True)
         t = t.permute(0, 2, 3, 4, 1)
         eng = self._engine
@@ -308,11 +365,11 @@ def train_adversarial(config, gen_model, dis_model, train_generator, validation_
                 real_patches, real_segs = next(train_generator)[:2]
                 if mode == "adv":
                     fake = gen_model.predict(real_patches, batch_size=config["batch_size"])
-                    d_x, d_y = input2discriminator(real_patches, real_segs, fake, d_out)
+                    d_x, d_y = input2discriminator(real_patches, real_segs, fake, d_out, dis_model=dis_model)
                 else:
                     semi_patches = next(semi_generator)[0]
                     fake = gen_model.predict(semi_patches, batch_size=config["batch_size"])
-                    d_x, d_y = input2discriminator(real_patches, real_segs, fake, d_out, fake_patches=semi_patches)
+                    d_x, d_y = input2discriminator(real_patches, real_segs, fake, d_out, fake_patches=semi_patches, dis_model=dis_model)
                 outputs += dis_model.train_on_batch(d_x, d_y)
             if scheduler.get_dsteps() > 0:
                 d_tot += outputs / scheduler.get_dsteps()
@@ -331,7 +388,7 @@ def train_adversarial(config, gen_model, dis_model, train_generator, validation_
             val_patches, val_segs = next(validation_generator)[:2]
             if scheduler.get_dsteps() > 0:
                 fake = gen_model.predict(val_patches, batch_size=config["validation_batch_size"])
-                d_x, d_y = input2discriminator(val_patches, val_segs, fake, d_out)
+                d_x, d_y = input2discriminator(val_patches, val_segs, fake, d_out, dis_model=dis_model)
                 dis_metrics += dis_model.evaluate(d_x, d_y, batch_size=config["validation_batch_size"])
             gen_metrics += gen_model.evaluate(val_patches, val_segs, batch_size=config["validation_batch_size"])
         dis_metrics /= float(max(n_validation_steps, 1))

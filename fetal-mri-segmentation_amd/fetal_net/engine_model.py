@@ -387,12 +387,20 @@ class Model(object):
         return p.float().cpu().numpy()
 
     def predict(self, x, batch_size=None, verbose=0):
+        """host array in -> host array out, as Keras; a CUDA tensor in (fetal_net.device_generator batches) -> a CUDA tensor out, in the
+        model's output layout, valid until the next call on this model (it is a view of the engine's probability buffer)"""
         if isinstance(x, (list, tuple)):
             x = x[0]
-        x = np.asarray(x)
+        on_device = _is_device_tensor(x)
+        if not on_device:
+            x = np.asarray(x)
         n = x.shape[0]
         eng = self.engine(n)
         eng.predict(self._to_device_x(x))
+        if on_device:
+            if self._input_layout == "channels_first_3d":
+                return eng.probs.reshape((n,) + tuple(eng.plan.level_dims(0)) + (eng.plan.n_labels,)).permute(0, 4, 1, 2, 3)
+            return eng.probs.reshape((n,) + tuple(eng.plan.spatial) + (eng.plan.n_labels,))
         return self._from_device_probs(eng, n)
 
     def _loss_kind(self):

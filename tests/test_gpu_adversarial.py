@@ -430,3 +430,94 @@ def test_discriminator_entry_points_reject_bad_arguments():
     g.dense(h, 1, activation="sigmoid")
     with pytest.raises(NotImplementedError):
         LayerGraphEngine(g.layers, 1, dtype=torch.float32)
+
+
+def test_experiment_script_main_runs_end_to_end(tmp_path, monkeypatch):
+    """fetal.experiments.train_adv.main / train_semi.main with the reference-side modules they import (fetal.utils, fetal_net.generator)
+    replaced by thin stand-ins: config -> data file (opened by fetal_net.data.open_data_file) -> both models by name from fetal_net.model
+    -> generators -> the adversarial loop -> a generator checkpoint in base_dir."""
+    import sys
+    import types
+    import fetal_net
+    from fetal_net.data import write_plain_data_file
+    from fetal_net.device_generator import device_data_generator
+    from oracle import unet_oracle as O
+    sp = (32, 32, 16)
+    x, y = O.synthetic_batch((3, 1) + sp)
+    data_file = str(tmp_path / "data.h5")
+    write_plain_data_file(data_file, [v[0].astype(np.float64) for v in x], [v[0].astype(np.uint8) for v in y], None, [b"a", b"b", b"c"])
+    calls = {}
+
+    def get_training_and_validation_generators(data_file_opened, **kw):
+        calls.setdefault("kw", []).append(kw)
+        assert len(data_file_opened.root.data) == 3
+        def gen(idx):
+            return device_data_generator(data_file_opened, idx, batch_size=kw["batch_size"], patch_shape=kw["patch_shape"], augment=None,
+                                         skip_blank=False, categorical=False, is3d=True, truth_index=0, truth_size=kw["patch_shape"][2],
+                                         samples_pad=0)
+        return gen([0, 1]), gen([2]), 2, 1
+
+    futils = types.ModuleType("fetal.utils")
+    futils.create_data_file = lambda config: (_ for _ in ()).throw(AssertionError("the data file exists"))
+    futils.get_last_model_path = lambda prefix: prefix
+    monkeypatch.setitem(sys.modules, "fetal.utils", futils)
+    gmod = types.ModuleType("fetal_net.generator")
+    gmod.get_training_and_validation_generators = get_training_and_validation_generators
+    monkeypatch.setitem(sys.modules, "fetal_net.generator", gmod)
+    monkeypatch.setattr(fetal_net, "generator", gmod, raising=False)
+    cfg = {"data_file": data_file, "model_name": "unet_model_3d", "loss": "dice_coefficient_loss", "input_shape": [1] + list(sp),
+           "initial_learning_rate": 1e-3, "dropout_rate": 0.1, "weight_mask": None, "old_model": None, "n_labels": 1, "model_file": str(tmp_path / "m_"),
+           "batch_size": 2, "validation_batch_size": 1, "validation_split": 0.67, "validation_file": "v.pkl", "training_file": "t.pkl", "test_file": "e.pkl",
+           "labels": (1,), "patch_shape": list(sp[:2]), "patch_depth": sp[2], "augment": None, "skip_blank_train": False, "skip_blank_val": False,
+           "truth_index": 0, "truth_size": sp[2], "prev_truth_index": None, "prev_truth_size": None, "truth_downsample": None, "truth_crop": True,
+           "patches_per_epoch": 4, "categorical": False, "3D": True, "drop_easy_patches_train": False, "drop_easy_patches_val": False,
+           "n_epochs": 2, "patience": 5, "learning_rate_drop": 0.5, "base_dir": str(tmp_path), "dis_model_name": "discriminator_image",
+           "overwrite": False}
+    from fetal.experiments import train_adv, train_semi
+    torch.manual_seed(0)
+    np.random.seed(0)
+    hist = train_adv.main(overwrite=False, config=dict(cfg))
+    assert len(hist) == 2 and all(np.isfinite(h["g_loss"]) and np.isfinite(h["d_loss"]) for h in hist)
+    assert any(f.startswith("g_0_") and f.endswith(".h5") for f in os.listdir(str(tmp_path)))
+    assert calls["kw"][0]["patch_shape"] == sp and calls["kw"][0]["is3d"] is True
+    hist2 = train_semi.main(overwrite=False, config=dict(cfg, n_epochs=1))
+    assert len(hist2) == 1 and np.isfinite(hist2[0]["g_seg_real_loss"])
+    assert "val_augment" in calls["kw"][-1] and "augment" not in calls["kw"][-1]
+
+
+@pytest.mark.parametrize("mul_merge", [True, False])
+def test_device_assembled_discriminator_batch_equals_the_host_one(monkeypatch, mul_merge):
+    """input2discriminator on CUDA tensors (assembled by fmri_discriminator_input in the discriminator's engine layout) against the numpy
+    form of the reference on the same data, labels and - with the noise branch off - values; with the branch on, the noised truth stays
+    within the clip and near the labels"""
+    import fetal_net.model as fmodel
+    from fetal_net import adversarial as ADV
+    sp, n = (16, 16, 8), 2
+    dis = fmodel.discriminator_image_3d(input_shape=[2] + list(sp), n_base_filters=4, depth=2, compute_dtype="fp32")
+    rs = np.random.RandomState(2)
+    x = rs.randn(n, 1, *sp).astype(np.float32)
+    segs = (rs.rand(n, 1, *sp) > 0.5).astype(np.uint8)
+    fake = rs.rand(n, 1, *sp).astype(np.float32)
+    monkeypatch.setattr(np.random, "choice", lambda a: False)
+    np.random.seed(4)
+    hx, hy = ADV.input2discriminator(x, segs, fake, (None, 1), mul_merge=mul_merge)
+    np.random.seed(4)
+    dx, dy = ADV.input2discriminator(torch.from_numpy(x).cuda(), torch.from_numpy(segs).cuda(), torch.from_numpy(fake).cuda(), (None, 1),
+                                     mul_merge=mul_merge, dis_model=dis)
+    assert isinstance(dx, ADV.EngineLayout) and dx.shape[:4] == (2 * n,) + sp
+    np.testing.assert_array_equal(hy, dy)
+    got = dx.tensor.float().cpu().numpy()
+    np.testing.assert_allclose(got[..., :2], np.transpose(hx, (0, 2, 3, 4, 1)), rtol=0, atol=1e-6)
+    assert np.all(got[..., 2:] == 0)
+    # the engine-layout batch goes straight into train_on_batch / evaluate
+    out = dis.train_on_batch(dx, dy)
+    assert len(out) == 2 and np.isfinite(out).all()
+    assert np.isfinite(dis.evaluate(dx, dy, batch_size=2)).all()
+    # noise branch: values move a little and stay in [0, 1]
+    monkeypatch.setattr(np.random, "choice", lambda a: True)
+    nx, _ = ADV.input2discriminator(torch.from_numpy(x).cuda(), torch.from_numpy(segs).cuda(), torch.from_numpy(fake).cuda(), (None, 1),
+                                    mul_merge=False, dis_model=dis)
+    noisy = nx.tensor.float().cpu().numpy()[:n, ..., 1]
+    assert noisy.min() >= 0.0 and noisy.max() <= 1.0 and 0 < np.abs(noisy - segs[:, 0]).max() < 0.25
+    with pytest.raises(TypeError):
+        ADV.input2discriminator(torch.from_numpy(x).cuda(), torch.from_numpy(segs).cuda(), torch.from_numpy(fake).cuda(), (None, 1))
