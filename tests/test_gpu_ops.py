@@ -714,8 +714,8 @@ def test_weighted_cross_entropy_loss_value_and_gradient(ops):
     pc = p.clamp(1e-7, 1 - 1e-7)
     loss = -dice + 0.7 * (w64 * -(t * torch.log(pc) + (1 - t) * torch.log(1 - pc))).mean()
     loss.backward()
-    want = MO.dice_and_xent(t.numpy(), p.detach().numpy(), xent_weight=0.7, weight_mask=w64.numpy()) if hasattr(MO, "dice_and_xent") else float(loss)
-    assert abs(got - float(loss)) <= 1e-5 and abs(got - float(want)) <= 1e-5
+    want = MO.dice_and_xent(t.numpy(), p.detach().numpy(), xent_weight=0.7, weight_mask=w64.numpy()) if hasattr(MO, "dice_and_xent") else float(loss.detach())
+    assert abs(got - float(loss.detach())) <= 1e-5 and abs(got - float(want)) <= 1e-5
     assert_close(dl, z.grad, 1e-4, 1e-5, what="weighted dice+xent gradient")
 
 

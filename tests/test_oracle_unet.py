@@ -90,7 +90,7 @@ def test_dice_gradient_closed_form():
     p = torch.tensor(rs.rand(2, 1, 4, 4, 4), requires_grad=True)
     loss = -O.dice_coefficient_t(y, p)
     loss.backward()
-    I, Sy, Sp = float((y * p).sum()), float(y.sum()), float(p.sum())
+    I, Sy, Sp = float((y * p).sum().detach()), float(y.sum()), float(p.sum().detach())
     den = Sy + Sp + 1
     closed = -(2 * y.numpy() * den - (2 * I + 1)) / den ** 2
     np.testing.assert_allclose(p.grad.numpy(), closed, atol=1e-12)
