@@ -12,7 +12,18 @@ def dt(t):
     raise TypeError("unsupported dtype %s" % t.dtype)
 
 
+import os as _os
+
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None) if _os.environ.get("FMRI_RAW_STREAM", "1") != "0" else None
+_cur_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def _s():
+    """the current HIP stream of the current device as a raw handle.  torch.cuda.current_stream() costs 10-40 us of Python per call
+    (device-index resolution, an is_available() probe with an environment lookup, a Stream object); an engine step makes ~100 of these
+    calls and the patch sampler is launch-bound, so the two C entry points torch itself uses on its fast paths are called directly."""
+    if _raw_stream is not None and _cur_device is not None:
+        return _raw_stream(_cur_device())
     return torch.cuda.current_stream().cuda_stream
 
 

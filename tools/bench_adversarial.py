@@ -52,6 +52,11 @@ def main():
     t_g = timed(lambda: gen.train_on_batch(x, y), "plain generator step")
     print("one round (dis_steps = gen_steps = 1, inputs resident): %.2f ms = %.1f patches/s" % (t_d + t_c, N / (t_d + t_c) * 1e3))
     print("adversarial term on top of the plain step: %.2f ms" % (t_c - t_g))
+    import json
+    print(json.dumps({"workload": "adversarial round (train_adv.py: 1 discriminator step on 2N + 1 generator step through the frozen discriminator)",
+                      "patch": list(sp), "batch": N, "discriminator_dtype": a.dis_dtype, "ms_discriminator_step": round(t_d, 3),
+                      "ms_generator_step_through_discriminator": round(t_c, 3), "ms_plain_generator_step": round(t_g, 3),
+                      "ms_per_round": round(t_d + t_c, 3), "patches_per_s": round(N / (t_d + t_c) * 1e3, 1)}))
 
 
 if __name__ == "__main__":

@@ -16,3 +16,4 @@ run python3 tools/bench_isensee.py                     # isensee2017_model_3d de
 run python3 tools/bench_variants.py                    # BatchNorm / InstanceNorm / Deconvolution3D variants of unet_model_3d
 run python3 tools/bench_fit.py                         # through train_model -> fit_generator (host generator, device generator)
 run python3 tools/bench_sampler.py                     # device patch sampler + augmentation
+run python3 tools/bench_adversarial.py                # adversarial round: discriminator step + generator step through the frozen discriminator
