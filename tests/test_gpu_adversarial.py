@@ -521,3 +521,35 @@ def test_device_assembled_discriminator_batch_equals_the_host_one(monkeypatch, m
     assert noisy.min() >= 0.0 and noisy.max() <= 1.0 and 0 < np.abs(noisy - segs[:, 0]).max() < 0.25
     with pytest.raises(TypeError):
         ADV.input2discriminator(torch.from_numpy(x).cuda(), torch.from_numpy(segs).cuda(), torch.from_numpy(fake).cuda(), (None, 1))
+
+
+def test_isensee_generator_through_the_frozen_discriminator_vs_oracle():
+    """the combined step with a layer-graph-engine generator (isensee2017_model_3d: dropout off, deep supervision on): every generator
+    gradient against autograd through the Isensee oracle and the discriminator oracle"""
+    import fetal_net.model as fmodel
+    from fetal_net.adversarial import CombinedModel
+    from oracle import discriminator_oracle as DO, isensee_oracle as I, unet_oracle as O
+    sp, N, ratio = (16, 16, 16), 2, 10.0
+    kw = dict(input_shape=(1,) + sp, depth=3, n_base_filters=4, n_segmentation_levels=2, dropout_rate=0.0)
+    gen = fmodel.isensee2017_model_3d(compute_dtype="fp32", **kw)
+    gspec = I.IsenseeSpec(**kw)
+    Wg = _perturb(gspec.init_weights(23))
+    dis = fmodel.discriminator_image_3d(input_shape=[2] + list(sp), n_base_filters=4, depth=2, dropout_rate=0.0, compute_dtype="fp32")
+    dspec = DO.DiscriminatorSpec((2,) + sp, 4, 2, 0.0)
+    Wd = _perturb(dspec.init_weights(7))
+    gen.set_weights_dict(Wg)
+    dis.set_weights_dict(Wd)
+    x, y = O.synthetic_batch((N, 1) + sp)
+    valid = np.array([[0.93], [0.99]])
+    ref = DO.combined_loss_and_grads(lambda Wt, xt: I.forward(gspec, Wt, xt, None)[1], Wg, dspec, Wd, x, y, valid, ratio)
+    comb = CombinedModel(gen, dis, gd_loss_ratio=ratio, lr=0.0)
+    got = dict(zip(comb.metrics_names, comb.train_on_batch(x, [valid, y])))
+    bar("combined_isensee.total_rel", abs(got["loss"] - ref["total"]) / abs(ref["total"]), 5e-8)
+    eg = gen._engine
+    G = eg.flat_to_keras(eg.G.detach().cpu().numpy())
+    worst = 0.0
+    for k, g in ref["grads"].items():
+        if k.endswith("/bias") and not k.startswith(tuple(h["name"] for h in gspec.heads.values())):
+            continue          # conv bias in front of an instance normalisation: exactly zero gradient
+        worst = max(worst, np.linalg.norm(G[k] - g) / (np.linalg.norm(g) + 1e-30))
+    bar("combined_isensee.grad_l2_rel", worst, 1e-5)
