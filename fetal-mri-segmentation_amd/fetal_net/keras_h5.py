@@ -333,7 +333,7 @@ def read_configs(path):
 
 def infer_builder(mc, tc=None):
     """(builder name, kwargs) from a Keras `model_config` (+ `training_config` for lr and loss name) of a model one of this package's
-    builders can produce: unet_model_3d, unet_model_2d, isensee2017_model_3d."""
+    builders can produce: unet_model_3d, unet_model_2d, isensee2017_model_3d, isensee2017_model, discriminator_image_3d."""
     layers = mc["config"]["layers"]
     cls = [l["class_name"] for l in layers]
     inputs = [l for l in layers if l["class_name"] == "InputLayer"]
@@ -349,6 +349,16 @@ def infer_builder(mc, tc=None):
     if tc is not None:
         kw["initial_learning_rate"] = float(tc["optimizer_config"]["config"]["lr"])
         kw["loss_function"] = {"__callable__": tc["loss"]} if isinstance(tc["loss"], str) else None
+    if "GlobalAveragePooling3D" in cls and "Dense" in cls:
+        # PatchGAN discriminator (reference model/discriminator/all_dis_3d.py): one SpatialDropout3D per conv block built, every level
+        # the early stop skipped became a Dense(128) in front of the Dense(1) output
+        drops = [l for l in layers if l["class_name"] == "SpatialDropout3D"]
+        dense = [l for l in layers if l["class_name"] == "Dense"]
+        kw.pop("activation_name", None)
+        kw.pop("loss_function", None)
+        kw.update(n_base_filters=int(convs[0]["config"]["filters"]), depth=len(drops) + len(dense) - 1,
+                  dropout_rate=float(drops[0]["config"]["rate"]) if drops else 0.0)
+        return "discriminator_image_3d", kw
     if "Add" in cls or "LeakyReLU" in cls:
         drops = [l for l in layers if l["class_name"].startswith("SpatialDropout")]
         heads = [l for l in convs if all(int(k) == 1 for k in l["config"]["kernel_size"]) and

@@ -194,3 +194,19 @@ def test_experiment_scripts_call_the_reference_generators_with_accepted_keywords
     assert d["dis_model_name"] == "discriminator_image_3d" and d["gd_loss_ratio"] == 10 and d["dis_steps"] == d["gen_steps"] == 1
     import fetal_net.model as fmodel
     assert callable(getattr(fmodel, d["dis_model_name"]))
+
+
+@pytest.mark.parametrize("case,kw", CASES)
+def test_discriminator_builder_call_is_recovered_from_a_keras_model_config(case, kw):
+    """keras_h5.infer_builder on the model_config / training_config of a discriminator: the same builder call comes back (what
+    load_old_model uses for a checkpoint without this package's own record)"""
+    from fetal_net import keras_h5
+    model = fmodel.discriminator_image_3d(**kw)
+    mc = json.loads(json.dumps(keras_h5.model_config(model)))
+    tc = json.loads(json.dumps(keras_h5.training_config(model)))
+    name, got = keras_h5.infer_builder(mc, tc)
+    assert name == "discriminator_image_3d"
+    again = fmodel.discriminator_image_3d(**{k: v for k, v in got.items() if k in ("input_shape", "n_base_filters", "depth", "dropout_rate",
+                                                                                  "initial_learning_rate")})
+    assert [(l.name, l.class_name, l.output_shape) for l in again.layers] == [(l.name, l.class_name, l.output_shape) for l in model.layers]
+    assert abs(again.optimizer.lr - model.optimizer.lr) <= 1e-7 * model.optimizer.lr and tc["optimizer_config"]["config"]["beta_1"] == 0.5      # lr is stored as float32, like Keras
