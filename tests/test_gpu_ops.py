@@ -794,3 +794,58 @@ def test_engine_tail_fusion_equals_separate_kernels(monkeypatch):
     assert_close(la, lb, 2e-6, 2e-6, what="fused logits")
     assert abs(sa[0] - sb[0]) <= 1e-6 * abs(sb[0]) and sa[7] == sb[7]
     assert float((ga - gb).abs().max()) <= 1e-4 * float(gb.abs().max())
+
+
+# ------------------------------------------------------------------------------------------------ seeded fuzz of the dispatch
+def _fuzz_cases(n=14, seed=2024):
+    rs = np.random.RandomState(seed)
+    out = []
+    while len(out) < n:
+        N, D, H, W = int(rs.choice([1, 2, 3, 5])), int(rs.choice([4, 8, 12, 20])), int(rs.choice([8, 16, 24, 40])), int(rs.choice([16, 32, 48]))
+        if N * D * H * W > 70000:
+            continue
+        C0, C1, Cout = int(rs.choice([32, 64, 96])), int(rs.choice([0, 0, 32, 64])), int(rs.choice([32, 64, 128]))
+        up0 = bool(rs.rand() < 0.3)
+        out.append((N, D, H, W, C0, up0, C1, Cout))
+    return out
+
+
+@pytest.mark.parametrize("case", _fuzz_cases(), ids=lambda c: "N%d_%dx%dx%d_c%d%s+%d_o%d" % (c[0], c[1], c[2], c[3], c[4], "up" if c[5] else "", c[6], c[7]))
+def test_conv_dispatch_fuzz_is_exact_on_dyadic_data(ops, case):
+    """random grids (odd tile counts, batch 3 and 5, grids that do and do not allow the compact XCD numbering) through the AUTO dispatch:
+    forward, input gradient and weight gradient on small dyadic values, where every product and every partial sum is exact in fp32 - the
+    bf16 result must equal the rounded CPU result bit for bit, the fp32 weight gradient exactly"""
+    N, D, H, W, C0, up0, C1, Cout = case
+    bf = torch.bfloat16
+    g = torch.Generator().manual_seed(N * 1000 + D + H + W + C0 + Cout)
+    dy4 = lambda shape, lo=-4, hi=5, div=4.0: (torch.randint(lo, hi, shape, generator=g).float() / div)
+    s0 = (N, D // 2, H // 2, W // 2, C0) if up0 else (N, D, H, W, C0)
+    x0 = dy4(s0)
+    x1 = dy4((N, D, H, W, C1)) if C1 else None
+    w = dy4((27, Cout, C0 + C1), -2, 3, 8.0)
+    bias = dy4((Cout,))
+    xin = ref_concat_input(x0, x1, up0).float()                         # NCDHW fp32 on the CPU
+    wk = keras_kernel_from_packed(w).float().requires_grad_(True)
+    xin.requires_grad_(True)
+    yref = F.conv3d(xin, wk, bias, padding=1)
+    y = torch.empty((N, D, H, W, Cout), dtype=bf, device="cuda")
+    ops.conv3d_fwd(x0.to(bf).cuda(), None if x1 is None else x1.to(bf).cuda(), w.to(bf).cuda(), bias.cuda(), y, up0=up0, act=1)
+    want = to_ndhwc(F.relu(yref).detach()).to(bf)
+    assert torch.equal(y.cpu().view(torch.int16), want.view(torch.int16)), "forward"
+    # weight gradient (fp32 sums of exact products: order-independent) and bias gradient
+    dy = dy4((N, D, H, W, Cout), -2, 3, 2.0)
+    yref.backward(to_ncdhw(dy).float())
+    dw = torch.zeros((27, Cout, C0 + C1), dtype=torch.float32, device="cuda")
+    db = torch.zeros((Cout,), dtype=torch.float32, device="cuda")
+    ops.conv3d_wgrad(x0.to(bf).cuda(), None if x1 is None else x1.to(bf).cuda(), dy.to(bf).cuda(), dw, db, up0=up0)
+    ref_dw = wk.grad.permute(2, 3, 4, 0, 1).reshape(27, Cout, C0 + C1)
+    assert torch.equal(dw.cpu(), ref_dw), "weight gradient: max diff %g" % float((dw.cpu() - ref_dw).abs().max())
+    assert torch.equal(db.cpu(), dy.sum(dim=(0, 1, 2, 3)))
+    # input gradient of the plain single-source form (tap-flipped transposed filters)
+    if not up0 and C1 == 0:
+        wd = torch.empty((27, C0, Cout), dtype=bf, device="cuda")
+        wf = torch.empty((27, Cout, C0), dtype=bf, device="cuda")
+        ops.pack_weights(w.cuda(), wf, wd)
+        dx = torch.empty((N, D, H, W, C0), dtype=bf, device="cuda")
+        ops.conv3d_dgrad(dy.to(bf).cuda(), wd, dx)
+        assert torch.equal(dx.cpu().view(torch.int16), to_ndhwc(xin.grad).to(bf).view(torch.int16)), "input gradient"
