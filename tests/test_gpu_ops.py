@@ -849,3 +849,65 @@ def test_conv_dispatch_fuzz_is_exact_on_dyadic_data(ops, case):
         dx = torch.empty((N, D, H, W, C0), dtype=bf, device="cuda")
         ops.conv3d_dgrad(dy.to(bf).cuda(), wd, dx)
         assert torch.equal(dx.cpu().view(torch.int16), to_ndhwc(xin.grad).to(bf).view(torch.int16)), "input gradient"
+
+
+def _upcat_fuzz_cases(n=8, seed=77):
+    rs = np.random.RandomState(seed)
+    out = []
+    while len(out) < n:
+        N, D, H, W = int(rs.choice([1, 2, 3])), int(rs.choice([8, 16, 24])), int(rs.choice([16, 32, 48])), int(rs.choice([32, 64]))
+        if N * D * H * W > 80000:
+            continue
+        out.append((N, D, H, W, int(rs.choice([64, 128])), int(rs.choice([0, 32, 64])), int(rs.choice([64, 128]))))
+    return out
+
+
+@pytest.mark.parametrize("case", _upcat_fuzz_cases(), ids=lambda c: "N%d_%dx%dx%d_up%d+%d_o%d" % c)
+def test_parity_form_fuzz_is_exact_on_dyadic_data(ops, case):
+    """the parity form of UpSampling3D -> concatenate -> Conv3D on random grids with small dyadic values: the pre-summed filters are exact
+    in bf16, every product and partial sum exact in fp32, so both input gradients and the weight gradient must equal the plain definition
+    bit for bit, and the forward result the plain definition with the one documented intermediate rounding (the up-sampled channels'
+    partial sum passes through bf16 between the two launches when there is a skip source)"""
+    N, D, H, W, C0, C1, Cout = case
+    bf = torch.bfloat16
+    if not (ops.conv3d_upcat_ok(C0, C1, Cout, D, H, W, bf) & 1):
+        pytest.skip("shape outside the parity-form kernels")
+    g = torch.Generator().manual_seed(sum(case))
+    dy4 = lambda shape, lo, hi, div: (torch.randint(lo, hi, shape, generator=g).float() / div)
+    x_low = dy4((N, D // 2, H // 2, W // 2, C0), -4, 5, 4.0)
+    x_skip = dy4((N, D, H, W, C1), -4, 5, 4.0) if C1 else None
+    w = dy4((27, Cout, C0 + C1), -2, 3, 8.0)
+    bias = dy4((Cout,), -4, 5, 4.0)
+    up_f = torch.empty((8, 8, Cout, C0), device="cuda", dtype=bf)
+    up_d = torch.empty((8, 8, C0, Cout), device="cuda", dtype=bf)
+    sk_f = torch.empty((27, Cout, C1), device="cuda", dtype=bf) if C1 else None
+    sk_d = torch.empty((27, C1, Cout), device="cuda", dtype=bf) if C1 else None
+    ops.conv3d_pack_up_weights(w.cuda(), C0, C1, up_f, up_d, sk_f, sk_d)
+    xl = x_low.clone().requires_grad_(True)
+    xs = x_skip.clone().requires_grad_(True) if C1 else None
+    wk = keras_kernel_from_packed(w).float().requires_grad_(True)
+    pre = F.conv3d(ref_concat_input(xl, xs, True), wk, bias, padding=1)
+    y = torch.empty((N, D, H, W, Cout), dtype=bf, device="cuda")
+    ops.conv3d_upcat_fwd(x_low.to(bf).cuda(), None if not C1 else x_skip.to(bf).cuda(), up_f, sk_f, bias.cuda(), y, act=1)
+    if C1:
+        # two launches: the up-sampled channels' partial sum is stored as bf16, the skip launch adds its own sum + bias in fp32 on top
+        part = F.conv3d(ref_concat_input(x_low, None, True), wk.detach()[:, :C0].contiguous(), None, padding=1).to(bf).float()
+        want = F.relu(part + F.conv3d(to_ncdhw(x_skip), wk.detach()[:, C0:].contiguous(), bias, padding=1))
+    else:
+        want = F.relu(pre).detach()
+    assert torch.equal(y.cpu().view(torch.int16), to_ndhwc(want).to(bf).view(torch.int16)), "forward"
+    dy = dy4((N, D, H, W, Cout), -2, 3, 2.0)
+    pre.backward(to_ncdhw(dy))
+    dx_low = torch.empty((N, D // 2, H // 2, W // 2, C0), dtype=bf, device="cuda")
+    dx_skip = torch.empty((N, D, H, W, C1), dtype=bf, device="cuda") if C1 else None
+    ops.conv3d_upcat_dgrad(dy.to(bf).cuda(), up_d, sk_d, None, None, dx_low, dx_skip)
+    assert torch.equal(dx_low.cpu().view(torch.int16), xl.grad.to(bf).view(torch.int16)), "gradient of the low-resolution source"
+    if C1:
+        assert torch.equal(dx_skip.cpu().view(torch.int16), xs.grad.to(bf).view(torch.int16)), "gradient of the skip source"
+    if ops.conv3d_upcat_ok(C0, C1, Cout, D, H, W, bf) & 2:
+        dw = torch.zeros((27, Cout, C0 + C1), device="cuda")
+        db = torch.zeros(Cout, device="cuda")
+        ops.conv3d_upcat_wgrad(x_low.to(bf).cuda(), None if not C1 else x_skip.to(bf).cuda(), dy.to(bf).cuda(), dw, db, torch.empty(64 * Cout * C0, device="cuda"))
+        ref_dw = wk.grad.permute(2, 3, 4, 0, 1).reshape(27, Cout, C0 + C1)
+        assert torch.equal(dw.cpu(), ref_dw), "weight gradient: max diff %g" % float((dw.cpu() - ref_dw).abs().max())
+        assert torch.equal(db.cpu(), dy.sum(dim=(0, 1, 2, 3)))
