@@ -911,3 +911,51 @@ def test_parity_form_fuzz_is_exact_on_dyadic_data(ops, case):
         ref_dw = wk.grad.permute(2, 3, 4, 0, 1).reshape(27, Cout, C0 + C1)
         assert torch.equal(dw.cpu(), ref_dw), "weight gradient: max diff %g" % float((dw.cpu() - ref_dw).abs().max())
         assert torch.equal(db.cpu(), dy.sum(dim=(0, 1, 2, 3)))
+
+
+def _planar_fuzz_cases(n=8, seed=5):
+    rs = np.random.RandomState(seed)
+    out = []
+    while len(out) < n:
+        S, H, W = int(rs.choice([1, 3, 8, 13])), int(rs.choice([16, 32, 48, 64])), int(rs.choice([16, 32, 64]))
+        if S * H * W > 30000:
+            continue
+        out.append((S, H, W, int(rs.choice([32, 64, 96])), int(rs.choice([0, 0, 32])), int(rs.choice([32, 64, 128])), bool(rs.rand() < 0.3)))
+    return out
+
+
+@pytest.mark.parametrize("case", _planar_fuzz_cases(), ids=lambda c: "S%d_%dx%d_c%d+%d_o%d%s" % (c[0], c[1], c[2], c[3], c[4], c[5], "_up" if c[6] else ""))
+def test_planar_conv_dispatch_fuzz_is_exact_on_dyadic_data(ops, case):
+    """2-D slices ride the kernels' D axis (planar = 1: no coupling between slices, 9 live taps): forward, weight gradient and input
+    gradient of random slice stacks, bit for bit against the 2-D definition"""
+    S, H, W, C0, C1, Cout, up0 = case
+    bf = torch.bfloat16
+    g = torch.Generator().manual_seed(sum(int(v) for v in case))
+    dy4 = lambda shape, lo, hi, div: (torch.randint(lo, hi, shape, generator=g).float() / div)
+    s0 = (1, S, H // 2, W // 2, C0) if up0 else (1, S, H, W, C0)
+    x0 = dy4(s0, -4, 5, 4.0)
+    x1 = dy4((1, S, H, W, C1), -4, 5, 4.0) if C1 else None
+    w = dy4((27, Cout, C0 + C1), -2, 3, 8.0)
+    bias = dy4((Cout,), -4, 5, 4.0)
+    xin = ref_concat_input(x0, x1, up0, planar=True).float().requires_grad_(True)
+    wk = keras_kernel_from_packed(w).float().requires_grad_(True)
+    yref = F.conv3d(xin, planar_kernel(wk), bias, padding=1)
+    y = torch.empty((1, S, H, W, Cout), dtype=bf, device="cuda")
+    ops.conv3d_fwd(x0.to(bf).cuda(), None if x1 is None else x1.to(bf).cuda(), w.to(bf).cuda(), bias.cuda(), y, up0=up0, act=1, planar=True)
+    assert torch.equal(y.cpu().view(torch.int16), to_ndhwc(F.relu(yref).detach()).to(bf).view(torch.int16)), "forward"
+    dy = dy4((1, S, H, W, Cout), -2, 3, 2.0)
+    yref.backward(to_ncdhw(dy))
+    dw = torch.zeros((27, Cout, C0 + C1), dtype=torch.float32, device="cuda")
+    db = torch.zeros((Cout,), dtype=torch.float32, device="cuda")
+    ops.conv3d_wgrad(x0.to(bf).cuda(), None if x1 is None else x1.to(bf).cuda(), dy.to(bf).cuda(), dw, db, up0=up0, planar=True)
+    ref_dw = wk.grad.permute(2, 3, 4, 0, 1).reshape(27, Cout, C0 + C1)
+    assert torch.equal(dw.cpu()[9:18], ref_dw[9:18]), "weight gradient (centre kd plane)"
+    assert float(dw.cpu()[:9].abs().max()) == 0.0 and float(dw.cpu()[18:].abs().max()) == 0.0      # the other planes do not exist in 2-D
+    assert torch.equal(db.cpu(), dy.sum(dim=(0, 1, 2, 3)))
+    if not up0 and C1 == 0:
+        wd = torch.empty((27, C0, Cout), dtype=bf, device="cuda")
+        wf = torch.empty((27, Cout, C0), dtype=bf, device="cuda")
+        ops.pack_weights(w.cuda(), wf, wd)
+        dx = torch.empty((1, S, H, W, C0), dtype=bf, device="cuda")
+        ops.conv3d_dgrad(dy.to(bf).cuda(), wd, dx, planar=True)
+        assert torch.equal(dx.cpu().view(torch.int16), to_ndhwc(xin.grad).to(bf).view(torch.int16)), "input gradient"
