@@ -1,5 +1,6 @@
 // HBM-bound kernels of the U-Net step: pooling, up-sampling, final 1x1x1 conv, sigmoid+Dice, Adam, weight packing,
 // sliding-window tile gather / overlap-add, casts.  All channels-last, vectorised where the channel count allows.
+#include <cstdlib>
 #include "common.h"
 
 // ------------------------------------------------------------------------------------------------ version / errors
@@ -448,7 +449,10 @@ extern "C" int fmri_conv1x1_bwd(const void* x, const float* w, const float* dlog
     hipStream_t s = as_stream(stream);
     size_t sh = (size_t)L * (2 * C + 1) * 4;
     if (int lpv = lpv_of(C, L)) {
-        int g2 = grid_for(nvox * lpv, 256, 256 * 16);
+        // two workgroups per CU (256 CUs): every workgroup ends with L x (C + 1) LDS + global atomics and starts with an LDS clear, and the
+        // streaming part wants few, long-running workgroups - measured on the benchmark's 4 x 64 x 128 x 128 x 64 tensor (ms per launch):
+        // 256 workgroups 0.39, 512 0.22, 768 0.29, 1024 0.23, 2048 0.26, 4096 (the former cap) 0.31, 8192 0.35
+        int g2 = grid_for(nvox * lpv, 256, 512);
         size_t sh2 = (size_t)L * (C + 1) * 4;
         if (dtype == FMRI_F32) { LAUNCH_LPV(k_conv1x1_bwd_v2, float, lpv, g2, sh2, s, (const float*)x, w, dlogits, (float*)dx, dw, db, nvox, C, L, relu_mask) }
         else if (dtype == FMRI_BF16) { LAUNCH_LPV(k_conv1x1_bwd_v2, bf16_t, lpv, g2, sh2, s, (const bf16_t*)x, w, dlogits, (bf16_t*)dx, dw, db, nvox, C, L, relu_mask) }
