@@ -285,7 +285,7 @@ int conv3d_first_fwd(const void* x, int C0, int planar, const void* w, const flo
 int conv3d_first_wgrad(const void* x, int C0, int planar, const void* dy, float* dw, float* db, int N, int D, int H, int W, int Cout,
                        hipStream_t st) {
     const int ntiles = N * (D / fg::TD) * (H / fg::TH) * (W / fg::TW);
-    int gx = 512 / (Cout / 32);
+    int gx = 1024 / (Cout / 32);      // workgroups in total (measured per launch: 256 -> 0.174 ms, 512 -> 0.124, 1024 -> 0.115, 2048 -> 0.151, 4096 -> 0.217)
     if (gx > ntiles) gx = ntiles;
     if (gx < 1) gx = 1;
 #define L_(CIN_, PL_) \
