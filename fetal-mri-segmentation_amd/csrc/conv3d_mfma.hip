@@ -2046,18 +2046,22 @@ int conv3d_wgrad_mfma_ld(const void* src0, int C0, int up0, int planar, const vo
     // kd-sharing kernels (a workgroup owns a (Cout, Cin) block for all 27 taps and walks columns; see k_conv_wgrad_kd).  Measured per layer
     // (profiles/r02_wgrad_kd_sharing_ab.log): the 4-wave form wins where the per-kd kernel has to fall back to 32-wide Cin blocks (enc0b
     // 32 -> 64 at full resolution: -17 %), is level with it on the 64- and 128-channel layers (0 ... -5 %) and loses on the fused-upsample
-    // launches.  FMRI_WGRAD_KD: 0 = off, 1 (default) = the layers with a 32-wide Cin block and >= 0.1 TFLOP, 2 = wherever the shape allows;
+    // launches.  Inside the training step (after the issue-cursor rewrite of both kernels; same-box A/B of whole steps and of the per-layer
+    // exclusive times, late round 2) the 4-wave form is level or ahead on EVERY launch that does not take the slab flush: dec0b 0.735 ->
+    // 0.667 ms, the skip halves of dec0a / dec1a 1.33 -> 1.19 / 0.695 -> 0.657, dec1b 0.39 -> 0.367, nothing slower; weight-gradient
+    // family 4.64 -> 4.34 ms per step, step 13.96 -> 13.73 ms.  FMRI_WGRAD_KD: 0 = off, 1 = only the layers with a 32-wide Cin block and
+    // >= 0.1 TFLOP (the default until then), 2 (default) = every launch without fused up-sampling, 3 = those too;
     // FMRI_WGRAD_KD_BLK = 32 (4-wave workgroups, two per CU) | 64 (8-wave workgroup, one per CU: slower, kept for the record).
     static int kd_mode = -1, kd_blk = 32;
     if (kd_mode < 0) {
         const char* e = getenv("FMRI_WGRAD_KD");
-        kd_mode = e ? atoi(e) : 1;
+        kd_mode = e ? atoi(e) : 2;
         const char* f = getenv("FMRI_WGRAD_KD_BLK");
         kd_blk = (f && atoi(f) == 64) ? 64 : 32;
     }
     const bool narrow = (C0 % 64) || (C1 % 64);
-    if (kd_mode && !planar && !use_ws && (!up0 || kd_mode == 2) && (C0 % kd_blk == 0) && (C1 % kd_blk == 0) && (Cout % kd_blk == 0) &&
-        (kd_mode == 2 || (narrow && kd_blk == 32 && flops_ >= 0.1e12))) {
+    if (kd_mode && !planar && !use_ws && (!up0 || kd_mode == 3) && (C0 % kd_blk == 0) && (C1 % kd_blk == 0) && (Cout % kd_blk == 0) &&
+        (kd_mode >= 2 || (narrow && kd_blk == 32 && flops_ >= 0.1e12))) {
         const int combos_kd = (Cout / kd_blk) * (Cin / kd_blk);
         const int nunits = N * D * (H / wg::TH) * (W / wg::TW);
         static int kd_wgs = -1;

@@ -409,7 +409,8 @@ print("DONE")
 
 def test_kd_sharing_weight_gradient_kernels_are_exact(tmp_path):
     """the kd-sharing weight-gradient kernels (one workgroup per (Cout, Cin) block walks columns of d-planes for all 27 taps through a 4-slot
-    x-plane ring; FMRI_WGRAD_KD=2 forces them wherever the shape allows: the 4-wave / 32-block form that is the default for narrow layers, and
+    x-plane ring; FMRI_WGRAD_KD=3 forces them wherever the shape allows: the 4-wave / 32-block form that is the default on every launch without
+    fused up-sampling, and
     the 8-wave / 64-block form) against the per-kd kernel (FMRI_WGRAD_KD=0) on dyadic data whose sums are exact in fp32 in any order: all three
     must agree BIT FOR BIT - runs that cross column boundaries, a dual source, a fused up-sampled source"""
     import subprocess
@@ -417,7 +418,7 @@ def test_kd_sharing_weight_gradient_kernels_are_exact(tmp_path):
     f = tmp_path / "kd.py"
     f.write_text(KD_SCRIPT % ROOT)
     res = []
-    for tag, env in (("kd32", dict(FMRI_WGRAD_KD="2")), ("kd64", dict(FMRI_WGRAD_KD="2", FMRI_WGRAD_KD_BLK="64")), ("perkd", dict(FMRI_WGRAD_KD="0"))):
+    for tag, env in (("kd32", dict(FMRI_WGRAD_KD="3")), ("kd64", dict(FMRI_WGRAD_KD="3", FMRI_WGRAD_KD_BLK="64")), ("perkd", dict(FMRI_WGRAD_KD="0"))):
         o = str(tmp_path / (tag + ".npz"))
         r = subprocess.run([sys.executable, str(f), o], capture_output=True, text=True, timeout=900, env=dict(os.environ, **env))
         assert r.returncode == 0 and "DONE" in r.stdout, (tag, r.stdout[-1000:], r.stderr[-3000:])
