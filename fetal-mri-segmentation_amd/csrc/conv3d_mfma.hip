@@ -2014,6 +2014,7 @@ static void wgrad_plan(int C0, int C1, int Cout, int N, int D, int H, int W, int
     }
     const double flops = 2.0 * (planar ? 9 : 27) * (double)Cin * Cout * (double)N * D * H * W;
     int target_wgs = flops >= 0.9e12 ? 2048 : (flops >= 0.06e12 ? 768 : 512);
+    if (planar) target_wgs = 512;       // 2-D slices (one kd plane per combo): two workgroups per CU throughout (configs[3] step: 13.7 -> 13.5 ms)
     if (with_ws && forced_slab >= 64) target_wgs = forced_slab;
     if (!with_ws && forced_wgs >= 64) target_wgs = forced_wgs;
     nslab = (target_wgs + combos - 1) / combos;
