@@ -2051,7 +2051,9 @@ int conv3d_wgrad_mfma_ld(const void* src0, int C0, int up0, int planar, const vo
     // exclusive times, late round 2) the 4-wave form is level or ahead on EVERY launch that does not take the slab flush: dec0b 0.735 ->
     // 0.667 ms, the skip halves of dec0a / dec1a 1.33 -> 1.19 / 0.695 -> 0.657, dec1b 0.39 -> 0.367, nothing slower; weight-gradient
     // family 4.64 -> 4.34 ms per step, step 13.96 -> 13.73 ms.  FMRI_WGRAD_KD: 0 = off, 1 = only the layers with a 32-wide Cin block and
-    // >= 0.1 TFLOP (the default until then), 2 (default) = every launch without fused up-sampling, 3 = those too;
+    // >= 0.1 TFLOP (the default until then), 2 (default) = also every launch of >= 0.3 TFLOP without fused up-sampling (below that the
+    // per-kd kernel is ahead, with the slab flush or - callers without a workspace, e.g. the layer-graph engine - with the atomic one:
+    // Isensee defaults 11.3 vs 11.65 ms per step), 3 = the fused-upsample launches too;
     // FMRI_WGRAD_KD_BLK = 32 (4-wave workgroups, two per CU) | 64 (8-wave workgroup, one per CU: slower, kept for the record).
     static int kd_mode = -1, kd_blk = 32;
     if (kd_mode < 0) {
@@ -2062,7 +2064,7 @@ int conv3d_wgrad_mfma_ld(const void* src0, int C0, int up0, int planar, const vo
     }
     const bool narrow = (C0 % 64) || (C1 % 64);
     if (kd_mode && !planar && !use_ws && (!up0 || kd_mode == 3) && (C0 % kd_blk == 0) && (C1 % kd_blk == 0) && (Cout % kd_blk == 0) &&
-        (kd_mode >= 2 || (narrow && kd_blk == 32 && flops_ >= 0.1e12))) {
+        ((kd_mode >= 2 && flops_ >= 0.3e12) || (narrow && kd_blk == 32 && flops_ >= 0.1e12))) {
         const int combos_kd = (Cout / kd_blk) * (Cin / kd_blk);
         const int nunits = N * D * (H / wg::TH) * (W / wg::TW);
         static int kd_wgs = -1;
