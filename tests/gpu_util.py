@@ -101,8 +101,9 @@ def bar(name, value, limit):
     import os
     value = float(value)
     if os.environ.get("FMRI_MEASURE", "0") == "1":
-        e = _BARS.setdefault(name, {"measured": 0.0, "limit": limit})
+        e = _BARS.setdefault(name, {"measured": value, "limit": limit, "n": 0})
         e["measured"] = max(e["measured"], value)
+        e["n"] += 1
         out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
         os.makedirs(out, exist_ok=True)
         with open(os.path.join(out, "bars_measured.json"), "w") as f:

@@ -147,7 +147,9 @@ def test_training_loss_decreases_bf16():
     for _ in range(12):
         s = eng.train_step(xd, yd, 1e-3)
         losses.append(eng.metrics_from_sums(s.cpu().numpy())["loss"])
-    assert losses[-1] < losses[0] - 0.02, losses
+    assert all(np.isfinite(losses)), losses
+    # 12 Adam steps on ONE batch: measured drop 0.05-0.07 on MI355X over repeated runs (atomic-order weight gradients move it in the 4th digit)
+    bar("train_bf16.loss_rise_over_12_steps", losses[-1] - losses[0], -0.02)
 
 
 def test_unet2d_fp32_and_bf16_vs_oracle():
