@@ -230,7 +230,7 @@ def per_layer_table(eng, detail_ms, steps):
                     "MFMA ceiling (23.9 %%, SURVEY 0/8d)" % steps}
 
 
-def launch_ranks(n, argv):
+def launch_ranks(n, argv, port_tries=3):
     """Parent of a bare `bench.py --gpus N`: N children, one per GPU, each a rank of a 127.0.0.1 rendezvous.  The parent never touches
     the GPU (a process that has initialised HIP must not fork/exec workers on this pool).  Returns the exit code."""
     import socket
@@ -238,6 +238,15 @@ def launch_ranks(n, argv):
     with socket.socket() as so:
         so.bind(("127.0.0.1", 0))
         port = so.getsockname()[1]
+    if port_tries > 1:
+        # the port is free now, not necessarily when rank 0 binds it (another job on the box may take it in between): a run that dies
+        # on the rendezvous before printing anything is started again on a fresh port
+        rc = 1
+        for _ in range(port_tries):
+            rc = launch_ranks(n, argv, port_tries=1)
+            if rc != 98:
+                return rc
+        return rc
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -285,7 +294,12 @@ def selftest_cpu(a, rank, world):
     gloo group and all-reduce a small gradient-like buffer per "step"; nothing is measured and the line says so."""
     import torch.distributed as dist
     if world > 1:
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        try:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        except Exception as e:
+            if rank == 0 and ("in use" in str(e).lower() or "EADDRINUSE" in str(e)):
+                sys.exit(98)
+            raise
         assert dist.get_world_size() == a.gpus
     g = torch.full((1 << 16,), float(rank + 1))
     t0 = time.perf_counter()
@@ -319,6 +333,8 @@ def main():
     ap.add_argument("--steps", type=int, default=50)      # 50 steps = 0.8 s: the first ten run ~2 % slower than the steady state
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=4, help="patches per GPU")
+    ap.add_argument("--prewarm-seconds", type=float, default=2.0,
+                    help="untimed steps for at least this long before the --warmup steps (clock settling; not part of the timed region)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-launch-timing", action="store_true")
     ap.add_argument("--no-exclusive-pass", action="store_true",
@@ -335,9 +351,8 @@ def main():
 
     if a.gpus > 1 and "RANK" not in os.environ:
         # bare multi-GPU invocation: become the parent of N ranks BEFORE anything initialises the GPU
-        if not a.selftest_cpu and torch.cuda.device_count() < a.gpus:          # device_count() alone does not initialise HIP
-            sys.stderr.write("bench.py: --gpus %d but only %d device(s) visible\n" % (a.gpus, torch.cuda.device_count()))
-            sys.exit(2)
+        # (no device-count probe here: on a ROCm build without amdsmi it is hipGetDeviceCount, which opens /dev/kfd in the parent; every
+        # rank checks its own LOCAL_RANK against the visible devices and exits 2, which launch_ranks relays)
         sys.exit(launch_ranks(a.gpus, sys.argv[1:]))
 
     rank = int(os.environ.get("RANK", "0"))
@@ -349,12 +364,21 @@ def main():
     if a.selftest_cpu:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         return selftest_cpu(a, rank, world)
+    if local_rank >= torch.cuda.device_count():
+        sys.stderr.write("bench.py: rank %d: LOCAL_RANK %d but only %d device(s) visible\n" % (rank, local_rank, torch.cuda.device_count()))
+        sys.exit(2)
     torch.cuda.set_device(local_rank)
     dctx = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        try:
+            dist.init_process_group("nccl", rank=rank, world_size=world)
+        except Exception as e:                                  # rendezvous port taken between the parent's probe and rank 0's bind
+            if rank == 0 and ("in use" in str(e).lower() or "EADDRINUSE" in str(e)):
+                sys.stderr.write("bench.py: rendezvous port busy: %s\n" % e)
+                sys.exit(98)
+            raise
         assert dist.get_world_size() == a.gpus, (dist.get_world_size(), a.gpus)
         from fmri_hip.dist import DataParallel
         dctx = DataParallel(world, rank)
@@ -432,6 +456,22 @@ def main():
             import torch.distributed as dist
             dist.barrier()
 
+    # Settled clock (SURVEY 8d ">= 2 s warm"; VERDICT r2: the driver's 5 warm-up steps are 74 ms): untimed steps for at least
+    # --prewarm-seconds of wall time BEFORE the W requested warm-up steps - the same number of steps on every rank (rank 0 decides)
+    prewarm_steps = 0
+    if a.prewarm_seconds > 0:
+        t_pw = time.perf_counter()
+        while True:
+            for _ in range(10):
+                eng.train_step(xd, yd, lr)
+            torch.cuda.synchronize()
+            prewarm_steps += 10
+            go_on = torch.tensor([1.0 if time.perf_counter() - t_pw < a.prewarm_seconds else 0.0], device="cuda")
+            if world > 1:
+                import torch.distributed as dist
+                dist.broadcast(go_on, 0)
+            if float(go_on.item()) == 0.0:
+                break
     for _ in range(a.warmup):
         eng.train_step(xd, yd, lr)
     torch.cuda.synchronize()
@@ -485,7 +525,7 @@ def main():
     out = {
         "metric": "3D patches/sec (64x128x128, bf16) fwd+bwd", "value": value, "unit": "patches/s", "n_gpus": world,
         "collective_ranks": (dctx.world if dctx is not None else 1),
-        "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
+        "steps": a.steps, "warmup": a.warmup, "prewarm_steps_untimed": prewarm_steps, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {"workload": "configs[1]: depth-4 3D U-Net, 32 base filters, bf16, batch %dx1x64x128x128 per GPU, "
                                "full step = fwd + Dice + bwd + Keras-Adam" % a.batch,

@@ -230,12 +230,15 @@ def save_model(model, path, include_optimizer=True, weights_only=False, extra_me
             og = f.create_group("optimizer_weights")
             keys = trainable_keys(model)
             # Keras 2.2.x Adam.weights = [iterations] + ms + vs + vhats (keras/optimizers.py Adam.get_updates): the slots are anonymous
-            # K.zeros variables ("training/Adam/Variable[_k]:0", numbered in creation order m, v, vhat, m, v, vhat ... per parameter), and
-            # with amsgrad=False every vhat is a K.zeros(1) placeholder that is still saved.  Keras restores them BY POSITION
-            # (optimizer.set_weights), so the count - 1 + 3n - is what has to be right for a file written here to resume there.
+            # K.zeros variables "training/Adam/Variable[_k]:0".  get_updates builds ms, vs and vhats as three separate list comprehensions,
+            # so the creation order - and with it the numbering - is ALL m (Variable .. Variable_{n-1}), then all v (_n .. _{2n-1}), then
+            # all vhat (_2n .. _{3n-1}); with amsgrad=False every vhat is a K.zeros(1) placeholder that is still saved.  Keras restores
+            # them BY POSITION (optimizer.set_weights), so the count - 1 + 3n - is what has to be right for a file written here to
+            # resume there; the names only have to be unique.  (No Keras exists in this image: the golden file this layout is tested
+            # against, tests/golden/keras_like_golden.h5, is generated by this repository's own restatement of Keras' saving sequence.)
             n = len(keys)
             var = lambda i: "training/Adam/Variable%s:0" % ("" if i == 0 else "_%d" % i)
-            names = ["Adam/iterations:0"] + [var(3 * i) for i in range(n)] + [var(3 * i + 1) for i in range(n)] + [var(3 * i + 2) for i in range(n)]
+            names = ["Adam/iterations:0"] + [var(i) for i in range(3 * n)]
             _set_list_attr(og, "weight_names", [n_.encode() for n_ in names])
             og.create_dataset(names[0], data=np.int64(t)).close()
             for i, k in enumerate(keys):

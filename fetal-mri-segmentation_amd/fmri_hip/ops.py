@@ -452,9 +452,10 @@ def gaussian_filter_f64(vol, sigma, truncate=4.0):
         radius = int(truncate * sd + 0.5)
         x = np.arange(-radius, radius + 1)
         phi = np.exp(-0.5 / (sd * sd) * x ** 2)               # scipy.ndimage._filters._gaussian_kernel1d, order 0
-        w = torch.from_numpy(phi / phi.sum()).cuda()
-        b = torch.empty_like(vol)
-        check(lib().fmri_correlate1d_f64(_p(a), _p(b), X, Y, Z, axis, _p(w), radius, _s()), "fmri_correlate1d_f64")
+        with torch.cuda.device(vol.device):                   # a volume on a non-current GPU: its device's stream, its device's weights
+            w = torch.from_numpy(phi / phi.sum()).to(vol.device)
+            b = torch.empty_like(vol)
+            check(lib().fmri_correlate1d_f64(_p(a), _p(b), X, Y, Z, axis, _p(w), radius, _s()), "fmri_correlate1d_f64")
         a = b
     return a if a is not vol else vol.clone()
 
@@ -462,13 +463,15 @@ def gaussian_filter_f64(vol, sigma, truncate=4.0):
 def threshold_f64(vol, thr):
     _need_cuda(vol)
     out = torch.empty(vol.shape, dtype=torch.uint8, device=vol.device)
-    check(lib().fmri_threshold_f64(_p(vol), _p(out), vol.numel(), float(thr), _s()), "fmri_threshold_f64")
+    with torch.cuda.device(vol.device):
+        check(lib().fmri_threshold_f64(_p(vol), _p(out), vol.numel(), float(thr), _s()), "fmri_threshold_f64")
     return out
 
 
-def _until_stable(step, sweeps=16, limit=100000):
-    """run `step(sweeps, changed)` until a batch of sweeps changes nothing (one 4-byte read-back per batch)"""
-    changed = torch.zeros(1, dtype=torch.int32, device="cuda")
+def _until_stable(step, device, sweeps=16, limit=100000):
+    """run `step(sweeps, changed)` until a batch of sweeps changes nothing (one 4-byte read-back per batch); the flag lives on the
+    volume's device (the callers run under torch.cuda.device(volume.device), so _s() is that device's stream)"""
+    changed = torch.zeros(1, dtype=torch.int32, device=device)
     done = 0
     while done < limit:
         changed.zero_()
@@ -486,9 +489,11 @@ def binary_fill_holes_u8(mask):
     X, Y, Z = mask.shape
     reached, out = torch.empty_like(mask), torch.empty_like(mask)
     L = lib()
-    check(L.fmri_fill_holes_step(_p(mask), _p(reached), 0, X, Y, Z, 0, 0, 0, _s()), "fmri_fill_holes_step")
-    _until_stable(lambda n, ch: check(L.fmri_fill_holes_step(_p(mask), _p(reached), 0, X, Y, Z, 1, n, _p(ch), _s()), "fmri_fill_holes_step"))
-    check(L.fmri_fill_holes_step(_p(mask), _p(reached), _p(out), X, Y, Z, 2, 0, 0, _s()), "fmri_fill_holes_step")
+    with torch.cuda.device(mask.device):
+        check(L.fmri_fill_holes_step(_p(mask), _p(reached), 0, X, Y, Z, 0, 0, 0, _s()), "fmri_fill_holes_step")
+        _until_stable(lambda n, ch: check(L.fmri_fill_holes_step(_p(mask), _p(reached), 0, X, Y, Z, 1, n, _p(ch), _s()), "fmri_fill_holes_step"),
+                      mask.device)
+        check(L.fmri_fill_holes_step(_p(mask), _p(reached), _p(out), X, Y, Z, 2, 0, 0, _s()), "fmri_fill_holes_step")
     return out
 
 
@@ -503,10 +508,11 @@ def largest_component_u8(mask):
     best = torch.empty(1, dtype=torch.int64, device=mask.device)
     out = torch.empty_like(mask)
     L = lib()
-    check(L.fmri_largest_component_step(_p(mask), _p(labels), 0, 0, 0, X, Y, Z, 0, 0, 0, _s()), "fmri_largest_component_step")
-    _until_stable(lambda k, ch: check(L.fmri_largest_component_step(0, _p(labels), 0, 0, 0, X, Y, Z, 1, k, _p(ch), _s()),
-                                      "fmri_largest_component_step"), sweeps=8)
-    check(L.fmri_largest_component_step(0, _p(labels), _p(counts), _p(best), _p(out), X, Y, Z, 2, 0, 0, _s()), "fmri_largest_component_step")
+    with torch.cuda.device(mask.device):
+        check(L.fmri_largest_component_step(_p(mask), _p(labels), 0, 0, 0, X, Y, Z, 0, 0, 0, _s()), "fmri_largest_component_step")
+        _until_stable(lambda k, ch: check(L.fmri_largest_component_step(0, _p(labels), 0, 0, 0, X, Y, Z, 1, k, _p(ch), _s()),
+                                          "fmri_largest_component_step"), mask.device, sweeps=8)
+        check(L.fmri_largest_component_step(0, _p(labels), _p(counts), _p(best), _p(out), X, Y, Z, 2, 0, 0, _s()), "fmri_largest_component_step")
     return out
 
 

@@ -85,7 +85,7 @@ def main():
         f.attrs['training_config'] = json.dumps(keras_h5.training_config(model)).encode('utf8')
         og = f.create_group('optimizer_weights')
         var = lambda i: "training/Adam/Variable%s:0" % ("" if i == 0 else "_%d" % i)
-        names = ["Adam/iterations:0"] + [var(3 * i) for i in range(n)] + [var(3 * i + 1) for i in range(n)] + [var(3 * i + 2) for i in range(n)]
+        names = ["Adam/iterations:0"] + [var(i) for i in range(3 * n)]          # ms, then vs, then vhats: three list comprehensions in Adam.get_updates
         vals = [np.asarray(iterations, dtype=np.int64)] + [m[k] for k in trainable] + [v[k] for k in trainable] + [np.zeros((1,), np.float32)] * n
         og.attrs['weight_names'] = [nm.encode('utf8') for nm in names]
         for nm, val in zip(names, vals):
