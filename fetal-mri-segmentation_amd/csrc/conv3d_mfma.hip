@@ -14,6 +14,7 @@
 // UpSampling3D / ConcatV2 emitted by Keras for fetal_net/model/unet3d/unet.py:45-66,89-115,132-138.
 #include "common.h"
 #include <type_traits>
+#include <utility>
 #include <cstdlib>
 
 namespace {
@@ -109,6 +110,18 @@ __device__ __forceinline__ int swz64(int row, int slot) { return row * 64 + ((sl
 __device__ __forceinline__ int xcd_logical_id(int b, int nb) {
     const int full = nb & ~7;
     return b < full ? (b & 7) * (full >> 3) + (b >> 3) : b;
+}
+
+// compile-time loop: body(std::integral_constant<int, I>{}) for I = 0 .. N-1 (a `#pragma unroll` loop whose body instantiates several large
+// lambdas can exceed the pragma-unroll size limit and silently stay a loop - its per-phase array indices then turn dynamic and the arrays
+// move to scratch memory)
+template <class F, int... Is>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    static_for_impl(f, std::make_integer_sequence<int, N>{});
 }
 
 struct FwdItem {          // one (tile, Cout block, 32-channel chunk) unit of the persistent stream
@@ -595,7 +608,16 @@ k_conv_fwd_mfma(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__
 //   waves 4-7 (producers, one per SIMD): all LDS-DMA (filter slabs, halo pieces), its address arithmetic and the counted waits.  Their issue
 //              stalls (100-180 cycles per instruction) no longer sit in front of the MFMAs of the same wave.
 // One s_barrier per phase hands both rings over exactly as before (a producer waits for its own DMA before it arrives).
-template <int NT, bool PL, int MODE, bool RES>
+//
+// ASYNC (round 3; 3-D launches without a residual): the tile's stores leave the MFMA waves' critical path.  The consumers only stage the
+// finished tile as bf16 in the consumed halo slot and go straight on to the next tile; the PRODUCERS read it back and store it (ReLU mask,
+// pooled copy and final 1x1x1 logits included) during phase 0 of the next tile, under the consumers' MFMAs.  The staged slot is the one the
+// next item's halo pieces go to, so those start one phase later (phases 1 .. NPH-2 instead of 0 .. NPH-2): every producer's reads of the
+// stage are in registers before it arrives at the phase-1 barrier, behind which the first piece is issued.  The mask lines of a tile are
+// requested by the producers during the tile's last phase (that phase carries no halo pieces) and have landed by the full wait of the next
+// item's phase 0.  The "staged" barrier IS the next tile's phase-0 barrier: one barrier less per tile.  On the level-0 layers of
+// BASELINE configs[1] (1-2 chunks per tile, 64 KB of stores + 64 KB of mask per 18-36 us tile) the epilogue was 13-25 % of a consumer's time.
+template <int NT, bool PL, int MODE, bool RES, bool ASYNC = false>
 __global__ void __launch_bounds__(fw::NTHREADS)
 k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ bias, const bf16_t* __restrict__ mask,
               const bf16_t* residual, bf16_t* y, int N, int D, int H, int W, int Cout, int act, float alpha, FwdTail tail) {
@@ -618,6 +640,12 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
     constexpr int NPAR = PL ? 4 : 8;
     constexpr int NPH = PAR ? (PL ? 2 : 4) : (PL ? 3 : 9);
     constexpr int PH0 = PL ? 3 : 0;
+    constexpr bool ASY = ASYNC && !RES && !PL && MODE == 0;
+    // the producers drain a staged tile in DP parts, one per phase, in phases 0 .. DP-1 of the next tile's first item (one part fits a
+    // phase beside the filter slab's DMA; the whole drain in phase 0 made the producers late for the phase-1 barrier: measured 8 % SLOWER
+    // than the synchronous epilogue); the halo pieces of that item's successor follow in phases DP .. NPH-2
+    constexpr int DP = ASY ? 4 : 0;
+    static_assert(!ASY || NPH >= DP + 3, "asynchronous epilogue: phases DP .. NPH-2 carry the halo pieces");
     static_assert(4 * 32 * JT * BN * 2 <= HALO_BYTES && 4 * 32 * BN * 4 <= HALO_BYTES, "epilogue staging must fit the consumed halo slot");
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * HALO_BYTES + 2 * FILT_BYTES];
 
@@ -669,36 +697,61 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
     int g = 0, hb = 0;
 
     // Plain epilogue, second half: the tile's 512 voxels x BN channels sit in the consumed halo slot as bf16, voxel-major (written by the
-    // consumers); ALL eight waves - the producers have nothing else to do at this point - read them back line-major and store 64 voxels each
-    // (8 or 4 lanes per voxel write its 128 or 64 contiguous bytes), with the optional ReLU mask of the producer of the tensor.
+    // consumers); NW waves (this one is number w of them) read them back line-major and store 512 / NW voxels each (8 or 4 lanes per voxel
+    // write its 128 or 64 contiguous bytes), with the optional ReLU mask of the producer of the tensor.  NW = 8: all waves, right behind the
+    // "staged" barrier (the producers have nothing else to do at that point); NW = 4: the producers alone, under the next tile's MFMAs (ASY).
     auto tile_d = [](int rt) { return rt >> 2; };
     auto tile_h = [](int rt, int rr) { return 2 * (rt & 3) + (rr >> 4); };
     auto lane_w = [](int rr) { return (rr >> 4) ? (((rr & 15) + 16 - (HW & 15)) & 15) : (rr & 15); };
-    auto store_share = [&](const FwdItem& it, int slot) {
-        constexpr int CPV = BN / 8;                  // 16-byte pieces per voxel
-        constexpr int VPI = 64 / CPV;                // voxels per store instruction
+    constexpr int CPV_ = BN / 8;                     // 16-byte pieces per voxel
+    constexpr int VPI_ = 64 / CPV_;                  // voxels per store instruction
+    // element offset in y (and in the mask) of piece q of tile voxel v (column tile v >> 5, lane v & 31)
+    auto piece_addr = [&](const FwdItem& it, int v, int q) -> int64_t {
+        const int rt = v >> 5, rr = v & 31;
+        if constexpr (MODE == 1 && PL) {
+            const int64_t org = ((((int64_t)it.n * D + it.d0) * 2 * H + 2 * it.h0 + ((it.par >> 1) & 1)) * 2 * W + 2 * it.w0 + (it.par & 1)) * Cout + it.co0;
+            return org + ((tile_d(rt) * 2 * H + 2 * tile_h(rt, rr)) * 2 * W + 2 * lane_w(rr)) * Cout + q * 8;
+        } else if constexpr (MODE == 1) {
+            const int64_t org = ((((int64_t)it.n * 2 * D + 2 * it.d0 + (it.par >> 2)) * 2 * H + 2 * it.h0 + ((it.par >> 1) & 1)) * 2 * W +
+                                 2 * it.w0 + (it.par & 1)) * Cout + it.co0;
+            return org + ((2 * tile_d(rt) * 2 * H + 2 * tile_h(rt, rr)) * 2 * W + 2 * lane_w(rr)) * Cout + q * 8;
+        } else {
+            const int64_t org = ((((int64_t)it.n * D + it.d0) * H + it.h0) * W + it.w0) * Cout + it.co0;
+            return org + ((tile_d(rt) * H + tile_h(rt, rr)) * W + lane_w(rr)) * Cout + q * 8;
+        }
+    };
+    // vector-memory instructions one wave issues in store_share<NW> (the producers' counted waits step over exactly these): one store per
+    // iteration, one more per iteration for the logits, the pooled pieces
+    // (part `part` of `nparts`: the store instructions [part, part + 1) * NIT / nparts; the pooled pieces go with the last part)
+    auto store_share_vmops = [&](int nw, int part, int nparts) {
+        const int nit = 512 / (nw * VPI_) / nparts;
+        int n = nit;
+        if (MODE == 0 && !RES) {
+            if (tail.logits) n += nit;
+            if (tail.pool && part == nparts - 1) n += (64 * CPV_ + nw * 64 - 1) / (nw * 64);
+        }
+        return n;
+    };
+    auto store_share = [&](const FwdItem& it, int slot, int w, auto nw_tag, auto pre_tag, const uint4* mk, auto part_tag, auto nparts_tag) {
+        constexpr int NW = decltype(nw_tag)::value;
+        constexpr bool PRE = decltype(pre_tag)::value;       // the mask lines were requested earlier (mk[kk], kk = store instruction)
+        constexpr int PART = decltype(part_tag)::value, NPARTS = decltype(nparts_tag)::value;
+        constexpr int CPV = CPV_, VPI = VPI_;
+        constexpr int NIT = 512 / (NW * VPI);        // store instructions per wave
+        static_assert(NIT % NPARTS == 0, "parts");
         constexpr int SWM = NT == 2 ? 7 : 3;
         const unsigned char* const stage = lds + slot * HALO_BYTES;
 #pragma unroll
-        for (int kk = 0; kk < CPV; ++kk) {
-            const int v = wv * 64 + kk * VPI + lane / CPV, q = lane % CPV;       // tile-wide voxel index: column tile v >> 5, lane v & 31
+        for (int kk = PART * (NIT / NPARTS); kk < (PART + 1) * (NIT / NPARTS); ++kk) {
+            const int v = w * (512 / NW) + kk * VPI + lane / CPV, q = lane % CPV;       // tile-wide voxel index: column tile v >> 5, lane v & 31
             const int vs = NT == 2 ? (v & 7) : ((v >> 2) & 3);
             uint4 o4 = *reinterpret_cast<const uint4*>(stage + v * (BN * 2) + (((q ^ vs) & SWM) << 4));
             const int rt = v >> 5, rr = v & 31;
-            int64_t ao;
-            if constexpr (MODE == 1 && PL) {
-                const int64_t org = ((((int64_t)it.n * D + it.d0) * 2 * H + 2 * it.h0 + ((it.par >> 1) & 1)) * 2 * W + 2 * it.w0 + (it.par & 1)) * Cout + it.co0;
-                ao = org + ((tile_d(rt) * 2 * H + 2 * tile_h(rt, rr)) * 2 * W + 2 * lane_w(rr)) * Cout + q * 8;
-            } else if constexpr (MODE == 1) {
-                const int64_t org = ((((int64_t)it.n * 2 * D + 2 * it.d0 + (it.par >> 2)) * 2 * H + 2 * it.h0 + ((it.par >> 1) & 1)) * 2 * W +
-                                     2 * it.w0 + (it.par & 1)) * Cout + it.co0;
-                ao = org + ((2 * tile_d(rt) * 2 * H + 2 * tile_h(rt, rr)) * 2 * W + 2 * lane_w(rr)) * Cout + q * 8;
-            } else {
-                const int64_t org = ((((int64_t)it.n * D + it.d0) * H + it.h0) * W + it.w0) * Cout + it.co0;
-                ao = org + ((tile_d(rt) * H + tile_h(rt, rr)) * W + lane_w(rr)) * Cout + q * 8;
-            }
+            const int64_t ao = piece_addr(it, v, q);
             if (mask) {
-                const uint4 m4 = *reinterpret_cast<const uint4*>(mask + ao);
+                uint4 m4;
+                if constexpr (PRE) m4 = mk[kk];
+                else m4 = *reinterpret_cast<const uint4*>(mask + ao);
                 const unsigned mm[4] = {m4.x, m4.y, m4.z, m4.w};
                 unsigned* const oo = reinterpret_cast<unsigned*>(&o4);
 #pragma unroll
@@ -726,20 +779,28 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
                         tail.logits[(((int64_t)it.n * D + it.d0 + tile_d(rt)) * H + it.h0 + tile_h(rt, rr)) * W + it.w0 + lane_w(rr)] = part + tail.b1[0];
                 }
             }
+            // four pieces at a time: left alone the scheduler hoists all NIT stage reads and addresses to the top (96+ live registers: the
+            // producer path of the ASYNC kernel spilled 150 of them)
+            if constexpr (NW == 4) {
+                if ((kk & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            }
         }
-        if constexpr (MODE == 0 && !RES) {
+        if constexpr (MODE == 0 && !RES && PART == NPARTS - 1) {
             if (tail.pool) {
-                // 2x2x2 max pooling of the staged tile: 2 x 4 x 8 pooled voxels x CPV 16-byte pieces, one per thread
-                const int idx = wv * 64 + lane;
-                if (idx < 64 * CPV) {
-                    const int pv = idx / CPV, q = idx % CPV;
+                // 2x2x2 max pooling of the staged tile: 2 x 4 x 8 pooled voxels x CPV 16-byte pieces, one per thread and round
+                constexpr int NPOOL = (64 * CPV + NW * 64 - 1) / (NW * 64);
+#pragma unroll
+                for (int pi = 0; pi < NPOOL; ++pi) {
+                    const int idx = (pi * NW + w) * 64 + lane;
+                    const bool live = idx < 64 * CPV;         // wave-uniform (64 * CPV is a multiple of 64)
+                    const int pv = (live ? idx : 0) / CPV, q = idx % CPV;
                     const int pd = pv >> 5, ph = (pv >> 3) & 3, pw = pv & 7;
                     float mx[8];
 #pragma unroll
                     for (int c = 0; c < 8; ++c) {
-                        const int d = 2 * pd + (c >> 2), h = 2 * ph + ((c >> 1) & 1), w = 2 * pw + (c & 1);
+                        const int d = 2 * pd + (c >> 2), h = 2 * ph + ((c >> 1) & 1), w_ = 2 * pw + (c & 1);
                         // inverse of (tile_d, tile_h, lane_w): column tile rt = d*4 + h/2, lane rr = (h&1)*16 + (w rotated by HW mod 16 on odd rows)
-                        const int v = (d * 4 + (h >> 1)) * 32 + ((h & 1) ? 16 + ((w + (HW & 15)) & 15) : w);
+                        const int v = (d * 4 + (h >> 1)) * 32 + ((h & 1) ? 16 + ((w_ + (HW & 15)) & 15) : w_);
                         const int vs = NT == 2 ? (v & 7) : ((v >> 2) & 3);
                         const uint4 p4 = *reinterpret_cast<const uint4*>(stage + v * (BN * 2) + (((q ^ vs) & SWM) << 4));
                         const unsigned pp[4] = {p4.x, p4.y, p4.z, p4.w};
@@ -757,7 +818,7 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
                     o.w = (__float_as_uint(mx[6]) >> 16) | (__float_as_uint(mx[7]) & 0xffff0000u);
                     const int64_t po = ((((int64_t)it.n * (D >> 1) + (it.d0 >> 1) + pd) * (H >> 1) + (it.h0 >> 1) + ph) * (W >> 1) + (it.w0 >> 1) + pw) * Cout +
                                        it.co0 + q * 8;
-                    *reinterpret_cast<uint4*>(tail.pool + po) = o;
+                    if (live) *reinterpret_cast<uint4*>(tail.pool + po) = o;
                 }
             }
         }
@@ -833,22 +894,32 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
         };
         // Halo pieces of the NEXT chunk issued in phase pl: spread over the first NPH-1 phases (all of them when a chunk has one phase
         // only... it has at least two), so that the last phase's wait - everything landed - finds them a phase old.
-        auto pieces_from = [](int pl) { return pl >= NPH - 1 ? NPIECE : pl * NPIECE / (NPH - 1); };
-        auto wait_newer = [](int n) {      // wait until at most n of this wave's DMA instructions are in flight (n folds to a constant)
+        // (ASY: the first item of a tile issues none in phase 0 - the slot they go to is the staged tile the producers drain in that phase)
+        auto pieces_from = [](int pl, bool drain) {
+            if (drain) return pl <= DP ? 0 : (pl >= NPH - 1 ? NPIECE : (pl - DP) * NPIECE / (NPH - 1 - DP > 0 ? NPH - 1 - DP : 1));
+            return pl >= NPH - 1 ? NPIECE : pl * NPIECE / (NPH - 1);
+        };
+        auto wait_newer = [](int n) {      // wait until at most n of this wave's vector-memory instructions are in flight (wave-uniform n)
+#define FMRI_W(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
             switch (n) {
-                case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-                case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
-                case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-                case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
-                case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-                case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
-                case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-                case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
-                case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-                case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+                FMRI_W(0) FMRI_W(1) FMRI_W(2) FMRI_W(3) FMRI_W(4) FMRI_W(5) FMRI_W(6) FMRI_W(7) FMRI_W(8) FMRI_W(9) FMRI_W(10) FMRI_W(11)
+                FMRI_W(12) FMRI_W(13) FMRI_W(14) FMRI_W(15) FMRI_W(16) FMRI_W(17) FMRI_W(18) FMRI_W(19) FMRI_W(20) FMRI_W(21) FMRI_W(22)
+                FMRI_W(23) FMRI_W(24) FMRI_W(25) FMRI_W(26) FMRI_W(27) FMRI_W(28) FMRI_W(29) FMRI_W(30) FMRI_W(31) FMRI_W(32) FMRI_W(33)
+                FMRI_W(34) FMRI_W(35) FMRI_W(36) FMRI_W(37) FMRI_W(38) FMRI_W(39) FMRI_W(40)
                 default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
             }
+#undef FMRI_W
         };
+        // ASY: the finished tile waiting to be stored (staged by the consumers in halo slot `hb ^ 1` as seen from the next item), the mask
+        // lines of this wave's share of it, and the number of vector-memory instructions the drain issues behind the phase-1 filter slab
+        constexpr int NDR = ASY ? 512 / (DW * VPI_) : 1;
+        uint4 mk[NDR] = {};
+        FwdItem done = cur;
+        bool pending = false;
+        constexpr int DPN = DP > 0 ? DP : 1;
+        int drain_vmops[DPN];
+#pragma unroll
+        for (int i = 0; i < DPN; ++i) drain_vmops[i] = ASY ? store_share_vmops(DW, i, DPN) : 0;
 #pragma unroll
         for (int ph = 0; ph < NPIECE; ++ph) {
             hp[ph] = halo_src(cur, h_pack[ph]);
@@ -866,34 +937,82 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
                 if (has_next) nxt = decode(npair, 0);
             }
             const bool fresh = MODE == 2 ? (nxt.ch % kpc == 0) : (nxt.ch == 0 || (nxt.ch << 5) == s.C0);
+            // keep the packed piece descriptors packed: hipcc otherwise hoists the three bit-field extractions of every piece out of the loop
+            // (51 more live registers) and spills them
 #pragma unroll
-            for (int pl = 0; pl < NPH; ++pl, ++g) {
-                // This phase's filter slab was issued one phase ago, FOLLOWED by that phase's halo pieces (which belong to the next chunk):
-                // wait for the slab only and leave those pieces in flight - a full vmcnt(0) here exposes the memory latency of every piece
-                // in every phase (measured: the producer chain issue + latency, not the MFMAs, set the phase time).  The first phase of a
-                // chunk needs its whole halo: everything must have landed, and the youngest piece is a phase old by then.
-                if (pl == 0) wait_newer(0);
-                else wait_newer(has_next ? pieces_from(pl) - pieces_from(pl - 1) : 0);
-                __builtin_amdgcn_s_barrier();                          // everybody's has landed; the previous phase is fully read
-                if (pl < NPH - 1) issue_filter(cur, pl + 1, (g + 1) & 1);
-                else if (has_next) issue_filter(nxt, 0, (g + 1) & 1);
-                if (has_next) {
-                    const int HP0 = pieces_from(pl), HPN = pieces_from(pl + 1) - HP0;
+            for (int ph = 0; ph < NPIECE; ++ph) asm volatile("" : "+v"(h_pack[ph]));
+            // the phases of one item; DRN (ASY only): a staged tile is drained in phase 0 and the halo pieces start a phase later
+            auto run_phases = [&](auto drn_tag) {
+                constexpr bool DRN = decltype(drn_tag)::value;
+                static_for<NPH>([&](auto pl_tag) {
+                    constexpr int pl = decltype(pl_tag)::value;
+                    // This phase's filter slab was issued one phase ago, FOLLOWED by that phase's halo pieces (which belong to the next chunk)
+                    // or by the stores of the drain: wait for the slab only and leave those in flight - a full vmcnt(0) here exposes the
+                    // memory latency of every piece in every phase (measured: the producer chain issue + latency, not the MFMAs, set the
+                    // phase time).  The first phase of a chunk needs its whole halo: everything must have landed, and the youngest piece is
+                    // a phase old by then.
+                    if constexpr (pl == 0) {
+                        wait_newer(0);
+                        if constexpr (DRN) {
+                            // the mask lines requested in the previous tile's last phase are in their registers now: tell the compiler here,
+                            // where it costs nothing (its own wait for them would otherwise sit behind the next filter slab's DMA)
+                            if (mask) {
 #pragma unroll
-                    for (int q = 0; q < NPIECE; ++q) {
-                        if (q < HPN) {
-                            if (fresh) hp[HP0 + q] = halo_src(nxt, h_pack[HP0 + q]);
-                            else hp[HP0 + q] += 32;
-                            issue_halo(HP0 + q, hb ^ 1);
+                                for (int i = 0; i < NDR; ++i) asm volatile("" : "+v"(mk[i].x), "+v"(mk[i].y), "+v"(mk[i].z), "+v"(mk[i].w));
+                            }
+                        }
+                    } else if constexpr (DRN && pl <= DP) wait_newer(drain_vmops[pl - 1]);
+                    else wait_newer(has_next ? pieces_from(pl, DRN) - pieces_from(pl - 1, DRN) : 0);
+                    __builtin_amdgcn_s_barrier();                          // everybody's has landed; the previous phase is fully read
+                    if (pl < NPH - 1) issue_filter(cur, pl + 1, (g + 1) & 1);
+                    else if (has_next) issue_filter(nxt, 0, (g + 1) & 1);
+                    if constexpr (DRN) {
+                        // part pl of the drain
+                        if constexpr (pl < DP)
+                            store_share(done, hb ^ 1, dwv, std::integral_constant<int, DW>{}, std::true_type{}, mk,
+                                        std::integral_constant<int, pl>{}, std::integral_constant<int, DPN>{});
+                    }
+                    if (has_next) {
+                        const int HP0 = pieces_from(pl, DRN), HPN = pieces_from(pl + 1, DRN) - HP0;
+#pragma unroll
+                        for (int q = 0; q < NPIECE; ++q) {
+                            if (q < HPN) {
+                                if (fresh) hp[HP0 + q] = halo_src(nxt, h_pack[HP0 + q]);
+                                else hp[HP0 + q] += 32;
+                                issue_halo(HP0 + q, hb ^ 1);
+                            }
                         }
                     }
-                }
-            }
+                    if constexpr (ASY) {
+                        // last phase of a tile (it carries no halo pieces): request the mask lines of this wave's share of the tile's stores
+                        if (pl == NPH - 1 && cur.ch == nch - 1 && mask) {
+#pragma unroll
+                            for (int kk = 0; kk < NDR; ++kk) {
+                                const int v = dwv * (512 / DW) + kk * VPI_ + lane / CPV_;
+                                mk[kk] = *reinterpret_cast<const uint4*>(mask + piece_addr(cur, v, lane % CPV_));
+                            }
+                        }
+                    }
+                    ++g;
+                });
+            };
+            if constexpr (ASY) {
+                if (pending) run_phases(std::true_type{});
+                else run_phases(std::false_type{});
+                pending = false;
+            } else run_phases(std::false_type{});
             if (cur.ch == nch - 1) {
                 __builtin_amdgcn_s_barrier();                          // the halo slot is fully read: the consumers stage the tile in it
-                if constexpr (!RES) {
+                if constexpr (ASY) {
+                    done = cur;
+                    pending = true;
+                    if (!has_next) {                                   // the last tile of this workgroup: nothing left to hide the stores under
+                        __builtin_amdgcn_s_barrier();                  // staged
+                        store_share(done, hb, dwv, std::integral_constant<int, DW>{}, std::true_type{}, mk, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
+                    }
+                } else if constexpr (!RES) {
                     __builtin_amdgcn_s_barrier();                      // staged
-                    store_share(cur, hb);
+                    store_share(cur, hb, wv, std::integral_constant<int, 8>{}, std::false_type{}, nullptr, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
                 }
             }
             if (!has_next) break;
@@ -946,6 +1065,18 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
     PROF_T(ck0);
 #endif
     bf16x8_t fa_[2][NT], fb_[2][JT];           // double-buffered filter / halo fragments (live across the phases of a tile)
+    // RES: the residual's 16-byte lines this lane adds in the epilogue, [column tile][store instruction] (see the RES epilogue)
+    constexpr int RKK = RES ? 32 / (64 / (BN / 8)) : 1;
+    // column tiles whose lines are requested a phase early: none - 16 registers per tile at BN = 64 held across the last phase's MFMAs made
+    // hipcc spill inside the matrix loop (tools/spill_sites.py); all lines are requested at the top of the epilogue, in front of its barrier
+    constexpr int RPRE = 0;
+    constexpr int RAHEAD = 2;                  // column tiles whose lines are in flight ahead of the one being finished (16 registers each)
+    uint4 res_q[RES ? RAHEAD : 1][RKK];
+    auto res_line = [&](int64_t org, int j, int kk) {
+        constexpr int LPV = BN / 8, VPI = 64 / LPV;
+        const int rt = JT * cw + j, rr = kk * VPI + lane / LPV, q8 = lane % LPV;
+        return *reinterpret_cast<const uint4*>(residual + org + ((tile_d(rt) * H + tile_h(rt, rr)) * W + lane_w(rr)) * Cout + q8 * 8);
+    };
     while (true) {
         bool has_next = true;
         FwdItem nxt = cur;
@@ -998,6 +1129,15 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
                 for (int j = 0; j < JT; ++j) load_b(lh, hoff, kw0, 0, 0, j);
             }
             PROF_T(c1);
+            if constexpr (RES) {
+                if (pl == NPH - 1 && cur.ch == nch - 1) {          // the tile's last phase: request the residual lines of the first column tile(s)
+                    const int64_t org = ((((int64_t)cur.n * D + cur.d0) * H + cur.h0) * W + cur.w0) * Cout + cur.co0;
+#pragma unroll
+                    for (int j = 0; j < RPRE; ++j)
+#pragma unroll
+                        for (int kk = 0; kk < RKK; ++kk) res_q[j & (RAHEAD - 1)][kk] = res_line(org, j, kk);
+                }
+            }
 #pragma unroll
             for (int st = 0; st < NST; ++st) {
                 const bool last = st + 1 == NST;
@@ -1033,13 +1173,20 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
         }
         PROF_T(ce0);
         if (RES && cur.ch == nch - 1) {
-            // y = act(acc + residual): fp32 transposition through LDS, one 32-voxel column tile at a time (wave-private 8 KiB)
+            // y = act(acc + residual): fp32 transposition through LDS, one 32-voxel column tile at a time (wave-private 8 KiB).  The
+            // residual lines of the first RPRE column tiles were requested at the top of the tile's last phase (res_q), the next RAHEAD tiles' lines are
+            // requested here, where the fragment registers have died, and each finished line's registers take the line RAHEAD tiles on: round 2 loaded each tile's lines inside its own iteration and waited four
+            // global-memory latencies per tile in a row (MFMA pipe 43 % busy on the dec0a launch).
             constexpr int PPV = BN / 4, LPV = BN / 8, VPI = 64 / LPV;
             float4 bvn[NT][4];
             load_bias(has_next ? nxt.co0 : cur.co0, bvn);
+            const int64_t org = ((((int64_t)cur.n * D + cur.d0) * H + cur.h0) * W + cur.w0) * Cout + cur.co0;
+#pragma unroll
+            for (int j = RPRE; j < RAHEAD; ++j)
+#pragma unroll
+                for (int kk = 0; kk < RKK; ++kk) res_q[j & (RAHEAD - 1)][kk] = res_line(org, j, kk);
             __builtin_amdgcn_s_barrier();
             unsigned char* const stage = lds + hb * HALO_BYTES + cw * (32 * BN * 4);
-            const int64_t org = ((((int64_t)cur.n * D + cur.d0) * H + cur.h0) * W + cur.w0) * Cout + cur.co0;
 #pragma unroll
             for (int j = 0; j < JT; ++j) {
 #pragma unroll
@@ -1057,7 +1204,7 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
                     const float4 a0 = *reinterpret_cast<const float4*>(stage + rr * (BN * 4) + ((((2 * q8) ^ rr) & (PPV - 1)) << 4));
                     const float4 a1 = *reinterpret_cast<const float4*>(stage + rr * (BN * 4) + ((((2 * q8 + 1) ^ rr) & (PPV - 1)) << 4));
                     const int64_t ao = org + ((tile_d(rt) * H + tile_h(rt, rr)) * W + lane_w(rr)) * Cout + q8 * 8;
-                    const uint4 r4 = *reinterpret_cast<const uint4*>(residual + ao);
+                    const uint4 r4 = res_q[j & (RAHEAD - 1)][kk];
                     float o[8] = {a0.x + __uint_as_float(r4.x << 16), a0.y + __uint_as_float(r4.x & 0xffff0000u),
                                   a0.z + __uint_as_float(r4.y << 16), a0.w + __uint_as_float(r4.y & 0xffff0000u),
                                   a1.x + __uint_as_float(r4.z << 16), a1.y + __uint_as_float(r4.z & 0xffff0000u),
@@ -1065,7 +1212,10 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
 #pragma unroll
                     for (int i = 0; i < 8; ++i) o[i] = vmax(o[i], __builtin_fmaf(o[i], act_s, 0.f));
                     *reinterpret_cast<uint4*>(y + ao) = make_uint4(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]), pack2bf(o[4], o[5]), pack2bf(o[6], o[7]));
+                    // this tile's line is consumed: request the one RAHEAD tiles on into the same registers
+                    if (j + RAHEAD < JT) res_q[j & (RAHEAD - 1)][kk] = res_line(org, j + RAHEAD, kk);
                 }
+                __builtin_amdgcn_sched_barrier(0);
             }
             init_acc(bvn);
         }
@@ -1126,9 +1276,14 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
             else stage_tile(std::integral_constant<int, FMRI_ACT_LEAKY>{});
             PROF_T(e2);
             init_acc(bvn);
-            __builtin_amdgcn_s_barrier();                              // the whole tile is staged: all eight waves store it
+            if constexpr (ASY) {
+                // the producers store the staged tile under the next tile's first phases; the "staged" barrier is that tile's phase-0 barrier
+                if (!has_next) __builtin_amdgcn_s_barrier();           // (the workgroup's last tile: the producers store it right away)
+            } else {
+                __builtin_amdgcn_s_barrier();                          // the whole tile is staged: all eight waves store it
+            }
             PROF_T(e3);
-            store_share(cur, hb);
+            if constexpr (!ASY) store_share(cur, hb, wv, std::integral_constant<int, 8>{}, std::false_type{}, nullptr, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
             PROF_T(e4);
 #ifdef FMRI_PROF
             cprof[7] += e1 - e0; cprof[8] += e2 - e1; cprof[9] += e3 - e2; cprof[10] += e4 - e3;
@@ -1913,6 +2068,14 @@ static int fwd_use_ws() {               // FMRI_FWD_WS=0: the symmetric kernel (
     }
     return use_ws;
 }
+static int fwd_async() {                // FMRI_FWD_ASYNC=0: the tile's stores by all eight waves behind a barrier (the round-2 epilogue)
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("FMRI_FWD_ASYNC");
+        v = e ? atoi(e) : 1;
+    }
+    return v;
+}
 static bool fwd_wide(int mode, int planar, int ntile, int Cout) {
     // 64-wide Cout blocks halve the halo traffic per MFMA, but a launch with fewer (tile, block) pairs than CUs (the 8x16x16 bottleneck
     // level) leaves CUs idle: 32-wide blocks double the pairs there
@@ -1930,7 +2093,11 @@ static int conv3d_fwd_mfma_launch(int mode, const void* src0, int C0, int up0, i
 #define FMRI_LAUNCH_FWD(NT_, PL_, MODE_, RES_)                                                                             \
     do {                                                                                                                  \
         const int np = ntile * (Cout / (32 * NT_)) * (MODE_ == 1 ? (PL_ ? 4 : 8) : 1);                                    \
-        if (use_ws && (!(PL_) || use_ws > 1))   /* planar: the producers are the bottleneck - symmetric kernel */ \
+        constexpr bool A_ = !(PL_) && !(RES_) && (MODE_) == 0;   /* asynchronous epilogue: plain 3-D launches */         \
+        if (use_ws && A_ && fwd_async() && np > ncu)   /* a single pair per workgroup has nothing to hide the stores under */ \
+            k_conv_fwd_ws<NT_, PL_, MODE_, RES_, A_><<<np < ncu ? np : ncu, fw::NTHREADS, 0, st>>>(                       \
+                s, (const bf16_t*)w, bias, (const bf16_t*)mask, (const bf16_t*)residual, (bf16_t*)y, N, D, H, W, Cout, act, alpha, tail); \
+        else if (use_ws && (!(PL_) || use_ws > 1))   /* planar: the producers are the bottleneck - symmetric kernel */ \
             k_conv_fwd_ws<NT_, PL_, MODE_, RES_><<<np < ncu ? np : ncu, fw::NTHREADS, 0, st>>>(                           \
                 s, (const bf16_t*)w, bias, (const bf16_t*)mask, (const bf16_t*)residual, (bf16_t*)y, N, D, H, W, Cout, act, alpha, tail); \
         else                                                                                                              \

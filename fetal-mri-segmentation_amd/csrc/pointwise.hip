@@ -568,6 +568,79 @@ extern "C" int fmri_sigmoid_loss_bwd(const float* probs, const uint8_t* y_true, 
     FMRI_LAUNCH_CHECK();
     return FMRI_OK;
 }
+// ---- weighted_dice_coefficient_loss (reference metrics.py:39-55): Dice per (sample, label) over the voxel axes, smooth 1e-5, MEAN over the
+// (sample, label) groups - the only loss whose values the reference's own tests pin (test/test_metrics.py:10-38).
+// gsums [G = nsamples * L][3] doubles: sum y*p, sum y, sum p of group g = n * L + l (element (n, v, l) sits at (n * vox + v) * L + l)
+__global__ void k_wdice_sums(const float* __restrict__ probs, const uint8_t* __restrict__ y, double* __restrict__ gsums, int64_t vox, int L) {
+    const int n = blockIdx.y;
+    const int64_t per = vox * L;
+    const float* const pp = probs + (int64_t)n * per;
+    const uint8_t* const yy = y + (int64_t)n * per;
+    __shared__ double red[3][4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int l = 0; l < L; ++l) {
+        double a = 0, b = 0, c = 0;
+        for (int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; v < vox; v += (int64_t)gridDim.x * blockDim.x) {
+            const float p = pp[v * L + l], t = (float)yy[v * L + l];
+            a += (double)(t * p);
+            b += (double)t;
+            c += (double)p;
+        }
+        a = wave_sum(a); b = wave_sum(b); c = wave_sum(c);
+        if (lane == 0) { red[0][wv] = a; red[1][wv] = b; red[2][wv] = c; }
+        __syncthreads();
+        if (threadIdx.x < 3) atomicAdd(&gsums[((int64_t)n * L + l) * 3 + threadIdx.x], red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3]);
+        __syncthreads();
+    }
+}
+// sums[10] += sum_g (2 I_g + s) / (Sy_g + Sp_g + s), sums[11] += G: additive over ranks, loss = -sums[10] / sums[11]
+__global__ void k_wdice_finish(const double* __restrict__ gsums, double* __restrict__ sums, int G, float smooth) {
+    double acc = 0;
+    for (int g = threadIdx.x; g < G; g += blockDim.x)
+        acc += (2.0 * gsums[3 * g] + (double)smooth) / (gsums[3 * g + 1] + gsums[3 * g + 2] + (double)smooth);
+    acc = wave_sum(acc);
+    if (threadIdx.x == 0) {
+        atomicAdd(&sums[10], acc);
+        atomicAdd(&sums[11], (double)G);
+    }
+}
+// dL/dlogit of -mean_g dice_g: group g's elements get -(1 / G_total) [2 y den_g - (2 I_g + s)] / den_g^2 * p (1 - p); G_total = sums[11]
+__global__ void k_wdice_bwd(const float* __restrict__ probs, const uint8_t* __restrict__ y, const double* __restrict__ gsums,
+                            const double* __restrict__ sums, float* __restrict__ dl, int64_t vox, int L, float smooth, float grad_scale) {
+    const int n = blockIdx.y;
+    const int64_t per = vox * L, base = (int64_t)n * per;
+    const double invg = 1.0 / sums[11];
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < per; i += (int64_t)gridDim.x * blockDim.x) {
+        const int l = (int)(i % L);
+        const double* const gs = gsums + ((int64_t)n * L + l) * 3;
+        const double den = gs[1] + gs[2] + (double)smooth;
+        const float a = (float)(2.0 / den * invg), c = (float)((2.0 * gs[0] + (double)smooth) / (den * den) * invg);
+        const float p = probs[base + i], t = (float)y[base + i];
+        dl[base + i] = grad_scale * -(a * t - c) * p * (1.f - p);
+    }
+}
+extern "C" int fmri_weighted_dice_fwd(const float* probs, const uint8_t* y_true, double* gsums, double* sums, int nsamples, int64_t vox, int L,
+                                      float smooth, fmri_stream_t stream) {
+    if (!probs || !y_true || !gsums || !sums || nsamples <= 0 || vox <= 0 || L <= 0 || nsamples > 65535) return FMRI_E_SHAPE;
+    hipStream_t s = as_stream(stream);
+    const int G = nsamples * L;
+    if (hipMemsetAsync(gsums, 0, (size_t)G * 3 * sizeof(double), s) != hipSuccess) return FMRI_E_LAUNCH;
+    int bx = (int)((vox + 256 * 16 - 1) / (256 * 16));
+    if (bx > 256) bx = 256;
+    k_wdice_sums<<<dim3(bx, nsamples), 256, 0, s>>>(probs, y_true, gsums, vox, L);
+    k_wdice_finish<<<1, 64, 0, s>>>(gsums, sums, G, smooth);
+    FMRI_LAUNCH_CHECK();
+    return FMRI_OK;
+}
+extern "C" int fmri_weighted_dice_bwd(const float* probs, const uint8_t* y_true, const double* gsums, const double* sums, float* dlogits,
+                                      int nsamples, int64_t vox, int L, float smooth, float grad_scale, fmri_stream_t stream) {
+    if (!probs || !y_true || !gsums || !sums || !dlogits || nsamples <= 0 || vox <= 0 || L <= 0 || nsamples > 65535) return FMRI_E_SHAPE;
+    int bx = (int)((vox * L + 256 * 8 - 1) / (256 * 8));
+    if (bx > 1024) bx = 1024;
+    k_wdice_bwd<<<dim3(bx, nsamples), 256, 0, as_stream(stream)>>>(probs, y_true, gsums, sums, dlogits, vox, L, smooth, grad_scale);
+    FMRI_LAUNCH_CHECK();
+    return FMRI_OK;
+}
 // the same two passes with a per-voxel weight on the cross-entropy term (reference metrics.py:72-76 weighted_cross_entropy_loss,
 // :89-95 dice_and_xent_mask: weight = exp(-distance_mask / sigma), computed by the caller); kinds 1 and 2 use it
 extern "C" int fmri_sigmoid_dice_fwd_weighted(const float* logits, const uint8_t* y_true, const float* weight, float* probs, double* sums,

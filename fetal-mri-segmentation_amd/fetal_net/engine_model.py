@@ -406,7 +406,7 @@ class Model(object):
     def _loss_kind(self):
         """(kind, param) of fmri_sigmoid_loss_bwd for the compiled loss token"""
         table = {M.dice_coefficient_loss: (0, 1.0), M.binary_crossentropy_loss: (1, 1.0), M.dice_and_xent: (2, 1.0), M.focal_loss: (3, 1.0),
-                 M.vod_coefficient_loss: (4, 1.0), M.double_dice_loss: (5, 10.0)}
+                 M.vod_coefficient_loss: (4, 1.0), M.double_dice_loss: (5, 10.0), M.weighted_dice_coefficient_loss: (6, 1.0)}
         if getattr(self.loss, "mask_weighted", False):       # dice_and_xent_mask(mask_input): Dice + w * mean(exp(-mask/sigma) * xent)
             return (2, self.loss.xent_weight)
         if self.loss not in table:

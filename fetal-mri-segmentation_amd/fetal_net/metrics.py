@@ -110,4 +110,5 @@ binary_crossentropy_loss = binary_crossentropy
 focal_loss = _focal_loss()
 
 # losses differentiated on the device (fmri_sigmoid_loss_bwd); the rest build but raise at the first training step
-DEVICE_LOSSES = (dice_coefficient_loss, binary_crossentropy_loss, dice_and_xent, focal_loss, vod_coefficient_loss, double_dice_loss)
+DEVICE_LOSSES = (dice_coefficient_loss, binary_crossentropy_loss, dice_and_xent, focal_loss, vod_coefficient_loss, double_dice_loss,
+                 weighted_dice_coefficient_loss)

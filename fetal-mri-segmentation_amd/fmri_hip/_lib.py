@@ -37,6 +37,8 @@ SIGNATURES = {
     "fmri_sigmoid_dice_fwd": [p, p, p, p, i64, p],
     "fmri_sigmoid_dice_bwd": [p, p, p, p, i64, f32, f32, p],
     "fmri_sigmoid_loss_bwd": [p, p, p, p, i64, i32, f32, f32, f32, p],
+    "fmri_weighted_dice_fwd": [p, p, p, p, i32, i64, i32, f32, p],
+    "fmri_weighted_dice_bwd": [p, p, p, p, p, i32, i64, i32, f32, f32, p],
     "fmri_maxpool3d_2x_fwd": [p, p, i32, i32, i32, i32, i32, i32, i32, p],
     "fmri_maxpool3d_2x_bwd": [p, p, p, i32, i32, p, i32, i32, i32, i32, i32, i32, i32, i32, p],
     "fmri_upsample_nearest2x_fwd": [p, p, i32, i32, i32, i32, i32, i32, i32, i32, i32, p],

@@ -587,9 +587,21 @@ class UNetEngine:
         """y_true uint8 [nvox*L] device.  probs + the 8 metric sums (accumulated into zeroed self.sums)."""
         self.sums.zero_()
         ops.sigmoid_dice_fwd(self.logits, y_true, self.probs, self.sums, weight=weight)
+        if self.loss_kind == ops.LOSS_WEIGHTED_DICE:
+            ns, nl = self._wdice_groups()
+            if getattr(self, "_gsums", None) is None or self._gsums.numel() < 3 * ns * nl:
+                self._gsums = torch.zeros(3 * ns * nl, dtype=torch.float64, device=self.dev)
+            ops.weighted_dice_fwd(self.probs, y_true, self._gsums, self.sums, ns, nl)
         if self.dist is not None and self.dist.world > 1 and self.dist.global_dice:
             self.dist.all_reduce_sums(self.sums)
         return self.sums
+
+    def _wdice_groups(self):
+        """(groups along the batch axis, labels per group) of weighted_dice_coefficient's axis=(-3,-2,-1) (reference metrics.py:39): the 3-D
+        models' (N, labels, X, Y, Z) tensors give one Dice per (sample, label), the 2-D models' (N, X, Y, labels) one per slice"""
+        if self.plan.ndim == 2:
+            return self.N, 1
+        return self.N, self.plan.n_labels
 
     def predict(self, x):
         self.forward(x, bn_training=False)
@@ -642,7 +654,10 @@ class UNetEngine:
         normed = p.norm is not None
         self._main_stream = torch.cuda.current_stream(self.dev) if self.dev.type == "cuda" else None
         self.G.zero_()
-        if seg_loss:
+        if seg_loss and self.loss_kind == ops.LOSS_WEIGHTED_DICE:
+            ns, nl = self._wdice_groups()
+            ops.weighted_dice_bwd(self.probs, y_true, self._gsums, self.sums, self.dlogits, ns, nl, grad_scale=grad_scale)
+        elif seg_loss:
             ops.sigmoid_loss_bwd(self.probs, y_true, self.sums, self.dlogits, self.loss_kind, self.loss_param, smooth=1.0, grad_scale=grad_scale,
                                  weight=weight)
         if dprobs is not None:

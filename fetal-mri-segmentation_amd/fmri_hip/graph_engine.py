@@ -598,9 +598,21 @@ class LayerGraphEngine(object):
     def loss_forward(self, y_true, weight=None):
         self.sums.zero_()
         ops.sigmoid_dice_fwd(self.logits, y_true, self.probs, self.sums, weight=weight)
+        if self.loss_kind == ops.LOSS_WEIGHTED_DICE:
+            ns, nl = self._wdice_groups()
+            if getattr(self, "_gsums", None) is None or self._gsums.numel() < 3 * ns * nl:
+                self._gsums = torch.zeros(3 * ns * nl, dtype=torch.float64, device=self.dev)
+            ops.weighted_dice_fwd(self.probs, y_true, self._gsums, self.sums, ns, nl)
         if self.dist is not None and self.dist.world > 1 and self.dist.global_dice:
             self.dist.all_reduce_sums(self.sums)
         return self.sums
+
+    def _wdice_groups(self):
+        """(groups along the batch axis, labels per group) of weighted_dice_coefficient's axis=(-3,-2,-1) (reference metrics.py:39): the 3-D
+        models' (N, labels, X, Y, Z) tensors give one Dice per (sample, label), the 2-D models' (N, X, Y, labels) one per slice"""
+        if self.plan.ndim == 2:
+            return self.N, 1
+        return self.N, self.plan.n_labels
 
     def bce_forward(self, target):
         """dense head: probs = sigmoid(logits); sums = [sum of binary cross-entropy terms, sum |p - t|, n] (loss = [0] / [2], mae = [1] / [2])"""
@@ -650,7 +662,10 @@ class LayerGraphEngine(object):
         if self.head == "dense":
             ops.sigmoid_bce_bwd(self.probs.reshape(-1), y_true.reshape(-1), self.dlogits.reshape(-1), grad_scale / self.probs.numel())
         else:
-            if seg_loss:
+            if seg_loss and self.loss_kind == ops.LOSS_WEIGHTED_DICE:
+                ns, nl = self._wdice_groups()
+                ops.weighted_dice_bwd(self.probs, y_true, self._gsums, self.sums, self.dlogits, ns, nl, grad_scale=grad_scale)
+            elif seg_loss:
                 ops.sigmoid_loss_bwd(self.probs, y_true, self.sums, self.dlogits, self.loss_kind, self.loss_param, smooth=1.0, grad_scale=grad_scale,
                                      weight=weight)
             if dprobs is not None:

@@ -298,7 +298,26 @@ def act_bwd(y, dy, dx, act, alpha=0.0):
 
 
 LOSS_KINDS = {"dice_coefficient_loss": 0, "binary_crossentropy_loss": 1, "dice_and_xent": 2, "focal_loss": 3, "vod_coefficient_loss": 4,
-              "double_dice_loss": 5}
+              "double_dice_loss": 5, "weighted_dice_coefficient_loss": 6}
+LOSS_WEIGHTED_DICE = 6          # not a kind of fmri_sigmoid_loss_bwd: per-(sample, label) sums, fmri_weighted_dice_fwd / _bwd
+WEIGHTED_DICE_SMOOTH = 1e-5     # reference metrics.py:39
+
+
+def weighted_dice_fwd(probs, y_true, gsums, sums, nsamples, n_labels, smooth=WEIGHTED_DICE_SMOOTH):
+    """per-(sample, label) Dice sums of probs / y_true [(n * vox + v) * L + l] into gsums [nsamples * L, 3] (float64, zeroed by the call);
+    sums[10] += sum of the groups' Dice coefficients, sums[11] += group count (reference metrics.py:39-51)"""
+    _need_cuda(probs, y_true, gsums, sums)
+    assert y_true.dtype == torch.uint8 and gsums.dtype == torch.float64 and sums.dtype == torch.float64 and sums.numel() >= 16
+    vox = probs.numel() // (nsamples * n_labels)
+    assert vox * nsamples * n_labels == probs.numel() == y_true.numel() and gsums.numel() >= 3 * nsamples * n_labels
+    check(lib().fmri_weighted_dice_fwd(_p(probs), _p(y_true), _p(gsums), _p(sums), nsamples, vox, n_labels, float(smooth), _s()), "fmri_weighted_dice_fwd")
+
+
+def weighted_dice_bwd(probs, y_true, gsums, sums, dlogits, nsamples, n_labels, smooth=WEIGHTED_DICE_SMOOTH, grad_scale=1.0):
+    _need_cuda(probs, y_true, gsums, sums, dlogits)
+    vox = probs.numel() // (nsamples * n_labels)
+    check(lib().fmri_weighted_dice_bwd(_p(probs), _p(y_true), _p(gsums), _p(sums), _p(dlogits), nsamples, vox, n_labels, float(smooth),
+                                       float(grad_scale), _s()), "fmri_weighted_dice_bwd")
 
 
 def sigmoid_loss_bwd(probs, y_true, sums, dlogits, kind, param=1.0, smooth=1.0, grad_scale=1.0, weight=None):
@@ -325,6 +344,8 @@ def loss_value_from_sums(s, kind, param=1.0, smooth=1.0):
         return float(s[9])
     if kind == 4:
         return -(I + smooth) / (Sy + Sp - I + smooth)
+    if kind == LOSS_WEIGHTED_DICE:
+        return -float(s[10]) / float(s[11])          # mean over the (sample, label) groups of the (all-reduced) per-group Dice
     return -dice + param * (2 * (Sp - I) + smooth) / ((n - Sy) + Sp + smooth)
 
 

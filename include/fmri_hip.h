@@ -153,6 +153,15 @@ int fmri_sigmoid_dice_bwd(const float* probs, const uint8_t* y_true, const doubl
  * 4 vod_coefficient_loss, 5 double_dice_loss (param = ratio). */
 int fmri_sigmoid_loss_bwd(const float* probs, const uint8_t* y_true, const double* sums, float* dlogits, int64_t n, int kind,
                           float param, float smooth, float grad_scale, fmri_stream_t stream);
+/* ---- weighted_dice_coefficient_loss — reference fetal_net/metrics.py:39-55 (values pinned by reference test/test_metrics.py:10-38):
+ * Dice per (sample, label) over the voxel axes with smooth = 1e-5, mean over the G = nsamples * L groups.  probs / y_true are indexed
+ * [(n * vox + v) * L + l] like the logits.  fwd: gsums [G][3] doubles (zeroed here) = sum y*p, sum y, sum p per group;
+ * sums[10] += sum_g (2 I_g + s) / (Sy_g + Sp_g + s), sums[11] += G (both additive over ranks: loss = -sums[10] / sums[11]).
+ * bwd: dlogits = grad_scale * dL/dp * p (1 - p) with the groups' own sums and the (possibly all-reduced) group count sums[11]. */
+int fmri_weighted_dice_fwd(const float* probs, const uint8_t* y_true, double* gsums, double* sums, int nsamples, int64_t vox, int L,
+                           float smooth, fmri_stream_t stream);
+int fmri_weighted_dice_bwd(const float* probs, const uint8_t* y_true, const double* gsums, const double* sums, float* dlogits,
+                           int nsamples, int64_t vox, int L, float smooth, float grad_scale, fmri_stream_t stream);
 /* the same with a per-voxel weight (device, n floats) on the cross-entropy term: sums[8] = sum(weight * xent); gradient kinds 1 and 2.
  * reference metrics.py:72-76 weighted_cross_entropy_loss and :89-95 dice_and_xent_mask (weight = exp(-distance_mask / sigma)) */
 int fmri_sigmoid_dice_fwd_weighted(const float* logits, const uint8_t* y_true, const float* weight, float* probs, double* sums, int64_t n,

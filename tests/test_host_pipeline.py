@@ -90,3 +90,30 @@ def test_flip_augmentation_median_and_resolution_round_trip():
     assert scaled["data"].shape == (16, 16, 16)
     with pytest.raises(Exception):
         predict_volume(vol, m, cfg, preprocess_method="nope")
+
+
+def test_resampling_steps_return_predictions_to_the_input_grid():
+    """the building blocks of VolumePipeline: every resampling undoes itself on a prediction (also on a stack of TTA variants)"""
+    from fetal_net.pipeline import Border, Box, Stage, VolumePipeline, Zoom
+    vol = _blob_volume((20, 24, 12), seed=3)
+    b = Border(3)
+    assert b.forward(vol).shape == (26, 30, 18) and b.forward(vol)[0, 0, 0] == vol.min()
+    np.testing.assert_array_equal(b.backward(b.forward(vol)), vol)
+    np.testing.assert_array_equal(b.backward(np.stack([b.forward(vol)] * 2)), np.stack([vol] * 2))
+    box = Box([2, 3, 1], [10, 20, 9], vol.shape)
+    back = box.backward(box.forward(vol))
+    assert back.shape == vol.shape and np.array_equal(back[2:10, 3:20, 1:9], vol[2:10, 3:20, 1:9]) and back[0].sum() == 0
+    assert box.backward(np.ones((3, 8, 17, 8))).shape == (3,) + vol.shape
+    z = Zoom([0.5, 0.5, 1.0], order_back=1)
+    assert z.forward(vol).shape == (10, 12, 12) and z.backward(z.forward(vol)).shape == vol.shape
+    with pytest.raises(ValueError):
+        Stage(None, {"patch_shape": [8, 8], "patch_depth": 4}, augment="rotate")
+    with pytest.raises(TypeError):
+        Stage(None, {"patch_shape": [8, 8], "patch_depth": 4, "preproc": "by_name"})
+    # a region of interest that touches the volume's border is clipped, not shifted
+    m = np.zeros(vol.shape, bool)
+    m[0:4, 10:14, 5:8] = True
+    roi = VolumePipeline(None, None).region_of_interest(m)
+    assert list(roi.start) == [0, 0, 0] and list(roi.end) == [20, 24, 12]
+    roi = VolumePipeline(None, None, roi_padding=(2, 2, 1)).region_of_interest(m)
+    assert list(roi.start) == [0, 8, 4] and list(roi.end) == [6, 16, 9]
