@@ -154,7 +154,8 @@ def cpu_baseline(budget_s=25.0):
                       "Keras/TF not installed" % (n, best, cands, ncpu)}
 
 
-TRAFFIC_PROFILE = os.path.join("profiles", "r02_pmc_traffic_per_step.json")
+TRAFFIC_PROFILE = os.path.join("profiles", "r03_pmc_traffic_per_step.json")
+MFMA_PROFILE = os.path.join("profiles", "r03_pmc_mfma.json")
 
 
 def kernel_source_hash():
@@ -194,6 +195,30 @@ def pmc_traffic(kernel_key):
             tot_b += (2.0 * v["fetch_kb"] + v["write_kb"]) * 1024.0
             calls += v["calls"]
     return ((tot_b / calls) if calls else None), stamp
+
+
+def pmc_mfma(kernel_key):
+    """MFMA utilisation of a kernel family from the committed counter pass (MFMA_PROFILE: SQ_VALU_MFMA_BUSY_CYCLES and GRBM_GUI_ACTIVE,
+    collected by tools/collect_profiles.sh in their own rocprofv3 --pmc run of this bench on one stream, summarised by tools/pmc_mfma.py):
+    matrix-pipe busy cycles / (active cycles x 1024 SIMDs) - a clock-independent figure next to the FLOP-derived fraction of the 2.5 PF peak,
+    which also carries clock / 2.4 GHz.  None when the file is missing or belongs to other kernel sources."""
+    path = os.path.join(ROOT, MFMA_PROFILE)
+    stamp = {"file": MFMA_PROFILE, "kernel_source_hash": None, "fresh": False}
+    if not os.path.exists(path):
+        return None, stamp
+    with open(path) as f:
+        d = json.load(f)
+    stamp["kernel_source_hash"] = d.get("_meta", {}).get("kernel_source_hash")
+    stamp["fresh"] = stamp["kernel_source_hash"] == kernel_source_hash()
+    if not stamp["fresh"]:
+        return None, stamp
+    busy = act = 0.0
+    for k, v in d.get("kernels", {}).items():
+        if k.startswith(kernel_key):
+            busy += v["mfma_busy_cycles_per_step"]
+            act += v["active_cycles_per_step"]
+    return ({"mfma_util": busy / (act * 1024.0), "mfma_busy_cycles_per_step": busy, "active_cycles_per_step": act,
+             "counters": "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs), exclusive launches"} if act else None), stamp
 
 
 def per_layer_table(eng, detail_ms, steps):
@@ -545,9 +570,10 @@ def main():
             t_ms, launches = per_step[dom]
             ach = flops / (t_ms * 1e-3) / 1e12
             traffic, stamp = pmc_traffic("k_conv_fwd_" if dom == "conv_fwd_mfma" else "k_conv_wgrad")   # every instantiation of the family
+            util, ustamp = pmc_mfma("k_conv_fwd_" if dom == "conv_fwd_mfma" else "k_conv_wgrad")
             r = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS,
                  "note": note,
-                 "traffic": traffic, "traffic_profile": stamp,
+                 "traffic": traffic, "traffic_profile": stamp, "mfma_util_pmc": util, "mfma_util_profile": ustamp,
                  "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, separate passes, FETCH_SIZE x2 corrected); null when the committed "
                                  "profile was collected on other kernel sources",
                  "algorithmic_flop_per_launch": flops / max(launches, 1), "launches_per_step": launches,

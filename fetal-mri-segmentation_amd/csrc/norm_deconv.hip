@@ -60,8 +60,7 @@ __global__ void k_norm_reduce_v(const T* __restrict__ x, double* __restrict__ ws
 #pragma unroll
     for (int k = 0; k < VEC; ++k) { red[0][threadIdx.x][k] = s[k]; red[1][threadIdx.x][k] = q[k]; }
     __syncthreads();
-    const int c = threadIdx.x;
-    if (c < C) {
+    for (int c = threadIdx.x; c < C; c += 256) {          // (C up to 512: 64 channel groups x 4 voxel lanes)
         double ds = 0, dq = 0;
         for (int l = 0; l < VL; ++l) { ds += red[0][l * CG + c / VEC][c % VEC]; dq += red[1][l * CG + c / VEC][c % VEC]; }
         const int gi = per_instance ? g : 0;
@@ -69,30 +68,39 @@ __global__ void k_norm_reduce_v(const T* __restrict__ x, double* __restrict__ ws
         atomicAdd(&ws[((int64_t)gi * C + c) * 2 + 1], dq);
     }
 }
-template <typename T, int VEC>
+// FROMX: the sign of the block's output is recomputed from x exactly as k_norm_apply formed it (z = fma(x, inv * gamma, beta - mean * inv *
+// gamma): the same operands in the same operations, so the same z bit for bit) instead of reading the stored y - one tensor read less in each
+// of the two backward passes (round 3; the normalisation passes are HBM-bound)
+template <typename T, int VEC, bool FROMX>
 __global__ void k_norm_bwd_reduce_v(const T* __restrict__ x, const T* __restrict__ y, const T* __restrict__ dy, const float* __restrict__ stats,
+                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                     double* __restrict__ ws, int64_t V, int C, int per_instance, int act, float alpha, int vchunk) {
     const int CG = C / VEC, VL = 256 / CG;
     const int cg = threadIdx.x % CG, vl = threadIdx.x / CG;
     const int g = blockIdx.z, gi = per_instance ? g : 0;
     const int64_t v0 = (int64_t)blockIdx.x * vchunk, v1 = min(V, v0 + vchunk);
-    float s[VEC], q[VEC], mean[VEC], inv[VEC];
+    float s[VEC], q[VEC], mean[VEC], inv[VEC], sc[VEC], sh[VEC];
 #pragma unroll
     for (int k = 0; k < VEC; ++k) {
         s[k] = q[k] = 0.f;
         mean[k] = stats[((int64_t)gi * C + cg * VEC + k) * 3];
         inv[k] = stats[((int64_t)gi * C + cg * VEC + k) * 3 + 1];
+        if constexpr (FROMX) {
+            sc[k] = inv[k] * gamma[cg * VEC + k];
+            sh[k] = fmaf(-mean[k], sc[k], beta[cg * VEC + k]);
+        }
     }
     const int64_t base = (int64_t)g * V * C + cg * VEC;
 #pragma unroll 4
     for (int64_t v = v0 + vl; v < v1; v += VL) {
         float xv[VEC], yv[VEC], dv[VEC];
         ldv<T, VEC>(x + base + v * C, xv);
-        ldv<T, VEC>(y + base + v * C, yv);
+        if constexpr (!FROMX) ldv<T, VEC>(y + base + v * C, yv);
         ldv<T, VEC>(dy + base + v * C, dv);
 #pragma unroll
         for (int k = 0; k < VEC; ++k) {
             float d = dv[k];
+            if constexpr (FROMX) yv[k] = fmaf(xv[k], sc[k], sh[k]);
             if (act == FMRI_ACT_RELU) d = yv[k] > 0.f ? d : 0.f;
             else if (act == FMRI_ACT_LEAKY) d = yv[k] > 0.f ? d : alpha * d;
             s[k] += d;
@@ -103,8 +111,7 @@ __global__ void k_norm_bwd_reduce_v(const T* __restrict__ x, const T* __restrict
 #pragma unroll
     for (int k = 0; k < VEC; ++k) { red[0][threadIdx.x][k] = s[k]; red[1][threadIdx.x][k] = q[k]; }
     __syncthreads();
-    const int c = threadIdx.x;
-    if (c < C) {
+    for (int c = threadIdx.x; c < C; c += 256) {
         double ds = 0, dq = 0;
         for (int l = 0; l < VL; ++l) { ds += red[0][l * CG + c / VEC][c % VEC]; dq += red[1][l * CG + c / VEC][c % VEC]; }
         atomicAdd(&ws[((int64_t)gi * C + c) * 2 + 0], ds);
@@ -124,7 +131,7 @@ static inline int norm_vchunk(int64_t V, int N, int per_instance, int C) {
 }
 static inline bool norm_vec_ok(int C, int dtype) {
     const int cg = C / 8;
-    return dtype == FMRI_BF16 && C % 8 == 0 && cg >= 1 && cg <= 32 && (cg & (cg - 1)) == 0;      // c = threadIdx.x < C needs C <= 256
+    return dtype == FMRI_BF16 && C % 8 == 0 && cg >= 1 && cg <= 64 && (cg & (cg - 1)) == 0;      // 256 threads = cg channel groups x 256 / cg voxel lanes
 }
 
 // stats[g][c] = {mean, 1/s, 1/sigma}: s = sqrt(var+eps) (batch norm, Keras) or sqrt(var)+eps (keras-contrib instance norm)
@@ -169,7 +176,7 @@ __global__ void k_norm_apply(const T* __restrict__ x, const float* __restrict__ 
                 const int c = cg * VEC + k;
                 const float* st = stats + ((int64_t)g * C + c) * 3;
                 sc[k] = st[1] * gamma[c];
-                sh[k] = beta[c] - st[0] * sc[k];
+                sh[k] = fmaf(-st[0], sc[k], beta[c]);        // one explicit fma: the backward recomputes this shift and must get the same bits
             }
             have_g = g;
             have_cg = cg;
@@ -190,6 +197,7 @@ __global__ void k_norm_apply(const T* __restrict__ x, const float* __restrict__ 
 // backward reduction: ws[g][c] += { sum dz, sum dz*xhat },  dz = dy * act'(y)
 template <typename T>
 __global__ void k_norm_bwd_reduce(const T* __restrict__ x, const T* __restrict__ y, const T* __restrict__ dy, const float* __restrict__ stats,
+                                  const float* __restrict__ gamma, const float* __restrict__ beta,
                                   double* __restrict__ ws, int64_t V, int C, int per_instance, int act, float alpha, int vchunk) {
     const int c = blockIdx.y * 64 + (threadIdx.x & 63);
     const int g = blockIdx.z;
@@ -200,10 +208,11 @@ __global__ void k_norm_bwd_reduce(const T* __restrict__ x, const T* __restrict__
     if (c < C) {
         const int gi = per_instance ? g : 0;
         const float mean = stats[((int64_t)gi * C + c) * 3], inv = stats[((int64_t)gi * C + c) * 3 + 1];
+        const float sc = beta ? inv * gamma[c] : 0.f, sh = beta ? fmaf(-mean, sc, beta[c]) : 0.f;
         const int64_t base = (int64_t)g * V * C + c;
         for (int64_t v = v0 + vl; v < v1; v += 4) {
             float d = to_f<T>(dy[base + v * C]);
-            const float yy = to_f<T>(y[base + v * C]);
+            const float yy = beta ? fmaf(to_f<T>(x[base + v * C]), sc, sh) : to_f<T>(y[base + v * C]);
             if (act == FMRI_ACT_RELU) d = yy > 0.f ? d : 0.f;
             else if (act == FMRI_ACT_LEAKY) d = yy > 0.f ? d : alpha * d;
             const float xh = (to_f<T>(x[base + v * C]) - mean) * inv;
@@ -236,12 +245,13 @@ __global__ void k_norm_bwd_params(const double* __restrict__ ws, float* __restri
 // coefficients a = gamma*inv, b = -gamma*inv*m2*invsig, c = -a*m1 - b*mean, kept in registers as in k_norm_apply
 template <typename T, int VEC>
 __global__ void k_norm_bwd_apply(const T* __restrict__ x, const T* __restrict__ y, const T* __restrict__ dy, const float* __restrict__ stats,
-                                 const float* __restrict__ gamma, const double* __restrict__ ws, T* __restrict__ dx, int64_t V, int C,
-                                 int per_instance, int act, float alpha, double M, int64_t total) {
+                                 const float* __restrict__ gamma, const float* __restrict__ beta, const double* __restrict__ ws,
+                                 T* __restrict__ dx, int64_t V, int C, int per_instance, int act, float alpha, double M, int64_t total) {
     const int CG = C / VEC;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const bool fixed = stride % CG == 0;
-    float ca[VEC], cb[VEC], cc[VEC];
+    const bool fromx = beta != nullptr;                 // sign of the output recomputed from x (see k_norm_bwd_reduce_v)
+    float ca[VEC], cb[VEC], cc[VEC], zs[VEC], zh[VEC];
     int have_g = -1, have_cg = -1;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += stride) {
         const int cg = (int)(i % CG);
@@ -257,17 +267,20 @@ __global__ void k_norm_bwd_apply(const T* __restrict__ x, const T* __restrict__ 
                 ca[k] = gamma[c] * inv;
                 cb[k] = -gamma[c] * inv * m2 * invsig;
                 cc[k] = -ca[k] * m1 - cb[k] * mean;
+                zs[k] = inv * gamma[c];
+                zh[k] = fromx ? fmaf(-mean, zs[k], beta[c]) : 0.f;
             }
             have_g = g;
             have_cg = cg;
         }
         float xv[VEC], yv[VEC], dv[VEC], o[VEC];
         ldv<T, VEC>(x + v * C + cg * VEC, xv);
-        ldv<T, VEC>(y + v * C + cg * VEC, yv);
+        if (!fromx) ldv<T, VEC>(y + v * C + cg * VEC, yv);
         ldv<T, VEC>(dy + v * C + cg * VEC, dv);
 #pragma unroll
         for (int k = 0; k < VEC; ++k) {
             float d = dv[k];
+            if (fromx) yv[k] = fmaf(xv[k], zs[k], zh[k]);
             if (act == FMRI_ACT_RELU) d = yv[k] > 0.f ? d : 0.f;
             else if (act == FMRI_ACT_LEAKY) d = yv[k] > 0.f ? d : alpha * d;
             o[k] = fmaf(ca[k], d, fmaf(cb[k], xv[k], cc[k]));
@@ -385,22 +398,26 @@ extern "C" int fmri_norm_act_fwd(const void* x, const float* gamma, const float*
     return FMRI_OK;
 }
 
-extern "C" int fmri_norm_act_bwd(const void* x, const void* y, const void* dy, const float* gamma, const float* stats, void* dx,
-                                 float* dgamma, float* dbeta, double* ws, int N, int64_t V, int C, int per_instance, int act,
-                                 float alpha, int dtype, fmri_stream_t stream) {
-    if (N <= 0 || V <= 0 || C <= 0 || !stats || !ws) return FMRI_E_SHAPE;
+static int norm_act_bwd_impl(const void* x, const void* y, const void* dy, const float* gamma, const float* beta, const float* stats, void* dx,
+                             float* dgamma, float* dbeta, double* ws, int N, int64_t V, int C, int per_instance, int act,
+                             float alpha, int dtype, fmri_stream_t stream) {
+    if (N <= 0 || V <= 0 || C <= 0 || !stats || !ws || (!y && !beta)) return FMRI_E_SHAPE;
     hipStream_t s = as_stream(stream);
     const int G = per_instance ? N : 1;
     k_zero_d<<<(G * C * 2 + 255) / 256, 256, 0, s>>>(ws, G * C * 2);
     const int vchunk = norm_vchunk(V, N, per_instance, C);
     dim3 grid((unsigned)ceil_div64(V, vchunk), (C + 63) / 64, N);
-    if (norm_vec_ok(C, dtype))
-        k_norm_bwd_reduce_v<bf16_t, 8><<<dim3(grid.x, 1, N), 256, 0, s>>>((const bf16_t*)x, (const bf16_t*)y, (const bf16_t*)dy, stats, ws, V, C,
-                                                                            per_instance, act, alpha, vchunk);
-    else if (dtype == FMRI_F32)
-        k_norm_bwd_reduce<float><<<grid, 256, 0, s>>>((const float*)x, (const float*)y, (const float*)dy, stats, ws, V, C, per_instance, act, alpha, vchunk);
+    if (norm_vec_ok(C, dtype)) {
+        if (beta)
+            k_norm_bwd_reduce_v<bf16_t, 8, true><<<dim3(grid.x, 1, N), 256, 0, s>>>((const bf16_t*)x, (const bf16_t*)y, (const bf16_t*)dy, stats, gamma,
+                                                                                      beta, ws, V, C, per_instance, act, alpha, vchunk);
+        else
+            k_norm_bwd_reduce_v<bf16_t, 8, false><<<dim3(grid.x, 1, N), 256, 0, s>>>((const bf16_t*)x, (const bf16_t*)y, (const bf16_t*)dy, stats, gamma,
+                                                                                       beta, ws, V, C, per_instance, act, alpha, vchunk);
+    } else if (dtype == FMRI_F32)
+        k_norm_bwd_reduce<float><<<grid, 256, 0, s>>>((const float*)x, (const float*)y, (const float*)dy, stats, gamma, beta, ws, V, C, per_instance, act, alpha, vchunk);
     else if (dtype == FMRI_BF16)
-        k_norm_bwd_reduce<bf16_t><<<grid, 256, 0, s>>>((const bf16_t*)x, (const bf16_t*)y, (const bf16_t*)dy, stats, ws, V, C, per_instance, act, alpha, vchunk);
+        k_norm_bwd_reduce<bf16_t><<<grid, 256, 0, s>>>((const bf16_t*)x, (const bf16_t*)y, (const bf16_t*)dy, stats, gamma, beta, ws, V, C, per_instance, act, alpha, vchunk);
     else return FMRI_E_DTYPE;
     if (dgamma && dbeta) k_norm_bwd_params<<<(C + 255) / 256, 256, 0, s>>>(ws, dgamma, dbeta, G, C);
     const double M = per_instance ? (double)V : (double)V * N;
@@ -408,11 +425,23 @@ extern "C" int fmri_norm_act_bwd(const void* x, const void* y, const void* dy, c
     const int64_t total = (int64_t)N * V * (C / vec);
     const int g2 = grid_for(total);
     if (dtype == FMRI_F32)
-        LAUNCH_TV(k_norm_bwd_apply, float, vec, g2, 256, s, (const float*)x, (const float*)y, (const float*)dy, stats, gamma, ws, (float*)dx, V, C, per_instance, act, alpha, M, total);
+        LAUNCH_TV(k_norm_bwd_apply, float, vec, g2, 256, s, (const float*)x, (const float*)y, (const float*)dy, stats, gamma, beta, ws, (float*)dx, V, C, per_instance, act, alpha, M, total);
     else
-        LAUNCH_TV(k_norm_bwd_apply, bf16_t, vec, g2, 256, s, (const bf16_t*)x, (const bf16_t*)y, (const bf16_t*)dy, stats, gamma, ws, (bf16_t*)dx, V, C, per_instance, act, alpha, M, total);
+        LAUNCH_TV(k_norm_bwd_apply, bf16_t, vec, g2, 256, s, (const bf16_t*)x, (const bf16_t*)y, (const bf16_t*)dy, stats, gamma, beta, ws, (bf16_t*)dx, V, C, per_instance, act, alpha, M, total);
     FMRI_LAUNCH_CHECK();
     return FMRI_OK;
+}
+extern "C" int fmri_norm_act_bwd(const void* x, const void* y, const void* dy, const float* gamma, const float* stats, void* dx,
+                                 float* dgamma, float* dbeta, double* ws, int N, int64_t V, int C, int per_instance, int act,
+                                 float alpha, int dtype, fmri_stream_t stream) {
+    if (!y) return FMRI_E_SHAPE;
+    return norm_act_bwd_impl(x, y, dy, gamma, nullptr, stats, dx, dgamma, dbeta, ws, N, V, C, per_instance, act, alpha, dtype, stream);
+}
+extern "C" int fmri_norm_act_bwd_x(const void* x, const void* dy, const float* gamma, const float* beta, const float* stats, void* dx,
+                                   float* dgamma, float* dbeta, double* ws, int N, int64_t V, int C, int per_instance, int act,
+                                   float alpha, int dtype, fmri_stream_t stream) {
+    if (!beta) return FMRI_E_SHAPE;
+    return norm_act_bwd_impl(x, nullptr, dy, gamma, beta, stats, dx, dgamma, dbeta, ws, N, V, C, per_instance, act, alpha, dtype, stream);
 }
 
 extern "C" int fmri_deconv3d_k2s2_fwd(const void* x, const void* w, const float* b, void* y, int N, int D, int H, int W, int Cin, int Cout,

@@ -45,6 +45,7 @@ SIGNATURES = {
     "fmri_upsample_nearest2x_bwd": [p, i32, i32, p, p, i32, i32, i32, i32, i32, i32, i32, p],
     "fmri_norm_act_fwd": [p, p, p, p, p, p, i32, i64, i32, i32, f32, i32, i32, f32, i32, p],
     "fmri_norm_act_bwd": [p, p, p, p, p, p, p, p, p, i32, i64, i32, i32, i32, f32, i32, p],
+    "fmri_norm_act_bwd_x": [p, p, p, p, p, p, p, p, p, i32, i64, i32, i32, i32, f32, i32, p],
     "fmri_deconv3d_k2s2_fwd": [p, p, p, p, i32, i32, i32, i32, i32, i32, i32, i32, p],
     "fmri_deconv3d_k2s2_bwd": [p, p, p, i32, i32, p, p, p, p, i32, i32, i32, i32, i32, i32, i32, i32, p],
     "fmri_conv3d_direct_fwd": [p, p, p, p, i32, i32, i32, i32, i32, i32, i32, i32, i32, f32, i32, p],

@@ -618,9 +618,10 @@ class UNetEngine:
         g = self.grad[name]
         if c.get("norm"):
             per, _ = self._norm_mode()
-            ops.norm_act_bwd(self._as_samples(self.pre[name]), self._as_samples(self.act[name]), self._as_samples(g),
+            # (beta given: the ReLU mask is recomputed from the pre-normalisation tensor, the block's output is not read)
+            ops.norm_act_bwd(self._as_samples(self.pre[name]), None, self._as_samples(g),
                              self.gb_view(name, "gamma"), self.nstats[name], self._as_samples(g), self.gb_view(name, "gamma", self.G),
-                             self.gb_view(name, "beta", self.G), self.norm_ws, per, act=ACT_RELU)
+                             self.gb_view(name, "beta", self.G), self.norm_ws, per, act=ACT_RELU, beta=self.gb_view(name, "beta"))
         def wgrad():
             if up0 and name in self.upcat_wgrad and self._use_upcat(name):
                 ops.conv3d_upcat_wgrad(src0, src1, g, self.w_view(name, self.G), self.b_view(name, self.G), self.dwc_scratch,

@@ -747,14 +747,14 @@ class LayerGraphEngine(object):
                 src = o["ins"][0]
                 if self.pad:
                     dg, dbt = self.dgp[name], self.dbetap[name]
-                    self._accum(src, lambda dst: ops.norm_act_bwd(self._smp(self._t(src)), self._smp(self.T[out]), self._smp(g), self.gp[name],
+                    self._accum(src, lambda dst: ops.norm_act_bwd(self._smp(self._t(src)), None, self._smp(g), self.gp[name],
                                                                   self.stats[name], self._smp(dst), dg, dbt, self.norm_ws,
-                                                                  1 if o["instance"] else 0, act=o["act"], alpha=LEAKY_ALPHA))
+                                                                  1 if o["instance"] else 0, act=o["act"], alpha=LEAKY_ALPHA, beta=self.betap[name]))
                     continue
-                self._accum(src, lambda dst: ops.norm_act_bwd(self._smp(self._t(src)), self._smp(self.T[out]), self._smp(g), self._v(name, "gamma"),
+                self._accum(src, lambda dst: ops.norm_act_bwd(self._smp(self._t(src)), None, self._smp(g), self._v(name, "gamma"),
                                                               self.stats[name], self._smp(dst), self._v(name, "gamma", self.G),
                                                               self._v(name, "beta", self.G), self.norm_ws,
-                                                              1 if o["instance"] else 0, act=o["act"], alpha=LEAKY_ALPHA))
+                                                              1 if o["instance"] else 0, act=o["act"], alpha=LEAKY_ALPHA, beta=self._v(name, "beta")))
             elif kind == "add":
                 for i in o["ins"]:
                     self._slice_into(i, g, 0)

@@ -212,10 +212,15 @@ def norm_act_fwd(x, gamma, beta, y, stats, ws, per_instance, eps=1e-3, eps_on_st
     return y
 
 
-def norm_act_bwd(x, y, dy, gamma, stats, dx, dgamma, dbeta, ws, per_instance, act=ACT_RELU, alpha=0.0):
-    _need_cuda(x, y, dy, gamma, stats, dx, dgamma, dbeta, ws)
+def norm_act_bwd(x, y, dy, gamma, stats, dx, dgamma, dbeta, ws, per_instance, act=ACT_RELU, alpha=0.0, beta=None):
+    """beta given: the sign of the block's output comes from x (recomputed exactly as the forward formed it), y is not read (may be None)"""
+    _need_cuda(x, y, dy, gamma, stats, dx, dgamma, dbeta, ws, beta)
     N, Cc = x.shape[0], x.shape[-1]
     V = x.numel() // (N * Cc)
+    if beta is not None:
+        check(lib().fmri_norm_act_bwd_x(_p(x), _p(dy), _p(gamma), _p(beta), _p(stats), _p(dx), _p(dgamma), _p(dbeta), _p(ws), N, V, Cc,
+                                        int(per_instance), act, float(alpha), dt(x), _s()), "fmri_norm_act_bwd_x")
+        return dx
     check(lib().fmri_norm_act_bwd(_p(x), _p(y), _p(dy), _p(gamma), _p(stats), _p(dx), _p(dgamma), _p(dbeta), _p(ws), N, V, Cc,
                                   int(per_instance), act, float(alpha), dt(x), _s()), "fmri_norm_act_bwd")
     return dx

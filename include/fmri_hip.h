@@ -197,6 +197,12 @@ int fmri_norm_act_fwd(const void* x, const float* gamma, const float* beta, void
 int fmri_norm_act_bwd(const void* x, const void* y, const void* dy, const float* gamma, const float* stats, void* dx, float* dgamma,
                       float* dbeta, double* ws, int N, int64_t V, int C, int per_instance, int act, float alpha, int dtype,
                       fmri_stream_t stream);
+/* the same without reading y: the sign of the block's output is recomputed from x, gamma, beta and the stored statistics with the very
+ * operations fmri_norm_act_fwd used (so it agrees with the stored y bit for bit) - each of the two HBM-bound backward passes reads two
+ * tensors instead of three. */
+int fmri_norm_act_bwd_x(const void* x, const void* dy, const float* gamma, const float* beta, const float* stats, void* dx, float* dgamma,
+                        float* dbeta, double* ws, int N, int64_t V, int C, int per_instance, int act, float alpha, int dtype,
+                        fmri_stream_t stream);
 
 /* ---- Deconvolution3D(filters, kernel_size=(2,2,2), strides=(2,2,2)) — reference unet.py:135.  x [N][D][H][W][Cin] ->
  * y [N][2D][2H][2W][Cout]; w [8 taps = ad*4+ah*2+aw][Cout][Cin] (dtype); planar: (1,2,2) taps 0..3 and D unchanged. */

@@ -368,9 +368,10 @@ def test_planar_pool_and_upsample(ops, dtype):
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("mode", ["batch", "instance"])
 @pytest.mark.parametrize("act", [1, 2])
-def test_norm_act_fwd_bwd(ops, dtype, mode, act):
+@pytest.mark.parametrize("C", [16, 512])          # 512: the widest layer of BASELINE configs[1] (64 channel groups x 4 voxel lanes per workgroup)
+def test_norm_act_fwd_bwd(ops, dtype, mode, act, C):
     from oracle import unet_oracle as O
-    N, D, H, W, C = 2, 4, 6, 8, 16
+    N, D, H, W = 2, 4, 6, 8
     alpha = 0.3
     x = rnd((N, D, H, W, C), 80, dtype, scale=1.5) + 0.3
     gamma = rnd((C,), 81, torch.float32) * 0.5 + 1.0
@@ -398,6 +399,12 @@ def test_norm_act_fwd_bwd(ops, dtype, mode, act):
     yr.backward(to_ncdhw(f64(dy)))
     tolb = (2e-4, 2e-5) if dtype == torch.float32 else (6e-3, 2e-3)
     assert_close(dx, to_ndhwc(xr.grad), *tolb, what="norm dx")
+    # the form that recomputes the sign of the output from x instead of reading y: the same operations as the forward, the same bits
+    dx2, dg2, db2 = torch.empty_like(x), torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+    ops.norm_act_bwd(x, None, dy, gamma, stats, dx2, dg2, db2, ws, per, act=act, alpha=alpha, beta=beta)
+    torch.cuda.synchronize()
+    assert torch.equal(dx2, dx), "norm backward from x differs from the one reading y: %g" % float((dx2.float() - dx.float()).abs().max())
+    assert_close(dg2, dg, 1e-6, 1e-6, what="norm dgamma (from x)")
     assert_close(dg, gr.grad, *tolb, what="norm dgamma")
     assert_close(db, br.grad, *tolb, what="norm dbeta")
 
