@@ -18,6 +18,9 @@ int conv3d_upcat_wgrad_mfma(const void*, int, const void*, int, const void*, flo
 int conv3d_fwd_mfma_ex(int, const void*, int, int, int, const void*, int, const void*, const float*, const void*, const void*, void*, int, int, int,
                        int, int, int, float, hipStream_t);
 
+int conv3d_upcat_wgrad_mfma_ex(const void*, int, const void*, int, const void*, float*, float*, float*, int, int, int, int, int, int, int, void*,
+                               int64_t, hipStream_t);
+int conv3d_fwd_mfma_res_b27(const void*, int, const void*, const float*, const void*, void*, int, int, int, int, int, int, float, hipStream_t);
 int conv3d_fwd_tail_ok(int C0, int Cout, int N, int D, int H, int W, int dtype);
 int conv3d_fwd_mfma_tail(const void*, int, const void*, const float*, void*, void*, const float*, const float*, float*, int, int, int, int, int, int,
                          float, hipStream_t);
@@ -237,6 +240,85 @@ int upcat_wgrad(const void* src0_low, int C0, const void* src1, int C1, const vo
                                    as_stream(stream));
 }
 }  // namespace
+
+// ---- Deconvolution3D(k 2, s 2) -> concatenate -> Conv3D folded into ONE parity-form convolution of the low-res tensor (round 3).
+// Output voxel 2g+p of the transposed conv is Wt[p] x[g] + bt; tap k of the following 3x3x3 conv at output voxel 2g+p therefore reads
+// low-res voxel g + floor((p+k-1)/2) through Wt[(p+k-1) mod 2] - the same two low-res neighbours per axis the nearest-upsample parity
+// form reads, with pre-MULTIPLIED filters W3[k] Wt[a] summed per (parity, neighbour) instead of pre-summed ones (the caller forms them).
+// The transposed conv's bias reaches an output voxel through the in-volume taps only: bias27 holds the effective bias per border class.
+namespace {
+// sums of dy per border class of the voxel: out [27][C] fp32 (zeroed by the caller), class = (cd*3 + ch)*3 + cw, c = 0 / 1 / 2 as in
+// FwdTail::bias27.  One workgroup per (n, d) plane, one thread per channel (channels beyond the block size in further rounds): the plane's
+// nine (ch, cw) classes are accumulated in registers - rows off the h faces contribute their two end voxels only, the interior class
+// (1, 1, 1) is never read: the caller gets it as (sum over all voxels) - (the 26 border classes) - and flushed with ONE atomic per class and
+// channel (the first version, a workgroup per row, spent 0.35 ms per launch on 4 M atomics into 27 x C addresses).
+template <typename T>
+__global__ void k_border_class_sums(const T* __restrict__ dy, float* __restrict__ out, int D, int H, int W, int C) {
+    const int plane = blockIdx.x;                     // n * D + d
+    const int d = plane % D;
+    const int cd = d == 0 ? 0 : (d == D - 1 ? 2 : 1);
+    const T* const base = dy + (int64_t)plane * H * W * C;
+    // 256 threads = G row groups x C channels (C <= 256 and a power of two), or one group striding over the channels; blockIdx.y cuts the
+    // rows further (the two d-face planes of a sample read every voxel)
+    const int G = (C <= 256 && 256 % C == 0) ? 256 / C : 1;
+    const int grp = G > 1 ? threadIdx.x / C : 0;
+    for (int c = G > 1 ? threadIdx.x % C : threadIdx.x; c < C; c += (G > 1 ? C : blockDim.x)) {
+        float acc[3][3] = {};
+        for (int h = blockIdx.y * G + grp; h < H; h += gridDim.y * G) {
+            const int ch = h == 0 ? 0 : (h == H - 1 ? 2 : 1);
+            const T* const row = base + (int64_t)h * W * C + c;
+            acc[ch][0] += to_f<T>(row[0]);
+            acc[ch][2] += to_f<T>(row[(int64_t)(W - 1) * C]);
+            if (cd != 1 || ch != 1) {
+                float m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f;
+                int w = 1;
+                for (; w + 3 < W - 1; w += 4) {
+                    m0 += to_f<T>(row[(int64_t)w * C]);
+                    m1 += to_f<T>(row[(int64_t)(w + 1) * C]);
+                    m2 += to_f<T>(row[(int64_t)(w + 2) * C]);
+                    m3 += to_f<T>(row[(int64_t)(w + 3) * C]);
+                }
+                for (; w < W - 1; ++w) m0 += to_f<T>(row[(int64_t)w * C]);
+                acc[ch][1] += (m0 + m1) + (m2 + m3);
+            }
+        }
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch)
+#pragma unroll
+            for (int cw = 0; cw < 3; ++cw)
+                if (!(cd == 1 && ch == 1 && cw == 1) && acc[ch][cw] != 0.f) atomicAdd(&out[((cd * 3 + ch) * 3 + cw) * C + c], acc[ch][cw]);
+    }
+}
+}  // namespace
+extern "C" int fmri_conv3d_upcat_fwd_bias27(const void* src0_low, int C0, const void* src1, int C1, const void* w_up_fwd, const void* w_skip_fwd,
+                                            const float* bias27, void* y, int N, int D, int H, int W, int Cout, int act, float alpha, int dtype,
+                                            fmri_stream_t stream) {
+    if (!src0_low || !src1 || !w_up_fwd || !w_skip_fwd || !bias27 || !y || N <= 0 || C1 <= 0) return FMRI_E_SHAPE;
+    if (!(upcat_ok(C0, C1, Cout, D, H, W, dtype, 0) & 1)) return FMRI_E_SHAPE;
+    if ((((uintptr_t)src0_low) | ((uintptr_t)src1) | ((uintptr_t)w_up_fwd) | ((uintptr_t)w_skip_fwd) | ((uintptr_t)y) | ((uintptr_t)bias27)) & 15) return FMRI_E_ALIGN;
+    int rc = conv3d_fwd_mfma_ex(1, src0_low, C0, 0, 0, nullptr, 0, w_up_fwd, nullptr, nullptr, nullptr, y, N, D / 2, H / 2, W / 2, Cout, FMRI_ACT_NONE, 0.f,
+                                as_stream(stream));
+    if (rc) return rc;
+    return conv3d_fwd_mfma_res_b27(src1, C1, w_skip_fwd, bias27, y, y, N, D, H, W, Cout, act, alpha, as_stream(stream));
+}
+extern "C" int fmri_conv3d_upcat_wgrad_parts(const void* src0_low, int C0, const void* src1, int C1, const void* dy, float* dw, float* db,
+                                             float* dwc, int N, int D, int H, int W, int Cout, int dtype, void* workspace, int64_t workspace_bytes,
+                                             fmri_stream_t stream) {
+    if (!src0_low || !dy || !dw || !dwc || N <= 0 || C1 <= 0 || !src1) return FMRI_E_SHAPE;
+    if (!(upcat_ok(C0, C1, Cout, D, H, W, dtype, 0) & 2)) return FMRI_E_SHAPE;
+    if ((((uintptr_t)src0_low) | ((uintptr_t)src1) | ((uintptr_t)dy)) & 15) return FMRI_E_ALIGN;
+    return conv3d_upcat_wgrad_mfma_ex(src0_low, C0, src1, C1, dy, dw, db, dwc, N, D, H, W, Cout, 0, 0, workspace, workspace_bytes, as_stream(stream));
+}
+extern "C" int fmri_border_class_sums(const void* dy, float* out27, int N, int D, int H, int W, int C, int dtype, fmri_stream_t stream) {
+    if (!dy || !out27 || N <= 0 || D < 2 || H < 2 || W < 2 || C <= 0) return FMRI_E_SHAPE;
+    hipStream_t s = as_stream(stream);
+    const dim3 grid(N * D, H >= 64 ? 8 : (H >= 16 ? 4 : 1));
+    if (dtype == FMRI_BF16) k_border_class_sums<bf16_t><<<grid, 256, 0, s>>>((const bf16_t*)dy, out27, D, H, W, C);
+    else if (dtype == FMRI_F32) k_border_class_sums<float><<<grid, 256, 0, s>>>((const float*)dy, out27, D, H, W, C);
+    else return FMRI_E_DTYPE;
+    FMRI_LAUNCH_CHECK();
+    return FMRI_OK;
+}
 
 extern "C" int fmri_conv3d_upcat_ok(int C0, int C1, int Cout, int D, int H, int W, int dtype) { return upcat_ok(C0, C1, Cout, D, H, W, dtype, 0); }
 extern "C" int fmri_conv3d_pack_up_weights(const float* w, int C0, int C1, int Cout, void* w_up_fwd, void* w_up_dgrad, void* w_skip_fwd,

@@ -137,6 +137,10 @@ struct FwdTail {
     const float* w1;
     const float* b1;
     float* logits;
+    // RES launches only: bias per BORDER CLASS of the output voxel, [27 = (cd*3 + ch)*3 + cw][Cout] fp32, c = 0 first voxel of the axis /
+    // 1 interior / 2 last voxel (round 3: Deconvolution3D folded into the following conv - the transposed conv's bias reaches an output
+    // voxel through the in-volume taps only, so the effective bias differs on the volume's faces, edges and corners); nullptr: `bias`
+    const float* bias27;
 };
 
 // MODE selects what the 3x3x3 machinery computes:
@@ -1047,6 +1051,31 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
                     acc[j][c][4 * gq + 3] = bv[c][gq].w;
                 }
     };
+    // RES with per-border-class bias (tail.bias27): accumulators of the tile `it` start from the bias of each lane's own output voxel.
+    // Interior tiles (most) take the interior class 13 for every lane; tiles on a face of the volume look the class up per voxel.
+    auto init_acc_b27 = [&](const FwdItem& it) {
+        const bool border = it.d0 == 0 || it.d0 + TD == D || it.h0 == 0 || it.h0 + TH == H || it.w0 == 0 || it.w0 + TW == W;
+#pragma unroll
+        for (int j = 0; j < JT; ++j) {
+            int cls = 13;
+            if (border) {
+                const int rt = JT * cw + j;
+                const int d = it.d0 + tile_d(rt), h = it.h0 + tile_h(rt, r), w = it.w0 + lane_w(r);
+                cls = ((d == 0 ? 0 : (d == D - 1 ? 2 : 1)) * 3 + (h == 0 ? 0 : (h == H - 1 ? 2 : 1))) * 3 + (w == 0 ? 0 : (w == W - 1 ? 2 : 1));
+            }
+            const float* const bp = tail.bias27 + (int64_t)cls * Cout + it.co0 + 4 * hk;
+#pragma unroll
+            for (int c = 0; c < NT; ++c)
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    const float4 b4 = *reinterpret_cast<const float4*>(bp + c * 32 + 8 * gq);
+                    acc[j][c][4 * gq] = b4.x;
+                    acc[j][c][4 * gq + 1] = b4.y;
+                    acc[j][c][4 * gq + 2] = b4.z;
+                    acc[j][c][4 * gq + 3] = b4.w;
+                }
+        }
+    };
     // lane r of a column tile: h-row r>>4, w rotated by HW mod 16 on the second row (conflict-free ds_read_b128 groups, see k_conv_fwd_mfma)
     int hv0[JT];
 #pragma unroll
@@ -1055,7 +1084,8 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
         hv0[j] = (tile_d(rt) * HH + tile_h(rt, r)) * HW + lane_w(r);
     }
     const int fa[2] = {swz64(r, hk), swz64(r, hk) ^ 32};
-    {
+    if (RES && tail.bias27) init_acc_b27(cur);
+    else {
         float4 bv0[NT][4];
         load_bias(cur.co0, bv0);
         init_acc(bv0);
@@ -1217,7 +1247,8 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            init_acc(bvn);
+            if (tail.bias27) init_acc_b27(has_next ? nxt : cur);
+            else init_acc(bvn);
         }
         if (!RES && cur.ch == nch - 1) {
             // bias is in the accumulators; activation, bf16, half-wave exchange, wave-private LDS transposition (16 KiB per consumer wave of
@@ -2140,7 +2171,7 @@ int conv3d_fwd_mfma_ex(int mode, const void* src0, int C0, int up0, int planar, 
                        const void* mask, const void* residual, void* y, int N, int D, int H, int W, int Cout, int act, float alpha,
                        hipStream_t st) {
     return conv3d_fwd_mfma_launch(mode, src0, C0, up0, planar, src1, C1, w, bias, mask, residual, y, N, D, H, W, Cout, act, alpha,
-                                  FwdTail{nullptr, nullptr, nullptr, nullptr}, st);
+                                  FwdTail{nullptr, nullptr, nullptr, nullptr, nullptr}, st);
 }
 // bit 0: the 2x2x2 max-pooled copy can be produced by the conv's epilogue, bit 1: the final 1x1x1 conv to one label can (plain 3-D
 // warp-specialised launch on the 4x8x16 tiling; the logits need the voxel's whole channel range in one workgroup: Cout == block width)
@@ -2155,7 +2186,15 @@ int conv3d_fwd_mfma_tail(const void* src0, int C0, const void* w, const float* b
     const int ok = conv3d_fwd_tail_ok(C0, Cout, N, D, H, W, FMRI_BF16);
     if ((pool && !(ok & 1)) || (logits && (!(ok & 2) || !w1 || !b1))) return FMRI_E_SHAPE;
     return conv3d_fwd_mfma_launch(0, src0, C0, 0, 0, nullptr, 0, w, bias, nullptr, nullptr, y, N, D, H, W, Cout, act, alpha,
-                                  FwdTail{(bf16_t*)pool, w1, b1, logits}, st);
+                                  FwdTail{(bf16_t*)pool, w1, b1, logits, nullptr}, st);
+}
+// plain 3-D conv whose epilogue adds `residual` and whose bias depends on the output voxel's border class (FwdTail::bias27); only the
+// warp-specialised kernel implements it
+int conv3d_fwd_mfma_res_b27(const void* src, int C, const void* w, const float* bias27, const void* residual, void* y, int N, int D, int H,
+                            int W, int Cout, int act, float alpha, hipStream_t st) {
+    if (!fwd_use_ws() || !bias27 || !residual) return FMRI_E_SHAPE;
+    return conv3d_fwd_mfma_launch(0, src, C, 0, 0, nullptr, 0, w, bias27 + 13 * (int64_t)Cout, nullptr, residual, y, N, D, H, W, Cout, act, alpha,
+                                  FwdTail{nullptr, nullptr, nullptr, nullptr, bias27}, st);
 }
 int conv3d_fwd_mfma(const void* src0, int C0, int up0, int planar, const void* src1, int C1, const void* w, const float* bias,
                     const void* mask, void* y, int N, int D, int H, int W, int Cout, int act, float alpha, hipStream_t st) {
@@ -2312,8 +2351,16 @@ __global__ void k_expand_up_wgrad(const float* __restrict__ dwc, float* __restri
 }
 }  // namespace
 
+int conv3d_upcat_wgrad_mfma_ex(const void* src0_low, int C0, const void* src1, int C1, const void* dy, float* dw, float* db, float* dwc, int N,
+                               int D, int H, int W, int Cout, int planar, int expand, void* workspace, int64_t workspace_bytes, hipStream_t st);
 int conv3d_upcat_wgrad_mfma(const void* src0_low, int C0, const void* src1, int C1, const void* dy, float* dw, float* db, float* dwc, int N,
                             int D, int H, int W, int Cout, int planar, void* workspace, int64_t workspace_bytes, hipStream_t st) {
+    return conv3d_upcat_wgrad_mfma_ex(src0_low, C0, src1, C1, dy, dw, db, dwc, N, D, H, W, Cout, planar, 1, workspace, workspace_bytes, st);
+}
+// expand = 0: the 64 parity-filter gradients stay in dwc [8][8][Cout][C0] for the caller (the folded transposed conv chains them through
+// its own weights); columns [0, C0) of dw are not touched
+int conv3d_upcat_wgrad_mfma_ex(const void* src0_low, int C0, const void* src1, int C1, const void* dy, float* dw, float* db, float* dwc, int N,
+                               int D, int H, int W, int Cout, int planar, int expand, void* workspace, int64_t workspace_bytes, hipStream_t st) {
     // D,H,W = output dims (planar: D = slices, not doubled).  1. parity-filter gradients over the low-res grid
     if (hipMemsetAsync(dwc, 0, (size_t)(planar ? 16 : 64) * Cout * C0 * sizeof(float), st) != hipSuccess) return FMRI_E_LAUNCH;
     {
@@ -2335,7 +2382,7 @@ int conv3d_upcat_wgrad_mfma(const void* src0_low, int C0, const void* src1, int 
         else k_conv_wgrad_mfma<1, true><<<combos * nslab, wg::NTHREADS, 0, st>>>(s, (const bf16_t*)dy, dwc, dbu, N, Dl, Hl, Wl, Cout, nslab, nullptr, C0);
     }
     // 2. fold them into the 27-tap gradient of the up-sampled input channels (columns [0, C0) of dw)
-    k_expand_up_wgrad<<<grid_for((int64_t)(planar ? 9 : 27) * Cout * C0, 256, 1024), 256, 0, st>>>(dwc, dw, Cout, C0, C0 + C1, planar);
+    if (expand) k_expand_up_wgrad<<<grid_for((int64_t)(planar ? 9 : 27) * Cout * C0, 256, 1024), 256, 0, st>>>(dwc, dw, Cout, C0, C0 + C1, planar);
     FMRI_LAUNCH_CHECK();
     if (C1 == 0) return FMRI_OK;
     // 3. the skip channels: plain weight gradient into columns [C0, C0+C1), bias gradient included

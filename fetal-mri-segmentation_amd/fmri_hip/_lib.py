@@ -66,6 +66,9 @@ SIGNATURES = {
     "fmri_tile_finalize": [p, p, p, p, i64, i32, p],
     "fmri_cast": [p, i32, p, i32, i64, p],
     "fmri_conv3d_upcat_ok": [i32, i32, i32, i32, i32, i32, i32],
+    "fmri_conv3d_upcat_fwd_bias27": [p, i32, p, i32, p, p, p, p, i32, i32, i32, i32, i32, i32, f32, i32, p],
+    "fmri_conv3d_upcat_wgrad_parts": [p, i32, p, i32, p, p, p, p, i32, i32, i32, i32, i32, i32, p, i64, p],
+    "fmri_border_class_sums": [p, p, i32, i32, i32, i32, i32, i32, p],
     "fmri_conv3d_pack_up_weights": [p, i32, i32, i32, p, p, p, p, i32, p],
     "fmri_conv3d_upcat_fwd": [p, i32, p, i32, p, p, p, p, i32, i32, i32, i32, i32, i32, f32, i32, p],
     "fmri_conv3d_upcat_dgrad": [p, i32, p, p, p, p, p, p, i32, i32, i32, i32, i32, i32, i32, p],

@@ -197,9 +197,42 @@ class UNetEngine:
                         Wd_["dw"] = torch.zeros((27, 4 * L["cout"], L["cin"]), dtype=torch.float32, device=dev)
                         Wd_["db"] = torch.zeros(4 * L["cout"], dtype=torch.float32, device=dev)
                     self.Wd2[u["name"]] = Wd_
+        # Deconvolution3D -> concatenate -> Conv3D FOLDED into one parity-form convolution of the low-res tensor (round 3; fmri_hip/deconv_fold.py,
+        # fmri_conv3d_upcat_fwd_bias27): the transposed conv's output is never materialised and the decoder 'a' conv does 8 instead of 27 taps
+        # on its up-sampled channels, exactly as in the UpSampling3D variant - with pre-MULTIPLIED instead of pre-summed filters.  Keyed by the
+        # 'a' conv's name.  FMRI_DECONV_FOLD=0 keeps the two-step form (transposed conv as one-tap parity form, then the plain 27-tap conv).
+        self.Wfd, self.fold = {}, None
+        if (not self.planar and self.dtype == torch.bfloat16 and p.norm is None and os.environ.get("FMRI_DECONV_FOLD", "1") != "0"
+                and os.environ.get("FMRI_FWD_WS", "1") != "0"):
+            from .deconv_fold import DeconvFold
+            for lv in p.dec:
+                a = lv[0]
+                if a["level"] not in p.up:
+                    continue
+                u = p.up[a["level"]]
+                Lu = self.layout[u["name"]]
+                D, H, W = p.level_dims(a["level"])
+                if Lu["cout"] == a["c_up"] and ops.conv3d_upcat_ok(Lu["cin"], a["c_skip"], a["cout"], D, H, W, self.dtype) == 3:
+                    if self.fold is None:
+                        self.fold = DeconvFold(dev)
+                    # weight GEMMs of the largest levels with bf16 operands (fp32 accumulation): 0.3 % relative error on filters that
+                    # are rounded to bf16 for the MFMA kernels anyway, 2.3x faster at 256 x 512 x 512 (tools/bench_fold.py); below
+                    # 2^25 multiply-adds per block fp32 is as fast
+                    F = dict(u=u["name"], cmid=Lu["cout"], cin=Lu["cin"], cs=a["c_skip"],
+                             gd=torch.bfloat16 if a["cout"] * Lu["cout"] * Lu["cin"] >= (1 << 25) else None,
+                             up_f=torch.empty((8, 8, a["cout"], Lu["cin"]), dtype=self.dtype, device=dev),
+                             sk_f=torch.empty((27, a["cout"], a["c_skip"]), dtype=self.dtype, device=dev), up_d=None, sk_d=None,
+                             bias27=torch.zeros((27, a["cout"]), dtype=torch.float32, device=dev))
+                    if self.training:
+                        F["up_d"] = torch.empty((8, 8, Lu["cin"], a["cout"]), dtype=self.dtype, device=dev)
+                        F["sk_d"] = torch.empty((27, a["c_skip"], a["cout"]), dtype=self.dtype, device=dev)
+                        F["s27"] = torch.zeros((27, a["cout"]), dtype=torch.float32, device=dev)
+                    self.Wfd[a["name"]] = F
+        self._folded_up = set(F["u"] for F in self.Wfd.values())          # transposed convs that no longer run on their own
         self.dwc_scratch = None
         need = [64 * self.layout[n]["cout"] * self.upcat[n][0] for n in self.upcat_wgrad] + \
-               [64 * self.layout[n]["cout"] * self.layout[n]["cin"] for n in self.Wdc]
+               [64 * self.layout[n]["cout"] * self.layout[n]["cin"] for n in self.Wdc] + \
+               [64 * self.layout[n]["cout"] * F["cin"] for n, F in self.Wfd.items()]
         if self.training and need:
             self.dwc_scratch = torch.empty(max(need), dtype=torch.float32, device=dev)
         self._par8 = torch.arange(8, device=dev)
@@ -380,14 +413,25 @@ class UNetEngine:
 
     def _repack(self, want):
         for name in self.Wf:
-            if want(name):
+            if want(name) and name not in self.Wfd:
                 ops.pack_weights(self.w_view(name), self.Wf[name], self.Wd.get(name))
+        for name, F in self.Wfd.items():
+            if not want(name):
+                continue
+            w3 = self.w_view(name)
+            weff, b27 = self.fold.effective(w3, self.w_view(F["u"]), self.b_view(name), self.b_view(F["u"]), F["cmid"], gemm_dtype=F["gd"])
+            F["up_f"].copy_(weff)
+            F["bias27"].copy_(b27)
+            F["sk_f"].copy_(w3[:, :, F["cmid"]:])
+            if F["up_d"] is not None:
+                F["up_d"].copy_(weff[:, self.fold.mirror].transpose(-1, -2))            # Wc[p][1 - t']^T (fmri_conv3d_pack_up_weights' w_up_dgrad)
+                F["sk_d"].copy_(w3[:, :, F["cmid"]:].flip(0).transpose(1, 2))           # tap-flipped transposed skip filters
         for name, W in self.Wup.items():
             if want(name):
                 c0, c1 = self.upcat[name]
                 ops.conv3d_pack_up_weights(self.w_view(name), c0, c1, W["up_f"], W["up_d"], W["sk_f"], W["sk_d"], planar=self.planar)
         for name, wt in self.Wt.items():
-            if not want(name):
+            if not want(name) or name in self._folded_up:
                 continue
             if name in self.Wd2:
                 Wd_, L = self.Wd2[name], self.layout[name]
@@ -445,7 +489,7 @@ class UNetEngine:
         for ld in range(p.depth - 1):
             A["pool_%d" % ld] = torch.empty(self._dims(ld + 1) + (p.enc[ld][1]["cout"],), dtype=dt, device=dev)
         for lv in p.dec:
-            if lv[0]["level"] in p.up:
+            if lv[0]["level"] in p.up and lv[0]["name"] not in self.Wfd:      # (a folded transposed conv's output never exists)
                 u = p.up[lv[0]["level"]]
                 A[u["name"]] = torch.empty(self._dims(u["level"]) + (u["cout"],), dtype=dt, device=dev)
             for c in lv:
@@ -469,7 +513,7 @@ class UNetEngine:
             a = lv[0]
             # gradient of the concatenated conv input; the parity form writes the up-sampled part straight at low resolution,
             # so only the skip channels remain
-            ccat = self.upcat[a["name"]][1] if self._use_upcat(a["name"]) else a["cin"]
+            ccat = self.upcat[a["name"]][1] if self._use_upcat(a["name"]) else (a["c_skip"] if a["name"] in self.Wfd else a["cin"])
             Gd["cat_%d" % a["level"]] = torch.empty(self._dims(a["level"]) + (ccat,), dtype=dt, device=dev)
         self.dlogits = torch.empty_like(self.logits)
         # scratch for the slab flush of the MFMA weight-gradient kernel (max over the layers of this plan)
@@ -561,7 +605,10 @@ class UNetEngine:
         for lv in p.dec:
             a, b = lv
             skip = A[p.enc[a["level"]][1]["name"]]
-            if a["level"] in p.up:
+            if a["name"] in self.Wfd:
+                F = self.Wfd[a["name"]]
+                ops.conv3d_upcat_fwd_bias27(h, skip, F["up_f"], F["sk_f"], F["bias27"], A[a["name"]], act=ACT_RELU)
+            elif a["level"] in p.up:
                 u = p.up[a["level"]]
                 if u["name"] in self.Wd2 and h.shape[1] % 4 == 0:
                     Wd_ = self.Wd2[u["name"]]
@@ -640,6 +687,37 @@ class UNetEngine:
         with torch.cuda.stream(self._wg_stream):
             wgrad()
 
+    def _folded_bwd(self, a, x_low, skip, cat, low):
+        """backward of the folded transposed conv + conv of decoder block `a`: G[a] holds dL/d(conv output).  Weight gradients (side
+        stream): parity-filter gradients from the MFMA kernel, chained through the transposed conv's weights by fmri_hip.deconv_fold;
+        input gradients: w.r.t. the low-res tensor (parity-form launch over the space-to-depth view of dy) and the skip tensor."""
+        name, F = a["name"], self.Wfd[a["name"]]
+        g = self.grad[name]
+
+        def wgrad():
+            Cout = a["cout"]
+            dwc = self.dwc_scratch[:64 * Cout * F["cin"]]
+            ops.conv3d_upcat_wgrad_parts(x_low, skip, g, self.w_view(name, self.G), self.b_view(name, self.G), dwc, workspace=self.wgrad_ws)
+            s27 = F["s27"]
+            s27.zero_()
+            ops.border_class_sums(g, s27)
+            s27[13] = self.b_view(name, self.G) - s27.sum(0)        # interior class = all voxels (the conv's bias gradient) - the 26 border classes
+            dw3u, dwt, dbt = self.fold.chain(dwc.view(8, 8, Cout, F["cin"]), self.w_view(name), self.w_view(F["u"]), self.b_view(F["u"]), F["cmid"], s27,
+                                             gemm_dtype=F["gd"])
+            self.w_view(name, self.G)[:, :, :F["cmid"]].add_(dw3u)
+            self.w_view(F["u"], self.G).add_(dwt)
+            self.b_view(F["u"], self.G).add_(dbt)
+            self._grad_ready(name)
+            self._grad_ready(F["u"])
+
+        if self._wg_stream is None:
+            wgrad()
+        else:
+            self._wg_stream.wait_stream(torch.cuda.current_stream(self.dev))
+            with torch.cuda.stream(self._wg_stream):
+                wgrad()
+        ops.conv3d_upcat_dgrad(g, F["up_d"], F["sk_d"], self._mask_of(low), None, self.grad[low], cat)
+
     def _mask_of(self, name):
         """ReLU mask tensor a consumer applies to the gradient of `name`'s output, or None when the block is normalised (its
         norm backward applies the activation derivative itself) or `name` is not a conv block."""
@@ -677,7 +755,9 @@ class UNetEngine:
             self._block_bwd(b, A[a["name"]], None, False)
             ops.conv3d_dgrad(Gd[b["name"]], self.Wd[b["name"]], Gd[a["name"]], mask=self._mask_of(a["name"]), planar=self.planar)
             cat = Gd["cat_%d" % ld]
-            if ld in p.up:
+            if a["name"] in self.Wfd:
+                self._folded_bwd(a, A[low], skip, cat, low)
+            elif ld in p.up:
                 u = p.up[ld]
                 self._block_bwd(a, A[u["name"]], skip, False)
                 ops.conv3d_dgrad(Gd[a["name"]], self.Wd[a["name"]], cat, planar=self.planar)

@@ -462,6 +462,37 @@ def conv3d_upcat_wgrad(src0_low, src1, dy, dw, db, dwc_scratch, workspace=None, 
           "fmri_conv3d_upcat_wgrad")
 
 
+# ---- Deconvolution3D -> concatenate -> Conv3D folded into one parity-form convolution (fmri_hip.deconv_fold holds the weight algebra)
+def conv3d_upcat_fwd_bias27(src0_low, src1, w_up_f, w_sk_f, bias27, y, act=ACT_RELU, alpha=0.0):
+    """as conv3d_upcat_fwd with the effective bias per border class of the output voxel: bias27 [27, Cout] fp32"""
+    _need_cuda(src0_low, src1, w_up_f, w_sk_f, bias27, y)
+    N, D, H, W, Cout = y.shape
+    assert bias27.dtype == torch.float32 and tuple(bias27.shape) == (27, Cout) and bias27.is_contiguous()
+    check(lib().fmri_conv3d_upcat_fwd_bias27(_p(src0_low), src0_low.shape[-1], _p(src1), src1.shape[-1], _p(w_up_f), _p(w_sk_f), _p(bias27), _p(y),
+                                             N, D, H, W, Cout, act, float(alpha), dt(y), _s()), "fmri_conv3d_upcat_fwd_bias27")
+    return y
+
+
+def conv3d_upcat_wgrad_parts(src0_low, src1, dy, dw, db, dwc, workspace=None):
+    """parity-filter gradients into dwc [8, 8, Cout, C0] fp32 (zeroed by the call), skip columns of dw [27, Cout, C0 + C1] and db accumulated"""
+    _need_cuda(src0_low, src1, dy, dw, db, dwc, workspace)
+    N, D, H, W, Cout = dy.shape
+    C0, C1 = src0_low.shape[-1], src1.shape[-1]
+    assert dwc.dtype == torch.float32 and dwc.numel() >= 64 * Cout * C0 and tuple(dw.shape) == (27, Cout, C0 + C1)
+    nws = 0 if workspace is None else workspace.numel() * workspace.element_size()
+    check(lib().fmri_conv3d_upcat_wgrad_parts(_p(src0_low), C0, _p(src1), C1, _p(dy), _p(dw), _p(db), _p(dwc), N, D, H, W, Cout, dt(dy), _p(workspace),
+                                              nws, _s()), "fmri_conv3d_upcat_wgrad_parts")
+
+
+def border_class_sums(dy, out27):
+    """out27 [27, C] fp32 += per-border-class sums of dy [N, D, H, W, C]; the interior class (row 13) is left untouched"""
+    _need_cuda(dy, out27)
+    N, D, H, W, C = dy.shape
+    assert out27.dtype == torch.float32 and tuple(out27.shape) == (27, C) and out27.is_contiguous()
+    check(lib().fmri_border_class_sums(_p(dy), _p(out27), N, D, H, W, C, dt(dy), _s()), "fmri_border_class_sums")
+    return out27
+
+
 # ---------------------------------------------------------------------------------------------------- post-processing (fetal_net.postprocess)
 def gaussian_filter_f64(vol, sigma, truncate=4.0):
     """scipy.ndimage.gaussian_filter(vol, sigma) (order 0, mode 'reflect') of a float64 device volume [X,Y,Z]: three separable passes with

@@ -80,6 +80,25 @@ int fmri_conv3d_wgrad(const void* src0, int C0, int up0, const void* src1, int C
 /* bytes of workspace fmri_conv3d_wgrad can use for this shape (0: the shape does not take the slab path) */
 int64_t fmri_conv3d_wgrad_workspace_bytes(int C0, int C1, int Cout, int N, int D, int H, int W, int dtype, int planar);
 
+/* ---- Deconvolution3D(filters = C, k 2, s 2) -> concatenate([up, skip]) -> Conv3D(3x3x3) - reference unet.py:132-138, :61, :102 with
+ * deconvolution=True - folded into ONE parity-form convolution of the LOW-res tensor (round 3).  Output voxel 2g+p of the transposed conv
+ * is Wt[p] x[g] + bt, so tap k of the following conv at output voxel 2g+p reads low-res voxel g + floor((p+k-1)/2) through Wt[(p+k-1) mod 2]:
+ * the two low-res neighbours per axis of the nearest-upsample parity form, with pre-MULTIPLIED filters sum_k W3[k] Wt[a(p,k)] per (parity,
+ * neighbour) in the w_up_fwd / w_up_dgrad layouts of fmri_conv3d_pack_up_weights (the caller forms them: 216 small GEMMs per layer and step).
+ * The transposed conv's bias reaches an output voxel through the in-volume taps only: bias27 [27 = (cd*3+ch)*3+cw][Cout] fp32 is the
+ * effective bias per border class of the OUTPUT voxel (c = 0 first voxel of the axis, 1 interior, 2 last).  D,H,W = output dims. */
+int fmri_conv3d_upcat_fwd_bias27(const void* src0_low, int C0, const void* src1, int C1, const void* w_up_fwd, const void* w_skip_fwd,
+                                 const float* bias27, void* y, int N, int D, int H, int W, int Cout, int act, float alpha, int dtype,
+                                 fmri_stream_t stream);
+/* weight gradient in parts: the 64 parity-filter gradients stay in dwc [8][8][Cout][C0] fp32 (zeroed here) for the caller to chain through
+ * the transposed conv's weights; the skip columns [C0, C0+C1) of dw [27][Cout][C0+C1] and db (= sum of dy) are accumulated as usual. */
+int fmri_conv3d_upcat_wgrad_parts(const void* src0_low, int C0, const void* src1, int C1, const void* dy, float* dw, float* db, float* dwc,
+                                  int N, int D, int H, int W, int Cout, int dtype, void* workspace, int64_t workspace_bytes,
+                                  fmri_stream_t stream);
+/* out27 [27][C] fp32 (ACCUMULATED, caller zeroes) += sum of dy [N][D][H][W][C] over the voxels of each border class EXCEPT the interior
+ * class 13, which is left untouched (it is the sum over all voxels minus the 26 others): the bias gradient of the folded transposed conv. */
+int fmri_border_class_sums(const void* dy, float* out27, int N, int D, int H, int W, int C, int dtype, fmri_stream_t stream);
+
 /* ---- [nearest_up2(src0) | src1] -> Conv3D(3x3x3) without the redundant taps (reference unet.py:132-138 UpSampling3D, :61
  * concatenate, :102 Conv3D).  Output voxel 2g+p of the up-sampled source only sees low-res voxels {g-1,g} (p = 0) or {g,g+1}
  * (p = 1) per axis with pre-summed weights: 8 parity classes x 8 taps on the LOW-res tensor instead of 27 taps on 8x the voxels.
