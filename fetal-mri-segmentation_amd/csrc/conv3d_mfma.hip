@@ -626,14 +626,27 @@ __global__ void __launch_bounds__(fw::NTHREADS)
 k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ bias, const bf16_t* __restrict__ mask,
               const bf16_t* residual, bf16_t* y, int N, int D, int H, int W, int Cout, int act, float alpha, FwdTail tail) {
     constexpr int TD = fw::TD, TH = fw::TH, TW = fw::TW;
-    constexpr int HD = TD + 2, HH = TH + 2, HW = TW + 2, HVOX = HD * HH * HW;
-    constexpr int H_INSTR = (HVOX * 4 + 63) / 64, HALO_BYTES = H_INSTR * 1024;
     static_assert(!(RES && MODE != 0), "unsupported combination");
     constexpr bool PAR = MODE != 0;
+    // TIGHT (round 3; the 3-D parity modes): a parity class reads, per axis, only the low-res voxels {g-1, g} or {g, g+1} - a
+    // (TD+1) x (TH+1) x (TW+1) box whose origin depends on the parity, not the 6 x 10 x 18 box of the 3-tap conv: 765 instead of 1080 rows,
+    // 48 instead of 68 LDS-DMA instructions per chunk.  These launches are bound by their producers' DMA issue (7.7 instructions per wave
+    // and 32-MFMA phase): the matrix pipe was 0.38-0.48 busy on them (profiles/r03_pmc_mfma.json).
+    constexpr bool TIGHT = PAR && !PL;
+    constexpr int HD = TIGHT ? TD + 1 : TD + 2, HH = TIGHT ? TH + 1 : TH + 2, HW = TIGHT ? TW + 1 : TW + 2, HVOX = HD * HH * HW;
+    constexpr int H_INSTR = (HVOX * 4 + 63) / 64, HALO_BYTES = H_INSTR * 1024;
+    // the two halo slots: back to back, or - TIGHT, where a slot (48 KiB) is smaller than the staged tile (64 KiB) - with a 16 KiB gap between
+    // them that the stage of either slot extends into: stage(slot) = [slot * HALO_BYTES, + 64 KiB) covers slot 0 + gap, resp. gap + slot 1
+    constexpr int STAGE_BYTES = 4 * 32 * 4 * 64 * 2 > 4 * 32 * 64 * 4 ? 4 * 32 * 4 * 64 * 2 : 4 * 32 * 64 * 4;
+    constexpr int HALO_STRIDE = TIGHT ? STAGE_BYTES : HALO_BYTES;
+    constexpr int HALO_SPAN = HALO_STRIDE + HALO_BYTES;          // bytes of the halo / stage area
     constexpr int BN = 32 * NT;
     constexpr int NKW = PAR ? 2 : 3;
-    constexpr int FILT_BYTES = 3 * BN * 64;
-    constexpr int F_INSTR = NKW * BN * 64 / 1024;        // 12 / 6 (8 / 4 in the up modes)
+    // TIGHT also has LDS to spare (2 x 48 + 16 KiB of halo / stage): a phase covers RPP = 2 (kd', kh') filter rows - 64 instead of 32 MFMAs
+    // per wave and barrier, 2 phases per chunk - with 16 KiB filter slots (BN = 64)
+    constexpr int RPP = TIGHT ? 2 : 1;                   // (kd, kh) filter rows per phase
+    constexpr int FILT_BYTES = (RPP * NKW > 3 ? RPP * NKW : 3) * BN * 64;
+    constexpr int F_INSTR = RPP * NKW * BN * 64 / 1024;  // 12 / 6 (8 / 4 in the planar up modes, 16 / 8 in the 3-D ones)
     constexpr int DW = 4;                                // DMA (producer) waves = MFMA (consumer) waves
     constexpr int JT = 4;                                // column tiles per consumer wave
     constexpr int F_PER_WAVE = (F_INSTR + DW - 1) / DW;  // 3 / 2 (2 / 1)
@@ -642,7 +655,9 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
     constexpr int H_I0 = PL ? 11 : 0, H_I1 = PL ? 57 : H_INSTR;
     constexpr int NPIECE = (H_I1 - H_I0 + DW - 1) / DW;  // 17 (12)
     constexpr int NPAR = PL ? 4 : 8;
-    constexpr int NPH = PAR ? (PL ? 2 : 4) : (PL ? 3 : 9);
+    constexpr int NROW = PAR ? (PL ? 2 : 4) : (PL ? 3 : 9);       // (kd, kh) filter rows per chunk
+    constexpr int NPH = NROW / RPP;                                // phases per chunk
+    static_assert(NPH * RPP == NROW, "rows per phase");
     constexpr int PH0 = PL ? 3 : 0;
     constexpr bool ASY = ASYNC && !RES && !PL && MODE == 0;
     // the producers drain a staged tile in DP parts, one per phase, in phases 0 .. DP-1 of the next tile's first item (one part fits a
@@ -650,8 +665,10 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
     // than the synchronous epilogue); the halo pieces of that item's successor follow in phases DP .. NPH-2
     constexpr int DP = ASY ? 4 : 0;
     static_assert(!ASY || NPH >= DP + 3, "asynchronous epilogue: phases DP .. NPH-2 carry the halo pieces");
-    static_assert(4 * 32 * JT * BN * 2 <= HALO_BYTES && 4 * 32 * BN * 4 <= HALO_BYTES, "epilogue staging must fit the consumed halo slot");
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * HALO_BYTES + 2 * FILT_BYTES];
+    static_assert(4 * 32 * JT * BN * 2 <= (TIGHT ? STAGE_BYTES : HALO_BYTES) && 4 * 32 * BN * 4 <= (TIGHT ? STAGE_BYTES : HALO_BYTES),
+                  "epilogue staging must fit the consumed halo slot (+ gap)");
+    static_assert(!TIGHT || HALO_BYTES + STAGE_BYTES - HALO_BYTES <= HALO_STRIDE, "stage of slot 0 must end where slot 1 begins");
+    __shared__ __attribute__((aligned(16))) unsigned char lds[HALO_SPAN + 2 * FILT_BYTES];
 
     const int Cin = s.C0 + s.C1;
     const int kpc = MODE == 2 ? (s.C0 >> 5) : 1;
@@ -666,7 +683,7 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
     const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
     const int r = lane & 31, hk = lane >> 5;
     const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr(lds));
-    const unsigned ldsf0 = lds0 + 2 * HALO_BYTES;
+    const unsigned ldsf0 = lds0 + HALO_SPAN;
 
     auto decode = [&](int pair, int ch) {
         FwdItem it;
@@ -854,8 +871,8 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
             int64_t slab;
             int koff;
             if constexpr (MODE == 0) { slab = PH0 + pl; koff = it.ch << 5; }
-            else if constexpr (MODE == 1) { slab = it.par * NPH + pl; koff = it.ch << 5; }
-            else { slab = (it.ch / kpc) * NPH + pl; koff = (it.ch % kpc) << 5; }
+            else if constexpr (MODE == 1) { slab = it.par * NROW + pl * RPP; koff = it.ch << 5; }
+            else { slab = (it.ch / kpc) * NROW + pl * RPP; koff = (it.ch % kpc) << 5; }
             const bf16_t* const base = wt + ((slab * NKW * Cout + it.co0) * Krow + koff);
 #pragma unroll
             for (int k = 0; k < F_PER_WAVE; ++k)
@@ -864,7 +881,12 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
         };
         const bf16_t* hp[NPIECE];
         auto halo_src = [&](const FwdItem& it, int pk) -> const bf16_t* {
-            const int gd = it.d0 - 1 + (pk & 15), gh = it.h0 - 1 + ((pk >> 4) & 15), gw = it.w0 - 1 + ((pk >> 8) & 31);
+            int od = 0, oh = 0, ow = 0;                            // TIGHT: the box starts at g - 1 + (parity of the taps) per axis
+            if constexpr (TIGHT) {
+                const int tp = MODE == 1 ? it.par : (NPAR - 1) - it.ch / kpc;
+                od = tp >> 2; oh = (tp >> 1) & 1; ow = tp & 1;
+            }
+            const int gd = it.d0 - 1 + od + (pk & 15), gh = it.h0 - 1 + oh + ((pk >> 4) & 15), gw = it.w0 - 1 + ow + ((pk >> 8) & 31);
             const int ls = (pk >> 13) & 3;
             const bool ok = (pk >> 15) && (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W;
             if constexpr (MODE == 2) {
@@ -894,7 +916,7 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
             // every wave issues exactly NPIECE instructions per chunk (the counted s_waitcnt below relies on it): the few past the last live
             // instruction copy zeros into the dead rows behind it
             const bool dead = instr >= H_I1;
-            dma16(dead ? (const void*)g_zero_page : (const void*)hp[ph], __builtin_amdgcn_readfirstlane(lds0 + slot * HALO_BYTES + instr * 1024));
+            dma16(dead ? (const void*)g_zero_page : (const void*)hp[ph], __builtin_amdgcn_readfirstlane(lds0 + slot * HALO_STRIDE + instr * 1024));
         };
         // Halo pieces of the NEXT chunk issued in phase pl: spread over the first NPH-1 phases (all of them when a chunk has one phase
         // only... it has at least two), so that the last phase's wait - everything landed - finds them a phase old.
@@ -1124,32 +1146,34 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
             kw0 = 0;
             if constexpr (!PAR) return (((PH0 + pl) / 3) * HH + ((PH0 + pl) % 3)) * HW;
             else {
+                if constexpr (TIGHT) return pl * HH * HW;        // phase pl = filter rows (kd' = pl, kh' = 0, 1); the parity is in the box's origin
                 const int p = MODE == 1 ? it.par : (NPAR - 1) - it.ch / kpc;
                 kw0 = p & 1;
                 if constexpr (PL) return (HH + pl + ((p >> 1) & 1)) * HW;
                 else return (((pl >> 1) + (p >> 2)) * HH + ((pl & 1) + ((p >> 1) & 1))) * HW;
             }
         };
-        constexpr int NST = NKW * 2;
+        constexpr int NST = RPP * NKW * 2;         // steps of a phase: (filter row, kw, k-step)
         // One wave per SIMD feeds the MFMA pipe alone: the fragments of step st+1 (a (kw, k-step) pair) are requested before the MFMAs of
         // step st are issued, into the other half of a double register set, threaded between those MFMAs (left to the compiler the reads
         // sat right in front of their MFMAs).  The pipeline runs ACROSS the phase barrier inside a tile: once the fragments of a phase's
         // last step are in registers this wave is done reading the rings, so it passes the next phase's barrier BEFORE issuing that step's
         // MFMAs and requests the next phase's first fragments under them - only the first phase of a tile starts with an exposed LDS latency.
         auto load_a = [&](const unsigned char* lfp, int st, int buf) {
-            const int kw = st >> 1, ks = st & 1;
+            const int t = st >> 1, ks = st & 1;          // t = filter row of the phase * NKW + kw: the slab holds them in this order
 #pragma unroll
-            for (int c = 0; c < NT; ++c) fa_[buf][c] = *reinterpret_cast<const bf16x8_t*>(lfp + fa[ks] + (kw * BN + c * 32) * 64);
+            for (int c = 0; c < NT; ++c) fa_[buf][c] = *reinterpret_cast<const bf16x8_t*>(lfp + fa[ks] + (t * BN + c * 32) * 64);
         };
         auto load_b = [&](const unsigned char* lhp, int hoffp, int kw0p, int st, int buf, int j) {
-            const int kw = st >> 1, ks = st & 1;
-            fb_[buf][j] = *reinterpret_cast<const bf16x8_t*>(lhp + (swz64(hv0[j] + hoffp + kw + kw0p, hk) ^ (ks << 5)));
+            const int t = st >> 1, ks = st & 1;
+            const int kw = t % NKW, row = t / NKW;       // (row > 0 only with RPP = 2: the phase's second filter row = the next h-row of the halo)
+            fb_[buf][j] = *reinterpret_cast<const bf16x8_t*>(lhp + (swz64(hv0[j] + hoffp + row * HW + kw + kw0p, hk) ^ (ks << 5)));
         };
 #pragma unroll
         for (int pl = 0; pl < NPH; ++pl, ++g) {
             PROF_T(c0);
-            const unsigned char* const lh = lds + hb * HALO_BYTES;
-            const unsigned char* const lf = lds + 2 * HALO_BYTES + (g & 1) * FILT_BYTES;
+            const unsigned char* const lh = lds + hb * HALO_STRIDE;
+            const unsigned char* const lf = lds + HALO_SPAN + (g & 1) * FILT_BYTES;
             int kw0;
             const int hoff = phase_hoff(cur, pl, kw0);
             if (pl == 0 && cur.ch == 0) {          // first phase of a tile: nothing was primed across the epilogue
@@ -1178,9 +1202,9 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
                 int hoffn = hoff, kw0n = kw0, stn = st + 1;
                 if (last) {
                     stn = 0;
-                    lfn = lds + 2 * HALO_BYTES + ((g + 1) & 1) * FILT_BYTES;
+                    lfn = lds + HALO_SPAN + ((g + 1) & 1) * FILT_BYTES;
                     if (pl + 1 < NPH) hoffn = phase_hoff(cur, pl + 1, kw0n);
-                    else { hoffn = phase_hoff(nxt, 0, kw0n); lhn = lds + (hb ^ 1) * HALO_BYTES; }
+                    else { hoffn = phase_hoff(nxt, 0, kw0n); lhn = lds + (hb ^ 1) * HALO_STRIDE; }
                 }
                 if (chain) {
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this phase's last fragments are in registers: done with the rings

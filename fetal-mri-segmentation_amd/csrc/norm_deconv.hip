@@ -126,6 +126,14 @@ static inline int norm_vchunk(int64_t V, int N, int per_instance, int C) {
     int64_t c = per_instance ? (V + 511) / 512 : (V * (int64_t)N + 1023) / 1024;
     const int64_t floor_c = (65536 + C - 1) / C;               // and at least ~64 K elements per workgroup: below that its LDS reduction
     if (c < floor_c) c = floor_c;                              // and atomics outweigh the loads (8 x 32 x 64 x 128 x 32: 4096 small workgroups ran 30 % slower)
+    // ... unless that leaves the chip mostly empty: the 8x16x16 level of BASELINE configs[1] (4 x 2048 voxels x 256 / 512 channels) ran on 16-32
+    // workgroups of 128 serial iterations each - 70 us per call for 4-8 MB (rocprofv3, round 3).  Aim at >= 256 workgroups, 64 voxels or more each.
+    const int64_t total = per_instance ? V : V * (int64_t)N;
+    if ((total + c - 1) / c * (per_instance ? N : 1) < 256) {
+        c = (total * (per_instance ? N : 1) + 255) / 256;
+        c = ((c + 63) / 64) * 64;
+        return (int)(c < 64 ? 64 : (c > 4096 ? 4096 : c));
+    }
     c = ((c + 255) / 256) * 256;
     return (int)(c < 512 ? 512 : (c > 4096 ? 4096 : c));
 }

@@ -33,5 +33,6 @@ for name, N, V, C, inst in (("unet level 0, instance", 4, 64 * 128 * 128, 64, 1)
 
     tf = t(lambda: ops.norm_act_fwd(x, gamma, beta, y, stats, ws, inst, eps=1e-3, eps_on_std=bool(inst), act=2, alpha=0.3))
     tb = t(lambda: ops.norm_act_bwd(x, y, dy, gamma, stats, dx, dg, db, ws, inst, act=2, alpha=0.3))
-    print("%-36s %6.1f MB  fwd %.3f ms = %.2f TB/s (3 tensor passes)   bwd %.3f ms = %.2f TB/s (7 tensor passes)" % (
-        name, nbytes / 1e6, tf * 1e3, 3 * nbytes / tf / 1e12, tb * 1e3, 7 * nbytes / tb / 1e12))
+    tx = t(lambda: ops.norm_act_bwd(x, None, dy, gamma, stats, dx, dg, db, ws, inst, act=2, alpha=0.3, beta=beta))
+    print("%-36s %6.1f MB  fwd %.3f ms = %.2f TB/s (3 tensor passes)   bwd %.3f ms = %.2f TB/s (7 tensor passes)   bwd without y %.3f ms = %.2f TB/s (5 passes)" % (
+        name, nbytes / 1e6, tf * 1e3, 3 * nbytes / tf / 1e12, tb * 1e3, 7 * nbytes / tb / 1e12, tx * 1e3, 5 * nbytes / tx / 1e12))
