@@ -621,7 +621,12 @@ k_conv_fwd_mfma(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__
 // requested by the producers during the tile's last phase (that phase carries no halo pieces) and have landed by the full wait of the next
 // item's phase 0.  The "staged" barrier IS the next tile's phase-0 barrier: one barrier less per tile.  On the level-0 layers of
 // BASELINE configs[1] (1-2 chunks per tile, 64 KB of stores + 64 KB of mask per 18-36 us tile) the epilogue was 13-25 % of a consumer's time.
-template <int NT, bool PL, int MODE, bool RES, bool ASYNC = false>
+// EPI (ASYNC instantiations): what the epilogue does besides storing the tile - 0 nothing or the pooled copy, 1 the ReLU mask of an input
+// gradient, 2 the logits of the final 1x1x1 conv; -1 = decided at run time (all of it compiled in).  One instantiation per case keeps the
+// producers' registers apart: the 16 prefetched mask lines (64 registers) and the 9 logit weights are only allocated where they are used -
+// with everything in one kernel the producers' path spilled 18 registers and the pooled-copy launch (enc0b forward, bound by its producers)
+// ran 5 % slower for registers only the other cases need.
+template <int NT, bool PL, int MODE, bool RES, bool ASYNC = false, int EPI = -1>
 __global__ void __launch_bounds__(fw::NTHREADS)
 k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ bias, const bf16_t* __restrict__ mask,
               const bf16_t* residual, bf16_t* y, int N, int D, int H, int W, int Cout, int act, float alpha, FwdTail tail) {
@@ -660,6 +665,7 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
     static_assert(NPH * RPP == NROW, "rows per phase");
     constexpr int PH0 = PL ? 3 : 0;
     constexpr bool ASY = ASYNC && !RES && !PL && MODE == 0;
+    constexpr bool HAS_MASK = EPI < 0 || EPI == 1, HAS_LOGITS = EPI < 0 || EPI == 2, HAS_POOL = EPI <= 0;
     // the producers drain a staged tile in DP parts, one per phase, in phases 0 .. DP-1 of the next tile's first item (one part fits a
     // phase beside the filter slab's DMA; the whole drain in phase 0 made the producers late for the phase-1 barrier: measured 8 % SLOWER
     // than the synchronous epilogue); the halo pieces of that item's successor follow in phases DP .. NPH-2
@@ -748,11 +754,22 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
         const int nit = 512 / (nw * VPI_) / nparts;
         int n = nit;
         if (MODE == 0 && !RES) {
-            if (tail.logits) n += nit;
-            if (tail.pool && part == nparts - 1) n += (64 * CPV_ + nw * 64 - 1) / (nw * 64);
+            if (HAS_LOGITS && tail.logits) n += nit;
+            if (HAS_POOL && tail.pool && part == nparts - 1) n += (64 * CPV_ + nw * 64 - 1) / (nw * 64);
         }
         return n;
     };
+    // weights of the final 1x1x1 conv for this lane's 16-byte piece of a voxel (q = lane % CPV), fetched once per kernel: as loads inside
+    // store_share they sat in every part of the asynchronous drain, in front of its stores
+    float4 w1a = make_float4(0.f, 0.f, 0.f, 0.f), w1b = w1a;
+    float b1v = 0.f;
+    if constexpr (MODE == 0 && !RES && HAS_LOGITS) {
+        if (tail.logits) {
+            w1a = *reinterpret_cast<const float4*>(tail.w1 + (lane % CPV_) * 8);
+            w1b = *reinterpret_cast<const float4*>(tail.w1 + (lane % CPV_) * 8 + 4);
+            b1v = tail.b1[0];
+        }
+    }
     auto store_share = [&](const FwdItem& it, int slot, int w, auto nw_tag, auto pre_tag, const uint4* mk, auto part_tag, auto nparts_tag) {
         constexpr int NW = decltype(nw_tag)::value;
         constexpr bool PRE = decltype(pre_tag)::value;       // the mask lines were requested earlier (mk[kk], kk = store instruction)
@@ -769,7 +786,7 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
             uint4 o4 = *reinterpret_cast<const uint4*>(stage + v * (BN * 2) + (((q ^ vs) & SWM) << 4));
             const int rt = v >> 5, rr = v & 31;
             const int64_t ao = piece_addr(it, v, q);
-            if (mask) {
+            if (HAS_MASK && mask) {
                 uint4 m4;
                 if constexpr (PRE) m4 = mk[kk];
                 else m4 = *reinterpret_cast<const uint4*>(mask + ao);
@@ -782,10 +799,10 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
                 }
             }
             *reinterpret_cast<uint4*>(y + ao) = o4;
-            if constexpr (MODE == 0 && !RES) {
+            if constexpr (MODE == 0 && !RES && HAS_LOGITS) {
                 if (tail.logits) {
                     // final 1x1x1 conv to one label: the CPV lanes of a voxel hold its BN (= Cout) channels, 8 each
-                    const float4 wa = *reinterpret_cast<const float4*>(tail.w1 + q * 8), wb = *reinterpret_cast<const float4*>(tail.w1 + q * 8 + 4);
+                    const float4 wa = w1a, wb = w1b;           // this lane's 8 weights (q = lane % CPV is the same in every iteration)
                     float part = __uint_as_float(o4.x << 16) * wa.x;
                     part = __builtin_fmaf(__uint_as_float(o4.x & 0xffff0000u), wa.y, part);
                     part = __builtin_fmaf(__uint_as_float(o4.y << 16), wa.z, part);
@@ -797,7 +814,7 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
 #pragma unroll
                     for (int m = 1; m < CPV; m <<= 1) part += __shfl_xor(part, m);
                     if (q == 0)
-                        tail.logits[(((int64_t)it.n * D + it.d0 + tile_d(rt)) * H + it.h0 + tile_h(rt, rr)) * W + it.w0 + lane_w(rr)] = part + tail.b1[0];
+                        tail.logits[(((int64_t)it.n * D + it.d0 + tile_d(rt)) * H + it.h0 + tile_h(rt, rr)) * W + it.w0 + lane_w(rr)] = part + b1v;
                 }
             }
             // four pieces at a time: left alone the scheduler hoists all NIT stage reads and addresses to the top (96+ live registers: the
@@ -806,7 +823,7 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
                 if ((kk & 3) == 3) __builtin_amdgcn_sched_barrier(0);
             }
         }
-        if constexpr (MODE == 0 && !RES && PART == NPARTS - 1) {
+        if constexpr (MODE == 0 && !RES && HAS_POOL && PART == NPARTS - 1) {
             if (tail.pool) {
                 // 2x2x2 max pooling of the staged tile: 2 x 4 x 8 pooled voxels x CPV 16-byte pieces, one per thread and round
                 constexpr int NPOOL = (64 * CPV + NW * 64 - 1) / (NW * 64);
@@ -938,7 +955,7 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
         };
         // ASY: the finished tile waiting to be stored (staged by the consumers in halo slot `hb ^ 1` as seen from the next item), the mask
         // lines of this wave's share of it, and the number of vector-memory instructions the drain issues behind the phase-1 filter slab
-        constexpr int NDR = ASY ? 512 / (DW * VPI_) : 1;
+        constexpr int NDR = (ASY && HAS_MASK) ? 512 / (DW * VPI_) : 1;
         uint4 mk[NDR] = {};
         FwdItem done = cur;
         bool pending = false;
@@ -982,7 +999,7 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
                         if constexpr (DRN) {
                             // the mask lines requested in the previous tile's last phase are in their registers now: tell the compiler here,
                             // where it costs nothing (its own wait for them would otherwise sit behind the next filter slab's DMA)
-                            if (mask) {
+                            if (HAS_MASK && mask) {
 #pragma unroll
                                 for (int i = 0; i < NDR; ++i) asm volatile("" : "+v"(mk[i].x), "+v"(mk[i].y), "+v"(mk[i].z), "+v"(mk[i].w));
                             }
@@ -1011,7 +1028,7 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
                     }
                     if constexpr (ASY) {
                         // last phase of a tile (it carries no halo pieces): request the mask lines of this wave's share of the tile's stores
-                        if (pl == NPH - 1 && cur.ch == nch - 1 && mask) {
+                        if (HAS_MASK && pl == NPH - 1 && cur.ch == nch - 1 && mask) {
 #pragma unroll
                             for (int kk = 0; kk < NDR; ++kk) {
                                 const int v = dwv * (512 / DW) + kk * VPI_ + lane / CPV_;
@@ -2149,10 +2166,18 @@ static int conv3d_fwd_mfma_launch(int mode, const void* src0, int C0, int up0, i
     do {                                                                                                                  \
         const int np = ntile * (Cout / (32 * NT_)) * (MODE_ == 1 ? (PL_ ? 4 : 8) : 1);                                    \
         constexpr bool A_ = !(PL_) && !(RES_) && (MODE_) == 0;   /* asynchronous epilogue: plain 3-D launches */         \
-        if (use_ws && A_ && fwd_async() && np > ncu)   /* a single pair per workgroup has nothing to hide the stores under */ \
-            k_conv_fwd_ws<NT_, PL_, MODE_, RES_, A_><<<np < ncu ? np : ncu, fw::NTHREADS, 0, st>>>(                       \
-                s, (const bf16_t*)w, bias, (const bf16_t*)mask, (const bf16_t*)residual, (bf16_t*)y, N, D, H, W, Cout, act, alpha, tail); \
-        else if (use_ws && (!(PL_) || use_ws > 1))   /* planar: the producers are the bottleneck - symmetric kernel */ \
+        const int epi_ = mask ? ((tail.pool || tail.logits) ? -1 : 1) : (tail.logits ? (tail.pool ? -1 : 2) : 0);                  \
+        if (use_ws && A_ && fwd_async() && np > ncu && epi_ >= 0) {   /* a single pair per workgroup has nothing to hide the stores under */ \
+            if (epi_ == 0)                                                                                                \
+                k_conv_fwd_ws<NT_, PL_, MODE_, RES_, A_, A_ ? 0 : -1><<<np < ncu ? np : ncu, fw::NTHREADS, 0, st>>>(               \
+                    s, (const bf16_t*)w, bias, (const bf16_t*)mask, (const bf16_t*)residual, (bf16_t*)y, N, D, H, W, Cout, act, alpha, tail); \
+            else if (epi_ == 1)                                                                                           \
+                k_conv_fwd_ws<NT_, PL_, MODE_, RES_, A_, A_ ? 1 : -1><<<np < ncu ? np : ncu, fw::NTHREADS, 0, st>>>(               \
+                    s, (const bf16_t*)w, bias, (const bf16_t*)mask, (const bf16_t*)residual, (bf16_t*)y, N, D, H, W, Cout, act, alpha, tail); \
+            else                                                                                                          \
+                k_conv_fwd_ws<NT_, PL_, MODE_, RES_, A_, A_ ? 2 : -1><<<np < ncu ? np : ncu, fw::NTHREADS, 0, st>>>(               \
+                    s, (const bf16_t*)w, bias, (const bf16_t*)mask, (const bf16_t*)residual, (bf16_t*)y, N, D, H, W, Cout, act, alpha, tail); \
+        } else if (use_ws && (!(PL_) || use_ws > 1))   /* planar: the producers are the bottleneck - symmetric kernel */ \
             k_conv_fwd_ws<NT_, PL_, MODE_, RES_><<<np < ncu ? np : ncu, fw::NTHREADS, 0, st>>>(                           \
                 s, (const bf16_t*)w, bias, (const bf16_t*)mask, (const bf16_t*)residual, (bf16_t*)y, N, D, H, W, Cout, act, alpha, tail); \
         else                                                                                                              \
