@@ -22,6 +22,36 @@ template <> struct Io<bf16_t> {
     static __device__ __forceinline__ void st(bf16_t* p, float v) { *p = f2bf(v); }
 };
 
+// ---- bit-reproducible gradient accumulation (round 3).  Floating-point atomics add a workgroup's partial sums in whatever order the
+// workgroups finish: the default training step is not reproducible bit for bit.  Integer adds are associative, so in DETERMINISTIC mode every
+// partial sum that would go to a gradient element by `atomicAdd(float)` is instead rounded to a 2^-40 fixed-point number (|v| < 2^23, which
+// gradients are) and added with a 64-bit integer atomic to a SHADOW of the gradient buffer; fmri_deterministic_finish() then adds the shadow
+// (converted back once) to the fp32 gradient and clears it.  The partial sums themselves come out of fixed-order MFMA / FMA chains and the
+// work partition of every launch is static, so the result no longer depends on the arrival order.  fmri_set_deterministic() registers
+// (gradient base, shadow base, element count); each translation unit that flushes gradients keeps its own copy of the registration (the
+// library is built without relocatable device code).  Cost: 64-bit atomics, i.e. twice the flush traffic; the default mode is untouched
+// apart from one scalar load and a uniform branch per flush.
+struct FmriDetCfg {
+    float* base;
+    unsigned long long* shadow;
+    long long n;
+};
+#define FMRI_DET_SCALE 1099511627776.f        /* 2^40 */
+#define FMRI_DET_TU(tag)                                                                                         \
+    static __device__ FmriDetCfg g_det_cfg;                                                                      \
+    static bool h_det_on = false;                                                                                \
+    int fmri_det_set_##tag(const FmriDetCfg& c) {                                                                \
+        h_det_on = c.base != nullptr;                                                                            \
+        return hipMemcpyToSymbol(HIP_SYMBOL(g_det_cfg), &c, sizeof(c)) == hipSuccess ? FMRI_OK : FMRI_E_LAUNCH;  \
+    }
+__device__ __forceinline__ void fmri_grad_add(const FmriDetCfg& c, float* p, float v) {
+    const long long i = p - c.base;
+    if (c.base != nullptr && i >= 0 && i < c.n)
+        atomicAdd(c.shadow + i, (unsigned long long)__float2ll_rn(v * FMRI_DET_SCALE));
+    else
+        atomicAdd(p, v);
+}
+
 #define FMRI_LAUNCH_CHECK()                                   \
     do {                                                      \
         if (hipGetLastError() != hipSuccess) return FMRI_E_LAUNCH; \

@@ -8,6 +8,7 @@ int conv3d_wgrad_generic(const void*, int, int, int, const void*, int, const voi
 bool conv3d_fwd_mfma_ok(int C0, int C1, int Cout, int D, int H, int W, int dtype);
 bool conv3d_wgrad_mfma_ok(int C0, int C1, int Cout, int D, int H, int W, int dtype);
 bool conv3d_fwd_needs_cube(int D, int H, int W);
+bool conv3d_wgrad_cout32_ok(int C0, int C1, int Cout, int N, int D, int H, int W, int dtype, int planar, int up0);
 int conv3d_fwd_mfma(const void*, int, int, int, const void*, int, const void*, const float*, const void*, void*, int, int, int, int, int, int,
                     float, hipStream_t);
 int conv3d_wgrad_mfma(const void*, int, int, int, const void*, int, const void*, float*, float*, int, int, int, int, int, void*, int64_t,
@@ -91,7 +92,12 @@ extern "C" int fmri_conv3d_wgrad(const void* src0, int C0, int up0, const void* 
     if (!dy || !dw) return FMRI_E_SHAPE;
     if (impl != FMRI_IMPL_GENERIC && conv3d_first_ok(C0, C1, Cout, D, H, W, dtype, up0, planar))
         return conv3d_first_wgrad(src0, C0, planar, dy, dw, db, N, D, H, W, Cout, as_stream(stream));
-    const bool can = conv3d_wgrad_mfma_ok(C0, C1, Cout, D, H, W, dtype);
+    bool can = conv3d_wgrad_mfma_ok(C0, C1, Cout, D, H, W, dtype);
+    if (!can && (Cout % 64) && conv3d_wgrad_cout32_ok(C0, C1, Cout, N, D, H, W, dtype, planar, up0)) {
+        can = true;                       // 32-wide Cout on the kd-sharing kernel (32 x 32 blocks): without a workspace, so that it takes the launch
+        workspace = nullptr;
+        workspace_bytes = 0;
+    }
     if (impl == FMRI_IMPL_MFMA && !can) return FMRI_E_SHAPE;
     if (can && impl != FMRI_IMPL_GENERIC) {
         if ((((uintptr_t)src0) | ((uintptr_t)src1) | ((uintptr_t)dy)) & 15) return FMRI_E_ALIGN;
@@ -100,6 +106,9 @@ extern "C" int fmri_conv3d_wgrad(const void* src0, int C0, int up0, const void* 
     return conv3d_wgrad_generic(src0, C0, up0, planar, src1, C1, dy, dw, db, N, D, H, W, Cout, dtype, as_stream(stream));
 }
 
+extern "C" int fmri_conv3d_wgrad_cout32_ok(int C0, int C1, int Cout, int N, int D, int H, int W, int dtype, int planar, int up0) {
+    return conv3d_wgrad_cout32_ok(C0, C1, Cout, N, D, H, W, dtype, planar, up0) ? 1 : 0;
+}
 extern "C" int64_t fmri_conv3d_wgrad_workspace_bytes(int C0, int C1, int Cout, int N, int D, int H, int W, int dtype, int planar) {
     if (!conv3d_wgrad_mfma_ok(C0, C1, Cout, D, H, W, dtype)) return 0;
     if (conv3d_first_ok(C0, C1, Cout, D, H, W, dtype, 0, planar)) return 0;

@@ -10,6 +10,8 @@
 // Conv3DBackpropFilterV2 / BiasAddGrad.
 #include "common.h"
 
+FMRI_DET_TU(first)
+
 namespace {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
@@ -235,20 +237,25 @@ k_conv_first_wgrad(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy, 
     float* const red = reinterpret_cast<float*>(lds);          // [NCT*32 columns][32 co] + [32] bias, tile buffers are dead now
     for (int i = t; i < NCT * 1024 + 32; i += NTHREADS) red[i] = 0.f;
     __syncthreads();
+    // the four waves add their accumulators ONE AFTER THE OTHER (each lane owns its elements within a wave): a fixed order, so the
+    // workgroup's sums are reproducible bit for bit (LDS float atomics from four waves were not)
+    if (db) bsum += __shfl_down(bsum, 32);
+    for (int w = 0; w < 4; ++w) {
+        if (wv == w) {
 #pragma unroll
-    for (int ct = 0; ct < NCT; ++ct)
+            for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            const int col = (reg & 3) + 8 * (reg >> 2) + 4 * hk;
-            atomicAdd(&red[(ct * 32 + r) * 32 + col], acc[ct][reg]);
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int col = (reg & 3) + 8 * (reg >> 2) + 4 * hk;
+                    red[(ct * 32 + r) * 32 + col] += acc[ct][reg];
+                }
+            if (db && hk == 0) red[NCT * 1024 + r] += bsum;
         }
-    if (db) {
-        bsum += __shfl_down(bsum, 32);
-        if (hk == 0) atomicAdd(&red[NCT * 1024 + r], bsum);
+        __syncthreads();
     }
-    __syncthreads();
-    for (int i = t; i < K * 32; i += NTHREADS) atomicAdd(&dw[k_widx<CIN, PLANAR>(i >> 5, cot * 32 + (i & 31), Cout)], red[i]);
-    if (db && t < 32) atomicAdd(&db[cot * 32 + t], red[NCT * 1024 + t]);
+    const FmriDetCfg dc = g_det_cfg;
+    for (int i = t; i < K * 32; i += NTHREADS) fmri_grad_add(dc, &dw[k_widx<CIN, PLANAR>(i >> 5, cot * 32 + (i & 31), Cout)], red[i]);
+    if (db && t < 32) fmri_grad_add(dc, &db[cot * 32 + t], red[NCT * 1024 + t]);
 }
 
 }  // namespace

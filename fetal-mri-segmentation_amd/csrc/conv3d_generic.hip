@@ -4,6 +4,8 @@
 // Reference ops: Conv3D / Conv3DBackpropFilterV2 emitted for create_convolution_block (unet3d/unet.py:89-115).
 #include "common.h"
 
+FMRI_DET_TU(generic)
+
 namespace {
 
 constexpr int TD = 2, TH = 8, TW = 16;            // output tile = 256 voxels = one thread each
@@ -158,10 +160,10 @@ k_conv_wgrad_generic(Src s, const T* __restrict__ dy, float* __restrict__ dw, fl
         const int o = t + 256 * j;
         if (o < WG_OUT) {
             const int ci = o % CK, co = (o / CK) % COB, tap = o / (CK * COB);
-            if (c0 + ci < Cin && co0 + co < Cout) atomicAdd(&dw[((int64_t)tap * Cout + co0 + co) * Cin + c0 + ci], acc[j]);
+            if (c0 + ci < Cin && co0 + co < Cout) fmri_grad_add(g_det_cfg, &dw[((int64_t)tap * Cout + co0 + co) * Cin + c0 + ci], acc[j]);
         }
     }
-    if (db && blockIdx.y == 0 && t < COB && co0 + t < Cout) atomicAdd(&db[co0 + t], bacc);
+    if (db && blockIdx.y == 0 && t < COB && co0 + t < Cout) fmri_grad_add(g_det_cfg, &db[co0 + t], bacc);
 }
 
 int ntiles_of(int N, int D, int H, int W) {

@@ -17,6 +17,8 @@
 #include <utility>
 #include <cstdlib>
 
+FMRI_DET_TU(mfma)
+
 namespace {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
@@ -1719,6 +1721,7 @@ k_conv_wgrad_mfma(SrcB s, const bf16_t* __restrict__ dy, float* __restrict__ dw,
         run(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
     }
     if (producer) return;
+    const FmriDetCfg dc = g_det_cfg;                    // deterministic mode: fixed-point shadow of the gradient buffer (common.h)
     // ---- flush: D rows = co, cols = ci (128-B contiguous per half-wave).  With a workspace: plain stores of this workgroup's partial
     // slab [9][64][CIB] (summed per element by k_wgrad_reduce: deterministic, ~5x the atomic rate); without: fp32 atomics into dw.
     if constexpr (UPW) {
@@ -1750,13 +1753,13 @@ k_conv_wgrad_mfma(SrcB s, const bf16_t* __restrict__ dy, float* __restrict__ dw,
             for (int reg = 0; reg < 16; ++reg) {
                 const int co = co0 + ct * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * hk;
                 const int ci = cc + it * 32 + r;
-                atomicAdd(&dw[((int64_t)(kd * 9 + tap) * Cout + co) * dw_ld + ci], acc[tap][reg]);
+                fmri_grad_add(dc, &dw[((int64_t)(kd * 9 + tap) * Cout + co) * dw_ld + ci], acc[tap][reg]);
             }
         }
     }
     if (do_bias) {
         bsum += __shfl_down(bsum, 32);
-        if (hk == 0) atomicAdd(&db[co0 + ct * 32 + r], bsum);
+        if (hk == 0) fmri_grad_add(dc, &db[co0 + ct * 32 + r], bsum);
     }
 }
 
@@ -2007,7 +2010,8 @@ __device__ __forceinline__ void wk_run(const WkArgs& a, unsigned char* lds, int 
             ++d;
         }
     }
-    // ---- flush: D rows = co, cols = ci; fp32 atomics, 128 contiguous bytes per half-wave
+    // ---- flush: D rows = co, cols = ci; fp32 atomics, 128 contiguous bytes per half-wave (deterministic mode: fixed-point shadow)
+    const FmriDetCfg dc = g_det_cfg;
 #pragma unroll
     for (int j = 0; j < NTAP; ++j) {
         const int tap = 7 * G + j;
@@ -2017,7 +2021,7 @@ __device__ __forceinline__ void wk_run(const WkArgs& a, unsigned char* lds, int 
             for (int reg = 0; reg < 16; ++reg) {
                 const int co = co0 + h * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * hk;
                 const int ci = cc + it * 32 + r;
-                atomicAdd(&a.dw[((int64_t)tap * Cout + co) * a.dw_ld + ci], acc[j][h][reg]);
+                fmri_grad_add(dc, &a.dw[((int64_t)tap * Cout + co) * a.dw_ld + ci], acc[j][h][reg]);
             }
     }
     if (do_bias) {
@@ -2025,7 +2029,7 @@ __device__ __forceinline__ void wk_run(const WkArgs& a, unsigned char* lds, int 
         for (int h = 0; h < NH; ++h) {
             float b = bsum[h];
             b += __shfl_down(b, 32);
-            if (hk == 0) atomicAdd(&a.db[co0 + h * 32 + r], b);
+            if (hk == 0) fmri_grad_add(dc, &a.db[co0 + h * 32 + r], b);
         }
     }
 }
@@ -2283,6 +2287,29 @@ int64_t conv3d_wgrad_mfma_ws_bytes(int C0, int C1, int Cout, int N, int D, int H
     return (int64_t)combos * nslab * (CIB == 32 ? 2 : 1) * 9 * 64 * CIB * (int64_t)sizeof(float);
 }
 
+// does this launch take the kd-sharing kernel (k_conv_wgrad_kd)?  use_ws: the slab flush was chosen for it
+static bool wgrad_takes_kd(int C0, int C1, int Cout, int N, int D, int H, int W, int planar, int up0, bool use_ws, int* blk_out) {
+    static int kd_mode = -1, kd_blk = 32;
+    if (kd_mode < 0) {
+        const char* e = getenv("FMRI_WGRAD_KD");
+        kd_mode = e ? atoi(e) : 2;
+        const char* f = getenv("FMRI_WGRAD_KD_BLK");
+        kd_blk = (f && atoi(f) == 64) ? 64 : 32;
+    }
+    if (blk_out) *blk_out = kd_blk;
+    const double flops_ = 2.0 * (planar ? 9 : 27) * (double)(C0 + C1) * Cout * (double)N * D * H * W;
+    const bool narrow = (C0 % 64) || (C1 % 64);
+    return kd_mode && !planar && !use_ws && (!up0 || kd_mode == 3) && (C0 % kd_blk == 0) && (C1 % kd_blk == 0) && (Cout % kd_blk == 0) &&
+           ((kd_mode >= 2 && flops_ >= 0.3e12) || (narrow && kd_blk == 32 && flops_ >= 0.1e12));
+}
+// A 32-wide Cout (not a multiple of the per-kd kernel's 64-wide block) is fine where the kd-sharing kernel with its 32 x 32 blocks takes the
+// launch: no workspace (slab flush), see wgrad_takes_kd.  Lets the channel-padded layer-graph engine pass a 32-channel dy as it is (it
+// made a zero-extended 64-channel copy of it per layer and step: 1.4 ms of copies per Isensee step).
+bool conv3d_wgrad_cout32_ok(int C0, int C1, int Cout, int N, int D, int H, int W, int dtype, int planar, int up0) {
+    if (dtype != FMRI_BF16 || (C0 % 32) || (C1 % 32) || C0 + C1 < 32 || (Cout % 32) || (H % wg::TH) || (W % wg::TW)) return false;
+    int blk = 32;
+    return wgrad_takes_kd(C0, C1, Cout, N, D, H, W, planar, up0, false, &blk) && blk == 32;
+}
 // dw_ld: row length of the dw image the gradient is added into (>= C0 + C1; lets a launch over a subset of the input channels write
 // its columns of the full [27][Cout][Cin] gradient: pass dw already offset to the first column)
 int conv3d_wgrad_mfma_ld(const void* src0, int C0, int up0, int planar, const void* src1, int C1, const void* dy, float* dw, int dw_ld,
@@ -2310,16 +2337,8 @@ int conv3d_wgrad_mfma_ld(const void* src0, int C0, int up0, int planar, const vo
     // per-kd kernel is ahead, with the slab flush or - callers without a workspace, e.g. the layer-graph engine - with the atomic one:
     // Isensee defaults 11.3 vs 11.65 ms per step), 3 = the fused-upsample launches too;
     // FMRI_WGRAD_KD_BLK = 32 (4-wave workgroups, two per CU) | 64 (8-wave workgroup, one per CU: slower, kept for the record).
-    static int kd_mode = -1, kd_blk = 32;
-    if (kd_mode < 0) {
-        const char* e = getenv("FMRI_WGRAD_KD");
-        kd_mode = e ? atoi(e) : 2;
-        const char* f = getenv("FMRI_WGRAD_KD_BLK");
-        kd_blk = (f && atoi(f) == 64) ? 64 : 32;
-    }
-    const bool narrow = (C0 % 64) || (C1 % 64);
-    if (kd_mode && !planar && !use_ws && (!up0 || kd_mode == 3) && (C0 % kd_blk == 0) && (C1 % kd_blk == 0) && (Cout % kd_blk == 0) &&
-        ((kd_mode >= 2 && flops_ >= 0.3e12) || (narrow && kd_blk == 32 && flops_ >= 0.1e12))) {
+    int kd_blk = 32;
+    if (wgrad_takes_kd(C0, C1, Cout, N, D, H, W, planar, up0, use_ws, &kd_blk)) {
         const int combos_kd = (Cout / kd_blk) * (Cin / kd_blk);
         const int nunits = N * D * (H / wg::TH) * (W / wg::TW);
         static int kd_wgs = -1;
@@ -2337,6 +2356,7 @@ int conv3d_wgrad_mfma_ld(const void* src0, int C0, int up0, int planar, const vo
         FMRI_LAUNCH_CHECK();
         return FMRI_OK;
     }
+    if (Cout % 64) return FMRI_E_SHAPE;                      // the per-kd kernel tiles Cout by 64
     int CIB, combos, nslab;
     wgrad_plan(C0, C1, Cout, N, D, H, W, planar, use_ws, CIB, combos, nslab);
     float* ws = use_ws ? (float*)workspace : nullptr;

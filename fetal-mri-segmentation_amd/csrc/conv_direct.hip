@@ -4,6 +4,8 @@
 // :66 segmentation heads).  Correctness-first VALU kernels, fp32 accumulate.
 #include "common.h"
 
+FMRI_DET_TU(direct)
+
 namespace {
 
 struct Geo {
@@ -105,9 +107,9 @@ __global__ void k_direct_wgrad(const T* __restrict__ x, const T* __restrict__ dy
             if ((unsigned)id >= (unsigned)g.D || (unsigned)ih >= (unsigned)g.H || (unsigned)iw >= (unsigned)g.W) continue;
             if (ci < g.Cin) acc = fmaf(gv, to_f<T>(x[((((int64_t)n * g.D + id) * g.H + ih) * g.W + iw) * g.Cin + ci]), acc);
         }
-        if (ci < g.Cin) atomicAdd(&dw[((int64_t)tap * g.Cout + co) * g.Cin + ci], acc);
+        if (ci < g.Cin) fmri_grad_add(g_det_cfg, &dw[((int64_t)tap * g.Cout + co) * g.Cin + ci], acc);
     }
-    if (db && threadIdx.x == 0 && tap == tap_b) atomicAdd(&db[co], bsum);
+    if (db && threadIdx.x == 0 && tap == tap_b) fmri_grad_add(g_det_cfg, &db[co], bsum);
 }
 
 template <typename T>

@@ -3,6 +3,9 @@
 #include <cstdlib>
 #include "common.h"
 
+FMRI_DET_TU(pointwise)
+static __device__ unsigned long long g_isums[16];      // metric sums of the deterministic mode, 2^-20 fixed point
+
 // ------------------------------------------------------------------------------------------------ version / errors
 extern "C" int fmri_version(void) { return 100; }
 extern "C" const char* fmri_error_string(int code) {
@@ -282,10 +285,11 @@ __global__ void k_conv1x1_bwd(const T* __restrict__ x, const float* __restrict__
         }
     }
     __syncthreads();
+    const FmriDetCfg dc = g_det_cfg;
     for (int i = threadIdx.x; i < L * (C + 1); i += blockDim.x) {
         int l = i / (C + 1), c = i % (C + 1);
-        if (c < C) atomicAdd(&dw[l * C + c], sacc[i]);
-        else if (db) atomicAdd(&db[l], sacc[i]);
+        if (c < C) fmri_grad_add(dc, &dw[l * C + c], sacc[i]);
+        else if (db) fmri_grad_add(dc, &db[l], sacc[i]);
     }
 }
 
@@ -327,8 +331,10 @@ template <typename T, int LPV>
 __global__ void __launch_bounds__(256)
 k_conv1x1_bwd_v2(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ dl, T* __restrict__ dx,
                  float* __restrict__ dw, float* __restrict__ db, int64_t nvox, int C, int L, int relu_mask) {
-    extern __shared__ __attribute__((aligned(16))) float sacc[];   // [L][C+1]
-    for (int i = threadIdx.x; i < L * (C + 1); i += blockDim.x) sacc[i] = 0.f;
+    // [L][C+1] sums of the workgroup in 2^-40 fixed point: 64-bit integer adds give the same bits in any order (fp32 LDS atomics from 32
+    // voxel lanes per element did not: the workgroup's partial sums - and with them dw of the last layer - differed from run to run)
+    extern __shared__ __attribute__((aligned(16))) unsigned long long sacc[];
+    for (int i = threadIdx.x; i < L * (C + 1); i += blockDim.x) sacc[i] = 0ull;
     __syncthreads();
     const int sub = threadIdx.x % LPV;
     float wr[4][8], aw[4][8], ab[4];
@@ -380,14 +386,16 @@ k_conv1x1_bwd_v2(const T* __restrict__ x, const float* __restrict__ w, const flo
     }
     for (int l = 0; l < L; ++l) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) atomicAdd(&sacc[l * (C + 1) + sub * 8 + k], aw[l][k]);
-        if (sub == 0) atomicAdd(&sacc[l * (C + 1) + C], ab[l]);
+        for (int k = 0; k < 8; ++k) atomicAdd(&sacc[l * (C + 1) + sub * 8 + k], (unsigned long long)__float2ll_rn(aw[l][k] * FMRI_DET_SCALE));
+        if (sub == 0) atomicAdd(&sacc[l * (C + 1) + C], (unsigned long long)__float2ll_rn(ab[l] * FMRI_DET_SCALE));
     }
     __syncthreads();
+    const FmriDetCfg dc = g_det_cfg;
     for (int i = threadIdx.x; i < L * (C + 1); i += blockDim.x) {
         int l = i / (C + 1), c = i % (C + 1);
-        if (c < C) atomicAdd(&dw[l * C + c], sacc[i]);
-        else if (db) atomicAdd(&db[l], sacc[i]);
+        const float v = (float)((double)(long long)sacc[i] * (1.0 / (double)FMRI_DET_SCALE));
+        if (c < C) fmri_grad_add(dc, &dw[l * C + c], v);
+        else if (db) fmri_grad_add(dc, &db[l], v);
     }
 }
 static int lpv_of(int C, int L) {
@@ -453,7 +461,7 @@ extern "C" int fmri_conv1x1_bwd(const void* x, const float* w, const float* dlog
         // streaming part wants few, long-running workgroups - measured on the benchmark's 4 x 64 x 128 x 128 x 64 tensor (ms per launch):
         // 256 workgroups 0.39, 512 0.22, 768 0.29, 1024 0.23, 2048 0.26, 4096 (the former cap) 0.31, 8192 0.35
         int g2 = grid_for(nvox * lpv, 256, 512);
-        size_t sh2 = (size_t)L * (C + 1) * 4;
+        size_t sh2 = (size_t)L * (C + 1) * 8;
         if (dtype == FMRI_F32) { LAUNCH_LPV(k_conv1x1_bwd_v2, float, lpv, g2, sh2, s, (const float*)x, w, dlogits, (float*)dx, dw, db, nvox, C, L, relu_mask) }
         else if (dtype == FMRI_BF16) { LAUNCH_LPV(k_conv1x1_bwd_v2, bf16_t, lpv, g2, sh2, s, (const bf16_t*)x, w, dlogits, (bf16_t*)dx, dw, db, nvox, C, L, relu_mask) }
         else return FMRI_E_DTYPE;
@@ -516,9 +524,30 @@ __global__ void k_sigmoid_dice_fwd(const float* __restrict__ logits, const uint8
     __syncthreads();
     if (threadIdx.x < 9) {
         double r = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
-        atomicAdd(&sums[threadIdx.x < 7 ? threadIdx.x : threadIdx.x + 1], r);     // [8] = sum xent, [9] = sum focal
+        const int k = threadIdx.x < 7 ? threadIdx.x : threadIdx.x + 1;            // [8] = sum xent, [9] = sum focal
+        // deterministic mode: the workgroups' sums meet as 2^-20 fixed-point integers (g_isums), k_isums_finish adds them to `sums`
+        if (g_det_cfg.base != nullptr) atomicAdd(&g_isums[k], (unsigned long long)__double2ll_rn(r * 1048576.0));
+        else atomicAdd(&sums[k], r);
     }
     if (blockIdx.x == 0 && threadIdx.x == 9) atomicAdd(&sums[7], (double)n);
+}
+__global__ void k_isums_finish(double* __restrict__ sums) {
+    const int k = threadIdx.x;
+    if (k < 16) {
+        const long long v = (long long)g_isums[k];
+        if (v) sums[k] += (double)v * (1.0 / 1048576.0);
+        g_isums[k] = 0ull;
+    }
+}
+// gradient += shadow * 2^-40, shadow = 0 (see FmriDetCfg in common.h)
+__global__ void k_det_finish(float* __restrict__ g, unsigned long long* __restrict__ shadow, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const long long v = (long long)shadow[i];
+        if (v) {
+            g[i] += (float)((double)v * (1.0 / (double)FMRI_DET_SCALE));
+            shadow[i] = 0ull;
+        }
+    }
 }
 __global__ void k_sigmoid_dice_bwd(const float* __restrict__ probs, const uint8_t* __restrict__ y, const double* __restrict__ sums,
                                    float* __restrict__ dl, int64_t n, float smooth, float grad_scale) {
@@ -647,6 +676,7 @@ extern "C" int fmri_sigmoid_dice_fwd_weighted(const float* logits, const uint8_t
                                               int64_t n, fmri_stream_t stream) {
     if (n <= 0 || !weight) return FMRI_E_SHAPE;
     k_sigmoid_dice_fwd<<<grid_for(n, 256, 1024), 256, 0, as_stream(stream)>>>(logits, y_true, weight, probs, sums, n);
+    if (h_det_on) k_isums_finish<<<1, 64, 0, as_stream(stream)>>>(sums);
     FMRI_LAUNCH_CHECK();
     return FMRI_OK;
 }
@@ -663,6 +693,7 @@ extern "C" int fmri_sigmoid_dice_fwd(const float* logits, const uint8_t* y_true,
                                      fmri_stream_t stream) {
     if (n <= 0) return FMRI_E_SHAPE;
     k_sigmoid_dice_fwd<<<grid_for(n, 256, 1024), 256, 0, as_stream(stream)>>>(logits, y_true, nullptr, probs, sums, n);
+    if (h_det_on) k_isums_finish<<<1, 64, 0, as_stream(stream)>>>(sums);
     FMRI_LAUNCH_CHECK();
     return FMRI_OK;
 }
@@ -815,6 +846,28 @@ extern "C" int fmri_cast(const void* src, int sd, void* dst, int dd, int64_t n, 
     else if (sd == FMRI_F32 && dd == FMRI_F32) k_cast<float, float><<<grid, 256, 0, s>>>((const float*)src, (float*)dst, n);
     else if (sd == FMRI_BF16 && dd == FMRI_BF16) k_cast<bf16_t, bf16_t><<<grid, 256, 0, s>>>((const bf16_t*)src, (bf16_t*)dst, n);
     else return FMRI_E_DTYPE;
+    FMRI_LAUNCH_CHECK();
+    return FMRI_OK;
+}
+
+// ---- deterministic mode (common.h, FmriDetCfg)
+int fmri_det_set_mfma(const FmriDetCfg&);
+int fmri_det_set_first(const FmriDetCfg&);
+int fmri_det_set_generic(const FmriDetCfg&);
+int fmri_det_set_direct(const FmriDetCfg&);
+extern "C" int fmri_set_deterministic(float* grad_base, void* shadow_i64, int64_t n) {
+    if ((grad_base == nullptr) != (shadow_i64 == nullptr) || (grad_base && n <= 0)) return FMRI_E_SHAPE;
+    const FmriDetCfg c{grad_base, (unsigned long long*)shadow_i64, grad_base ? (long long)n : 0};
+    int rc = fmri_det_set_pointwise(c);
+    if (!rc) rc = fmri_det_set_mfma(c);
+    if (!rc) rc = fmri_det_set_first(c);
+    if (!rc) rc = fmri_det_set_generic(c);
+    if (!rc) rc = fmri_det_set_direct(c);
+    return rc;
+}
+extern "C" int fmri_deterministic_finish(float* grad_base, void* shadow_i64, int64_t n, fmri_stream_t stream) {
+    if (!grad_base || !shadow_i64 || n <= 0) return FMRI_E_SHAPE;
+    k_det_finish<<<grid_for(n, 256, 2048), 256, 0, as_stream(stream)>>>(grad_base, (unsigned long long*)shadow_i64, n);
     FMRI_LAUNCH_CHECK();
     return FMRI_OK;
 }

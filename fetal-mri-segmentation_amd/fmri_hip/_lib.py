@@ -31,6 +31,7 @@ SIGNATURES = {
     "fmri_conv3d_dgrad": [p, i32, p, p, p, i32, i32, i32, i32, i32, i32, i32, i32, p],
     "fmri_conv3d_wgrad": [p, i32, i32, p, i32, p, p, p, i32, i32, i32, i32, i32, i32, i32, i32, p, i64, p],
     "fmri_conv3d_wgrad_workspace_bytes": [i32] * 9,
+    "fmri_conv3d_wgrad_cout32_ok": [i32] * 10,
     "fmri_conv3d_pack_weights": [p, p, p, i32, i32, i32, p],
     "fmri_conv1x1_fwd": [p, p, p, p, i64, i32, i32, i32, p],
     "fmri_conv1x1_bwd": [p, p, p, p, p, p, i64, i32, i32, i32, i32, p],
@@ -61,6 +62,8 @@ SIGNATURES = {
     "fmri_slice_channels": [p, i32, i32, p, i32, i64, i32, i32, p],
     "fmri_channel_scale": [p, p, p, i32, i64, i32, i32, p],
     "fmri_adam_step": [p, p, p, p, i64, f32, f32, f32, f32, f32, p],
+    "fmri_set_deterministic": [p, p, i64],
+    "fmri_deterministic_finish": [p, p, i64, p],
     "fmri_tile_gather": [p, i32, i32, i32, p, i32, i32, i32, i32, p, i32, p],
     "fmri_tile_scatter_accumulate": [p, p, i32, i32, i32, i32, i32, p, p, i32, i32, i32, p],
     "fmri_tile_finalize": [p, p, p, p, i64, i32, p],

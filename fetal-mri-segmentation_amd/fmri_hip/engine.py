@@ -101,6 +101,10 @@ class UNetEngine:
         self._wg_stream = (torch.cuda.Stream(device=self.dev) if (training and self.dev.type == "cuda" and os.environ.get("FMRI_WGRAD_STREAM", "1") != "0")
                            else None)
         self.loss_kind, self.loss_param = 0, 1.0      # ops.LOSS_KINDS: 0 = dice_coefficient_loss
+        # FMRI_DETERMINISTIC=1: bit-reproducible training steps (same weights + same batch -> the same bits in every gradient and metric):
+        # gradient partial sums meet as fixed-point integers in a shadow of G (ops.set_deterministic), the parity-form weight gradient -
+        # whose scratch is filled by fp32 atomics - gives way to the fused-upsample 27-tap one.  One engine per process at a time.
+        self.deterministic = bool(training and self.dev.type == "cuda" and os.environ.get("FMRI_DETERMINISTIC", "0") == "1")
         self._bufsets = {}
         self._build_params(seed)
         self.set_batch(batch)
@@ -137,6 +141,13 @@ class UNetEngine:
             self.G = torch.zeros_like(self.P)
             self.M = torch.zeros_like(self.P)
             self.V = torch.zeros_like(self.P)
+            if self.deterministic:
+                if p.norm is not None or p.deconvolution:
+                    raise NotImplementedError("FMRI_DETERMINISTIC=1 covers the plain unet_model_3d / unet_model_2d step (no normalisation layers, "
+                                              "UpSampling up-convolution): the normalisation statistics and the folded transposed conv still "
+                                              "accumulate with floating-point atomics")
+                self.G64 = torch.zeros(self.n_flat, dtype=torch.int64, device=dev)
+                ops.set_deterministic(self.G, self.G64)
         # compute-dtype copies of the 3x3x3 filters
         self.Wf, self.Wd, self.Wup = {}, {}, {}
         self.upcat = self._upcat_layers()
@@ -355,7 +366,7 @@ class UNetEngine:
         import os
         p = self.plan
         out = {}
-        self.upcat_wgrad = set()                           # ... of which the weight gradient takes the parity form too
+        self.upcat_wgrad = set()                           # ... of which the weight gradient takes the parity form too (never in deterministic mode)
         if self.dtype != torch.bfloat16 or os.environ.get("FMRI_UPCAT", "1") == "0":
             return out
         for lv in p.dec:
@@ -369,7 +380,7 @@ class UNetEngine:
             ok = ops.conv3d_upcat_ok(c0, c1, a["cout"], D, H, W, self.dtype, planar=self.planar)
             if ok & 1:
                 out[a["name"]] = (c0, c1)
-                if ok & 2:
+                if ok & 2 and not self.deterministic:
                     self.upcat_wgrad.add(a["name"])
         return out
 
@@ -809,6 +820,8 @@ class UNetEngine:
                 ops.conv3d_dgrad(Gd[ca["name"]], self.Wd[ca["name"]], Gd["pool_%d" % (ld - 1)], planar=self.planar)
         if self._wg_stream is not None:
             torch.cuda.current_stream(self.dev).wait_stream(self._wg_stream)
+        if self.deterministic:
+            ops.deterministic_finish(self.G, self.G64)       # G += the fixed-point sums of every gradient kernel of this pass
         if self.dist is not None:
             self.dist.finish(self)
 

@@ -263,6 +263,18 @@ class LayerGraphEngine(object):
                 base += self.shape[i][0] if (i != self.input_name or self.input_grad) else c
             cinp = base
             c64 = ((coutp + 63) // 64) * 64                  # the weight-gradient kernel may be fed a dy zero-extended to 64 channels
+            # ... unless the kd-sharing weight-gradient kernel (32 x 32 blocks) takes the 32-channel dy as it is: then the gradient image
+            # has the filter's own 32 rows per tap.  Decided once, for batch 1 (larger batches only raise the launch's FLOPs, the threshold)
+            self._c32 = getattr(self, "_c32", {})
+            self._c32[name] = False
+            if coutp % 64 and not self.planar and self.dtype == torch.bfloat16 and op["k"] == 3:
+                from ._lib import lib, BF16
+                sp = tuple(self.shape[op["ins"][0]][1:]) if op.get("sub") is not None else tuple(self.shape[name][1:])
+                if op["up0"] and op.get("sub") is None:
+                    pass                                      # (fused up-sampling: the per-kd kernel)
+                elif len(sp) == 3 and lib().fmri_conv3d_wgrad_cout32_ok(cinp, 0, coutp, 1, sp[0], sp[1], sp[2], BF16, 0, 0):
+                    self._c32[name] = True
+                    c64 = coutp
             geo[name] = (coutp, cinp, c64, np.asarray(idx, np.int64))
             self.cin_map[name] = torch.tensor(idx, dtype=torch.long, device=dev)
             segs_p += [((name, "w"), (27, coutp, cinp)), ((name, "b"), (coutp,))]
@@ -700,8 +712,9 @@ class LayerGraphEngine(object):
                         if self.pad:
                             dwp, dbp = self.dWp[name], self.dbp[name]          # views of Gp (zeroed once per backward, gathered at the end)
                             gw = g
-                            if g.shape[-1] % 64:
-                                # the MFMA weight-gradient kernel tiles Cout by 64: hand it a zero-extended copy of dy (the extra rows of dw stay 0)
+                            if g.shape[-1] % 64 and not self._c32.get(name, False):
+                                # the per-kd MFMA weight-gradient kernel tiles Cout by 64: hand it a zero-extended copy of dy (the extra rows of
+                                # dw stay 0) - unless the kd-sharing kernel (32 x 32 blocks) takes the launch as it is
                                 gw = self._dy64(g)
                             if name in self.Wup and self.Wup[name]["wgrad"] and gw is g:
                                 ops.conv3d_upcat_wgrad(s0, None, g, dwp, dbp, self.dwc_scratch)

@@ -354,6 +354,23 @@ def loss_value_from_sums(s, kind, param=1.0, smooth=1.0):
     return -dice + param * (2 * (Sp - I) + smooth) / ((n - Sy) + Sp + smooth)
 
 
+def set_deterministic(grad, shadow):
+    """register (fp32 gradient buffer, zeroed int64 shadow of the same length) for bit-reproducible gradient accumulation, or (None, None)
+    to switch it off (include/fmri_hip.h: fmri_set_deterministic); process-wide"""
+    if grad is None:
+        check(lib().fmri_set_deterministic(0, 0, 0), "fmri_set_deterministic")
+        return
+    _need_cuda(grad, shadow)
+    assert grad.dtype == torch.float32 and shadow.dtype == torch.int64 and shadow.numel() == grad.numel() and grad.is_contiguous() and shadow.is_contiguous()
+    check(lib().fmri_set_deterministic(_p(grad), _p(shadow), grad.numel()), "fmri_set_deterministic")
+
+
+def deterministic_finish(grad, shadow):
+    """grad += shadow * 2^-40, shadow = 0: once per backward pass, behind every gradient kernel"""
+    _need_cuda(grad, shadow)
+    check(lib().fmri_deterministic_finish(_p(grad), _p(shadow), grad.numel(), _s()), "fmri_deterministic_finish")
+
+
 def conv3d_wgrad_workspace_bytes(C0, C1, Cout, N, D, H, W, dtype, planar=False):
     d = BF16 if dtype == torch.bfloat16 else F32
     return int(lib().fmri_conv3d_wgrad_workspace_bytes(C0, C1, Cout, N, D, H, W, d, int(planar)))

@@ -77,6 +77,10 @@ int fmri_conv3d_dgrad(const void* dy, int Cout, const void* w_dgrad, const void*
 int fmri_conv3d_wgrad(const void* src0, int C0, int up0, const void* src1, int C1, const void* dy, float* dw, float* db,
                       int N, int D, int H, int W, int Cout, int dtype, int impl, int planar, void* workspace,
                       int64_t workspace_bytes, fmri_stream_t stream);
+/* 1 when fmri_conv3d_wgrad takes a dy whose channel count is a multiple of 32 but not of 64 on the MFMA path (the kd-sharing kernel with its
+ * 32 x 32 blocks takes the launch: bf16, 3-D, no fused up-sampling, >= 0.1 TFLOP; the call then ignores any workspace) - otherwise such a
+ * launch runs on the generic kernel, and callers that want MFMA speed hand over a zero-extended 64-channel copy of dy. */
+int fmri_conv3d_wgrad_cout32_ok(int C0, int C1, int Cout, int N, int D, int H, int W, int dtype, int planar, int up0);
 /* bytes of workspace fmri_conv3d_wgrad can use for this shape (0: the shape does not take the slab path) */
 int64_t fmri_conv3d_wgrad_workspace_bytes(int C0, int C1, int Cout, int N, int D, int H, int W, int dtype, int planar);
 
@@ -256,6 +260,17 @@ int fmri_slice_channels(const void* src, int ld, int off, void* dst, int C, int6
                         fmri_stream_t stream);
 /* y[n][v][c] = x[n][v][c] * scale[n][c] — SpatialDropout3D (reference isensee2017.py:109): the host draws the 0 | 1/(1-p) mask */
 int fmri_channel_scale(const void* x, const float* scale, void* y, int N, int64_t V, int C, int dtype, fmri_stream_t stream);
+
+/* ---- bit-reproducible gradients (round 3).  The default step adds workgroups' partial sums to the gradient buffer with fp32 atomics, in
+ * arrival order.  After fmri_set_deterministic(G, shadow, n) - G the fp32 gradient buffer every dw / db pointer of the following calls
+ * points into, shadow n zeroed int64 - those partial sums are rounded to 2^-40 fixed point and added with 64-bit integer atomics to
+ * shadow[i] instead (integer adds commute exactly); fmri_deterministic_finish adds shadow * 2^-40 to G and clears it (call it once per
+ * backward pass, after every gradient kernel, before the optimizer).  The metric sums of fmri_sigmoid_dice_fwd meet the same way (2^-20).
+ * Process-wide state (one engine at a time); (NULL, NULL, 0) switches it off.  Covered: the 3x3x3 / first-layer / 1x1x1 / direct
+ * weight and bias gradients of the plain U-Net step; NOT covered: the parity-form weight gradient's scratch (fmri_conv3d_upcat_wgrad*:
+ * use fmri_conv3d_wgrad with up0), the normalisation statistics, fmri_weighted_dice_fwd, fmri_border_class_sums. */
+int fmri_set_deterministic(float* grad_base, void* shadow_i64, int64_t n);
+int fmri_deterministic_finish(float* grad_base, void* shadow_i64, int64_t n, fmri_stream_t stream);
 
 /* ---- Keras Adam.get_updates — reference unet.py:85.  lr_t = lr*sqrt(1-b2^t)/(1-b1^t) is computed by the host.
  * g is multiplied by grad_scale first.  p -= lr_t * m/(sqrt(v)+eps). One launch over the flat parameter buffer. */

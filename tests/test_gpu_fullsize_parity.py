@@ -428,3 +428,105 @@ def test_kd_sharing_weight_gradient_kernels_are_exact(tmp_path):
         assert float(np.abs(res[2][k]).max()) > 0
         assert np.array_equal(res[0][k], res[2][k]), ("kd32", k)
         assert np.array_equal(res[1][k], res[2][k]), ("kd64", k)
+
+
+# ---------------------------------------------------------------------------------------------------------- deterministic mode
+def test_bench_step_is_bit_reproducible_in_deterministic_mode(monkeypatch):
+    """FMRI_DETERMINISTIC=1 at the size bench.py times (depth 4 / 32 filters, 4 x 64x128x128, bf16, two gradient streams): the same weights
+    and batch give the SAME BITS in every gradient element and metric sum, pass after pass, and two optimizer steps from the same state end in
+    bit-identical parameters.  (The default mode adds workgroups' partial sums with fp32 atomics in arrival order; here they meet as 2^-40
+    fixed-point integers in a shadow of the gradient buffer - include/fmri_hip.h, fmri_set_deterministic.)  The deterministic gradients
+    agree with the default mode's to fp32 summation-order accuracy."""
+    from fmri_hip import ops
+    from fmri_hip.engine import UNetEngine, UNetPlan
+    import bench
+    N = 4
+    x, y = bench.synthetic_batch((N, 1) + SPATIAL)
+    xd = torch.from_numpy(x).cuda().to(torch.bfloat16).reshape(N, *SPATIAL, 1).contiguous()
+    yd = torch.from_numpy(y).cuda().reshape(-1).contiguous()
+    plan = UNetPlan(1, SPATIAL, depth=4, n_base_filters=32)
+    monkeypatch.setenv("FMRI_DETERMINISTIC", "1")
+    eng = UNetEngine(plan, N, dtype=torch.bfloat16, seed=42)
+    try:
+        assert eng.deterministic and not eng.upcat_wgrad and eng._wg_stream is not None
+        P0 = eng.P.clone()
+        runs = []
+        for _ in range(3):
+            eng.forward(xd)
+            s = eng.loss_forward(yd).clone()
+            eng.backward(yd)
+            torch.cuda.synchronize()
+            runs.append((eng.G.clone(), s, eng.logits.clone()))
+        for G, s, lg in runs[1:]:
+            assert torch.equal(G, runs[0][0]), "gradients differ between two passes: %d elements" % int((G != runs[0][0]).sum())
+            assert torch.equal(s, runs[0][1]) and torch.equal(lg, runs[0][2])
+        assert int(eng.G64.abs().max()) == 0                      # the shadow is cleared by the finish
+        assert float(runs[0][0].abs().max()) > 0
+        ends = []
+        for _ in range(2):
+            eng.P.copy_(P0)
+            eng.M.zero_()
+            eng.V.zero_()
+            eng.t = 0
+            eng.refresh_weight_copies()
+            for _ in range(2):
+                eng.train_step(xd, yd, 1e-4)
+            torch.cuda.synchronize()
+            ends.append(eng.P.clone())
+        assert torch.equal(ends[0], ends[1]) and not torch.equal(ends[0], P0)
+    finally:
+        ops.set_deterministic(None, None)
+    # against the default mode (fp32 atomics, parity-form weight gradient): same gradients up to summation order / the parity form's rounding
+    monkeypatch.setenv("FMRI_DETERMINISTIC", "0")
+    ref = UNetEngine(plan, N, dtype=torch.bfloat16, seed=42)
+    assert not ref.deterministic
+    ref.forward(xd)
+    ref.loss_forward(yd)
+    ref.backward(yd)
+    torch.cuda.synchronize()
+    assert torch.equal(ref.logits, runs[0][2])
+    g0, g1 = runs[0][0].double(), ref.G.double()
+    for name, L in ref.layout.items():
+        o, n = L["w"]
+        e = float((g0[o:o + n] - g1[o:o + n]).norm() / (g1[o:o + n].norm() + 1e-30))
+        assert e < (2e-2 if name in ref.upcat_wgrad else 1e-4), (name, e)
+
+
+def test_folded_transposed_conv_at_full_size_vs_the_two_step_form(monkeypatch):
+    """`deconvolution=True` at the benchmark's size (depth 4 / 32 filters, 1 x 64x128x128, bf16): the folded form (one parity-form conv of
+    the low-res tensor per decoder level, fmri_hip/deconv_fold.py) against the two-step form (transposed conv materialised, then the plain
+    27-tap conv over the concatenation) on the same weights - non-zero biases everywhere - and batch: logits, Dice and every gradient tensor,
+    the transposed convs' included.  Both are bf16 paths with different rounding points (the two-step form rounds the up-sampled tensor to
+    bf16, the folded one the pre-multiplied filters), so the bars are those of the bf16-vs-fp32 comparisons of this file."""
+    from fmri_hip.engine import UNetEngine, UNetPlan
+    import bench
+    x, y = bench.synthetic_batch((1, 1) + SPATIAL)
+    xd = torch.from_numpy(x).cuda().to(torch.bfloat16).reshape(1, *SPATIAL, 1).contiguous()
+    yd = torch.from_numpy(y).cuda().reshape(-1).contiguous()
+    res = {}
+    for fold in ("1", "0"):
+        monkeypatch.setenv("FMRI_DECONV_FOLD", fold)
+        eng = UNetEngine(UNetPlan(1, SPATIAL, depth=4, n_base_filters=32, deconvolution=True), 1, dtype=torch.bfloat16, seed=42)
+        assert len(eng.Wfd) == (3 if fold == "1" else 0)
+        g = torch.Generator().manual_seed(5)
+        for name, L in eng.layout.items():
+            o, n = L["b"]
+            eng.P[o:o + n] = (torch.rand(n, generator=g) - 0.5).cuda() * 0.2
+        eng.refresh_weight_copies()
+        eng.forward(xd)
+        s = eng.loss_forward(yd).cpu().numpy()
+        eng.backward(yd)
+        torch.cuda.synchronize()
+        res[fold] = (eng.logits.float().cpu().numpy().copy(), eng.metrics_from_sums(s)["dice_coefficient"], eng.G.cpu().numpy().copy(), eng.layout)
+        del eng
+        torch.cuda.empty_cache()
+    la, da, ga, layout = res["1"]
+    lb, db_, gb, _ = res["0"]
+    e_log = _rel(la, lb)
+    worst = 0.0
+    for name, L in layout.items():
+        for key in ("w", "b"):
+            o, n = L[key]
+            worst = max(worst, _l2(ga[o:o + n], gb[o:o + n]))
+    print("MEASURED deconv fold vs two-step: logits %.3e dice %.3e worst grad l2 %.3e" % (e_log, abs(da - db_), worst))
+    assert e_log <= 2.0e-2 and abs(da - db_) <= 2e-5 and worst <= 3.0e-2, (e_log, abs(da - db_), worst)
