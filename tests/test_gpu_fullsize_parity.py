@@ -529,4 +529,5 @@ def test_folded_transposed_conv_at_full_size_vs_the_two_step_form(monkeypatch):
             o, n = L[key]
             worst = max(worst, _l2(ga[o:o + n], gb[o:o + n]))
     print("MEASURED deconv fold vs two-step: logits %.3e dice %.3e worst grad l2 %.3e" % (e_log, abs(da - db_), worst))
-    assert e_log <= 2.0e-2 and abs(da - db_) <= 2e-5 and worst <= 3.0e-2, (e_log, abs(da - db_), worst)
+    # bars = 2 x measured on MI355X (round 3): logits 7.2e-3, Dice 5.4e-7, worst gradient tensor 1.34e-2
+    assert e_log <= 1.5e-2 and abs(da - db_) <= 1.1e-6 and worst <= 2.7e-2, (e_log, abs(da - db_), worst)
