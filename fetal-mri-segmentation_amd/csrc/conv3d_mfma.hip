@@ -494,10 +494,13 @@ k_conv_fwd_mfma(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__
                     const float4 a1 = *reinterpret_cast<const float4*>(stage + rr * (BN * 4) + ((((2 * q8 + 1) ^ rr) & (PPV - 1)) << 4));
                     const int64_t ao = org + ((tile_d(rt) * H + tile_h(rt, rr)) * W + lane_w(rr)) * Cout + q8 * 8;
                     const uint4 r4 = *reinterpret_cast<const uint4*>(residual + ao);
-                    float o[8] = {a0.x + __uint_as_float(r4.x << 16), a0.y + __uint_as_float(r4.x & 0xffff0000u),
-                                  a0.z + __uint_as_float(r4.y << 16), a0.w + __uint_as_float(r4.y & 0xffff0000u),
-                                  a1.x + __uint_as_float(r4.z << 16), a1.y + __uint_as_float(r4.z & 0xffff0000u),
-                                  a1.z + __uint_as_float(r4.w << 16), a1.w + __uint_as_float(r4.w & 0xffff0000u)};
+                    // (the partial sum is rounded to bf16 before the residual is added - what the asynchronous form, EPI 3 of k_conv_fwd_ws,
+                    // stages: every form of this launch gives the same bits, whichever one the grid size selects)
+                    const unsigned p0 = pack2bf(a0.x, a0.y), p1 = pack2bf(a0.z, a0.w), p2 = pack2bf(a1.x, a1.y), p3 = pack2bf(a1.z, a1.w);
+                    float o[8] = {__uint_as_float(p0 << 16) + __uint_as_float(r4.x << 16), __uint_as_float(p0 & 0xffff0000u) + __uint_as_float(r4.x & 0xffff0000u),
+                                  __uint_as_float(p1 << 16) + __uint_as_float(r4.y << 16), __uint_as_float(p1 & 0xffff0000u) + __uint_as_float(r4.y & 0xffff0000u),
+                                  __uint_as_float(p2 << 16) + __uint_as_float(r4.z << 16), __uint_as_float(p2 & 0xffff0000u) + __uint_as_float(r4.z & 0xffff0000u),
+                                  __uint_as_float(p3 << 16) + __uint_as_float(r4.w << 16), __uint_as_float(p3 & 0xffff0000u) + __uint_as_float(r4.w & 0xffff0000u)};
 #pragma unroll
                     for (int i = 0; i < 8; ++i) o[i] = vmax(o[i], __builtin_fmaf(o[i], act_s, 0.f));
                     *reinterpret_cast<uint4*>(y + ao) = make_uint4(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]), pack2bf(o[4], o[5]), pack2bf(o[6], o[7]));
@@ -668,6 +671,12 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
     constexpr int PH0 = PL ? 3 : 0;
     constexpr bool ASY = ASYNC && !RES && !PL && MODE == 0;
     constexpr bool HAS_MASK = EPI < 0 || EPI == 1, HAS_LOGITS = EPI < 0 || EPI == 2, HAS_POOL = EPI <= 0;
+    // EPI 3 (ASYNC only): y = act(staged + residual) - the skip launch of the parity form.  The MFMA waves stage bf16(acc + bias) WITHOUT the
+    // activation; the producers add the residual lines (prefetched like the mask lines) in fp32, activate, round and store.  One bf16 rounding
+    // more than the RES epilogue (which adds the residual to the fp32 accumulators): both partial sums of the parity form - the up-sampled
+    // channels' (stored as bf16 by the MODE 1 launch) and now the skip channels' - are rounded before they meet.
+    constexpr bool HAS_RESID = EPI == 3;
+    constexpr bool HAS_LINES = HAS_MASK || HAS_RESID;      // per-store 16-byte lines the producers prefetch into mk[]
     // the producers drain a staged tile in DP parts, one per phase, in phases 0 .. DP-1 of the next tile's first item (one part fits a
     // phase beside the filter slab's DMA; the whole drain in phase 0 made the producers late for the phase-1 barrier: measured 8 % SLOWER
     // than the synchronous epilogue); the halo pieces of that item's successor follow in phases DP .. NPH-2
@@ -765,6 +774,7 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
     // store_share they sat in every part of the asynchronous drain, in front of its stores
     float4 w1a = make_float4(0.f, 0.f, 0.f, 0.f), w1b = w1a;
     float b1v = 0.f;
+    const float act_s = act == FMRI_ACT_RELU ? 0.f : (act == FMRI_ACT_LEAKY ? alpha : 1.f);
     if constexpr (MODE == 0 && !RES && HAS_LOGITS) {
         if (tail.logits) {
             w1a = *reinterpret_cast<const float4*>(tail.w1 + (lane % CPV_) * 8);
@@ -798,6 +808,21 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
                 for (int i = 0; i < 4; ++i) {
                     if (!(__uint_as_float(mm[i] << 16) > 0.f)) oo[i] &= 0xffff0000u;
                     if (!(__uint_as_float(mm[i] & 0xffff0000u) > 0.f)) oo[i] &= 0x0000ffffu;
+                }
+            }
+            if constexpr (HAS_RESID) {
+                uint4 r4;
+                if constexpr (PRE) r4 = mk[kk];
+                else r4 = *reinterpret_cast<const uint4*>(residual + ao);
+                const unsigned rr4[4] = {r4.x, r4.y, r4.z, r4.w};
+                unsigned* const oo = reinterpret_cast<unsigned*>(&o4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float lo = __uint_as_float(oo[i] << 16) + __uint_as_float(rr4[i] << 16);
+                    float hi = __uint_as_float(oo[i] & 0xffff0000u) + __uint_as_float(rr4[i] & 0xffff0000u);
+                    lo = vmax(lo, __builtin_fmaf(lo, act_s, 0.f));          // act(v) = max(v, s v), s = 0 ReLU / alpha LeakyReLU / 1 none
+                    hi = vmax(hi, __builtin_fmaf(hi, act_s, 0.f));
+                    oo[i] = pack2bf(lo, hi);
                 }
             }
             *reinterpret_cast<uint4*>(y + ao) = o4;
@@ -957,7 +982,7 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
         };
         // ASY: the finished tile waiting to be stored (staged by the consumers in halo slot `hb ^ 1` as seen from the next item), the mask
         // lines of this wave's share of it, and the number of vector-memory instructions the drain issues behind the phase-1 filter slab
-        constexpr int NDR = (ASY && HAS_MASK) ? 512 / (DW * VPI_) : 1;
+        constexpr int NDR = (ASY && HAS_LINES) ? 512 / (DW * VPI_) : 1;
         uint4 mk[NDR] = {};
         FwdItem done = cur;
         bool pending = false;
@@ -1001,7 +1026,7 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
                         if constexpr (DRN) {
                             // the mask lines requested in the previous tile's last phase are in their registers now: tell the compiler here,
                             // where it costs nothing (its own wait for them would otherwise sit behind the next filter slab's DMA)
-                            if (HAS_MASK && mask) {
+                            if ((HAS_MASK && mask) || HAS_RESID) {
 #pragma unroll
                                 for (int i = 0; i < NDR; ++i) asm volatile("" : "+v"(mk[i].x), "+v"(mk[i].y), "+v"(mk[i].z), "+v"(mk[i].w));
                             }
@@ -1030,11 +1055,12 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
                     }
                     if constexpr (ASY) {
                         // last phase of a tile (it carries no halo pieces): request the mask lines of this wave's share of the tile's stores
-                        if (HAS_MASK && pl == NPH - 1 && cur.ch == nch - 1 && mask) {
+                        if (pl == NPH - 1 && cur.ch == nch - 1 && ((HAS_MASK && mask) || HAS_RESID)) {
+                            const bf16_t* const lines = HAS_RESID ? residual : mask;      // (the residual of a tile is read before anyone stores to it)
 #pragma unroll
                             for (int kk = 0; kk < NDR; ++kk) {
                                 const int v = dwv * (512 / DW) + kk * VPI_ + lane / CPV_;
-                                mk[kk] = *reinterpret_cast<const uint4*>(mask + piece_addr(cur, v, lane % CPV_));
+                                mk[kk] = *reinterpret_cast<const uint4*>(lines + piece_addr(cur, v, lane % CPV_));
                             }
                         }
                     }
@@ -1071,7 +1097,6 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
     // ---------------------------------------------------------------------------------------------------------------- consumer
     const int cw = wv;
     f32x16 acc[JT][NT];
-    const float act_s = act == FMRI_ACT_RELU ? 0.f : (act == FMRI_ACT_LEAKY ? alpha : 1.f);
     auto load_bias = [&](int co0, float4 (&bv)[NT][4]) {
 #pragma unroll
         for (int c = 0; c < NT; ++c)
@@ -1125,7 +1150,7 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
         hv0[j] = (tile_d(rt) * HH + tile_h(rt, r)) * HW + lane_w(r);
     }
     const int fa[2] = {swz64(r, hk), swz64(r, hk) ^ 32};
-    if (RES && tail.bias27) init_acc_b27(cur);
+    if ((RES || HAS_RESID) && tail.bias27) init_acc_b27(cur);
     else {
         float4 bv0[NT][4];
         load_bias(cur.co0, bv0);
@@ -1278,10 +1303,13 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
                     const float4 a1 = *reinterpret_cast<const float4*>(stage + rr * (BN * 4) + ((((2 * q8 + 1) ^ rr) & (PPV - 1)) << 4));
                     const int64_t ao = org + ((tile_d(rt) * H + tile_h(rt, rr)) * W + lane_w(rr)) * Cout + q8 * 8;
                     const uint4 r4 = res_q[j & (RAHEAD - 1)][kk];
-                    float o[8] = {a0.x + __uint_as_float(r4.x << 16), a0.y + __uint_as_float(r4.x & 0xffff0000u),
-                                  a0.z + __uint_as_float(r4.y << 16), a0.w + __uint_as_float(r4.y & 0xffff0000u),
-                                  a1.x + __uint_as_float(r4.z << 16), a1.y + __uint_as_float(r4.z & 0xffff0000u),
-                                  a1.z + __uint_as_float(r4.w << 16), a1.w + __uint_as_float(r4.w & 0xffff0000u)};
+                    // (the partial sum is rounded to bf16 before the residual is added - what the asynchronous form, EPI 3 of k_conv_fwd_ws,
+                    // stages: every form of this launch gives the same bits, whichever one the grid size selects)
+                    const unsigned p0 = pack2bf(a0.x, a0.y), p1 = pack2bf(a0.z, a0.w), p2 = pack2bf(a1.x, a1.y), p3 = pack2bf(a1.z, a1.w);
+                    float o[8] = {__uint_as_float(p0 << 16) + __uint_as_float(r4.x << 16), __uint_as_float(p0 & 0xffff0000u) + __uint_as_float(r4.x & 0xffff0000u),
+                                  __uint_as_float(p1 << 16) + __uint_as_float(r4.y << 16), __uint_as_float(p1 & 0xffff0000u) + __uint_as_float(r4.y & 0xffff0000u),
+                                  __uint_as_float(p2 << 16) + __uint_as_float(r4.z << 16), __uint_as_float(p2 & 0xffff0000u) + __uint_as_float(r4.z & 0xffff0000u),
+                                  __uint_as_float(p3 << 16) + __uint_as_float(r4.w << 16), __uint_as_float(p3 & 0xffff0000u) + __uint_as_float(r4.w & 0xffff0000u)};
 #pragma unroll
                     for (int i = 0; i < 8; ++i) o[i] = vmax(o[i], __builtin_fmaf(o[i], act_s, 0.f));
                     *reinterpret_cast<uint4*>(y + ao) = make_uint4(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]), pack2bf(o[4], o[5]), pack2bf(o[6], o[7]));
@@ -1345,11 +1373,12 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
                     }
                 }
             };
-            if (act == FMRI_ACT_NONE) stage_tile(std::integral_constant<int, FMRI_ACT_NONE>{});
+            if (HAS_RESID || act == FMRI_ACT_NONE) stage_tile(std::integral_constant<int, FMRI_ACT_NONE>{});     // (EPI 3: the producers activate)
             else if (act == FMRI_ACT_RELU) stage_tile(std::integral_constant<int, FMRI_ACT_RELU>{});
             else stage_tile(std::integral_constant<int, FMRI_ACT_LEAKY>{});
             PROF_T(e2);
-            init_acc(bvn);
+            if (HAS_RESID && tail.bias27) init_acc_b27(has_next ? nxt : cur);
+            else init_acc(bvn);
             if constexpr (ASY) {
                 // the producers store the staged tile under the next tile's first phases; the "staged" barrier is that tile's phase-0 barrier
                 if (!has_next) __builtin_amdgcn_s_barrier();           // (the workgroup's last tile: the producers store it right away)
@@ -2210,7 +2239,22 @@ static int conv3d_fwd_mfma_launch(int mode, const void* src0, int C0, int up0, i
     } else if (residual && planar) {
         if (wide) FMRI_LAUNCH_FWD(2, true, 0, true); else FMRI_LAUNCH_FWD(1, true, 0, true);
     } else if (residual) {
-        if (wide) FMRI_LAUNCH_FWD(2, false, 0, true); else FMRI_LAUNCH_FWD(1, false, 0, true);
+        // the residual added by the producers in the asynchronous drain (EPI 3) - FMRI_RES_ASYNC=0 keeps the RES epilogue on the MFMA waves.
+        // Both add bf16(partial sum) + residual in fp32: the same bits from either, so a result does not depend on the grid size
+        static int res_async = -1;
+        if (res_async < 0) {
+            const char* e = getenv("FMRI_RES_ASYNC");
+            res_async = e ? atoi(e) : 1;
+        }
+        const int np_ = ntile * (Cout / (wide ? 64 : 32));
+        if (res_async && use_ws && fwd_async() && np_ > ncu && !mask && !tail.pool && !tail.logits) {
+            if (wide)
+                k_conv_fwd_ws<2, false, 0, false, true, 3><<<ncu, fw::NTHREADS, 0, st>>>(s, (const bf16_t*)w, bias, nullptr, (const bf16_t*)residual,
+                                                                                          (bf16_t*)y, N, D, H, W, Cout, act, alpha, tail);
+            else
+                k_conv_fwd_ws<1, false, 0, false, true, 3><<<ncu, fw::NTHREADS, 0, st>>>(s, (const bf16_t*)w, bias, nullptr, (const bf16_t*)residual,
+                                                                                          (bf16_t*)y, N, D, H, W, Cout, act, alpha, tail);
+        } else if (wide) FMRI_LAUNCH_FWD(2, false, 0, true); else FMRI_LAUNCH_FWD(1, false, 0, true);
     } else if (wide) {
         if (planar) FMRI_LAUNCH_FWD(2, true, 0, false); else FMRI_LAUNCH_FWD(2, false, 0, false);
     } else {

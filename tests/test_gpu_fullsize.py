@@ -174,6 +174,13 @@ dy = rnd((N, D, H, W, Cout)); dxl, dxs = torch.empty_like(xl), torch.empty_like(
 ops.conv3d_upcat_dgrad(dy, up_d, sk_d, rnd(tuple(xl.shape)), None, dxl, dxs)
 torch.cuda.synchronize()
 out["up_fwd"], out["up_dxl"], out["up_dxs"] = (t.view(torch.int16).cpu().numpy() for t in (y, dxl, dxs))
+# the same with more tiles than CUs (288): the skip launch takes the asynchronous residual epilogue unless FMRI_RES_ASYNC=0
+N, D, H, W = 3, 16, 32, 96
+xl, xs = rnd((N, D // 2, H // 2, W // 2, C0)), rnd((N, D, H, W, C1))
+y = torch.empty((N, D, H, W, Cout), device="cuda", dtype=torch.bfloat16)
+ops.conv3d_upcat_fwd(xl, xs, up_f, sk_f, torch.randn(Cout, generator=g).cuda(), y, act=2, alpha=0.01)
+torch.cuda.synchronize()
+out["up_fwd_big"] = y.view(torch.int16).cpu().numpy()
 np.savez(sys.argv[1], **out)
 print("DONE")
 """
@@ -182,21 +189,26 @@ print("DONE")
 def test_warp_specialised_kernel_is_bit_identical_to_the_symmetric_one(tmp_path):
     """k_conv_fwd_ws (4 MFMA waves + 4 LDS-DMA waves) against k_conv_fwd_mfma (FMRI_FWD_WS=0) on the same seeded inputs: both accumulate
     every output in the same (chunk, (kd,kh), kw, k-step) order, so forward, input gradients (with and without mask), dual-source /
-    fused-upsample reads and the parity-form launches must agree BIT FOR BIT - any race in the producer/consumer hand-over shows up here."""
+    fused-upsample reads and the parity-form launches must agree BIT FOR BIT - any race in the producer/consumer hand-over shows up here.
+    Third run: FMRI_RES_ASYNC=0 (the skip launch's residual added by the MFMA waves instead of the LDS-DMA waves' drain) - the same bits
+    again, so a result does not depend on which form the grid size selects."""
     import subprocess, sys, os
     import numpy as np
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     f = tmp_path / "ws.py"
     f.write_text(WS_SCRIPT % root)
     outs = []
-    for ws in ("1", "0"):
-        o = str(tmp_path / ("out%s.npz" % ws))
-        r = subprocess.run([sys.executable, str(f), o], capture_output=True, text=True, timeout=600, env=dict(os.environ, FMRI_FWD_WS=ws))
+    for ws, ra in (("1", "1"), ("0", "1"), ("1", "0")):
+        o = str(tmp_path / ("out%s%s.npz" % (ws, ra)))
+        r = subprocess.run([sys.executable, str(f), o], capture_output=True, text=True, timeout=600,
+                           env=dict(os.environ, FMRI_FWD_WS=ws, FMRI_RES_ASYNC=ra))
         assert r.returncode == 0 and "DONE" in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])
         outs.append(np.load(o))
-    assert set(outs[0].files) == set(outs[1].files) and len(outs[0].files) >= 13
-    for k in outs[0].files:
-        assert np.array_equal(outs[0][k], outs[1][k]), k
+    assert len(outs[0].files) >= 14
+    for other in outs[1:]:
+        assert set(outs[0].files) == set(other.files)
+        for k in outs[0].files:
+            assert np.array_equal(outs[0][k], other[k]), k
 
 
 def test_bench_contract_line(tmp_path):

@@ -173,8 +173,9 @@ def test_forward_is_exact_on_dyadic_data_at_full_size(case):
     """x = k/4 (|x| <= 1), w = k/8 (|w| <= 1/4), bias = k/4: every term is a multiple of 1/32 and the sum of <= 27*192 of them stays
     below 2^24/32, i.e. exact in fp32 in ANY order; the kernel's only rounding is the final bf16 store (RNE = torch's .to(bfloat16)).
     enc0b_n2: 2 x 64x128x128, 32 -> 64 (1,024 tiles: several compact XCD blocks per XCD); dec0a: [up2(128) | 64] -> 64 at 64x128x128
-    as fused-upsample 27-tap launch and in parity form (there the up-sampled channels' partial sum is stored as bf16 once more - the
-    expected value applies that rounding too)."""
+    as fused-upsample 27-tap launch and in parity form (there the up-sampled channels' partial sum is stored as bf16 once more and the
+    skip channels' partial sum is rounded to bf16 before the two meet in fp32: the expected value applies those roundings too; every step
+    in between is exact, so the comparison stays bit for bit)."""
     from fmri_hip import ops
     torch.set_num_threads(min(32, os.cpu_count() or 1))
     g = torch.Generator().manual_seed(11)
@@ -199,7 +200,8 @@ def test_forward_is_exact_on_dyadic_data_at_full_size(case):
         ops.conv3d_upcat_fwd(x0d, x1d, up_f, sk_f, bias.cuda(), y, act=1)
         part_up = _cpu_conv_ndhwc(_up2(x0), w[:, :, :C0].contiguous())            # exact; the kernel stores it as bf16 ...
         part_up = part_up.to(bf).float()
-        expect = F.relu(part_up + _cpu_conv_ndhwc(x1, w[:, :, C0:].contiguous(), bias))   # ... and adds the skip part + bias in fp32
+        part_sk = _cpu_conv_ndhwc(x1, w[:, :, C0:].contiguous(), bias).to(bf).float()   # ... the skip part + bias is rounded to bf16 too, and the two meet in fp32
+        expect = F.relu(part_up + part_sk)
     else:
         ops.conv3d_fwd(x0d, x1d, w.to(bf).cuda(), bias.cuda(), y, up0=(case != "enc0b_n2"), act=1)
         xin = x0 if x1 is None else torch.cat([_up2(x0), x1], dim=-1)

@@ -873,8 +873,8 @@ def _upcat_fuzz_cases(n=8, seed=77):
 def test_parity_form_fuzz_is_exact_on_dyadic_data(ops, case):
     """the parity form of UpSampling3D -> concatenate -> Conv3D on random grids with small dyadic values: the pre-summed filters are exact
     in bf16, every product and partial sum exact in fp32, so both input gradients and the weight gradient must equal the plain definition
-    bit for bit, and the forward result the plain definition with the one documented intermediate rounding (the up-sampled channels'
-    partial sum passes through bf16 between the two launches when there is a skip source)"""
+    bit for bit, and the forward result the plain definition with the two documented intermediate roundings (with a skip source both
+    launches' partial sums pass through bf16 before they meet in fp32)"""
     N, D, H, W, C0, C1, Cout = case
     bf = torch.bfloat16
     if not (ops.conv3d_upcat_ok(C0, C1, Cout, D, H, W, bf) & 1):
@@ -897,9 +897,9 @@ def test_parity_form_fuzz_is_exact_on_dyadic_data(ops, case):
     y = torch.empty((N, D, H, W, Cout), dtype=bf, device="cuda")
     ops.conv3d_upcat_fwd(x_low.to(bf).cuda(), None if not C1 else x_skip.to(bf).cuda(), up_f, sk_f, bias.cuda(), y, act=1)
     if C1:
-        # two launches: the up-sampled channels' partial sum is stored as bf16, the skip launch adds its own sum + bias in fp32 on top
+        # two launches: the up-sampled channels' partial sum is stored as bf16, the skip launch rounds its own sum + bias to bf16 and adds the two in fp32
         part = F.conv3d(ref_concat_input(x_low, None, True), wk.detach()[:, :C0].contiguous(), None, padding=1).to(bf).float()
-        want = F.relu(part + F.conv3d(to_ncdhw(x_skip), wk.detach()[:, C0:].contiguous(), bias, padding=1))
+        want = F.relu(part + F.conv3d(to_ncdhw(x_skip), wk.detach()[:, C0:].contiguous(), bias, padding=1).to(bf).float())
     else:
         want = F.relu(pre).detach()
     assert torch.equal(y.cpu().view(torch.int16), to_ndhwc(want).to(bf).view(torch.int16)), "forward"
