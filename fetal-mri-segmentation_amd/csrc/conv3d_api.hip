@@ -26,6 +26,13 @@ int conv3d_fwd_tail_ok(int C0, int Cout, int N, int D, int H, int W, int dtype);
 int conv3d_fwd_mfma_tail(const void*, int, const void*, const float*, void*, void*, const float*, const float*, float*, int, int, int, int, int, int,
                          float, hipStream_t);
 
+int conv3d_fwd_ntail_ok(int C0, int C1, int Cout, int N, int D, int H, int W, int dtype);
+int conv3d_fwd_mfma_ntail(int, const void*, int, int, const void*, int, const void*, const float*, const void*, void*, int, int, int, int, int, int,
+                          float, double*, int, const float*, hipStream_t);
+int norm_ws_zero(double* ws, int n, hipStream_t s);
+int norm_ws_fold(double* ws, int nslot, int n, hipStream_t s);
+int conv3d_fwd_ntail_slots();
+
 bool conv3d_first_ok(int C0, int C1, int Cout, int D, int H, int W, int dtype, int up0, int planar);
 int conv3d_first_fwd(const void*, int, int, const void*, const float*, void*, int, int, int, int, int, int, float, hipStream_t);
 int conv3d_first_wgrad(const void*, int, int, const void*, float*, float*, int, int, int, int, int, hipStream_t);
@@ -327,6 +334,73 @@ extern "C" int fmri_border_class_sums(const void* dy, float* out27, int N, int D
     else return FMRI_E_DTYPE;
     FMRI_LAUNCH_CHECK();
     return FMRI_OK;
+}
+
+// ---- normalisation tails (round 3): the conv in front of a BatchNormalization / InstanceNormalization layer (reference
+// create_convolution_block, unet.py:103-115; isensee2017.py:12) sums its own output for the layer's statistics, and the input-gradient launch
+// behind a normalised block applies the activation's derivative and forms the two reductions of the normalisation's backward pass - in the
+// asynchronous epilogue of the warp-specialised kernel (k_conv_fwd_ws EPI 4 / 6 / 5), i.e. only for launches with more (tile, channel block)
+// pairs than CUs: fmri_conv3d_fwd_ntail_ok() tells, per shape, whether these entry points take the launch (the caller otherwise keeps
+// fmri_conv3d_fwd + fmri_norm_act_fwd / fmri_norm_act_bwd_x, which give the same results up to summation order).
+// doubles of `ws` the three entry points below need for G groups of C channels: one [G][C][2] block for the totals (what
+// fmri_norm_act_fwd_pre / fmri_norm_act_bwd_pre read) + one per workgroup of the persistent launch for its partial sums
+extern "C" int64_t fmri_norm_tail_ws_doubles(int G, int C) { return (int64_t)(1 + conv3d_fwd_ntail_slots()) * G * C * 2; }
+extern "C" int fmri_conv3d_fwd_ntail_ok(int C0, int C1, int Cout, int N, int D, int H, int W, int dtype) {
+    if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || C0 <= 0 || C1 < 0 || Cout <= 0) return 0;
+    return conv3d_fwd_ntail_ok(C0, C1, Cout, N, D, H, W, dtype);
+}
+// y = act(conv(src0 | src1) + bias) and ws[g][Cout][2] (double; zeroed here) = {sum y, sum y^2} over the voxels of group g (g = sample when
+// per_instance, else 0), summed over the bf16 values as stored: what fmri_norm_act_fwd's own reduction pass would read
+extern "C" int fmri_conv3d_fwd_stats(const void* src0, int C0, int up0, const void* src1, int C1, const void* w, const float* bias, void* y,
+                                     int N, int D, int H, int W, int Cout, int act, float alpha, double* ws, int per_instance, int dtype,
+                                     fmri_stream_t stream) {
+    int rc = check_common(src0, C0, up0, 0, src1, C1, N, D, H, W, Cout);
+    if (rc) return rc;
+    if (!ws || !w || !y || !conv3d_fwd_ntail_ok(C0, C1, Cout, N, D, H, W, dtype)) return FMRI_E_SHAPE;
+    if ((((uintptr_t)src0) | ((uintptr_t)src1) | ((uintptr_t)w) | ((uintptr_t)y) | ((uintptr_t)ws)) & 15) return FMRI_E_ALIGN;
+    const int nent = (per_instance ? N : 1) * Cout * 2, nslot = conv3d_fwd_ntail_slots();
+    rc = norm_ws_zero(ws, (1 + nslot) * nent, as_stream(stream));
+    if (rc) return rc;
+    rc = conv3d_fwd_mfma_ntail(0, src0, C0, up0, src1, C1, w, bias, nullptr, y, N, D, H, W, Cout, act, alpha, ws, per_instance, nullptr,
+                               as_stream(stream));
+    if (rc) return rc;
+    return norm_ws_fold(ws, nslot, nent, as_stream(stream));
+}
+// the same for UpSampling3D -> concatenate -> Conv3D in parity form (fmri_conv3d_upcat_fwd): the skip launch, which finishes the output, sums it
+extern "C" int fmri_conv3d_upcat_fwd_stats(const void* src0_low, int C0, const void* src1, int C1, const void* w_up_fwd, const void* w_skip_fwd,
+                                           const float* bias, void* y, int N, int D, int H, int W, int Cout, int act, float alpha, double* ws,
+                                           int per_instance, int dtype, fmri_stream_t stream) {
+    if (!src0_low || !src1 || !w_up_fwd || !w_skip_fwd || !y || !ws || N <= 0 || C1 <= 0) return FMRI_E_SHAPE;
+    if (!(upcat_ok(C0, C1, Cout, D, H, W, dtype, 0) & 1) || !conv3d_fwd_ntail_ok(C1, 0, Cout, N, D, H, W, dtype)) return FMRI_E_SHAPE;
+    if ((((uintptr_t)src0_low) | ((uintptr_t)src1) | ((uintptr_t)w_up_fwd) | ((uintptr_t)w_skip_fwd) | ((uintptr_t)y) | ((uintptr_t)ws)) & 15) return FMRI_E_ALIGN;
+    const int nent = (per_instance ? N : 1) * Cout * 2, nslot = conv3d_fwd_ntail_slots();
+    int rc = norm_ws_zero(ws, (1 + nslot) * nent, as_stream(stream));
+    if (rc) return rc;
+    rc = conv3d_fwd_mfma_ex(1, src0_low, C0, 0, 0, nullptr, 0, w_up_fwd, nullptr, nullptr, nullptr, y, N, D / 2, H / 2, W / 2, Cout, FMRI_ACT_NONE, 0.f,
+                            as_stream(stream));
+    if (rc) return rc;
+    rc = conv3d_fwd_mfma_ntail(0, src1, C1, 0, nullptr, 0, w_skip_fwd, bias, y, y, N, D, H, W, Cout, act, alpha, ws, per_instance, nullptr,
+                               as_stream(stream));
+    if (rc) return rc;
+    return norm_ws_fold(ws, nslot, nent, as_stream(stream));
+}
+// Input gradient of a conv whose INPUT is the output of a normalised block: dz = conv_dgrad(dy) * act'(z), z = fma(x, sc, sh) recomputed
+// from that block's conv output x and nss[g][Cin][2] = {sc, sh} (fmri_norm_scale_shift), and ws[g][Cin][2] (zeroed here) = {sum dz, sum dz * x}
+// over the stored bf16 values of dz - fmri_norm_act_bwd_pre() finishes the normalisation's backward pass from these.  act / alpha: the
+// normalised block's activation.  Cout = channels of dy, Cin = channels of dz and x.
+extern "C" int fmri_conv3d_dgrad_norm(const void* dy, int Cout, const void* w_dgrad, const void* x, const float* nss, void* dz, int N, int D, int H,
+                                      int W, int Cin, int act, float alpha, double* ws, int per_instance, int dtype, fmri_stream_t stream) {
+    int rc = check_common(dy, Cout, 0, 0, nullptr, 0, N, D, H, W, Cin);
+    if (rc) return rc;
+    if (!ws || !w_dgrad || !x || !nss || !dz || !conv3d_fwd_ntail_ok(Cout, 0, Cin, N, D, H, W, dtype)) return FMRI_E_SHAPE;
+    if ((((uintptr_t)dy) | ((uintptr_t)w_dgrad) | ((uintptr_t)x) | ((uintptr_t)dz) | ((uintptr_t)ws) | ((uintptr_t)nss)) & 15) return FMRI_E_ALIGN;
+    const int nent = (per_instance ? N : 1) * Cin * 2, nslot = conv3d_fwd_ntail_slots();
+    rc = norm_ws_zero(ws, (1 + nslot) * nent, as_stream(stream));
+    if (rc) return rc;
+    rc = conv3d_fwd_mfma_ntail(1, dy, Cout, 0, nullptr, 0, w_dgrad, nullptr, x, dz, N, D, H, W, Cin, act, alpha, ws, per_instance, nss,
+                               as_stream(stream));
+    if (rc) return rc;
+    return norm_ws_fold(ws, nslot, nent, as_stream(stream));
 }
 
 extern "C" int fmri_conv3d_upcat_ok(int C0, int C1, int Cout, int D, int H, int W, int dtype) { return upcat_ok(C0, C1, Cout, D, H, W, dtype, 0); }

@@ -143,6 +143,19 @@ struct FwdTail {
     // 1 interior / 2 last voxel (round 3: Deconvolution3D folded into the following conv - the transposed conv's bias reaches an output
     // voxel through the in-volume taps only, so the effective bias differs on the volume's faces, edges and corners); nullptr: `bias`
     const float* bias27;
+    // normalisation tails of the asynchronous epilogue (round 3, EPI 4 / 5 / 6): per-(group, channel) sums added to nws[g][Cout][2] (double,
+    // zeroed by the caller), g = sample (n_per = 1, instance norm) or 0 (batch norm).  EPI 4 / 6: {sum y, sum y^2} of the stored bf16 values.
+    // EPI 5 (input-gradient launch in front of a normalised block): {sum dz, sum dz * x}, dz = dy * act'(z), z = fma(x, sc, sh) with the
+    // block's scale / shift nss[g][Cout][2] = {sc, sh} (k_norm_scale_shift: the operations of the forward's apply pass, the same z bit for
+    // bit); x (the block's conv output) comes in `mask`
+    // The sums go to the workgroup's OWN slot, nws[1 + blockIdx.x][G][Cout][2] (slot 0 is the total the caller folds them into): every
+    // workgroup of a launch flushes at the same moments (its last tile; the tile where the sample changes), and device-scope fp64 atomics of
+    // 1,024 waves on the same 128 addresses cost 30-45 us per flush (measured: instance norm, four flushes per workgroup, +50-80 % on the
+    // launch).  Only the four producer waves of a workgroup meet in a slot.
+    double* nws;
+    int n_per;
+    int n_grp;              // G
+    const float* nss;
 };
 
 // MODE selects what the 3x3x3 machinery computes:
@@ -675,8 +688,20 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
     // activation; the producers add the residual lines (prefetched like the mask lines) in fp32, activate, round and store.  One bf16 rounding
     // more than the RES epilogue (which adds the residual to the fp32 accumulators): both partial sums of the parity form - the up-sampled
     // channels' (stored as bf16 by the MODE 1 launch) and now the skip channels' - are rounded before they meet.
-    constexpr bool HAS_RESID = EPI == 3;
-    constexpr bool HAS_LINES = HAS_MASK || HAS_RESID;      // per-store 16-byte lines the producers prefetch into mk[]
+    constexpr bool HAS_RESID = EPI == 3 || EPI == 6;
+    // EPI 4 / 6 (ASYNC only): the producers also sum the values they store and their squares per channel - the statistics of the
+    // normalisation layer behind this conv (reference create_convolution_block, unet.py:103-115), which then needs no pass of its own over
+    // the tensor.  EPI 5: the launch is the input gradient in front of a normalised block: the producers turn dy into dz = dy * act'(z)
+    // (z recomputed from the block's conv output x, whose lines they prefetch like mask lines) and sum dz and dz * x per channel - the
+    // reductions of the normalisation's backward pass.  Per lane 8 + 8 fp32 partial sums (a lane keeps its 8 channels for the whole
+    // kernel), reduced across the lanes of a wave and added to the fp64 accumulators when the (group, channel block) changes.
+    constexpr bool HAS_STATS = EPI == 4 || EPI == 6;
+    constexpr bool HAS_NBWD = EPI == 5;
+    constexpr bool HAS_SUMS = HAS_STATS || HAS_NBWD;
+    constexpr bool HAS_LINES = HAS_MASK || HAS_RESID || HAS_NBWD;      // per-store 16-byte lines the producers prefetch into mk[]
+    // EPI 5: the lines are prefetched one PART of the drain ahead (two buffers of a part's lines) instead of the whole tile's at once - the
+    // partial sums and the scale / shift need the registers (64 -> 32 for the lines at BN = 64)
+    constexpr bool LINES_PIPE = HAS_NBWD;
     // the producers drain a staged tile in DP parts, one per phase, in phases 0 .. DP-1 of the next tile's first item (one part fits a
     // phase beside the filter slab's DMA; the whole drain in phase 0 made the producers late for the phase-1 barrier: measured 8 % SLOWER
     // than the synchronous epilogue); the halo pieces of that item's successor follow in phases DP .. NPH-2
@@ -758,6 +783,41 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
             return org + ((tile_d(rt) * H + tile_h(rt, rr)) * W + lane_w(rr)) * Cout + q * 8;
         }
     };
+    // the same address as wave-uniform tile origin (64-bit, scalar registers) + 32-bit lane offset: `base + piece_addr(...)` made hipcc hoist
+    // one sign-extended 64-bit offset per store instruction out of the tile loop (32 registers at BN = 64, the first to be spilled)
+    auto piece_ptr = [&](const bf16_t* base, const FwdItem& it, int v, int q) -> const char* {
+        const int rt = v >> 5, rr = v & 31;
+        int64_t org;
+        unsigned off;
+        if constexpr (MODE == 1 && PL) {
+            org = ((((int64_t)it.n * D + it.d0) * 2 * H + 2 * it.h0 + ((it.par >> 1) & 1)) * 2 * W + 2 * it.w0 + (it.par & 1)) * Cout + it.co0;
+            off = ((tile_d(rt) * 2 * H + 2 * tile_h(rt, rr)) * 2 * W + 2 * lane_w(rr)) * Cout + q * 8;
+        } else if constexpr (MODE == 1) {
+            org = ((((int64_t)it.n * 2 * D + 2 * it.d0 + (it.par >> 2)) * 2 * H + 2 * it.h0 + ((it.par >> 1) & 1)) * 2 * W + 2 * it.w0 + (it.par & 1)) * Cout + it.co0;
+            off = ((2 * tile_d(rt) * 2 * H + 2 * tile_h(rt, rr)) * 2 * W + 2 * lane_w(rr)) * Cout + q * 8;
+        } else {
+            org = ((((int64_t)it.n * D + it.d0) * H + it.h0) * W + it.w0) * Cout + it.co0;
+            off = ((tile_d(rt) * H + tile_h(rt, rr)) * W + lane_w(rr)) * Cout + q * 8;
+        }
+#ifdef FMRI_PIECE_ADDR64          // (A/B aid: the former 64-bit form)
+        return reinterpret_cast<const char*>(base + piece_addr(it, v, q));
+#endif
+        return reinterpret_cast<const char*>(base + org) + (off * 2u);
+    };
+    // EPI >= 4 (the producers' drain, 4 waves x 4 parts): store instruction kk of producer wave w covers one half (BN = 64) or one row
+    // (BN = 32) of column tile 4 w + kk / LPQ, so everything but the lane's place in it is wave-uniform: address = scalar base (tile origin +
+    // the instruction's rows) + one of LPQ 32-bit lane offsets that never change - no per-store 64-bit offset to keep in registers (the
+    // partial sums need them) and none to rebuild with quarter-rate integer multiplies either
+    constexpr int LPQ = 32 / VPI_;                   // store instructions per column tile (4 | 2) = per part of the drain
+    auto line_ptr = [&](const bf16_t* base, const FwdItem& it, int w, int kk) -> const char* {
+        const int rt = 4 * w + kk / LPQ, j = kk % LPQ;
+        const int hrow = 2 * (rt & 3) + ((j * VPI_) >> 4);
+        const int64_t org = ((((int64_t)it.n * D + it.d0 + (rt >> 2)) * H + it.h0 + hrow) * W + it.w0) * Cout + it.co0;
+        const int rr = (j * VPI_ + lane / CPV_) & 31;
+        const unsigned off = (unsigned)(lane_w(rr) * Cout + (lane % CPV_) * 8) * 2u;
+        return reinterpret_cast<const char*>(base + org) + off;
+    };
+    constexpr bool FASTD = ASY && EPI >= 4;
     // vector-memory instructions one wave issues in store_share<NW> (the producers' counted waits step over exactly these): one store per
     // iteration, one more per iteration for the logits, the pooled pieces
     // (part `part` of `nparts`: the store instructions [part, part + 1) * NIT / nparts; the pooled pieces go with the last part)
@@ -782,6 +842,50 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
             b1v = tail.b1[0];
         }
     }
+    float ns_[8] = {}, nq_[8] = {}, nsc[8] = {}, nsh[8] = {};
+    int ng_n = -1, ng_co0 = -1;                      // (group, channel block) the partial sums belong to
+    auto nsum_flush = [&]() {
+        if constexpr (HAS_SUMS) {
+            if (ng_co0 < 0) return;
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+#pragma unroll
+                for (int m = CPV_; m < 64; m <<= 1) {
+                    ns_[k] += __shfl_xor(ns_[k], m);
+                    nq_[k] += __shfl_xor(nq_[k], m);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            if (lane < CPV_) {
+                double* const p = tail.nws + ((((int64_t)blockIdx.x + 1) * tail.n_grp + ng_n) * Cout + ng_co0 + lane * 8) * 2;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    unsafeAtomicAdd(p + 2 * k, (double)ns_[k]);
+                    unsafeAtomicAdd(p + 2 * k + 1, (double)nq_[k]);
+                    __builtin_amdgcn_sched_barrier(0);          // one pair at a time: hoisted, the 16 conversions and addresses take 64 registers
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) ns_[k] = nq_[k] = 0.f;
+        }
+    };
+    // in front of a tile's first store: the sums move on to the tile's (group, channel block) - and with them, EPI 5, the lane's scale / shift
+    auto nsum_group = [&](const FwdItem& it) {
+        if constexpr (HAS_SUMS) {
+            const int gn = tail.n_per ? it.n : 0;
+            if (gn == ng_n && it.co0 == ng_co0) return;
+            nsum_flush();
+            ng_n = gn;
+            ng_co0 = it.co0;
+            if constexpr (HAS_NBWD) {
+                const float4* const t4 = reinterpret_cast<const float4*>(tail.nss + ((int64_t)gn * Cout + it.co0 + (lane % CPV_) * 8) * 2);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float4 t = t4[j];
+                    nsc[2 * j] = t.x; nsh[2 * j] = t.y; nsc[2 * j + 1] = t.z; nsh[2 * j + 1] = t.w;
+                }
+            }
+        }
+    };
     auto store_share = [&](const FwdItem& it, int slot, int w, auto nw_tag, auto pre_tag, const uint4* mk, auto part_tag, auto nparts_tag) {
         constexpr int NW = decltype(nw_tag)::value;
         constexpr bool PRE = decltype(pre_tag)::value;       // the mask lines were requested earlier (mk[kk], kk = store instruction)
@@ -791,17 +895,29 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
         static_assert(NIT % NPARTS == 0, "parts");
         constexpr int SWM = NT == 2 ? 7 : 3;
         const unsigned char* const stage = lds + slot * HALO_BYTES;
+        if constexpr (HAS_SUMS && PART == 0) nsum_group(it);
+        constexpr bool FD = FASTD && NW == 4;
+        const int ln = lane;
+        // (FD: the swizzle term of the staged voxel depends on the lane only - v & 7 = (lane / 8) & 7, (v >> 2) & 3 = (lane / 16) & 3 - so a
+        // lane reads all its lines from one LDS address + immediate offsets)
+        const int vs_l = NT == 2 ? ((lane / CPV) & 7) : (((lane / CPV) >> 2) & 3);
+        const unsigned char* const stage_l = stage + (lane / CPV) * (BN * 2) + ((((lane % CPV) ^ vs_l) & SWM) << 4);
+        auto gp = [&](const bf16_t* base, int kk, int v, int q) -> const char* {
+            if constexpr (FD) return line_ptr(base, it, w, kk);
+            else return piece_ptr(base, it, v, q);
+        };
 #pragma unroll
         for (int kk = PART * (NIT / NPARTS); kk < (PART + 1) * (NIT / NPARTS); ++kk) {
-            const int v = w * (512 / NW) + kk * VPI + lane / CPV, q = lane % CPV;       // tile-wide voxel index: column tile v >> 5, lane v & 31
+            const int v = w * (512 / NW) + kk * VPI + ln / CPV, q = ln % CPV;       // tile-wide voxel index: column tile v >> 5, lane v & 31
             const int vs = NT == 2 ? (v & 7) : ((v >> 2) & 3);
-            uint4 o4 = *reinterpret_cast<const uint4*>(stage + v * (BN * 2) + (((q ^ vs) & SWM) << 4));
+            uint4 o4;
+            if constexpr (FD) o4 = *reinterpret_cast<const uint4*>(stage_l + (w * (512 / NW) + kk * VPI) * (BN * 2));
+            else o4 = *reinterpret_cast<const uint4*>(stage + v * (BN * 2) + (((q ^ vs) & SWM) << 4));
             const int rt = v >> 5, rr = v & 31;
-            const int64_t ao = piece_addr(it, v, q);
             if (HAS_MASK && mask) {
                 uint4 m4;
                 if constexpr (PRE) m4 = mk[kk];
-                else m4 = *reinterpret_cast<const uint4*>(mask + ao);
+                else m4 = *reinterpret_cast<const uint4*>(gp(mask, kk, v, q));
                 const unsigned mm[4] = {m4.x, m4.y, m4.z, m4.w};
                 unsigned* const oo = reinterpret_cast<unsigned*>(&o4);
 #pragma unroll
@@ -813,7 +929,7 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
             if constexpr (HAS_RESID) {
                 uint4 r4;
                 if constexpr (PRE) r4 = mk[kk];
-                else r4 = *reinterpret_cast<const uint4*>(residual + ao);
+                else r4 = *reinterpret_cast<const uint4*>(gp(residual, kk, v, q));
                 const unsigned rr4[4] = {r4.x, r4.y, r4.z, r4.w};
                 unsigned* const oo = reinterpret_cast<unsigned*>(&o4);
 #pragma unroll
@@ -825,7 +941,39 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
                     oo[i] = pack2bf(lo, hi);
                 }
             }
-            *reinterpret_cast<uint4*>(y + ao) = o4;
+            if constexpr (HAS_NBWD) {
+                uint4 x4;
+                if constexpr (PRE) x4 = mk[LINES_PIPE ? (PART & 1) * (NIT / NPARTS) + kk - PART * (NIT / NPARTS) : kk];
+                else x4 = *reinterpret_cast<const uint4*>(gp(mask, kk, v, q));
+                const unsigned xx[4] = {x4.x, x4.y, x4.z, x4.w};
+                unsigned* const oo = reinterpret_cast<unsigned*>(&o4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float xlo = __uint_as_float(xx[i] << 16), xhi = __uint_as_float(xx[i] & 0xffff0000u);
+                    float dlo = __uint_as_float(oo[i] << 16), dhi = __uint_as_float(oo[i] & 0xffff0000u);
+                    dlo = __builtin_fmaf(xlo, nsc[2 * i], nsh[2 * i]) > 0.f ? dlo : dlo * act_s;          // act'(z): 1 | s (0 ReLU, alpha LeakyReLU, 1 none)
+                    dhi = __builtin_fmaf(xhi, nsc[2 * i + 1], nsh[2 * i + 1]) > 0.f ? dhi : dhi * act_s;
+                    oo[i] = pack2bf(dlo, dhi);
+                    dlo = __uint_as_float(oo[i] << 16);                 // the sums run over the values as stored (what the apply pass reads)
+                    dhi = __uint_as_float(oo[i] & 0xffff0000u);
+                    ns_[2 * i] += dlo;
+                    ns_[2 * i + 1] += dhi;
+                    nq_[2 * i] = __builtin_fmaf(dlo, xlo, nq_[2 * i]);
+                    nq_[2 * i + 1] = __builtin_fmaf(dhi, xhi, nq_[2 * i + 1]);
+                }
+            }
+            if constexpr (HAS_STATS) {
+                const unsigned oo[4] = {o4.x, o4.y, o4.z, o4.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float lo = __uint_as_float(oo[i] << 16), hi = __uint_as_float(oo[i] & 0xffff0000u);
+                    ns_[2 * i] += lo;
+                    ns_[2 * i + 1] += hi;
+                    nq_[2 * i] = __builtin_fmaf(lo, lo, nq_[2 * i]);
+                    nq_[2 * i + 1] = __builtin_fmaf(hi, hi, nq_[2 * i + 1]);
+                }
+            }
+            *reinterpret_cast<uint4*>(const_cast<char*>(gp(y, kk, v, q))) = o4;
             if constexpr (MODE == 0 && !RES && HAS_LOGITS) {
                 if (tail.logits) {
                     // final 1x1x1 conv to one label: the CPV lanes of a voxel hold its BN (= Cout) channels, 8 each
@@ -901,16 +1049,29 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
             const int ls = ps ^ ((row >> 2) & 3);
             f_voff[k] = (unsigned)(((row / BN) * Cout + (row % BN)) * Krow + ls * 8) * 2u;
         }
-        int h_pack[NPIECE];            // halo piece ph: hd | hh<<4 | hw<<8 | ls<<13 | valid<<15
-#pragma unroll
-        for (int ph = 0; ph < NPIECE; ++ph) {
-            const int i = (H_I0 + ph * DW + dwv) * 64 + lane;
+        auto make_pack = [&](int ph, int ln) {      // halo piece ph: hd | hh<<4 | hw<<8 | ls<<13 | valid<<15
+            const int i = (H_I0 + ph * DW + dwv) * 64 + ln;
             const int hv = i >> 2, ps = i & 3;
             const int ls = ps ^ ((hv >> 2) & 3);
             const int hvc = hv < HVOX ? hv : 0;
             const int hw_ = hvc % HW, hq = hvc / HW;
-            h_pack[ph] = (hq / HH) | ((hq % HH) << 4) | (hw_ << 8) | (ls << 13) | ((hv < HVOX ? 1 : 0) << 15);
+            return (hq / HH) | ((hq % HH) << 4) | (hw_ << 8) | (ls << 13) | ((hv < HVOX ? 1 : 0) << 15);
+        };
+        // (EPI 5 / 6: no table either - a piece's descriptor is rebuilt from the lane index when the piece is issued, see KEEP_HP below)
+        constexpr bool KEEP_PACK = EPI < 5;
+        int h_pack[KEEP_PACK ? NPIECE : 1];
+        if constexpr (KEEP_PACK) {
+#pragma unroll
+            for (int ph = 0; ph < NPIECE; ++ph) h_pack[ph] = make_pack(ph, lane);
         }
+        auto pack_of = [&](int ph) {
+            if constexpr (KEEP_PACK) return h_pack[ph];
+            else {
+                int ln = lane;
+                asm volatile("" : "+v"(ln));         // (or hipcc hoists all NPIECE descriptors out of the tile loop again)
+                return make_pack(ph, ln);
+            }
+        };
         auto issue_filter = [&](const FwdItem& it, int pl, int fb) {
             int64_t slab;
             int koff;
@@ -923,7 +1084,10 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
                 if (k == 0 || dwv + DW * k < F_INSTR)
                     dma16_s(base, f_voff[k], __builtin_amdgcn_readfirstlane(ldsf0 + fb * FILT_BYTES + ((dwv + DW * k) % F_INSTR) * 1024));
         };
-        const bf16_t* hp[NPIECE];
+        // source address of every halo piece, kept across the chunks of a tile (+ 32 channels per chunk) - except in the instantiations
+        // whose drain needs the registers (EPI 5 / 6: prefetched lines + partial sums): those rebuild a piece's address when they issue it
+        constexpr bool KEEP_HP = EPI < 5;
+        const bf16_t* hp[KEEP_HP ? NPIECE : 1];
         auto halo_src = [&](const FwdItem& it, int pk) -> const bf16_t* {
             int od = 0, oh = 0, ow = 0;                            // TIGHT: the box starts at g - 1 + (parity of the taps) per axis
             if constexpr (TIGHT) {
@@ -955,12 +1119,12 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
             }
         };
         static_assert(NPIECE * DW >= H_I1 - H_I0 && NPIECE * DW - (H_I1 - H_I0) < DW, "piece map");
-        auto issue_halo = [&](int ph, int slot) {
+        auto issue_halo = [&](int ph, int slot, const bf16_t* src) {
             const int instr = H_I0 + ph * DW + dwv;
             // every wave issues exactly NPIECE instructions per chunk (the counted s_waitcnt below relies on it): the few past the last live
             // instruction copy zeros into the dead rows behind it
             const bool dead = instr >= H_I1;
-            dma16(dead ? (const void*)g_zero_page : (const void*)hp[ph], __builtin_amdgcn_readfirstlane(lds0 + slot * HALO_STRIDE + instr * 1024));
+            dma16(dead ? (const void*)g_zero_page : (const void*)src, __builtin_amdgcn_readfirstlane(lds0 + slot * HALO_STRIDE + instr * 1024));
         };
         // Halo pieces of the NEXT chunk issued in phase pl: spread over the first NPH-1 phases (all of them when a chunk has one phase
         // only... it has at least two), so that the last phase's wait - everything landed - finds them a phase old.
@@ -982,18 +1146,29 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
         };
         // ASY: the finished tile waiting to be stored (staged by the consumers in halo slot `hb ^ 1` as seen from the next item), the mask
         // lines of this wave's share of it, and the number of vector-memory instructions the drain issues behind the phase-1 filter slab
-        constexpr int NDR = (ASY && HAS_LINES) ? 512 / (DW * VPI_) : 1;
+        constexpr int NIT_ = 512 / (DW * VPI_);                  // store instructions (= lines) per producer wave and tile
+        constexpr int LP = NIT_ / (DP > 0 ? DP : 1);              // ... per part of the drain
+        constexpr int NDR = (ASY && HAS_LINES) ? (LINES_PIPE ? 2 * LP : NIT_) : 1;
         uint4 mk[NDR] = {};
+        // the lines of part `part` of tile `it`'s drain -> buffer part & 1 (LINES_PIPE)
+        auto fetch_lines = [&](const FwdItem& it, auto part_tag) {
+            constexpr int PART = decltype(part_tag)::value;
+            if constexpr (LINES_PIPE) {
+#pragma unroll
+                for (int i = 0; i < LP; ++i) mk[(PART & 1) * LP + i] = *reinterpret_cast<const uint4*>(line_ptr(mask, it, dwv, PART * LP + i));
+            }
+        };
         FwdItem done = cur;
         bool pending = false;
         constexpr int DPN = DP > 0 ? DP : 1;
         int drain_vmops[DPN];
 #pragma unroll
-        for (int i = 0; i < DPN; ++i) drain_vmops[i] = ASY ? store_share_vmops(DW, i, DPN) : 0;
+        for (int i = 0; i < DPN; ++i) drain_vmops[i] = ASY ? store_share_vmops(DW, i, DPN) + (LINES_PIPE && i + 1 < DPN ? LP : 0) : 0;
 #pragma unroll
         for (int ph = 0; ph < NPIECE; ++ph) {
-            hp[ph] = halo_src(cur, h_pack[ph]);
-            issue_halo(ph, 0);
+            const bf16_t* const src = halo_src(cur, pack_of(ph));
+            if constexpr (KEEP_HP) hp[ph] = src;
+            issue_halo(ph, 0, src);
         }
         issue_filter(cur, 0, 0);
         while (true) {
@@ -1010,7 +1185,7 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
             // keep the packed piece descriptors packed: hipcc otherwise hoists the three bit-field extractions of every piece out of the loop
             // (51 more live registers) and spills them
 #pragma unroll
-            for (int ph = 0; ph < NPIECE; ++ph) asm volatile("" : "+v"(h_pack[ph]));
+            for (int ph = 0; ph < (KEEP_PACK ? NPIECE : 1); ++ph) asm volatile("" : "+v"(h_pack[ph]));
             // the phases of one item; DRN (ASY only): a staged tile is drained in phase 0 and the halo pieces start a phase later
             auto run_phases = [&](auto drn_tag) {
                 constexpr bool DRN = decltype(drn_tag)::value;
@@ -1026,41 +1201,60 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
                         if constexpr (DRN) {
                             // the mask lines requested in the previous tile's last phase are in their registers now: tell the compiler here,
                             // where it costs nothing (its own wait for them would otherwise sit behind the next filter slab's DMA)
-                            if ((HAS_MASK && mask) || HAS_RESID) {
+                            if ((HAS_MASK && mask) || HAS_RESID || HAS_NBWD) {
 #pragma unroll
-                                for (int i = 0; i < NDR; ++i) asm volatile("" : "+v"(mk[i].x), "+v"(mk[i].y), "+v"(mk[i].z), "+v"(mk[i].w));
+                                for (int i = 0; i < (LINES_PIPE ? LP : NDR); ++i) asm volatile("" : "+v"(mk[i].x), "+v"(mk[i].y), "+v"(mk[i].z), "+v"(mk[i].w));
                             }
                         }
-                    } else if constexpr (DRN && pl <= DP) wait_newer(drain_vmops[pl - 1]);
+                    } else if constexpr (DRN && pl <= DP) {
+                        wait_newer(drain_vmops[pl - 1]);
+                        if constexpr (LINES_PIPE && pl < DP) {
+                            // part pl's lines were requested a phase ago, in front of part pl - 1's stores: the compiler's own wait for them
+                            // (it does not see the DMA instructions) belongs here, before this phase's filter slab is issued
+#pragma unroll
+                            for (int i = 0; i < LP; ++i) {
+                                uint4& m = mk[(pl & 1) * LP + i];
+                                asm volatile("" : "+v"(m.x), "+v"(m.y), "+v"(m.z), "+v"(m.w));
+                            }
+                        }
+                    }
                     else wait_newer(has_next ? pieces_from(pl, DRN) - pieces_from(pl - 1, DRN) : 0);
                     __builtin_amdgcn_s_barrier();                          // everybody's has landed; the previous phase is fully read
                     if (pl < NPH - 1) issue_filter(cur, pl + 1, (g + 1) & 1);
                     else if (has_next) issue_filter(nxt, 0, (g + 1) & 1);
                     if constexpr (DRN) {
                         // part pl of the drain
-                        if constexpr (pl < DP)
+                        if constexpr (pl < DP) {
+                            if constexpr (LINES_PIPE && pl + 1 < DP) fetch_lines(done, std::integral_constant<int, pl + 1>{});
                             store_share(done, hb ^ 1, dwv, std::integral_constant<int, DW>{}, std::true_type{}, mk,
                                         std::integral_constant<int, pl>{}, std::integral_constant<int, DPN>{});
+                        }
                     }
                     if (has_next) {
                         const int HP0 = pieces_from(pl, DRN), HPN = pieces_from(pl + 1, DRN) - HP0;
 #pragma unroll
                         for (int q = 0; q < NPIECE; ++q) {
                             if (q < HPN) {
-                                if (fresh) hp[HP0 + q] = halo_src(nxt, h_pack[HP0 + q]);
-                                else hp[HP0 + q] += 32;
-                                issue_halo(HP0 + q, hb ^ 1);
+                                if constexpr (KEEP_HP) {
+                                    if (fresh) hp[HP0 + q] = halo_src(nxt, h_pack[HP0 + q]);
+                                    else hp[HP0 + q] += 32;
+                                    issue_halo(HP0 + q, hb ^ 1, hp[HP0 + q]);
+                                } else issue_halo(HP0 + q, hb ^ 1, halo_src(nxt, pack_of(HP0 + q)));
                             }
                         }
                     }
                     if constexpr (ASY) {
                         // last phase of a tile (it carries no halo pieces): request the mask lines of this wave's share of the tile's stores
-                        if (pl == NPH - 1 && cur.ch == nch - 1 && ((HAS_MASK && mask) || HAS_RESID)) {
+                        if (pl == NPH - 1 && cur.ch == nch - 1 && ((HAS_MASK && mask) || HAS_RESID || HAS_NBWD)) {
                             const bf16_t* const lines = HAS_RESID ? residual : mask;      // (the residual of a tile is read before anyone stores to it)
+                            if constexpr (LINES_PIPE) fetch_lines(cur, std::integral_constant<int, 0>{});
+                            else {
 #pragma unroll
-                            for (int kk = 0; kk < NDR; ++kk) {
-                                const int v = dwv * (512 / DW) + kk * VPI_ + lane / CPV_;
-                                mk[kk] = *reinterpret_cast<const uint4*>(lines + piece_addr(cur, v, lane % CPV_));
+                                for (int kk = 0; kk < NDR; ++kk) {
+                                    const int v = dwv * (512 / DW) + kk * VPI_ + lane / CPV_;
+                                    if constexpr (FASTD) mk[kk] = *reinterpret_cast<const uint4*>(line_ptr(lines, cur, dwv, kk));
+                                    else mk[kk] = *reinterpret_cast<const uint4*>(piece_ptr(lines, cur, v, lane % CPV_));
+                                }
                             }
                         }
                     }
@@ -1079,7 +1273,8 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
                     pending = true;
                     if (!has_next) {                                   // the last tile of this workgroup: nothing left to hide the stores under
                         __builtin_amdgcn_s_barrier();                  // staged
-                        store_share(done, hb, dwv, std::integral_constant<int, DW>{}, std::true_type{}, mk, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
+                        store_share(done, hb, dwv, std::integral_constant<int, DW>{}, std::integral_constant<bool, !LINES_PIPE>{}, mk, std::integral_constant<int, 0>{},
+                                    std::integral_constant<int, 1>{});
                     }
                 } else if constexpr (!RES) {
                     __builtin_amdgcn_s_barrier();                      // staged
@@ -1091,6 +1286,7 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
             pair = npair;
             hb ^= 1;
         }
+        nsum_flush();
         return;
     }
 
@@ -1373,7 +1569,7 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
                     }
                 }
             };
-            if (HAS_RESID || act == FMRI_ACT_NONE) stage_tile(std::integral_constant<int, FMRI_ACT_NONE>{});     // (EPI 3: the producers activate)
+            if (HAS_RESID || HAS_NBWD || act == FMRI_ACT_NONE) stage_tile(std::integral_constant<int, FMRI_ACT_NONE>{});     // (EPI 3 / 5 / 6: `act` is the producers')
             else if (act == FMRI_ACT_RELU) stage_tile(std::integral_constant<int, FMRI_ACT_RELU>{});
             else stage_tile(std::integral_constant<int, FMRI_ACT_LEAKY>{});
             PROF_T(e2);
@@ -2218,6 +2414,22 @@ static int conv3d_fwd_mfma_launch(int mode, const void* src0, int C0, int up0, i
                 s, (const bf16_t*)w, bias, (const bf16_t*)mask, (const bf16_t*)residual, (bf16_t*)y, N, D, H, W, Cout, act, alpha); \
     } while (0)
     const bool wide = fwd_wide(mode, planar, ntile, Cout);
+    if (tail.nws) {
+        // normalisation tails (EPI 4: statistics of the output, 6: the same behind the residual, 5: the backward reductions): asynchronous
+        // epilogue only - conv3d_fwd_ntail_ok() tells the caller beforehand
+        const int np_ = ntile * (Cout / (wide ? 64 : 32));
+        if (cube || mode != 0 || planar || !use_ws || !fwd_async() || np_ <= ncu || tail.pool || tail.logits || tail.bias27) return FMRI_E_SHAPE;
+        if (tail.nss ? (!mask || residual) : (mask != nullptr)) return FMRI_E_SHAPE;
+#define FMRI_LAUNCH_NT(NT_, EPI_)                                                                                          \
+        k_conv_fwd_ws<NT_, false, 0, false, true, EPI_><<<ncu, fw::NTHREADS, 0, st>>>(s, (const bf16_t*)w, bias, (const bf16_t*)mask,     \
+                                                                                       (const bf16_t*)residual, (bf16_t*)y, N, D, H, W, Cout, act, alpha, tail)
+        if (tail.nss) { if (wide) FMRI_LAUNCH_NT(2, 5); else FMRI_LAUNCH_NT(1, 5); }
+        else if (residual) { if (wide) FMRI_LAUNCH_NT(2, 6); else FMRI_LAUNCH_NT(1, 6); }
+        else { if (wide) FMRI_LAUNCH_NT(2, 4); else FMRI_LAUNCH_NT(1, 4); }
+#undef FMRI_LAUNCH_NT
+        FMRI_LAUNCH_CHECK();
+        return FMRI_OK;
+    }
     if (cube) {
         if (mode != 0 || residual || planar) return FMRI_E_SHAPE;
         const int nt = wide ? 2 : 1;
@@ -2284,6 +2496,28 @@ int conv3d_fwd_mfma_tail(const void* src0, int C0, const void* w, const float* b
     if ((pool && !(ok & 1)) || (logits && (!(ok & 2) || !w1 || !b1))) return FMRI_E_SHAPE;
     return conv3d_fwd_mfma_launch(0, src0, C0, 0, 0, nullptr, 0, w, bias, nullptr, nullptr, y, N, D, H, W, Cout, act, alpha,
                                   FwdTail{(bf16_t*)pool, w1, b1, logits, nullptr}, st);
+}
+// can this plain 3-D launch carry a normalisation tail (statistics of its output / the backward reductions in its asynchronous epilogue)?
+int conv3d_fwd_ntail_ok(int C0, int C1, int Cout, int N, int D, int H, int W, int dtype) {
+    if (!conv3d_fwd_mfma_ok(C0, C1, Cout, D, H, W, dtype) || conv3d_fwd_needs_cube(D, H, W) || !fwd_use_ws() || !fwd_async()) return 0;
+    const int ntile = N * (D / fw::TD) * (H / fw::TH) * (W / fw::TW);
+    return ntile * (Cout / (fwd_wide(0, 0, ntile, Cout) ? 64 : 32)) > fwd_cu_count();
+}
+int conv3d_fwd_ntail_slots() { return fwd_cu_count(); }      // nws holds 1 + this many [G][Cout][2] blocks
+// kind 0: y = act(conv(src) [+ residual]) and nws += {sum y, sum y^2};  kind 1: y = dz = conv(src) * act'(z(x)), nws += {sum dz, sum dz * x}
+// (x = the normalised block's conv output, passed as `lines`; nss[g][Cout][2] = that block's {scale, shift}).  nws: [1 + slots][G][Cout][2],
+// zero on entry; the sums are left in the slots 1.. (one per workgroup) for the caller to fold into block 0.
+int conv3d_fwd_mfma_ntail(int kind, const void* src0, int C0, int up0, const void* src1, int C1, const void* w, const float* bias,
+                          const void* lines, void* y, int N, int D, int H, int W, int Cout, int act, float alpha, double* nws, int per_instance,
+                          const float* nss, hipStream_t st) {
+    if (!nws || (kind == 1 && (!lines || !nss))) return FMRI_E_SHAPE;
+    FwdTail t{};
+    t.nws = nws;
+    t.n_per = per_instance;
+    t.n_grp = per_instance ? N : 1;
+    if (kind == 1) t.nss = nss;
+    return conv3d_fwd_mfma_launch(0, src0, C0, up0, 0, src1, C1, w, bias, kind == 1 ? lines : nullptr, kind == 1 ? nullptr : lines, y, N, D, H, W,
+                                  Cout, act, alpha, t, st);
 }
 // plain 3-D conv whose epilogue adds `residual` and whose bias depends on the output voxel's border class (FwdTail::bias27); only the
 // warp-specialised kernel implements it

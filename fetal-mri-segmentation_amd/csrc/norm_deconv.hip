@@ -161,6 +161,24 @@ __global__ void k_zero_d(double* p, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = 0.0;
 }
+// nss[g][c] = {scale, shift} of the apply pass, z = fma(x, scale, shift): the very operations of k_norm_apply, so that a kernel that
+// recomputes z from x (the normalisation tail of the input-gradient launch, conv3d_mfma.hip EPI 5) gets the forward's z bit for bit
+__global__ void k_norm_scale_shift(const float* __restrict__ stats, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float* __restrict__ nss, int G, int C) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= G * C) return;
+    const int c = i % C;
+    const float sc = stats[i * 3 + 1] * gamma[c];
+    nss[i * 2] = sc;
+    nss[i * 2 + 1] = fmaf(-stats[i * 3], sc, beta[c]);
+}
+// ws[g][c] = {sum dz, sum dz * x} (raw, from the conv epilogue) -> {sum dz, sum dz * xhat}, xhat = (x - mean) * inv: in double, the
+// cancellation mean * sum dz against sum dz * x happens once, on the totals
+__global__ void k_norm_bwd_center(double* __restrict__ ws, const float* __restrict__ stats, int G, int C) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= G * C) return;
+    ws[i * 2 + 1] = (ws[i * 2 + 1] - (double)stats[i * 3] * ws[i * 2]) * (double)stats[i * 3 + 1];
+}
 
 // y = act((x - mean) * inv * gamma + beta).  A thread keeps its channel group for the whole grid-stride loop whenever the stride is a
 // multiple of C/VEC (always, for power-of-two channel counts), so the per-channel scale / shift live in registers and are only rebuilt
@@ -283,7 +301,7 @@ __global__ void k_norm_bwd_apply(const T* __restrict__ x, const T* __restrict__ 
         }
         float xv[VEC], yv[VEC], dv[VEC], o[VEC];
         ldv<T, VEC>(x + v * C + cg * VEC, xv);
-        if (!fromx) ldv<T, VEC>(y + v * C + cg * VEC, yv);
+        if (!fromx && act != FMRI_ACT_NONE) ldv<T, VEC>(y + v * C + cg * VEC, yv);      // (act none: dy is taken as it is - the `pre` form)
         ldv<T, VEC>(dy + v * C + cg * VEC, dv);
 #pragma unroll
         for (int k = 0; k < VEC; ++k) {
@@ -374,15 +392,41 @@ __global__ void k_deconv_wgrad(const T* __restrict__ x, const T* __restrict__ dy
 
 }  // namespace
 
+int norm_ws_zero(double* ws, int n, hipStream_t s) {
+    if (!ws || n <= 0) return FMRI_E_SHAPE;
+    k_zero_d<<<(n + 255) / 256, 256, 0, s>>>(ws, n);
+    FMRI_LAUNCH_CHECK();
+    return FMRI_OK;
+}
+// ws[0][i] = sum over the slots s = 1 .. nslot of ws[s][i], i < n (the per-workgroup partial sums of a conv launch's normalisation tail)
+__global__ void k_ws_fold(double* __restrict__ ws, int nslot, int n) {
+    const int i = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;       // 4 slot ranges per entry
+    __shared__ double red[4][64];
+    double a = 0.0;
+    if (i < n)
+        for (int s = 1 + part; s <= nslot; s += 4) a += ws[(int64_t)s * n + i];
+    red[part][threadIdx.x & 63] = a;
+    __syncthreads();
+    if (part == 0 && i < n) ws[i] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+int norm_ws_fold(double* ws, int nslot, int n, hipStream_t s) {
+    if (!ws || n <= 0 || nslot <= 0) return FMRI_E_SHAPE;
+    k_ws_fold<<<(n + 63) / 64, 256, 0, s>>>(ws, nslot, n);
+    FMRI_LAUNCH_CHECK();
+    return FMRI_OK;
+}
+
 // -------------------------------------------------------------------------------------------------------------- C ABI
-extern "C" int fmri_norm_act_fwd(const void* x, const float* gamma, const float* beta, void* y, float* stats, double* ws, int N,
-                                 int64_t V, int C, int per_instance, float eps, int eps_on_std, int act, float alpha, int dtype,
-                                 fmri_stream_t stream) {
+// have_sums: ws already holds {sum x, sum x^2} per (group, channel) - the conv in front summed its own output (fmri_conv3d_fwd_stats)
+static int norm_act_fwd_impl(const void* x, const float* gamma, const float* beta, void* y, float* stats, double* ws, int N,
+                             int64_t V, int C, int per_instance, float eps, int eps_on_std, int act, float alpha, int dtype,
+                             bool have_sums, fmri_stream_t stream) {
     if (N <= 0 || V <= 0 || C <= 0 || !stats || !ws) return FMRI_E_SHAPE;
     hipStream_t s = as_stream(stream);
     if (dtype != FMRI_F32 && dtype != FMRI_BF16) return FMRI_E_DTYPE;
     if (per_instance >= 0) {            // per_instance < 0: inference with the statistics already in `stats` (moving averages)
         const int G = per_instance ? N : 1;
+        if (!have_sums) {
         k_zero_d<<<(G * C * 2 + 255) / 256, 256, 0, s>>>(ws, G * C * 2);
         const int vchunk = norm_vchunk(V, N, per_instance, C);
         dim3 grid((unsigned)ceil_div64(V, vchunk), (C + 63) / 64, N);
@@ -390,6 +434,7 @@ extern "C" int fmri_norm_act_fwd(const void* x, const float* gamma, const float*
             k_norm_reduce_v<bf16_t, 8><<<dim3(grid.x, 1, N), 256, 0, s>>>((const bf16_t*)x, ws, V, C, per_instance, vchunk);
         else if (dtype == FMRI_F32) k_norm_reduce<float><<<grid, 256, 0, s>>>((const float*)x, ws, V, C, per_instance, vchunk);
         else k_norm_reduce<bf16_t><<<grid, 256, 0, s>>>((const bf16_t*)x, ws, V, C, per_instance, vchunk);
+        }
         const double M = per_instance ? (double)V : (double)V * N;
         k_norm_finalize<<<(G * C + 255) / 256, 256, 0, s>>>(ws, stats, G, C, M, eps, eps_on_std);
     } else {
@@ -405,17 +450,45 @@ extern "C" int fmri_norm_act_fwd(const void* x, const float* gamma, const float*
     FMRI_LAUNCH_CHECK();
     return FMRI_OK;
 }
+extern "C" int fmri_norm_act_fwd(const void* x, const float* gamma, const float* beta, void* y, float* stats, double* ws, int N,
+                                 int64_t V, int C, int per_instance, float eps, int eps_on_std, int act, float alpha, int dtype,
+                                 fmri_stream_t stream) {
+    return norm_act_fwd_impl(x, gamma, beta, y, stats, ws, N, V, C, per_instance, eps, eps_on_std, act, alpha, dtype, false, stream);
+}
+// as fmri_norm_act_fwd with the reduction pass already done: ws[g][C][2] = {sum x, sum x^2} as left by fmri_conv3d_fwd_stats /
+// fmri_conv3d_upcat_fwd_stats (training statistics only: per_instance 0 | 1)
+extern "C" int fmri_norm_act_fwd_pre(const void* x, const float* gamma, const float* beta, void* y, float* stats, double* ws, int N,
+                                     int64_t V, int C, int per_instance, float eps, int eps_on_std, int act, float alpha, int dtype,
+                                     fmri_stream_t stream) {
+    if (per_instance < 0) return FMRI_E_SHAPE;
+    return norm_act_fwd_impl(x, gamma, beta, y, stats, ws, N, V, C, per_instance, eps, eps_on_std, act, alpha, dtype, true, stream);
+}
+extern "C" int fmri_norm_scale_shift(const float* stats, const float* gamma, const float* beta, float* nss, int G, int C, fmri_stream_t stream) {
+    if (!stats || !gamma || !beta || !nss || G <= 0 || C <= 0) return FMRI_E_SHAPE;
+    k_norm_scale_shift<<<(G * C + 255) / 256, 256, 0, as_stream(stream)>>>(stats, gamma, beta, nss, G, C);
+    FMRI_LAUNCH_CHECK();
+    return FMRI_OK;
+}
 
+// pre: dy is already dz = dy * act'(z) and ws holds the raw sums {sum dz, sum dz * x} (fmri_conv3d_dgrad_norm)
 static int norm_act_bwd_impl(const void* x, const void* y, const void* dy, const float* gamma, const float* beta, const float* stats, void* dx,
                              float* dgamma, float* dbeta, double* ws, int N, int64_t V, int C, int per_instance, int act,
-                             float alpha, int dtype, fmri_stream_t stream) {
-    if (N <= 0 || V <= 0 || C <= 0 || !stats || !ws || (!y && !beta)) return FMRI_E_SHAPE;
+                             float alpha, int dtype, fmri_stream_t stream, bool pre = false) {
+    if (N <= 0 || V <= 0 || C <= 0 || !stats || !ws || (!y && !beta && !pre)) return FMRI_E_SHAPE;
     hipStream_t s = as_stream(stream);
     const int G = per_instance ? N : 1;
-    k_zero_d<<<(G * C * 2 + 255) / 256, 256, 0, s>>>(ws, G * C * 2);
     const int vchunk = norm_vchunk(V, N, per_instance, C);
     dim3 grid((unsigned)ceil_div64(V, vchunk), (C + 63) / 64, N);
-    if (norm_vec_ok(C, dtype)) {
+    if (pre) {
+        if (dtype != FMRI_F32 && dtype != FMRI_BF16) return FMRI_E_DTYPE;
+        k_norm_bwd_center<<<(G * C + 255) / 256, 256, 0, s>>>(ws, stats, G, C);
+        act = FMRI_ACT_NONE;           // the apply pass takes dz as it is
+        beta = nullptr;
+        y = x;                         // (never read with act == none)
+    } else
+    k_zero_d<<<(G * C * 2 + 255) / 256, 256, 0, s>>>(ws, G * C * 2);
+    if (pre) {
+    } else if (norm_vec_ok(C, dtype)) {
         if (beta)
             k_norm_bwd_reduce_v<bf16_t, 8, true><<<dim3(grid.x, 1, N), 256, 0, s>>>((const bf16_t*)x, (const bf16_t*)y, (const bf16_t*)dy, stats, gamma,
                                                                                       beta, ws, V, C, per_instance, act, alpha, vchunk);
@@ -450,6 +523,13 @@ extern "C" int fmri_norm_act_bwd_x(const void* x, const void* dy, const float* g
                                    float alpha, int dtype, fmri_stream_t stream) {
     if (!beta) return FMRI_E_SHAPE;
     return norm_act_bwd_impl(x, nullptr, dy, gamma, beta, stats, dx, dgamma, dbeta, ws, N, V, C, per_instance, act, alpha, dtype, stream);
+}
+// the rest of the normalisation's backward pass behind fmri_conv3d_dgrad_norm: dz (activation derivative applied) and ws = {sum dz, sum dz * x}
+// come from that launch's epilogue; parameter gradients and dx = gamma * [(dz - mean(dz)) / s - xhat * mean(dz * xhat) / sigma] remain
+extern "C" int fmri_norm_act_bwd_pre(const void* x, const void* dz, const float* gamma, const float* stats, void* dx, float* dgamma, float* dbeta,
+                                     double* ws, int N, int64_t V, int C, int per_instance, int dtype, fmri_stream_t stream) {
+    if (!x || !dz || !dx) return FMRI_E_SHAPE;
+    return norm_act_bwd_impl(x, nullptr, dz, gamma, nullptr, stats, dx, dgamma, dbeta, ws, N, V, C, per_instance, FMRI_ACT_NONE, 0.f, dtype, stream, true);
 }
 
 extern "C" int fmri_deconv3d_k2s2_fwd(const void* x, const void* w, const float* b, void* y, int N, int D, int H, int W, int Cin, int Cout,

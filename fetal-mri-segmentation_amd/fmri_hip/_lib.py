@@ -47,6 +47,14 @@ SIGNATURES = {
     "fmri_norm_act_fwd": [p, p, p, p, p, p, i32, i64, i32, i32, f32, i32, i32, f32, i32, p],
     "fmri_norm_act_bwd": [p, p, p, p, p, p, p, p, p, i32, i64, i32, i32, i32, f32, i32, p],
     "fmri_norm_act_bwd_x": [p, p, p, p, p, p, p, p, p, i32, i64, i32, i32, i32, f32, i32, p],
+    "fmri_conv3d_fwd_ntail_ok": [i32, i32, i32, i32, i32, i32, i32, i32],
+    "fmri_norm_tail_ws_doubles": [i32, i32],
+    "fmri_conv3d_fwd_stats": [p, i32, i32, p, i32, p, p, p, i32, i32, i32, i32, i32, i32, f32, p, i32, i32, p],
+    "fmri_conv3d_upcat_fwd_stats": [p, i32, p, i32, p, p, p, p, i32, i32, i32, i32, i32, i32, f32, p, i32, i32, p],
+    "fmri_norm_act_fwd_pre": [p, p, p, p, p, p, i32, i64, i32, i32, f32, i32, i32, f32, i32, p],
+    "fmri_norm_scale_shift": [p, p, p, p, i32, i32, p],
+    "fmri_conv3d_dgrad_norm": [p, i32, p, p, p, p, i32, i32, i32, i32, i32, i32, f32, p, i32, i32, p],
+    "fmri_norm_act_bwd_pre": [p, p, p, p, p, p, p, p, i32, i64, i32, i32, i32, p],
     "fmri_deconv3d_k2s2_fwd": [p, p, p, p, i32, i32, i32, i32, i32, i32, i32, i32, p],
     "fmri_deconv3d_k2s2_bwd": [p, p, p, i32, i32, p, p, p, p, i32, i32, i32, i32, i32, i32, i32, i32, p],
     "fmri_conv3d_direct_fwd": [p, p, p, p, i32, i32, i32, i32, i32, i32, i32, i32, i32, f32, i32, p],
@@ -118,7 +126,7 @@ def lib():
         for name, args in SIGNATURES.items():
             fn = getattr(L, name)
             fn.argtypes = args
-            fn.restype = C.c_char_p if name == "fmri_error_string" else (i64 if name.endswith("_workspace_bytes") else i32)
+            fn.restype = C.c_char_p if name == "fmri_error_string" else (i64 if name.endswith(("_workspace_bytes", "_ws_doubles")) else i32)
         _lib = L
     return _lib
 

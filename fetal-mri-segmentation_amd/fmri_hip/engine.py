@@ -466,12 +466,12 @@ class UNetEngine:
             self.N = N
             self._build_buffers()
             self._bufsets[key] = dict(act=self.act, grad=getattr(self, "grad", None), logits=self.logits, probs=self.probs,
-                                      dlogits=getattr(self, "dlogits", None), pre=self.pre, nstats=self.nstats, norm_ws=self.norm_ws,
+                                      dlogits=getattr(self, "dlogits", None), pre=self.pre, nstats=self.nstats, nss=self.nss, norm_ws=self.norm_ws,
                                       wgrad_ws=getattr(self, "wgrad_ws", None),
                                       dummy_y=torch.zeros(self.logits.numel(), dtype=torch.uint8, device=self.dev))
         b = self._bufsets[key]
         self.N, self.act, self.grad, self.logits, self.probs, self.dlogits = N, b["act"], b["grad"], b["logits"], b["probs"], b["dlogits"]
-        self.pre, self.nstats, self.norm_ws, self.wgrad_ws = b["pre"], b["nstats"], b["norm_ws"], b["wgrad_ws"]
+        self.pre, self.nstats, self.nss, self.norm_ws, self.wgrad_ws = b["pre"], b["nstats"], b["nss"], b["norm_ws"], b["wgrad_ws"]
         self._dummy_y = b["dummy_y"]       # per buffer set and never freed: captured hipGraphs keep raw pointers to it
 
     def _dims(self, level):
@@ -484,6 +484,7 @@ class UNetEngine:
         p, N, dt, dev = self.plan, self.N, self.dtype, self.dev
         A = self.act = {}
         self.pre, self.nstats = {}, {}            # conv outputs before normalisation; saved statistics {mean, 1/s, 1/sigma}
+        self.nss = {}                             # {scale, shift} of the apply pass, for the normalisation tail of the input-gradient launches
         G = N if (p.norm == "instance" and not self.planar) else 1
         if p.norm == "instance" and self.planar:
             G = N                                  # 2-D: every slice is a sample
@@ -493,6 +494,7 @@ class UNetEngine:
             if c.get("norm"):
                 self.pre[c["name"]] = torch.empty_like(A[c["name"]])
                 self.nstats[c["name"]] = torch.zeros((G, c["cout"], 3), dtype=torch.float32, device=dev)
+                self.nss[c["name"]] = torch.zeros((G, c["cout"], 2), dtype=torch.float32, device=dev)
 
         for lv in p.enc:
             for c in lv:
@@ -506,7 +508,9 @@ class UNetEngine:
             for c in lv:
                 block_bufs(c)
         cmax = max(c["cout"] for c in p.convs_forward_order())
-        self.norm_ws = torch.zeros((max(G, 1), cmax, 2), dtype=torch.float64, device=dev) if p.norm else None
+        # scratch of the normalisation sums: [G][C][2] doubles - and, behind them, the per-workgroup blocks of the conv launches' tails
+        self.norm_ws = torch.zeros(max(max(G, 1) * cmax * 2, ops.norm_tail_ws_doubles(max(G, 1), cmax) if dev.type == "cuda" else 0),
+                                   dtype=torch.float64, device=dev) if p.norm else None
         nvox0 = int(np.prod(self._dims(0)))
         self.logits = torch.empty((nvox0, p.n_labels), dtype=torch.float32, device=dev)
         self.probs = torch.empty_like(self.logits)
@@ -558,6 +562,26 @@ class UNetEngine:
             cache[key] = ops.conv3d_fwd_tail_ok(c["cin"], c["cout"], d[0], d[1], d[2], d[3], self.dtype)
         return cache[key]
 
+    def _ntail_ok(self, c0, c1, cout, level, kind=1):
+        """does the 3-D MFMA launch (c0 | c1) -> cout at `level` carry a normalisation tail (kind 1: statistics of its output, kind 2: the
+        backward reductions - in its asynchronous epilogue: ops.conv3d_fwd_ntail_ok)?  FMRI_NORM_FUSE = bit mask of the kinds in use,
+        FMRI_NORM_FUSE_MAXLEVEL = deepest level that uses them.  Defaults from the interleaved A/B inside the configs[1] step
+        (tools/ab_norm_tails.py, profiles/r03_norm_tails_ab.log): the statistics tail down to level 1 (batch norm: 21.02 -> 20.74 ms) or on
+        level 0 only (instance norm: a workgroup's sums are flushed whenever the sample changes; 21.41 -> 21.27 ms); the backward tail is
+        built and tested but off: it saves 170-340 us of reduction passes per full-resolution layer and costs the input-gradient launch
+        100-180 us (tools/bench_ntail.py) - a launch that shares the chip with the weight-gradient stream, under which the HBM-bound
+        reduction passes were already hidden (step +0.13 ms with it)."""
+        if self.plan.norm is None or self.planar or self.dtype != torch.bfloat16 or not (int(os.environ.get("FMRI_NORM_FUSE", "1")) & kind):
+            return False
+        if level > int(os.environ.get("FMRI_NORM_FUSE_MAXLEVEL", "1" if self.plan.norm == "batch" else "0")):
+            return False
+        key = (c0, c1, cout, level, self.N)
+        cache = self.__dict__.setdefault("_ntail_cache", {})
+        if key not in cache:
+            d = self._dims(level)
+            cache[key] = ops.conv3d_fwd_ntail_ok(c0, c1, cout, d[0], d[1], d[2], d[3], self.dtype)
+        return cache[key]
+
     def _block_fwd(self, c, src0, src1, up0, bn_training, pool=None, final=None):
         """one [conv -> (norm) -> ReLU] block (reference create_convolution_block, unet.py:89-115).  pool: tensor that receives
         MaxPooling3D(2) of the block's output; final: the final 1x1x1 conv descriptor whose logits the epilogue computes - both only
@@ -570,14 +594,25 @@ class UNetEngine:
                                 b1=self.b_view(final["name"]) if final is not None else None,
                                 logits=self.logits.reshape(-1) if final is not None else None, act=act)
             return self.act[name]
+        # normalised block with training statistics: the conv sums its own output in its epilogue where the launch allows it
+        per, eos = self._norm_mode()
+        want_sums = bool(c.get("norm")) and not (self.plan.norm == "batch" and not bn_training)
+        c0, c1 = src0.shape[-1], (0 if src1 is None else src1.shape[-1])
+        summed = False
         if up0 and self._use_upcat(name):
             W = self.Wup[name]
-            ops.conv3d_upcat_fwd(src0, src1, W["up_f"], W["sk_f"], self.b_view(name), out, act=act, planar=self.planar)
+            if want_sums and src1 is not None and self._ntail_ok(c1, 0, c["cout"], c["level"]):
+                ops.conv3d_upcat_fwd_stats(src0, src1, W["up_f"], W["sk_f"], self.b_view(name), out, self.norm_ws, per, act=act)
+                summed = True
+            else:
+                ops.conv3d_upcat_fwd(src0, src1, W["up_f"], W["sk_f"], self.b_view(name), out, act=act, planar=self.planar)
+        elif want_sums and self._ntail_ok(c0, c1, c["cout"], c["level"]):
+            ops.conv3d_fwd_stats(src0, src1, self.Wf[name], self.b_view(name), out, self.norm_ws, per, up0=up0, act=act)
+            summed = True
         else:
             ops.conv3d_fwd(src0, src1, self.Wf[name], self.b_view(name), out, up0=up0, act=act, planar=self.planar)
         if not c.get("norm"):
             return self.act[name]
-        per, eos = self._norm_mode()
         st = self.nstats[name]
         if self.plan.norm == "batch" and not bn_training:
             mv = self.moving[name]                                            # inference: moving averages (Keras learning_phase 0)
@@ -585,8 +620,9 @@ class UNetEngine:
             st[0, :, 1] = torch.rsqrt(mv[1] + 1e-3)
             st[0, :, 2] = st[0, :, 1]
             per = -1
-        ops.norm_act_fwd(self._as_samples(self.pre[name]), self.gb_view(name, "gamma"), self.gb_view(name, "beta"),
-                         self._as_samples(self.act[name]), st, self.norm_ws, per, eps=1e-3, eps_on_std=eos, act=ACT_RELU)
+        (ops.norm_act_fwd_pre if summed else ops.norm_act_fwd)(
+            self._as_samples(self.pre[name]), self.gb_view(name, "gamma"), self.gb_view(name, "beta"),
+            self._as_samples(self.act[name]), st, self.norm_ws, per, eps=1e-3, eps_on_std=eos, act=ACT_RELU)
         if self.plan.norm == "batch" and bn_training:
             # Keras moving statistics (momentum 0.99); the variance fed to the moving average is sample-size corrected
             M = float(self.pre[name].numel() // c["cout"])
@@ -674,7 +710,12 @@ class UNetEngine:
         G[c] and accumulates the block's parameter gradients."""
         name = c["name"]
         g = self.grad[name]
-        if c.get("norm"):
+        if c.get("norm") and name in self._dz_ready:
+            # the input-gradient launch that produced g already applied the ReLU mask and left the two reductions in norm_ws (_dgrad_into)
+            self._dz_ready.discard(name)
+            ops.norm_act_bwd_pre(self.pre[name], g, self.gb_view(name, "gamma"), self.nstats[name], g, self.gb_view(name, "gamma", self.G),
+                                 self.gb_view(name, "beta", self.G), self.norm_ws, self._norm_mode()[0])
+        elif c.get("norm"):
             per, _ = self._norm_mode()
             # (beta given: the ReLU mask is recomputed from the pre-normalisation tensor, the block's output is not read)
             ops.norm_act_bwd(self._as_samples(self.pre[name]), None, self._as_samples(g),
@@ -729,6 +770,19 @@ class UNetEngine:
                 wgrad()
         ops.conv3d_upcat_dgrad(g, F["up_d"], F["sk_d"], self._mask_of(low), None, self.grad[low], cat)
 
+    def _dgrad_into(self, b, a):
+        """dL/d(output of block a) from block b's conv (whose only input is a's output) -> grad[a].  a normalised: the launch's epilogue
+        applies a's ReLU mask (recomputed from a's conv output) and sums dz and dz * x for a's normalisation backward where it can."""
+        Gd = self.grad
+        an, bn = a["name"], b["name"]
+        if an in self.pre and self._ntail_ok(b["cout"], 0, a["cout"], a["level"], kind=2):
+            per = self._norm_mode()[0]
+            ops.norm_scale_shift(self.nstats[an], self.gb_view(an, "gamma"), self.gb_view(an, "beta"), self.nss[an])
+            ops.conv3d_dgrad_norm(Gd[bn], self.Wd[bn], self.pre[an], self.nss[an], Gd[an], self.norm_ws, per, act=ACT_RELU)
+            self._dz_ready.add(an)
+        else:
+            ops.conv3d_dgrad(Gd[bn], self.Wd[bn], Gd[an], mask=self._mask_of(an), planar=self.planar)
+
     def _mask_of(self, name):
         """ReLU mask tensor a consumer applies to the gradient of `name`'s output, or None when the block is normalised (its
         norm backward applies the activation derivative itself) or `name` is not a conv block."""
@@ -743,6 +797,7 @@ class UNetEngine:
         p, A, Gd = self.plan, self.act, self.grad
         normed = p.norm is not None
         self._main_stream = torch.cuda.current_stream(self.dev) if self.dev.type == "cuda" else None
+        self._dz_ready = set()
         self.G.zero_()
         if seg_loss and self.loss_kind == ops.LOSS_WEIGHTED_DICE:
             ns, nl = self._wdice_groups()
@@ -764,7 +819,7 @@ class UNetEngine:
             low = self._dec_input_name(ld)
             skip = A[p.enc[ld][1]["name"]]
             self._block_bwd(b, A[a["name"]], None, False)
-            ops.conv3d_dgrad(Gd[b["name"]], self.Wd[b["name"]], Gd[a["name"]], mask=self._mask_of(a["name"]), planar=self.planar)
+            self._dgrad_into(b, a)
             cat = Gd["cat_%d" % ld]
             if a["name"] in self.Wfd:
                 self._folded_bwd(a, A[low], skip, cat, low)
@@ -813,7 +868,7 @@ class UNetEngine:
                 ops.maxpool_bwd(A[cb["name"]], Gd["pool_%d" % ld], Gd[cb["name"]], add=cat, add_off=cat.shape[-1] - cb["cout"],
                                 relu_mask=not normed, planar=self.planar)
             self._block_bwd(cb, A[ca["name"]], None, False)
-            ops.conv3d_dgrad(Gd[cb["name"]], self.Wd[cb["name"]], Gd[ca["name"]], mask=self._mask_of(ca["name"]), planar=self.planar)
+            self._dgrad_into(cb, ca)
             xin = self.x_in if ld == 0 else A["pool_%d" % (ld - 1)]
             self._block_bwd(ca, xin, None, False)
             if ld > 0:

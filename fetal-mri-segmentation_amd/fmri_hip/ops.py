@@ -226,6 +226,71 @@ def norm_act_bwd(x, y, dy, gamma, stats, dx, dgamma, dbeta, ws, per_instance, ac
     return dx
 
 
+# ---- normalisation tails of the conv launches (include/fmri_hip.h: "Normalisation tails")
+def conv3d_fwd_ntail_ok(C0, C1, Cout, N, D, H, W, dtype):
+    return bool(lib().fmri_conv3d_fwd_ntail_ok(C0, C1, Cout, N, D, H, W, BF16 if dtype == torch.bfloat16 else F32))
+
+
+def norm_tail_ws_doubles(G, C):
+    """fp64 elements of the `ws` the tail entry points need (the totals [G,C,2] in front + one block per workgroup of the persistent launch)"""
+    return int(lib().fmri_norm_tail_ws_doubles(int(G), int(C)))
+
+
+def conv3d_fwd_stats(src0, src1, w, bias, y, ws, per_instance, up0=False, act=ACT_NONE, alpha=0.0):
+    """conv3d_fwd whose epilogue leaves {sum y, sum y^2} per (group, channel) in front of ws (fp64, norm_tail_ws_doubles(G, Cout) elements,
+    zeroed by the call)"""
+    _need_cuda(src0, src1, w, bias, y, ws)
+    N, D, H, W, Cout = y.shape
+    c0, c1 = src0.shape[-1], (0 if src1 is None else src1.shape[-1])
+    check(lib().fmri_conv3d_fwd_stats(_p(src0), c0, int(up0), _p(src1), c1, _p(w), _p(bias), _p(y), N, D, H, W, Cout, act, float(alpha), _p(ws),
+                                      int(per_instance), dt(y), _s()), "fmri_conv3d_fwd_stats")
+    return y
+
+
+def conv3d_upcat_fwd_stats(src0_low, src1, w_up_f, w_sk_f, bias, y, ws, per_instance, act=ACT_NONE, alpha=0.0):
+    _need_cuda(src0_low, src1, w_up_f, w_sk_f, bias, y, ws)
+    N, D, H, W, Cout = y.shape
+    check(lib().fmri_conv3d_upcat_fwd_stats(_p(src0_low), src0_low.shape[-1], _p(src1), src1.shape[-1], _p(w_up_f), _p(w_sk_f), _p(bias), _p(y),
+                                            N, D, H, W, Cout, act, float(alpha), _p(ws), int(per_instance), dt(y), _s()),
+          "fmri_conv3d_upcat_fwd_stats")
+    return y
+
+
+def norm_act_fwd_pre(x, gamma, beta, y, stats, ws, per_instance, eps=1e-3, eps_on_std=False, act=ACT_RELU, alpha=0.0):
+    """norm_act_fwd with the sums {sum x, sum x^2} already in ws (conv3d_fwd_stats / conv3d_upcat_fwd_stats)"""
+    _need_cuda(x, gamma, beta, y, stats, ws)
+    N, Cc = x.shape[0], x.shape[-1]
+    V = x.numel() // (N * Cc)
+    check(lib().fmri_norm_act_fwd_pre(_p(x), _p(gamma), _p(beta), _p(y), _p(stats), _p(ws), N, V, Cc, int(per_instance), float(eps),
+                                      int(eps_on_std), act, float(alpha), dt(x), _s()), "fmri_norm_act_fwd_pre")
+    return y
+
+
+def norm_scale_shift(stats, gamma, beta, nss):
+    """nss [G,C,2] fp32 = {scale, shift} of the apply pass (z = fma(x, scale, shift))"""
+    _need_cuda(stats, gamma, beta, nss)
+    check(lib().fmri_norm_scale_shift(_p(stats), _p(gamma), _p(beta), _p(nss), stats.shape[0], stats.shape[1], _s()), "fmri_norm_scale_shift")
+    return nss
+
+
+def conv3d_dgrad_norm(dy, w_dgrad, x, nss, dz, ws, per_instance, act=ACT_RELU, alpha=0.0):
+    """conv3d_dgrad into a normalised block: dz = dgrad * act'(z(x)), ws [G,Cin,2] = {sum dz, sum dz * x}"""
+    _need_cuda(dy, w_dgrad, x, nss, dz, ws)
+    N, D, H, W, Cin = dz.shape
+    check(lib().fmri_conv3d_dgrad_norm(_p(dy), dy.shape[-1], _p(w_dgrad), _p(x), _p(nss), _p(dz), N, D, H, W, Cin, act, float(alpha), _p(ws),
+                                       int(per_instance), dt(dz), _s()), "fmri_conv3d_dgrad_norm")
+    return dz
+
+
+def norm_act_bwd_pre(x, dz, gamma, stats, dx, dgamma, dbeta, ws, per_instance):
+    _need_cuda(x, dz, gamma, stats, dx, dgamma, dbeta, ws)
+    N, Cc = x.shape[0], x.shape[-1]
+    V = x.numel() // (N * Cc)
+    check(lib().fmri_norm_act_bwd_pre(_p(x), _p(dz), _p(gamma), _p(stats), _p(dx), _p(dgamma), _p(dbeta), _p(ws), N, V, Cc, int(per_instance),
+                                      dt(x), _s()), "fmri_norm_act_bwd_pre")
+    return dx
+
+
 def deconv_fwd(x, w, b, y, planar=False):
     """x [N,D,H,W,Cin], w [8,Cout,Cin] (compute dtype), y [N,2D,2H,2W,Cout]"""
     _need_cuda(x, w, b, y)

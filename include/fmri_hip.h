@@ -227,6 +227,38 @@ int fmri_norm_act_bwd_x(const void* x, const void* dy, const float* gamma, const
                         float* dbeta, double* ws, int N, int64_t V, int C, int per_instance, int act, float alpha, int dtype,
                         fmri_stream_t stream);
 
+/* ---- Normalisation tails of the conv launches (round 3; north-star "fused InstanceNorm+ReLU"; reference create_convolution_block,
+ * fetal_net/model/unet3d/unet.py:103-115, isensee2017.py:12: Conv3D -> BatchNormalization | InstanceNormalization -> activation).
+ * The conv in front of the normalisation layer sums its own output for the layer's statistics (no reduction pass over the tensor), and
+ * the input-gradient launch behind a normalised block applies the activation's derivative and forms the two reductions of the
+ * normalisation's backward pass - both in the asynchronous epilogue of the bf16 MFMA kernel, i.e. for launches with more (tile, channel
+ * block) pairs than CUs: fmri_conv3d_fwd_ntail_ok(C0, C1, Cout, ...) != 0.  Elsewhere the caller keeps fmri_conv3d_fwd +
+ * fmri_norm_act_fwd / fmri_norm_act_bwd_x (same results up to the order of summation).  ws: fmri_norm_tail_ws_doubles(G, C) doubles,
+ * zeroed by these calls: the totals [G][C][2] in front (what the *_pre functions read), behind them one block per workgroup of the
+ * persistent launch - every workgroup sums into its own, a small kernel folds them (1,024 waves adding to the same 128 addresses with
+ * device-scope atomics cost more than the reduction pass the tail replaces). */
+int64_t fmri_norm_tail_ws_doubles(int G, int C);
+int fmri_conv3d_fwd_ntail_ok(int C0, int C1, int Cout, int N, int D, int H, int W, int dtype);
+/* fmri_conv3d_fwd (3-D, MFMA path) + ws[g][c] = {sum y, sum y^2} over the bf16 values as stored */
+int fmri_conv3d_fwd_stats(const void* src0, int C0, int up0, const void* src1, int C1, const void* w, const float* bias, void* y, int N, int D,
+                          int H, int W, int Cout, int act, float alpha, double* ws, int per_instance, int dtype, fmri_stream_t stream);
+/* fmri_conv3d_upcat_fwd + the same sums (needs fmri_conv3d_fwd_ntail_ok(C1, 0, Cout, ...): the skip launch finishes and sums the output) */
+int fmri_conv3d_upcat_fwd_stats(const void* src0_low, int C0, const void* src1, int C1, const void* w_up_fwd, const void* w_skip_fwd,
+                                const float* bias, void* y, int N, int D, int H, int W, int Cout, int act, float alpha, double* ws,
+                                int per_instance, int dtype, fmri_stream_t stream);
+/* fmri_norm_act_fwd without its reduction pass: ws already holds {sum x, sum x^2} (per_instance 0 | 1) */
+int fmri_norm_act_fwd_pre(const void* x, const float* gamma, const float* beta, void* y, float* stats, double* ws, int N, int64_t V, int C,
+                          int per_instance, float eps, int eps_on_std, int act, float alpha, int dtype, fmri_stream_t stream);
+/* nss[g][c] = {scale, shift} with z = fma(x, scale, shift) the normalised pre-activation - the apply pass's own operations */
+int fmri_norm_scale_shift(const float* stats, const float* gamma, const float* beta, float* nss, int G, int C, fmri_stream_t stream);
+/* fmri_conv3d_dgrad (3-D, MFMA path; needs fmri_conv3d_fwd_ntail_ok(Cout, 0, Cin, ...)) whose output feeds a normalised block's backward:
+ * dz = conv_dgrad(dy) * act'(z(x)), x = that block's conv output, nss its {scale, shift}; ws[g][c] = {sum dz, sum dz * x} */
+int fmri_conv3d_dgrad_norm(const void* dy, int Cout, const void* w_dgrad, const void* x, const float* nss, void* dz, int N, int D, int H, int W,
+                           int Cin, int act, float alpha, double* ws, int per_instance, int dtype, fmri_stream_t stream);
+/* the rest of the normalisation's backward pass from dz and those sums: dgamma / dbeta (ACCUMULATED) and dx (may alias dz) */
+int fmri_norm_act_bwd_pre(const void* x, const void* dz, const float* gamma, const float* stats, void* dx, float* dgamma, float* dbeta,
+                          double* ws, int N, int64_t V, int C, int per_instance, int dtype, fmri_stream_t stream);
+
 /* ---- Deconvolution3D(filters, kernel_size=(2,2,2), strides=(2,2,2)) — reference unet.py:135.  x [N][D][H][W][Cin] ->
  * y [N][2D][2H][2W][Cout]; w [8 taps = ad*4+ah*2+aw][Cout][Cin] (dtype); planar: (1,2,2) taps 0..3 and D unchanged. */
 int fmri_deconv3d_k2s2_fwd(const void* x, const void* w, const float* b, void* y, int N, int D, int H, int W, int Cin, int Cout,

@@ -295,6 +295,35 @@ def _tie_free_weights(init, fwd_z, lo=21, hi=60, thr=2e-5):
     return W
 
 
+@pytest.mark.parametrize("norm", ["batch", "instance"])
+def test_norm_tails_match_the_separate_passes_bf16(norm, monkeypatch):
+    """bf16 engine with normalisation layers at a size whose level-0 launches have more tiles than CUs (2 x 32x64x64, depth 3, 32
+    filters): the statistics summed in the conv epilogues and the backward reductions formed by the input-gradient launches (default)
+    against the separate reduction passes (FMRI_NORM_FUSE=0).  The conv outputs are the same bits either way; the sums differ by the order
+    of summation, which can move a normalised bf16 value by one unit in the last place."""
+    from fmri_hip.engine import UNetEngine, UNetPlan
+    from oracle import unet_oracle as O
+    spatial, N = (32, 64, 64), 2
+    x, y = O.synthetic_batch((N, 1) + spatial)
+    out = []
+    monkeypatch.setenv("FMRI_NORM_FUSE_MAXLEVEL", "9")
+    for fuse in ("3", "0"):                               # 3: the statistics tails and the backward tails (the latter are off by default)
+        monkeypatch.setenv("FMRI_NORM_FUSE", fuse)
+        eng = UNetEngine(UNetPlan(1, spatial, depth=3, n_base_filters=32, norm=norm), N, dtype=torch.bfloat16, seed=7)
+        xd, yd = _dev_inputs(eng, x, y)
+        eng.forward(xd)
+        eng.loss_forward(yd)
+        eng.backward(yd)
+        torch.cuda.synchronize()
+        fused = sorted(k for k, v in eng._ntail_cache.items() if v) if fuse == "3" else []
+        out.append((eng.logits.double().cpu(), eng.G.double().cpu(), fused))
+    assert len(out[0][2]) >= 3, out[0][2]             # (32,0,64): enc0b forward; (64,0,64): dec0a skip launch, dec0b forward, dec0b input gradient; (64,0,32): enc0b input gradient
+    el = float((out[0][0] - out[1][0]).norm() / out[1][0].norm())
+    eg = float((out[0][1] - out[1][1]).norm() / out[1][1].norm())
+    print("%s: fused launches %s; logits rel L2 %.2e, gradient buffer rel L2 %.2e" % (norm, out[0][2], el, eg))
+    assert el <= 5e-3 and eg <= 2e-2
+
+
 def test_isensee_graph_engine_fp32_vs_oracle():
     """reference isensee2017.py topology (depth 3, 2 segmentation levels, SpatialDropout3D with fixed masks) on the generic
     layer-graph engine: logits, Dice and every gradient vs the torch-CPU restatement."""

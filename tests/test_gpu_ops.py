@@ -409,6 +409,115 @@ def test_norm_act_fwd_bwd(ops, dtype, mode, act, C):
     assert_close(db, br.grad, *tolb, what="norm dbeta")
 
 
+# (N, D, H, W, Cin, Cout): more (tile, channel block) pairs than CUs - 64-wide blocks (Cout 128 -> 2 per tile), 32-wide (Cout 32)
+NTAIL_CASES = [(2, 16, 64, 64, 32, 128), (3, 16, 64, 64, 64, 32)]
+
+
+@pytest.mark.parametrize("case", NTAIL_CASES, ids=lambda c: "N%d_%dx%dx%d_%d_%d" % c)
+@pytest.mark.parametrize("per", [0, 1])
+def test_conv_fwd_stats_tail(ops, case, per):
+    """fmri_conv3d_fwd_stats: the output is the plain launch's bit for bit, and ws holds the sums of the stored bf16 values and of their
+    squares per (group, channel) - what the normalisation's own reduction pass would compute (fp64 sums of the same values as reference)"""
+    N, D, H, W, Cin, Cout = case
+    bf = torch.bfloat16
+    assert ops.conv3d_fwd_ntail_ok(Cin, 0, Cout, N, D, H, W, bf)
+    x = rnd((N, D, H, W, Cin), 300, bf)
+    w = rnd((27, Cout, Cin), 301, bf, scale=0.06)
+    b = rnd((Cout,), 302, torch.float32)
+    y0, y1 = torch.empty((N, D, H, W, Cout), dtype=bf, device="cuda"), torch.empty((N, D, H, W, Cout), dtype=bf, device="cuda")
+    ops.conv3d_fwd(x, None, w, b, y0, act=0)
+    G = N if per else 1
+    wsb = torch.full((ops.norm_tail_ws_doubles(G, Cout),), 7.0, dtype=torch.float64, device="cuda")          # (the call zeroes it)
+    ops.conv3d_fwd_stats(x, None, w, b, y1, wsb, per, act=0)
+    torch.cuda.synchronize()
+    ws = wsb[:G * Cout * 2].view(G, Cout, 2)             # the totals; behind them the per-workgroup partial sums
+    assert torch.equal(y0, y1)
+    yd = y0.double().reshape(G, -1, Cout)
+    ref = torch.stack([yd.sum(1), (yd * yd).sum(1)], dim=-1)
+    scale = torch.stack([yd.abs().sum(1), (yd * yd).sum(1)], dim=-1)
+    err = float(((ws - ref).abs() / scale).max())
+    print("sums vs fp64: max error relative to the sum of magnitudes %.2e" % err)
+    assert err <= 2e-6            # fp32 partial sums of <= 128 values per lane, fp64 from there on
+
+
+@pytest.mark.parametrize("per", [0, 1])
+def test_upcat_fwd_stats_tail(ops, per):
+    N, D, H, W, C0, C1, Cout = 2, 16, 64, 64, 64, 32, 128
+    bf = torch.bfloat16
+    assert ops.conv3d_upcat_ok(C0, C1, Cout, D, H, W, bf) & 1 and ops.conv3d_fwd_ntail_ok(C1, 0, Cout, N, D, H, W, bf)
+    xl, xs = rnd((N, D // 2, H // 2, W // 2, C0), 310, bf), rnd((N, D, H, W, C1), 311, bf)
+    w = rnd((27, Cout, C0 + C1), 312, torch.float32, scale=0.05)
+    up_f = torch.empty((8, 8, Cout, C0), device="cuda", dtype=bf)
+    sk_f = torch.empty((27, Cout, C1), device="cuda", dtype=bf)
+    ops.conv3d_pack_up_weights(w, C0, C1, up_f, None, sk_f, None)
+    b = rnd((Cout,), 313, torch.float32)
+    y0, y1 = torch.empty((N, D, H, W, Cout), dtype=bf, device="cuda"), torch.empty((N, D, H, W, Cout), dtype=bf, device="cuda")
+    ops.conv3d_upcat_fwd(xl, xs, up_f, sk_f, b, y0, act=0)
+    G = N if per else 1
+    wsb = torch.zeros(ops.norm_tail_ws_doubles(G, Cout), dtype=torch.float64, device="cuda")
+    ops.conv3d_upcat_fwd_stats(xl, xs, up_f, sk_f, b, y1, wsb, per, act=0)
+    torch.cuda.synchronize()
+    ws = wsb[:G * Cout * 2].view(G, Cout, 2)
+    assert torch.equal(y0, y1)
+    yd = y0.double().reshape(G, -1, Cout)
+    ref = torch.stack([yd.sum(1), (yd * yd).sum(1)], dim=-1)
+    scale = torch.stack([yd.abs().sum(1), (yd * yd).sum(1)], dim=-1)
+    assert float(((ws - ref).abs() / scale).max()) <= 2e-6
+
+
+@pytest.mark.parametrize("case", NTAIL_CASES, ids=lambda c: "N%d_%dx%dx%d_%d_%d" % c)
+@pytest.mark.parametrize("mode", ["batch", "instance"])
+@pytest.mark.parametrize("act", [1, 2])
+def test_dgrad_norm_tail_matches_the_separate_passes(ops, case, mode, act):
+    """conv -> norm -> activation -> conv, backward through the second conv's input gradient into the first block's normalisation:
+    fmri_conv3d_dgrad_norm + fmri_norm_act_bwd_pre against fmri_conv3d_dgrad + fmri_norm_act_bwd_x.  ReLU: dz is the same tensor bit
+    for bit and the sums differ by the order of summation only; LeakyReLU: the fused form rounds alpha * dy to bf16 before it is summed and
+    used (one rounding more), the two forms then agree to bf16 resolution."""
+    N, D, H, W, Cdy, Cx = case                 # the second conv: Cx -> Cdy; its input gradient has Cx channels
+    bf = torch.bfloat16
+    alpha = 0.2
+    per = mode == "instance"
+    G = N if per else 1
+    assert ops.conv3d_fwd_ntail_ok(Cdy, 0, Cx, N, D, H, W, bf)
+    x = rnd((N, D, H, W, Cx), 320, bf, scale=1.3) + 0.2                   # the first block's conv output
+    gamma = rnd((Cx,), 321, torch.float32) * 0.5 + 1.0
+    beta = rnd((Cx,), 322, torch.float32) * 0.3
+    stats = torch.zeros((G, Cx, 3), device="cuda")
+    ws = torch.zeros((G, Cx, 2), dtype=torch.float64, device="cuda")
+    y = torch.empty_like(x)
+    ops.norm_act_fwd(x, gamma, beta, y, stats, ws, per, eps=1e-3, eps_on_std=per, act=act, alpha=alpha)
+    dy2 = rnd((N, D, H, W, Cdy), 323, bf)                                   # gradient at the second conv's output
+    wd = rnd((27, Cx, Cdy), 324, bf, scale=0.05)
+    # separate passes
+    g0 = torch.empty_like(x)
+    ops.conv3d_dgrad(dy2, wd, g0)
+    dx0, dg0, db0 = torch.empty_like(x), torch.zeros(Cx, device="cuda"), torch.zeros(Cx, device="cuda")
+    ops.norm_act_bwd(x, None, g0, gamma, stats, dx0, dg0, db0, ws, per, act=act, alpha=alpha, beta=beta)
+    # tails
+    nss = torch.empty((G, Cx, 2), device="cuda")
+    ops.norm_scale_shift(stats, gamma, beta, nss)
+    dz = torch.empty_like(x)
+    wsb = torch.full((ops.norm_tail_ws_doubles(G, Cx),), 3.0, dtype=torch.float64, device="cuda")
+    ops.conv3d_dgrad_norm(dy2, wd, x, nss, dz, wsb, per, act=act, alpha=alpha)
+    torch.cuda.synchronize()
+    ws1 = wsb[:G * Cx * 2].view(G, Cx, 2)
+    # dz against its definition on the separate path's tensors: the sign of z from the stored y (same sign as z for both activations)
+    want = torch.where(y.float() > 0, g0.float(), g0.float() * (0.0 if act == 1 else alpha)).to(bf)
+    assert torch.equal(dz, want), "dz: %d of %d values differ" % (int((dz != want).sum()), dz.numel())
+    dzd, xd = dz.double().reshape(G, -1, Cx), x.double().reshape(G, -1, Cx)
+    ref = torch.stack([dzd.sum(1), (dzd * xd).sum(1)], dim=-1)
+    scale = torch.stack([dzd.abs().sum(1), (dzd * xd).abs().sum(1)], dim=-1)
+    assert float(((ws1 - ref).abs() / (scale + 1e-30)).max()) <= 2e-6
+    dx1, dg1, db1 = torch.empty_like(x), torch.zeros(Cx, device="cuda"), torch.zeros(Cx, device="cuda")
+    ops.norm_act_bwd_pre(x, dz, gamma, stats, dx1, dg1, db1, ws1, per)
+    torch.cuda.synchronize()
+    rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())
+    e = (rel(dx1, dx0), rel(dg1, dg0), rel(db1, db0))
+    print("dx %.2e dgamma %.2e dbeta %.2e" % e)
+    bar = 1e-5 if act == 1 else 3e-3                # ReLU: summation order only (+ a rare last-bit flip of a bf16 dx); LeakyReLU: bf16(alpha * dy)
+    assert e[0] <= max(bar, 2e-4) and e[1] <= bar and e[2] <= bar
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("planar", [False, True])
 def test_deconv_k2s2_fwd_bwd(ops, dtype, planar):
