@@ -768,23 +768,9 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
     auto lane_w = [](int rr) { return (rr >> 4) ? (((rr & 15) + 16 - (HW & 15)) & 15) : (rr & 15); };
     constexpr int CPV_ = BN / 8;                     // 16-byte pieces per voxel
     constexpr int VPI_ = 64 / CPV_;                  // voxels per store instruction
-    // element offset in y (and in the mask) of piece q of tile voxel v (column tile v >> 5, lane v & 31)
-    auto piece_addr = [&](const FwdItem& it, int v, int q) -> int64_t {
-        const int rt = v >> 5, rr = v & 31;
-        if constexpr (MODE == 1 && PL) {
-            const int64_t org = ((((int64_t)it.n * D + it.d0) * 2 * H + 2 * it.h0 + ((it.par >> 1) & 1)) * 2 * W + 2 * it.w0 + (it.par & 1)) * Cout + it.co0;
-            return org + ((tile_d(rt) * 2 * H + 2 * tile_h(rt, rr)) * 2 * W + 2 * lane_w(rr)) * Cout + q * 8;
-        } else if constexpr (MODE == 1) {
-            const int64_t org = ((((int64_t)it.n * 2 * D + 2 * it.d0 + (it.par >> 2)) * 2 * H + 2 * it.h0 + ((it.par >> 1) & 1)) * 2 * W +
-                                 2 * it.w0 + (it.par & 1)) * Cout + it.co0;
-            return org + ((2 * tile_d(rt) * 2 * H + 2 * tile_h(rt, rr)) * 2 * W + 2 * lane_w(rr)) * Cout + q * 8;
-        } else {
-            const int64_t org = ((((int64_t)it.n * D + it.d0) * H + it.h0) * W + it.w0) * Cout + it.co0;
-            return org + ((tile_d(rt) * H + tile_h(rt, rr)) * W + lane_w(rr)) * Cout + q * 8;
-        }
-    };
-    // the same address as wave-uniform tile origin (64-bit, scalar registers) + 32-bit lane offset: `base + piece_addr(...)` made hipcc hoist
-    // one sign-extended 64-bit offset per store instruction out of the tile loop (32 registers at BN = 64, the first to be spilled)
+    // address in y (and in the mask / residual) of piece q of tile voxel v (column tile v >> 5, lane v & 31):
+    // wave-uniform tile origin (64-bit, scalar registers) + 32-bit lane offset - as one 64-bit sum per lane hipcc hoisted a sign-extended
+    // offset per store instruction out of the tile loop (32 registers at BN = 64, the first to be spilled)
     auto piece_ptr = [&](const bf16_t* base, const FwdItem& it, int v, int q) -> const char* {
         const int rt = v >> 5, rr = v & 31;
         int64_t org;
@@ -799,9 +785,6 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
             org = ((((int64_t)it.n * D + it.d0) * H + it.h0) * W + it.w0) * Cout + it.co0;
             off = ((tile_d(rt) * H + tile_h(rt, rr)) * W + lane_w(rr)) * Cout + q * 8;
         }
-#ifdef FMRI_PIECE_ADDR64          // (A/B aid: the former 64-bit form)
-        return reinterpret_cast<const char*>(base + piece_addr(it, v, q));
-#endif
         return reinterpret_cast<const char*>(base + org) + (off * 2u);
     };
     // EPI >= 4 (the producers' drain, 4 waves x 4 parts): store instruction kk of producer wave w covers one half (BN = 64) or one row
