@@ -349,7 +349,7 @@ extern "C" int fmri_conv3d_fwd_ntail_ok(int C0, int C1, int Cout, int N, int D, 
     if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || C0 <= 0 || C1 < 0 || Cout <= 0) return 0;
     return conv3d_fwd_ntail_ok(C0, C1, Cout, N, D, H, W, dtype);
 }
-// y = act(conv(src0 | src1) + bias) and ws[g][Cout][2] (double; zeroed here) = {sum y, sum y^2} over the voxels of group g (g = sample when
+// y = act(conv(src0 | src1) + bias) and ws[g][Cout][2] (double; zero on entry like every fmri_norm_* scratch, see the header) = {sum y, sum y^2} over the voxels of group g (g = sample when
 // per_instance, else 0), summed over the bf16 values as stored: what fmri_norm_act_fwd's own reduction pass would read
 extern "C" int fmri_conv3d_fwd_stats(const void* src0, int C0, int up0, const void* src1, int C1, const void* w, const float* bias, void* y,
                                      int N, int D, int H, int W, int Cout, int act, float alpha, double* ws, int per_instance, int dtype,
@@ -359,8 +359,6 @@ extern "C" int fmri_conv3d_fwd_stats(const void* src0, int C0, int up0, const vo
     if (!ws || !w || !y || !conv3d_fwd_ntail_ok(C0, C1, Cout, N, D, H, W, dtype)) return FMRI_E_SHAPE;
     if ((((uintptr_t)src0) | ((uintptr_t)src1) | ((uintptr_t)w) | ((uintptr_t)y) | ((uintptr_t)ws)) & 15) return FMRI_E_ALIGN;
     const int nent = (per_instance ? N : 1) * Cout * 2, nslot = conv3d_fwd_ntail_slots();
-    rc = norm_ws_zero(ws, (1 + nslot) * nent, as_stream(stream));
-    if (rc) return rc;
     rc = conv3d_fwd_mfma_ntail(0, src0, C0, up0, src1, C1, w, bias, nullptr, y, N, D, H, W, Cout, act, alpha, ws, per_instance, nullptr,
                                as_stream(stream));
     if (rc) return rc;
@@ -374,8 +372,7 @@ extern "C" int fmri_conv3d_upcat_fwd_stats(const void* src0_low, int C0, const v
     if (!(upcat_ok(C0, C1, Cout, D, H, W, dtype, 0) & 1) || !conv3d_fwd_ntail_ok(C1, 0, Cout, N, D, H, W, dtype)) return FMRI_E_SHAPE;
     if ((((uintptr_t)src0_low) | ((uintptr_t)src1) | ((uintptr_t)w_up_fwd) | ((uintptr_t)w_skip_fwd) | ((uintptr_t)y) | ((uintptr_t)ws)) & 15) return FMRI_E_ALIGN;
     const int nent = (per_instance ? N : 1) * Cout * 2, nslot = conv3d_fwd_ntail_slots();
-    int rc = norm_ws_zero(ws, (1 + nslot) * nent, as_stream(stream));
-    if (rc) return rc;
+    int rc;
     rc = conv3d_fwd_mfma_ex(1, src0_low, C0, 0, 0, nullptr, 0, w_up_fwd, nullptr, nullptr, nullptr, y, N, D / 2, H / 2, W / 2, Cout, FMRI_ACT_NONE, 0.f,
                             as_stream(stream));
     if (rc) return rc;
@@ -385,7 +382,7 @@ extern "C" int fmri_conv3d_upcat_fwd_stats(const void* src0_low, int C0, const v
     return norm_ws_fold(ws, nslot, nent, as_stream(stream));
 }
 // Input gradient of a conv whose INPUT is the output of a normalised block: dz = conv_dgrad(dy) * act'(z), z = fma(x, sc, sh) recomputed
-// from that block's conv output x and nss[g][Cin][2] = {sc, sh} (fmri_norm_scale_shift), and ws[g][Cin][2] (zeroed here) = {sum dz, sum dz * x}
+// from that block's conv output x and nss[g][Cin][2] = {sc, sh} (fmri_norm_scale_shift), and ws[g][Cin][2] = {sum dz, sum dz * x}
 // over the stored bf16 values of dz - fmri_norm_act_bwd_pre() finishes the normalisation's backward pass from these.  act / alpha: the
 // normalised block's activation.  Cout = channels of dy, Cin = channels of dz and x.
 extern "C" int fmri_conv3d_dgrad_norm(const void* dy, int Cout, const void* w_dgrad, const void* x, const float* nss, void* dz, int N, int D, int H,
@@ -395,8 +392,6 @@ extern "C" int fmri_conv3d_dgrad_norm(const void* dy, int Cout, const void* w_dg
     if (!ws || !w_dgrad || !x || !nss || !dz || !conv3d_fwd_ntail_ok(Cout, 0, Cin, N, D, H, W, dtype)) return FMRI_E_SHAPE;
     if ((((uintptr_t)dy) | ((uintptr_t)w_dgrad) | ((uintptr_t)x) | ((uintptr_t)dz) | ((uintptr_t)ws) | ((uintptr_t)nss)) & 15) return FMRI_E_ALIGN;
     const int nent = (per_instance ? N : 1) * Cin * 2, nslot = conv3d_fwd_ntail_slots();
-    rc = norm_ws_zero(ws, (1 + nslot) * nent, as_stream(stream));
-    if (rc) return rc;
     rc = conv3d_fwd_mfma_ntail(1, dy, Cout, 0, nullptr, 0, w_dgrad, nullptr, x, dz, N, D, H, W, Cin, act, alpha, ws, per_instance, nss,
                                as_stream(stream));
     if (rc) return rc;

@@ -143,7 +143,7 @@ static inline bool norm_vec_ok(int C, int dtype) {
 }
 
 // stats[g][c] = {mean, 1/s, 1/sigma}: s = sqrt(var+eps) (batch norm, Keras) or sqrt(var)+eps (keras-contrib instance norm)
-__global__ void k_norm_finalize(const double* __restrict__ ws, float* __restrict__ stats, int G, int C, double M, float eps,
+__global__ void k_norm_finalize(double* __restrict__ ws, float* __restrict__ stats, int G, int C, double M, float eps,
                                 int eps_on_std) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= G * C) return;
@@ -156,6 +156,9 @@ __global__ void k_norm_finalize(const double* __restrict__ ws, float* __restrict
     stats[i * 3 + 1] = (float)(1.0 / s);
     // a constant channel (sigma = 0, e.g. channel padding) has xhat = 0 everywhere, so the sigma-term of the gradient vanishes: 1/sigma := 0
     stats[i * 3 + 2] = (float)(eps_on_std ? (sigma > 0 ? 1.0 / sigma : 0.0) : 1.0 / s);
+    // leave the accumulators zero for the next reduction (see "ws" in include/fmri_hip.h): one launch less per layer than zeroing in front
+    ws[i * 2] = 0.0;
+    ws[i * 2 + 1] = 0.0;
 }
 __global__ void k_zero_d(double* p, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -171,6 +174,18 @@ __global__ void k_norm_scale_shift(const float* __restrict__ stats, const float*
     const float sc = stats[i * 3 + 1] * gamma[c];
     nss[i * 2] = sc;
     nss[i * 2 + 1] = fmaf(-stats[i * 3], sc, beta[c]);
+}
+// Keras BatchNormalization moving statistics (momentum m): moving = m * moving + (1 - m) * batch value, the variance fed to the average
+// sample-size corrected (x M / (M - 1 - eps), as Keras' fused batch norm does).  One launch instead of the half-dozen element-wise
+// launches per layer the host expression took (56 per step of the batch-norm variant, each serialised between two conv launches).
+__global__ void k_norm_moving_update(const float* __restrict__ stats, float* __restrict__ mmean, float* __restrict__ mvar, int C, float momentum,
+                                     float eps, float corr) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float mean = stats[c * 3], inv = stats[c * 3 + 1];
+    const float var = (1.0f / (inv * inv) - eps) * corr;
+    mmean[c] = mmean[c] * momentum + mean * (1.0f - momentum);
+    mvar[c] = mvar[c] * momentum + var * (1.0f - momentum);
 }
 // ws[g][c] = {sum dz, sum dz * x} (raw, from the conv epilogue) -> {sum dz, sum dz * xhat}, xhat = (x - mean) * inv: in double, the
 // cancellation mean * sum dz against sum dz * x happens once, on the totals
@@ -258,14 +273,21 @@ __global__ void k_norm_bwd_reduce(const T* __restrict__ x, const T* __restrict__
         atomicAdd(&ws[((int64_t)gi * C + c) * 2 + 1], dq);
     }
 }
-// dgamma[c] += sum_g ws[g][c][1], dbeta[c] += sum_g ws[g][c][0]
-__global__ void k_norm_bwd_params(const double* __restrict__ ws, float* __restrict__ dgamma, float* __restrict__ dbeta, int G, int C) {
+// dgamma[c] += sum_g ws[g][c][1], dbeta[c] += sum_g ws[g][c][0]; the last reader of the backward sums (launched behind the apply pass)
+// leaves them zero for the next reduction
+__global__ void k_norm_bwd_params(double* __restrict__ ws, float* __restrict__ dgamma, float* __restrict__ dbeta, int G, int C) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     double a = 0, b = 0;
-    for (int g = 0; g < G; ++g) { b += ws[((int64_t)g * C + c) * 2]; a += ws[((int64_t)g * C + c) * 2 + 1]; }
-    dgamma[c] += (float)a;
-    dbeta[c] += (float)b;
+    for (int g = 0; g < G; ++g) {
+        double* const w = ws + ((int64_t)g * C + c) * 2;
+        b += w[0];
+        a += w[1];
+        w[0] = 0.0;
+        w[1] = 0.0;
+    }
+    if (dgamma) dgamma[c] += (float)a;
+    if (dbeta) dbeta[c] += (float)b;
 }
 // dx = gamma * [ (dz - mean(dz)) * inv_s - xhat * mean(dz*xhat) * inv_sigma ]  =  a*dz + b*x + c  with per-(instance, channel)
 // coefficients a = gamma*inv, b = -gamma*inv*m2*invsig, c = -a*m1 - b*mean, kept in registers as in k_norm_apply
@@ -404,7 +426,10 @@ __global__ void k_ws_fold(double* __restrict__ ws, int nslot, int n) {
     __shared__ double red[4][64];
     double a = 0.0;
     if (i < n)
-        for (int s = 1 + part; s <= nslot; s += 4) a += ws[(int64_t)s * n + i];
+        for (int s = 1 + part; s <= nslot; s += 4) {
+            a += ws[(int64_t)s * n + i];
+            ws[(int64_t)s * n + i] = 0.0;            // the scratch is left zero (the slots overlap other layers' [G][C][2] blocks)
+        }
     red[part][threadIdx.x & 63] = a;
     __syncthreads();
     if (part == 0 && i < n) ws[i] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
@@ -427,7 +452,6 @@ static int norm_act_fwd_impl(const void* x, const float* gamma, const float* bet
     if (per_instance >= 0) {            // per_instance < 0: inference with the statistics already in `stats` (moving averages)
         const int G = per_instance ? N : 1;
         if (!have_sums) {
-        k_zero_d<<<(G * C * 2 + 255) / 256, 256, 0, s>>>(ws, G * C * 2);
         const int vchunk = norm_vchunk(V, N, per_instance, C);
         dim3 grid((unsigned)ceil_div64(V, vchunk), (C + 63) / 64, N);
         if (norm_vec_ok(C, dtype))
@@ -463,6 +487,14 @@ extern "C" int fmri_norm_act_fwd_pre(const void* x, const float* gamma, const fl
     if (per_instance < 0) return FMRI_E_SHAPE;
     return norm_act_fwd_impl(x, gamma, beta, y, stats, ws, N, V, C, per_instance, eps, eps_on_std, act, alpha, dtype, true, stream);
 }
+extern "C" int fmri_norm_moving_update(const float* stats, float* moving_mean, float* moving_var, int C, double M, float momentum, float eps,
+                                       fmri_stream_t stream) {
+    if (!stats || !moving_mean || !moving_var || C <= 0 || M <= 0) return FMRI_E_SHAPE;
+    const double den = M - (1.0 + (double)eps);
+    k_norm_moving_update<<<(C + 255) / 256, 256, 0, as_stream(stream)>>>(stats, moving_mean, moving_var, C, momentum, eps, (float)(M / (den > 1.0 ? den : 1.0)));
+    FMRI_LAUNCH_CHECK();
+    return FMRI_OK;
+}
 extern "C" int fmri_norm_scale_shift(const float* stats, const float* gamma, const float* beta, float* nss, int G, int C, fmri_stream_t stream) {
     if (!stats || !gamma || !beta || !nss || G <= 0 || C <= 0) return FMRI_E_SHAPE;
     k_norm_scale_shift<<<(G * C + 255) / 256, 256, 0, as_stream(stream)>>>(stats, gamma, beta, nss, G, C);
@@ -485,8 +517,7 @@ static int norm_act_bwd_impl(const void* x, const void* y, const void* dy, const
         act = FMRI_ACT_NONE;           // the apply pass takes dz as it is
         beta = nullptr;
         y = x;                         // (never read with act == none)
-    } else
-    k_zero_d<<<(G * C * 2 + 255) / 256, 256, 0, s>>>(ws, G * C * 2);
+    }
     if (pre) {
     } else if (norm_vec_ok(C, dtype)) {
         if (beta)
@@ -500,7 +531,6 @@ static int norm_act_bwd_impl(const void* x, const void* y, const void* dy, const
     else if (dtype == FMRI_BF16)
         k_norm_bwd_reduce<bf16_t><<<grid, 256, 0, s>>>((const bf16_t*)x, (const bf16_t*)y, (const bf16_t*)dy, stats, gamma, beta, ws, V, C, per_instance, act, alpha, vchunk);
     else return FMRI_E_DTYPE;
-    if (dgamma && dbeta) k_norm_bwd_params<<<(C + 255) / 256, 256, 0, s>>>(ws, dgamma, dbeta, G, C);
     const double M = per_instance ? (double)V : (double)V * N;
     const int vec = pick_vec(C);
     const int64_t total = (int64_t)N * V * (C / vec);
@@ -509,6 +539,7 @@ static int norm_act_bwd_impl(const void* x, const void* y, const void* dy, const
         LAUNCH_TV(k_norm_bwd_apply, float, vec, g2, 256, s, (const float*)x, (const float*)y, (const float*)dy, stats, gamma, beta, ws, (float*)dx, V, C, per_instance, act, alpha, M, total);
     else
         LAUNCH_TV(k_norm_bwd_apply, bf16_t, vec, g2, 256, s, (const bf16_t*)x, (const bf16_t*)y, (const bf16_t*)dy, stats, gamma, beta, ws, (bf16_t*)dx, V, C, per_instance, act, alpha, M, total);
+    k_norm_bwd_params<<<(C + 255) / 256, 256, 0, s>>>(ws, dgamma, dbeta, G, C);          // parameter gradients; zeroes ws behind its last reader
     FMRI_LAUNCH_CHECK();
     return FMRI_OK;
 }

@@ -53,6 +53,7 @@ SIGNATURES = {
     "fmri_conv3d_upcat_fwd_stats": [p, i32, p, i32, p, p, p, p, i32, i32, i32, i32, i32, i32, f32, p, i32, i32, p],
     "fmri_norm_act_fwd_pre": [p, p, p, p, p, p, i32, i64, i32, i32, f32, i32, i32, f32, i32, p],
     "fmri_norm_scale_shift": [p, p, p, p, i32, i32, p],
+    "fmri_norm_moving_update": [p, p, p, i32, C.c_double, f32, f32, p],
     "fmri_conv3d_dgrad_norm": [p, i32, p, p, p, p, i32, i32, i32, i32, i32, i32, f32, p, i32, i32, p],
     "fmri_norm_act_bwd_pre": [p, p, p, p, p, p, p, p, i32, i64, i32, i32, i32, p],
     "fmri_deconv3d_k2s2_fwd": [p, p, p, p, i32, i32, i32, i32, i32, i32, i32, i32, p],

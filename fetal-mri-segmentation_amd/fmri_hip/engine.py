@@ -566,11 +566,11 @@ class UNetEngine:
         """does the 3-D MFMA launch (c0 | c1) -> cout at `level` carry a normalisation tail (kind 1: statistics of its output, kind 2: the
         backward reductions - in its asynchronous epilogue: ops.conv3d_fwd_ntail_ok)?  FMRI_NORM_FUSE = bit mask of the kinds in use,
         FMRI_NORM_FUSE_MAXLEVEL = deepest level that uses them.  Defaults from the interleaved A/B inside the configs[1] step
-        (tools/ab_norm_tails.py, profiles/r03_norm_tails_ab.log): the statistics tail down to level 1 (batch norm: 21.02 -> 20.74 ms) or on
-        level 0 only (instance norm: a workgroup's sums are flushed whenever the sample changes; 21.41 -> 21.27 ms); the backward tail is
+        (tools/ab_norm_tails.py, profiles/r03_norm_tails_ab.log): the statistics tail down to level 1 (batch norm: 19.91 -> 19.55 ms) or on
+        level 0 only (instance norm: a workgroup's sums are flushed whenever the sample changes; 20.65 -> 20.47 ms); the backward tail is
         built and tested but off: it saves 170-340 us of reduction passes per full-resolution layer and costs the input-gradient launch
         100-180 us (tools/bench_ntail.py) - a launch that shares the chip with the weight-gradient stream, under which the HBM-bound
-        reduction passes were already hidden (step +0.13 ms with it)."""
+        reduction passes were already hidden (step +0.2 ... 0.5 ms with it)."""
         if self.plan.norm is None or self.planar or self.dtype != torch.bfloat16 or not (int(os.environ.get("FMRI_NORM_FUSE", "1")) & kind):
             return False
         if level > int(os.environ.get("FMRI_NORM_FUSE_MAXLEVEL", "1" if self.plan.norm == "batch" else "0")):
@@ -627,9 +627,12 @@ class UNetEngine:
             # Keras moving statistics (momentum 0.99); the variance fed to the moving average is sample-size corrected
             M = float(self.pre[name].numel() // c["cout"])
             mv = self.moving[name]
-            var = (1.0 / (st[0, :, 1] * st[0, :, 1]) - 1e-3) * (M / max(M - (1.0 + 1e-3), 1.0))
-            mv[0].mul_(0.99).add_(st[0, :, 0], alpha=0.01)
-            mv[1].mul_(0.99).add_(var, alpha=0.01)
+            if st.is_cuda:
+                ops.norm_moving_update(st, mv[0], mv[1], M)
+            else:
+                var = (1.0 / (st[0, :, 1] * st[0, :, 1]) - 1e-3) * (M / max(M - (1.0 + 1e-3), 1.0))
+                mv[0].mul_(0.99).add_(st[0, :, 0], alpha=0.01)
+                mv[1].mul_(0.99).add_(var, alpha=0.01)
         return self.act[name]
 
     def forward(self, x, bn_training=None):

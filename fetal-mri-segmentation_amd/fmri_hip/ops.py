@@ -266,6 +266,13 @@ def norm_act_fwd_pre(x, gamma, beta, y, stats, ws, per_instance, eps=1e-3, eps_o
     return y
 
 
+def norm_moving_update(stats, moving_mean, moving_var, M, momentum=0.99, eps=1e-3):
+    """Keras BatchNormalization moving mean / variance after a training forward (one launch)"""
+    _need_cuda(stats, moving_mean, moving_var)
+    check(lib().fmri_norm_moving_update(_p(stats), _p(moving_mean), _p(moving_var), moving_mean.numel(), float(M), float(momentum), float(eps), _s()),
+          "fmri_norm_moving_update")
+
+
 def norm_scale_shift(stats, gamma, beta, nss):
     """nss [G,C,2] fp32 = {scale, shift} of the apply pass (z = fma(x, scale, shift))"""
     _need_cuda(stats, gamma, beta, nss)

@@ -212,7 +212,8 @@ int fmri_upsample_nearest2x_bwd(const void* dy, int dy_ld, int dy_off, const voi
  * unet.py:103-115.  x, y: [N][V][C] (V = D*H*W voxels).  per_instance = 0: statistics over all N*V voxels per channel (Keras
  * training-mode batch norm, eps inside the sqrt); 1: per (sample, channel) (instance norm; eps_on_std = 1 reproduces
  * keras-contrib's (x-mean)/(std+eps)).  stats [G][C][3] fp32 = {mean, 1/s, 1/sigma} is written for the backward (G = N or 1);
- * ws = [G][C][2] doubles of scratch (zeroed internally).  y = act(gamma*(x-mean)/s + beta). */
+ * ws = [G][C][2] doubles of scratch: ZERO on first use (allocate it zeroed) - every fmri_norm_* call leaves it zero again (the last
+ * kernel that reads the sums clears them: one launch per layer and pass less than clearing in front).  y = act(gamma*(x-mean)/s + beta). */
 int fmri_norm_act_fwd(const void* x, const float* gamma, const float* beta, void* y, float* stats, double* ws, int N, int64_t V,
                       int C, int per_instance, float eps, int eps_on_std, int act, float alpha, int dtype, fmri_stream_t stream);
 /* dy is the gradient w.r.t. y (NOT yet multiplied by act'): dz = dy*act'(y); dgamma/dbeta (fp32, ACCUMULATED) ;
@@ -234,9 +235,10 @@ int fmri_norm_act_bwd_x(const void* x, const void* dy, const float* gamma, const
  * normalisation's backward pass - both in the asynchronous epilogue of the bf16 MFMA kernel, i.e. for launches with more (tile, channel
  * block) pairs than CUs: fmri_conv3d_fwd_ntail_ok(C0, C1, Cout, ...) != 0.  Elsewhere the caller keeps fmri_conv3d_fwd +
  * fmri_norm_act_fwd / fmri_norm_act_bwd_x (same results up to the order of summation).  ws: fmri_norm_tail_ws_doubles(G, C) doubles,
- * zeroed by these calls: the totals [G][C][2] in front (what the *_pre functions read), behind them one block per workgroup of the
- * persistent launch - every workgroup sums into its own, a small kernel folds them (1,024 waves adding to the same 128 addresses with
- * device-scope atomics cost more than the reduction pass the tail replaces). */
+ * zero on first use and left zero by every call like the scratch of fmri_norm_act_fwd: the totals [G][C][2] in front (what the *_pre
+ * functions read and clear), behind them one block per workgroup of the persistent launch - every workgroup sums into its own, a small
+ * kernel folds and clears them (1,024 waves adding to the same 128 addresses with device-scope atomics cost more than the reduction pass
+ * the tail replaces). */
 int64_t fmri_norm_tail_ws_doubles(int G, int C);
 int fmri_conv3d_fwd_ntail_ok(int C0, int C1, int Cout, int N, int D, int H, int W, int dtype);
 /* fmri_conv3d_fwd (3-D, MFMA path) + ws[g][c] = {sum y, sum y^2} over the bf16 values as stored */
@@ -249,6 +251,10 @@ int fmri_conv3d_upcat_fwd_stats(const void* src0_low, int C0, const void* src1, 
 /* fmri_norm_act_fwd without its reduction pass: ws already holds {sum x, sum x^2} (per_instance 0 | 1) */
 int fmri_norm_act_fwd_pre(const void* x, const float* gamma, const float* beta, void* y, float* stats, double* ws, int N, int64_t V, int C,
                           int per_instance, float eps, int eps_on_std, int act, float alpha, int dtype, fmri_stream_t stream);
+/* Keras BatchNormalization moving statistics after a training forward (batch statistics in stats[0][C][3], M = elements per channel):
+ * moving = momentum * moving + (1 - momentum) * {mean, var * M / (M - 1 - eps)} */
+int fmri_norm_moving_update(const float* stats, float* moving_mean, float* moving_var, int C, double M, float momentum, float eps,
+                            fmri_stream_t stream);
 /* nss[g][c] = {scale, shift} with z = fma(x, scale, shift) the normalised pre-activation - the apply pass's own operations */
 int fmri_norm_scale_shift(const float* stats, const float* gamma, const float* beta, float* nss, int G, int C, fmri_stream_t stream);
 /* fmri_conv3d_dgrad (3-D, MFMA path; needs fmri_conv3d_fwd_ntail_ok(Cout, 0, Cin, ...)) whose output feeds a normalised block's backward:

@@ -427,11 +427,11 @@ def test_conv_fwd_stats_tail(ops, case, per):
     y0, y1 = torch.empty((N, D, H, W, Cout), dtype=bf, device="cuda"), torch.empty((N, D, H, W, Cout), dtype=bf, device="cuda")
     ops.conv3d_fwd(x, None, w, b, y0, act=0)
     G = N if per else 1
-    wsb = torch.full((ops.norm_tail_ws_doubles(G, Cout),), 7.0, dtype=torch.float64, device="cuda")          # (the call zeroes it)
+    wsb = torch.zeros(ops.norm_tail_ws_doubles(G, Cout), dtype=torch.float64, device="cuda")
     ops.conv3d_fwd_stats(x, None, w, b, y1, wsb, per, act=0)
     torch.cuda.synchronize()
-    ws = wsb[:G * Cout * 2].view(G, Cout, 2)             # the totals; behind them the per-workgroup partial sums
-    assert torch.equal(y0, y1)
+    ws = wsb[:G * Cout * 2].view(G, Cout, 2)             # the totals; behind them the per-workgroup partial sums, folded and cleared
+    assert torch.equal(y0, y1) and float(wsb[G * Cout * 2:].abs().max()) == 0.0
     yd = y0.double().reshape(G, -1, Cout)
     ref = torch.stack([yd.sum(1), (yd * yd).sum(1)], dim=-1)
     scale = torch.stack([yd.abs().sum(1), (yd * yd).sum(1)], dim=-1)
@@ -497,7 +497,7 @@ def test_dgrad_norm_tail_matches_the_separate_passes(ops, case, mode, act):
     nss = torch.empty((G, Cx, 2), device="cuda")
     ops.norm_scale_shift(stats, gamma, beta, nss)
     dz = torch.empty_like(x)
-    wsb = torch.full((ops.norm_tail_ws_doubles(G, Cx),), 3.0, dtype=torch.float64, device="cuda")
+    wsb = torch.zeros(ops.norm_tail_ws_doubles(G, Cx), dtype=torch.float64, device="cuda")
     ops.conv3d_dgrad_norm(dy2, wd, x, nss, dz, wsb, per, act=act, alpha=alpha)
     torch.cuda.synchronize()
     ws1 = wsb[:G * Cx * 2].view(G, Cx, 2)
