@@ -40,7 +40,7 @@ __global__ void k_norm_reduce(const T* __restrict__ x, double* __restrict__ ws, 
 // Same reductions with 16-byte loads (bf16 x 8 channels per lane): C/8 lanes cover one voxel's channels, 256/(C/8) voxels per pass.
 // Used when C/8 is a power of two <= 256 (the scalar kernels above move 2 bytes per lane and reach ~1/4 of the HBM rate).
 template <typename T, int VEC>
-__global__ void k_norm_reduce_v(const T* __restrict__ x, double* __restrict__ ws, int64_t V, int C, int per_instance, int vchunk) {
+__global__ void __launch_bounds__(256) k_norm_reduce_v(const T* __restrict__ x, double* __restrict__ ws, int64_t V, int C, int per_instance, int vchunk) {
     const int CG = C / VEC, VL = 256 / CG;
     const int cg = threadIdx.x % CG, vl = threadIdx.x / CG;
     const int g = blockIdx.z;
@@ -72,22 +72,23 @@ __global__ void k_norm_reduce_v(const T* __restrict__ x, double* __restrict__ ws
 // gamma): the same operands in the same operations, so the same z bit for bit) instead of reading the stored y - one tensor read less in each
 // of the two backward passes (round 3; the normalisation passes are HBM-bound)
 template <typename T, int VEC, bool FROMX>
-__global__ void k_norm_bwd_reduce_v(const T* __restrict__ x, const T* __restrict__ y, const T* __restrict__ dy, const float* __restrict__ stats,
+__global__ void __launch_bounds__(256) k_norm_bwd_reduce_v(const T* __restrict__ x, const T* __restrict__ y, const T* __restrict__ dy, const float* __restrict__ stats,
                                     const float* __restrict__ gamma, const float* __restrict__ beta,
                                     double* __restrict__ ws, int64_t V, int C, int per_instance, int act, float alpha, int vchunk) {
     const int CG = C / VEC, VL = 256 / CG;
     const int cg = threadIdx.x % CG, vl = threadIdx.x / CG;
     const int g = blockIdx.z, gi = per_instance ? g : 0;
     const int64_t v0 = (int64_t)blockIdx.x * vchunk, v1 = min(V, v0 + vchunk);
-    float s[VEC], q[VEC], mean[VEC], inv[VEC], sc[VEC], sh[VEC];
+    // per lane: sum dz and the RAW second sum, sum dz * x (round 3: the centred form kept mean and 1/s of the lane's 8 channels in registers
+    // as well - 128 registers with spills inside the loop, 2.2-3.5 TB/s); the workgroup centres its totals in double before they leave
+    float s[VEC], q[VEC], sc[VEC], sh[VEC];
 #pragma unroll
     for (int k = 0; k < VEC; ++k) {
         s[k] = q[k] = 0.f;
-        mean[k] = stats[((int64_t)gi * C + cg * VEC + k) * 3];
-        inv[k] = stats[((int64_t)gi * C + cg * VEC + k) * 3 + 1];
         if constexpr (FROMX) {
-            sc[k] = inv[k] * gamma[cg * VEC + k];
-            sh[k] = fmaf(-mean[k], sc[k], beta[cg * VEC + k]);
+            const float* const st = stats + ((int64_t)gi * C + cg * VEC + k) * 3;
+            sc[k] = st[1] * gamma[cg * VEC + k];
+            sh[k] = fmaf(-st[0], sc[k], beta[cg * VEC + k]);
         }
     }
     const int64_t base = (int64_t)g * V * C + cg * VEC;
@@ -104,7 +105,7 @@ __global__ void k_norm_bwd_reduce_v(const T* __restrict__ x, const T* __restrict
             if (act == FMRI_ACT_RELU) d = yv[k] > 0.f ? d : 0.f;
             else if (act == FMRI_ACT_LEAKY) d = yv[k] > 0.f ? d : alpha * d;
             s[k] += d;
-            q[k] = fmaf(d, (xv[k] - mean[k]) * inv[k], q[k]);
+            q[k] = fmaf(d, xv[k], q[k]);
         }
     }
     __shared__ float red[2][256][VEC + 1];
@@ -114,8 +115,9 @@ __global__ void k_norm_bwd_reduce_v(const T* __restrict__ x, const T* __restrict
     for (int c = threadIdx.x; c < C; c += 256) {
         double ds = 0, dq = 0;
         for (int l = 0; l < VL; ++l) { ds += red[0][l * CG + c / VEC][c % VEC]; dq += red[1][l * CG + c / VEC][c % VEC]; }
+        const float* const st = stats + ((int64_t)gi * C + c) * 3;
         atomicAdd(&ws[((int64_t)gi * C + c) * 2 + 0], ds);
-        atomicAdd(&ws[((int64_t)gi * C + c) * 2 + 1], dq);
+        atomicAdd(&ws[((int64_t)gi * C + c) * 2 + 1], (dq - (double)st[0] * ds) * (double)st[1]);      // sum dz * xhat, xhat = (x - mean) * inv
     }
 }
 // voxels per reduction workgroup.  Every workgroup ends with one fp64 atomic per channel into its group's accumulators, so the number of
@@ -199,7 +201,7 @@ __global__ void k_norm_bwd_center(double* __restrict__ ws, const float* __restri
 // multiple of C/VEC (always, for power-of-two channel counts), so the per-channel scale / shift live in registers and are only rebuilt
 // when the loop crosses into another instance (the four scalar loads per element they replace made the kernel instruction-bound).
 template <typename T, int VEC>
-__global__ void k_norm_apply(const T* __restrict__ x, const float* __restrict__ stats, const float* __restrict__ gamma,
+__global__ void __launch_bounds__(256) k_norm_apply(const T* __restrict__ x, const float* __restrict__ stats, const float* __restrict__ gamma,
                              const float* __restrict__ beta, T* __restrict__ y, int64_t V, int C, int per_instance, int act, float alpha,
                              int64_t total) {
     const int CG = C / VEC;
@@ -334,6 +336,61 @@ __global__ void k_norm_bwd_apply(const T* __restrict__ x, const T* __restrict__ 
             o[k] = fmaf(ca[k], d, fmaf(cb[k], xv[k], cc[k]));
         }
         stv<T, VEC>(dx + v * C + cg * VEC, o);
+    }
+}
+
+// The same apply pass, sample-local (round 3): workgroup = a voxel range of ONE sample, so the per-(instance, channel) coefficients are
+// built once per workgroup - by its threads together, one channel each, through LDS - instead of by every thread for its 8 channels
+// whenever its grid-stride walk crossed into another sample (instance norm, 4 x 32x64x64 x 128: every second item; 16 fp64 divisions and
+// 48 loads each time - the pass ran at 1.5 TB/s there, 3.4 at level 0).  SRC: 0 the block's output y gives the activation's derivative,
+// 1 it is recomputed from x (z = fma(x, a, zh): the scale of z IS the coefficient a), 2 dy is already dz.
+template <typename T, int VEC, int SRC>
+__global__ void __launch_bounds__(256) k_norm_bwd_apply_s(const T* __restrict__ x, const T* __restrict__ y, const T* __restrict__ dy,
+                                                          const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, const double* __restrict__ ws, T* __restrict__ dx,
+                                                          int64_t V, int C, int per_instance, int act, float alpha, double M, int vchunk) {
+    const int CG = C / VEC, VL = 256 / CG;
+    const int cg = threadIdx.x % CG, vl = threadIdx.x / CG;
+    const int g = blockIdx.z, gi = per_instance ? g : 0;
+    const int64_t v0 = (int64_t)blockIdx.x * vchunk, v1 = min(V, v0 + vchunk);
+    __shared__ float coef[4][512];
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const int64_t sc = (int64_t)gi * C + c;
+        const float mean = stats[sc * 3], inv = stats[sc * 3 + 1], invsig = stats[sc * 3 + 2];
+        const float m1 = (float)(ws[sc * 2] / M), m2 = (float)(ws[sc * 2 + 1] / M);
+        const float a = gamma[c] * inv, b = -gamma[c] * inv * m2 * invsig;
+        coef[0][c] = a;
+        coef[1][c] = b;
+        coef[2][c] = -a * m1 - b * mean;
+        coef[3][c] = SRC == 1 ? fmaf(-mean, inv * gamma[c], beta[c]) : 0.f;
+    }
+    __syncthreads();
+    float ca[VEC], cb[VEC], cc[VEC], zh[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+        ca[k] = coef[0][cg * VEC + k];
+        cb[k] = coef[1][cg * VEC + k];
+        cc[k] = coef[2][cg * VEC + k];
+        zh[k] = coef[3][cg * VEC + k];
+    }
+    const int64_t base = (int64_t)g * V * C + cg * VEC;
+#pragma unroll 4
+    for (int64_t v = v0 + vl; v < v1; v += VL) {
+        float xv[VEC], yv[VEC], dv[VEC], o[VEC];
+        ldv<T, VEC>(x + base + v * C, xv);
+        if constexpr (SRC == 0) ldv<T, VEC>(y + base + v * C, yv);
+        ldv<T, VEC>(dy + base + v * C, dv);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            float d = dv[k];
+            if constexpr (SRC == 1) yv[k] = fmaf(xv[k], ca[k], zh[k]);       // (inv * gamma and gamma * inv are the same product)
+            if constexpr (SRC != 2) {
+                if (act == FMRI_ACT_RELU) d = yv[k] > 0.f ? d : 0.f;
+                else if (act == FMRI_ACT_LEAKY) d = yv[k] > 0.f ? d : alpha * d;
+            }
+            o[k] = fmaf(ca[k], d, fmaf(cb[k], xv[k], cc[k]));
+        }
+        stv<T, VEC>(dx + base + v * C, o);
     }
 }
 
@@ -535,7 +592,15 @@ static int norm_act_bwd_impl(const void* x, const void* y, const void* dy, const
     const int vec = pick_vec(C);
     const int64_t total = (int64_t)N * V * (C / vec);
     const int g2 = grid_for(total);
-    if (dtype == FMRI_F32)
+    if (norm_vec_ok(C, dtype)) {
+        const dim3 ga((unsigned)ceil_div64(V, vchunk), 1, N);
+#define FMRI_APPLY_S(SRC_) k_norm_bwd_apply_s<bf16_t, 8, SRC_><<<ga, 256, 0, s>>>((const bf16_t*)x, (const bf16_t*)y, (const bf16_t*)dy, stats, gamma, \
+                                                                                beta, ws, (bf16_t*)dx, V, C, per_instance, act, alpha, M, vchunk)
+        if (pre || act == FMRI_ACT_NONE) FMRI_APPLY_S(2);
+        else if (beta) FMRI_APPLY_S(1);
+        else FMRI_APPLY_S(0);
+#undef FMRI_APPLY_S
+    } else if (dtype == FMRI_F32)
         LAUNCH_TV(k_norm_bwd_apply, float, vec, g2, 256, s, (const float*)x, (const float*)y, (const float*)dy, stats, gamma, beta, ws, (float*)dx, V, C, per_instance, act, alpha, M, total);
     else
         LAUNCH_TV(k_norm_bwd_apply, bf16_t, vec, g2, 256, s, (const bf16_t*)x, (const bf16_t*)y, (const bf16_t*)dy, stats, gamma, beta, ws, (bf16_t*)dx, V, C, per_instance, act, alpha, M, total);
