@@ -55,7 +55,7 @@ __global__ void k_maxpool_fwd(const T* __restrict__ x, T* __restrict__ y, int N,
 // backward: one thread per (pooled voxel, channel group): recompute the window max, route dy to the FIRST max in
 // (d,h,w) scan order, add the skip gradient, apply the producer's ReLU mask, write all 8 children.
 template <typename T, int VEC>
-__global__ void k_maxpool_bwd(const T* __restrict__ x, const T* __restrict__ dy, const T* __restrict__ add, int add_ld,
+__global__ void __launch_bounds__(256) k_maxpool_bwd(const T* __restrict__ x, const T* __restrict__ dy, const T* __restrict__ add, int add_ld,
                               int add_off, T* __restrict__ dx, int N, int D, int H, int W, int C, int relu_mask, int pd) {
     const int Do = D >> pd, Ho = H >> 1, Wo = W >> 1, CG = C / VEC;
     const int64_t total = (int64_t)N * Do * Ho * Wo * CG;
