@@ -159,14 +159,14 @@ MFMA_PROFILE = os.path.join("profiles", "r03_pmc_mfma.json")
 
 
 def kernel_source_hash():
-    """sha256 over the kernel sources the library is built from (csrc/*.hip, common.h, the public header).  A profile under profiles/
+    """sha256 over the kernel sources the library is built from (csrc/*.hip, common.h, the Makefile with its per-file flags, the public header).  A profile under profiles/
     carries the hash of the tree it was collected on; the GPU box has no .git, so THIS is what bench.py can check at run time (the
     profile also records `git rev-parse HEAD` for the reader)."""
     import glob
     import hashlib
     h = hashlib.sha256()
     csrc = os.path.join(ROOT, "fetal-mri-segmentation_amd", "csrc")
-    for f in sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h")) + [os.path.join(ROOT, "include", "fmri_hip.h")]):
+    for f in sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h")) + [os.path.join(csrc, "Makefile"), os.path.join(ROOT, "include", "fmri_hip.h")]):
         h.update(os.path.basename(f).encode())
         with open(f, "rb") as fh:
             h.update(fh.read())

@@ -297,7 +297,12 @@ def test_hdf5_checkpoint_resumes_training_exactly(tmp_path, monkeypatch, variant
     for k in Wa:
         if normed and k.endswith("/bias") and not k.startswith("conv3d_transpose"):
             continue        # a bias in front of a normalisation has a zero gradient: Adam turns its rounding noise into +-lr steps
-        np.testing.assert_allclose(Wb[k], Wa[k], atol=1e-4, err_msg=k)
+        # Lossless state = the two trajectories coincide.  The runs themselves are not bit-reproducible (fp32 atomics in the weight-gradient
+        # flush and the normalisation sums), and Adam turns the rounding noise of a near-zero gradient element into a step of up to lr in
+        # either direction: a handful of such elements may differ (2 of 3,456 by 1.2e-4 in one recorded run), a lost optimizer state or
+        # step counter would move EVERY element by ~lr = 1e-2.
+        d = np.abs(np.asarray(Wb[k], np.float64) - np.asarray(Wa[k], np.float64))
+        assert float(np.mean(d > 1e-4)) <= 5e-3 and float(d.max()) <= 4e-2 and float(np.median(d)) <= 1e-5, (k, float(d.max()), float(np.mean(d > 1e-4)))
 
 
 def test_two_stage_pipeline_on_device_models(monkeypatch):
