@@ -97,7 +97,7 @@ class UNetEngine:
         self.planar = plan.ndim == 2      # 2-D: tensors are [1][slices][H][W][C], every op is planar (no coupling along D)
         self.dist = dist_ctx
         self.t = 0                       # Adam step counter
-        self._pack_stream, self._pack_event, self._pack_event_dec, self._pack_pending = None, None, None, 0
+        self._pack_stream, self._pack_events, self._pack_event_dec, self._pack_pending = None, None, None, []
         self._wg_stream = (torch.cuda.Stream(device=self.dev) if (training and self.dev.type == "cuda" and os.environ.get("FMRI_WGRAD_STREAM", "1") != "0")
                            else None)
         self.loss_kind, self.loss_param = 0, 1.0      # ops.LOSS_KINDS: 0 = dice_coefficient_loss
@@ -391,36 +391,41 @@ class UNetEngine:
     def refresh_weight_copies(self, overlap=False):
         """compute-dtype images of the fp32 parameters (forward filters, tap-flipped transposed filters for the input gradients, parity
         filters).  overlap=True (the optimizer step): only the first encoder level is repacked on the current stream; the other layers -
-        whose weights are the large ones and are first read a whole level later - are repacked on a side stream that `forward` joins
-        after level 0, i.e. under the first convolutions of the NEXT step instead of in front of them."""
+        whose weights are the large ones and are first read a whole level later - are repacked on a side stream, in order of first use,
+        with one event per encoder level and one for the decoder: `forward` waits for a level's event in front of that level, i.e. the
+        repack runs under the first convolutions of the NEXT step instead of in front of them.  (One event for the whole encoder made the
+        level-1 convs wait for the 256 -> 512 image, whose kernel - like every kernel next to a persistent conv launch, which fills all
+        CUs - only gets CUs between two conv launches: 74 us of stall behind the first level in the rocprofv3 timeline; un-profiled the
+        step does not notice: 13.09-13.15 ms either way.)"""
         early = set(c["name"] for c in self.plan.enc[0])
         if overlap and self.dev.type == "cuda" and os.environ.get("FMRI_PACK_OVERLAP", "1") != "0":
             if self._pack_stream is None:
                 self._pack_stream = torch.cuda.Stream(device=self.dev)
-                self._pack_event, self._pack_event_dec = torch.cuda.Event(), torch.cuda.Event()
+                self._pack_events = {ld: torch.cuda.Event() for ld in range(1, len(self.plan.enc))}
+                self._pack_event_dec = torch.cuda.Event()
             self._repack(lambda name: name in early)
             main = torch.cuda.current_stream(self.dev)
             self._pack_stream.wait_stream(main)
             enc = set(c["name"] for lv in self.plan.enc for c in lv) - early
             with torch.cuda.stream(self._pack_stream):
                 # in order of first use: the encoder's images (joined after level 0), then the decoder's (joined in front of the decoder)
-                self._repack(lambda name: name in enc)
-                self._pack_event.record(self._pack_stream)
+                for ld in range(1, len(self.plan.enc)):
+                    lvl = set(c["name"] for c in self.plan.enc[ld])
+                    self._repack(lambda name: name in lvl)
+                    self._pack_events[ld].record(self._pack_stream)
                 self._repack(lambda name: name not in early and name not in enc)
                 self._pack_event_dec.record(self._pack_stream)
-            self._pack_pending = 2
+            self._pack_pending = list(range(1, len(self.plan.enc))) + ["dec"]
             return
         self._join_packs()
         self._repack(lambda name: True)
 
-    def _join_packs(self, decoder=True):
-        """make the current stream wait for the side-stream repack: the encoder's images, or (decoder=True) all of them"""
-        if self._pack_pending == 2:
-            torch.cuda.current_stream(self.dev).wait_event(self._pack_event)
-            self._pack_pending = 1
-        if decoder and self._pack_pending == 1:
-            torch.cuda.current_stream(self.dev).wait_event(self._pack_event_dec)
-            self._pack_pending = 0
+    def _join_packs(self, level=None):
+        """make the current stream wait for the side-stream repack: the images of encoder level `level` (and of the levels before it), or
+        (level=None) all of them"""
+        while self._pack_pending and (level is None or (self._pack_pending[0] != "dec" and self._pack_pending[0] <= level)):
+            k = self._pack_pending.pop(0)
+            torch.cuda.current_stream(self.dev).wait_event(self._pack_event_dec if k == "dec" else self._pack_events[k])
 
     def _repack(self, want):
         for name in self.Wf:
@@ -643,12 +648,12 @@ class UNetEngine:
         self.x_in = x
         h = x
         for ld, lv in enumerate(p.enc):
+            if ld > 0:                                      # this level's weight images were repacked on the side stream (FMRI_PACK_LEVELS=0: A/B,
+                self._join_packs(level=ld if os.environ.get("FMRI_PACK_LEVELS", "1") != "0" else len(p.enc))     # wait for the whole encoder's)
             h = self._block_fwd(lv[0], h, None, False, bn_training)
             # MaxPooling3D behind the level's second block comes out of that conv's epilogue when the kernel can do it
             fuse_pool = ld < p.depth - 1 and (self._tail_ok(lv[1]) & 1)
             h = self._block_fwd(lv[1], h, None, False, bn_training, pool=A["pool_%d" % ld] if fuse_pool else None)
-            if ld == 0:
-                self._join_packs(decoder=False)             # the deeper layers' weight images were repacked on the side stream
             if ld < p.depth - 1:
                 h = A["pool_%d" % ld] if fuse_pool else ops.maxpool_fwd(h, A["pool_%d" % ld], planar=self.planar)
         self._join_packs()
@@ -738,6 +743,7 @@ class UNetEngine:
             return
         # the weight gradients are off the critical path of the backward pass (nothing reads them before the optimizer step): they run on
         # their own stream, behind the event "dL/d(conv output) is final", next to the input-gradient chain of the main stream
+        # (a third stream for the first conv's weight gradient - HBM-bound, ready last - measured nothing: 13.09-13.13 ms either way)
         self._wg_stream.wait_stream(torch.cuda.current_stream(self.dev))
         with torch.cuda.stream(self._wg_stream):
             wgrad()
