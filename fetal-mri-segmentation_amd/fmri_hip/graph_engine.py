@@ -21,6 +21,7 @@ Backward walks the op list in reverse; a tensor with several consumers receives 
 `first writes, later ones accumulate`.  Parameters/gradients/Adam state are flat fp32 buffers like in UNetEngine.
 """
 import math
+import os
 from collections import OrderedDict
 
 import numpy as np
@@ -231,6 +232,7 @@ class LayerGraphEngine(object):
         if self.training:
             self.G, self.M, self.V = torch.zeros_like(self.P), torch.zeros_like(self.P), torch.zeros_like(self.P)
         self.Wf, self.Wd, self.Wup, self._dy64_buf = {}, {}, {}, {}
+        self.Ws2, self._s2 = {}, None
         if self.pad:
             self._build_padded_params()
         else:
@@ -337,6 +339,27 @@ class LayerGraphEngine(object):
                 self.dDense[name] = (view(self.Gp, offs_g, (name, "w")), view(self.Gp, offs_g, (name, "b")))
         self.map_p = torch.from_numpy(map_p).to(dev)
         self.map_g = torch.from_numpy(map_g).to(dev)
+        # Conv3D(3x3x3, strides 2) (reference isensee2017.py:51): on the parity kernels (fmri_hip/strided_parity.py) where the shapes allow -
+        # forward + input gradient (bit 0), weight gradient (bit 1: 64-wide blocks of the input's channels); FMRI_S2_PARITY=0: A/B
+        self.Ws2, self._s2 = {}, None
+        if self.pad and not self.planar and self.dtype == torch.bfloat16 and os.environ.get("FMRI_S2_PARITY", "1") != "0":
+            for name, op in self.convs.items():
+                if op.get("sub") != (2, 2, 2) or op["k"] != 3 or op["act"] != ACT_NONE or len(op["ins"]) != 1:
+                    continue
+                coutp, cinp = self.shape[name][0], self.Wp32[name].shape[2]
+                fine = tuple(self.shape[op["ins"][0]][1:])
+                if any(d % 2 for d in fine) or self._is_input(op["ins"]):
+                    continue
+                ok = ops.conv3d_upcat_ok(coutp, 0, cinp, fine[0], fine[1], fine[2], self.dtype)
+                if ok & 1:
+                    if self._s2 is None:
+                        from .strided_parity import StridedParity
+                        self._s2 = StridedParity(dev)
+                    self.Ws2[name] = dict(fwd=torch.zeros((8, 8, coutp, cinp), dtype=self.dtype, device=dev),
+                                          dgrad=torch.zeros((8, 8, cinp, coutp), dtype=self.dtype, device=dev) if self.training else None,
+                                          wgrad=bool(ok & 2) and self.training, bias=torch.zeros(coutp, dtype=self.dtype, device=dev))
+                    if self.Ws2[name]["wgrad"]:
+                        self.Ws2[name].update(dw27=torch.zeros((27, cinp, coutp), dtype=f32, device=dev), db=torch.zeros(cinp, dtype=f32, device=dev))
         # UpSampling3D -> Conv3D (reference isensee2017.py:101-104): parity form, 8 pre-summed 2x2x2 filters on the low-res tensor
         self.Wup, self.dwc_scratch = {}, None
         for name, op in self.convs.items():
@@ -348,9 +371,9 @@ class LayerGraphEngine(object):
                     if self.training:
                         W["up_d"] = torch.empty((8, 8, cinp, coutp), dtype=self.dtype, device=dev)
                     self.Wup[name] = W
-        if self.training and any(W["wgrad"] for W in self.Wup.values()):
-            need = max(64 * self.shape[n][0] * self.Wp32[n].shape[2] for n, W in self.Wup.items() if W["wgrad"])
-            self.dwc_scratch = torch.empty(need, dtype=f32, device=dev)
+        need = [64 * self.shape[n][0] * self.Wp32[n].shape[2] for n, W in list(self.Wup.items()) + list(self.Ws2.items()) if W["wgrad"]]
+        if self.training and need:
+            self.dwc_scratch = torch.empty(max(need), dtype=f32, device=dev)
         for name in self.norms:
             self.gp[name], self.betap[name] = view(self.Pp, offs_p, (name, "gamma")), view(self.Pp, offs_p, (name, "beta"))
             if self.training:
@@ -454,6 +477,14 @@ class LayerGraphEngine(object):
                     W = self.Wup[name]
                     ops.conv3d_pack_up_weights(self.Wp32[name], self.Wp32[name].shape[2], 0, W["up_f"], W["up_d"], None, None)
                     continue                                  # forward and input gradient use the parity filters only
+                if name in self.Ws2:
+                    W = self.Ws2[name]
+                    self._s2.pack(self.Wp32[name], W["fwd"], W["dgrad"])
+                    W["bias"].copy_(self.bp[name])
+                    if W["wgrad"]:
+                        continue                              # no stride-1 image is read any more
+                    ops.pack_weights(self.Wp32[name], self.Wf[name], None)      # (the stride-1 weight-gradient path reads neither image; kept for load/save symmetry)
+                    continue
                 ops.pack_weights(self.Wp32[name], self.Wf[name], self.Wd.get(name))
             return
         for name, op in self.convs.items():
@@ -485,10 +516,14 @@ class LayerGraphEngine(object):
             full, gfull = {}, {}
             for o in self.ops:                            # strided convs run as `sub`: the stride-1 result at the input resolution (+ gradient)
                 if o["kind"] == "conv" and o["sub"] is not None:
+                    s2 = self.Ws2.get(o["name"])
+                    if s2 is not None and (s2["wgrad"] or not self.training):
+                        continue                          # stride 2 on the parity kernels: no stride-1 temporaries
                     sp_in = tuple(self.shape[o["ins"][0]][1:])
-                    full[o["name"]] = torch.empty(self._lead(N) + sp_in + (o["shape"][0],), dtype=self.dtype, device=self.dev)
+                    if s2 is None:
+                        full[o["name"]] = torch.empty(self._lead(N) + sp_in + (o["shape"][0],), dtype=self.dtype, device=self.dev)
                     if self.training:
-                        gfull[o["name"]] = torch.zeros_like(full[o["name"]])
+                        gfull[o["name"]] = torch.zeros(self._lead(N) + sp_in + (o["shape"][0],), dtype=self.dtype, device=self.dev)
             cmax = max([self.shape[n][0] for n in self.norms] + [1])
             nvox = N * int(np.prod(self.plan.spatial)) if self.head == "seg" else N
             Lb = self.plan.n_labels
@@ -534,6 +569,12 @@ class LayerGraphEngine(object):
             out = self.T[o["out"]]
             if kind == "conv":
                 name = o["name"]
+                if name in self.Ws2:
+                    # stride 2 on the parity kernels: the gather launch over the input + the bias (one more bf16 rounding than a bias inside
+                    # the accumulators; the instance norm behind the conv removes a per-channel constant anyway)
+                    ops.conv3d_upcat_dgrad(self._t(o["ins"][0]), self.Ws2[name]["fwd"], None, None, None, out, None)
+                    out.add_(self.Ws2[name]["bias"])
+                    continue
                 dst = out if o["sub"] is None else self.full[name]
                 if self.pad:
                     s0 = self._t(o["ins"][0])
@@ -700,7 +741,10 @@ class LayerGraphEngine(object):
                     ops.act_bwd(self.T[out], g, g, o["act"], LEAKY_ALPHA)
                 dw, db = self.w_view(name, self.G), self._v(name, "b", self.G)
                 ins = o["ins"]
-                if o["sub"] is not None:                     # gradient of "sample every second voxel": scatter into the stride-1 grid
+                s2 = self.Ws2.get(name)
+                g_out = g                                    # gradient at the conv's own (strided) output
+                if o["sub"] is not None and (s2 is None or not s2["wgrad"]):
+                    # gradient of "sample every second voxel": scatter into the stride-1 grid
                     gf = self.gfull[name]
                     self._sub(gf, o["sub"]).copy_(g)             # the other voxels stay zero (zeroed at allocation, never written)
                     g = gf
@@ -708,7 +752,14 @@ class LayerGraphEngine(object):
                     s0 = self._t(ins[0])
                     s1 = self._t(ins[1]) if len(ins) > 1 else None
 
-                    def wgrad(o=o, name=name, g=g, s0=s0, s1=s1, dw=dw, db=db):
+                    def wgrad(o=o, name=name, g=g, s0=s0, s1=s1, dw=dw, db=db, s2=s2, g_out=g_out):
+                        if s2 is not None and s2["wgrad"]:
+                            # stride 2 on the parity kernels: the 64 slot gradients of (low-res source = dy, full-resolution tensor = x), 27 read back
+                            coutp, cinp = g_out.shape[-1], s0.shape[-1]
+                            ops.conv3d_upcat_wgrad(g_out, None, s0, s2["dw27"], s2["db"], self.dwc_scratch)
+                            self.dWp[name][:, :coutp, :].add_(self._s2.unpack_wgrad(self.dwc_scratch, coutp, cinp))
+                            self.dbp[name][:coutp].add_(g_out.reshape(-1, coutp).sum(0, dtype=torch.float32))
+                            return
                         if self.pad:
                             dwp, dbp = self.dWp[name], self.dbp[name]          # views of Gp (zeroed once per backward, gathered at the end)
                             gw = g
@@ -733,6 +784,8 @@ class LayerGraphEngine(object):
                             wgrad()
                     if name in self.Wup and self.training:
                         self._accum(ins[0], lambda dst: ops.conv3d_upcat_dgrad(g, self.Wup[name]["up_d"], None, None, None, dst, None))
+                    elif s2 is not None:
+                        self._accum(ins[0], lambda dst: ops.conv3d_upcat_fwd(g_out, None, s2["dgrad"], None, None, dst, act=ACT_NONE))
                     elif name in self.Wd:
                         if len(ins) == 1 and not o["up0"]:
                             self._accum(ins[0], lambda dst: ops.conv3d_dgrad(g, self.Wd[name], dst, planar=self.planar))

@@ -409,6 +409,47 @@ def test_norm_act_fwd_bwd(ops, dtype, mode, act, C):
     assert_close(db, br.grad, *tolb, what="norm dbeta")
 
 
+@pytest.mark.parametrize("shape", [(1, 16, 32, 64, 32, 64), (2, 8, 16, 32, 64, 32)], ids=lambda c: "N%d_%dx%dx%d_%d_%d" % c)
+def test_stride2_conv_on_the_parity_kernels_is_exact_on_dyadic_data(ops, shape):
+    """fmri_hip.strided_parity: Conv3D(3x3x3, strides 2, 'same') = the up-backward gather launch over the input with the filter's 27 taps in
+    27 of its 64 (parity, block offset) slots; its input gradient = the up-forward scatter launch; its weight gradient = 27 of the 64 slot
+    gradients.  Small dyadic values: every sum is exact in fp32, so all three must equal torch's strided convolution bit for bit (TF 'same'
+    on even dims pads one plane BEHIND the volume: out[o] = sum_t W[t] x[2o + t])."""
+    from fmri_hip.strided_parity import StridedParity
+    N, D, H, W, Cin, Cout = shape
+    bf = torch.bfloat16
+    ok = ops.conv3d_upcat_ok(Cout, 0, Cin, D, H, W, bf)          # bit 1 (weight gradient): needs 64-wide blocks of the input's channels
+    assert ok & 1
+    g = torch.Generator().manual_seed(sum(shape))
+    dy4 = lambda sh, lo, hi, div: torch.randint(lo, hi, sh, generator=g).float() / div
+    x = dy4((N, D, H, W, Cin), -4, 5, 4.0)
+    w = dy4((27, Cout, Cin), -2, 3, 8.0)
+    sp = StridedParity("cuda")
+    fwd_img = torch.zeros((8, 8, Cout, Cin), device="cuda", dtype=bf)
+    dg_img = torch.zeros((8, 8, Cin, Cout), device="cuda", dtype=bf)
+    sp.pack(w.cuda(), fwd_img, dg_img)
+    y = torch.empty((N, D // 2, H // 2, W // 2, Cout), device="cuda", dtype=bf)
+    ops.conv3d_upcat_dgrad(x.to(bf).cuda(), fwd_img, None, None, None, y, None)
+    xr = to_ncdhw(x).requires_grad_(True)
+    wk = keras_kernel_from_packed(w).float().requires_grad_(True)
+    ref = F.conv3d(F.pad(xr, (0, 1, 0, 1, 0, 1)), wk, None, stride=2)
+    assert torch.equal(y.cpu().view(torch.int16), to_ndhwc(ref.detach()).to(bf).view(torch.int16)), "forward"
+    dy = dy4((N, D // 2, H // 2, W // 2, Cout), -2, 3, 2.0)
+    ref.backward(to_ncdhw(dy))
+    dx = torch.empty((N, D, H, W, Cin), device="cuda", dtype=bf)
+    ops.conv3d_upcat_fwd(dy.to(bf).cuda(), None, dg_img, None, None, dx, act=0)
+    assert torch.equal(dx.cpu().view(torch.int16), to_ndhwc(xr.grad).to(bf).view(torch.int16)), "input gradient"
+    if not ok & 2:
+        return
+    dw27 = torch.zeros((27, Cin, Cout), device="cuda")
+    db = torch.zeros(Cin, device="cuda")
+    dwc = torch.zeros(64 * Cin * Cout, device="cuda")
+    ops.conv3d_upcat_wgrad(dy.to(bf).cuda(), None, x.to(bf).cuda(), dw27, db, dwc)
+    dw = sp.unpack_wgrad(dwc, Cout, Cin)
+    ref_dw = wk.grad.permute(2, 3, 4, 0, 1).reshape(27, Cout, Cin)
+    assert torch.equal(dw.cpu(), ref_dw), "weight gradient: max diff %g" % float((dw.cpu() - ref_dw).abs().max())
+
+
 # (N, D, H, W, Cin, Cout): more (tile, channel block) pairs than CUs - 64-wide blocks (Cout 128 -> 2 per tile), 32-wide (Cout 32)
 NTAIL_CASES = [(2, 16, 64, 64, 32, 128), (3, 16, 64, 64, 64, 32)]
 
