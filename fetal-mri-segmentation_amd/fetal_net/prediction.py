@@ -269,19 +269,31 @@ class _TTAVariant:
         v.swap = bool(np.random.choice([True, False]))
         return v
 
+    @staticmethod
+    def _rotate(vol, angle, order, reshape):
+        """scipy.ndimage.rotate(vol, angle, order=order, reshape=reshape) - on the device through fetal_net.spline_rotate (scipy's own
+        arithmetic in float64 on torch tensors, equal to 1e-12; a 160x256x256 volume takes scipy 1-2 s per rotation, 64 rotations per
+        predict_augment call) when a GPU is there, FMRI_TTA_TORCH_ROTATE=1 forces the torch form on the host, =0 scipy"""
+        mode = os.environ.get("FMRI_TTA_TORCH_ROTATE", "auto")
+        import torch
+        if mode == "0" or (mode == "auto" and not torch.cuda.is_available()) or vol.ndim != 3:
+            from scipy import ndimage
+            return ndimage.rotate(vol, angle, order=order, reshape=reshape)
+        from .spline_rotate import rotate
+        dev = "cuda" if torch.cuda.is_available() else "cpu"
+        return rotate(torch.from_numpy(np.ascontiguousarray(vol, dtype=np.float64)).to(dev), angle, order=order, reshape=reshape).cpu().numpy()
+
     def forward(self, vol):
         """volume -> variant: window, mirror, swap, rotate (quadratic spline, shape kept)"""
-        from scipy import ndimage
         out = flip_it(contrast_augment(vol, self.lo, self.hi), self.mirror)
         if self.swap:
             out = np.swapaxes(out, 0, 1)
-        return ndimage.rotate(out, self.angle, order=2, reshape=False)
+        return self._rotate(out, self.angle, 2, False)
 
     def inverse(self, pred):
         """prediction of the variant -> frame of the original volume.  The back-rotation keeps scipy's defaults (cubic spline,
         reshape=True), as the reference's does - the result can be larger than the input when angle != 0."""
-        from scipy import ndimage
-        out = ndimage.rotate(pred, -self.angle)
+        out = self._rotate(pred, -self.angle, 3, True)
         if self.swap:
             out = np.swapaxes(out, 0, 1)
         return flip_it(out, self.mirror)
@@ -289,7 +301,7 @@ class _TTAVariant:
 
 def predict_augment(data, model, overlap_factor, patch_shape, num_augments=32):
     """Random intensity / mirror / swap / rotation variants of the volume (reference prediction.py:25-62), each predicted patch-wise on
-    the device tile loop and mapped back; the volume-sized spline rotations stay on the host (scipy), as in the reference.  Like the
+    the device tile loop and mapped back; the volume-sized spline rotations run on the device too (fetal_net.spline_rotate).  Like the
     reference, stacking succeeds only when all back-rotated predictions end up with one shape (num_augments = 1, or equal angles)."""
     vmin, vmax = data.min(), data.max()
     vol = data.squeeze()
