@@ -2607,7 +2607,11 @@ int conv3d_wgrad_mfma_ld(const void* src0, int C0, int up0, int planar, const vo
             const char* e = getenv("FMRI_WGRAD_KD_WGS");
             kd_wgs = e ? atoi(e) : 0;
         }
-        const int target = kd_wgs > 0 ? kd_wgs : (kd_blk == 64 ? 2 : 4) * fwd_cu_count();
+        // workgroups per launch: two per CU, i.e. ONE resident round (round 3: four per CU until then - every workgroup ends in a flush of
+        // 27 x 32 x 32 fp32 atomics onto the same filter block as the others of its column, so half the workgroups are half the flush
+        // traffic: weight-gradient family 4.64-4.73 -> 4.44-4.57 ms per step, step +0.2 ... 2.1 % in four interleaved same-box pairs;
+        // one per CU leaves the second slot of the CUs empty: 5.1-5.2 ms).  FMRI_WGRAD_KD_WGS overrides.
+        const int target = kd_wgs > 0 ? kd_wgs : 2 * fwd_cu_count();
         int nsl = (target + combos_kd - 1) / combos_kd;
         if (nsl > nunits) nsl = nunits;
         if (nsl < 1) nsl = 1;
