@@ -11,7 +11,7 @@ anything touches the GPU - relays rank 0's JSON line and exits non-zero when any
 --gpus refuses to run (a single-GPU number can no longer be labelled as a scaling run).
 
 Prints ONE JSON line on rank 0.  Besides the driver contract it carries
-  "roofline"     for the dominant kernel (live HIP-event timing of its launches in the timed region: every launch of every 5th timed
+  "roofline"     for the dominant kernel (live HIP-event timing of its launches in the timed region: every launch of every 10th timed
                  step - event brackets on every step cost 2.3 % of the step, see --launch-timing-every), and
   "cpu_baseline" the CPU oracle (torch-CPU restatement; Keras/TF are absent here and on the GPU box) timed on the host.
 """
@@ -363,7 +363,7 @@ def main():
                     help="untimed steps for at least this long before the --warmup steps (clock settling; not part of the timed region)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-launch-timing", action="store_true")
-    ap.add_argument("--launch-timing-every", type=int, default=5,
+    ap.add_argument("--launch-timing-every", type=int, default=10,
                     help="HIP-event brackets on every n-th step of the timed region (1 = every step; they cost 2.3 %% of the step time when on every step)")
     ap.add_argument("--no-exclusive-pass", action="store_true",
                     help="skip the second (single-stream) pass that measures exclusive kernel durations (used when profiling the timed region alone)")
@@ -510,7 +510,7 @@ def main():
     # MAIN stream - each event is one more packet in the chain of dependent input-gradient launches that the step's length hangs on
     # (events around the weight-gradient stream's ops alone: 310-311, i.e. free; around the main stream's conv ops alone: 287-293, the
     # main stream then falls behind the other).  So the launch durations are SAMPLED: every --launch-timing-every-th step of the timed
-    # region (default 5) carries the brackets, around every op as before; `roofline` is computed from those steps' launches
+    # region (default 10) carries the brackets, around every op as before; `roofline` is computed from those steps' launches
     # (`roofline.sampled_steps`), `value` from the wall clock over all K steps.
     every = max(1, a.launch_timing_every)
     sampled = 0
