@@ -155,6 +155,165 @@ def cpu_baseline(budget_s=25.0):
                       "Keras/TF not installed" % (n, best, cands, ncpu)}
 
 
+def val_dice_leg(batch, steps, spatial=(64, 128, 128), volume=(160, 256, 256), lr=1e-4, log=None):
+    """The val-Dice leg of BASELINE.json's metric (VERDICT r3 row g), AFTER the timed region: a fresh bf16 model of the
+    benchmarked configuration is trained for `steps` Adam steps on the learnable synthetic task (tools/learnable_task.py: image and label
+    from one latent field, batches generated in HBM) THROUGH the reference's API - fetal_net.training.train_model() with its callbacks
+    and checkpoints - then
+      soft              = -val_loss of the last epoch's Keras log = dice_coefficient (reference metrics.py:11-15) on held-out batches,
+      hard_cfg5_volume  = 2|t&p| / (|t| + |p|) (reference fetal/evaluate.py:16-17), p > 0.5, over a held-out 160x256x256 volume
+                          reconstructed by fetal_net.prediction.patch_wise_prediction (patch 64x128x128, overlap_factor 0.5, 36 tiles).
+    Convergence parity with the fp32 engine and the CPU oracle is what tests/test_gpu_val_dice.py asserts (same task, smaller patches)."""
+    import itertools
+    import tempfile
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import learnable_task as LT
+    import fetal_net.metrics as FM
+    import fetal_net.model as fmodel
+    from fetal_net.prediction import patch_wise_prediction
+    from fetal_net.training import train_model
+    t0 = time.perf_counter()
+    model = fmodel.unet_model_3d(input_shape=(1,) + tuple(spatial), depth=4, n_base_filters=32, initial_learning_rate=lr,
+                                 loss_function=FM.dice_coefficient_loss)
+    epochs = 3 if steps % 3 == 0 else 1
+    vsteps = 4
+    held = [LT.device_batch(LT.HELD_OUT + k * batch, batch, spatial) for k in range(vsteps)]
+    with tempfile.TemporaryDirectory() as tmp:
+        t1 = time.perf_counter()
+        import contextlib
+        import io
+        with contextlib.redirect_stdout(io.StringIO()):          # the epoch lines of fit_generator / ModelCheckpoint: not part of the JSON line
+            hist = train_model(model, os.path.join(tmp, "fetal_net_model"), LT.device_generator(0, batch, spatial), itertools.cycle(held),
+                               steps_per_epoch=steps // epochs, validation_steps=vsteps, initial_learning_rate=lr, n_epochs=epochs,
+                               output_folder=tmp).history
+        torch.cuda.synchronize()
+        t_train = time.perf_counter() - t1
+    # (predict() of a device batch returns a view of the engine's probability buffer: use it before the next call)
+    hard_b = float(np.mean([LT.hard_dice(y.cpu().numpy(), (model.predict(x) > 0.5).cpu().numpy()) for x, y in held]))
+    vx, vy = LT.device_patch(LT.HELD_OUT + 500_000, tuple(volume))
+    rec = patch_wise_prediction(model, vx.cpu().numpy()[None].astype(np.float64), spatial, overlap_factor=0.5)
+    return {"soft": -float(hist["val_loss"][-1]), "hard_cfg5_volume": LT.hard_dice(vy.cpu().numpy(), rec[..., 0] > 0.5),
+            "soft_cfg5_volume": LT.soft_dice(vy.cpu().numpy(), rec[..., 0]), "hard_held_out_batches": hard_b,
+            "steps": int(steps), "soft_per_epoch": [-float(v) for v in hist["val_loss"]], "train_dice_per_epoch": [-float(v) for v in hist["loss"]],
+            "lr": lr, "dtype": "bf16", "held_out_patches": vsteps * batch,
+            "task": "tools/learnable_task.py: y = blobs of a smooth latent field (%.0f %% foreground), x = zscore(%.1f * y + N(0,1)); training seeds "
+                    "0.., held-out seeds %d.." % (100 * LT.FG, LT.CONTRAST, LT.HELD_OUT),
+            "through": "fetal_net.training.train_model -> fit_generator (device batches, %d epochs, callbacks + checkpoints) -> patch_wise_prediction" % epochs,
+            "train_model_seconds": round(t_train, 2), "seconds": round(time.perf_counter() - t0, 2)}, model
+
+
+def reference_api_leg(model, batch, spatial=(64, 128, 128), steps=40):
+    """patches/s of the SAME training step driven through the reference-facing surface (`Model.fit_generator`, what train_model() calls):
+    (a) a reference-style host generator yielding float64 numpy batches (generator.py:397-401; one ready batch re-yielded: isolates the
+    boundary cost), (b) batches that are already in HBM.  `value` of the headline has the batch resident and no Python loop around it."""
+    rs = np.random.RandomState(0)
+    xb = rs.randn(batch, 1, *spatial)
+    yb = (rs.rand(batch, 1, *spatial) > 0.7).astype(np.uint8)
+    xd, yd = torch.from_numpy(xb.astype(np.float32)).cuda(), torch.from_numpy(yb).cuda()
+
+    def host_gen():
+        while True:
+            yield xb, yb
+
+    def dev_gen():
+        while True:
+            yield xd, yd
+
+    out = {}
+    for name, g in (("host_float64_generator", host_gen()), ("device_batches", dev_gen())):
+        model.fit_generator(g, steps_per_epoch=5, epochs=1, verbose=0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        model.fit_generator(g, steps_per_epoch=steps, epochs=1, verbose=0)
+        torch.cuda.synchronize()
+        out[name + "_patches_per_s"] = steps * batch / (time.perf_counter() - t0)
+    out["steps"] = steps
+    return out
+
+
+def cfg3_leg(steps=10, warmup=3):
+    """BASELINE configs[3]: 2-D mode (reference fetal_net/model/unet/unet.py:22-88), 256x256 slices x 5 channels, batch 64 per GPU, depth 4 /
+    32 filters, bf16: full training step in slices/s; the 3x3 convs' algorithmic FLOPs (2*9*Cin*Cout*pixels, fwd + dgrad + wgrad) against
+    the dense bf16 MFMA peak (11.7 k slices/s is the MFMA ceiling)."""
+    from fmri_hip.engine import UNetEngine, UNetPlan
+    B, X, Y, C = 64, 256, 256, 5
+    eng = UNetEngine(UNetPlan(C, (X, Y), depth=4, n_base_filters=32, ndim=2), B, dtype=torch.bfloat16)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn((1, B, X, Y, C), generator=g).cuda().to(torch.bfloat16)
+    y = (torch.rand((B * X * Y,), generator=g) > 0.7).to(torch.uint8).cuda()
+    for _ in range(warmup):
+        eng.train_step(x, y, 1e-4)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        eng.train_step(x, y, 1e-4)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    fl = 0.0
+    first = eng.plan.enc[0][0]["name"]
+    for c in eng.plan.convs_forward_order():
+        _, H, W = eng.plan.level_dims(c["level"], B)
+        fl += 2.0 * 9 * c["cin"] * c["cout"] * B * H * W * (2 if c["name"] == first else 3)
+    return {"workload": "configs[3]: 2-D U-Net depth 4 / 32 filters, 64x256x256x5 bf16 per GPU, full training step", "slices_per_s": B / dt,
+            "ms_per_step": dt * 1e3, "steps": steps, "conv_tflops_algorithmic": fl / dt / 1e12, "mfma_frac": fl / dt / 1e12 / PEAK_BF16_TFLOPS}
+
+
+def cfg4_leg(model=None, reps=3):
+    """BASELINE configs[4]: sliding-window inference over one 160x256x256 volume (reference fetal_net/prediction.py:118-210), patch
+    64x128x128, overlap_factor 0.5 = the reference's 36 tiles, hipGraph-replayed tile groups: seconds per volume end to end (host volume
+    in, float64 volume out) and for the device tile loop alone; 36 x 1,893.5 GFLOP of forward convs against the MFMA peak."""
+    import fetal_net.model as fmodel
+    from fetal_net.prediction import patch_wise_prediction
+    patch = (64, 128, 128)
+    if model is None:
+        model = fmodel.unet_model_3d(input_shape=(1,) + patch)
+    data = np.random.RandomState(0).randn(1, 160, 256, 256).astype(np.float32)
+    out = patch_wise_prediction(model=model, data=data, patch_shape=patch, overlap_factor=0.5)      # captures the graphs
+    times = []
+    for _ in range(reps):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = patch_wise_prediction(model=model, data=data, patch_shape=patch, overlap_factor=0.5)
+        times.append(time.perf_counter() - t0)
+    st = model._tile_state
+    sizes = sorted(st["per_b"], reverse=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    left = 36
+    while left > 0:
+        B = next(b for b in sizes if b <= left)
+        pb = st["per_b"][B]
+        pb["graph"].replay() if pb["graph"] is not None else pb["body"]()
+        left -= B
+    torch.cuda.synchronize()
+    dev = time.perf_counter() - t0
+    e2e = min(times)
+    return {"workload": "configs[4]: 160x256x256 volume, patch 64x128x128, overlap_factor 0.5, 36 tiles, device tile groups %s, hipGraph" % sizes,
+            "end_to_end_s_per_volume": e2e, "device_tile_loop_s": dev, "host_share": 1.0 - dev / e2e, "volumes_per_s": 1.0 / e2e,
+            "fwd_tflops_device": 36 * 1893.5e9 / dev / 1e12, "mfma_frac_device": 36 * 1893.5e9 / dev / 1e12 / PEAK_BF16_TFLOPS,
+            "finite": bool(np.isfinite(out).all())}
+
+
+def secondary_line(cfg):
+    """`bench.py --config cfg3|cfg4`: one JSON line for a secondary BASELINE configuration, same keys as the headline line"""
+    torch.cuda.set_device(0)
+    if cfg == "cfg3":
+        r = cfg3_leg(steps=20, warmup=5)
+        line = {"metric": "2D slices/sec (256x256x5, bf16) fwd+bwd", "value": r["slices_per_s"], "unit": "slices/s", "ms_per_step": r["ms_per_step"],
+                "steps": r["steps"], "warmup": 5, "dtype": "bf16",
+                "roofline": {"bound": "mfma", "achieved": r["conv_tflops_algorithmic"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": r["mfma_frac"],
+                             "traffic": None, "note": "whole-step figure: all 3x3 conv FLOPs of a step / step time (not one kernel's launches)"}}
+    else:
+        r = cfg4_leg()
+        line = {"metric": "sliding-window volumes/sec (160x256x256, patch 64x128x128, overlap 0.5, bf16)", "value": r["volumes_per_s"], "unit": "volumes/s",
+                "ms_per_step": r["end_to_end_s_per_volume"] * 1e3, "steps": 3, "warmup": 1, "dtype": "bf16",
+                "roofline": {"bound": "mfma", "achieved": r["fwd_tflops_device"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": r["mfma_frac_device"],
+                             "traffic": None, "note": "device tile loop: 36 x 1,893.5 GFLOP of forward convs / loop time"}}
+    line.update({"n_gpus": 1, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "data": "synthetic", "config": {"workload": r["workload"]},
+                 "detail": r})
+    print(json.dumps(line))
+
+
 TRAFFIC_PROFILE = os.path.join("profiles", "r03_pmc_traffic_per_step.json")
 MFMA_PROFILE = os.path.join("profiles", "r03_pmc_mfma.json")
 
@@ -363,8 +522,16 @@ def main():
                     help="untimed steps for at least this long before the --warmup steps (clock settling; not part of the timed region)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-launch-timing", action="store_true")
-    ap.add_argument("--launch-timing-every", type=int, default=10,
-                    help="HIP-event brackets on every n-th step of the timed region (1 = every step; they cost 2.3 %% of the step time when on every step)")
+    ap.add_argument("--launch-timing-every", type=int, default=None,
+                    help="HIP-event brackets on every n-th step of the timed region (1 = every step; they cost 2.3 %% of the step time when on every "
+                         "step).  Default: 10, or 5 when --steps <= 20, so that `roofline` rests on at least four sampled steps")
+    ap.add_argument("--config", choices=("cfg1", "cfg3", "cfg4"), default="cfg1",
+                    help="cfg1 (default): the headline configs[1] training step.  cfg3 / cfg4: ONE line for BASELINE configs[3] (2-D training step) "
+                         "or configs[4] (sliding-window inference of a 160x256x256 volume), N = 1")
+    ap.add_argument("--val-dice-steps", type=int, default=150,
+                    help="Adam steps of the val-Dice leg (after the timed region, N = 1 only; 0 = skip): see val_dice_leg")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the short configs[3] / configs[4] / reference-API measurements that the default N = 1 line carries after the timed region")
     ap.add_argument("--no-exclusive-pass", action="store_true",
                     help="skip the second (single-stream) pass that measures exclusive kernel durations (used when profiling the timed region alone)")
     ap.add_argument("--serialize-streams", action="store_true",
@@ -376,6 +543,12 @@ def main():
     a = ap.parse_args()
     if a.gpus < 1:
         ap.error("--gpus must be >= 1")
+    if a.launch_timing_every is None:
+        a.launch_timing_every = 5 if a.steps <= 20 else 10
+    if a.config != "cfg1":
+        if a.gpus != 1:
+            ap.error("--config cfg3|cfg4 are single-GPU lines")
+        return secondary_line(a.config)
 
     if a.gpus > 1 and "RANK" not in os.environ:
         # bare multi-GPU invocation: become the parent of N ranks BEFORE anything initialises the GPU
@@ -630,6 +803,22 @@ def main():
         with open(a.per_layer, "w") as f:
             json.dump(tab, f, indent=1)
         out["per_layer_total"] = tab["total"]
+    if world == 1 and (a.val_dice_steps > 0 or not a.no_secondary):
+        # after the timed region, never inside it: the bench engine's buffers go first (each leg builds its own model)
+        del eng, xd, yd
+        torch.cuda.empty_cache()
+        model = None
+        if a.val_dice_steps > 0:
+            out["val_dice"], model = val_dice_leg(a.batch, a.val_dice_steps)
+        if not a.no_secondary:
+            import fetal_net.metrics as FM
+            import fetal_net.model as fmodel
+            if model is None:
+                model = fmodel.unet_model_3d(input_shape=(1, 64, 128, 128), depth=4, n_base_filters=32, initial_learning_rate=1e-4,
+                                             loss_function=FM.dice_coefficient_loss)
+            out["reference_api"] = reference_api_leg(model, a.batch)
+            out["reference_api"]["resident_batch_patches_per_s"] = value
+            out["secondary"] = {"cfg4": cfg4_leg(model), "cfg3": cfg3_leg()}
     if world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
     print(json.dumps(out))

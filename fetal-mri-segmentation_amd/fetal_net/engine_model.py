@@ -14,7 +14,8 @@ import os
 import threading
 import time
 from collections import OrderedDict
-from queue import Queue
+from collections import deque
+from queue import Full, Queue
 
 import numpy as np
 
@@ -236,19 +237,37 @@ def _batch_len(x):
     return int(x.shape[0]) if hasattr(x, "shape") else int(np.asarray(x).shape[0])
 
 
-def _prefetch(generator, max_queue_size):
-    """one producer thread, bounded queue (Keras GeneratorEnqueuer with workers=1, reference training.py:115-117)"""
+def _prefetch(generator, max_queue_size, stage=None):
+    """one producer thread, bounded queue (Keras GeneratorEnqueuer with workers=1, reference training.py:115-117).  `stage` (a
+    `_Stager.stage` bound method) turns a generator batch into a staged device batch ON THE PRODUCER THREAD: float64 -> fp32 / uint8
+    conversion into pinned buffers and the H2D copy on a copy stream, off the thread that enqueues the training steps."""
     q = Queue(maxsize=max(1, max_queue_size))
     stop = threading.Event()
+
+    def put(item):
+        while not stop.is_set():
+            try:
+                q.put(item, timeout=0.1)
+                return True
+            except Full:
+                continue
+        return False
 
     def run():
         try:
             while not stop.is_set():
-                q.put(("ok", next(generator)))
+                if stage is not None:
+                    b = stage(generator, stop)         # next(generator) + staging, under the copy stream
+                    if b is None:                      # stopped while waiting for a free staging slot
+                        return
+                else:
+                    b = next(generator)
+                if not put(("ok", b)):
+                    return
         except StopIteration:
-            q.put(("stop", None))
+            put(("stop", None))
         except BaseException as e:
-            q.put(("err", e))
+            put(("err", e))
 
     th = threading.Thread(target=run, daemon=True)
     th.start()
@@ -261,7 +280,221 @@ def _prefetch(generator, max_queue_size):
             raise StopIteration
         return val
 
-    return get, stop
+    class _Stop(object):
+        """`set()` ends the producer and waits for it (bounded): the caller may hand the same generator - and the same staging ring - to
+        the next fit_generator call right away"""
+        def set(self, join=10.0):
+            stop.set()
+            if th is not threading.current_thread():
+                th.join(timeout=join)
+
+        def is_set(self):
+            return stop.is_set()
+
+    return get, _Stop()
+
+
+def _overrides(cb, name):
+    """does callback `cb` do anything in hook `name` (a subclass method, an instance attribute as LambdaCallback sets, or a foreign
+    duck-typed callback)?"""
+    f = getattr(cb, name, None)
+    return f is not None and getattr(f, "__func__", f) is not getattr(Callback, name)
+
+
+class _Staged(object):
+    """one batch in HBM in the engine's layout: x (compute dtype, NDHWC / planar), y (flat uint8), optional loss weight; `ready` = HIP
+    event on the copy stream behind the last copy / cast; `slot` = the staging slot to hand back once the step has been enqueued"""
+    __slots__ = ("x", "y", "weight", "n", "ready", "slot", "raw")
+
+    def __init__(self, x, y, weight, n, ready=None, slot=None, raw=None):
+        self.x, self.y, self.weight, self.n, self.ready, self.slot, self.raw = x, y, weight, n, ready, slot, raw
+
+
+class _Slot(object):
+    __slots__ = ("pin", "dev", "free", "done")
+
+    def __init__(self):
+        self.pin, self.dev = {}, {}
+        self.free = threading.Event()
+        self.free.set()
+        self.done = None                 # HIP event on the consumer's stream: the step that read this slot's device buffers has been enqueued up to here
+
+
+class _Stager(object):
+    """Producer-thread side of `fit_generator`: a ring of `depth` staging slots, each with pinned host buffers and
+    device buffers that are allocated once per batch shape.  Host batches: numpy converts float64 -> fp32 (x, masks) / uint8 (y) straight
+    into the pinned buffers, the H2D copies and the cast to the engine's dtype and layout run on a copy stream; the consumer only makes
+    its stream wait for the slot's `ready` event.  Device batches (fetal_net.device_generator) are produced under the copy stream and
+    pass through with the layout change only.  A slot is reused when the step that consumed it has finished on the device
+    (`done.synchronize()` on the producer thread - never on the training thread)."""
+
+    def __init__(self, model, depth=3):
+        import torch
+        self.model, self.torch = model, torch
+        self.device = torch.cuda.current_device()
+        self.main = torch.cuda.current_stream()
+        self.copy = torch.cuda.Stream()
+        self.slots = [_Slot() for _ in range(max(2, depth))]
+        self.k = 0
+        self._thread_ready = False
+
+    def reset(self):
+        """a new producer thread takes the ring over (the previous one has ended): all slots free, the caller's current stream is the consumer"""
+        self.main = self.torch.cuda.current_stream()
+        self.k = 0
+        self._thread_ready = False
+        for sl in self.slots:
+            sl.free.set()
+
+    def _buf(self, slot, key, shape, np_dtype, torch_dtype):
+        torch = self.torch
+        have = slot.pin.get(key)
+        if have is None or tuple(have.shape) != tuple(shape) or have.dtype != torch_dtype:
+            slot.pin[key] = torch.empty(tuple(shape), dtype=torch_dtype).pin_memory()
+            slot.dev[key] = torch.empty(tuple(shape), dtype=torch_dtype, device="cuda")
+        return slot.pin[key], slot.dev[key]
+
+    def _upload(self, slot, key, arr, np_dtype, torch_dtype):
+        """host array -> pinned buffer (conversion fused into the copy) -> device buffer of the slot, on the copy stream"""
+        arr = np.asarray(arr)
+        pin, dev = self._buf(slot, key, arr.shape, np_dtype, torch_dtype)
+        np.copyto(pin.numpy(), arr, casting="unsafe")
+        dev.copy_(pin, non_blocking=True)
+        return dev
+
+    def stage(self, generator, stop):
+        """next(generator) -> _Staged.  The generator itself runs under the copy stream: a device generator's kernels and the casts
+        behind them are ordered on it, the training stream joins through the `ready` event."""
+        torch, m = self.torch, self.model
+        if not self._thread_ready:
+            torch.cuda.set_device(self.device)            # the producer thread issues device work: bind it to the trainer's GPU first
+            self._thread_ready = True
+        slot = self.slots[self.k % len(self.slots)]
+        self.k += 1
+        while not slot.free.wait(timeout=0.1):
+            if stop.is_set():
+                return None
+        slot.free.clear()
+        if slot.done is not None:
+            slot.done.synchronize()                       # the step that read this slot's device buffers is over
+        with torch.cuda.stream(self.copy):
+            try:
+                batch = next(generator)
+            except BaseException:
+                slot.free.set()
+                raise
+            x, y = batch[0], batch[1]
+            masks = None
+            if isinstance(x, (list, tuple)):
+                masks = x[1] if len(x) > 1 else None
+                x = x[0]
+            n = _batch_len(x)
+            xd = x if _is_device_tensor(x) else self._upload(slot, "x", x, np.float32, torch.float32)
+            yd = y if _is_device_tensor(y) else self._upload(slot, "y", y, np.uint8, torch.uint8)
+            xe = m._to_device_x(xd)
+            ye = m._to_device_y(yd)
+            w = None
+            if getattr(m.loss, "mask_weighted", False):
+                if masks is None:
+                    raise ValueError("this model was built with mask_shape: feed [x, masks] (reference generator.py:397-401)")
+                md = masks if _is_device_tensor(masks) else self._upload(slot, "m", masks, np.float32, torch.float32)
+                w = torch.exp(-md.float() / m.loss.dist_sigma).reshape(-1).contiguous()
+            ready = torch.cuda.Event()
+            ready.record(self.copy)
+        for t in (xe, ye, w):
+            if t is not None:
+                t.record_stream(self.main)                # allocated under the copy stream, read on the training stream
+        return _Staged(xe, ye, w, n, ready, slot, raw=(x, y))
+
+    def consumed(self, staged):
+        """training thread, after the step that reads `staged` has been enqueued: hand the slot back to the producer"""
+        slot = staged.slot
+        if slot is None:
+            return
+        if slot.done is None:
+            slot.done = self.torch.cuda.Event()
+        slot.done.record(self.torch.cuda.current_stream())
+        slot.free.set()
+
+
+class _PendingLogs(object):
+    """metric sums of one step on their way to the host: a pinned fp64[16] buffer filled by an asynchronous D2H copy behind `event`.
+    `values()` waits for that event only (not for the stream) and turns the sums into Keras' [loss, metric...] list."""
+    __slots__ = ("model", "buf", "event", "_vals", "n")
+
+    def __init__(self, model, buf, event, n):
+        self.model, self.buf, self.event, self._vals, self.n = model, buf, event, None, n
+
+    def done(self):
+        return self._vals is not None or self.event.query()
+
+    def values(self):
+        if self._vals is None:
+            self.event.synchronize()
+            logs = self.model._batch_logs(self.buf.numpy().copy())
+            self._vals = [logs[k] for k in self.model.metrics_names]
+        return self._vals
+
+
+class LazyBatchLogs(dict):
+    """the `logs` dict of `on_batch_end`: `batch` and `size` are there at once, the metric values are read from the device the first
+    time a callback looks at them (the reference's callbacks - checkpoint, CSV log, lr policy, early stopping - only act on epoch ends,
+    so the training thread never waits for a step it has just enqueued)."""
+
+    def __init__(self, pending, names, batch, size):
+        dict.__init__(self, batch=batch, size=size)
+        self._pending, self._names = pending, names
+
+    def _force(self):
+        p = self._pending
+        if p is not None:
+            self._pending = None
+            for k, v in zip(self._names, p.values()):
+                dict.__setitem__(self, k, v)
+
+    def __getitem__(self, k):
+        if k not in ("batch", "size"):
+            self._force()
+        return dict.__getitem__(self, k)
+
+    def get(self, k, default=None):
+        if k not in ("batch", "size"):
+            self._force()
+        return dict.get(self, k, default)
+
+    def __contains__(self, k):
+        if k in ("batch", "size"):
+            return True
+        self._force()
+        return dict.__contains__(self, k)
+
+    def __iter__(self):
+        self._force()
+        return dict.__iter__(self)
+
+    def __len__(self):
+        self._force()
+        return dict.__len__(self)
+
+    def keys(self):
+        self._force()
+        return dict.keys(self)
+
+    def values(self):
+        self._force()
+        return dict.values(self)
+
+    def items(self):
+        self._force()
+        return dict.items(self)
+
+    def copy(self):
+        self._force()
+        return dict(self)
+
+    def __repr__(self):
+        self._force()
+        return dict.__repr__(self)
 
 
 class Model(object):
@@ -438,27 +671,47 @@ class Model(object):
         t = m if _is_device_tensor(m) else torch.from_numpy(np.ascontiguousarray(np.asarray(m), dtype=np.float32)).cuda(non_blocking=True)
         return torch.exp(-t.float() / self.loss.dist_sigma).reshape(-1).contiguous()
 
+    # -- steps: enqueue now, read the metric sums later --------------------------------------------------------------------------
+    LOG_RING = 8          # pinned fp64[16] buffers for the metric sums in flight (the training thread runs at most this many steps ahead)
+
+    def _stage_inline(self, x, y):
+        """(x, y) of a direct train_on_batch / test_on_batch call -> _Staged on the calling thread's stream"""
+        weight = self._loss_weight(x)
+        if isinstance(x, (list, tuple)):
+            x = x[0]
+        return _Staged(self._to_device_x(x), self._to_device_y(y), weight, _batch_len(x))
+
+    def _step_async(self, staged, train=True):
+        """enqueue one training (or evaluation) step on the current stream and the D2H copy of its metric sums behind it; nothing here
+        waits for the device.  -> _PendingLogs"""
+        import torch
+        eng = self.engine(staged.n)
+        if staged.ready is not None:
+            torch.cuda.current_stream().wait_event(staged.ready)
+        if train:
+            sums = eng.train_step(staged.x, staged.y, self.optimizer.lr, weight=staged.weight)
+        else:
+            eng.forward(staged.x, bn_training=False)                # Keras evaluates with learning_phase = 0
+            sums = eng.loss_forward(staged.y, staged.weight)
+        ring = self.__dict__.get("_log_ring")
+        if ring is None:
+            ring = self.__dict__["_log_ring"] = dict(k=0, slots=[[torch.empty(16, dtype=torch.float64).pin_memory(), torch.cuda.Event(), None]
+                                                                 for _ in range(self.LOG_RING)])
+        slot = ring["slots"][ring["k"] % self.LOG_RING]
+        ring["k"] += 1
+        if slot[2] is not None:
+            slot[2].values()                                         # the buffer's previous owner reads it before it is overwritten
+        slot[0].copy_(sums, non_blocking=True)
+        slot[1].record(torch.cuda.current_stream())
+        slot[2] = _PendingLogs(self, slot[0], slot[1], staged.n)
+        return slot[2]
+
     def train_on_batch(self, x, y, **kw):
         self._check_loss()
-        weight = self._loss_weight(x)
-        if isinstance(x, (list, tuple)):
-            x = x[0]
-        n = _batch_len(x)
-        eng = self.engine(n)
-        sums = eng.train_step(self._to_device_x(x), self._to_device_y(y), self.optimizer.lr, weight=weight)
-        logs = self._batch_logs(sums.cpu().numpy())
-        return [logs[k] for k in self.metrics_names]
+        return list(self._step_async(self._stage_inline(x, y), train=True).values())
 
     def test_on_batch(self, x, y, **kw):
-        weight = self._loss_weight(x)
-        if isinstance(x, (list, tuple)):
-            x = x[0]
-        n = _batch_len(x)
-        eng = self.engine(n)
-        eng.forward(self._to_device_x(x), bn_training=False)        # Keras evaluates with learning_phase = 0
-        sums = eng.loss_forward(self._to_device_y(y), weight)
-        logs = self._batch_logs(sums.cpu().numpy())
-        return [logs[k] for k in self.metrics_names]
+        return list(self._step_async(self._stage_inline(x, y), train=False).values())
 
     def evaluate(self, x, y, batch_size=None, verbose=0):
         """Keras `model.evaluate(x, y, batch_size)`: batch-size-weighted means of test_on_batch (reference fetal/experiments/train_adv.py:253-262)"""
@@ -477,32 +730,65 @@ class Model(object):
         doc.update(keras_version=keras_h5.KERAS_VERSION, backend=keras_h5.BACKEND)
         return json.dumps(doc, **kw)
 
+    def _staging(self, max_queue_size, role="train"):
+        """the staging ring for the producer thread of fit_generator / evaluate_generator (one per role, kept on the model: its pinned
+        and device buffers outlive the call); FMRI_STAGE_PREFETCH=0 keeps the round-3 behaviour (conversion and pageable upload on the
+        training thread) for A/B runs"""
+        if os.environ.get("FMRI_STAGE_PREFETCH", "1") == "0" or self._unsupported:
+            return None
+        import torch
+        if not torch.cuda.is_available():
+            return None
+        cache = self.__dict__.setdefault("_stagers", {})
+        st = cache.get(role)
+        if st is None or st.device != torch.cuda.current_device():
+            st = cache[role] = _Stager(self, depth=int(os.environ.get("FMRI_STAGE_DEPTH", "3")))
+        st.reset()
+        return st
+
+    def _as_staged(self, batch):
+        if isinstance(batch, _Staged):
+            return batch
+        return self._stage_inline(batch[0], batch[1])
+
     def evaluate_generator(self, generator, steps, max_queue_size=10, workers=1, use_multiprocessing=False, verbose=0):
-        get, stop = _prefetch(generator, max_queue_size)
-        outs, sizes = [], []
+        stager = self._staging(max_queue_size, "val")
+        get, stop = _prefetch(generator, max_queue_size, stager.stage if stager else None)
+        pend = []
         try:
             for _ in range(steps):
-                x, y = get()[:2]
-                outs.append(self.test_on_batch(x, y))
-                sizes.append(_batch_len(x))
+                b = self._as_staged(get())
+                pend.append(self._step_async(b, train=False))
+                if stager:
+                    stager.consumed(b)
         finally:
             stop.set()
+        outs, sizes = [p.values() for p in pend], [p.n for p in pend]
         return [float(np.average([o[i] for o in outs], weights=sizes)) for i in range(len(outs[0]))]
 
     def fit_generator(self, generator, steps_per_epoch=None, epochs=1, verbose=1, callbacks=None, validation_data=None,
                       validation_steps=None, class_weight=None, max_queue_size=10, workers=1, use_multiprocessing=False,
                       shuffle=True, initial_epoch=0):
+        """Keras 2.2 `fit_generator` loop (reference training.py:110-124).  The training thread only ENQUEUES: batches arrive staged in
+        HBM from the producer thread (`_Stager`), the metric sums of step k are read back from a pinned buffer a few steps later
+        (`_PendingLogs`), a callback that looks at a batch log forces that one read (`LazyBatchLogs`); epoch logs are complete before
+        `on_epoch_end`, as in Keras."""
         self._check_loss()
         self.history = History()
         cbs = list(callbacks or []) + [self.history]
         for cb in cbs:
             cb.set_model(self)
+        batch_cbs = [cb for cb in cbs if _overrides(cb, "on_batch_end") or _overrides(cb, "on_batch_begin")]
         self.stop_training = False
         names = self.metrics_names
-        get, stop = _prefetch(generator, max_queue_size)
+        stager = self._staging(max_queue_size)
+        stage = stager.stage if stager else None
+        get, stop = _prefetch(generator, max_queue_size, stage)
         vget, vstop = (None, None)
         if validation_data is not None and not isinstance(validation_data, (tuple, list)):
-            vget, vstop = _prefetch(validation_data, max_queue_size)
+            vstager = self._staging(max_queue_size, "val")
+            vget, vstop = _prefetch(validation_data, max_queue_size, vstager.stage if vstager else None)
+        lag = max(1, self.LOG_RING // 2)
         for cb in cbs:
             cb.on_train_begin({})
         try:
@@ -511,29 +797,41 @@ class Model(object):
                     cb.on_epoch_begin(epoch, {})
                 t0 = time.time()
                 tot, seen = np.zeros(len(names)), 0
+                pend = deque()
+
+                def drain(keep):
+                    nonlocal tot, seen
+                    while len(pend) > keep:
+                        p = pend.popleft()
+                        tot += np.asarray(p.values()) * p.n
+                        seen += p.n
+
                 for step in range(steps_per_epoch):
-                    batch = get()
-                    x, y = batch[0], batch[1]
-                    bs = _batch_len(x)
-                    for cb in cbs:
-                        cb.on_batch_begin(step, {"batch": step, "size": bs})
-                    vals = self.train_on_batch(x, y)
-                    tot += np.asarray(vals) * bs
-                    seen += bs
-                    blog = dict(zip(names, vals), batch=step, size=bs)
-                    for cb in cbs:
-                        cb.on_batch_end(step, blog)
+                    b = self._as_staged(get())
+                    for cb in batch_cbs:
+                        cb.on_batch_begin(step, {"batch": step, "size": b.n})
+                    p = self._step_async(b, train=True)
+                    if stager:
+                        stager.consumed(b)
+                    pend.append(p)
+                    if batch_cbs:
+                        blog = LazyBatchLogs(p, names, step, b.n)
+                        for cb in batch_cbs:
+                            cb.on_batch_end(step, blog)
+                    drain(lag)                                   # step k - lag has long finished: reading it does not stall the queue
                     if self.stop_training:
                         break
+                drain(0)
                 logs = OrderedDict((k, float(v)) for k, v in zip(names, tot / max(seen, 1)))
                 if validation_data is not None:
                     if vget is not None:
-                        vouts, vsizes = [], []
+                        vp = []
                         for _ in range(validation_steps):
-                            vb = vget()
-                            vx, vy = vb[0], vb[1]
-                            vouts.append(self.test_on_batch(vx, vy))
-                            vsizes.append(np.asarray(vx[0] if isinstance(vx, (list, tuple)) else vx).shape[0])
+                            vb = self._as_staged(vget())
+                            vp.append(self._step_async(vb, train=False))
+                            if vstager:
+                                vstager.consumed(vb)
+                        vouts, vsizes = [q.values() for q in vp], [q.n for q in vp]
                         vals = [float(np.average([o[i] for o in vouts], weights=vsizes)) for i in range(len(names))]
                     else:
                         vals = self.test_on_batch(validation_data[0], validation_data[1])

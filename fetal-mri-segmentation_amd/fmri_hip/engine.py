@@ -147,7 +147,7 @@ class UNetEngine:
                                               "UpSampling up-convolution): the normalisation statistics and the folded transposed conv still "
                                               "accumulate with floating-point atomics")
                 self.G64 = torch.zeros(self.n_flat, dtype=torch.int64, device=dev)
-                ops.set_deterministic(self.G, self.G64)
+                _register_deterministic(self)
         # compute-dtype copies of the 3x3x3 filters
         self.Wf, self.Wd, self.Wup = {}, {}, {}
         self.upcat = self._upcat_layers()
@@ -886,6 +886,8 @@ class UNetEngine:
             torch.cuda.current_stream(self.dev).wait_stream(self._wg_stream)
         if self.deterministic:
             ops.deterministic_finish(self.G, self.G64)       # G += the fixed-point sums of every gradient kernel of this pass
+            if self.dist is not None:
+                self.dist.begin()                            # nothing was reduced during this backward: one range, the whole buffer
         if self.dist is not None:
             self.dist.finish(self)
 
@@ -913,12 +915,20 @@ class UNetEngine:
                 return lv[1]["name"]
         raise KeyError(ld)
 
+    def close(self):
+        """give up the process-wide deterministic registration (FMRI_DETERMINISTIC=1; also done when the engine is garbage-collected)"""
+        fin = self.__dict__.pop("_det_finalizer", None)
+        if fin is not None:
+            fin()
+
     def grad_streams(self):
         """streams that enqueue parameter-gradient kernels during backward (a gradient bucket is complete when all of them got there)"""
         return [st for st in (getattr(self, "_main_stream", None), self._wg_stream) if st is not None]
 
     def _grad_ready(self, name):
-        if self.dist is not None:
+        # deterministic mode: the gradients sit in the int64 shadow until deterministic_finish at the end of backward(), so no bucket of
+        # G may be reduced before that - the whole buffer goes in dist.finish (ADVICE r3: early buckets all-reduced zeros)
+        if self.dist is not None and not self.deterministic:
             self.dist.grad_ready(self, name)
 
     # ------------------------------------------------------------------------------------------------ optimizer
@@ -945,6 +955,32 @@ class UNetEngine:
         vod = (s[3] + smooth) / (s[4] + s[5] - s[3] + smooth)
         return dict(loss=ops.loss_value_from_sums(s, loss_kind, loss_param, smooth), dice_coefficient=dice, vod_coefficient=vod,
                     binary_accuracy=s[6] / max(s[7], 1.0))
+
+
+_DET_OWNER = []          # [weakref to the engine that holds the process-wide fmri_set_deterministic registration]
+
+
+def _release_deterministic(token):
+    if _DET_OWNER and _DET_OWNER[0] is token:
+        _DET_OWNER.clear()
+        try:
+            ops.set_deterministic(None, None)
+        except Exception:                                    # interpreter shutdown: the library may be gone already
+            pass
+
+
+def _register_deterministic(eng):
+    """fmri_set_deterministic keeps raw device pointers process-wide: ONE engine may hold the registration, and it is given back when
+    that engine dies or is closed (a stale registration redirected a later engine's gradients into freed memory)"""
+    import weakref
+    if _DET_OWNER and _DET_OWNER[0]() is not None:
+        raise RuntimeError("FMRI_DETERMINISTIC=1: another engine of this process holds the deterministic-gradient registration "
+                           "(one deterministic engine per process at a time; call its close() first)")
+    _DET_OWNER.clear()
+    ref = weakref.ref(eng)
+    _DET_OWNER.append(ref)
+    ops.set_deterministic(eng.G, eng.G64)
+    eng._det_finalizer = weakref.finalize(eng, _release_deterministic, ref)
 
 
 def _glorot(rs, shape):

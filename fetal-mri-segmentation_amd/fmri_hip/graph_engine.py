@@ -346,6 +346,11 @@ class LayerGraphEngine(object):
             for name, op in self.convs.items():
                 if op.get("sub") != (2, 2, 2) or op["k"] != 3 or op["act"] != ACT_NONE or len(op["ins"]) != 1:
                     continue
+                # the bias of this form is a bf16 tensor added in a second pass (two roundings): harmless only where a normalisation layer
+                # consumes the output and removes a per-channel constant - every other strided conv keeps the kernel-epilogue bias
+                readers = [o2 for o2 in self.ops if op["out"] in o2.get("ins", ())]
+                if not readers or any(o2["kind"] != "norm" for o2 in readers):
+                    continue
                 coutp, cinp = self.shape[name][0], self.Wp32[name].shape[2]
                 fine = tuple(self.shape[op["ins"][0]][1:])
                 if any(d % 2 for d in fine) or self._is_input(op["ins"]):

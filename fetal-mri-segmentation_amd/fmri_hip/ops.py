@@ -237,8 +237,10 @@ def norm_tail_ws_doubles(G, C):
 
 
 def conv3d_fwd_stats(src0, src1, w, bias, y, ws, per_instance, up0=False, act=ACT_NONE, alpha=0.0):
-    """conv3d_fwd whose epilogue leaves {sum y, sum y^2} per (group, channel) in front of ws (fp64, norm_tail_ws_doubles(G, Cout) elements,
-    zeroed by the call)"""
+    """conv3d_fwd whose epilogue leaves {sum y, sum y^2} per (group, channel) in front of ws (fp64, norm_tail_ws_doubles(G, Cout) elements).
+    ws must be ZERO on entry (allocate it zeroed): no fmri_norm_* / *_stats call clears it in front any more - the last reader of the sums
+    (norm_act_fwd_pre / norm_act_bwd_pre / the fold kernel) leaves it zero for the next call.  After a call sequence that was interrupted
+    between the summing launch and its reader, zero it again before reuse."""
     _need_cuda(src0, src1, w, bias, y, ws)
     N, D, H, W, Cout = y.shape
     c0, c1 = src0.shape[-1], (0 if src1 is None else src1.shape[-1])

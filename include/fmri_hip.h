@@ -217,13 +217,14 @@ int fmri_upsample_nearest2x_bwd(const void* dy, int dy_ld, int dy_off, const voi
 int fmri_norm_act_fwd(const void* x, const float* gamma, const float* beta, void* y, float* stats, double* ws, int N, int64_t V,
                       int C, int per_instance, float eps, int eps_on_std, int act, float alpha, int dtype, fmri_stream_t stream);
 /* dy is the gradient w.r.t. y (NOT yet multiplied by act'): dz = dy*act'(y); dgamma/dbeta (fp32, ACCUMULATED) ;
- * dx = gamma*[(dz-mean(dz))/s - xhat*mean(dz*xhat)/sigma].  dx may alias dy. */
+ * dx = gamma*[(dz-mean(dz))/s - xhat*mean(dz*xhat)/sigma].  dx may alias dy.  ws: ZERO ON ENTRY (see above), left zero. */
 int fmri_norm_act_bwd(const void* x, const void* y, const void* dy, const float* gamma, const float* stats, void* dx, float* dgamma,
                       float* dbeta, double* ws, int N, int64_t V, int C, int per_instance, int act, float alpha, int dtype,
                       fmri_stream_t stream);
 /* the same without reading y: the sign of the block's output is recomputed from x, gamma, beta and the stored statistics with the very
  * operations fmri_norm_act_fwd used (so it agrees with the stored y bit for bit) - each of the two HBM-bound backward passes reads two
- * tensors instead of three. */
+ * tensors instead of three.  ws: ZERO ON ENTRY, left zero (a caller with uninitialised scratch, or one whose sequence was cut between a
+ * summing launch and its reader, gets wrong statistics without an error: zero it again). */
 int fmri_norm_act_bwd_x(const void* x, const void* dy, const float* gamma, const float* beta, const float* stats, void* dx, float* dgamma,
                         float* dbeta, double* ws, int N, int64_t V, int C, int per_instance, int act, float alpha, int dtype,
                         fmri_stream_t stream);

@@ -18,7 +18,7 @@ def pytest_configure(config):
 
 # Hot path first: under `pytest -x` a failure in a late, stochastic row of SURVEY 8(f) must not hide the kernels the bench
 # times.  Files not listed keep their alphabetical place behind the listed ones; CPU tests are not reordered among themselves.
-GPU_FILE_ORDER = ["test_gpu_ops", "test_gpu_losses", "test_gpu_engine", "test_gpu_fullsize_parity", "test_gpu_model", "test_gpu_fullsize", "test_gpu_dist",
+GPU_FILE_ORDER = ["test_gpu_ops", "test_gpu_losses", "test_gpu_engine", "test_gpu_fullsize_parity", "test_gpu_val_dice", "test_gpu_model", "test_gpu_fullsize", "test_gpu_dist",
                   "test_gpu_integration_snippet", "test_gpu_augment", "test_gpu_postprocess", "test_gpu_tta", "test_gpu_adversarial"]
 
 

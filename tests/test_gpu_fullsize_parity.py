@@ -476,8 +476,16 @@ def test_bench_step_is_bit_reproducible_in_deterministic_mode(monkeypatch):
             torch.cuda.synchronize()
             ends.append(eng.P.clone())
         assert torch.equal(ends[0], ends[1]) and not torch.equal(ends[0], P0)
+        # one registration per process: a second deterministic engine is refused while this one lives, accepted after close()
+        with pytest.raises(RuntimeError):
+            UNetEngine(UNetPlan(1, (8, 16, 32), depth=2, n_base_filters=32), 1, dtype=torch.bfloat16)
     finally:
-        ops.set_deterministic(None, None)
+        eng.close()
+    eng2 = UNetEngine(UNetPlan(1, (8, 16, 32), depth=2, n_base_filters=32), 1, dtype=torch.bfloat16)
+    assert eng2.deterministic
+    del eng2                                                      # garbage collection gives the registration back as well
+    import gc
+    gc.collect()
     # against the default mode (fp32 atomics, parity-form weight gradient): same gradients up to summation order / the parity form's rounding
     monkeypatch.setenv("FMRI_DETERMINISTIC", "0")
     ref = UNetEngine(plan, N, dtype=torch.bfloat16, seed=42)

@@ -5,7 +5,7 @@ mkdir -p gpurun_out
 for rep in 1 2; do
   for cfg in "" "$@"; do
     tag=${cfg:-default}
-    env $cfg python3 bench.py --steps 40 --warmup 10 --no-cpu-baseline 2>/dev/null | python3 -c "
+    env $cfg python3 bench.py --steps 40 --warmup 10 --no-cpu-baseline --val-dice-steps 0 --no-secondary 2>/dev/null | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
 x=d.get('roofline_exclusive',{}).get('kernel_ms_per_step',{})

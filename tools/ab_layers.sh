@@ -6,7 +6,7 @@ REPS=${REPS:-2}
 for rep in $(seq 1 $REPS); do
   i=0
   for cfg in "" "$@"; do
-    env $cfg python3 bench.py --steps 30 --warmup 5 --no-cpu-baseline --per-layer gpurun_out/ab/pl_${i}_$rep.json > gpurun_out/ab/bench_${i}_$rep.json 2>/dev/null
+    env $cfg python3 bench.py --steps 30 --warmup 5 --no-cpu-baseline --val-dice-steps 0 --no-secondary --per-layer gpurun_out/ab/pl_${i}_$rep.json > gpurun_out/ab/bench_${i}_$rep.json 2>/dev/null
     i=$((i+1))
   done
 done

@@ -7,8 +7,8 @@ OUT=$ROOT/gpurun_out/bench_all.jsonl
 mkdir -p "$ROOT/gpurun_out"
 : > "$OUT"
 run() { echo "# $*" >&2; "$@" 2>/dev/null | tail -1 | tee -a "$OUT"; }
-run python3 bench.py --no-cpu-baseline                 # configs[1]: headline 3-D training step (two streams) + roofline objects
-run python3 bench.py --no-cpu-baseline --serialize-streams --no-launch-timing
+run python3 bench.py --no-cpu-baseline --val-dice-steps 0 --no-secondary                 # configs[1]: headline 3-D training step (two streams) + roofline objects
+run python3 bench.py --no-cpu-baseline --val-dice-steps 0 --no-secondary --serialize-streams --no-launch-timing
 run python3 tools/bench_2d.py                          # configs[3]: 2-D training step
 run python3 tools/infer_volume.py                      # configs[4]: sliding-window inference of a 160x256x256 volume
 run python3 tools/infer_volume_2d.py                   # 2-D sliding-window inference

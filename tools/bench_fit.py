@@ -19,7 +19,7 @@ def main():
     from fetal_net.device_generator import DeviceDataFile, device_data_generator
     from fetal_net.metrics import dice_coefficient_loss
     from fetal_net.model import unet_model_3d
-    patch, B, steps = (64, 128, 128), 4, 30
+    patch, B, steps = (64, 128, 128), 4, 60
     model = unet_model_3d(input_shape=(1,) + patch, depth=4, n_base_filters=32, initial_learning_rate=1e-4, loss_function=dice_coefficient_loss)
     rs = np.random.RandomState(0)
     xb = rs.randn(B, 1, *patch)                                     # float64, as the reference's generator yields

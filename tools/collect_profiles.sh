@@ -19,16 +19,16 @@ want() { [[ " $PASSES " == *" $1 "* ]]; }
 rocprofv3 -L > "$OUT/counters_available.txt" 2>&1
 cd /tmp
 # default command: the weight-gradient kernels run on a second stream, concurrently with the input-gradient chain (durations overlap)
-want stats && rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o stats -- python3 "$ROOT/bench.py" --steps 10 --warmup 3 --no-cpu-baseline --no-exclusive-pass > "$OUT/stats.log" 2>&1
+want stats && rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o stats -- python3 "$ROOT/bench.py" --steps 10 --warmup 3 --no-cpu-baseline --val-dice-steps 0 --no-secondary --no-exclusive-pass > "$OUT/stats.log" 2>&1
 # one stream: exclusive kernel durations (what bench.py reports as roofline_exclusive)
-want stats && rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_serial" -o stats -- python3 "$ROOT/bench.py" --steps 10 --warmup 3 --no-cpu-baseline --serialize-streams --per-layer "$OUT/per_layer.json" > "$OUT/stats_serial.log" 2>&1
-want traffic && rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch" -o fetch -- python3 "$ROOT/bench.py" --steps 1 --warmup 1 --prewarm-seconds 0 --no-cpu-baseline --serialize-streams > "$OUT/pmc_fetch.log" 2>&1
-want traffic && rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_write" -o write -- python3 "$ROOT/bench.py" --steps 1 --warmup 1 --prewarm-seconds 0 --no-cpu-baseline --serialize-streams > "$OUT/pmc_write.log" 2>&1
+want stats && rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_serial" -o stats -- python3 "$ROOT/bench.py" --steps 10 --warmup 3 --no-cpu-baseline --val-dice-steps 0 --no-secondary --serialize-streams --per-layer "$OUT/per_layer.json" > "$OUT/stats_serial.log" 2>&1
+want traffic && rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch" -o fetch -- python3 "$ROOT/bench.py" --steps 1 --warmup 1 --prewarm-seconds 0 --no-cpu-baseline --val-dice-steps 0 --no-secondary --serialize-streams > "$OUT/pmc_fetch.log" 2>&1
+want traffic && rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_write" -o write -- python3 "$ROOT/bench.py" --steps 1 --warmup 1 --prewarm-seconds 0 --no-cpu-baseline --val-dice-steps 0 --no-secondary --serialize-streams > "$OUT/pmc_write.log" 2>&1
 # MFMA utilisation from the counters (north_star / SURVEY 8d "SQ_VALU_MFMA_BUSY_CYCLES"): SQ + GRBM counters only, their own pass, the
 # program directly behind `--`.  SQ_VALU_MFMA_BUSY_CYCLES counts shader cycles in which a SIMD's matrix pipe is busy (32 per
 # v_mfma_f32_32x32x16_bf16), GRBM_GUI_ACTIVE is the sum over the 8 XCDs of their active cycles (MI355X_MICROARCH.md, DVFS give-back).
-want mfma && rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$OUT/pmc_mfma" -o mfma -- python3 "$ROOT/bench.py" --steps 1 --warmup 1 --prewarm-seconds 0 --no-cpu-baseline --serialize-streams > "$OUT/pmc_mfma.log" 2>&1
-want mfma && rocprofv3 --pmc SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_BF16 --kernel-trace --output-format csv -d "$OUT/pmc_sq" -o sq -- python3 "$ROOT/bench.py" --steps 1 --warmup 1 --prewarm-seconds 0 --no-cpu-baseline --serialize-streams > "$OUT/pmc_sq.log" 2>&1
+want mfma && rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$OUT/pmc_mfma" -o mfma -- python3 "$ROOT/bench.py" --steps 1 --warmup 1 --prewarm-seconds 0 --no-cpu-baseline --val-dice-steps 0 --no-secondary --serialize-streams > "$OUT/pmc_mfma.log" 2>&1
+want mfma && rocprofv3 --pmc SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_BF16 --kernel-trace --output-format csv -d "$OUT/pmc_sq" -o sq -- python3 "$ROOT/bench.py" --steps 1 --warmup 1 --prewarm-seconds 0 --no-cpu-baseline --val-dice-steps 0 --no-secondary --serialize-streams > "$OUT/pmc_sq.log" 2>&1
 cd "$ROOT"
 want mfma && python3 tools/pmc_mfma.py "$OUT" 2 "$HEAD" "$(python3 -c "import bench; print(bench.kernel_source_hash())")" > "$OUT/pmc_mfma.json"
 SRC_HASH=$(python3 -c "import bench; print(bench.kernel_source_hash())")

@@ -2,8 +2,8 @@
 # Runs the whole -m gpu suite the way the driver does (pytest -x -q) and keeps its log STAMPED with the hash of the kernel sources it
 # ran on: gpurun_out/<tag>_gputest_final.log (copy it to profiles/).  tests/test_profiles_fresh.py (CPU) fails while that stamp differs
 # from the tree's kernel_source_hash, i.e. whenever a kernel changed after the last recorded green run.
-#   /usr/local/graft/bin/gpurun --timeout 900 -- 'bash tools/gputest_stamp.sh r03'
-TAG=${1:-r03}
+#   /usr/local/graft/bin/gpurun --timeout 900 -- 'bash tools/gputest_stamp.sh r04'
+TAG=${1:-r04}
 mkdir -p gpurun_out
 HASH=$(python3 -c "import bench; print(bench.kernel_source_hash())")
 SO=$(sha256sum fetal-mri-segmentation_amd/lib/libfmri_hip.so | cut -c1-16)

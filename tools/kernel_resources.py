@@ -5,10 +5,21 @@ import re
 import subprocess
 import sys
 
+
+def per_file_flags(src):
+    """the extra flags csrc/Makefile gives this file (FLAGS_<stem> = ...): the numbers printed here must describe the binary that ships"""
+    import os
+    mk = os.path.join(os.path.dirname(os.path.abspath(src)), "Makefile")
+    stem = os.path.splitext(os.path.basename(src))[0]
+    if not os.path.exists(mk):
+        return []
+    m = re.search(r"^FLAGS_%s\s*=\s*(.*)$" % re.escape(stem), open(mk).read(), re.M)
+    return m.group(1).split() if m else []
+
 src = sys.argv[1]
 flt = sys.argv[2] if len(sys.argv) > 2 else ""
 out = subprocess.run(["hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wno-comment", "-Rpass-analysis=kernel-resource-usage",
-                      "-c", src, "-o", "/dev/null"] + sys.argv[3:], capture_output=True, text=True).stderr
+                      "-c", src, "-o", "/dev/null"] + per_file_flags(src) + sys.argv[3:], capture_output=True, text=True).stderr
 cur = None
 rows = {}
 for ln in out.splitlines():

@@ -4,12 +4,24 @@ scratch instructions before / inside / after the span of its MFMA instructions a
 matrix loop is a performance bug, one in a prologue or in a producer wave's path usually is not).
 usage: tools/spill_sites.py <file.hip> <mangled-name substring> [extra hipcc flags]"""
 import bisect
+import re
 import subprocess
 import sys
 
+
+def per_file_flags(src):
+    """the extra flags csrc/Makefile gives this file (FLAGS_<stem> = ...): the numbers printed here must describe the binary that ships"""
+    import os
+    mk = os.path.join(os.path.dirname(os.path.abspath(src)), "Makefile")
+    stem = os.path.splitext(os.path.basename(src))[0]
+    if not os.path.exists(mk):
+        return []
+    m = re.search(r"^FLAGS_%s\s*=\s*(.*)$" % re.escape(stem), open(mk).read(), re.M)
+    return m.group(1).split() if m else []
+
 src, pat = sys.argv[1], sys.argv[2]
 asm = "/tmp/_spill_sites.s"
-subprocess.run(["hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wno-comment", "-S", "--cuda-device-only", "-o", asm, src] + sys.argv[3:],
+subprocess.run(["hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wno-comment", "-S", "--cuda-device-only", "-o", asm, src] + per_file_flags(src) + sys.argv[3:],
                check=True, stderr=subprocess.DEVNULL)
 lines = open(asm).read().split("\n")
 for i, l in enumerate(lines):
