@@ -3,6 +3,8 @@
 Bars (BASELINE.json north_star): fp32 mode logits <= 1e-3 relative, |dDice| <= 1e-4 vs the CPU restatement on identical
 seeded weights / synthetic volumes.  bf16 mode is checked against the same oracle at bf16-appropriate tolerances.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -190,6 +192,46 @@ def test_unet2d_fp32_and_bf16_vs_oracle():
         Wx = eng.export_keras_weights()
         for k in W:
             assert Wx[k].shape == W[k].shape
+
+
+def test_unet2d_full_resolution_bf16_vs_oracle():
+    """BASELINE configs[3] at its own resolution against the CPU ORACLE (the oracle had seen the 2-D model at toy size
+    only, the full-size check compared HIP bf16 with HIP fp32): 8 slices of 256x256x5, depth 4 / 32 filters, bf16 on the planar MFMA
+    kernels (first-layer MFMA kernel with (tap, channel) pairs as k, planar parity form in the decoder: 8 slices tile) vs
+    oracle.loss_and_grads in fp32 - logits, Dice, every parameter gradient (reference model/unet/unet.py:22-88)."""
+    from fmri_hip.engine import UNetEngine, UNetPlan
+    from oracle import unet_oracle as O
+    N, X, Y, C = 8, 256, 256, 5
+    spec = O.Spec((X, Y, C), ndim=2, depth=4, n_base_filters=32)
+    W = spec.init_weights(11)
+    rs = np.random.RandomState(3)
+    x = rs.randn(N, X, Y, C).astype(np.float32)
+    y = (rs.rand(N, X, Y, 1) > 0.7).astype(np.uint8)
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    ref = O.loss_and_grads(spec, W, x, y, dtype=torch.float32)
+    eng = UNetEngine(UNetPlan(C, (X, Y), depth=4, n_base_filters=32, ndim=2), N, dtype=torch.bfloat16)
+    assert len(eng.Wup) == 3 and all(eng._use_upcat(n) for n in eng.Wup)          # the planar parity form is what runs
+    eng.load_keras_weights(W)
+    xd = torch.from_numpy(x).cuda().to(torch.bfloat16).unsqueeze(0).contiguous()
+    yd = torch.from_numpy(y).cuda().reshape(-1).contiguous()
+    eng.forward(xd)
+    sums = eng.loss_forward(yd)
+    eng.backward(yd)
+    torch.cuda.synchronize()
+    logits = eng.logits.cpu().numpy().reshape(ref["logits"].shape)
+    bar("unet2d_full.bf16.logits_rel", _rel(logits, ref["logits"]), 1.5e-2)                 # measured 7.3e-3
+    bar("unet2d_full.bf16.dice_abs", abs(eng.metrics_from_sums(sums.cpu().numpy())["dice_coefficient"] - ref["dice"]), 4.7e-5)   # measured 2.3e-5
+    worst = 0.0
+    for name, L in eng.layout.items():
+        gk = ref["grads"][name + "/kernel"]
+        if L["kind"] == "conv":
+            mine = eng.w_view(name, eng.G).cpu().numpy().reshape(3, 3, 3, L["cout"], L["cin"]).transpose(0, 1, 2, 4, 3)
+            assert float(np.abs(mine[0]).max()) == 0 and float(np.abs(mine[2]).max()) == 0     # dead kd planes stay untouched
+            mine = mine[1]
+        else:
+            mine = eng.w_view(name, eng.G).cpu().numpy().T.reshape(gk.shape)
+        worst = max(worst, float(np.linalg.norm(mine.astype(np.float64) - gk) / (np.linalg.norm(gk) + 1e-30)))
+    bar("unet2d_full.bf16.worst_grad_l2_rel", worst, 2.6e-2)                                # measured 1.28e-2
 
 
 @pytest.mark.parametrize("slices", [8, 6])
