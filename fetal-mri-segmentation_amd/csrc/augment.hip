@@ -63,10 +63,25 @@ __global__ void k_minmax_init(unsigned* mm) {
     mm[0] = 0xffffffffu;
     mm[1] = 0u;
 }
+// 16-byte loads, wave shuffle, then ONE atomic pair per workgroup (4 waves through LDS) and at most 256 workgroups: the round-2 form
+// (4 B per thread and iteration, one atomic pair per WAVE of up to 1,024 workgroups: 8,192 device-scope atomics on two addresses) took
+// 100 us per 64x128x128 patch next to the training step's kernels - 0.8 ms of an augmented batch of four (rocprofv3, tools/trace_fit.sh)
 template <typename T>
-__global__ void k_minmax(const T* __restrict__ x, int64_t n, unsigned* mm) {
+__global__ void __launch_bounds__(256) k_minmax(const T* __restrict__ x, int64_t n, unsigned* mm) {
+    constexpr int V = 16 / sizeof(T);
     float lo = INFINITY, hi = -INFINITY;
-    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t nv = ((reinterpret_cast<uintptr_t>(x) & 15) == 0) ? n / V : 0;      // vector part (aligned base), the tail goes scalar
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < nv; t += (int64_t)gridDim.x * blockDim.x) {
+        const uint4 q = reinterpret_cast<const uint4*>(x)[t];
+        const T* e = reinterpret_cast<const T*>(&q);
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            const float v = to_f<T>(e[i]);
+            lo = fminf(lo, v);
+            hi = fmaxf(hi, v);
+        }
+    }
+    for (int64_t t = nv * V + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
         const float v = to_f<T>(x[t]);
         lo = fminf(lo, v);
         hi = fmaxf(hi, v);
@@ -76,9 +91,16 @@ __global__ void k_minmax(const T* __restrict__ x, int64_t n, unsigned* mm) {
         lo = fminf(lo, __shfl_xor(lo, o));
         hi = fmaxf(hi, __shfl_xor(hi, o));
     }
-    if ((threadIdx.x & 63) == 0 && lo <= hi) {
-        atomicMin(&mm[0], f2key(lo));
-        atomicMax(&mm[1], f2key(hi));
+    __shared__ float slo[4], shi[4];
+    if ((threadIdx.x & 63) == 0) { slo[threadIdx.x >> 6] = lo; shi[threadIdx.x >> 6] = hi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        lo = fminf(fminf(slo[0], slo[1]), fminf(slo[2], slo[3]));
+        hi = fmaxf(fmaxf(shi[0], shi[1]), fmaxf(shi[2], shi[3]));
+        if (lo <= hi) {
+            atomicMin(&mm[0], f2key(lo));
+            atomicMax(&mm[1], f2key(hi));
+        }
     }
 }
 __global__ void k_minmax_decode(unsigned* mm) {
@@ -192,7 +214,7 @@ extern "C" int fmri_minmax(const void* x, int64_t n, int dtype, float* out2, fmr
     hipStream_t st = as_stream(stream);
     unsigned* mm = reinterpret_cast<unsigned*>(out2);
     k_minmax_init<<<1, 1, 0, st>>>(mm);
-    const int grid = grid_for(n, 256, 1024);
+    const int grid = grid_for((n + 3) / 4, 256, 256);
     if (dtype == FMRI_F32) k_minmax<float><<<grid, 256, 0, st>>>((const float*)x, n, mm);
     else if (dtype == FMRI_BF16) k_minmax<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)x, n, mm);
     else return FMRI_E_DTYPE;

@@ -1143,6 +1143,9 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
         };
         FwdItem done = cur;
         bool pending = false;
+#ifdef FMRI_PROF
+        unsigned long long pprof[12] = {};       // producers: [0] counted DMA wait, [11] barrier wait, [2] issue (filter slab, drain part, halo pieces)
+#endif
         constexpr int DPN = DP > 0 ? DP : 1;
         int drain_vmops[DPN];
 #pragma unroll
@@ -1174,6 +1177,7 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
                 constexpr bool DRN = decltype(drn_tag)::value;
                 static_for<NPH>([&](auto pl_tag) {
                     constexpr int pl = decltype(pl_tag)::value;
+                    PROF_T(pw0);
                     // This phase's filter slab was issued one phase ago, FOLLOWED by that phase's halo pieces (which belong to the next chunk)
                     // or by the stores of the drain: wait for the slab only and leave those in flight - a full vmcnt(0) here exposes the
                     // memory latency of every piece in every phase (measured: the producer chain issue + latency, not the MFMAs, set the
@@ -1202,7 +1206,9 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
                         }
                     }
                     else wait_newer(has_next ? pieces_from(pl, DRN) - pieces_from(pl - 1, DRN) : 0);
+                    PROF_T(pw1);
                     __builtin_amdgcn_s_barrier();                          // everybody's has landed; the previous phase is fully read
+                    PROF_T(pw2);
                     if (pl < NPH - 1) issue_filter(cur, pl + 1, (g + 1) & 1);
                     else if (has_next) issue_filter(nxt, 0, (g + 1) & 1);
                     if constexpr (DRN) {
@@ -1241,6 +1247,9 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
                             }
                         }
                     }
+#ifdef FMRI_PROF
+                    { PROF_T(pw3); pprof[0] += pw1 - pw0; pprof[11] += pw2 - pw1; pprof[2] += pw3 - pw2; }
+#endif
                     ++g;
                 });
             };
@@ -1270,6 +1279,9 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
             hb ^= 1;
         }
         nsum_flush();
+#ifdef FMRI_PROF
+        if (lane == 0) { atomicAdd(&g_prof[0], pprof[0]); atomicAdd(&g_prof[11], pprof[11]); atomicAdd(&g_prof[2], pprof[2]); }
+#endif
         return;
     }
 

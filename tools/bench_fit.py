@@ -33,7 +33,10 @@ def main():
     dev_gen = device_data_generator(ddf, list(range(6)), batch_size=B, patch_shape=patch, augment=AUG, truth_index=0, truth_size=patch[2], is3d=True,
                                     categorical=False, skip_blank=False)
     out = {}
+    only = os.environ.get("FMRI_BENCH_FIT_ONLY", "")          # "host" | "device": one leg only (tools/trace_fit.sh)
     for name, g in (("host_float64_generator", host_gen()), ("device_generator", dev_gen)):
+        if only and not name.startswith(only):
+            continue
         model.fit_generator(g, steps_per_epoch=5, epochs=1, verbose=0)          # warm-up
         torch.cuda.synchronize()
         t0 = time.time()

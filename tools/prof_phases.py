@@ -39,5 +39,9 @@ for name, C0, up0, C1, Cout, D, H, W in LAYERS:
         epd = "(barrier %.1f, pack+stage %.1f, barrier %.1f, store %.1f)" % tuple(p[i] / tot * 100 for i in (7, 8, 9, 10))
     else:
         epd = "(barrier %.1f, bias+pack+lds-write %.1f, lds-read+store %.1f)" % (p[7] / tot * 100, p[8] / tot * 100, (p[4] - p[7] - p[8]) / tot * 100)
+    if p[11]:     # warp-specialised kernel: the PRODUCER waves' phase (same clock, same number of waves): counted DMA wait | barrier wait | issue
+        print("%-7s producers: dma-wait %5.1f%%  barrier %5.1f%%  issue (filter slab + drain part + halo pieces) %5.1f%%" % (
+            name, p[0] / tot * 100, p[11] / tot * 100, p[2] / tot * 100))
+        sec[0] = sec[2] = 0.0
     print("%-7s cyc/phase %6.0f | dma-wait %5.1f%%  barrier %5.1f%%  dma-issue %5.1f%%  mfma-loop %5.1f%%  epilogue %5.1f%% %s  other %5.1f%%"
           % (name, tot / max(p[6], 1), sec[0], sec[1], sec[2], sec[3], ep, epd, 100 - sum(sec) - ep))
