@@ -188,13 +188,28 @@ def val_dice_leg(batch, steps, spatial=(64, 128, 128), volume=(160, 256, 256), l
                                output_folder=tmp).history
         torch.cuda.synchronize()
         t_train = time.perf_counter() - t1
+    # the step time ON THIS TASK with the trained weights (resident batch, same loop as the headline's timed region): MI355X's power-limited
+    # shader clock depends on the operands' statistics, so the headline's recipe (labels independent of the image - the net ends up
+    # predicting the base rate) and a model that is really learning need not run at the same clock
+    eng = model.engine(batch)
+    xb, yb = LT.device_batch(LT.HELD_OUT + 900_000, batch, spatial)
+    xe, ye = model._to_device_x(xb), model._to_device_y(yb)
+    for _ in range(10):
+        eng.train_step(xe, ye, 0.0)
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    for _ in range(40):
+        eng.train_step(xe, ye, 0.0)              # lr 0: the trained weights stay as they are (and the held-out numbers below are unaffected)
+    torch.cuda.synchronize()
+    task_rate = 40 * batch / (time.perf_counter() - t2)
+    eng.t -= 50                                   # (the Adam step counter: these were not training steps)
     # (predict() of a device batch returns a view of the engine's probability buffer: use it before the next call)
     hard_b = float(np.mean([LT.hard_dice(y.cpu().numpy(), (model.predict(x) > 0.5).cpu().numpy()) for x, y in held]))
     vx, vy = LT.device_patch(LT.HELD_OUT + 500_000, tuple(volume))
     rec = patch_wise_prediction(model, vx.cpu().numpy()[None].astype(np.float64), spatial, overlap_factor=0.5)
     return {"soft": -float(hist["val_loss"][-1]), "hard_cfg5_volume": LT.hard_dice(vy.cpu().numpy(), rec[..., 0] > 0.5),
             "soft_cfg5_volume": LT.soft_dice(vy.cpu().numpy(), rec[..., 0]), "hard_held_out_batches": hard_b,
-            "steps": int(steps), "soft_per_epoch": [-float(v) for v in hist["val_loss"]], "train_dice_per_epoch": [-float(v) for v in hist["loss"]],
+            "patches_per_s_on_this_task": task_rate, "steps": int(steps), "soft_per_epoch": [-float(v) for v in hist["val_loss"]], "train_dice_per_epoch": [-float(v) for v in hist["loss"]],
             "lr": lr, "dtype": "bf16", "held_out_patches": vsteps * batch,
             "task": "tools/learnable_task.py: y = blobs of a smooth latent field (%.0f %% foreground), x = zscore(%.1f * y + N(0,1)); training seeds "
                     "0.., held-out seeds %d.." % (100 * LT.FG, LT.CONTRAST, LT.HELD_OUT),
@@ -204,12 +219,13 @@ def val_dice_leg(batch, steps, spatial=(64, 128, 128), volume=(160, 256, 256), l
 
 def reference_api_leg(model, batch, spatial=(64, 128, 128), steps=40):
     """patches/s of the SAME training step driven through the reference-facing surface (`Model.fit_generator`, what train_model() calls):
-    (a) a reference-style host generator yielding float64 numpy batches (generator.py:397-401; one ready batch re-yielded: isolates the
-    boundary cost), (b) batches that are already in HBM.  `value` of the headline has the batch resident and no Python loop around it."""
-    rs = np.random.RandomState(0)
-    xb = rs.randn(batch, 1, *spatial)
-    yb = (rs.rand(batch, 1, *spatial) > 0.7).astype(np.uint8)
-    xd, yd = torch.from_numpy(xb.astype(np.float32)).cuda(), torch.from_numpy(yb).cuda()
+    (a) a reference-style host generator yielding float64 numpy batches (generator.py:397-401; one ready batch of the learnable task re-yielded:
+    isolates the boundary cost), (b) the same batch already in HBM, (c) the bare engine loop on that batch (= the headline's loop), all three on
+    the same model in the same state."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import learnable_task as LT
+    xd, yd = LT.device_batch(LT.HELD_OUT + 700_000, batch, spatial)
+    xb, yb = xd.cpu().numpy().astype(np.float64), yd.cpu().numpy()
 
     def host_gen():
         while True:
@@ -227,6 +243,16 @@ def reference_api_leg(model, batch, spatial=(64, 128, 128), steps=40):
         model.fit_generator(g, steps_per_epoch=steps, epochs=1, verbose=0)
         torch.cuda.synchronize()
         out[name + "_patches_per_s"] = steps * batch / (time.perf_counter() - t0)
+    eng = model.engine(batch)
+    xe, ye = model._to_device_x(xd), model._to_device_y(yd)
+    for _ in range(5):
+        eng.train_step(xe, ye, model.optimizer.lr)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        eng.train_step(xe, ye, model.optimizer.lr)
+    torch.cuda.synchronize()
+    out["resident_batch_patches_per_s"] = steps * batch / (time.perf_counter() - t0)
     out["steps"] = steps
     return out
 
@@ -238,15 +264,25 @@ def cfg3_leg(steps=10, warmup=3):
     from fmri_hip.engine import UNetEngine, UNetPlan
     B, X, Y, C = 64, 256, 256, 5
     eng = UNetEngine(UNetPlan(C, (X, Y), depth=4, n_base_filters=32, ndim=2), B, dtype=torch.bfloat16)
-    g = torch.Generator().manual_seed(0)
-    x = torch.randn((1, B, X, Y, C), generator=g).cuda().to(torch.bfloat16)
-    y = (torch.rand((B * X * Y,), generator=g) > 0.7).to(torch.uint8).cuda()
-    for _ in range(warmup):
-        eng.train_step(x, y, 1e-4)
+    # live data, as in the headline: a small pool of slice-stack batches of the learnable task, trained on at lr 1e-4
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import learnable_task as LT
+    pool = []
+    for k in range(2):
+        xb, yb = LT.device_batch_2d(5_000 + k * B, B, (X, Y), C)
+        pool.append((xb.to(torch.bfloat16).unsqueeze(0).contiguous(), yb.reshape(-1).contiguous()))
+    t_w = time.perf_counter()
+    i = 0
+    while i < warmup or time.perf_counter() - t_w < 1.0:          # >= 1 s of untimed steps: a settled clock and a learning network
+        eng.train_step(*pool[i % 2], 1e-4)
+        i += 1
+        if i % 5 == 0:
+            torch.cuda.synchronize()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
-        eng.train_step(x, y, 1e-4)
+        s_ = eng.train_step(*pool[i % 2], 1e-4)
+        i += 1
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     fl = 0.0
@@ -255,7 +291,8 @@ def cfg3_leg(steps=10, warmup=3):
         _, H, W = eng.plan.level_dims(c["level"], B)
         fl += 2.0 * 9 * c["cin"] * c["cout"] * B * H * W * (2 if c["name"] == first else 3)
     return {"workload": "configs[3]: 2-D U-Net depth 4 / 32 filters, 64x256x256x5 bf16 per GPU, full training step", "slices_per_s": B / dt,
-            "ms_per_step": dt * 1e3, "steps": steps, "conv_tflops_algorithmic": fl / dt / 1e12, "mfma_frac": fl / dt / 1e12 / PEAK_BF16_TFLOPS}
+            "ms_per_step": dt * 1e3, "steps": steps, "conv_tflops_algorithmic": fl / dt / 1e12, "mfma_frac": fl / dt / 1e12 / PEAK_BF16_TFLOPS,
+            "train_dice_last_step": eng.metrics_from_sums(s_.cpu().numpy())["dice_coefficient"], "data": "learnable task, 2-D form (tools/learnable_task.py)"}
 
 
 def cfg4_leg(model=None, reps=3):
@@ -520,6 +557,12 @@ def main():
     ap.add_argument("--batch", type=int, default=4, help="patches per GPU")
     ap.add_argument("--prewarm-seconds", type=float, default=2.0,
                     help="untimed steps for at least this long before the --warmup steps (clock settling; not part of the timed region)")
+    ap.add_argument("--lr", type=float, default=1e-4, help="learning rate of the timed steps (reference default 1e-4, fetal/config_utils.py:39); 0 keeps the "
+                    "random-init weights as they are - a diagnostic: the power-limited shader clock depends on the operands' statistics")
+    ap.add_argument("--data", choices=("learnable", "survey"), default="learnable",
+                    help="learnable (default): a pool of batches of tools/learnable_task.py, walked round-robin; survey: rounds 1-3's ONE batch with labels "
+                         "independent of the image (the net collapses to all-foreground and the backward kernels multiply ~0 gradients: a faster clock)")
+    ap.add_argument("--pool", type=int, default=8, help="batches in the resident pool (learnable data)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-launch-timing", action="store_true")
     ap.add_argument("--launch-timing-every", type=int, default=None,
@@ -594,10 +637,36 @@ def main():
         dctx.broadcast_params(eng)
     if a.serialize_streams:
         eng._wg_stream = None
-    x, y = synthetic_batch((a.batch, 1) + spatial, seed_x=1234 + rank, seed_y=1235 + rank)
-    xd = torch.from_numpy(x).cuda().to(torch.bfloat16).reshape(a.batch, *spatial, 1).contiguous()
-    yd = torch.from_numpy(y).cuda().reshape(-1).contiguous()
-    lr = 1e-4
+    # Input data (round 4): a pool of batches of the LEARNABLE task (tools/learnable_task.py), resident in HBM, walked round-robin, trained on
+    # at the reference's learning rate - a network that is really learning.  Rounds 1-3 trained the timed steps on ONE batch whose labels were
+    # independent of the image (SURVEY 8d's recipe, 30 % foreground): with the reference's Dice loss that network falls into the
+    # all-foreground solution within ~25 steps (train Dice 0.4615 = 2 fg / (1 + fg)), the sigmoid saturates, the gradients that the
+    # input-gradient and weight-gradient kernels multiply are ~0 - and MI355X's power-limited shader clock rises: the SAME kernels ran 13-15 %
+    # faster (313 against 272 patches/s on one box: profiles/r04_data_dependence.json).  That state says nothing about training; `value` is
+    # now measured on live data.  --data survey restores the old recipe (the `continuity` object of the line reports it as well).
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import learnable_task as LT
+
+    def make_pool(kind, n):
+        pool = []
+        for k in range(n):
+            if kind == "survey":
+                x, y = synthetic_batch((a.batch, 1) + spatial, seed_x=1234 + rank + 97 * k, seed_y=1235 + rank + 97 * k)
+                xt, yt = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+            else:
+                xt, yt = LT.device_batch(1_000 * rank + k * a.batch, a.batch, spatial)
+            pool.append((xt.to(torch.bfloat16).reshape(a.batch, *spatial, 1).contiguous(), yt.reshape(-1).contiguous()))
+        return pool
+
+    pool = make_pool(a.data, 1 if a.data == "survey" else a.pool)
+    nxt = [0]
+
+    def step():
+        xd, yd = pool[nxt[0] % len(pool)]
+        nxt[0] += 1
+        return eng.train_step(xd, yd, lr)
+
+    lr = a.lr
 
     timer = LaunchTimer()
     if not a.no_launch_timing:
@@ -664,7 +733,7 @@ def main():
         t_pw = time.perf_counter()
         while True:
             for _ in range(10):
-                eng.train_step(xd, yd, lr)
+                step()
             torch.cuda.synchronize()
             prewarm_steps += 10
             go_on = torch.tensor([1.0 if time.perf_counter() - t_pw < a.prewarm_seconds else 0.0], device="cuda")
@@ -674,7 +743,7 @@ def main():
             if float(go_on.item()) == 0.0:
                 break
     for _ in range(a.warmup):
-        eng.train_step(xd, yd, lr)
+        step()
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
@@ -691,7 +760,7 @@ def main():
     for i in range(a.steps):
         timer.on = (not a.no_launch_timing) and (i % every == 0)
         sampled += 1 if timer.on else 0
-        sums = eng.train_step(xd, yd, lr)
+        sums = step()
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
@@ -712,12 +781,12 @@ def main():
         # contain the gradient all-reduce).
         keep, eng._wg_stream = eng._wg_stream, None
         for _ in range(2):
-            eng.train_step(xd, yd, lr)
+            step()
         torch.cuda.synchronize()
         timer.rec, timer.detail = {}, {}
         timer.on = True
         for _ in range(a.steps):
-            eng.train_step(xd, yd, lr)
+            step()
         torch.cuda.synchronize()
         timer.on = False
         tot_excl = timer.totals_ms()
@@ -737,7 +806,9 @@ def main():
         "metric": "3D patches/sec (64x128x128, bf16) fwd+bwd", "value": value, "unit": "patches/s", "n_gpus": world,
         "collective_ranks": (dctx.world if dctx is not None else 1),
         "steps": a.steps, "warmup": a.warmup, "prewarm_steps_untimed": prewarm_steps, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "vs_baseline": None, "dtype": "bf16",
+        "data": ("synthetic (learnable task: image and label from one latent field, %d resident batches walked round-robin, lr %g; random-init weights)" % (len(pool), lr))
+        if a.data == "learnable" else "synthetic (SURVEY 8d recipe: one batch, labels independent of the image; lr %g)" % lr,
         "config": {"workload": "configs[1]: depth-4 3D U-Net, 32 base filters, bf16, batch %dx1x64x128x128 per GPU, "
                                "full step = fwd + Dice + bwd + Keras-Adam" % a.batch,
                    "global_batch": a.batch * world, "parallelism": "dp%d" % world},
@@ -805,7 +876,30 @@ def main():
         out["per_layer_total"] = tab["total"]
     if world == 1 and (a.val_dice_steps > 0 or not a.no_secondary):
         # after the timed region, never inside it: the bench engine's buffers go first (each leg builds its own model)
-        del eng, xd, yd
+        if a.data == "learnable" and not a.no_secondary:
+            # continuity with rounds 1-3: the same engine, re-initialised, on the old recipe (one batch, independent labels), >= 1.5 s of
+            # untimed steps (by then it has collapsed), then 20 timed steps
+            eng.init_glorot(42)
+            eng.M.zero_()
+            eng.V.zero_()
+            eng.t = 0
+            xo, yo = make_pool("survey", 1)[0]
+            t_c = time.perf_counter()
+            while time.perf_counter() - t_c < 1.5:
+                for _ in range(10):
+                    eng.train_step(xo, yo, 1e-4)
+                torch.cuda.synchronize()
+            t_c = time.perf_counter()
+            for _ in range(20):
+                so = eng.train_step(xo, yo, 1e-4)
+            torch.cuda.synchronize()
+            dt_c = time.perf_counter() - t_c
+            out["continuity"] = {"recipe": "rounds 1-3: ONE batch, labels independent of the image (SURVEY 8d), trained on at lr 1e-4 - the net sits in the "
+                                           "all-foreground solution of the Dice loss, the backward kernels multiply ~0 gradients, the power-limited clock rises",
+                                 "value": 20 * a.batch / dt_c, "unit": "patches/s", "steps": 20,
+                                 "train_dice_last_step": eng.metrics_from_sums(so.cpu().numpy())["dice_coefficient"]}
+            del xo, yo
+        del eng, pool
         torch.cuda.empty_cache()
         model = None
         if a.val_dice_steps > 0:
@@ -817,7 +911,6 @@ def main():
                 model = fmodel.unet_model_3d(input_shape=(1, 64, 128, 128), depth=4, n_base_filters=32, initial_learning_rate=1e-4,
                                              loss_function=FM.dice_coefficient_loss)
             out["reference_api"] = reference_api_leg(model, a.batch)
-            out["reference_api"]["resident_batch_patches_per_s"] = value
             out["secondary"] = {"cfg4": cfg4_leg(model), "cfg3": cfg3_leg()}
     if world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()

@@ -397,6 +397,8 @@ class UNetEngine:
         level-1 convs wait for the 256 -> 512 image, whose kernel - like every kernel next to a persistent conv launch, which fills all
         CUs - only gets CUs between two conv launches: 74 us of stall behind the first level in the rocprofv3 timeline; un-profiled the
         step does not notice: 13.09-13.15 ms either way.)"""
+        if overlap and os.environ.get("FMRI_EXP_SKIP_REPACK", "0") == "1":      # timing experiment only (stale weight images): what the repack costs the step
+            return
         early = set(c["name"] for c in self.plan.enc[0])
         if overlap and self.dev.type == "cuda" and os.environ.get("FMRI_PACK_OVERLAP", "1") != "0":
             if self._pack_stream is None:

@@ -762,9 +762,13 @@ def gaussian_filter_f32(patch, sigma, truncate=4.0, mode="nearest"):
     _need_cuda(patch)
     assert patch.dtype == torch.float32 and patch.dim() == 3
     X, Y, Z = patch.shape
-    sig = [float(sigma)] * 3
-    if Z == 3:
-        sig[2] = 0.0
+    if np.isscalar(sigma):
+        sig = [float(sigma)] * 3
+        if Z == 3:
+            sig[2] = 0.0
+    else:                                                 # one sigma per axis (0: the axis is left alone)
+        sig = [float(v) for v in sigma]
+        assert len(sig) == 3
     a = patch
     for axis, sd in enumerate(sig):
         if sd <= 1e-15:

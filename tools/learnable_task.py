@@ -60,9 +60,7 @@ def device_patch(seed, spatial, device="cuda", sigma=SIGMA, fg=FG, contrast=CONT
     from fmri_hip import ops
     g = torch.Generator(device=device).manual_seed(int(seed))
     f = torch.randn(spatial, generator=g, device=device, dtype=torch.float32)
-    for_axis = [min(sigma, s / 8.0) for s in spatial]
-    assert len(set(for_axis)) == 1, "device form: one sigma for all axes"
-    f = ops.gaussian_filter_f32(f, for_axis[0])
+    f = ops.gaussian_filter_f32(f, [min(sigma, s / 8.0) for s in spatial])
     k = max(1, int(round((1.0 - fg) * f.numel())))
     thr = torch.kthvalue(f.reshape(-1), k).values
     y = f > thr
@@ -76,6 +74,24 @@ def device_batch(first_seed, n, spatial, device="cuda"):
     import torch
     xs, ys = zip(*(device_patch(first_seed + i, spatial, device) for i in range(n)))
     return torch.stack(xs)[:, None].contiguous(), torch.stack(ys)[:, None].contiguous()
+
+
+def device_batch_2d(first_seed, n, plane, channels, device="cuda", sigma=SIGMA, fg=FG, contrast=CONTRAST):
+    """2-D models (reference fetal_net/model/unet/unet.py: x (N,X,Y,C) slice stacks, y (N,X,Y,1) = the label of the middle slice): every slice of a
+    stack carries its own in-plane blobs and is brighter on them, the label is the middle slice's.  -> x float32 (N,X,Y,C), y uint8 (N,X,Y,1)"""
+    import torch
+    from fmri_hip import ops
+    xs, ys = [], []
+    for i in range(n):
+        g = torch.Generator(device=device).manual_seed(int(first_seed + i))
+        shape = tuple(plane) + (channels,)
+        f = ops.gaussian_filter_f32(torch.randn(shape, generator=g, device=device, dtype=torch.float32), [sigma, sigma, 0.0])
+        k = max(1, int(round((1.0 - fg) * f.numel())))
+        yall = f > torch.kthvalue(f.reshape(-1), k).values
+        x = contrast * yall.to(torch.float32) + torch.randn(shape, generator=g, device=device, dtype=torch.float32)
+        xs.append((x - x.mean()) / x.std(unbiased=False))
+        ys.append(yall[..., channels // 2:channels // 2 + 1].to(torch.uint8))
+    return torch.stack(xs).contiguous(), torch.stack(ys).contiguous()
 
 
 def device_generator(first_seed, n, spatial, steps=None, device="cuda"):
