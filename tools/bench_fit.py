@@ -21,9 +21,10 @@ def main():
     from fetal_net.model import unet_model_3d
     patch, B, steps = (64, 128, 128), 4, 60
     model = unet_model_3d(input_shape=(1,) + patch, depth=4, n_base_filters=32, initial_learning_rate=1e-4, loss_function=dice_coefficient_loss)
-    rs = np.random.RandomState(0)
-    xb = rs.randn(B, 1, *patch)                                     # float64, as the reference's generator yields
-    yb = (rs.rand(B, 1, *patch) > 0.7).astype(np.uint8)
+    # one batch of the learnable task (float64 on the host, as the reference's generator yields): a live network, as in bench.py
+    import learnable_task as LT
+    xd_, yd_ = LT.device_batch(LT.HELD_OUT + 700_000, B, patch)
+    xb, yb = xd_.cpu().numpy().astype(np.float64), yd_.cpu().numpy()
 
     def host_gen():
         while True:

@@ -25,11 +25,17 @@ class _Root:
 
 
 class Vols:
+    """n volumes of the learnable task (tools/learnable_task.py: blobs of a smooth field, brighter in the image): a network trained on
+    patches of them is really learning - with labels independent of the image it collapses and the step runs at another clock
+    (profiles/r04_data_dependence.json)"""
+
     def __init__(self, n, shape, seed=0):
-        rs = np.random.RandomState(seed)
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import learnable_task as LT
+        vols = [LT.host_patch(seed + i, shape) for i in range(n)]
         self.root = _Root()
-        self.root.data = [rs.randn(*shape).astype(np.float32) for _ in range(n)]
-        self.root.truth = [(rs.rand(*shape) > 0.7).astype(np.uint8) for _ in range(n)]
+        self.root.data = [v[0] for v in vols]
+        self.root.truth = [v[1] for v in vols]
         self.root.subject_ids = [b"s"] * n
 
 

@@ -53,6 +53,14 @@ def host_generator(first_seed, n, spatial, steps=None, dtype=np.float64):
         k += 1
 
 
+def _gauss_threshold(f, fg):
+    """the (1 - fg) quantile of a smoothed N(0,1) field from its mean and standard deviation (the field is Gaussian): two reductions
+    instead of a 1M-element selection (torch.kthvalue took 4 ms per patch - 0.85 ms per step of a profiled bench run went to the pool's
+    creation).  The foreground fraction is fg up to the field's sampling error (a few tenths of a percent)."""
+    from statistics import NormalDist
+    return f.mean() + NormalDist().inv_cdf(1.0 - fg) * f.std(unbiased=False)
+
+
 def device_patch(seed, spatial, device="cuda", sigma=SIGMA, fg=FG, contrast=CONTRAST):
     """the same recipe on the device: torch's device RNG, fmri_correlate1d_f32 (mode 'nearest') for the smoothing.  Not bit-identical to
     host_patch (other RNG, other border rule) - the same distribution.  -> x float32 [X,Y,Z], y uint8 [X,Y,Z]"""
@@ -61,9 +69,7 @@ def device_patch(seed, spatial, device="cuda", sigma=SIGMA, fg=FG, contrast=CONT
     g = torch.Generator(device=device).manual_seed(int(seed))
     f = torch.randn(spatial, generator=g, device=device, dtype=torch.float32)
     f = ops.gaussian_filter_f32(f, [min(sigma, s / 8.0) for s in spatial])
-    k = max(1, int(round((1.0 - fg) * f.numel())))
-    thr = torch.kthvalue(f.reshape(-1), k).values
-    y = f > thr
+    y = f > _gauss_threshold(f, fg)
     x = contrast * y.to(torch.float32) + torch.randn(spatial, generator=g, device=device, dtype=torch.float32)
     x = (x - x.mean()) / x.std(unbiased=False)
     return x, y.to(torch.uint8)
@@ -86,8 +92,7 @@ def device_batch_2d(first_seed, n, plane, channels, device="cuda", sigma=SIGMA, 
         g = torch.Generator(device=device).manual_seed(int(first_seed + i))
         shape = tuple(plane) + (channels,)
         f = ops.gaussian_filter_f32(torch.randn(shape, generator=g, device=device, dtype=torch.float32), [sigma, sigma, 0.0])
-        k = max(1, int(round((1.0 - fg) * f.numel())))
-        yall = f > torch.kthvalue(f.reshape(-1), k).values
+        yall = f > _gauss_threshold(f, fg)
         x = contrast * yall.to(torch.float32) + torch.randn(shape, generator=g, device=device, dtype=torch.float32)
         xs.append((x - x.mean()) / x.std(unbiased=False))
         ys.append(yall[..., channels // 2:channels // 2 + 1].to(torch.uint8))
