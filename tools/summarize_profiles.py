@@ -148,6 +148,25 @@ def summary(tag):
     return "\n".join(L) + "\n"
 
 
+BEGIN, END = "<!-- generated: profiles/%s_summary.md -->", "<!-- end generated -->"
+
+
+def design_block(tag):
+    """the text between DESIGN.md's markers for `tag` (None when the markers are absent)"""
+    text = open(os.path.join(ROOT, "DESIGN.md")).read()
+    b = BEGIN % tag
+    if b not in text:
+        return None
+    a = text.index(b) + len(b)
+    return text[a:text.index(END, a)].strip("\n") + "\n"
+
+
+def demote(text):
+    """the summary as a block of DESIGN.md: its headings one level down, without the title line"""
+    lines = text.splitlines()[1:]
+    return "\n".join(("##" + ln) if ln.startswith("## ") else ln for ln in lines).strip("\n") + "\n"
+
+
 if __name__ == "__main__":
     tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
     text = summary(tag)
@@ -157,3 +176,12 @@ if __name__ == "__main__":
         with open(os.path.join(P, "%s_summary.md" % tag), "w") as f:
             f.write(text)
         print("wrote profiles/%s_summary.md (%d lines)" % (tag, text.count("\n")))
+        dpath = os.path.join(ROOT, "DESIGN.md")
+        d = open(dpath).read()
+        b = BEGIN % tag
+        if b in d:
+            a = d.index(b) + len(b)
+            e = d.index(END, a)
+            with open(dpath, "w") as f:
+                f.write(d[:a] + "\n" + demote(text) + d[e:])
+            print("updated the generated block of DESIGN.md")
