@@ -57,9 +57,15 @@ extern "C" void fmri_debug_chk(long long* out) { hipMemcpyFromSymbol(out, HIP_SY
 #endif
 #ifdef FMRI_PROF
 __device__ unsigned long long g_prof[12];
+// per phase index of an item (0..8), producers' issue time and count: [0..8] items that drain a staged tile, [9..17] other items, [18..35] counts
+__device__ unsigned long long g_prof_ph[36];
 extern "C" void fmri_debug_prof(unsigned long long* out, int reset) {
     if (out) hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof), sizeof(g_prof));
     if (reset) { unsigned long long z[12] = {}; hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof(z)); }
+}
+extern "C" void fmri_debug_prof_phases(unsigned long long* out, int reset) {
+    if (out) hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof_ph), sizeof(g_prof_ph));
+    if (reset) { unsigned long long z[36] = {}; hipMemcpyToSymbol(HIP_SYMBOL(g_prof_ph), z, sizeof(z)); }
 }
 #define PROF_T(x) const unsigned long long x = __builtin_amdgcn_s_memtime()
 #define PROF_ADD(i, a, b) prof[i] += (b) - (a)
@@ -98,6 +104,14 @@ __device__ __forceinline__ unsigned pack2bf(float a, float b) {
     typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
     const f32x2 v = {a, b};
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+}
+// per 16-bit half of a dword of two bf16 values: 0xffff where the value is > 0, else 0 - three packed 16-bit integer instructions (a bf16 is
+// positive exactly when its bits, read as int16, are: +0 is 0, negative values and -0 have the sign bit; a NaN counts by its sign).  The
+// float form (shift, compare, select per half) took eight instructions per dword in the drain of every input-gradient launch.
+__device__ __forceinline__ unsigned pos_mask2(unsigned m, unsigned zero2, unsigned one2) {
+    unsigned t;
+    asm("v_pk_max_i16 %0, %1, %2\n\tv_pk_min_u16 %0, %0, %3\n\tv_pk_sub_u16 %0, %2, %0" : "=&v"(t) : "v"(m), "v"(zero2), "v"(one2));
+    return t;
 }
 __device__ __forceinline__ unsigned lds_addr(const void* p) {
     return (unsigned)(size_t)(__attribute__((address_space(3))) const unsigned char*)p;
@@ -172,7 +186,7 @@ struct FwdTail {
 // CUBE: the workgroup tile is 8 x 8 x 8 instead of 4 x 8 x 16 voxels (halo 10^3 = 1000 rows): the shape of the deepest levels of
 // deep models (e.g. 8^3 at level 4 of a 128^3 Isensee net), whose W is not a multiple of 16.  A 32-voxel column tile is then 4 h-rows
 // of 8 voxels; everything else is the same machinery.
-template <int NT, bool PL, int MODE, bool RES, bool CUBE = false>  // NT = 32-wide Cout tiles per workgroup (BN = 32*NT); PL = planar
+template <int NT, bool PL, int MODE, bool RES, bool CUBE = false, bool FH = false>  // NT = 32-wide Cout tiles per workgroup (BN = 32*NT); PL = planar; FH: see k_conv_fwd_ws
 __global__ void __launch_bounds__(fw::NTHREADS)
 k_conv_fwd_mfma(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ bias, const bf16_t* __restrict__ mask,
                 const bf16_t* residual, bf16_t* y, int N, int D, int H, int W, int Cout, int act, float alpha) {
@@ -246,7 +260,7 @@ k_conv_fwd_mfma(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__
         const int ls = ps ^ ((row >> 2) & 3);
         f_voff[k] = (unsigned)(((row / BN) * Cout + (row % BN)) * Krow + ls * 8) * 2u;
     }
-    int h_pack[9];                 // halo piece ph: hd | hh<<4 | hw<<8 | ls<<13 | valid<<15
+    int h_pack[9];                 // halo piece ph: hd | hh<<4 | hw<<8 | ls<<13 | valid<<15 | edge<<16 (faces of the halo box the row lies on, see k_conv_fwd_ws)
 #pragma unroll
     for (int ph = 0; ph < 9; ++ph) {
         const int i = (ph * 8 + wv) * 64 + lane;
@@ -254,7 +268,9 @@ k_conv_fwd_mfma(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__
         const int ls = ps ^ ((hv >> 2) & 3);
         const int hvc = hv < HVOX ? hv : 0;
         const int hw_ = hvc % HW, hq = hvc / HW;
-        h_pack[ph] = (hq / HH) | ((hq % HH) << 4) | (hw_ << 8) | (ls << 13) | ((hv < HVOX ? 1 : 0) << 15);
+        const int hd_ = hq / HH, hh_ = hq % HH;
+        const int edge = (hd_ == 0 ? 1 : 0) | (hd_ == HD - 1 ? 2 : 0) | (hh_ == 0 ? 4 : 0) | (hh_ == HH - 1 ? 8 : 0) | (hw_ == 0 ? 16 : 0) | (hw_ == HW - 1 ? 32 : 0);
+        h_pack[ph] = hd_ | (hh_ << 4) | (hw_ << 8) | (ls << 13) | ((hv < HVOX ? 1 : 0) << 15) | (edge << 16);
     }
     // filter slab of phase `pl` (= (kd,kh) row PH0 + pl; up modes: (parity, kd', kh')) for item `it` into filter ring slot `fb`:
     // scalar base + constant lane offset
@@ -279,7 +295,7 @@ k_conv_fwd_mfma(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__
             const int p = it.ch / kpc, coff = (it.ch % kpc) << 5;
             const int gd = it.d0 - 1 + (pk & 15), gh = it.h0 - 1 + ((pk >> 4) & 15), gw = it.w0 - 1 + ((pk >> 8) & 31);
             const int ls = (pk >> 13) & 3;
-            const bool ok = (pk >> 15) && (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W;
+            const bool ok = ((pk >> 15) & 1) && (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W;
             // planar: p = (ph, pw), the slice axis is not doubled
             const int sd = PL ? min(max(gd, 0), D - 1) : 2 * min(max(gd, 0), D - 1) + (p >> 2);
             const int sh = 2 * min(max(gh, 0), H - 1) + ((p >> 1) & 1), sw = 2 * min(max(gw, 0), W - 1) + (p & 1);
@@ -296,7 +312,7 @@ k_conv_fwd_mfma(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__
         const int sD = D >> shd, sH = H >> sh, sW = W >> sh;
         const int gd = it.d0 - 1 + (pk & 15), gh = it.h0 - 1 + ((pk >> 4) & 15), gw = it.w0 - 1 + ((pk >> 8) & 31);
         const int ls = (pk >> 13) & 3;
-        const bool ok = (pk >> 15) && (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W;
+        const bool ok = ((pk >> 15) & 1) && (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W;
         const int gdc = min(max(gd, 0), D - 1) >> shd, ghc = min(max(gh, 0), H - 1) >> sh, gwc = min(max(gw, 0), W - 1) >> sh;
         const int off = ((gdc * sH + ghc) * sW + gwc) * sC + coff + ls * 8;      // inside one sample: < 2^31 elements
         const bf16_t* real = sp + (int64_t)it.n * sD * sH * sW * sC + off;
@@ -326,6 +342,29 @@ k_conv_fwd_mfma(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__
         // DMA instructions that lie entirely inside them (16 rows each) are not issued
         if (PL && (ph * 8 + wv < 11 || ph * 8 + wv >= 57)) return;
         if (ph * 8 + wv < H_INSTR) dma16(hp[ph], __builtin_amdgcn_readfirstlane(lds0 + hb * HALO_BYTES + (ph * 8 + wv) * 1024));
+    };
+    // FH (round 4): fast halo addressing as in k_conv_fwd_ws - here EVERY wave issues halo pieces, so the ~50 vector instructions of a freshly
+    // worked-out address sat in front of the MFMAs of all eight waves (the 2-D layers of configs[3] are one- and two-chunk layers at 256 x 256)
+    constexpr bool FASTH_CT = FH && MODE == 0 && !CUBE;
+    unsigned hoff[FASTH_CT ? 9 : 1];
+    auto fast_base = [&](const FwdItem& it, unsigned& tmask) -> const char* {
+        tmask = __builtin_amdgcn_readfirstlane((it.d0 == 0 ? 1u : 0u) | (it.d0 + TD == D ? 2u : 0u) | (it.h0 == 0 ? 4u : 0u) | (it.h0 + TH == H ? 8u : 0u) |
+                                               (it.w0 == 0 ? 16u : 0u) | (it.w0 + TW == W ? 32u : 0u));
+        const unsigned long long a = reinterpret_cast<unsigned long long>(s.p0 + ((((int64_t)it.n * D + it.d0 - 1) * H + it.h0 - 1) * W + it.w0 - 1) * s.C0 + (it.ch << 5));
+        const unsigned alo = __builtin_amdgcn_readfirstlane((unsigned)a), ahi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+        return reinterpret_cast<const char*>(((unsigned long long)ahi << 32) | alo);
+    };
+    auto issue_halo_fast = [&](int ph, int hb, const char* sb, unsigned tmask) {
+        const int instr = ph * 8 + wv;
+        if (PL && (instr < 11 || instr >= 57)) return;
+        if (instr >= H_INSTR) return;
+        const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + hb * HALO_BYTES + instr * 1024);
+        if (tmask == 0) dma16_s(sb, hoff[ph], dst);
+        else {
+            const int pk = h_pack[ph];
+            const bool bad = !((pk >> 15) & 1) || (((unsigned)pk >> 16) & tmask) != 0;
+            dma16(bad ? (const void*)g_zero_page : (const void*)(sb + hoff[ph]), dst);
+        }
     };
 
     f32x16 acc[2][NT];
@@ -384,10 +423,21 @@ k_conv_fwd_mfma(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__
         init_acc(bv0);
     }
     // prologue: the whole halo of the first item and its first filter slab
+    if constexpr (FASTH_CT) {
+        unsigned tm0;
+        const char* const sb0 = fast_base(cur, tm0);
 #pragma unroll
-    for (int ph = 0; ph < 9; ++ph) {
-        hp[ph] = halo_src(cur, h_pack[ph]);
-        issue_halo(ph, 0);
+        for (int ph = 0; ph < 9; ++ph) {
+            const int pk = h_pack[ph];
+            hoff[ph] = (unsigned)((((pk & 15) * H + ((pk >> 4) & 15)) * W + ((pk >> 8) & 31)) * s.C0 + ((pk >> 13) & 3) * 8) * 2u;
+            issue_halo_fast(ph, 0, sb0, tm0);
+        }
+    } else {
+#pragma unroll
+        for (int ph = 0; ph < 9; ++ph) {
+            hp[ph] = halo_src(cur, h_pack[ph]);
+            issue_halo(ph, 0);
+        }
     }
     issue_filter(cur, 0, 0);
     int g = 0, hb = 0;
@@ -408,6 +458,11 @@ k_conv_fwd_mfma(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__
         }
         // new tile, first chunk of the second source, or (up-backward) first chunk of the next parity class
         const bool fresh = MODE == 2 ? (nxt.ch % kpc == 0) : (nxt.ch == 0 || (nxt.ch << 5) == s.C0);
+        unsigned ntm = 0;
+        const char* nsb = nullptr;
+        if constexpr (FASTH_CT) {
+            if (has_next) nsb = fast_base(nxt, ntm);
+        }
         const unsigned char* const lh = lds + hb * HALO_BYTES;
         // keep the 54 per-(phase,tap) fragment addresses out of long-lived registers: recomputing them costs a few VALU
         // instructions per MFMA, which issue in the MFMA's shadow, whereas hoisting them spills
@@ -431,9 +486,12 @@ k_conv_fwd_mfma(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__
 #pragma unroll
                     for (int q = 0; q < 5; ++q) {
                         if (q < HPN) {
-                            if (fresh) hp[HP0 + q] = halo_src(nxt, h_pack[HP0 + q]);
-                            else hp[HP0 + q] += 32;
-                            issue_halo(HP0 + q, hb ^ 1);
+                            if constexpr (FASTH_CT) issue_halo_fast(HP0 + q, hb ^ 1, nsb, ntm);
+                            else {
+                                if (fresh) hp[HP0 + q] = halo_src(nxt, h_pack[HP0 + q]);
+                                else hp[HP0 + q] += 32;
+                                issue_halo(HP0 + q, hb ^ 1);
+                            }
                         }
                     }
                 }
@@ -644,7 +702,7 @@ k_conv_fwd_mfma(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__
 // producers' registers apart: the 16 prefetched mask lines (64 registers) and the 9 logit weights are only allocated where they are used -
 // with everything in one kernel the producers' path spilled 18 registers and the pooled-copy launch (enc0b forward, bound by its producers)
 // ran 5 % slower for registers only the other cases need.
-template <int NT, bool PL, int MODE, bool RES, bool ASYNC = false, int EPI = -1>
+template <int NT, bool PL, int MODE, bool RES, bool ASYNC = false, int EPI = -1, bool FH = false>   // FH: fast halo addressing (producers, below)
 __global__ void __launch_bounds__(fw::NTHREADS)
 k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ bias, const bf16_t* __restrict__ mask,
               const bf16_t* residual, bf16_t* y, int N, int D, int H, int W, int Cout, int act, float alpha, FwdTail tail) {
@@ -800,7 +858,7 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
         const unsigned off = (unsigned)(lane_w(rr) * Cout + (lane % CPV_) * 8) * 2u;
         return reinterpret_cast<const char*>(base + org) + off;
     };
-    constexpr bool FASTD = ASY && EPI >= 4;
+    constexpr bool FASTD = ASY && EPI >= 4;         // (round 4: tried for EPI 0-3 as well - nothing gained, enc0b's input gradient 3 % slower)
     // vector-memory instructions one wave issues in store_share<NW> (the producers' counted waits step over exactly these): one store per
     // iteration, one more per iteration for the logits, the pooled pieces
     // (part `part` of `nparts`: the store instructions [part, part + 1) * NIT / nparts; the pooled pieces go with the last part)
@@ -903,11 +961,10 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
                 else m4 = *reinterpret_cast<const uint4*>(gp(mask, kk, v, q));
                 const unsigned mm[4] = {m4.x, m4.y, m4.z, m4.w};
                 unsigned* const oo = reinterpret_cast<unsigned*>(&o4);
+                unsigned z2 = 0u, o2 = 0x00010001u;
+                asm volatile("" : "+v"(z2), "+v"(o2));          // two registers for the whole drain, not an immediate per instruction
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    if (!(__uint_as_float(mm[i] << 16) > 0.f)) oo[i] &= 0xffff0000u;
-                    if (!(__uint_as_float(mm[i] & 0xffff0000u) > 0.f)) oo[i] &= 0x0000ffffu;
-                }
+                for (int i = 0; i < 4; ++i) oo[i] &= pos_mask2(mm[i], z2, o2);
             }
             if constexpr (HAS_RESID) {
                 uint4 r4;
@@ -1032,13 +1089,17 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
             const int ls = ps ^ ((row >> 2) & 3);
             f_voff[k] = (unsigned)(((row / BN) * Cout + (row % BN)) * Krow + ls * 8) * 2u;
         }
-        auto make_pack = [&](int ph, int ln) {      // halo piece ph: hd | hh<<4 | hw<<8 | ls<<13 | valid<<15
+        // halo piece ph: hd | hh<<4 | hw<<8 | ls<<13 | valid<<15 | edge<<16, edge = which faces of the halo box the row lies on
+        // (bit 0 hd == 0, 1 hd == HD-1, 2 hh == 0, 3 hh == HH-1, 4 hw == 0, 5 hw == HW-1): the only rows a border tile can have outside the volume
+        auto make_pack = [&](int ph, int ln) {
             const int i = (H_I0 + ph * DW + dwv) * 64 + ln;
             const int hv = i >> 2, ps = i & 3;
             const int ls = ps ^ ((hv >> 2) & 3);
             const int hvc = hv < HVOX ? hv : 0;
             const int hw_ = hvc % HW, hq = hvc / HW;
-            return (hq / HH) | ((hq % HH) << 4) | (hw_ << 8) | (ls << 13) | ((hv < HVOX ? 1 : 0) << 15);
+            const int hd_ = hq / HH, hh_ = hq % HH;
+            const int edge = (hd_ == 0 ? 1 : 0) | (hd_ == HD - 1 ? 2 : 0) | (hh_ == 0 ? 4 : 0) | (hh_ == HH - 1 ? 8 : 0) | (hw_ == 0 ? 16 : 0) | (hw_ == HW - 1 ? 32 : 0);
+            return hd_ | (hh_ << 4) | (hw_ << 8) | (ls << 13) | ((hv < HVOX ? 1 : 0) << 15) | (edge << 16);
         };
         // (EPI 5 / 6: no table either - a piece's descriptor is rebuilt from the lane index when the piece is issued, see KEEP_HP below)
         constexpr bool KEEP_PACK = EPI < 5;
@@ -1070,7 +1131,8 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
         // source address of every halo piece, kept across the chunks of a tile (+ 32 channels per chunk) - except in the instantiations
         // whose drain needs the registers (EPI 5 / 6: prefetched lines + partial sums): those rebuild a piece's address when they issue it
         constexpr bool KEEP_HP = EPI < 5;
-        const bf16_t* hp[KEEP_HP ? NPIECE : 1];
+        const bf16_t* hp[(KEEP_HP && !(FH && !PL && EPI < 5)) ? NPIECE : 1];
+        unsigned hoff[(FH && !PL && EPI < 5) ? NPIECE : 1];      // FH: the per-lane byte offset of each piece inside the halo box (constant for the whole kernel)
         auto halo_src = [&](const FwdItem& it, int pk) -> const bf16_t* {
             int od = 0, oh = 0, ow = 0;                            // TIGHT: the box starts at g - 1 + (parity of the taps) per axis
             if constexpr (TIGHT) {
@@ -1079,7 +1141,7 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
             }
             const int gd = it.d0 - 1 + od + (pk & 15), gh = it.h0 - 1 + oh + ((pk >> 4) & 15), gw = it.w0 - 1 + ow + ((pk >> 8) & 31);
             const int ls = (pk >> 13) & 3;
-            const bool ok = (pk >> 15) && (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W;
+            const bool ok = ((pk >> 15) & 1) && (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W;
             if constexpr (MODE == 2) {
                 const int p = it.ch / kpc, coff = (it.ch % kpc) << 5;
                 const int sd = PL ? min(max(gd, 0), D - 1) : 2 * min(max(gd, 0), D - 1) + (p >> 2);
@@ -1109,11 +1171,78 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
             const bool dead = instr >= H_I1;
             dma16(dead ? (const void*)g_zero_page : (const void*)src, __builtin_amdgcn_readfirstlane(lds0 + slot * HALO_STRIDE + instr * 1024));
         };
+        // FAST halo addressing (round 4; plain single-source 3-D launches = every MODE 0 launch of the benchmarked step).  The producers'
+        // per-phase instrumentation (tools/prof_phases.py) showed a piece whose address is worked out afresh (halo_src: clamps, three bounds
+        // checks, 64-bit multiplies - ~50 VALU instructions) costing its wave ~600 cycles against ~150 for one that only advances its pointer:
+        // on a one-chunk layer EVERY piece is fresh (17 per wave and tile) and the producers, not the MFMA waves, set the phase time
+        // (enc0b: 3,300-cycle halo phases against 1,900 cycles of MFMA work).  Here a piece's address is
+        //     [wave-uniform base of the tile's halo corner (n, d0-1, h0-1, w0-1), chunk included]  +  [per-lane constant of the piece]
+        // The constant ((hd*H + hh)*W + hw)*C0 + 8*ls never changes during the kernel: it is worked out once and kept in hp[] (as a byte
+        // offset).  Tiles and the volume are aligned, so a row can only be outside the volume if it lies on a face of the halo box (edge
+        // bits of h_pack) on a side where the tile touches the volume's border (6 wave-uniform bits): interior tiles issue
+        // `global_load_lds` with a scalar base + 32-bit lane offset and NO vector address arithmetic, border tiles select the zero page per lane.
+        // The parity modes (TIGHT box; MODE 2 gathers voxel 2g + p of dy) have the same structure: the parity moves the box's origin (od, oh, ow) -
+        // and with it which faces can leave the volume - and, MODE 2, the scalar base; the lane constant uses doubled strides there.
+        constexpr bool FASTH_CT = FH && !PL && KEEP_HP && KEEP_PACK;
+        // ... for launches whose pieces are mostly FRESH: with many chunks per tile (or, MODE 2, per parity class) the old scheme's "advance
+        // every lane's pointer by 64 B" (two vector instructions per piece) beats one base computation per item + a per-lane border select per
+        // piece (measured: dec2a / dec1a parity launches 3-7 % slower with the fast form, enc0b 10-15 % and dec0a's input gradient 7 % faster).
+        // Its OWN instantiation (template parameter FH, chosen by the launcher for single-source launches with at most two chunks per fresh
+        // address): compiled into one kernel behind a run-time switch, the second path cost the launches that do not take it 5-8 %
+        // (profiles/r04_fast_halo_ab.log).
+        constexpr bool fasth = FASTH_CT;
+        auto fast_off = [&](int pk) -> unsigned {
+            const int hd_ = pk & 15, hh_ = (pk >> 4) & 15, hw_ = (pk >> 8) & 31, ls = (pk >> 13) & 3;
+            if constexpr (MODE == 2) return (unsigned)((((2 * hd_) * (2 * H) + 2 * hh_) * (2 * W) + 2 * hw_) * s.C0 + ls * 8) * 2u;
+            else return (unsigned)(((hd_ * H + hh_) * W + hw_) * s.C0 + ls * 8) * 2u;
+        };
+        auto fast_base = [&](const FwdItem& it, unsigned& tmask) -> const char* {
+            int od = 0, oh = 0, ow = 0;
+            bool lo_d = it.d0 == 0, hi_d = it.d0 + TD == D, lo_h = it.h0 == 0, hi_h = it.h0 + TH == H, lo_w = it.w0 == 0, hi_w = it.w0 + TW == W;
+            if constexpr (TIGHT) {
+                const int tp = MODE == 1 ? it.par : (NPAR - 1) - it.ch / kpc;
+                od = tp >> 2; oh = (tp >> 1) & 1; ow = tp & 1;
+                // box rows g - 1 + o .. g + T - 1 + o per axis: row 0 is outside only for o = 0 on the low border, row T only for o = 1 on the high one
+                lo_d = lo_d && od == 0; hi_d = hi_d && od == 1;
+                lo_h = lo_h && oh == 0; hi_h = hi_h && oh == 1;
+                lo_w = lo_w && ow == 0; hi_w = hi_w && ow == 1;
+            }
+            // (the item's fields come out of integer divisions by run-time values, i.e. out of the vector ALU: wave-uniform, but in vector
+            // registers - the scalar base and the border mask are moved to scalar registers explicitly)
+            tmask = __builtin_amdgcn_readfirstlane((lo_d ? 1u : 0u) | (hi_d ? 2u : 0u) | (lo_h ? 4u : 0u) | (hi_h ? 8u : 0u) | (lo_w ? 16u : 0u) | (hi_w ? 32u : 0u));
+            const int bd = it.d0 - 1 + od, bh = it.h0 - 1 + oh, bw = it.w0 - 1 + ow;
+            int64_t eoff;
+            if constexpr (MODE == 2) {
+                const int p = it.ch / kpc, coff = (it.ch % kpc) << 5;
+                eoff = ((((int64_t)it.n * 2 * D + 2 * bd + (p >> 2)) * 2 * H + 2 * bh + ((p >> 1) & 1)) * 2 * W + 2 * bw + (p & 1)) * s.C0 + coff;
+            } else {
+                eoff = ((((int64_t)it.n * D + bd) * H + bh) * W + bw) * s.C0 + (it.ch << 5);
+            }
+            const unsigned long long a = reinterpret_cast<unsigned long long>(s.p0 + eoff);
+            const unsigned alo = __builtin_amdgcn_readfirstlane((unsigned)a), ahi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+            return reinterpret_cast<const char*>(((unsigned long long)ahi << 32) | alo);
+        };
+        auto issue_halo_fast = [&](int ph, int slot, const char* sb, unsigned tmask) {
+            const int instr = H_I0 + ph * DW + dwv;
+            const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + slot * HALO_STRIDE + instr * 1024);
+            const unsigned off = hoff[ph];
+            if (tmask == 0 && instr < H_I1) {
+                dma16_s(sb, off, dst);
+            } else {
+                const int pk = h_pack[ph];
+                const bool bad = instr >= H_I1 || !((pk >> 15) & 1) || (((unsigned)pk >> 16) & tmask) != 0;
+                dma16(bad ? (const void*)g_zero_page : (const void*)(sb + off), dst);
+            }
+        };
         // Halo pieces of the NEXT chunk issued in phase pl: spread over the first NPH-1 phases (all of them when a chunk has one phase
         // only... it has at least two), so that the last phase's wait - everything landed - finds them a phase old.
         // (ASY: the first item of a tile issues none in phase 0 - the slot they go to is the staged tile the producers drain in that phase)
         auto pieces_from = [](int pl, bool drain) {
             if (drain) return pl <= DP ? 0 : (pl >= NPH - 1 ? NPIECE : (pl - DP) * NPIECE / (NPH - 1 - DP > 0 ? NPH - 1 - DP : 1));
+            // two-phase chunks (the tight parity modes; round 4): a third of the pieces in the LAST phase as well - all twelve in phase 0 made that
+            // phase producer-bound (3,300 cycles of issue against ~2,500 of MFMA work) and left phase 1 at 600; the pieces of the last phase
+            // still land before the next chunk's full wait (dec0a / dec1a / dec2a forward and input gradient -1 ... -3.5 %, same-box A/B)
+            if (NPH == 2) return pl >= NPH ? NPIECE : (pl * 2 * NPIECE) / 3;
             return pl >= NPH - 1 ? NPIECE : pl * NPIECE / (NPH - 1);
         };
         auto wait_newer = [](int n) {      // wait until at most n of this wave's vector-memory instructions are in flight (wave-uniform n)
@@ -1145,16 +1274,27 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
         bool pending = false;
 #ifdef FMRI_PROF
         unsigned long long pprof[12] = {};       // producers: [0] counted DMA wait, [11] barrier wait, [2] issue (filter slab, drain part, halo pieces)
+        unsigned long long pph[36] = {};
 #endif
         constexpr int DPN = DP > 0 ? DP : 1;
         int drain_vmops[DPN];
 #pragma unroll
         for (int i = 0; i < DPN; ++i) drain_vmops[i] = ASY ? store_share_vmops(DW, i, DPN) + (LINES_PIPE && i + 1 < DPN ? LP : 0) : 0;
+        if constexpr (FASTH_CT) {
+            unsigned tm0;
+            const char* const sb0 = fast_base(cur, tm0);
 #pragma unroll
-        for (int ph = 0; ph < NPIECE; ++ph) {
-            const bf16_t* const src = halo_src(cur, pack_of(ph));
-            if constexpr (KEEP_HP) hp[ph] = src;
-            issue_halo(ph, 0, src);
+            for (int ph = 0; ph < NPIECE; ++ph) {
+                hoff[ph] = fast_off(h_pack[ph]);
+                issue_halo_fast(ph, 0, sb0, tm0);
+            }
+        } else {
+#pragma unroll
+            for (int ph = 0; ph < NPIECE; ++ph) {
+                const bf16_t* const src = halo_src(cur, pack_of(ph));
+                if constexpr (KEEP_HP) hp[ph] = src;
+                issue_halo(ph, 0, src);
+            }
         }
         issue_filter(cur, 0, 0);
         while (true) {
@@ -1168,6 +1308,11 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
                 if (has_next) nxt = decode(npair, 0);
             }
             const bool fresh = MODE == 2 ? (nxt.ch % kpc == 0) : (nxt.ch == 0 || (nxt.ch << 5) == s.C0);
+            unsigned ntm = 0;
+            const char* nsb = nullptr;
+            if constexpr (FASTH_CT) {
+                if (has_next) nsb = fast_base(nxt, ntm);
+            }
             // keep the packed piece descriptors packed: hipcc otherwise hoists the three bit-field extractions of every piece out of the loop
             // (51 more live registers) and spills them
 #pragma unroll
@@ -1205,7 +1350,10 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
                             }
                         }
                     }
-                    else wait_newer(has_next ? pieces_from(pl, DRN) - pieces_from(pl - 1, DRN) : 0);
+                    else {
+                        int nfl = has_next ? pieces_from(pl, DRN) - pieces_from(pl - 1, DRN) : 0;
+                        wait_newer(nfl);
+                    }
                     PROF_T(pw1);
                     __builtin_amdgcn_s_barrier();                          // everybody's has landed; the previous phase is fully read
                     PROF_T(pw2);
@@ -1224,7 +1372,8 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
 #pragma unroll
                         for (int q = 0; q < NPIECE; ++q) {
                             if (q < HPN) {
-                                if constexpr (KEEP_HP) {
+                                if constexpr (FASTH_CT) issue_halo_fast(HP0 + q, hb ^ 1, nsb, ntm);
+                                else if constexpr (KEEP_HP) {
                                     if (fresh) hp[HP0 + q] = halo_src(nxt, h_pack[HP0 + q]);
                                     else hp[HP0 + q] += 32;
                                     issue_halo(HP0 + q, hb ^ 1, hp[HP0 + q]);
@@ -1248,7 +1397,8 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
                         }
                     }
 #ifdef FMRI_PROF
-                    { PROF_T(pw3); pprof[0] += pw1 - pw0; pprof[11] += pw2 - pw1; pprof[2] += pw3 - pw2; }
+                    { PROF_T(pw3); pprof[0] += pw1 - pw0; pprof[11] += pw2 - pw1; pprof[2] += pw3 - pw2;
+                      if (pl < 9) { pph[(DRN ? 0 : 9) + pl] += pw3 - pw2; pph[18 + (DRN ? 0 : 9) + pl] += 1; } }
 #endif
                     ++g;
                 });
@@ -1280,7 +1430,10 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
         }
         nsum_flush();
 #ifdef FMRI_PROF
-        if (lane == 0) { atomicAdd(&g_prof[0], pprof[0]); atomicAdd(&g_prof[11], pprof[11]); atomicAdd(&g_prof[2], pprof[2]); }
+        if (lane == 0) {
+            atomicAdd(&g_prof[0], pprof[0]); atomicAdd(&g_prof[11], pprof[11]); atomicAdd(&g_prof[2], pprof[2]);
+            for (int i = 0; i < 36; ++i) if (pph[i]) atomicAdd(&g_prof_ph[i], pph[i]);
+        }
 #endif
         return;
     }
@@ -2364,6 +2517,14 @@ static int fwd_use_ws() {               // FMRI_FWD_WS=0: the symmetric kernel (
     }
     return use_ws;
 }
+static int fwd_fast_halo() {            // FMRI_FAST_HALO=0: every halo piece's address worked out per lane as in rounds 1-3 (A/B)
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("FMRI_FAST_HALO");
+        v = e ? atoi(e) : 1;
+    }
+    return v;
+}
 static int fwd_async() {                // FMRI_FWD_ASYNC=0: the tile's stores by all eight waves behind a barrier (the round-2 epilogue)
     static int v = -1;
     if (v < 0) {
@@ -2386,24 +2547,32 @@ static int conv3d_fwd_mfma_launch(int mode, const void* src0, int C0, int up0, i
     const int ntile = cube ? N * (D / 8) * (H / 8) * (W / 8) : N * (D / fw::TD) * (H / fw::TH) * (W / fw::TW);
     const int ncu = fwd_cu_count();
     const int use_ws = fwd_use_ws();
+    // fast halo addressing (k_conv_fwd_ws<..., FH = true>): single plain source, at most two 32-channel chunks per freshly addressed halo
+    const bool fh_any = fwd_fast_halo() && !cube && C1 == 0 && !up0 && (mode == 2 ? C0 / 32 : (C0 + C1) / 32) <= 2;
+    const bool fh = fh_any && !planar;                 // (the warp-specialised kernel's form covers the 3-D launches)
+#define FMRI_WS(NT_, PL_, MODE_, RES_, A_, EPI_, GRID_)                                                                    \
+    do {                                                                                                                  \
+        if (fh && !(PL_))                                                                                                 \
+            k_conv_fwd_ws<NT_, PL_, MODE_, RES_, A_, EPI_, !(PL_)><<<GRID_, fw::NTHREADS, 0, st>>>(                       \
+                s, (const bf16_t*)w, bias, (const bf16_t*)mask, (const bf16_t*)residual, (bf16_t*)y, N, D, H, W, Cout, act, alpha, tail); \
+        else                                                                                                              \
+            k_conv_fwd_ws<NT_, PL_, MODE_, RES_, A_, EPI_, false><<<GRID_, fw::NTHREADS, 0, st>>>(                        \
+                s, (const bf16_t*)w, bias, (const bf16_t*)mask, (const bf16_t*)residual, (bf16_t*)y, N, D, H, W, Cout, act, alpha, tail); \
+    } while (0)
 #define FMRI_LAUNCH_FWD(NT_, PL_, MODE_, RES_)                                                                             \
     do {                                                                                                                  \
         const int np = ntile * (Cout / (32 * NT_)) * (MODE_ == 1 ? (PL_ ? 4 : 8) : 1);                                    \
         constexpr bool A_ = !(PL_) && !(RES_) && (MODE_) == 0;   /* asynchronous epilogue: plain 3-D launches */         \
         const int epi_ = mask ? ((tail.pool || tail.logits) ? -1 : 1) : (tail.logits ? (tail.pool ? -1 : 2) : 0);                  \
         if (use_ws && A_ && fwd_async() && np > ncu && epi_ >= 0) {   /* a single pair per workgroup has nothing to hide the stores under */ \
-            if (epi_ == 0)                                                                                                \
-                k_conv_fwd_ws<NT_, PL_, MODE_, RES_, A_, A_ ? 0 : -1><<<np < ncu ? np : ncu, fw::NTHREADS, 0, st>>>(               \
-                    s, (const bf16_t*)w, bias, (const bf16_t*)mask, (const bf16_t*)residual, (bf16_t*)y, N, D, H, W, Cout, act, alpha, tail); \
-            else if (epi_ == 1)                                                                                           \
-                k_conv_fwd_ws<NT_, PL_, MODE_, RES_, A_, A_ ? 1 : -1><<<np < ncu ? np : ncu, fw::NTHREADS, 0, st>>>(               \
-                    s, (const bf16_t*)w, bias, (const bf16_t*)mask, (const bf16_t*)residual, (bf16_t*)y, N, D, H, W, Cout, act, alpha, tail); \
-            else                                                                                                          \
-                k_conv_fwd_ws<NT_, PL_, MODE_, RES_, A_, A_ ? 2 : -1><<<np < ncu ? np : ncu, fw::NTHREADS, 0, st>>>(               \
-                    s, (const bf16_t*)w, bias, (const bf16_t*)mask, (const bf16_t*)residual, (bf16_t*)y, N, D, H, W, Cout, act, alpha, tail); \
+            if (epi_ == 0) FMRI_WS(NT_, PL_, MODE_, RES_, A_, (A_ ? 0 : -1), (np < ncu ? np : ncu));                              \
+            else if (epi_ == 1) FMRI_WS(NT_, PL_, MODE_, RES_, A_, (A_ ? 1 : -1), (np < ncu ? np : ncu));                         \
+            else FMRI_WS(NT_, PL_, MODE_, RES_, A_, (A_ ? 2 : -1), (np < ncu ? np : ncu));                                        \
         } else if (use_ws && (!(PL_) || use_ws > 1))   /* planar: the producers are the bottleneck - symmetric kernel */ \
-            k_conv_fwd_ws<NT_, PL_, MODE_, RES_><<<np < ncu ? np : ncu, fw::NTHREADS, 0, st>>>(                           \
-                s, (const bf16_t*)w, bias, (const bf16_t*)mask, (const bf16_t*)residual, (bf16_t*)y, N, D, H, W, Cout, act, alpha, tail); \
+            FMRI_WS(NT_, PL_, MODE_, RES_, false, -1, (np < ncu ? np : ncu));                                             \
+        else if (fh_any && (MODE_) == 0)                                                                                  \
+            k_conv_fwd_mfma<NT_, PL_, MODE_, RES_, false, (MODE_) == 0><<<np < ncu ? np : ncu, fw::NTHREADS, 0, st>>>(    \
+                s, (const bf16_t*)w, bias, (const bf16_t*)mask, (const bf16_t*)residual, (bf16_t*)y, N, D, H, W, Cout, act, alpha); \
         else                                                                                                              \
             k_conv_fwd_mfma<NT_, PL_, MODE_, RES_><<<np < ncu ? np : ncu, fw::NTHREADS, 0, st>>>(                         \
                 s, (const bf16_t*)w, bias, (const bf16_t*)mask, (const bf16_t*)residual, (bf16_t*)y, N, D, H, W, Cout, act, alpha); \
@@ -2455,12 +2624,8 @@ static int conv3d_fwd_mfma_launch(int mode, const void* src0, int C0, int up0, i
         }
         const int np_ = ntile * (Cout / (wide ? 64 : 32));
         if (res_async && use_ws && fwd_async() && np_ > ncu && !mask && !tail.pool && !tail.logits) {
-            if (wide)
-                k_conv_fwd_ws<2, false, 0, false, true, 3><<<ncu, fw::NTHREADS, 0, st>>>(s, (const bf16_t*)w, bias, nullptr, (const bf16_t*)residual,
-                                                                                          (bf16_t*)y, N, D, H, W, Cout, act, alpha, tail);
-            else
-                k_conv_fwd_ws<1, false, 0, false, true, 3><<<ncu, fw::NTHREADS, 0, st>>>(s, (const bf16_t*)w, bias, nullptr, (const bf16_t*)residual,
-                                                                                          (bf16_t*)y, N, D, H, W, Cout, act, alpha, tail);
+            if (wide) FMRI_WS(2, false, 0, false, true, 3, ncu);
+            else FMRI_WS(1, false, 0, false, true, 3, ncu);
         } else if (wide) FMRI_LAUNCH_FWD(2, false, 0, true); else FMRI_LAUNCH_FWD(1, false, 0, true);
     } else if (wide) {
         if (planar) FMRI_LAUNCH_FWD(2, true, 0, false); else FMRI_LAUNCH_FWD(2, false, 0, false);
@@ -2468,6 +2633,7 @@ static int conv3d_fwd_mfma_launch(int mode, const void* src0, int C0, int up0, i
         if (planar) FMRI_LAUNCH_FWD(1, true, 0, false); else FMRI_LAUNCH_FWD(1, false, 0, false);
     }
 #undef FMRI_LAUNCH_FWD
+#undef FMRI_WS
     FMRI_LAUNCH_CHECK();
     return FMRI_OK;
 }

@@ -22,16 +22,20 @@ def test_recorded_gpu_suite_run_matches_the_kernel_sources():
 
 
 def test_recorded_run_used_the_library_this_tree_builds():
-    """The build is bit-reproducible (csrc/Makefile: fixed -cuid per file), `make` records the library's sha256 in the TRACKED file
-    lib/libfmri_hip.so.sha256, and tools/gputest_stamp.sh stamps the sha of the .so the suite actually loaded: all three must agree
-    (the shipped .so had been rebuilt after the stamped run and nothing would have noticed a difference)."""
+    """`make` records the hash of the library's DEVICE CODE (tools/lib_code_hash.py: .text + .rodata of every gfx950 code object; the
+    whole-file sha of a clean rebuild can take two values - hipcc orders a few .bss symbols either way) in the TRACKED file
+    lib/libfmri_hip.so.sha256, tools/gputest_stamp.sh stamps the same hash of the .so the suite actually loaded, and an in-tree .so must
+    carry it too: the three agree (the shipped .so had been rebuilt after the stamped run and nothing would have noticed a
+    difference)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import lib_code_hash
     sha_file = os.path.join(ROOT, "fetal-mri-segmentation_amd", "lib", "libfmri_hip.so.sha256")
-    assert os.path.exists(sha_file), "build() has not recorded the library's sha256"
+    assert os.path.exists(sha_file), "build() has not recorded the library's code hash"
     recorded = open(sha_file).read().strip()
     assert re.fullmatch(r"[0-9a-f]{64}", recorded)
-    m = re.search(r"libfmri_hip_so_sha256_16=([0-9a-f]{16})", open(LOG).read().splitlines()[0])
-    assert m and recorded.startswith(m.group(1)), "the recorded GPU suite ran on another build of the library (%s vs %s)" % (m and m.group(1), recorded[:16])
+    m = re.search(r"libfmri_hip_code_sha256_16=([0-9a-f]{16})", open(LOG).read().splitlines()[0])
+    assert m and recorded.startswith(m.group(1)), "the recorded GPU suite ran on other device code (%s vs %s)" % (m and m.group(1), recorded[:16])
     so = os.path.join(ROOT, "fetal-mri-segmentation_amd", "lib", "libfmri_hip.so")
     if os.path.exists(so):
-        import hashlib
-        assert hashlib.sha256(open(so, "rb").read()).hexdigest() == recorded, "libfmri_hip.so in the tree is not the recorded build: run make"
+        assert lib_code_hash.code_hash(so)[0] == recorded, "libfmri_hip.so in the tree is not the recorded build: run make"

@@ -6,10 +6,10 @@
 TAG=${1:-r04}
 mkdir -p gpurun_out
 HASH=$(python3 -c "import bench; print(bench.kernel_source_hash())")
-SO=$(sha256sum fetal-mri-segmentation_amd/lib/libfmri_hip.so | cut -c1-16)
+SO=$(python3 tools/lib_code_hash.py fetal-mri-segmentation_amd/lib/libfmri_hip.so | cut -c1-16)
 LOG=gpurun_out/${TAG}_gputest_final.log
 {
-    echo "# kernel_source_hash=$HASH libfmri_hip_so_sha256_16=$SO tag=$TAG date=$(date -u +%Y-%m-%dT%H:%MZ)"
+    echo "# kernel_source_hash=$HASH libfmri_hip_code_sha256_16=$SO tag=$TAG date=$(date -u +%Y-%m-%dT%H:%MZ)"
     echo "# command: python -m pytest tests -x -q -m gpu -p no:cacheprovider --durations=10"
 } > $LOG
 python -m pytest tests -x -q -m gpu -p no:cacheprovider --durations=10 >> $LOG 2>&1
