@@ -217,43 +217,50 @@ def val_dice_leg(batch, steps, spatial=(64, 128, 128), volume=(160, 256, 256), l
             "train_model_seconds": round(t_train, 2), "seconds": round(time.perf_counter() - t0, 2)}, model
 
 
-def reference_api_leg(model, batch, spatial=(64, 128, 128), steps=40):
+def reference_api_leg(model, batch, spatial=(64, 128, 128), steps=40, pool=4):
     """patches/s of the SAME training step driven through the reference-facing surface (`Model.fit_generator`, what train_model() calls):
-    (a) a reference-style host generator yielding float64 numpy batches (generator.py:397-401; one ready batch of the learnable task re-yielded:
-    isolates the boundary cost), (b) the same batch already in HBM, (c) the bare engine loop on that batch (= the headline's loop), all three on
-    the same model in the same state."""
+    (a) a reference-style host generator yielding float64 numpy batches (generator.py:397-401; a small pool of ready batches of the learnable
+    task: isolates the boundary cost), (b) the same batches already in HBM, (c) the bare engine loop on them (= the headline's loop).  All
+    three on the same model with the learning rate set to 0 for the duration: the weights - and with them the operands' statistics and the
+    power-limited clock - are the same for the three legs (a model that keeps training on four batches drifts towards memorising them, its
+    gradients shrink and the later legs would run at a higher clock)."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import learnable_task as LT
-    xd, yd = LT.device_batch(LT.HELD_OUT + 700_000, batch, spatial)
-    xb, yb = xd.cpu().numpy().astype(np.float64), yd.cpu().numpy()
+    dev = [LT.device_batch(LT.HELD_OUT + 700_000 + k * batch, batch, spatial) for k in range(pool)]
+    host = [(x.cpu().numpy().astype(np.float64), y.cpu().numpy()) for x, y in dev]
 
-    def host_gen():
+    def cycle(items):
+        k = 0
         while True:
-            yield xb, yb
+            yield items[k % len(items)]
+            k += 1
 
-    def dev_gen():
-        while True:
-            yield xd, yd
-
+    lr_keep = model.optimizer.lr
+    model.optimizer.lr = 0.0
     out = {}
-    for name, g in (("host_float64_generator", host_gen()), ("device_batches", dev_gen())):
-        model.fit_generator(g, steps_per_epoch=5, epochs=1, verbose=0)
+    try:
+        for name, items in (("host_float64_generator", host), ("device_batches", dev)):
+            g = cycle(items)
+            model.fit_generator(g, steps_per_epoch=5, epochs=1, verbose=0)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            model.fit_generator(g, steps_per_epoch=steps, epochs=1, verbose=0)
+            torch.cuda.synchronize()
+            out[name + "_patches_per_s"] = steps * batch / (time.perf_counter() - t0)
+        eng = model.engine(batch)
+        res = [(model._to_device_x(x), model._to_device_y(y)) for x, y in dev]
+        for k in range(5):
+            eng.train_step(*res[k % pool], 0.0)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        model.fit_generator(g, steps_per_epoch=steps, epochs=1, verbose=0)
+        for k in range(steps):
+            eng.train_step(*res[k % pool], 0.0)
         torch.cuda.synchronize()
-        out[name + "_patches_per_s"] = steps * batch / (time.perf_counter() - t0)
-    eng = model.engine(batch)
-    xe, ye = model._to_device_x(xd), model._to_device_y(yd)
-    for _ in range(5):
-        eng.train_step(xe, ye, model.optimizer.lr)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        eng.train_step(xe, ye, model.optimizer.lr)
-    torch.cuda.synchronize()
-    out["resident_batch_patches_per_s"] = steps * batch / (time.perf_counter() - t0)
+        out["resident_batch_patches_per_s"] = steps * batch / (time.perf_counter() - t0)
+    finally:
+        model.optimizer.lr = lr_keep
     out["steps"] = steps
+    out["note"] = "learning rate 0 during the three legs (same weights, same clock); %d batches of the learnable task" % pool
     return out
 
 
