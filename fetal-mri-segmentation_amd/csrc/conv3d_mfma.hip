@@ -1313,6 +1313,14 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
             if constexpr (FASTH_CT) {
                 if (has_next) nsb = fast_base(nxt, ntm);
             }
+            // CHEAP_FRESH (tight parity modes outside FH: many chunks per fresh address): the pointers are kept and advanced as before, but a
+            // FRESH pointer is formed the fast way - base of the box corner + lane constant, zero page where an edge row leaves the volume -
+            // instead of halo_src's clamps and 64-bit multiplies (these launches always have one plain source: conv3d_api.hip).  dec2a / dec1a
+            // input gradient -2.7 %, dec0a / dec1a forward -1 ... -2 % (same-box A/B)
+            constexpr bool CHEAP_FRESH = TIGHT && KEEP_HP && KEEP_PACK && !FASTH_CT;
+            if constexpr (CHEAP_FRESH) {
+                if (has_next && fresh) nsb = fast_base(nxt, ntm);
+            }
             // keep the packed piece descriptors packed: hipcc otherwise hoists the three bit-field extractions of every piece out of the loop
             // (51 more live registers) and spills them
 #pragma unroll
@@ -1374,8 +1382,13 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
                             if (q < HPN) {
                                 if constexpr (FASTH_CT) issue_halo_fast(HP0 + q, hb ^ 1, nsb, ntm);
                                 else if constexpr (KEEP_HP) {
-                                    if (fresh) hp[HP0 + q] = halo_src(nxt, h_pack[HP0 + q]);
-                                    else hp[HP0 + q] += 32;
+                                    if (fresh) {
+                                        if constexpr (CHEAP_FRESH) {
+                                            const int pk = h_pack[HP0 + q];
+                                            const bool bad = !((pk >> 15) & 1) || (((unsigned)pk >> 16) & ntm) != 0;
+                                            hp[HP0 + q] = bad ? (const bf16_t*)g_zero_page : reinterpret_cast<const bf16_t*>(nsb + fast_off(pk));
+                                        } else hp[HP0 + q] = halo_src(nxt, h_pack[HP0 + q]);
+                                    } else hp[HP0 + q] += 32;
                                     issue_halo(HP0 + q, hb ^ 1, hp[HP0 + q]);
                                 } else issue_halo(HP0 + q, hb ^ 1, halo_src(nxt, pack_of(HP0 + q)));
                             }
@@ -2351,9 +2364,16 @@ __device__ __forceinline__ void wk_run(const WkArgs& a, unsigned char* lds, int 
         issue_x(d + 1, 2);
         issue_y(d, 0);
         int xs = 2, yb = 0;                              // ring slot of the newest x plane (kd = 2) of the current unit; dy slot
+#ifdef FMRI_PROF
+        unsigned long long wprof[12] = {};               // [0] DMA wait, [1] barrier, [2] DMA issue (+ column set-up), [3] fragment reads + MFMAs, [4] fresh-column tail, [6] units
+        PROF_T(wk0);
+#endif
         for (; u < u_end; ++u) {
+            PROF_T(w0);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            PROF_T(w1);
             __builtin_amdgcn_s_barrier();                // this unit's planes have landed everywhere; the previous unit is fully read
+            PROF_T(w2);
             const bool more = u + 1 < u_end;
             const bool fresh = more && d + 1 == D;       // the next unit starts a new column: it needs three new planes, one slot is free
             if (more) {
@@ -2366,11 +2386,16 @@ __device__ __forceinline__ void wk_run(const WkArgs& a, unsigned char* lds, int 
                 issue_x(fresh ? -1 : d + 2, (xs + 1) & 3);
                 issue_y(d + 1, yb ^ 1);
             }
+            PROF_T(w3);
             int xb[3] = {((xs + 2) & 3) * K::XS_BYTES, ((xs + 3) & 3) * K::XS_BYTES, xs * K::XS_BYTES};
 #pragma unroll
             for (int k = 0; k < 3; ++k) asm volatile("" : "+s"(xb[k]));       // slot bases stay scalar: base + lane offset is added per read
             wk_compute<BLK, G>(lds, xb, K::NXS * K::XS_BYTES + yb * K::YS_BYTES, pre_x, pre_y, acc, bsum, do_bias);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            PROF_T(w4);
+#ifdef FMRI_PROF
+            wprof[0] += w1 - w0; wprof[1] += w2 - w1; wprof[2] += w3 - w2; wprof[3] += w4 - w3; wprof[6] += 1;
+#endif
             if (fresh) {
                 __builtin_amdgcn_s_barrier();            // everybody is done with the old column's planes: its other two slots are free
                 issue_x(0, (xs + 2) & 3);
@@ -2381,7 +2406,14 @@ __device__ __forceinline__ void wk_run(const WkArgs& a, unsigned char* lds, int 
             }
             yb ^= 1;
             ++d;
+#ifdef FMRI_PROF
+            { PROF_T(w5); wprof[4] += w5 - w4; }
+#endif
         }
+#ifdef FMRI_PROF
+        { PROF_T(wk1); wprof[5] = wk1 - wk0; }
+        if (lane == 0) for (int i = 0; i < 7; ++i) atomicAdd(&g_prof[i], wprof[i]);
+#endif
     }
     // ---- flush: D rows = co, cols = ci; fp32 atomics, 128 contiguous bytes per half-wave (deterministic mode: fixed-point shadow)
     const FmriDetCfg dc = g_det_cfg;

@@ -34,5 +34,5 @@ for name, C0, up0, C1, Cout, D, H, W in LAYERS:
     p = list(buf)
     tot, units = max(p[5], 1), max(p[6], 1)
     sec = [p[i] / tot * 100 for i in range(4)]
-    print("%-7s ticks/unit %6.0f | dma-wait %5.1f%%  barrier %5.1f%%  dma-issue %5.1f%%  reads+mfma %5.1f%% (%5.0f ticks/unit)  rest %5.1f%%"
-          % (name, tot / units, sec[0], sec[1], sec[2], sec[3], p[3] / units, 100 - sum(sec)))
+    print("%-7s ticks/unit %6.0f | dma-wait %5.1f%%  barrier %5.1f%%  dma-issue %5.1f%%  reads+mfma %5.1f%% (%5.0f ticks/unit)  fresh-column tail %4.1f%%  rest (prologue) %5.1f%%"
+          % (name, tot / units, sec[0], sec[1], sec[2], sec[3], p[3] / units, p[4] / tot * 100, 100 - sum(sec) - p[4] / tot * 100))
