@@ -230,6 +230,67 @@ def test_isensee_mask_weighted_loss(tmp_path):
     assert getattr(m3.loss, "mask_weighted", False) and abs(m3.test_on_batch([x, masks], y)[0] - m1.test_on_batch([x, masks], y)[0]) <= 1e-5
 
 
+def test_fit_generator_staged_prefetch_equals_the_inline_path(monkeypatch):
+    """fit_generator with the producer thread's pinned staging ring + deferred metric reads (round 4) against FMRI_STAGE_PREFETCH=0 (round 3:
+    conversion, pageable upload and a synchronous read-back on the training thread): same batches, same weights -> the same epoch logs
+    (fp32 engine; atomics order only), for a plain U-Net with varying batch sizes and validation, and for the mask-weighted Isensee model
+    whose generator yields ([x, masks], y) (reference generator.py:397-401).  Batch logs read inside a callback equal train_on_batch's."""
+    import fetal_net.model as fmodel
+    from fetal_net import metrics as M
+    from fetal_net.engine_model import Callback
+
+    def unet():
+        return fmodel.unet_model_3d(input_shape=(1, 8, 16, 16), depth=2, n_base_filters=8, initial_learning_rate=1e-2, compute_dtype="fp32")
+
+    def gen(seed, sizes, with_masks=False, shape=(1, 8, 16, 16)):
+        rs = np.random.RandomState(seed)
+        k = 0
+        while True:
+            n = sizes[k % len(sizes)]
+            k += 1
+            x = rs.randn(n, *shape)
+            y = (rs.rand(n, *shape) > 0.6).astype(np.uint8)
+            yield ([x, rs.rand(n, *shape) * 12], y) if with_masks else (x, y)
+
+    class BatchLosses(Callback):
+        def __init__(self):
+            self.v = []
+
+        def on_batch_end(self, batch, logs=None):
+            self.v.append((logs["size"], float(logs["loss"])))
+
+    hists, batch_logs = [], []
+    for staged in ("1", "0"):
+        monkeypatch.setenv("FMRI_STAGE_PREFETCH", staged)
+        m = unet()
+        if hists:
+            m.set_weights_dict(W0)
+        else:
+            W0 = m.get_weights_dict()
+        cb = BatchLosses()
+        h = m.fit_generator(gen(1, [2, 3, 1]), steps_per_epoch=7, epochs=2, validation_data=gen(2, [2]), validation_steps=3, verbose=0, callbacks=[cb]).history
+        hists.append(h)
+        batch_logs.append(cb.v)
+    assert [s for s, _ in batch_logs[0]] == [s for s, _ in batch_logs[1]] == ([2, 3, 1] * 5)[:14]        # the generator runs on across epochs, as in Keras
+    np.testing.assert_allclose([v for _, v in batch_logs[0]], [v for _, v in batch_logs[1]], atol=2e-5)
+    for k in ("loss", "binary_accuracy", "vod_coefficient", "val_loss", "val_binary_accuracy"):
+        np.testing.assert_allclose(hists[0][k], hists[1][k], atol=3e-5, err_msg=k)
+    # mask-weighted loss: the masks are staged by the producer thread too
+    shape = (1, 16, 16, 16)
+    kw = dict(input_shape=shape, depth=3, n_base_filters=4, n_segmentation_levels=2, dropout_rate=0.0, compute_dtype="fp32")
+    outs = []
+    for staged in ("1", "0"):
+        monkeypatch.setenv("FMRI_STAGE_PREFETCH", staged)
+        m = fmodel.isensee2017_model_3d(loss_function=M.dice_and_xent_mask, mask_shape=shape, **kw)
+        if outs:
+            m.set_weights_dict(W1)
+        else:
+            W1 = m.get_weights_dict()
+        outs.append(m.fit_generator(gen(3, [2], with_masks=True, shape=shape), steps_per_epoch=5, epochs=2, verbose=0).history["loss"])
+    np.testing.assert_allclose(outs[0], outs[1], atol=3e-5)
+    assert outs[0][1] < outs[0][0]
+
+
 def test_2d_patch_wise_prediction_device_path_equals_host_tiling():
     """2-D models: the device overlap-add loop (tile = slice stack = channels-last input, one output slice per tile) against the
     reference-style host tiling around the same model (forced through a duck-typed proxy)"""
