@@ -463,6 +463,33 @@ k_conv_fwd_mfma(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__
         if constexpr (FASTH_CT) {
             if (has_next) nsb = fast_base(nxt, ntm);
         }
+        // CHEAP_FRESH (the parity modes, i.e. the decoder 'a' layers of the 2-D path, which run on this kernel): pointers kept and advanced as
+        // before, a FRESH pointer formed as base of the box corner + lane constant, zero page where an edge row leaves the volume (see
+        // k_conv_fwd_ws) - every wave of this kernel issues halo pieces, so halo_src's ~50 instructions per piece sat in front of all MFMAs
+        constexpr bool CHEAP_FRESH = PAR && !CUBE;
+        if constexpr (CHEAP_FRESH) {
+            if (has_next && fresh) {
+                const FwdItem& it = nxt;
+                ntm = __builtin_amdgcn_readfirstlane((it.d0 == 0 ? 1u : 0u) | (it.d0 + TD == D ? 2u : 0u) | (it.h0 == 0 ? 4u : 0u) | (it.h0 + TH == H ? 8u : 0u) |
+                                                     (it.w0 == 0 ? 16u : 0u) | (it.w0 + TW == W ? 32u : 0u));
+                int64_t eoff;
+                if constexpr (MODE == 2) {
+                    const int p = it.ch / kpc, coff = (it.ch % kpc) << 5;
+                    const int64_t dd = PL ? ((int64_t)it.n * D + it.d0 - 1) : ((int64_t)it.n * 2 * D + 2 * (it.d0 - 1) + (p >> 2));
+                    eoff = ((dd * 2 * H + 2 * (it.h0 - 1) + ((p >> 1) & 1)) * 2 * W + 2 * (it.w0 - 1) + (p & 1)) * s.C0 + coff;
+                } else {
+                    eoff = ((((int64_t)it.n * D + it.d0 - 1) * H + it.h0 - 1) * W + it.w0 - 1) * s.C0 + (it.ch << 5);
+                }
+                const unsigned long long a = reinterpret_cast<unsigned long long>(s.p0 + eoff);
+                const unsigned alo = __builtin_amdgcn_readfirstlane((unsigned)a), ahi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+                nsb = reinterpret_cast<const char*>(((unsigned long long)ahi << 32) | alo);
+            }
+        }
+        auto cheap_off = [&](int pk) -> unsigned {
+            const int hd_ = pk & 15, hh_ = (pk >> 4) & 15, hw_ = (pk >> 8) & 31, ls = (pk >> 13) & 3;
+            if constexpr (MODE == 2) return (unsigned)((((PL ? hd_ : 2 * hd_) * (2 * H) + 2 * hh_) * (2 * W) + 2 * hw_) * s.C0 + ls * 8) * 2u;
+            else return (unsigned)(((hd_ * H + hh_) * W + hw_) * s.C0 + ls * 8) * 2u;
+        };
         const unsigned char* const lh = lds + hb * HALO_BYTES;
         // keep the 54 per-(phase,tap) fragment addresses out of long-lived registers: recomputing them costs a few VALU
         // instructions per MFMA, which issue in the MFMA's shadow, whereas hoisting them spills
@@ -488,8 +515,13 @@ k_conv_fwd_mfma(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__
                         if (q < HPN) {
                             if constexpr (FASTH_CT) issue_halo_fast(HP0 + q, hb ^ 1, nsb, ntm);
                             else {
-                                if (fresh) hp[HP0 + q] = halo_src(nxt, h_pack[HP0 + q]);
-                                else hp[HP0 + q] += 32;
+                                if (fresh) {
+                                    if constexpr (CHEAP_FRESH) {
+                                        const int pk = h_pack[HP0 + q];
+                                        const bool bad = !((pk >> 15) & 1) || (((unsigned)pk >> 16) & ntm) != 0;
+                                        hp[HP0 + q] = bad ? (const bf16_t*)g_zero_page : reinterpret_cast<const bf16_t*>(nsb + cheap_off(pk));
+                                    } else hp[HP0 + q] = halo_src(nxt, h_pack[HP0 + q]);
+                                } else hp[HP0 + q] += 32;
                                 issue_halo(HP0 + q, hb ^ 1);
                             }
                         }
