@@ -113,6 +113,12 @@ __device__ __forceinline__ unsigned pos_mask2(unsigned m, unsigned zero2, unsign
     asm("v_pk_max_i16 %0, %1, %2\n\tv_pk_min_u16 %0, %0, %3\n\tv_pk_sub_u16 %0, %2, %0" : "=&v"(t) : "v"(m), "v"(zero2), "v"(one2));
     return t;
 }
+// max(x, 0) on two packed bf16 values through their int16 bit patterns
+__device__ __forceinline__ unsigned relu2(unsigned m, unsigned zero2) {
+    unsigned t;
+    asm("v_pk_max_i16 %0, %1, %2" : "=v"(t) : "v"(m), "v"(zero2));
+    return t;
+}
 __device__ __forceinline__ unsigned lds_addr(const void* p) {
     return (unsigned)(size_t)(__attribute__((address_space(3))) const unsigned char*)p;
 }
@@ -1726,6 +1732,8 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
             // operations - the general max(v, alpha * v) form for all three spent 256 VALU instructions per tile and wave on the identity
             auto stage_tile = [&](auto act_tag) {
                 constexpr int ACT = decltype(act_tag)::value;
+                unsigned zero2_ = 0u;
+                asm volatile("" : "+v"(zero2_));
 #pragma unroll
                 for (int j = 0; j < JT; ++j) {
                     const int v = j * 32 + r;
@@ -1742,12 +1750,17 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
 #pragma unroll
                                 for (int i = 0; i < 4; ++i) {
                                     const float vv = acc[j][c][4 * gq + i];
-                                    if constexpr (ACT == FMRI_ACT_NONE) o[i] = vv;
-                                    else if constexpr (ACT == FMRI_ACT_RELU) o[i] = vmax(vv, 0.f);
-                                    else o[i] = vmax(vv, __builtin_fmaf(vv, act_s, 0.f));
+                                    if constexpr (ACT == FMRI_ACT_LEAKY) o[i] = vmax(vv, __builtin_fmaf(vv, act_s, 0.f));
+                                    else o[i] = vv;
                                 }
                                 pk[u][0] = pack2bf(o[0], o[1]);
                                 pk[u][1] = pack2bf(o[2], o[3]);
+                                if constexpr (ACT == FMRI_ACT_RELU) {
+                                    // ReLU on the packed pair: max(int16(bits), 0) per half - a bf16 is negative (or -0) exactly when its bits are
+                                    // a negative int16, and rounding never changes the sign: the same bits as bf16(max(v, 0)), half the instructions
+                                    pk[u][0] = relu2(pk[u][0], zero2_);
+                                    pk[u][1] = relu2(pk[u][1], zero2_);
+                                }
                             }
 #pragma unroll
                             for (int q = 0; q < 2; ++q) {
