@@ -862,6 +862,15 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
     auto tile_d = [](int rt) { return rt >> 2; };
     auto tile_h = [](int rt, int rr) { return 2 * (rt & 3) + (rr >> 4); };
     auto lane_w = [](int rr) { return (rr >> 4) ? (((rr & 15) + 16 - (HW & 15)) & 15) : (rr & 15); };
+    // Slot swizzle of the halo rows (64 B = four 16-byte slots per voxel): slot ^= key(COLUMN of the row in the halo box).  Rounds 1-3 keyed on
+    // the row number ((row >> 2) & 3), which every tap moves: an MFMA wave rebuilt each fragment address with 6 vector instructions (32 per
+    // 8-MFMA step, on the SIMD it shares with a producer wave).  Keyed on the column, a tap's (kd, kh) and the column tile only add a constant
+    // to the address - the instruction's immediate offset - and the three kw x two k-steps are six registers per lane, set up once: no
+    // address arithmetic in the matrix loop at all.  The key tables are 4-colourings of the "same bank group" graph of the four 16-lane
+    // groups a ds_read_b128 is served in, for every kw (tests/test_host_lds_swizzle.py re-derives them): conflict-free like the row key.
+    constexpr unsigned long long HKEY = HW == 18 ? 0xfa50fa50ull /* (hw >> 1) & 3 */ : 0x267fe640ull /* HW = 17 (TIGHT): 0 0 0 1 2 1 2 3 3 3 3 1 2 1 2 0 0 */;
+    static_assert(HW == 18 || HW == 17, "halo width");
+    auto halo_key = [](int hw) { return (int)((HKEY >> (2 * hw)) & 3); };
     constexpr int CPV_ = BN / 8;                     // 16-byte pieces per voxel
     constexpr int VPI_ = 64 / CPV_;                  // voxels per store instruction
     // address in y (and in the mask / residual) of piece q of tile voxel v (column tile v >> 5, lane v & 31):
@@ -1132,9 +1141,9 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
         auto make_pack = [&](int ph, int ln) {
             const int i = (H_I0 + ph * DW + dwv) * 64 + ln;
             const int hv = i >> 2, ps = i & 3;
-            const int ls = ps ^ ((hv >> 2) & 3);
             const int hvc = hv < HVOX ? hv : 0;
             const int hw_ = hvc % HW, hq = hvc / HW;
+            const int ls = ps ^ halo_key(hw_);
             const int hd_ = hq / HH, hh_ = hq % HH;
             const int edge = (hd_ == 0 ? 1 : 0) | (hd_ == HD - 1 ? 2 : 0) | (hh_ == 0 ? 4 : 0) | (hh_ == HH - 1 ? 8 : 0) | (hw_ == 0 ? 16 : 0) | (hw_ == HW - 1 ? 32 : 0);
             return hd_ | (hh_ << 4) | (hw_ << 8) | (ls << 13) | ((hv < HVOX ? 1 : 0) << 15) | (edge << 16);
@@ -1538,11 +1547,15 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
         }
     };
     // lane r of a column tile: h-row r>>4, w rotated by HW mod 16 on the second row (conflict-free ds_read_b128 groups, see k_conv_fwd_mfma)
-    int hv0[JT];
+    // B-fragment (halo) addresses of this lane: [k-step][kw (+ the parity's first kw)] for column tile 0 of this wave, filter row (0, 0), in
+    // the halo slot the NEXT request goes to (the slot's base is added / subtracted once per item); everything else is an immediate
+    static_assert(JT == 4, "tile_d(JT * cw + j) = cw, tile_h = 2 j + (r >> 4)");
+    int pre[2][3];
 #pragma unroll
-    for (int j = 0; j < JT; ++j) {
-        const int rt = JT * cw + j;
-        hv0[j] = (tile_d(rt) * HH + tile_h(rt, r)) * HW + lane_w(r);
+    for (int k = 0; k < 3; ++k) {
+        const int hwc = lane_w(r) + k;
+        pre[0][k] = ((cw * HH + (r >> 4)) * HW + hwc) * 64 + ((hk ^ halo_key(hwc)) << 4);
+        pre[1][k] = pre[0][k] ^ 32;
     }
     const int fa[2] = {swz64(r, hk), swz64(r, hk) ^ 32};
     if ((RES || HAS_RESID) && tail.bias27) init_acc_b27(cur);
@@ -1579,7 +1592,7 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
             if (has_next) nxt = decode(npair, 0);
         }
 #pragma unroll
-        for (int j = 0; j < JT; ++j) asm volatile("" : "+v"(hv0[j]));
+        for (int k = 0; k < 3; ++k) asm volatile("" : "+v"(pre[0][k]), "+v"(pre[1][k]));
         // (halo slot, halo row offset of the (kd,kh) row, first kw) of phase `pl` of item `it` whose halo sits in slot `slot`
         auto phase_hoff = [&](const FwdItem& it, int pl, int& kw0) {
             kw0 = 0;
@@ -1603,15 +1616,17 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
 #pragma unroll
             for (int c = 0; c < NT; ++c) fa_[buf][c] = *reinterpret_cast<const bf16x8_t*>(lfp + fa[ks] + (t * BN + c * 32) * 64);
         };
-        auto load_b = [&](const unsigned char* lhp, int hoffp, int kw0p, int st, int buf, int j) {
+        auto load_b = [&](int hoffp, int kw0p, int st, int buf, int j) {
             const int t = st >> 1, ks = st & 1;
             const int kw = t % NKW, row = t / NKW;       // (row > 0 only with RPP = 2: the phase's second filter row = the next h-row of the halo)
-            fb_[buf][j] = *reinterpret_cast<const bf16x8_t*>(lhp + (swz64(hv0[j] + hoffp + row * HW + kw + kw0p, hk) ^ (ks << 5)));
+            int base;
+            if constexpr (PAR && !TIGHT) base = kw0p ? pre[ks][kw + 1] : pre[ks][kw];
+            else base = pre[ks][kw];
+            fb_[buf][j] = *reinterpret_cast<const bf16x8_t*>(lds + base + (hoffp + (row + 2 * j) * HW) * 64);
         };
 #pragma unroll
         for (int pl = 0; pl < NPH; ++pl, ++g) {
             PROF_T(c0);
-            const unsigned char* const lh = lds + hb * HALO_STRIDE;
             const unsigned char* const lf = lds + HALO_SPAN + (g & 1) * FILT_BYTES;
             int kw0;
             const int hoff = phase_hoff(cur, pl, kw0);
@@ -1619,7 +1634,7 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
                 __builtin_amdgcn_s_barrier();
                 load_a(lf, 0, 0);
 #pragma unroll
-                for (int j = 0; j < JT; ++j) load_b(lh, hoff, kw0, 0, 0, j);
+                for (int j = 0; j < JT; ++j) load_b(hoff, kw0, 0, 0, j);
             }
             PROF_T(c1);
             if constexpr (RES) {
@@ -1637,13 +1652,18 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
                 // a next phase of the SAME tile follows (same chunk, or the next chunk of this tile in the other halo slot)
                 const bool chain = last && (pl + 1 < NPH || cur.ch + 1 < nch);
                 const unsigned char* lfn = lf;
-                const unsigned char* lhn = lh;
                 int hoffn = hoff, kw0n = kw0, stn = st + 1;
                 if (last) {
                     stn = 0;
                     lfn = lds + HALO_SPAN + ((g + 1) & 1) * FILT_BYTES;
                     if (pl + 1 < NPH) hoffn = phase_hoff(cur, pl + 1, kw0n);
-                    else { hoffn = phase_hoff(nxt, 0, kw0n); lhn = lds + (hb ^ 1) * HALO_STRIDE; }
+                    else {
+                        // every later request is for the next item, whose halo sits in the other slot: move the six addresses there
+                        hoffn = phase_hoff(nxt, 0, kw0n);
+                        const int dlt = hb ? -HALO_STRIDE : HALO_STRIDE;
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) { pre[0][k] += dlt; pre[1][k] += dlt; }
+                    }
                 }
                 if (chain) {
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this phase's last fragments are in registers: done with the rings
@@ -1655,7 +1675,7 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
 #pragma unroll
                     for (int c = 0; c < NT; ++c)
                         acc[j][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_[st & 1][c], fb_[st & 1][j], acc[j][c], 0, 0, 0);
-                    if (!last || chain) load_b(lhn, hoffn, kw0n, stn, stn & 1, j);
+                    if (!last || chain) load_b(hoffn, kw0n, stn, stn & 1, j);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
