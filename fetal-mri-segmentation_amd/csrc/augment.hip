@@ -174,6 +174,56 @@ __global__ void k_shot_noise(T* __restrict__ x, int64_t n, const float* __restri
     }
 }
 
+// ---- imgaug's two augmenters of the reference's DEFAULT config (fetal/config_utils.py:104-112): ElasticTransformation and CoarseDropout,
+// applied by reference fetal_net/augment.py:116-120 (coarse dropout) and :149-170 (elastic transform).  imgaug sees a patch [X][Y][Z] as an
+// image of height X, width Y with Z channels: one in-plane displacement field / one low-resolution mask grid for all slices.
+//
+// Elastic: dst[i][j][c] = src[:, :, c] at (i - d0[i][j], j - d1[i][j]) (imgaug 0.4.0 `_map_coordinates`: x_shifted = x + (-1) * dx),
+// scipy map_coordinates order 0 (floor(c + 0.5)) or 1 (bilinear), mode 'nearest' (coordinates clamped to the image); fp64 coordinates.
+template <typename T>
+__global__ void k_elastic_warp(const T* __restrict__ src, int X, int Y, int C, int src_ld, const float* __restrict__ d0, const float* __restrict__ d1,
+                               int order, T* __restrict__ dst, int dst_ld) {
+    const int64_t total = (int64_t)X * Y * C;
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(t % C);
+        const int64_t ij = t / C;
+        const int j = (int)(ij % Y), i = (int)(ij / Y);
+        const double ci = (double)i - (double)d0[ij], cj = (double)j - (double)d1[ij];
+        float v;
+        if (order == 0) {
+            const int si = min(max((int)floor(ci + 0.5), 0), X - 1), sj = min(max((int)floor(cj + 0.5), 0), Y - 1);
+            v = ld_any<T>(src, ((int64_t)si * Y + sj) * src_ld + c);
+        } else {
+            const double fi = floor(ci), fj = floor(cj);
+            const double ti = ci - fi, tj = cj - fj;
+            const int i0 = min(max((int)fi, 0), X - 1), i1 = min(max((int)fi + 1, 0), X - 1);
+            const int j0 = min(max((int)fj, 0), Y - 1), j1 = min(max((int)fj + 1, 0), Y - 1);
+            const double v00 = ld_any<T>(src, ((int64_t)i0 * Y + j0) * src_ld + c), v01 = ld_any<T>(src, ((int64_t)i0 * Y + j1) * src_ld + c);
+            const double v10 = ld_any<T>(src, ((int64_t)i1 * Y + j0) * src_ld + c), v11 = ld_any<T>(src, ((int64_t)i1 * Y + j1) * src_ld + c);
+            v = (float)((1.0 - ti) * ((1.0 - tj) * v00 + tj * v01) + ti * ((1.0 - tj) * v10 + tj * v11));
+        }
+        st_any<T>(dst, ij * dst_ld + c, v);
+    }
+}
+
+// Coarse dropout: x[i][j][c] keeps its value where the low-resolution mask keep[hs][ws][kc] (kc = C: one grid per slice, or 1), enlarged to
+// X x Y by nearest neighbour the way cv2.resize(INTER_NEAREST) does it (source index = min(floor(dst * hs / X), hs - 1)), is 1; a dropped
+// voxel becomes 0 in the reference's [0, 255] min-max scaling, i.e. the patch's minimum (stats[0] = fmri_minmax of x before the call).
+template <typename T>
+__global__ void k_coarse_dropout(T* __restrict__ x, int X, int Y, int C, int ld, const uint8_t* __restrict__ keep, int hs, int ws, int kc,
+                                 const float* __restrict__ stats) {
+    const int64_t total = (int64_t)X * Y * C;
+    const double fi = (double)hs / X, fj = (double)ws / Y;
+    const float lo = stats[0];
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(t % C);
+        const int64_t ij = t / C;
+        const int j = (int)(ij % Y), i = (int)(ij / Y);
+        const int si = min((int)floor(i * fi), hs - 1), sj = min((int)floor(j * fj), ws - 1);
+        if (!keep[((int64_t)si * ws + sj) * kc + (kc == 1 ? 0 : c)]) st_any<T>(x, ij * ld + c, lo);
+    }
+}
+
 }  // namespace
 
 extern "C" int fmri_shot_noise_step(void* x, int64_t n, int dtype, const float* stats, int* present, float* rates, const float* draws, int phase,
@@ -183,6 +233,30 @@ extern "C" int fmri_shot_noise_step(void* x, int64_t n, int dtype, const float* 
     const int grid = grid_for(n);
     if (dtype == FMRI_F32) k_shot_noise<float><<<grid, 256, 0, st>>>((float*)x, n, stats, present, rates, draws, phase);
     else if (dtype == FMRI_BF16) k_shot_noise<bf16_t><<<grid, 256, 0, st>>>((bf16_t*)x, n, stats, present, rates, draws, phase);
+    else return FMRI_E_DTYPE;
+    FMRI_LAUNCH_CHECK();
+    return FMRI_OK;
+}
+
+extern "C" int fmri_elastic_warp(const void* src, int dtype, int X, int Y, int C, int src_ld, const float* d0, const float* d1, int order, void* dst,
+                                int dst_ld, fmri_stream_t stream) {
+    if (X < 1 || Y < 1 || C < 1 || src_ld < C || dst_ld < C || (order != 0 && order != 1) || !d0 || !d1 || src == dst) return FMRI_E_SHAPE;
+    hipStream_t st = as_stream(stream);
+    const int grid = grid_for((int64_t)X * Y * C);
+    if (dtype == FMRI_F32) k_elastic_warp<float><<<grid, 256, 0, st>>>((const float*)src, X, Y, C, src_ld, d0, d1, order, (float*)dst, dst_ld);
+    else if (dtype == FMRI_U8) k_elastic_warp<uint8_t><<<grid, 256, 0, st>>>((const uint8_t*)src, X, Y, C, src_ld, d0, d1, order, (uint8_t*)dst, dst_ld);
+    else return FMRI_E_DTYPE;
+    FMRI_LAUNCH_CHECK();
+    return FMRI_OK;
+}
+
+extern "C" int fmri_coarse_dropout(void* x, int dtype, int X, int Y, int C, int ld, const uint8_t* keep, int hs, int ws, int kc, const float* stats,
+                                   fmri_stream_t stream) {
+    if (X < 1 || Y < 1 || C < 1 || ld < C || hs < 1 || ws < 1 || (kc != 1 && kc != C) || !keep || !stats) return FMRI_E_SHAPE;
+    hipStream_t st = as_stream(stream);
+    const int grid = grid_for((int64_t)X * Y * C);
+    if (dtype == FMRI_F32) k_coarse_dropout<float><<<grid, 256, 0, st>>>((float*)x, X, Y, C, ld, keep, hs, ws, kc, stats);
+    else if (dtype == FMRI_BF16) k_coarse_dropout<bf16_t><<<grid, 256, 0, st>>>((bf16_t*)x, X, Y, C, ld, keep, hs, ws, kc, stats);
     else return FMRI_E_DTYPE;
     FMRI_LAUNCH_CHECK();
     return FMRI_OK;

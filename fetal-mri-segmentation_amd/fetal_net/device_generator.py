@@ -12,11 +12,14 @@ yield ([x, masks], y) like the reference's convert_data (generator.py:397-401): 
 = 0, same transformation) at the label slices.  As in the reference the masks are NOT padded with the volumes.
 
 `device_data_generator` keeps the keyword arguments of the reference's `data_generator` (generator.py:222-225).
-Applied augmenters: flip, scale, iso_scale, rotate, translate, contrast, intensity_multiplication, gaussian_filter (skimage.filters.gaussian),
-poisson_noise (the reference's shot_noise), speckle_noise, gaussian_noise - in the reference's order (augment.py:348-367).
-Not applied (their random draws are still consumed so that the affine part stays aligned with a seeded reference run): imgaug's
-piecewise_affine, elastic_transform, coarse_dropout - a warning is issued once, or NotImplementedError with strict=True.  The noise
-fields (normal and Poisson draws) come from a torch device generator (`noise_seed`), not numpy.
+Applied augmenters: flip, scale, iso_scale, rotate, translate, elastic_transform (imgaug ElasticTransformation), contrast,
+intensity_multiplication, gaussian_filter (skimage.filters.gaussian), poisson_noise (the reference's shot_noise), speckle_noise,
+gaussian_noise, coarse_dropout (imgaug CoarseDropout) - in the reference's order (augment.py:344-375), i.e. everything the reference's
+default config switches on (fetal/config_utils.py:81-123).  The two imgaug augmenters follow imgaug 0.4.0 as published (the reference
+does not pin a version and the package is not installed here: their oracle says "parity unpinned", oracle/augment_oracle.py).
+Not applied (its random draw is still consumed so that the affine part stays aligned with a seeded reference run): imgaug's
+piecewise_affine (commented out in the reference's default config) - a warning is issued once, or NotImplementedError with strict=True.
+The noise fields (normal, uniform and Poisson draws) come from a torch device generator (`noise_seed`), not numpy.
 """
 import random
 import warnings
@@ -25,7 +28,7 @@ import numpy as np
 
 from .augment import distort_image, draw_augment_parameters
 
-_UNSUPPORTED = ("piecewise_affine", "elastic_transform", "coarse_dropout")        # imgaug's augmenters
+_UNSUPPORTED = ("piecewise_affine",)        # imgaug's PiecewiseAffine (commented out in the reference's default config, config_utils.py:101-103)
 
 
 class DeviceDataFile(object):
@@ -92,6 +95,21 @@ def list_generator(index_list):
         yield from index_list
 
 
+def _coarse_grid(shape2d, size_percent, rng):
+    """imgaug parameters.FromLowerResolution: one size_percent per axis - a list is a choice among its values (the reference's default
+    [0.10, 0.30]), a tuple a uniform range, a number itself; grid = int(extent * percent), at least 1"""
+    out = []
+    for extent in shape2d:
+        if isinstance(size_percent, list):
+            sp = size_percent[int(rng.randint(len(size_percent)))]
+        elif isinstance(size_percent, tuple):
+            sp = rng.uniform(size_percent[0], size_percent[1])
+        else:
+            sp = size_percent
+        out.append(max(int(extent * sp), 1))
+    return tuple(out)
+
+
 class _Sampler(object):
     def __init__(self, ddf, patch_shape, augment, truth_index, truth_size, prev_truth_index, prev_truth_size, strict, noise_seed):
         import torch
@@ -106,8 +124,11 @@ class _Sampler(object):
         self.stats = torch.empty(2, device=ddf.device, dtype=torch.float32)
         self.gen = torch.Generator(device=ddf.device)
         self.gen.manual_seed(noise_seed)
+        # imgaug keeps its own random state (the reference's numpy / python streams are not advanced by its draws): the grid sizes of the coarse
+        # dropout come from a private host generator, everything per voxel from the device generator
+        self.host_rng = np.random.RandomState(noise_seed)
         if augment is not None:
-            bad = [k for k in _UNSUPPORTED if augment.get(k) is not None and not (k == "elastic_transform" and augment[k]["alpha"] <= 0)]
+            bad = [k for k in _UNSUPPORTED if augment.get(k) is not None]
             if bad:
                 msg = "augmenters not applied on the device path: %s" % ", ".join(bad)
                 if strict:
@@ -134,19 +155,37 @@ class _Sampler(object):
                                       rotate_factor=p["rotate_factor"], translate_factor=p["translate_factor"])
         else:
             p, A, At, Am = None, np.eye(4), np.eye(4), np.eye(4)
+        # elastic transform (reference augment.py:349-353, imgaug ElasticTransformation): ONE in-plane displacement field for every slice and for
+        # image (bilinear), truth, previous-slice truth and mask (nearest) - the affine samples land in scratch tensors and are warped into the slots
+        elastic = None
+        if p is not None and p["elastic_transform_scale"] > 0:
+            elastic = ops.elastic_fields((ps[0], ps[1]), p["elastic_transform_scale"], self.augment["elastic_transform"]["sigma"], generator=self.gen)
+
+        def target(slot, shape, dtype):
+            return slot if elastic is None else self.torch.empty(shape, device=slot.device, dtype=dtype)
+
+        def settle(tmp, slot, order):
+            if elastic is not None:
+                ops.elastic_warp(tmp, elastic[0], elastic[1], order, slot)
+
+        tshape = (ps[0], ps[1], self.truth_size)
         # image: trilinear, outside = the volume's minimum; labels: nearest, outside = 0 (identity affine = the plain crop)
-        ops.affine_sample(data, A, corner, ps, x_slot, order=1, cval=ddf.min[index], out_ld=self.n_chan)
-        ops.affine_sample(truth, At, (corner[0], corner[1], zt), (ps[0], ps[1], self.truth_size), y_slot, order=0, cval=0.0,
-                          out_ld=self.truth_size)
+        xt = target(x_slot[..., :ps[2]], ps, self.torch.float32)
+        ops.affine_sample(data, A, corner, ps, xt, order=1, cval=ddf.min[index], out_ld=self.n_chan if elastic is None else ps[2])
+        settle(xt, x_slot[..., :ps[2]], 1)
+        yt = target(y_slot, tshape, self.torch.uint8)
+        ops.affine_sample(truth, At, (corner[0], corner[1], zt), tshape, yt, order=0, cval=0.0, out_ld=self.truth_size)
+        settle(yt, y_slot, 0)
         if m_slot is not None:
             # augmented: outside the mask = 0 (interpolate_affine_range, cval 0); plain crop: edge values
             src = ddf.mask[index] if p is not None else ddf.mask_for_crops(index)
-            ops.affine_sample(src, Am, (corner[0], corner[1], zt), (ps[0], ps[1], self.truth_size), m_slot, order=0, cval=0.0,
-                              out_ld=self.truth_size)
+            mt = target(m_slot, tshape, self.torch.float32)
+            ops.affine_sample(src, Am, (corner[0], corner[1], zt), tshape, mt, order=0, cval=0.0, out_ld=self.truth_size)
+            settle(mt, m_slot, 0)
         img = x_slot if self.n_chan == ps[2] else None
         if p is not None:
             need_intensity = (p["contrast"] is not None or p["intensity_multiplication"] != 1 or p["apply_speckle_noise"] or p["apply_gaussian_noise"]
-                              or p["apply_gaussian_filter"] or p["apply_poisson_noise"])
+                              or p["apply_gaussian_filter"] or p["apply_poisson_noise"] or p["coarse_dropout"])
             if need_intensity:
                 if img is None:                            # image channels interleaved with the previous-slice truth: work on a copy
                     img = x_slot[..., :ps[2]].contiguous()
@@ -167,12 +206,22 @@ class _Sampler(object):
                         ops.minmax(img, self.stats)
                         noise = self.torch.randn(img.numel(), device=img.device, dtype=self.torch.float32, generator=self.gen)
                         ops.noise_augment(img, self.stats, noise, kind, self.augment[key]["sigma"])
+                if p["coarse_dropout"]:
+                    # reference augment.py:373-375 (last step): imgaug CoarseDropout(p=rate, size_percent, per_channel) in a [0, 255] scaling
+                    cd = self.augment["coarse_dropout"]
+                    per_channel = bool(cd.get("per_channel", True))
+                    hs, ws = _coarse_grid((ps[0], ps[1]), cd["size_percent"], self.host_rng)
+                    keep = (self.torch.rand((hs, ws, ps[2] if per_channel else 1), device=img.device, generator=self.gen) >= float(cd["rate"]))
+                    ops.minmax(img, self.stats)
+                    ops.coarse_dropout(img, keep.to(self.torch.uint8).contiguous(), self.stats, per_channel)
                 if img is not x_slot:
                     x_slot[..., :ps[2]] = img
         if self.prev_truth_index is not None:
             zp = corner[2] + self.prev_truth_index
             prev = self.torch.empty((ps[0], ps[1], self.prev_truth_size), device=x_slot.device, dtype=self.torch.float32)
             ops.affine_sample(truth, At, (corner[0], corner[1], zp), (ps[0], ps[1], self.prev_truth_size), prev, order=0, cval=0.0)
+            if elastic is not None:
+                prev = ops.elastic_warp(prev, elastic[0], elastic[1], 0, self.torch.empty_like(prev))
             x_slot[..., ps[2]:] = prev
 
 

@@ -98,6 +98,8 @@ SIGNATURES = {
     "fmri_noise_augment": [p, i64, i32, p, p, i32, f32, p],
     "fmri_shot_noise_step": [p, i64, i32, p, p, p, p, i32, p],
     "fmri_correlate1d_f32": [p, p, i32, i32, i32, i32, p, i32, i32, p],
+    "fmri_elastic_warp": [p, i32, i32, i32, i32, i32, p, p, i32, p, i32, p],
+    "fmri_coarse_dropout": [p, i32, i32, i32, i32, i32, p, i32, i32, i32, p, p],
     "fmri_avgpool3d_2x_fwd": [p, p, i32, i32, i32, i32, i32, i32, i32, p],
     "fmri_avgpool3d_2x_bwd": [p, p, i32, i32, i32, i32, i32, i32, i32, p],
     "fmri_global_avgpool_fwd": [p, p, i32, i64, i32, i32, p],

@@ -783,6 +783,68 @@ def gaussian_filter_f32(patch, sigma, truncate=4.0, mode="nearest"):
     return a
 
 
+def elastic_ksize(sigma):
+    """imgaug 0.4.0 blur.py `_compute_gaussian_blur_ksize` + the odd-size rule of `blur_gaussian_`: width of the truncated Gaussian kernel"""
+    k = 3.3 * sigma if sigma < 3.0 else (2.9 * sigma if sigma < 5.0 else 2.6 * sigma)
+    k = int(max(k, 5))
+    return k + 1 if k % 2 == 0 else k
+
+
+def elastic_fields(shape2d, alpha, sigma, generator=None, noise=None):
+    """-> (d0, d1): the displacement along axis 0 (imgaug's dy) and axis 1 (dx) of an X x Y image, fp32 device tensors.
+    imgaug 0.4.0 ElasticTransformation._generate_shift_maps: uniform(-1, 1) noise on the image padded by the kernel width on every side
+    (one draw of (2 * h_pad, w_pad): dx from the first half, dy from the second), blurred with the truncated normalised Gaussian kernel
+    (cv2.GaussianBlur(ksize, sigma)), times alpha, padding cropped - the border mode never reaches the kept part.  `noise`: the draw itself
+    (fp32 device tensor (2, h_pad, w_pad), block 0 = dx) instead of the device generator's (tests feed the oracle's)."""
+    import numpy as np
+    X, Y = int(shape2d[0]), int(shape2d[1])
+    k = elastic_ksize(float(sigma))
+    hp, wp = X + 2 * k, Y + 2 * k
+    if noise is None:
+        dev = torch.device("cuda", torch.cuda.current_device()) if generator is None else generator.device
+        noise = torch.rand((2, hp, wp), device=dev, dtype=torch.float32, generator=generator) * 2 - 1
+    _need_cuda(noise)
+    assert tuple(noise.shape) == (2, hp, wp) and noise.dtype == torch.float32 and noise.is_contiguous()
+    xs = np.arange(k, dtype=np.float64) - (k - 1) / 2.0
+    w = np.exp(-(xs * xs) / (2.0 * float(sigma) ** 2))
+    wd = torch.from_numpy(w / w.sum()).to(noise.device)
+    a = noise
+    for axis in (1, 2):
+        b = torch.empty_like(a)
+        check(lib().fmri_correlate1d_f32(_p(a), _p(b), 2, hp, wp, axis, _p(wd), k // 2, 0, _s()), "fmri_correlate1d_f32")
+        a = b
+    f = a[:, k:k + X, k:k + Y] * float(alpha)
+    return f[1].contiguous(), f[0].contiguous()
+
+
+def elastic_warp(src, d0, d1, order, out):
+    """out[i, j, c] = src[:, :, c] at (i - d0[i, j], j - d1[i, j]), order 0 / 1, mode 'nearest' (fmri_elastic_warp); src, out: (X, Y, C) float32 or
+    uint8 device tensors whose last axis may be a view into a wider row (stride(1) = row length)."""
+    _need_cuda(d0, d1)
+    if not src.is_cuda or not out.is_cuda:
+        raise RuntimeError("fmri_hip ops need device tensors (no CPU path)")
+    X, Y, C = src.shape
+    assert tuple(out.shape) == (X, Y, C) and out.dtype == src.dtype and tuple(d0.shape) == (X, Y) == tuple(d1.shape)
+    assert d0.dtype == torch.float32 and d1.dtype == torch.float32
+    for t in (src, out):
+        assert t.stride(2) == 1 and t.stride(0) == Y * t.stride(1), "rows of equal length, channels contiguous"
+    check(lib().fmri_elastic_warp(_p(src), _dt_any(src), X, Y, C, int(src.stride(1)), _p(d0), _p(d1), int(order), _p(out), int(out.stride(1)), _s()),
+          "fmri_elastic_warp")
+    return out
+
+
+def coarse_dropout(x, keep, stats, per_channel=True):
+    """in place on x (X, Y, C) fp32 / bf16 (last axis may be a view into a wider row): voxels whose cell of `keep` (uint8 (hs, ws, C) or (hs, ws, 1))
+    is 0 take stats[0] (= minmax(x) before the call)"""
+    _need_cuda(keep, stats)
+    X, Y, C = x.shape
+    hs, ws, kc = keep.shape
+    assert keep.dtype == torch.uint8 and keep.is_contiguous() and kc == (C if per_channel else 1)
+    assert x.stride(2) == 1 and x.stride(0) == Y * x.stride(1)
+    check(lib().fmri_coarse_dropout(_p(x), dt(x), X, Y, C, int(x.stride(1)), _p(keep), hs, ws, kc, _p(stats), _s()), "fmri_coarse_dropout")
+    return x
+
+
 def shot_noise(x, stats, generator=None, draws_fn=None):
     """reference augment.py:87-94 in place on `x` (fp32 / bf16 device tensor); `stats` = minmax(x) taken before the call.  The Poisson
     draws come from torch's device generator (`draws_fn(rates)` overrides them: tests feed the oracle's own draws)."""

@@ -353,6 +353,18 @@ int fmri_noise_augment(void* x, int64_t n, int dtype, const float* stats, const 
  * draws[t] ~ Poisson(rates[t]) (fp32, device).  stats = fmri_minmax of x before phase 0. */
 int fmri_shot_noise_step(void* x, int64_t n, int dtype, const float* stats, int* present, float* rates, const float* draws, int phase,
                          fmri_stream_t stream);
+/* imgaug ElasticTransformation as the reference applies it (fetal_net/augment.py:149-170; in the DEFAULT config, fetal/config_utils.py:104-107):
+ * dst[i][j][c] = src[:, :, c] sampled at (i - d0[i][j], j - d1[i][j]) - one in-plane displacement field for every slice c and for image, truth,
+ * previous-slice truth and mask alike; order 1 (image: bilinear) or 0 (labels: nearest, floor(c + 0.5)), mode 'nearest' (coordinates clamped).
+ * src, dst: [X][Y] rows of src_ld / dst_ld elements (>= C), dtype FMRI_F32 or FMRI_U8; d0, d1 fp32 [X][Y].  src != dst. */
+int fmri_elastic_warp(const void* src, int dtype, int X, int Y, int C, int src_ld, const float* d0, const float* d1, int order, void* dst,
+                      int dst_ld, fmri_stream_t stream);
+/* imgaug CoarseDropout as the reference applies it (fetal_net/augment.py:116-120, :373-375; DEFAULT config, config_utils.py:109-113): a voxel
+ * whose cell of the low-resolution grid keep[hs][ws][kc] (uint8; kc = C: one grid per slice = per_channel, or 1) is 0 takes the patch minimum
+ * (0 in the reference's [0, 255] scaling); the grid is enlarged by nearest neighbour, source index = min(floor(i * hs / X), hs - 1).
+ * stats = fmri_minmax of x before the call.  In place; dtype FMRI_F32 or FMRI_BF16. */
+int fmri_coarse_dropout(void* x, int dtype, int X, int Y, int C, int ld, const uint8_t* keep, int hs, int ws, int kc, const float* stats,
+                        fmri_stream_t stream);
 /* one axis of skimage.filters.gaussian on an fp32 patch [X][Y][Z] (reference augment.py:113-114): weights fp64 [2*radius+1] on the device,
  * sums in fp64 in scipy's order, result rounded to fp32; mode 0 = 'reflect', 1 = 'nearest' (skimage's default).  src != dst. */
 int fmri_correlate1d_f32(const float* src, float* dst, int X, int Y, int Z, int axis, const double* weights, int radius, int mode,

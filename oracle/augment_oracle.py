@@ -20,6 +20,11 @@ sklearn-style MinMaxScaler over the whole array (reference utils.py:116-313).  P
 the reference's own contrast_augment / add_gaussian_noise / add_speckle_noise / shot_noise / apply_gaussian_filter run over
 scikit-image 0.18.3 and scikit-learn 0.24.2 (generator tests/golden/make_skimage_fixture.py, run under the container's conda
 interpreter); tests/test_oracle_augment.py checks every restatement below against them.
+PARITY UNPINNED for the two imgaug augmenters (elastic_*, coarse_dropout below): the reference's requirements.txt names `imgaug` without a
+version and the package is installed nowhere here, so there is neither a fixture nor a run of the reference to pin them to.  They restate
+imgaug 0.4.0 (the last release) as published - augmenters/geometric.py ElasticTransformation (`_generate_shift_maps`, `_map_coordinates`),
+augmenters/blur.py `blur_gaussian_` / `_compute_gaussian_blur_ksize`, augmenters/arithmetic.py CoarseDropout = MultiplyElementwise over
+parameters.FromLowerResolution(Binomial(1 - p)) - anchored on the reference's call sites (fetal_net/augment.py:116-120, :149-170, :373-375).
 """
 import itertools
 import random
@@ -120,6 +125,79 @@ def apply_gaussian_filter(data, sigma):
     if data.ndim == 3 and data.shape[-1] == 3:
         sig[-1] = 0
     return ndimage.gaussian_filter(data, sig, mode="nearest", truncate=4.0)
+
+
+# ------------------------------------------------------------------------------------------------ imgaug (parity unpinned, see the header)
+def elastic_ksize(sigma):
+    """blur.py `_compute_gaussian_blur_ksize` (3.3 / 2.9 / 2.6 sigma: 99 / 97 / 95 % of the weight; at least 5) made odd as `blur_gaussian_` does"""
+    k = 3.3 * sigma if sigma < 3.0 else (2.9 * sigma if sigma < 5.0 else 2.6 * sigma)
+    k = int(max(k, 5))
+    return k + 1 if k % 2 == 0 else k
+
+
+def elastic_shift_maps(shape2d, alpha, sigma, noise):
+    """geometric.py `_generate_shift_maps`: `noise` = random_state.random((2 * h_pad, w_pad)) * 2 - 1 with h_pad = h + 2 * ksize (given as
+    (2, h_pad, w_pad): block 0 = dx); each block blurred by cv2.GaussianBlur((ksize, ksize), sigma) - a separable correlation with
+    exp(-x^2 / 2 sigma^2) / sum on ksize taps - times alpha, padding cropped.  -> (dx, dy): displacement along axis 1, along axis 0"""
+    h, w = shape2d
+    k = elastic_ksize(sigma)
+    noise = np.asarray(noise, dtype=np.float64)
+    assert noise.shape == (2, h + 2 * k, w + 2 * k)
+    xs = np.arange(k, dtype=np.float64) - (k - 1) / 2.0
+    wt = np.exp(-(xs * xs) / (2.0 * sigma * sigma))
+    wt /= wt.sum()
+    out = []
+    for blk in noise:
+        b = ndimage.correlate1d(ndimage.correlate1d(blk, wt, axis=0, mode="mirror"), wt, axis=1, mode="mirror")     # BORDER_REFLECT_101; cropped away
+        out.append(b[k:k + h, k:k + w] * alpha)
+    return out[0], out[1]
+
+
+def elastic_apply(image, dx, dy, order):
+    """geometric.py `_map_coordinates`: every channel image[:, :, c] sampled at (y - dy, x - dx), scipy map_coordinates(order, mode='nearest')
+    (the reference passes mode="nearest", order 1 for the volume and 0 for truth / previous truth / mask, augment.py:151-168)"""
+    image = np.asarray(image)
+    h, w = image.shape[:2]
+    yy, xx = np.meshgrid(np.arange(h, dtype=np.float64), np.arange(w, dtype=np.float64), indexing="ij")
+    coords = np.stack([yy - dy, xx - dx])
+    out = np.empty(image.shape, dtype=np.float64)
+    for c in range(image.shape[2]):
+        out[:, :, c] = map_coordinates(image[:, :, c].astype(np.float64), coords, order=order, mode="nearest")
+    return out
+
+
+def coarse_dropout(data, keep_small):
+    """reference augment.py:116-120: MinMaxScaler((0, 255)) over the whole array, imgaug CoarseDropout, inverse scaling.  `keep_small`: the
+    Binomial(1 - rate) draw on the low-resolution grid (hs, ws, C) or (hs, ws, 1) (hs = int(h * size_percent), at least 1; size_percent drawn
+    per axis); enlarged to (h, w) by nearest neighbour as cv2.resize does (source index = min(floor(i * hs / h), hs - 1)); the image is
+    multiplied by it, so a dropped voxel is 0 in the scaled range = the array's minimum"""
+    data = np.asarray(data, dtype=np.float64)
+    h, w, c = data.shape
+    hs, ws, kc = keep_small.shape
+    si = np.minimum(np.floor(np.arange(h) * (hs / h)).astype(int), hs - 1)
+    sj = np.minimum(np.floor(np.arange(w) * (ws / w)).astype(int), ws - 1)
+    up = keep_small[si][:, sj]                                       # (h, w, kc)
+    dmin, dmax = float(data.min()), float(data.max())
+    rng = dmax - dmin
+    scale = 255.0 / (rng if rng != 0 else 1.0)
+    mn = 0.0 - dmin * scale
+    scaled = (data * scale + mn) * up
+    return (scaled - mn) / scale
+
+
+def coarse_dropout_grid(shape2d, size_percent, rng):
+    """parameters.FromLowerResolution.draw_samples: one size_percent per axis (a list = a choice among its values, a tuple = uniform, a number
+    = itself), grid = int(extent * percent), at least 1"""
+    out = []
+    for extent in shape2d:
+        if isinstance(size_percent, list):
+            sp = size_percent[int(rng.randint(len(size_percent)))]
+        elif isinstance(size_percent, tuple):
+            sp = rng.uniform(size_percent[0], size_percent[1])
+        else:
+            sp = size_percent
+        out.append(max(int(extent * sp), 1))
+    return tuple(out)
 
 
 # ------------------------------------------------------------------------------------------------ augment_data

@@ -258,3 +258,129 @@ def test_device_generator_applies_gaussian_filter_and_poisson_noise():
     rough = lambda a: np.abs(np.diff(a, axis=2)).mean()
     assert not np.allclose(xp, xa)
     assert xa.min() >= xp.min() - 1e-3 * abs(xp.min()) - 1e-3 and xa.max() <= xp.max() + 1e-3 * abs(xp.max()) + 1e-3      # smoothing + clipped noise stay in range
+
+
+# ---------------------------------------------------------------------------------------------- imgaug's augmenters (oracle: parity unpinned)
+@pytest.mark.parametrize("seed,shape,sigma,alpha", [(0, (64, 48, 5), 10.0, 5.0), (1, (33, 70, 3), 2.0, 40.0), (2, (40, 40, 1), 4.0, 120.0)])
+def test_elastic_fields_and_warp_vs_oracle(ops, seed, shape, sigma, alpha):
+    """same uniform noise -> same displacement fields (fp32 correlation on the device, fp64 in the oracle); same fields -> the warped image
+    (bilinear) to 1e-6 of its range and the warped labels (nearest) bit for bit, also into a strided destination slot"""
+    from oracle import augment_oracle as AO
+    rs = np.random.RandomState(seed)
+    X, Y, C = shape
+    k = AO.elastic_ksize(sigma)
+    assert k == ops.elastic_ksize(sigma) and k % 2 == 1
+    noise = (rs.rand(2, X + 2 * k, Y + 2 * k) * 2 - 1).astype(np.float32)
+    dx, dy = AO.elastic_shift_maps((X, Y), alpha, sigma, noise)
+    d0, d1 = ops.elastic_fields((X, Y), alpha, sigma, noise=torch.from_numpy(noise).cuda())
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(d0.cpu().numpy(), dy, rtol=0, atol=2e-6 * alpha)
+    np.testing.assert_allclose(d1.cpu().numpy(), dx, rtol=0, atol=2e-6 * alpha)
+    assert np.abs(dx).max() > 0.05                                     # a field that moves something
+    # warp with the DEVICE's fields on both sides (the oracle takes them as float64)
+    f0, f1 = d0.cpu().numpy().astype(np.float64), d1.cpu().numpy().astype(np.float64)
+    img = rs.randn(X, Y, C).astype(np.float32)
+    lab = (rs.rand(X, Y, C) > 0.6).astype(np.uint8)
+    want_img, want_lab = AO.elastic_apply(img, f1, f0, 1), AO.elastic_apply(lab, f1, f0, 0)
+    wide = torch.full((X, Y, C + 2), -7.0, device="cuda")              # destination = the first C channels of a wider row
+    ops.elastic_warp(torch.from_numpy(img).cuda(), d0, d1, 1, wide[..., :C])
+    got_lab = ops.elastic_warp(torch.from_numpy(lab).cuda(), d0, d1, 0, torch.empty((X, Y, C), device="cuda", dtype=torch.uint8))
+    torch.cuda.synchronize()
+    w = wide.cpu().numpy()
+    np.testing.assert_allclose(w[..., :C], want_img, rtol=0, atol=2e-6 * float(np.abs(img).max()))
+    assert (w[..., C:] == -7.0).all()
+    # nearest: a coordinate within 1e-6 of a half-integer may round either way in fp32-derived fields; none do here
+    assert np.array_equal(got_lab.cpu().numpy(), want_lab.astype(np.uint8))
+
+
+def test_elastic_zero_field_is_the_identity_and_borders_clamp(ops):
+    X, Y, C = 12, 9, 2
+    img = torch.randn(X, Y, C, device="cuda")
+    z = torch.zeros(X, Y, device="cuda")
+    out = ops.elastic_warp(img, z, z, 1, torch.empty_like(img))
+    assert torch.equal(out, img)
+    far = torch.full((X, Y), 100.0, device="cuda")                     # every voxel reads from beyond the top-left corner: clamped to it
+    out = ops.elastic_warp(img, far, far, 1, torch.empty_like(img))
+    assert torch.equal(out, img[0:1, 0:1, :].expand(X, Y, C))
+
+
+@pytest.mark.parametrize("per_channel", [True, False])
+def test_coarse_dropout_vs_oracle(ops, per_channel):
+    from oracle import augment_oracle as AO
+    rs = np.random.RandomState(3)
+    X, Y, C = 50, 37, 6
+    img = (rs.randn(X, Y, C) * 3 + 1).astype(np.float32)
+    hs, ws = AO.coarse_dropout_grid((X, Y), [0.10, 0.30], rs)
+    assert hs in (5, 15) and ws in (3, 11)
+    keep = (rs.rand(hs, ws, C if per_channel else 1) >= 0.2).astype(np.uint8)
+    want = AO.coarse_dropout(img, keep)
+    x = torch.from_numpy(img).cuda()
+    stats = torch.empty(2, device="cuda")
+    ops.minmax(x, stats)
+    ops.coarse_dropout(x, torch.from_numpy(keep).cuda(), stats, per_channel)
+    torch.cuda.synchronize()
+    got = x.cpu().numpy()
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-6 * float(np.abs(img).max()))
+    dropped = got == img.min()
+    assert 0.05 < dropped.mean() < 0.45 and np.array_equal(got[~dropped], img[~dropped])       # kept voxels are untouched, bit for bit
+
+
+def test_device_generator_runs_the_reference_default_augmentation_without_warnings():
+    """fetal/config_utils.py:81-123 verbatim: elastic transform and coarse dropout included - no 'not applied' warning; labels stay binary,
+    the image stays inside the volume's range, about `rate` of the voxels sit at the patch minimum; piecewise_affine still warns"""
+    import warnings
+    from fetal_net.device_generator import device_data_generator
+    default = {"flip": [0.5, 0.5, 0.5], "permute": False, "translate": (15, 15, 7), "scale": (0.1, 0.1, 0), "rotate": (0, 0, 90), "poisson_noise": 1,
+               "gaussian_filter": {"prob": 0.0, "max_sigma": 1}, "contrast": {"prob": 0, "min_factor": 0.2, "max_factor": 0.1},
+               "elastic_transform": {"alpha": 5, "sigma": 10},
+               "coarse_dropout": {"rate": 0.2, "size_percent": [0.10, 0.30], "per_channel": True},
+               "gaussian_noise": {"prob": 0.5, "sigma": 0.05}, "speckle_noise": {"prob": 0.5, "sigma": 0.05}}
+    vols, truths = synth_volumes(3, [(72, 72, 40)])
+    df = FakeDataFile(vols, truths)
+    np.random.seed(5)
+    random.seed(5)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        gen = device_data_generator(df, [0], batch_size=2, augment=default, patch_shape=(48, 48, 16), skip_blank=False, categorical=False, is3d=True,
+                                    truth_index=0, truth_size=16, shuffle_index_list=False)
+        x, y = next(gen)
+        x2, _ = next(gen)
+    x, y = x.float().cpu().numpy(), y.cpu().numpy()
+    assert x.shape == (2, 1, 48, 48, 16) and np.isfinite(x).all() and set(np.unique(y)) <= {0, 1}
+    assert not np.array_equal(x, x2.float().cpu().numpy())
+    # the dropped share, measured without the geometric part (a rotated patch is also at the volume's minimum wherever it leaves the volume)
+    still = dict(default, rotate=None, translate=None, scale=None, flip=[0, 0, 0])
+    np.random.seed(6)
+    random.seed(6)
+    xs, _ = next(device_data_generator(df, [0], batch_size=4, augment=still, patch_shape=(48, 48, 16), skip_blank=False, categorical=False, is3d=True,
+                                       truth_index=0, truth_size=16, shuffle_index_list=False))
+    xs = xs.float().cpu().numpy()
+    at_min = float(np.mean([(xs[b] == xs[b].min()).mean() for b in range(4)]))
+    assert 0.10 < at_min < 0.32, at_min                               # Binomial(0.8) keeps on 4 / 14-cell grids, one per slice: 0.2 on average
+    with pytest.warns(UserWarning, match="piecewise_affine"):
+        next(device_data_generator(df, [0], batch_size=1, augment=dict(default, piecewise_affine={"scale": 2}), patch_shape=(48, 48, 16),
+                                   skip_blank=False, categorical=False, is3d=True, truth_index=0, truth_size=16, shuffle_index_list=False))
+
+
+def test_elastic_moves_image_and_labels_together():
+    """a strong field (alpha 300, sigma 6) through the generator: the label patch still marks the bright blob of the image patch - the
+    same field warps both (reference augment.py:149-170: four augmenters over one random state)"""
+    from fetal_net.device_generator import device_data_generator
+    rs = np.random.RandomState(0)
+    X = 64
+    g = np.stack(np.meshgrid(*[np.arange(X)] * 3, indexing="ij"))
+    blob = (((g[:2] - X / 2) ** 2).sum(0) < (X / 4) ** 2)           # a cylinder along z: every slice of any patch crosses its boundary
+    vol = blob * 4.0 + rs.randn(X, X, X) * 0.05
+    df = FakeDataFile([vol.astype(np.float32)], [blob.astype(np.uint8)])
+    outs = {}
+    for tag, aug in (("plain", {"flip": [0, 0, 0]}), ("elastic", {"flip": [0, 0, 0], "elastic_transform": {"alpha": 600, "sigma": 6}})):
+        np.random.seed(1)
+        random.seed(1)
+        gen = device_data_generator(df, [0], batch_size=1, augment=aug, patch_shape=(48, 48, 8), skip_blank=False, categorical=False, is3d=True,
+                                    truth_index=0, truth_size=8, shuffle_index_list=False, noise_seed=4)
+        x, y = next(gen)
+        outs[tag] = (x.float().cpu().numpy()[0, 0], y.cpu().numpy()[0, 0])
+    (xp, yp), (xe, ye) = outs["plain"], outs["elastic"]
+    assert (yp != ye).mean() > 0.005                                   # the field moved the boundary
+    agree = ((xe > 2.0) == (ye > 0)).mean()
+    assert agree > 0.985, agree                                        # bilinear image vs nearest label: they differ on the boundary voxels only

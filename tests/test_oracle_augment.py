@@ -182,3 +182,63 @@ def test_gaussian_filter_matches_skimage_filters_gaussian(golden_dir):
     got = A.apply_gaussian_filter(vol, 1.0)
     from scipy import ndimage
     assert np.allclose(got, ndimage.gaussian_filter(vol, [1.0, 1.0, 0.0], mode="nearest", truncate=4.0))
+
+
+# ---------------------------------------------------------------------------------------------- imgaug restatements (PARITY UNPINNED)
+# imgaug is neither pinned by the reference (requirements.txt: "imgaug") nor installed anywhere here: no fixture can exist.  These tests
+# hold the restatements (imgaug 0.4.0 as published) to their own definitions, written out differently.
+def test_elastic_shift_maps_are_a_truncated_gaussian_blur_of_the_padded_noise():
+    rs = np.random.RandomState(0)
+    h, w, sigma, alpha = 20, 17, 3.0, 7.0
+    k = A.elastic_ksize(sigma)
+    assert (A.elastic_ksize(1.0), A.elastic_ksize(2.0), k, A.elastic_ksize(4.0), A.elastic_ksize(10.0)) == (5, 7, 9, 11, 27)
+    noise = rs.rand(2, h + 2 * k, w + 2 * k) * 2 - 1
+    dx, dy = A.elastic_shift_maps((h, w), alpha, sigma, noise)
+    xs = np.arange(k) - (k - 1) / 2
+    g = np.exp(-xs ** 2 / (2 * sigma ** 2))
+    g /= g.sum()
+    K = np.outer(g, g)
+    r = k // 2
+    for blk, got in ((noise[0], dx), (noise[1], dy)):
+        for (i, j) in ((0, 0), (h - 1, w - 1), (7, 11)):
+            ci, cj = i + k, j + k                                     # the kept part starts `k` in: the kernel (radius k // 2) never leaves the padded block
+            want = (blk[ci - r:ci + r + 1, cj - r:cj + r + 1] * K).sum() * alpha
+            assert got[i, j] == pytest.approx(want, abs=1e-12)
+    # the reference's default (alpha <= 5, sigma 10) barely moves anything: smoothed uniform noise has a small standard deviation
+    big = rs.rand(2, 128 + 54, 128 + 54) * 2 - 1
+    ddx, _ = A.elastic_shift_maps((128, 128), 5.0, 10.0, big)
+    assert np.abs(ddx).max() < 0.6
+
+
+def test_elastic_apply_is_a_backward_warp_with_clamped_coordinates():
+    rs = np.random.RandomState(1)
+    img = rs.rand(9, 7, 2)
+    zero = np.zeros((9, 7))
+    assert np.array_equal(A.elastic_apply(img, zero, zero, 1), img) and np.array_equal(A.elastic_apply(img, zero, zero, 0), img)
+    one = np.ones((9, 7))
+    out = A.elastic_apply(img, one, zero, 1)                          # dx = 1: every voxel reads its left neighbour (x - dx), column 0 clamps
+    assert np.allclose(out[:, 1:], img[:, :-1]) and np.allclose(out[:, 0], img[:, 0])
+    half = np.full((9, 7), 0.5)
+    out = A.elastic_apply(img, zero, half, 1)                         # dy = 0.5: the mean of a voxel and the one above it
+    assert np.allclose(out[1:], 0.5 * (img[1:] + img[:-1]))
+    lab = (rs.rand(9, 7, 1) > 0.5).astype(np.uint8)
+    out0 = A.elastic_apply(lab, np.full((9, 7), 0.4), zero, 0)        # nearest: a shift of 0.4 rounds back to the voxel itself
+    assert np.array_equal(out0, lab)
+
+
+def test_coarse_dropout_enlarges_the_grid_by_nearest_neighbour_and_drops_to_the_minimum():
+    rs = np.random.RandomState(2)
+    data = rs.randn(10, 6, 3) * 2 + 5
+    keep = np.ones((3, 2, 3), dtype=np.uint8)
+    keep[1, 0, 2] = 0                                                  # grid cell (1, 0) of slice 2
+    out = A.coarse_dropout(data, keep)
+    rows = [i for i in range(10) if min(int(np.floor(i * 3 / 10)), 2) == 1]        # cv2.resize INTER_NEAREST: floor(i * hs / h)
+    assert rows == [4, 5, 6]
+    want = data.copy()
+    want[4:7, 0:3, 2] = data.min()
+    assert np.allclose(out, want, atol=1e-12)
+    both = A.coarse_dropout(data, np.zeros((1, 1, 1), dtype=np.uint8))
+    assert np.allclose(both, data.min())
+    g = [A.coarse_dropout_grid((128, 128), [0.10, 0.30], np.random.RandomState(s)) for s in range(20)]
+    assert set(v for pair in g for v in pair) == {12, 38}              # a list is a choice between its two values, per axis
+    assert A.coarse_dropout_grid((5, 5), 0.01, rs) == (1, 1)
