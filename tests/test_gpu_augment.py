@@ -384,3 +384,37 @@ def test_elastic_moves_image_and_labels_together():
     assert (yp != ye).mean() > 0.005                                   # the field moved the boundary
     agree = ((xe > 2.0) == (ye > 0)).mean()
     assert agree > 0.985, agree                                        # bilinear image vs nearest label: they differ on the boundary voxels only
+
+
+def test_elastic_warps_mask_and_previous_slice_truth_with_the_same_field():
+    """2-D flow with the previous-slice truth in the input channels and distance masks in the data file (reference generator.py:18-21,
+    :300-328): under a strong elastic field the previous-slice truth channel (a label slice) and the mask stay consistent with the warped
+    labels: with truth_index = prev_truth_index the extra input channel IS the label patch, and the mask of a binary 0 / 1 'mask volume'
+    equal to the labels IS the label patch as float"""
+    from fetal_net.device_generator import device_data_generator
+    X = 64
+    g = np.stack(np.meshgrid(*[np.arange(X)] * 3, indexing="ij"))
+    blob = (((g[:2] - X / 2) ** 2).sum(0) < (X / 4) ** 2)
+    vol = (blob * 4.0 + np.random.RandomState(0).randn(X, X, X) * 0.05).astype(np.float32)
+    lab = blob.astype(np.uint8)
+    pad = 3                                                             # samples_pad: labels are padded with the volumes, masks are not
+    mask = np.pad(lab.astype(np.float32), ((pad, pad), (pad, pad), (pad, pad)))
+    df = FakeDataFile([vol], [lab], [mask])
+    np.random.seed(3)
+    random.seed(3)
+    gen = device_data_generator(df, [0], batch_size=2, augment={"flip": [0, 0, 0], "elastic_transform": {"alpha": 600, "sigma": 6}},
+                                patch_shape=(48, 48, 5), skip_blank=False, categorical=False, is3d=False, truth_index=2, truth_size=1,
+                                prev_truth_index=2, prev_truth_size=1, shuffle_index_list=False, noise_seed=9)
+    (x, m), y = next(gen)
+    torch.cuda.synchronize()
+    x, m, y = x.cpu().numpy(), m.cpu().numpy(), y.cpu().numpy()
+    assert x.shape == (2, 48, 48, 6) and m.shape == (2, 48, 48, 1) and y.shape == (2, 48, 48, 1)
+    assert 0.02 < y.mean() < 0.98                                       # the patches cross the cylinder's boundary
+    assert np.array_equal(x[..., 5:6], y.astype(np.float32))             # previous-slice truth channel = the (warped) label slice
+    assert np.array_equal(m, y.astype(np.float32))                       # mask volume = labels: warped by the same field, same rounding
+    plain = device_data_generator(df, [0], batch_size=2, augment={"flip": [0, 0, 0]}, patch_shape=(48, 48, 5), skip_blank=False, categorical=False,
+                                  is3d=False, truth_index=2, truth_size=1, prev_truth_index=2, prev_truth_size=1, shuffle_index_list=False)
+    np.random.seed(3)
+    random.seed(3)
+    (_, _), y0 = next(plain)
+    assert (y0.cpu().numpy() != y).mean() > 0.003                        # and the field did move the labels
