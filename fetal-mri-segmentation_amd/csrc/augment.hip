@@ -206,6 +206,37 @@ __global__ void k_elastic_warp(const T* __restrict__ src, int X, int Y, int C, i
     }
 }
 
+// imgaug PiecewiseAffine with the reference's 2 x 2 grid (fetal_net/augment.py:131-146: nb_rows = nb_cols = 2): the four image corners move, skimage's
+// PiecewiseAffineTransform triangulates the SOURCE corners (scipy Delaunay: the diagonal (0,0) - (h,w); simplices {p3,p2,p0} and {p1,p3,p0}) and
+// warp() reads output pixel (i, j) from tri(i, j) . (i, j, 1): triangle 0 where j * X <= i * Y (below the diagonal), else triangle 1.  Sampling as
+// k_affine_sample (scipy map_coordinates mode 'constant', cval 0: no interpolation beyond the edges), per slice c.  m: 2 x (2 x 3) fp64.
+struct Pw2 { double m[12]; };
+template <typename T>
+__global__ void k_piecewise_affine2(const T* __restrict__ src, int X, int Y, int C, int src_ld, Pw2 P, int order, T* __restrict__ dst, int dst_ld) {
+    const int64_t total = (int64_t)X * Y * C;
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(t % C);
+        const int64_t ij = t / C;
+        const int j = (int)(ij % Y), i = (int)(ij / Y);
+        const double* m = P.m + (((int64_t)j * X <= (int64_t)i * Y) ? 0 : 6);
+        const double ci = m[0] * i + m[1] * j + m[2], cj = m[3] * i + m[4] * j + m[5];
+        float v = 0.f;
+        if (ci >= 0.0 && ci <= (double)(X - 1) && cj >= 0.0 && cj <= (double)(Y - 1)) {
+            if (order == 0) {
+                v = ld_any<T>(src, ((int64_t)floor(ci + 0.5) * Y + (int64_t)floor(cj + 0.5)) * src_ld + c);
+            } else {
+                const int i0 = (int)floor(ci), j0 = (int)floor(cj);
+                const double ti = ci - i0, tj = cj - j0;
+                const int i1 = min(i0 + 1, X - 1), j1 = min(j0 + 1, Y - 1);
+                const double v00 = ld_any<T>(src, ((int64_t)i0 * Y + j0) * src_ld + c), v01 = ld_any<T>(src, ((int64_t)i0 * Y + j1) * src_ld + c);
+                const double v10 = ld_any<T>(src, ((int64_t)i1 * Y + j0) * src_ld + c), v11 = ld_any<T>(src, ((int64_t)i1 * Y + j1) * src_ld + c);
+                v = (float)((1.0 - ti) * ((1.0 - tj) * v00 + tj * v01) + ti * ((1.0 - tj) * v10 + tj * v11));
+            }
+        }
+        st_any<T>(dst, ij * dst_ld + c, v);
+    }
+}
+
 // Coarse dropout: x[i][j][c] keeps its value where the low-resolution mask keep[hs][ws][kc] (kc = C: one grid per slice, or 1), enlarged to
 // X x Y by nearest neighbour the way cv2.resize(INTER_NEAREST) does it (source index = min(floor(dst * hs / X), hs - 1)), is 1; a dropped
 // voxel becomes 0 in the reference's [0, 255] min-max scaling, i.e. the patch's minimum (stats[0] = fmri_minmax of x before the call).
@@ -245,6 +276,20 @@ extern "C" int fmri_elastic_warp(const void* src, int dtype, int X, int Y, int C
     const int grid = grid_for((int64_t)X * Y * C);
     if (dtype == FMRI_F32) k_elastic_warp<float><<<grid, 256, 0, st>>>((const float*)src, X, Y, C, src_ld, d0, d1, order, (float*)dst, dst_ld);
     else if (dtype == FMRI_U8) k_elastic_warp<uint8_t><<<grid, 256, 0, st>>>((const uint8_t*)src, X, Y, C, src_ld, d0, d1, order, (uint8_t*)dst, dst_ld);
+    else return FMRI_E_DTYPE;
+    FMRI_LAUNCH_CHECK();
+    return FMRI_OK;
+}
+
+extern "C" int fmri_piecewise_affine2(const void* src, int dtype, int X, int Y, int C, int src_ld, const double* tri, int order, void* dst, int dst_ld,
+                                     fmri_stream_t stream) {
+    if (X < 1 || Y < 1 || C < 1 || src_ld < C || dst_ld < C || (order != 0 && order != 1) || !tri || src == dst) return FMRI_E_SHAPE;
+    Pw2 P;
+    for (int i = 0; i < 12; ++i) P.m[i] = tri[i];
+    hipStream_t st = as_stream(stream);
+    const int grid = grid_for((int64_t)X * Y * C);
+    if (dtype == FMRI_F32) k_piecewise_affine2<float><<<grid, 256, 0, st>>>((const float*)src, X, Y, C, src_ld, P, order, (float*)dst, dst_ld);
+    else if (dtype == FMRI_U8) k_piecewise_affine2<uint8_t><<<grid, 256, 0, st>>>((const uint8_t*)src, X, Y, C, src_ld, P, order, (uint8_t*)dst, dst_ld);
     else return FMRI_E_DTYPE;
     FMRI_LAUNCH_CHECK();
     return FMRI_OK;

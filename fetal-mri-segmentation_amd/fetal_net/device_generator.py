@@ -12,13 +12,13 @@ yield ([x, masks], y) like the reference's convert_data (generator.py:397-401): 
 = 0, same transformation) at the label slices.  As in the reference the masks are NOT padded with the volumes.
 
 `device_data_generator` keeps the keyword arguments of the reference's `data_generator` (generator.py:222-225).
-Applied augmenters: flip, scale, iso_scale, rotate, translate, elastic_transform (imgaug ElasticTransformation), contrast,
+Applied augmenters: flip, scale, iso_scale, rotate, translate, piecewise_affine, elastic_transform (imgaug), contrast,
 intensity_multiplication, gaussian_filter (skimage.filters.gaussian), poisson_noise (the reference's shot_noise), speckle_noise,
 gaussian_noise, coarse_dropout (imgaug CoarseDropout) - in the reference's order (augment.py:344-375), i.e. everything the reference's
-default config switches on (fetal/config_utils.py:81-123).  The two imgaug augmenters follow imgaug 0.4.0 as published (the reference
+default config switches on (fetal/config_utils.py:81-123).  The three imgaug augmenters follow imgaug 0.4.0 as published (the reference
 does not pin a version and the package is not installed here: their oracle says "parity unpinned", oracle/augment_oracle.py).
-Not applied (its random draw is still consumed so that the affine part stays aligned with a seeded reference run): imgaug's
-piecewise_affine (commented out in the reference's default config) - a warning is issued once, or NotImplementedError with strict=True.
+imgaug's piecewise_affine (commented out in the reference's default config, config_utils.py:101-103) is applied as well when configured,
+between the affine sampling and the elastic transform (augment.py:344-347), on the reference's 2 x 2 grid.
 The noise fields (normal, uniform and Poisson draws) come from a torch device generator (`noise_seed`), not numpy.
 """
 import random
@@ -28,7 +28,7 @@ import numpy as np
 
 from .augment import distort_image, draw_augment_parameters
 
-_UNSUPPORTED = ("piecewise_affine",)        # imgaug's PiecewiseAffine (commented out in the reference's default config, config_utils.py:101-103)
+_UNSUPPORTED = ()                          # every augmenter of reference augment.py:222-377 is applied
 
 
 class DeviceDataFile(object):
@@ -157,21 +157,32 @@ class _Sampler(object):
             p, A, At, Am = None, np.eye(4), np.eye(4), np.eye(4)
         # elastic transform (reference augment.py:349-353, imgaug ElasticTransformation): ONE in-plane displacement field for every slice and for
         # image (bilinear), truth, previous-slice truth and mask (nearest) - the affine samples land in scratch tensors and are warped into the slots
-        elastic = None
+        # piecewise affine (augment.py:344-347, imgaug PiecewiseAffine on a 2 x 2 grid: the four corners move by Normal(0, scale) of the extent,
+        # clipped to the image; two triangles), then the elastic transform - each a resampling of its own, as in the reference
+        elastic, corners = None, None
+        if p is not None and p["piecewise_affine_scale"] > 0:
+            h, w = float(ps[0]), float(ps[1])
+            src = np.array([[0, 0], [0, w], [h, 0], [h, w]], dtype=np.float64)
+            corners = src + self.host_rng.normal(0.0, p["piecewise_affine_scale"], size=(4, 2)) * np.array([h, w])
+            corners[:, 0] = np.clip(corners[:, 0], 0, h - 1)
+            corners[:, 1] = np.clip(corners[:, 1], 0, w - 1)
         if p is not None and p["elastic_transform_scale"] > 0:
             elastic = ops.elastic_fields((ps[0], ps[1]), p["elastic_transform_scale"], self.augment["elastic_transform"]["sigma"], generator=self.gen)
+        warped = elastic is not None or corners is not None
 
         def target(slot, shape, dtype):
-            return slot if elastic is None else self.torch.empty(shape, device=slot.device, dtype=dtype)
+            return slot if not warped else self.torch.empty(shape, device=slot.device, dtype=dtype)
 
         def settle(tmp, slot, order):
+            if corners is not None:
+                tmp = ops.piecewise_affine(tmp, corners, order, slot if elastic is None else self.torch.empty_like(tmp))
             if elastic is not None:
                 ops.elastic_warp(tmp, elastic[0], elastic[1], order, slot)
 
         tshape = (ps[0], ps[1], self.truth_size)
         # image: trilinear, outside = the volume's minimum; labels: nearest, outside = 0 (identity affine = the plain crop)
         xt = target(x_slot[..., :ps[2]], ps, self.torch.float32)
-        ops.affine_sample(data, A, corner, ps, xt, order=1, cval=ddf.min[index], out_ld=self.n_chan if elastic is None else ps[2])
+        ops.affine_sample(data, A, corner, ps, xt, order=1, cval=ddf.min[index], out_ld=self.n_chan if not warped else ps[2])
         settle(xt, x_slot[..., :ps[2]], 1)
         yt = target(y_slot, tshape, self.torch.uint8)
         ops.affine_sample(truth, At, (corner[0], corner[1], zt), tshape, yt, order=0, cval=0.0, out_ld=self.truth_size)
@@ -220,6 +231,8 @@ class _Sampler(object):
             zp = corner[2] + self.prev_truth_index
             prev = self.torch.empty((ps[0], ps[1], self.prev_truth_size), device=x_slot.device, dtype=self.torch.float32)
             ops.affine_sample(truth, At, (corner[0], corner[1], zp), (ps[0], ps[1], self.prev_truth_size), prev, order=0, cval=0.0)
+            if corners is not None:
+                prev = ops.piecewise_affine(prev, corners, 0, self.torch.empty_like(prev))
             if elastic is not None:
                 prev = ops.elastic_warp(prev, elastic[0], elastic[1], 0, self.torch.empty_like(prev))
             x_slot[..., ps[2]:] = prev

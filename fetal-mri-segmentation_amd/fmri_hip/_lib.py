@@ -100,6 +100,7 @@ SIGNATURES = {
     "fmri_correlate1d_f32": [p, p, i32, i32, i32, i32, p, i32, i32, p],
     "fmri_elastic_warp": [p, i32, i32, i32, i32, i32, p, p, i32, p, i32, p],
     "fmri_coarse_dropout": [p, i32, i32, i32, i32, i32, p, i32, i32, i32, p, p],
+    "fmri_piecewise_affine2": [p, i32, i32, i32, i32, i32, p, i32, p, i32, p],
     "fmri_avgpool3d_2x_fwd": [p, p, i32, i32, i32, i32, i32, i32, i32, p],
     "fmri_avgpool3d_2x_bwd": [p, p, i32, i32, i32, i32, i32, i32, i32, p],
     "fmri_global_avgpool_fwd": [p, p, i32, i64, i32, i32, p],

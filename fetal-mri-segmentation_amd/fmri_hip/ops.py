@@ -833,6 +833,35 @@ def elastic_warp(src, d0, d1, order, out):
     return out
 
 
+def piecewise_affine_matrices(shape2d, dest_yx):
+    """the two triangle maps of imgaug PiecewiseAffine(nb_rows=2, nb_cols=2): corners (0,0), (0,w), (h,0), (h,w) (y, x) moved to dest_yx (4, 2);
+    triangle 0 = {p0, p2, p3}: in = d0 + (y/h)(d2 - d0) + (x/w)(d3 - d2); triangle 1 = {p0, p1, p3}: in = d0 + (x/w)(d1 - d0) + (y/h)(d3 - d1).
+    -> 12 floats: per triangle (row_in = a i + b j + c), (col_in = a i + b j + c)"""
+    import numpy as np
+    h, w = float(shape2d[0]), float(shape2d[1])
+    d = np.asarray(dest_yx, dtype=np.float64)
+    out = []
+    for (dy, dx) in (((d[2] - d[0]) / h, (d[3] - d[2]) / w), ((d[3] - d[1]) / h, (d[1] - d[0]) / w)):
+        out += [dy[0], dx[0], d[0][0], dy[1], dx[1], d[0][1]]
+    return np.asarray(out, dtype=np.float64)
+
+
+def piecewise_affine(src, dest_yx, order, out):
+    """out[i, j, c] = src[:, :, c] at the piecewise-affine image of (i, j) (fmri_piecewise_affine2); dest_yx: the moved corners, host (4, 2)"""
+    import ctypes
+    if not src.is_cuda or not out.is_cuda:
+        raise RuntimeError("fmri_hip ops need device tensors (no CPU path)")
+    X, Y, C = src.shape
+    assert tuple(out.shape) == (X, Y, C) and out.dtype == src.dtype
+    for t in (src, out):
+        assert t.stride(2) == 1 and t.stride(0) == Y * t.stride(1), "rows of equal length, channels contiguous"
+    m = piecewise_affine_matrices((X, Y), dest_yx)
+    arr = (ctypes.c_double * 12)(*m.tolist())
+    check(lib().fmri_piecewise_affine2(_p(src), _dt_any(src), X, Y, C, int(src.stride(1)), ctypes.cast(arr, ctypes.c_void_p), int(order), _p(out),
+                                       int(out.stride(1)), _s()), "fmri_piecewise_affine2")
+    return out
+
+
 def coarse_dropout(x, keep, stats, per_channel=True):
     """in place on x (X, Y, C) fp32 / bf16 (last axis may be a view into a wider row): voxels whose cell of `keep` (uint8 (hs, ws, C) or (hs, ws, 1))
     is 0 take stats[0] (= minmax(x) before the call)"""

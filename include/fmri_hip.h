@@ -359,6 +359,12 @@ int fmri_shot_noise_step(void* x, int64_t n, int dtype, const float* stats, int*
  * src, dst: [X][Y] rows of src_ld / dst_ld elements (>= C), dtype FMRI_F32 or FMRI_U8; d0, d1 fp32 [X][Y].  src != dst. */
 int fmri_elastic_warp(const void* src, int dtype, int X, int Y, int C, int src_ld, const float* d0, const float* d1, int order, void* dst,
                       int dst_ld, fmri_stream_t stream);
+/* imgaug PiecewiseAffine on the reference's 2 x 2 grid (fetal_net/augment.py:131-146; commented out in the default config): output pixel (i, j) of
+ * every slice reads the source at tri_t . (i, j, 1), t = 0 where j * X <= i * Y (the triangle below the diagonal (0,0) - (X,Y) of skimage's Delaunay
+ * triangulation of the four corners), else t = 1; tri: 2 x (2 x 3) fp64 on the HOST, rows = (source row, source column).  order 1 / 0, scipy
+ * map_coordinates mode 'constant' with cval 0 (imgaug's defaults).  dtype FMRI_F32 or FMRI_U8; src != dst. */
+int fmri_piecewise_affine2(const void* src, int dtype, int X, int Y, int C, int src_ld, const double* tri, int order, void* dst, int dst_ld,
+                           fmri_stream_t stream);
 /* imgaug CoarseDropout as the reference applies it (fetal_net/augment.py:116-120, :373-375; DEFAULT config, config_utils.py:109-113): a voxel
  * whose cell of the low-resolution grid keep[hs][ws][kc] (uint8; kc = C: one grid per slice = per_channel, or 1) is 0 takes the patch minimum
  * (0 in the reference's [0, 255] scaling); the grid is enlarged by nearest neighbour, source index = min(floor(i * hs / X), hs - 1).

@@ -20,11 +20,12 @@ sklearn-style MinMaxScaler over the whole array (reference utils.py:116-313).  P
 the reference's own contrast_augment / add_gaussian_noise / add_speckle_noise / shot_noise / apply_gaussian_filter run over
 scikit-image 0.18.3 and scikit-learn 0.24.2 (generator tests/golden/make_skimage_fixture.py, run under the container's conda
 interpreter); tests/test_oracle_augment.py checks every restatement below against them.
-PARITY UNPINNED for the two imgaug augmenters (elastic_*, coarse_dropout below): the reference's requirements.txt names `imgaug` without a
+PARITY UNPINNED for the three imgaug augmenters (elastic_*, piecewise_affine_*, coarse_dropout below): the reference's requirements.txt names `imgaug` without a
 version and the package is installed nowhere here, so there is neither a fixture nor a run of the reference to pin them to.  They restate
-imgaug 0.4.0 (the last release) as published - augmenters/geometric.py ElasticTransformation (`_generate_shift_maps`, `_map_coordinates`),
+imgaug 0.4.0 (the last release) as published - augmenters/geometric.py ElasticTransformation (`_generate_shift_maps`, `_map_coordinates`) and PiecewiseAffine (`_get_transformer`, over
+skimage.transform.PiecewiseAffineTransform / warp),
 augmenters/blur.py `blur_gaussian_` / `_compute_gaussian_blur_ksize`, augmenters/arithmetic.py CoarseDropout = MultiplyElementwise over
-parameters.FromLowerResolution(Binomial(1 - p)) - anchored on the reference's call sites (fetal_net/augment.py:116-120, :149-170, :373-375).
+parameters.FromLowerResolution(Binomial(1 - p)) - anchored on the reference's call sites (fetal_net/augment.py:116-120, :131-170, :373-375).
 """
 import itertools
 import random
@@ -163,6 +164,44 @@ def elastic_apply(image, dx, dy, order):
     out = np.empty(image.shape, dtype=np.float64)
     for c in range(image.shape[2]):
         out[:, :, c] = map_coordinates(image[:, :, c].astype(np.float64), coords, order=order, mode="nearest")
+    return out
+
+
+def piecewise_affine_points(shape2d, jitter, nb_rows=2, nb_cols=2):
+    """geometric.py PiecewiseAffine._get_transformer: a regular nb_rows x nb_cols grid of points over [0, h] x [0, w] (y, x), each moved by
+    `jitter` (nb_rows * nb_cols, 2) ~ Normal(0, scale) times (h, w), destinations clipped to the image ([0, h - 1] x [0, w - 1])"""
+    h, w = shape2d
+    yy, xx = np.meshgrid(np.linspace(0, h, nb_rows), np.linspace(0, w, nb_cols), indexing="ij")
+    src = np.stack([yy.ravel(), xx.ravel()], axis=1)
+    dst = src + np.asarray(jitter, dtype=np.float64) * np.array([h, w], dtype=np.float64)
+    dst[:, 0] = np.clip(dst[:, 0], 0, h - 1)
+    dst[:, 1] = np.clip(dst[:, 1], 0, w - 1)
+    return src, dst
+
+
+def piecewise_affine_apply(image, src_yx, dst_yx, order):
+    """skimage.transform.warp(image, PiecewiseAffineTransform().estimate(src (x, y), dst (x, y)), order, mode='constant', cval=0): Delaunay
+    triangulation of the SOURCE points (scipy.spatial.Delaunay, as skimage does), one affine per triangle taking its source vertices to
+    their destinations, output pixel (x, y) read at affine_of_its_triangle(x, y); scipy map_coordinates(mode='constant') per channel"""
+    from scipy.spatial import Delaunay
+    image = np.asarray(image)
+    h, w = image.shape[:2]
+    sxy, dxy = np.asarray(src_yx, dtype=np.float64)[:, ::-1], np.asarray(dst_yx, dtype=np.float64)[:, ::-1]
+    tess = Delaunay(sxy)
+    yy, xx = np.meshgrid(np.arange(h, dtype=np.float64), np.arange(w, dtype=np.float64), indexing="ij")
+    pts = np.stack([xx.ravel(), yy.ravel()], axis=1)
+    simplex = tess.find_simplex(pts)
+    assert (simplex >= 0).all()
+    coords = np.empty_like(pts)
+    for t, tri in enumerate(tess.simplices):
+        S = np.hstack([sxy[tri], np.ones((3, 1))])                     # [x y 1] M = [x' y']
+        M = np.linalg.solve(S, dxy[tri])
+        sel = simplex == t
+        coords[sel] = np.hstack([pts[sel], np.ones((int(sel.sum()), 1))]).dot(M)
+    cc = np.stack([coords[:, 1].reshape(h, w), coords[:, 0].reshape(h, w)])
+    out = np.empty(image.shape, dtype=np.float64)
+    for c in range(image.shape[2]):
+        out[:, :, c] = map_coordinates(image[:, :, c].astype(np.float64), cc, order=order, mode="constant", cval=0.0)
     return out
 
 

@@ -327,7 +327,7 @@ def test_coarse_dropout_vs_oracle(ops, per_channel):
 
 def test_device_generator_runs_the_reference_default_augmentation_without_warnings():
     """fetal/config_utils.py:81-123 verbatim: elastic transform and coarse dropout included - no 'not applied' warning; labels stay binary,
-    the image stays inside the volume's range, about `rate` of the voxels sit at the patch minimum; piecewise_affine still warns"""
+    the image stays inside the volume's range, about `rate` of the voxels sit at the patch minimum"""
     import warnings
     from fetal_net.device_generator import device_data_generator
     default = {"flip": [0.5, 0.5, 0.5], "permute": False, "translate": (15, 15, 7), "scale": (0.1, 0.1, 0), "rotate": (0, 0, 90), "poisson_noise": 1,
@@ -357,9 +357,11 @@ def test_device_generator_runs_the_reference_default_augmentation_without_warnin
     xs = xs.float().cpu().numpy()
     at_min = float(np.mean([(xs[b] == xs[b].min()).mean() for b in range(4)]))
     assert 0.10 < at_min < 0.32, at_min                               # Binomial(0.8) keeps on 4 / 14-cell grids, one per slice: 0.2 on average
-    with pytest.warns(UserWarning, match="piecewise_affine"):
-        next(device_data_generator(df, [0], batch_size=1, augment=dict(default, piecewise_affine={"scale": 2}), patch_shape=(48, 48, 16),
-                                   skip_blank=False, categorical=False, is3d=True, truth_index=0, truth_size=16, shuffle_index_list=False))
+    with warnings.catch_warnings():                                   # the commented-out entry of the default config, switched on: applied too
+        warnings.simplefilter("error")
+        xp_, yp_ = next(device_data_generator(df, [0], batch_size=1, augment=dict(default, piecewise_affine={"scale": 2}), patch_shape=(48, 48, 16),
+                                              skip_blank=False, categorical=False, is3d=True, truth_index=0, truth_size=16, shuffle_index_list=False))
+    assert np.isfinite(xp_.float().cpu().numpy()).all() and set(np.unique(yp_.cpu().numpy())) <= {0, 1}
 
 
 def test_elastic_moves_image_and_labels_together():
@@ -418,3 +420,35 @@ def test_elastic_warps_mask_and_previous_slice_truth_with_the_same_field():
     random.seed(3)
     (_, _), y0 = next(plain)
     assert (y0.cpu().numpy() != y).mean() > 0.003                        # and the field did move the labels
+
+
+@pytest.mark.parametrize("seed,shape,scale", [(0, (48, 64, 3), 0.05), (1, (64, 48, 2), 0.2), (2, (40, 40, 1), 2.0)])
+def test_piecewise_affine_vs_oracle(ops, seed, shape, scale):
+    """the two-triangle warp of the device (closed-form triangle maps, diagonal test) against the oracle's generic route (scipy Delaunay of the
+    source grid, one solved affine per simplex, map_coordinates): image to 1e-5 of its range - a coordinate within 1e-12 of the image border or of a
+    half-integer may fall either way, so a handful of voxels are allowed to differ - labels likewise"""
+    from oracle import augment_oracle as AO
+    rs = np.random.RandomState(seed)
+    X, Y, C = shape
+    src, dst = AO.piecewise_affine_points((X, Y), rs.normal(0, scale, size=(4, 2)))
+    assert np.array_equal(src, [[0, 0], [0, Y], [X, 0], [X, Y]]) and dst[:, 0].max() <= X - 1 and dst[:, 1].max() <= Y - 1 and dst.min() >= 0
+    img = (rs.rand(X, Y, C) + 0.5).astype(np.float32)                  # strictly positive: a voxel read from outside (cval 0) is recognisable
+    lab = (rs.rand(X, Y, C) > 0.5).astype(np.uint8)
+    want_img, want_lab = AO.piecewise_affine_apply(img, src, dst, 1), AO.piecewise_affine_apply(lab, src, dst, 0)
+    got_img = ops.piecewise_affine(torch.from_numpy(img).cuda(), dst, 1, torch.empty((X, Y, C), device="cuda"))
+    got_lab = ops.piecewise_affine(torch.from_numpy(lab).cuda(), dst, 0, torch.empty((X, Y, C), device="cuda", dtype=torch.uint8))
+    torch.cuda.synchronize()
+    bad_img = np.abs(got_img.cpu().numpy() - want_img) > 1e-5 * 1.5
+    bad_lab = got_lab.cpu().numpy() != want_lab.astype(np.uint8)
+    assert bad_img.mean() <= 2e-3 and bad_lab.mean() <= 2e-3, (bad_img.mean(), bad_lab.mean())
+    assert (want_img != 0).mean() > 0.2                                # the warp keeps a good part of the image in view
+
+
+def test_piecewise_affine_with_unmoved_corners_is_a_crop_of_the_identity(ops):
+    X, Y, C = 20, 30, 2
+    img = torch.rand(X, Y, C, device="cuda") + 1.0
+    out = ops.piecewise_affine(img, [[0, 0], [0, Y], [X, 0], [X, Y]], 1, torch.empty_like(img))
+    assert torch.allclose(out, img, atol=1e-6)
+    # corners pulled to the image's own corner voxels (what the clip to [0, h-1] x [0, w-1] does to an unmoved grid): a slight zoom, nothing from outside
+    out = ops.piecewise_affine(img, [[0, 0], [0, Y - 1], [X - 1, 0], [X - 1, Y - 1]], 1, torch.empty_like(img))
+    assert float(out.min()) >= 1.0 - 1e-6

@@ -242,3 +242,21 @@ def test_coarse_dropout_enlarges_the_grid_by_nearest_neighbour_and_drops_to_the_
     g = [A.coarse_dropout_grid((128, 128), [0.10, 0.30], np.random.RandomState(s)) for s in range(20)]
     assert set(v for pair in g for v in pair) == {12, 38}              # a list is a choice between its two values, per axis
     assert A.coarse_dropout_grid((5, 5), 0.01, rs) == (1, 1)
+
+
+def test_piecewise_affine_restatement_on_a_2x2_grid():
+    """scipy's Delaunay splits the four corners along the diagonal (0,0) - (h,w) for every extent (what the device kernel hard-codes); with unmoved
+    points the warp is the identity; a pure translation of all four destinations is a shift with zeros entering"""
+    from scipy.spatial import Delaunay
+    for h, w in ((128, 128), (48, 64), (64, 48), (17, 300)):
+        tess = Delaunay(np.array([[0, 0], [w, 0], [0, h], [w, h]], dtype=float))
+        assert sorted(sorted(t) for t in tess.simplices.tolist()) == [[0, 1, 3], [0, 2, 3]]
+    rs = np.random.RandomState(4)
+    img = rs.rand(12, 9, 2) + 1
+    src, dst = A.piecewise_affine_points((12, 9), np.zeros((4, 2)))
+    assert np.array_equal(dst, [[0, 0], [0, 8], [11, 0], [11, 8]])     # clipped to the image: [0, h - 1] x [0, w - 1]
+    out = A.piecewise_affine_apply(img, src, src, 1)
+    assert np.allclose(out, img)
+    shifted = src + np.array([2.0, 1.0])
+    out = A.piecewise_affine_apply(img, src, shifted, 1)                # output (y, x) reads input (y + 2, x + 1)
+    assert np.allclose(out[:-2, :-1], img[2:, 1:]) and np.allclose(out[-2:], 0) and np.allclose(out[:, -1:], 0)
