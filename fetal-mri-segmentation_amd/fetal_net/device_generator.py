@@ -155,15 +155,15 @@ class _Sampler(object):
                                       rotate_factor=p["rotate_factor"], translate_factor=p["translate_factor"])
         else:
             p, A, At, Am = None, np.eye(4), np.eye(4), np.eye(4)
-        # elastic transform (reference augment.py:349-353, imgaug ElasticTransformation): ONE in-plane displacement field for every slice and for
-        # image (bilinear), truth, previous-slice truth and mask (nearest) - the affine samples land in scratch tensors and are warped into the slots
-        # piecewise affine (augment.py:344-347, imgaug PiecewiseAffine on a 2 x 2 grid: the four corners move by Normal(0, scale) of the extent,
-        # clipped to the image; two triangles), then the elastic transform - each a resampling of its own, as in the reference
+        # imgaug's two geometric augmenters, each a resampling of its own as in the reference: piecewise affine (augment.py:344-347; a 2 x 2 grid:
+        # the four corners move by Normal(0, scale) of the extent, clipped to the image; two triangles), then the elastic transform (:349-353).
+        # ONE set of moved corners / ONE in-plane displacement field for every slice and for image (bilinear), truth, previous-slice truth and mask
+        # (nearest): the affine samples land in scratch tensors and are warped into the slots
         elastic, corners = None, None
         if p is not None and p["piecewise_affine_scale"] > 0:
             h, w = float(ps[0]), float(ps[1])
-            src = np.array([[0, 0], [0, w], [h, 0], [h, w]], dtype=np.float64)
-            corners = src + self.host_rng.normal(0.0, p["piecewise_affine_scale"], size=(4, 2)) * np.array([h, w])
+            grid = np.array([[0, 0], [0, w], [h, 0], [h, w]], dtype=np.float64)
+            corners = grid + self.host_rng.normal(0.0, p["piecewise_affine_scale"], size=(4, 2)) * np.array([h, w])
             corners[:, 0] = np.clip(corners[:, 0], 0, h - 1)
             corners[:, 1] = np.clip(corners[:, 1], 0, w - 1)
         if p is not None and p["elastic_transform_scale"] > 0:
