@@ -763,11 +763,17 @@ def main():
     # (`roofline.sampled_steps`), `value` from the wall clock over all K steps.
     every = max(1, a.launch_timing_every)
     sampled = 0
+    # shader clock of the timed region: two {s_memtime, s_memrealtime} stamps per XCD on the main stream, one launch
+    # of 64 one-wave workgroups each - outside the K steps' kernels, inside the synchronised bracket (2 x ~5 us of 0.7 s)
+    stamp0, stamp1 = torch.zeros(16, dtype=torch.int64, device="cuda"), torch.zeros(16, dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
+    ops.clock_stamp(stamp0)
     for i in range(a.steps):
         timer.on = (not a.no_launch_timing) and (i % every == 0)
         sampled += 1 if timer.on else 0
         sums = step()
+    ops.clock_stamp(stamp1)
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
@@ -822,6 +828,11 @@ def main():
         "train_dice_last_step": m["dice_coefficient"],
         "hbm_roofline_frac_conv_algorithmic": (value / world) * ALGO_BYTES_PER_PATCH / 1e9 / PEAK_HBM_GBS,
     }
+    ghz, per_xcd = ops.clock_ghz(stamp0, stamp1)
+    out["clock_ghz"] = None if ghz is None else round(ghz, 3)
+    out["clock_ghz_note"] = ("average shader clock over the timed region of rank 0: d(s_memtime) / d(s_memrealtime) x 0.1 GHz between two stamps on the "
+                             "main stream, median over the XCDs (per XCD: %s); the chip is power-limited under this workload, 2.4 GHz is the "
+                             "clock behind the 2.5 PF peak" % " ".join("%.3f" % v for v in per_xcd))
     if not a.no_launch_timing:
         fl = conv_flops(eng)
 
@@ -884,26 +895,31 @@ def main():
     if world == 1 and (a.val_dice_steps > 0 or not a.no_secondary):
         # after the timed region, never inside it: the bench engine's buffers go first (each leg builds its own model)
         if a.data == "learnable" and not a.no_secondary:
-            # continuity with rounds 1-3: the same engine, re-initialised, on the old recipe (one batch, independent labels), >= 1.5 s of
-            # untimed steps (by then it has collapsed), then 20 timed steps
+            # continuity with rounds 1-3: the same engine, re-initialised, on the old recipe (one batch, independent labels), >= 2 s of
+            # untimed steps (by then it has collapsed and the clock has settled), then 50 timed steps (round 4: 1.5 s + 20 steps scattered
+            # 306-337 patches/s from box to box)
             eng.init_glorot(42)
             eng.M.zero_()
             eng.V.zero_()
             eng.t = 0
             xo, yo = make_pool("survey", 1)[0]
             t_c = time.perf_counter()
-            while time.perf_counter() - t_c < 1.5:
+            while time.perf_counter() - t_c < 2.0:
                 for _ in range(10):
                     eng.train_step(xo, yo, 1e-4)
                 torch.cuda.synchronize()
+            n_c = 50
             t_c = time.perf_counter()
-            for _ in range(20):
+            ops.clock_stamp(stamp0)
+            for _ in range(n_c):
                 so = eng.train_step(xo, yo, 1e-4)
+            ops.clock_stamp(stamp1)
             torch.cuda.synchronize()
             dt_c = time.perf_counter() - t_c
+            ghz_c, _ = ops.clock_ghz(stamp0, stamp1)
             out["continuity"] = {"recipe": "rounds 1-3: ONE batch, labels independent of the image (SURVEY 8d), trained on at lr 1e-4 - the net sits in the "
                                            "all-foreground solution of the Dice loss, the backward kernels multiply ~0 gradients, the power-limited clock rises",
-                                 "value": 20 * a.batch / dt_c, "unit": "patches/s", "steps": 20,
+                                 "value": n_c * a.batch / dt_c, "unit": "patches/s", "steps": n_c, "clock_ghz": None if ghz_c is None else round(ghz_c, 3),
                                  "train_dice_last_step": eng.metrics_from_sums(so.cpu().numpy())["dice_coefficient"]}
             del xo, yo
         del eng, pool

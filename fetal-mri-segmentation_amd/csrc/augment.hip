@@ -180,6 +180,11 @@ __global__ void k_shot_noise(T* __restrict__ x, int64_t n, const float* __restri
 //
 // Elastic: dst[i][j][c] = src[:, :, c] at (i - d0[i][j], j - d1[i][j]) (imgaug 0.4.0 `_map_coordinates`: x_shifted = x + (-1) * dx),
 // scipy map_coordinates order 0 (floor(c + 0.5)) or 1 (bilinear), mode 'nearest' (coordinates clamped to the image); fp64 coordinates.
+// This is `_map_coordinates`' SCIPY branch.  For float32 / float64 images at order 0 / 1 imgaug 0.4.0 prefers its cv2 branch
+// (cv2.convertMaps to CV_16SC2 + cv2.remap: coordinates quantised to 1/32 pixel, fixed-point INTER_LINEAR weights, cvRound for order 0,
+// BORDER_REPLICATE) and keeps scipy for the dtypes cv2 rejects - cv2 is installed nowhere here, so the fallback branch is the one
+// restated.  With the reference's alpha <= 5, sigma = 10 the displacement is ~0.1 pixel: the two branches differ by at most 1/64 pixel
+// of coordinate.  Parity unpinned either way (oracle/augment_oracle.py).
 template <typename T>
 __global__ void k_elastic_warp(const T* __restrict__ src, int X, int Y, int C, int src_ld, const float* __restrict__ d0, const float* __restrict__ d1,
                                int order, T* __restrict__ dst, int dst_ld) {

@@ -51,6 +51,15 @@ constexpr int NTHREADS = 512;
 // Zeros: the DMA source for out-of-volume halo rows.  The fwd kernel advances EVERY lane's source pointer by 64 B per channel chunk,
 // zero-page lanes included, so the page must cover Cin * 2 bytes: 8 KiB + slack = Cin <= 4096 (checked in conv3d_fwd_mfma_ok).
 __device__ uint4 g_zero_page[520];
+// Its address, fetched ONCE per kernel into a scalar register pair the compiler cannot re-derive (round 5): written as `g_zero_page` at the
+// point of use, hipcc re-materialised the address at EVERY DMA piece that may select it - s_getpc + s_load_dwordx2 from the GOT + a full
+// s_waitcnt lgkmcnt(0) in front of the piece, i.e. one scalar-memory latency in the issuing wave's path per piece: every x-plane piece of the
+// weight-gradient kernels (three per unit and wave) and every halo piece of a border tile of the forward kernels.
+__device__ __forceinline__ const unsigned char* zero_page_addr() {
+    const unsigned char* p = reinterpret_cast<const unsigned char*>(g_zero_page);
+    asm volatile("" : "+s"(p));
+    return p;
+}
 #ifdef FMRI_CHECK
 __device__ long long g_chk[16];
 extern "C" void fmri_debug_chk(long long* out) { hipMemcpyFromSymbol(out, HIP_SYMBOL(g_chk), sizeof(g_chk)); }
@@ -91,6 +100,27 @@ __device__ __forceinline__ void dma16_s(const void* sbase, unsigned voff, unsign
                  : "=&s"(keep)
                  : "v"(voff), "s"(sbase), "s"(lds_dst)
                  : "memory");
+}
+// LDS-DMA through a buffer descriptor (round 5): wave-uniform 128-bit resource (base, num_records = 2^31, raw) + one 32-bit byte offset per
+// lane.  A lane whose offset fails the range check (>= num_records) gets ZEROS written to its 16 bytes of LDS (tools/probe/probe_bufdma.hip),
+// so an out-of-volume halo row needs neither a zero page nor a per-lane pointer select: its offset is simply out of range.
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+constexpr unsigned DMA_OOB = 0x80000000u;
+__device__ __forceinline__ void dma16_buf(i32x4 rsrc, unsigned voff, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(rsrc), "s"(lds_dst)
+                 : "memory");
+}
+__device__ __forceinline__ i32x4 dma_rsrc(const void* base, int records = (int)DMA_OOB) {
+    const unsigned long long a = reinterpret_cast<unsigned long long>(base);
+    i32x4 r;
+    r[0] = __builtin_amdgcn_readfirstlane((unsigned)a);
+    r[1] = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32)) & 0xffff;      // stride 0, no swizzle
+    r[2] = __builtin_amdgcn_readfirstlane(records);                            // every offset >= records is out of range: 0 = the whole piece
+    r[3] = 0x00020000;
+    return r;
 }
 // max of two non-NaN-critical floats as ONE v_max_f32 (fmaxf adds a canonicalising v_max x,x per operand)
 __device__ __forceinline__ float vmax(float a, float b) {
@@ -176,6 +206,7 @@ struct FwdTail {
     int n_per;
     int n_grp;              // G
     const float* nss;
+    int prio;               // != 0: the MFMA waves raise their issue priority (s_setprio 3) over the producer wave on their SIMD (FMRI_FWD_PRIO, A/B)
 };
 
 // MODE selects what the 3x3x3 machinery computes:
@@ -212,6 +243,7 @@ k_conv_fwd_mfma(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__
     constexpr int NPH = PAR ? (PL ? 2 : 4) : (PL ? 3 : 9);   // phases per chunk = (kd,kh) rows that exist
     constexpr int PH0 = PL ? 3 : 0;                      // first (kd,kh) row (planar: kd = 1)
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * HALO_BYTES + 2 * FILT_BYTES];
+    const unsigned char* const zpage = zero_page_addr();
 
     const int Cin = s.C0 + s.C1;
     const int kpc = MODE == 2 ? (s.C0 >> 5) : 1;         // up-backward: chunks per parity class (s.C0 = channels of dy)
@@ -306,7 +338,7 @@ k_conv_fwd_mfma(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__
             const int sd = PL ? min(max(gd, 0), D - 1) : 2 * min(max(gd, 0), D - 1) + (p >> 2);
             const int sh = 2 * min(max(gh, 0), H - 1) + ((p >> 1) & 1), sw = 2 * min(max(gw, 0), W - 1) + (p & 1);
             const int64_t off = ((((int64_t)it.n * (PL ? D : 2 * D) + sd) * 2 * H + sh) * 2 * W + sw) * s.C0 + coff + ls * 8;
-            return ok ? s.p0 + off : (const bf16_t*)g_zero_page;
+            return ok ? s.p0 + off : (const bf16_t*)zpage;
         }
         const int cc = it.ch << 5;
         const bool from0 = cc < s.C0;
@@ -322,13 +354,13 @@ k_conv_fwd_mfma(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__
         const int gdc = min(max(gd, 0), D - 1) >> shd, ghc = min(max(gh, 0), H - 1) >> sh, gwc = min(max(gw, 0), W - 1) >> sh;
         const int off = ((gdc * sH + ghc) * sW + gwc) * sC + coff + ls * 8;      // inside one sample: < 2^31 elements
         const bf16_t* real = sp + (int64_t)it.n * sD * sH * sW * sC + off;
-        return ok ? real : (const bf16_t*)g_zero_page;
+        return ok ? real : (const bf16_t*)zpage;
     };
     auto issue_halo = [&](int ph, int hb) {            // ph is a compile-time constant at every call site
 #ifdef FMRI_CHECK
         {
             const char* q = (const char*)hp[ph];
-            const char* z = (const char*)g_zero_page;
+            const char* z = (const char*)zpage;
             const char* a0 = (const char*)s.p0; const char* a1 = (const char*)s.p1;
             const long long e0 = (long long)N * (D >> (s.up0 & s.dsh)) * (H >> s.up0) * (W >> s.up0) * s.C0 * 2;
             const long long e1 = (long long)N * D * H * W * s.C1 * 2;
@@ -340,7 +372,7 @@ k_conv_fwd_mfma(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__
                     g_chk[1] = ph; g_chk[2] = wv; g_chk[3] = lane; g_chk[4] = (long long)q; g_chk[5] = (long long)z; g_chk[6] = (long long)a0;
                     g_chk[7] = e0; g_chk[8] = blockIdx.x; g_chk[9] = hb;
                 }
-                hp[ph] = (const bf16_t*)g_zero_page;
+                hp[ph] = (const bf16_t*)zpage;
             }
         }
 #endif
@@ -369,7 +401,7 @@ k_conv_fwd_mfma(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__
         else {
             const int pk = h_pack[ph];
             const bool bad = !((pk >> 15) & 1) || (((unsigned)pk >> 16) & tmask) != 0;
-            dma16(bad ? (const void*)g_zero_page : (const void*)(sb + hoff[ph]), dst);
+            dma16(bad ? (const void*)zpage : (const void*)(sb + hoff[ph]), dst);
         }
     };
 
@@ -525,7 +557,7 @@ k_conv_fwd_mfma(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__
                                     if constexpr (CHEAP_FRESH) {
                                         const int pk = h_pack[HP0 + q];
                                         const bool bad = !((pk >> 15) & 1) || (((unsigned)pk >> 16) & ntm) != 0;
-                                        hp[HP0 + q] = bad ? (const bf16_t*)g_zero_page : reinterpret_cast<const bf16_t*>(nsb + cheap_off(pk));
+                                        hp[HP0 + q] = bad ? (const bf16_t*)zpage : reinterpret_cast<const bf16_t*>(nsb + cheap_off(pk));
                                     } else hp[HP0 + q] = halo_src(nxt, h_pack[HP0 + q]);
                                 } else hp[HP0 + q] += 32;
                                 issue_halo(HP0 + q, hb ^ 1);
@@ -740,7 +772,12 @@ k_conv_fwd_mfma(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__
 // producers' registers apart: the 16 prefetched mask lines (64 registers) and the 9 logit weights are only allocated where they are used -
 // with everything in one kernel the producers' path spilled 18 registers and the pooled-copy launch (enc0b forward, bound by its producers)
 // ran 5 % slower for registers only the other cases need.
-template <int NT, bool PL, int MODE, bool RES, bool ASYNC = false, int EPI = -1, bool FH = false>   // FH: fast halo addressing (producers, below)
+// S16 (round 5): the MFMA waves issue v_mfma_f32_16x16x32_bf16 instead of 32x32x16 - the SAME output tile per wave (one d-plane of the tile:
+// 128 voxels x BN channels, 128 accumulator registers) cut into 8 h-rows of 16 voxels x BN / 16 channel fragments, the whole 32-channel chunk
+// as ONE k-step.  LDS bytes per MAC are the same ((M + N) * K); what changes is the energy per MAC: on live data the chip is power-limited
+//  and holds a higher clock on this shape (MI355X guide, 'DVFS give-back' item 7).  A 16-lane group of a fragment read is one
+// h-row of the halo at one 16-byte slot - the access pattern the column-keyed swizzle was derived for - and no row rotation is needed.
+template <int NT, bool PL, int MODE, bool RES, bool ASYNC = false, int EPI = -1, bool FH = false, bool S16 = false>   // FH: fast halo addressing (producers, below)
 __global__ void __launch_bounds__(fw::NTHREADS)
 k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ bias, const bf16_t* __restrict__ mask,
               const bf16_t* residual, bf16_t* y, int N, int D, int H, int W, int Cout, int act, float alpha, FwdTail tail) {
@@ -807,6 +844,7 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
                   "epilogue staging must fit the consumed halo slot (+ gap)");
     static_assert(!TIGHT || HALO_BYTES + STAGE_BYTES - HALO_BYTES <= HALO_STRIDE, "stage of slot 0 must end where slot 1 begins");
     __shared__ __attribute__((aligned(16))) unsigned char lds[HALO_SPAN + 2 * FILT_BYTES];
+    const unsigned char* const zpage = zero_page_addr();
 
     const int Cin = s.C0 + s.C1;
     const int kpc = MODE == 2 ? (s.C0 >> 5) : 1;
@@ -1145,7 +1183,9 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
             const int hw_ = hvc % HW, hq = hvc / HW;
             const int ls = ps ^ halo_key(hw_);
             const int hd_ = hq / HH, hh_ = hq % HH;
-            const int edge = (hd_ == 0 ? 1 : 0) | (hd_ == HD - 1 ? 2 : 0) | (hh_ == 0 ? 4 : 0) | (hh_ == HH - 1 ? 8 : 0) | (hw_ == 0 ? 16 : 0) | (hw_ == HW - 1 ? 32 : 0);
+            // (bit 6: a row past the end of the box - "outside" whatever the tile)
+            const int edge = (hd_ == 0 ? 1 : 0) | (hd_ == HD - 1 ? 2 : 0) | (hh_ == 0 ? 4 : 0) | (hh_ == HH - 1 ? 8 : 0) | (hw_ == 0 ? 16 : 0) | (hw_ == HW - 1 ? 32 : 0) |
+                             (hv < HVOX ? 0 : 64);
             return hd_ | (hh_ << 4) | (hw_ << 8) | (ls << 13) | ((hv < HVOX ? 1 : 0) << 15) | (edge << 16);
         };
         // (EPI 5 / 6: no table either - a piece's descriptor is rebuilt from the lane index when the piece is issued, see KEEP_HP below)
@@ -1180,6 +1220,7 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
         constexpr bool KEEP_HP = EPI < 5;
         const bf16_t* hp[(KEEP_HP && !(FH && !PL && EPI < 5)) ? NPIECE : 1];
         unsigned hoff[(FH && !PL && EPI < 5) ? NPIECE : 1];      // FH: the per-lane byte offset of each piece inside the halo box (constant for the whole kernel)
+        unsigned heff[(FH && !PL && EPI < 5) ? NPIECE : 1];      // ... as issued for the current tile: out of range (DMA_OOB) where the row leaves the volume
         auto halo_src = [&](const FwdItem& it, int pk) -> const bf16_t* {
             int od = 0, oh = 0, ow = 0;                            // TIGHT: the box starts at g - 1 + (parity of the taps) per axis
             if constexpr (TIGHT) {
@@ -1194,7 +1235,7 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
                 const int sd = PL ? min(max(gd, 0), D - 1) : 2 * min(max(gd, 0), D - 1) + (p >> 2);
                 const int sh = 2 * min(max(gh, 0), H - 1) + ((p >> 1) & 1), sw = 2 * min(max(gw, 0), W - 1) + (p & 1);
                 const int64_t off = ((((int64_t)it.n * (PL ? D : 2 * D) + sd) * 2 * H + sh) * 2 * W + sw) * s.C0 + coff + ls * 8;
-                return ok ? s.p0 + off : (const bf16_t*)g_zero_page;
+                return ok ? s.p0 + off : (const bf16_t*)zpage;
             } else {
                 const int cc = it.ch << 5;
                 const bool from0 = cc < s.C0;
@@ -1207,7 +1248,7 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
                 const int gdc = min(max(gd, 0), D - 1) >> shd, ghc = min(max(gh, 0), H - 1) >> sh, gwc = min(max(gw, 0), W - 1) >> sh;
                 const int off = ((gdc * sH + ghc) * sW + gwc) * sC + coff + ls * 8;
                 const bf16_t* real = sp + (int64_t)it.n * sD * sH * sW * sC + off;
-                return ok ? real : (const bf16_t*)g_zero_page;
+                return ok ? real : (const bf16_t*)zpage;
             }
         };
         static_assert(NPIECE * DW >= H_I1 - H_I0 && NPIECE * DW - (H_I1 - H_I0) < DW, "piece map");
@@ -1216,7 +1257,7 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
             // every wave issues exactly NPIECE instructions per chunk (the counted s_waitcnt below relies on it): the few past the last live
             // instruction copy zeros into the dead rows behind it
             const bool dead = instr >= H_I1;
-            dma16(dead ? (const void*)g_zero_page : (const void*)src, __builtin_amdgcn_readfirstlane(lds0 + slot * HALO_STRIDE + instr * 1024));
+            dma16(dead ? (const void*)zpage : (const void*)src, __builtin_amdgcn_readfirstlane(lds0 + slot * HALO_STRIDE + instr * 1024));
         };
         // FAST halo addressing (round 4; plain single-source 3-D launches = every MODE 0 launch of the benchmarked step).  The producers'
         // per-phase instrumentation (tools/prof_phases.py) showed a piece whose address is worked out afresh (halo_src: clamps, three bounds
@@ -1269,17 +1310,19 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
             const unsigned alo = __builtin_amdgcn_readfirstlane((unsigned)a), ahi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
             return reinterpret_cast<const char*>(((unsigned long long)ahi << 32) | alo);
         };
-        auto issue_halo_fast = [&](int ph, int slot, const char* sb, unsigned tmask) {
+        // (round 5: through a buffer descriptor whose base is the item's box corner.  Which rows of a piece lie outside the volume depends on
+        // the tile only, so the offsets are fixed up when the stream moves to a new tile (`fresh_item`: three vector instructions per piece)
+        // and every other chunk of the tile issues its pieces with NO vector arithmetic at all, border tiles included - the round-4 form
+        // selected the zero page per lane for every piece of every chunk of a border tile, and the launches with many chunks per tile, whose
+        // deep levels consist of border tiles, stayed on the pointer-advance scheme for it.)
+        auto issue_halo_fast = [&](int ph, int slot, i32x4 rs, unsigned tmask, bool fresh_item) {
             const int instr = H_I0 + ph * DW + dwv;
             const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + slot * HALO_STRIDE + instr * 1024);
-            const unsigned off = hoff[ph];
-            if (tmask == 0 && instr < H_I1) {
-                dma16_s(sb, off, dst);
-            } else {
-                const int pk = h_pack[ph];
-                const bool bad = instr >= H_I1 || !((pk >> 15) & 1) || (((unsigned)pk >> 16) & tmask) != 0;
-                dma16(bad ? (const void*)g_zero_page : (const void*)(sb + off), dst);
+            if (fresh_item) {
+                const bool bad = instr >= H_I1 || (((unsigned)h_pack[ph] >> 16) & (tmask | 64u)) != 0;
+                heff[ph] = bad ? DMA_OOB : hoff[ph];
             }
+            dma16_buf(rs, heff[ph], dst);
         };
         // Halo pieces of the NEXT chunk issued in phase pl: spread over the first NPH-1 phases (all of them when a chunk has one phase
         // only... it has at least two), so that the last phase's wait - everything landed - finds them a phase old.
@@ -1329,11 +1372,11 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
         for (int i = 0; i < DPN; ++i) drain_vmops[i] = ASY ? store_share_vmops(DW, i, DPN) + (LINES_PIPE && i + 1 < DPN ? LP : 0) : 0;
         if constexpr (FASTH_CT) {
             unsigned tm0;
-            const char* const sb0 = fast_base(cur, tm0);
+            const i32x4 rs0 = dma_rsrc(fast_base(cur, tm0));
 #pragma unroll
             for (int ph = 0; ph < NPIECE; ++ph) {
                 hoff[ph] = fast_off(h_pack[ph]);
-                issue_halo_fast(ph, 0, sb0, tm0);
+                issue_halo_fast(ph, 0, rs0, tm0, true);
             }
         } else {
 #pragma unroll
@@ -1357,8 +1400,9 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
             const bool fresh = MODE == 2 ? (nxt.ch % kpc == 0) : (nxt.ch == 0 || (nxt.ch << 5) == s.C0);
             unsigned ntm = 0;
             const char* nsb = nullptr;
+            i32x4 nrs = {0, 0, 0, 0};
             if constexpr (FASTH_CT) {
-                if (has_next) nsb = fast_base(nxt, ntm);
+                if (has_next) nrs = dma_rsrc(fast_base(nxt, ntm));
             }
             // CHEAP_FRESH (tight parity modes outside FH: many chunks per fresh address): the pointers are kept and advanced as before, but a
             // FRESH pointer is formed the fast way - base of the box corner + lane constant, zero page where an edge row leaves the volume -
@@ -1427,13 +1471,13 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
 #pragma unroll
                         for (int q = 0; q < NPIECE; ++q) {
                             if (q < HPN) {
-                                if constexpr (FASTH_CT) issue_halo_fast(HP0 + q, hb ^ 1, nsb, ntm);
+                                if constexpr (FASTH_CT) issue_halo_fast(HP0 + q, hb ^ 1, nrs, ntm, fresh);
                                 else if constexpr (KEEP_HP) {
                                     if (fresh) {
                                         if constexpr (CHEAP_FRESH) {
                                             const int pk = h_pack[HP0 + q];
                                             const bool bad = !((pk >> 15) & 1) || (((unsigned)pk >> 16) & ntm) != 0;
-                                            hp[HP0 + q] = bad ? (const bf16_t*)g_zero_page : reinterpret_cast<const bf16_t*>(nsb + fast_off(pk));
+                                            hp[HP0 + q] = bad ? (const bf16_t*)zpage : reinterpret_cast<const bf16_t*>(nsb + fast_off(pk));
                                         } else hp[HP0 + q] = halo_src(nxt, h_pack[HP0 + q]);
                                     } else hp[HP0 + q] += 32;
                                     issue_halo(HP0 + q, hb ^ 1, hp[HP0 + q]);
@@ -1500,31 +1544,69 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
 
     // ---------------------------------------------------------------------------------------------------------------- consumer
     const int cw = wv;
-    f32x16 acc[JT][NT];
+    if (tail.prio) __builtin_amdgcn_s_setprio(3);
+    static_assert(!(S16 && PL), "the 16x16x32 form covers the 3-D launches");
+    // S16: fragment index j = h-row of the wave's d-plane (16 voxels along w: lane & 15), c = 16-channel block; a lane's four accumulator
+    // registers are channels 16 c + 4 kq .. + 3 of its voxel (kq = lane >> 4, also the 8-channel k-group the lane reads of both operands)
+    constexpr int JN = S16 ? 8 : JT, CN = S16 ? 2 * NT : NT;
+    typedef std::conditional_t<S16, f32x4, f32x16> acc_t;
+    const int w16 = lane & 15, kq = lane >> 4;
+    acc_t acc[JN][CN];
+    // (S16 keeps only the first NT floats4 of bv: [c >> 2][c & 3] = the lane's 4 channels of 16-channel block c)
     auto load_bias = [&](int co0, float4 (&bv)[NT][4]) {
+        if constexpr (S16) {
 #pragma unroll
-        for (int c = 0; c < NT; ++c)
-#pragma unroll
-            for (int gq = 0; gq < 4; ++gq)
-                bv[c][gq] = bias ? *reinterpret_cast<const float4*>(bias + co0 + c * 32 + 8 * gq + 4 * hk) : make_float4(0.f, 0.f, 0.f, 0.f);
-    };
-    auto init_acc = [&](const float4 (&bv)[NT][4]) {
-#pragma unroll
-        for (int j = 0; j < JT; ++j)
+            for (int c = 0; c < CN; ++c)
+                bv[c >> 2][c & 3] = bias ? *reinterpret_cast<const float4*>(bias + co0 + c * 16 + 4 * kq) : make_float4(0.f, 0.f, 0.f, 0.f);
+        } else {
 #pragma unroll
             for (int c = 0; c < NT; ++c)
 #pragma unroll
-                for (int gq = 0; gq < 4; ++gq) {
-                    acc[j][c][4 * gq] = bv[c][gq].x;
-                    acc[j][c][4 * gq + 1] = bv[c][gq].y;
-                    acc[j][c][4 * gq + 2] = bv[c][gq].z;
-                    acc[j][c][4 * gq + 3] = bv[c][gq].w;
+                for (int gq = 0; gq < 4; ++gq)
+                    bv[c][gq] = bias ? *reinterpret_cast<const float4*>(bias + co0 + c * 32 + 8 * gq + 4 * hk) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto init_acc = [&](const float4 (&bv)[NT][4]) {
+        if constexpr (S16) {
+#pragma unroll
+            for (int j = 0; j < JN; ++j)
+#pragma unroll
+                for (int c = 0; c < CN; ++c) {
+                    acc[j][c] = __builtin_bit_cast(f32x4, bv[c >> 2][c & 3]);
                 }
+        } else {
+#pragma unroll
+            for (int j = 0; j < JT; ++j)
+#pragma unroll
+                for (int c = 0; c < NT; ++c)
+#pragma unroll
+                    for (int gq = 0; gq < 4; ++gq) {
+                        acc[j][c][4 * gq] = bv[c][gq].x;
+                        acc[j][c][4 * gq + 1] = bv[c][gq].y;
+                        acc[j][c][4 * gq + 2] = bv[c][gq].z;
+                        acc[j][c][4 * gq + 3] = bv[c][gq].w;
+                    }
+        }
     };
     // RES with per-border-class bias (tail.bias27): accumulators of the tile `it` start from the bias of each lane's own output voxel.
     // Interior tiles (most) take the interior class 13 for every lane; tiles on a face of the volume look the class up per voxel.
     auto init_acc_b27 = [&](const FwdItem& it) {
         const bool border = it.d0 == 0 || it.d0 + TD == D || it.h0 == 0 || it.h0 + TH == H || it.w0 == 0 || it.w0 + TW == W;
+        if constexpr (S16) {
+#pragma unroll
+            for (int j = 0; j < JN; ++j) {
+                int cls = 13;
+                if (border) {
+                    const int d = it.d0 + cw, h = it.h0 + j, w = it.w0 + w16;
+                    cls = ((d == 0 ? 0 : (d == D - 1 ? 2 : 1)) * 3 + (h == 0 ? 0 : (h == H - 1 ? 2 : 1))) * 3 + (w == 0 ? 0 : (w == W - 1 ? 2 : 1));
+                }
+                const float* const bp = tail.bias27 + (int64_t)cls * Cout + it.co0 + 4 * kq;
+#pragma unroll
+                for (int c = 0; c < CN; ++c) {
+                    acc[j][c] = *reinterpret_cast<const f32x4*>(bp + c * 16);
+                }
+            }
+        } else {
 #pragma unroll
         for (int j = 0; j < JT; ++j) {
             int cls = 13;
@@ -1545,19 +1627,21 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
                     acc[j][c][4 * gq + 3] = b4.w;
                 }
         }
+        }
     };
     // lane r of a column tile: h-row r>>4, w rotated by HW mod 16 on the second row (conflict-free ds_read_b128 groups, see k_conv_fwd_mfma)
     // B-fragment (halo) addresses of this lane: [k-step][kw (+ the parity's first kw)] for column tile 0 of this wave, filter row (0, 0), in
     // the halo slot the NEXT request goes to (the slot's base is added / subtracted once per item); everything else is an immediate
     static_assert(JT == 4, "tile_d(JT * cw + j) = cw, tile_h = 2 j + (r >> 4)");
+    // (S16: pre[0][kw] only - voxel w16 of h-row 0 of the wave's d-plane, slot kq: the chunk's 32 channels are one k-step)
     int pre[2][3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        const int hwc = lane_w(r) + k;
-        pre[0][k] = ((cw * HH + (r >> 4)) * HW + hwc) * 64 + ((hk ^ halo_key(hwc)) << 4);
+        const int hwc = (S16 ? w16 : lane_w(r)) + k;
+        pre[0][k] = S16 ? (cw * HH * HW + hwc) * 64 + ((kq ^ halo_key(hwc)) << 4) : ((cw * HH + (r >> 4)) * HW + hwc) * 64 + ((hk ^ halo_key(hwc)) << 4);
         pre[1][k] = pre[0][k] ^ 32;
     }
-    const int fa[2] = {swz64(r, hk), swz64(r, hk) ^ 32};
+    const int fa[2] = {S16 ? swz64(w16, kq) : swz64(r, hk), swz64(r, hk) ^ 32};
     if ((RES || HAS_RESID) && tail.bias27) init_acc_b27(cur);
     else {
         float4 bv0[NT][4];
@@ -1568,7 +1652,12 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
     unsigned long long cprof[12] = {};
     PROF_T(ck0);
 #endif
-    bf16x8_t fa_[2][NT], fb_[2][JT];           // double-buffered filter / halo fragments (live across the phases of a tile)
+    // double-buffered filter / halo fragments (live across the phases of a tile).  S16: a halo fragment serves CN consecutive MFMAs and is
+    // dead after them - the next step's is requested into the same registers (fb_[0] only)
+    // (S16, NBR = 4: the halo fragments run FOUR 4-MFMA blocks - 256 cycles of matrix pipe, the look-ahead of the 32x32x16 form - ahead
+    // of their use in a ring of four: a whole step's eight fragments held 16 registers more than the 64-wide instantiations have)
+    constexpr int NBR = 4;
+    bf16x8_t fa_[2][CN], fb_[2][S16 ? NBR : JN];
     // RES: the residual's 16-byte lines this lane adds in the epilogue, [column tile][store instruction] (see the RES epilogue)
     constexpr int RKK = RES ? 32 / (64 / (BN / 8)) : 1;
     // column tiles whose lines are requested a phase early: none - 16 registers per tile at BN = 64 held across the last phase's MFMAs made
@@ -1581,16 +1670,25 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
         const int rt = JT * cw + j, rr = kk * VPI + lane / LPV, q8 = lane % LPV;
         return *reinterpret_cast<const uint4*>(residual + org + ((tile_d(rt) * H + tile_h(rt, rr)) * W + lane_w(rr)) * Cout + q8 * 8);
     };
-    while (true) {
-        bool has_next = true;
-        FwdItem nxt = cur;
-        int npair = pair;
+    // The consumers' stream: item_next() works out the item after `cur`, run_item() is the phases of `cur`, tile_epilogue() what follows a
+    // tile's last chunk.  The 32x32x16 form drives them as ONE flat loop over items (rounds 1-4).  S16 drives them as a loop over tiles
+    // around a loop over the tile's chunks: in the flat form hipcc (ROCm 7.2) failed to coalesce the accumulator phis of the conditional
+    // epilogue for the 32 four-register accumulators - three copies of all of them alive at the merge, 545 spills at BN = 64.
+    bool has_next = true;
+    FwdItem nxt = cur;
+    int npair = pair;
+    auto item_next = [&]() {
+        has_next = true;
+        nxt = cur;
+        npair = pair;
         if (cur.ch + 1 < nch) nxt.ch = cur.ch + 1;
         else {
             npair = pair + gridDim.x;
             has_next = npair < npairs;
             if (has_next) nxt = decode(npair, 0);
         }
+    };
+    auto run_item = [&]() {
 #pragma unroll
         for (int k = 0; k < 3; ++k) asm volatile("" : "+v"(pre[0][k]), "+v"(pre[1][k]));
         // (halo slot, halo row offset of the (kd,kh) row, first kw) of phase `pl` of item `it` whose halo sits in slot `slot`
@@ -1605,24 +1703,25 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
                 else return (((pl >> 1) + (p >> 2)) * HH + ((pl & 1) + ((p >> 1) & 1))) * HW;
             }
         };
-        constexpr int NST = RPP * NKW * 2;         // steps of a phase: (filter row, kw, k-step)
+        constexpr int NST = RPP * NKW * (S16 ? 1 : 2);         // steps of a phase: (filter row, kw, k-step); S16: (filter row, kw)
         // One wave per SIMD feeds the MFMA pipe alone: the fragments of step st+1 (a (kw, k-step) pair) are requested before the MFMAs of
         // step st are issued, into the other half of a double register set, threaded between those MFMAs (left to the compiler the reads
         // sat right in front of their MFMAs).  The pipeline runs ACROSS the phase barrier inside a tile: once the fragments of a phase's
         // last step are in registers this wave is done reading the rings, so it passes the next phase's barrier BEFORE issuing that step's
         // MFMAs and requests the next phase's first fragments under them - only the first phase of a tile starts with an exposed LDS latency.
         auto load_a = [&](const unsigned char* lfp, int st, int buf) {
-            const int t = st >> 1, ks = st & 1;          // t = filter row of the phase * NKW + kw: the slab holds them in this order
+            const int t = S16 ? st : st >> 1, ks = S16 ? 0 : st & 1;          // t = filter row of the phase * NKW + kw: the slab holds them in this order
 #pragma unroll
-            for (int c = 0; c < NT; ++c) fa_[buf][c] = *reinterpret_cast<const bf16x8_t*>(lfp + fa[ks] + (t * BN + c * 32) * 64);
+            for (int c = 0; c < CN; ++c) fa_[buf][c] = *reinterpret_cast<const bf16x8_t*>(lfp + fa[ks] + (t * BN + c * (S16 ? 16 : 32)) * 64);
         };
         auto load_b = [&](int hoffp, int kw0p, int st, int buf, int j) {
-            const int t = st >> 1, ks = st & 1;
+            const int t = S16 ? st : st >> 1, ks = S16 ? 0 : st & 1;
             const int kw = t % NKW, row = t / NKW;       // (row > 0 only with RPP = 2: the phase's second filter row = the next h-row of the halo)
             int base;
             if constexpr (PAR && !TIGHT) base = kw0p ? pre[ks][kw + 1] : pre[ks][kw];
             else base = pre[ks][kw];
-            fb_[buf][j] = *reinterpret_cast<const bf16x8_t*>(lds + base + (hoffp + (row + 2 * j) * HW) * 64);
+            // a 32-voxel column tile is two h-rows (the lane's row is in `pre`), an S16 fragment is one
+            fb_[S16 ? 0 : buf][S16 ? j % NBR : j] = *reinterpret_cast<const bf16x8_t*>(lds + base + (hoffp + (row + (S16 ? j : 2 * j)) * HW) * 64);
         };
 #pragma unroll
         for (int pl = 0; pl < NPH; ++pl, ++g) {
@@ -1634,7 +1733,7 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
                 __builtin_amdgcn_s_barrier();
                 load_a(lf, 0, 0);
 #pragma unroll
-                for (int j = 0; j < JT; ++j) load_b(hoff, kw0, 0, 0, j);
+                for (int j = 0; j < (S16 ? NBR : JN); ++j) load_b(hoff, kw0, 0, 0, j);
             }
             PROF_T(c1);
             if constexpr (RES) {
@@ -1660,32 +1759,70 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
                     else {
                         // every later request is for the next item, whose halo sits in the other slot: move the six addresses there
                         hoffn = phase_hoff(nxt, 0, kw0n);
-                        const int dlt = hb ? -HALO_STRIDE : HALO_STRIDE;
+                        if constexpr (!S16) {
+                            const int dlt = hb ? -HALO_STRIDE : HALO_STRIDE;
 #pragma unroll
-                        for (int k = 0; k < 3; ++k) { pre[0][k] += dlt; pre[1][k] += dlt; }
+                            for (int k = 0; k < 3; ++k) { pre[0][k] += dlt; pre[1][k] += dlt; }
+                        }
                     }
                 }
-                if (chain) {
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this phase's last fragments are in registers: done with the rings
-                    __builtin_amdgcn_s_barrier();                          // = the next phase's barrier
-                }
-                if (!last || chain) load_a(lfn, stn, stn & 1);
+                // the hand-over to the next phase: this phase's last fragments are in registers = this wave is done with the rings, so it
+                // passes the next phase's barrier here, in front of the MFMAs that still use them
+                auto hand_over = [&]() {
+                    if (chain) {
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_s_barrier();                          // = the next phase's barrier
+                    }
+                };
+                if constexpr (!S16) hand_over();
+                // The two filter-fragment buffers alternate per step through the whole chunk (step pl * NST + st; a chunk's first step uses
+                // buffer 0).  The plain S16 form has 27 steps per chunk: its last step sits in buffer 0 as well, so the next chunk's first
+                // filter fragments are requested AFTER that step's MFMAs have been issued (one exposed LDS latency per chunk, ~1 %; a third
+                // buffer costs 16 registers the 64-wide instantiations do not have: 41 spills, some inside this loop).
+                const int ab = (pl * NST + st) & 1;
+                const bool late = (NPH * NST) % 2 == 1 && pl == NPH - 1 && last;
+                const int abn = (last && pl == NPH - 1) ? 0 : ab ^ 1;
+                // (S16, last step: the next phase's filter fragments are requested behind the hand-over, inside the block loop)
+                if ((!last || (chain && !S16)) && !late) load_a(lfn, stn, abn);
 #pragma unroll
-                for (int j = 0; j < JT; ++j) {
+                for (int j = 0; j < JN; ++j) {
 #pragma unroll
-                    for (int c = 0; c < NT; ++c)
-                        acc[j][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_[st & 1][c], fb_[st & 1][j], acc[j][c], 0, 0, 0);
-                    if (!last || chain) load_b(hoffn, kw0n, stn, stn & 1, j);
+                    for (int c = 0; c < CN; ++c) {
+                        if constexpr (S16) acc[j][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa_[ab][c], fb_[0][j % NBR], acc[j][c], 0, 0, 0);
+                        else acc[j][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_[ab][c], fb_[ab][j], acc[j][c], 0, 0, 0);
+                    }
+                    if constexpr (S16) {
+                        // the fragment NBR blocks on takes this one's place: of this step while it has them, else of the next one
+                        if (j + NBR < JN) load_b(hoff, kw0, st, 0, j + NBR);
+                        else {
+                            if (last && j + NBR == JN) {
+                                // a phase's last step: its last request into the rings went out a block ago.  (The chunk's last phase: the next
+                                // item's halo sits in the other slot - the three addresses move there now, not before: the requests of
+                                // blocks 0 .. JN - NBR - 1 still went to this chunk's slot, which the barrier below hands to the producers.)
+                                hand_over();
+                                if (pl + 1 == NPH) {
+                                    const int dlt = hb ? -HALO_STRIDE : HALO_STRIDE;
+#pragma unroll
+                                    for (int k = 0; k < 3; ++k) pre[0][k] += dlt;
+                                }
+                                if (chain && !late) load_a(lfn, stn, abn);
+                            }
+                            if (!last || chain) load_b(hoffn, kw0n, stn, 0, j + NBR - JN);
+                        }
+                    } else if (!last || chain) load_b(hoffn, kw0n, stn, abn, j);
                     __builtin_amdgcn_sched_barrier(0);
                 }
+                if (late && chain) load_a(lfn, stn, abn);
             }
             PROF_T(c2);
 #ifdef FMRI_PROF
             cprof[1] += c1 - c0; cprof[3] += c2 - c1; cprof[6] += 1;
 #endif
         }
+    };
+    auto tile_epilogue = [&]() {
         PROF_T(ce0);
-        if (RES && cur.ch == nch - 1) {
+        if constexpr (RES) {
             // y = act(acc + residual): fp32 transposition through LDS, one 32-voxel column tile at a time (wave-private 8 KiB).  The
             // residual lines of the first RPRE column tiles were requested at the top of the tile's last phase (res_q), the next RAHEAD tiles' lines are
             // requested here, where the fragment registers have died, and each finished line's registers take the line RAHEAD tiles on: round 2 loaded each tile's lines inside its own iteration and waited four
@@ -1702,6 +1839,19 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
             unsigned char* const stage = lds + hb * HALO_BYTES + cw * (32 * BN * 4);
 #pragma unroll
             for (int j = 0; j < JT; ++j) {
+                if constexpr (S16) {
+                    // column tile j = h-rows 2 j and 2 j + 1 of the plane; the lane's voxel sits at index rr of the tile (second row rotated, lane_w)
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj) {
+                        const int rr = jj ? 16 + ((w16 + (HW & 15)) & 15) : w16;
+#pragma unroll
+                        for (int c = 0; c < CN; ++c) {
+                            const int q = c * 4 + kq;
+                            *reinterpret_cast<float4*>(stage + rr * (BN * 4) + (((q ^ rr) & (PPV - 1)) << 4)) =
+                                make_float4(acc[2 * j + jj][c][0], acc[2 * j + jj][c][1], acc[2 * j + jj][c][2], acc[2 * j + jj][c][3]);
+                        }
+                    }
+                } else {
 #pragma unroll
                 for (int c = 0; c < NT; ++c)
 #pragma unroll
@@ -1710,6 +1860,7 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
                         *reinterpret_cast<float4*>(stage + r * (BN * 4) + (((q ^ r) & (PPV - 1)) << 4)) =
                             make_float4(acc[j][c][4 * gq], acc[j][c][4 * gq + 1], acc[j][c][4 * gq + 2], acc[j][c][4 * gq + 3]);
                     }
+                }
                 const int rt = JT * cw + j;
 #pragma unroll
                 for (int kk = 0; kk < 32 / VPI; ++kk) {
@@ -1736,7 +1887,7 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
             if (tail.bias27) init_acc_b27(has_next ? nxt : cur);
             else init_acc(bvn);
         }
-        if (!RES && cur.ch == nch - 1) {
+        if constexpr (!RES) {
             // bias is in the accumulators; activation, bf16, half-wave exchange, wave-private LDS transposition (16 KiB per consumer wave of
             // the consumed halo slot), line-major stores
             constexpr int CPV = BN / 8;                  // 16-byte pieces per voxel
@@ -1754,6 +1905,44 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
                 constexpr int ACT = decltype(act_tag)::value;
                 unsigned zero2_ = 0u;
                 asm volatile("" : "+v"(zero2_));
+                if constexpr (S16) {
+                    // a lane holds 4 channels (two dwords of bf16) of its voxel per 16-channel block; v_permlane16_swap of blocks 2 p and 2 p + 1
+                    // (rows 1 <-> 0 and 3 <-> 2 of the two operands) leaves every lane with one 16-byte piece: lane row kq gets piece
+                    // 4 p + 2 (kq & 1) + (kq >> 1) of the voxel's BN / 8
+#pragma unroll
+                    for (int j = 0; j < JN; ++j) {
+                        const int v = (j >> 1) * 32 + ((j & 1) ? 16 + ((w16 + (HW & 15)) & 15) : w16);      // place in the staged tile (lane_w's rotation on odd rows)
+                        const int vs = NT == 2 ? (v & 7) : ((v >> 2) & 3);
+#pragma unroll
+                        for (int p = 0; p < NT; ++p) {
+                            unsigned pk[2][2];
+#pragma unroll
+                            for (int u = 0; u < 2; ++u) {
+                                float o[4];
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) {
+                                    const float vv = acc[j][2 * p + u][i];
+                                    if constexpr (ACT == FMRI_ACT_LEAKY) o[i] = vmax(vv, __builtin_fmaf(vv, act_s, 0.f));
+                                    else o[i] = vv;
+                                }
+                                pk[u][0] = pack2bf(o[0], o[1]);
+                                pk[u][1] = pack2bf(o[2], o[3]);
+                                if constexpr (ACT == FMRI_ACT_RELU) {
+                                    pk[u][0] = relu2(pk[u][0], zero2_);
+                                    pk[u][1] = relu2(pk[u][1], zero2_);
+                                }
+                            }
+#pragma unroll
+                            for (int q = 0; q < 2; ++q) {
+                                auto sw = __builtin_amdgcn_permlane16_swap(pk[0][q], pk[1][q], false, false);
+                                pk[0][q] = sw[0];
+                                pk[1][q] = sw[1];
+                            }
+                            const int q = p * 4 + ((kq & 1) << 1) + (kq >> 1);
+                            *reinterpret_cast<uint4*>(stage + v * (BN * 2) + (((q ^ vs) & SWM) << 4)) = make_uint4(pk[0][0], pk[0][1], pk[1][0], pk[1][1]);
+                        }
+                    }
+                } else
 #pragma unroll
                 for (int j = 0; j < JT; ++j) {
                     const int v = j * 32 + r;
@@ -1817,10 +2006,32 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
 #ifdef FMRI_PROF
         { PROF_T(ce1); cprof[4] += ce1 - ce0; }
 #endif
-        if (!has_next) break;
-        cur = nxt;
-        pair = npair;
-        hb ^= 1;
+    };
+    if constexpr (S16) {
+        while (true) {
+            while (true) {
+                item_next();
+                run_item();
+                if (cur.ch == nch - 1) break;
+                cur = nxt;
+                hb ^= 1;
+            }
+            tile_epilogue();
+            if (!has_next) break;
+            cur = nxt;
+            pair = npair;
+            hb ^= 1;
+        }
+    } else {
+        while (true) {
+            item_next();
+            run_item();
+            if (cur.ch == nch - 1) tile_epilogue();
+            if (!has_next) break;
+            cur = nxt;
+            pair = npair;
+            hb ^= 1;
+        }
     }
 #ifdef FMRI_PROF
     PROF_T(ck1);
@@ -1900,6 +2111,7 @@ k_conv_wgrad_mfma(SrcB s, const bf16_t* __restrict__ dy, float* __restrict__ dw,
     constexpr int STAGE_BYTES = X_BYTES + Y_BYTES;
     constexpr int NSTAGE = WS ? 3 : 2;                   // WS: the producers run TWO units ahead (one workgroup per CU leaves the LDS for it)
     __shared__ __attribute__((aligned(16))) unsigned char lds[NSTAGE * STAGE_BYTES];
+    const unsigned char* const zpage = zero_page_addr();
 
     const int Cin = s.C0 + s.C1;
     const int ncib = Cin / CIB, ncob = (UPW ? (s.planar ? 4 : 8) : 1) * (Cout / 64);
@@ -2017,12 +2229,14 @@ k_conv_wgrad_mfma(SrcB s, const bf16_t* __restrict__ dy, float* __restrict__ dw,
                             : dy + ((((int64_t)n * 2 * D + 2 * d + (par >> 2)) * 2 * H + 2 * h0 + ((par >> 1) & 1)) * 2 * W + 2 * w0 + (par & 1)) * Cout + co0)
                 : dy + ((((int64_t)n * D + d) * H + h0) * W + w0) * Cout + co0;
         const unsigned sbase = lds0 + buf * STAGE_BYTES;
-        const unsigned okm = dok ? x_ok : 0u;
+        // (round 5: through buffer descriptors, see k_conv_wgrad_kd's issue_x - out-of-volume rows are out-of-range offsets, an
+        // out-of-volume plane a descriptor of zero records)
+        const i32x4 xrs = dma_rsrc(xbase, dok ? (int)DMA_OOB : 0), yrs = dma_rsrc(ybase);
 #pragma unroll
         for (int j = 0; j < XPW; ++j)
-            dma16(((okm >> j) & 1) ? (const void*)(xbase + x_off[j]) : (const void*)g_zero_page, __builtin_amdgcn_readfirstlane(sbase + x_doff[j]));
+            dma16_buf(xrs, ((x_ok >> j) & 1) ? (unsigned)x_off[j] * 2u : DMA_OOB, __builtin_amdgcn_readfirstlane(sbase + x_doff[j]));
 #pragma unroll
-        for (int j = 0; j < YPW; ++j) dma16(ybase + y_soff[j], __builtin_amdgcn_readfirstlane(sbase + y_doff[j]));
+        for (int j = 0; j < YPW; ++j) dma16_buf(yrs, (unsigned)y_soff[j] * 2u, __builtin_amdgcn_readfirstlane(sbase + y_doff[j]));
         // advance the cursor: up the column, then on to the next column of the run
         if (++ic_d == D) {
             ic_d = 0;
@@ -2300,6 +2514,69 @@ __device__ __forceinline__ void wk_compute(const unsigned char* lds, const int (
     }
 }
 
+// S16 (round 5; BLK = 32): the same (32 Cout, 32 Cin) x 7-tap block per wave on v_mfma_f32_16x16x32_bf16 - four 16 x 16 accumulators per tap,
+// k = 32 voxels = two h-rows of the 8 x 16 plane tile per step.  The order of the voxels inside the k dimension is free as long as both
+// operands use the same one: k-group g (= lane >> 4, 8 voxels) of a step is h-row 2 m + (g >> 1), w = 4 (g & 1) + {0..3} and + 8, so one
+// transposing read (4 voxel rows x 32 bytes per 16-lane group) touches rows R .. R + 3 in group 0 and R + 4 .. R + 7 in group 1; with the
+// 32-byte halves of a 64-byte LDS row flipped on bit 2 of the row index (applied on the DMA source, WkCfg rows) the two groups of a
+// half-wave fall into different bank halves - the job the Cin / Cout half-selection does in the 32x32x16 form.
+template <int G>
+__device__ __forceinline__ void wk_compute16(const unsigned char* lds, const int (&xb)[3], int yb, const int (&pre_x)[8], int pre_y,
+                                             f32x4 (&acc)[G == 3 ? 6 : 7][2][2], float (&bsum)[2], bool do_bias) {
+    constexpr int NTAP = G == 3 ? 6 : 7, T0 = 7 * G, ROWB = 64;
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    // dy fragment of k-step m, Cout half h: rows m * 32 + (lane part), 16-channel half h = +32 bytes (flipped with the row's swizzle bit,
+    // which the lane part already carries: m * 32 rows never change it)
+    auto load_a = [&](int m, s16x8 (&av)[2]) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const unsigned char* p0 = lds + yb + (h ? (pre_y ^ 32) : pre_y) + m * 32 * ROWB;
+            s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p0);
+            s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p0 + 8 * ROWB));
+            av[h] = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+    };
+    // x fragment of (k-step m, tap T0 + j), Cin half h: halo row (2 m + kh) * XW + kw + (lane part); the lane part's swizzle bit depends on
+    // the row constant mod 8 (pre_x[c & 7]), the rest of the constant is a multiple of 8 rows
+    auto load_b = [&](int st, int h) {
+        const int m = st / NTAP, t = T0 + st % NTAP, kd = t / 9, kh = (t / 3) % 3, kw = t % 3;
+        const int c = (2 * m + kh) * wg::XW + kw;
+        const unsigned char* pb = lds + xb[kd] + (h ? (pre_x[c & 7] ^ 32) : pre_x[c & 7]) + (c >> 3) * 8 * ROWB;
+        s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)pb);
+        // (the second read is 8 rows on: same swizzle bit)
+        s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(pb + 8 * ROWB));
+        return __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
+    };
+    constexpr int NS = 4 * NTAP, PF = 2, RING = PF + 1;      // x fragment pairs in flight ahead of their MFMAs
+    s16x8 av[2], b[RING][2];
+#pragma unroll
+    for (int q = 0; q < PF; ++q) { b[q][0] = load_b(q, 0); b[q][1] = load_b(q, 1); }
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        load_a(m, av);
+        if constexpr (G == 3) {
+            if (do_bias) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) bsum[h] += bf2f((unsigned short)av[h][q]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NTAP; ++j) {
+            const int st = m * NTAP + j;
+            if (st + PF < NS) { b[(st + PF) % RING][0] = load_b(st + PF, 0); b[(st + PF) % RING][1] = load_b(st + PF, 1); }
+#pragma unroll
+            for (int hi = 0; hi < 2; ++hi)
+#pragma unroll
+                for (int ho = 0; ho < 2; ++ho)
+                    acc[j][ho][hi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, av[ho]), __builtin_bit_cast(bf16x8_t, b[st % RING][hi]),
+                                                                            acc[j][ho][hi], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
 struct WkArgs {
     SrcB s;
     const bf16_t* dy;
@@ -2309,8 +2586,9 @@ struct WkArgs {
 };
 
 // everything a wave does, instantiated per tap group so that the accumulators are one fixed register set for the kernel's lifetime
-template <int BLK, int G>
+template <int BLK, int G, bool S16 = false>
 __device__ __forceinline__ void wk_run(const WkArgs& a, unsigned char* lds, int wv, int lane) {
+    static_assert(!S16 || BLK == 32, "the 16x16x32 form is built for the 4-wave kernel");
     typedef WkCfg<BLK> K;
     constexpr int NTAP = G == 3 ? 6 : 7, NW = K::NW, NH = K::NH, ROWB = K::ROWB, RS = K::RS;
     const SrcB& s = a.s;
@@ -2336,18 +2614,27 @@ __device__ __forceinline__ void wk_run(const WkArgs& a, unsigned char* lds, int 
     // bias gradient = sum over the dy fragments: in the 6-tap group (it has registers to spare) of Cin half 0 / Cin block 0
     const bool do_bias = G == 3 && (a.db != nullptr) && cib == 0 && it == 0;
 
-    f32x16 acc[NTAP][NH];
+    f32x16 acc[S16 ? 1 : NTAP][NH];
+    f32x4 acc16[S16 ? NTAP : 1][2][2];
+    if constexpr (S16) {
 #pragma unroll
-    for (int q = 0; q < NTAP; ++q)
+        for (int q = 0; q < NTAP; ++q)
 #pragma unroll
-        for (int h = 0; h < NH; ++h)
+            for (int h = 0; h < 4; ++h) acc16[q][h >> 1][h & 1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    } else {
 #pragma unroll
-            for (int k = 0; k < 16; ++k) acc[q][h][k] = 0.f;
+        for (int q = 0; q < NTAP; ++q)
+#pragma unroll
+            for (int h = 0; h < NH; ++h)
+#pragma unroll
+                for (int k = 0; k < 16; ++k) acc[q][h][k] = 0.f;
+    }
     float bsum[2] = {0.f, 0.f};
 
     const int twn = W / wg::TW, thn = H / wg::TH;
     const int nunits = N * D * thn * twn;
     const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr(lds));
+    const unsigned char* const zpage = zero_page_addr();
 
     // ---- DMA.  A unit's wave-instructions (X_INSTR for an x plane, Y_INSTR for a dy plane) are dealt round-robin over the NW waves.  The
     // issue side keeps a cursor (cn, ch0, cw0) of the column being issued and, per column, the lane constants of its pieces: element offset
@@ -2364,12 +2651,13 @@ __device__ __forceinline__ void wk_run(const WkArgs& a, unsigned char* lds, int 
             const int id = wv + NW * k;
             const int i = id * 64 + lane;
             const int row = i / RS, ps = i % RS;
-            const int ls = RS == 8 ? (ps ^ (((row >> 1) & 1) << 2)) : ps;       // 128-byte rows flip their halves on row bit 1 (wg_slot_off)
+            // 128-byte rows flip their 64-byte halves on row bit 1 (wg_slot_off); S16: 64-byte rows flip their 32-byte halves on row bit 2
+            const int ls = RS == 8 ? (ps ^ (((row >> 1) & 1) << 2)) : (S16 ? (ps ^ (((row >> 2) & 1) << 1)) : ps);
             const int xh = row / wg::XW, xw = row % wg::XW;
             const int gh = h0 - 1 + xh, gw = w0 - 1 + xw;
             const bool ok = id < K::X_INSTR && row < wg::XROWS && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W;
             const int ghc = min(max(gh, 0), H - 1) >> sh, gwc = min(max(gw, 0), W - 1) >> sh;
-            x_off[k] = (ghc * sW + gwc) * sC + ls * 8;
+            x_off[k] = ((ghc * sW + gwc) * sC + ls * 8) * 2;                    // bytes
             x_ok |= (ok ? 1u : 0u) << k;
         }
 #pragma unroll
@@ -2377,8 +2665,8 @@ __device__ __forceinline__ void wk_run(const WkArgs& a, unsigned char* lds, int 
             const int id = (NW - 1 - wv) + NW * k;            // dealt from the other end: the waves with one x instruction fewer go first
             const int i = id * 64 + lane;
             const int row = i / RS, ps = i % RS;
-            const int ls = RS == 8 ? (ps ^ (((row >> 1) & 1) << 2)) : ps;
-            y_off[k] = ((row >> 4) * W + (row & 15)) * Cout + ls * 8;
+            const int ls = RS == 8 ? (ps ^ (((row >> 1) & 1) << 2)) : (S16 ? (ps ^ (((row >> 2) & 1) << 1)) : ps);
+            y_off[k] = (((row >> 4) * W + (row & 15)) * Cout + ls * 8) * 2;      // bytes
         }
     };
     // plane `gd` (may lie outside the volume: zeros) of the cursor's column into x slot `slot`
@@ -2386,21 +2674,23 @@ __device__ __forceinline__ void wk_run(const WkArgs& a, unsigned char* lds, int 
         const bool dok = (unsigned)gd < (unsigned)D;
         const int gdc = min(max(gd, 0), D - 1) >> shd;
         const bf16_t* const xbase = sp + ((int64_t)cn * sD + gdc) * sH * sW * sC + coff;
-        const unsigned okm = dok ? x_ok : 0u;
+        // (round 5: through a buffer descriptor - a halo row outside the volume in h or w gets an out-of-range offset and lands as zeros, a
+        // plane outside the volume in d a descriptor of zero records: no zero page, no 64-bit pointer select per lane)
+        const i32x4 rs = dma_rsrc(xbase, dok ? (int)DMA_OOB : 0);
 #pragma unroll
         for (int k = 0; k < K::XPW; ++k) {
             const int id = wv + NW * k;
             if (id < K::X_INSTR)
-                dma16(((okm >> k) & 1) ? (const void*)(xbase + x_off[k]) : (const void*)g_zero_page,
+                dma16_buf(rs, ((x_ok >> k) & 1) ? (unsigned)x_off[k] : DMA_OOB,
                       __builtin_amdgcn_readfirstlane(lds0 + slot * K::XS_BYTES + id * 1024));
         }
     };
     auto issue_y = [&](int d, int ybuf) {
-        const bf16_t* const ybase = a.dy + ((((int64_t)cn * D + d) * H + ch0) * W + cw0) * Cout + co0;
+        const i32x4 yrs = dma_rsrc(a.dy + ((((int64_t)cn * D + d) * H + ch0) * W + cw0) * Cout + co0);
 #pragma unroll
         for (int k = 0; k < K::YPW; ++k) {
             const int id = (NW - 1 - wv) + NW * k;
-            if (id < K::Y_INSTR) dma16(ybase + y_off[k], __builtin_amdgcn_readfirstlane(lds0 + K::NXS * K::XS_BYTES + ybuf * K::YS_BYTES + id * 1024));
+            if (id < K::Y_INSTR) dma16_buf(yrs, (unsigned)y_off[k], __builtin_amdgcn_readfirstlane(lds0 + K::NXS * K::XS_BYTES + ybuf * K::YS_BYTES + id * 1024));
         }
     };
 
@@ -2408,10 +2698,19 @@ __device__ __forceinline__ void wk_run(const WkArgs& a, unsigned char* lds, int 
     const int gq = lane >> 4, qd = (lane & 15) >> 2, pp = lane & 3;
     const int lrow = 8 * (gq >> 1) + qd;
     const int lslot_x = it * 4 + 2 * (gq & 1) + (pp >> 1), lslot_y = 2 * (gq & 1) + (pp >> 1);
-    int pre_x[4];
+    int pre_x[S16 ? 8 : 4];
+    int pre_y;
+    if constexpr (S16) {
+        // lane (g = k-group, qd = voxel row of the read, pp = 8-byte piece of the 32-byte half): voxel (h-row g >> 1, w = 4 (g & 1) + qd) of the step
+        const int lx = (gq >> 1) * wg::XW + 4 * (gq & 1) + qd, ly = (gq >> 1) * wg::TW + 4 * (gq & 1) + qd;
 #pragma unroll
-    for (int m = 0; m < 4; ++m) pre_x[m] = wg_slot_off<ROWB>(lrow + m, lslot_x) + (pp & 1) * 8;
-    const int pre_y = wg_slot_off<ROWB>(lrow, lslot_y) + (pp & 1) * 8;
+        for (int m = 0; m < 8; ++m) pre_x[m] = ((lx + m) * 64 + pp * 8) ^ ((((lx + m) >> 2) & 1) << 5);
+        pre_y = (ly * 64 + pp * 8) ^ (((ly >> 2) & 1) << 5);
+    } else {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) pre_x[m] = wg_slot_off<ROWB>(lrow + m, lslot_x) + (pp & 1) * 8;
+        pre_y = wg_slot_off<ROWB>(lrow, lslot_y) + (pp & 1) * 8;
+    }
 
     const int per = (nunits + a.nslab - 1) / a.nslab;
     int u = slab * per;
@@ -2455,7 +2754,8 @@ __device__ __forceinline__ void wk_run(const WkArgs& a, unsigned char* lds, int 
             int xb[3] = {((xs + 2) & 3) * K::XS_BYTES, ((xs + 3) & 3) * K::XS_BYTES, xs * K::XS_BYTES};
 #pragma unroll
             for (int k = 0; k < 3; ++k) asm volatile("" : "+s"(xb[k]));       // slot bases stay scalar: base + lane offset is added per read
-            wk_compute<BLK, G>(lds, xb, K::NXS * K::XS_BYTES + yb * K::YS_BYTES, pre_x, pre_y, acc, bsum, do_bias);
+            if constexpr (S16) wk_compute16<G>(lds, xb, K::NXS * K::XS_BYTES + yb * K::YS_BYTES, pre_x, pre_y, acc16, bsum, do_bias);
+            else wk_compute<BLK, G>(lds, xb, K::NXS * K::XS_BYTES + yb * K::YS_BYTES, pre_x, pre_y, acc, bsum, do_bias);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             PROF_T(w4);
 #ifdef FMRI_PROF
@@ -2482,6 +2782,34 @@ __device__ __forceinline__ void wk_run(const WkArgs& a, unsigned char* lds, int 
     }
     // ---- flush: D rows = co, cols = ci; fp32 atomics, 128 contiguous bytes per half-wave (deterministic mode: fixed-point shadow)
     const FmriDetCfg dc = g_det_cfg;
+    if constexpr (S16) {
+        // D rows = co (4 (lane >> 4) + reg inside the 16-channel half), cols = ci (lane & 15): 64 contiguous bytes per 16-lane group
+#pragma unroll
+        for (int j = 0; j < NTAP; ++j) {
+            const int tap = 7 * G + j;
+#pragma unroll
+            for (int ho = 0; ho < 2; ++ho)
+#pragma unroll
+                for (int hi = 0; hi < 2; ++hi)
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) {
+                        const int co = co0 + ho * 16 + 4 * (lane >> 4) + reg;
+                        const int ci = cc + hi * 16 + (lane & 15);
+                        fmri_grad_add(dc, &a.dw[((int64_t)tap * Cout + co) * a.dw_ld + ci], acc16[j][ho][hi][reg]);
+                    }
+        }
+        if (do_bias) {
+            // a lane summed its 8 voxels of every step for Cout lane & 15 of half h: the four k-groups meet
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                float b = bsum[h];
+                b += __shfl_down(b, 32);
+                b += __shfl_down(b, 16);
+                if (lane < 16) fmri_grad_add(dc, &a.db[co0 + h * 16 + lane], b);
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < NTAP; ++j) {
         const int tap = 7 * G + j;
@@ -2504,16 +2832,16 @@ __device__ __forceinline__ void wk_run(const WkArgs& a, unsigned char* lds, int 
     }
 }
 
-template <int BLK>
+template <int BLK, bool S16 = false>
 __global__ void __launch_bounds__(WkCfg<BLK>::NW * 64, BLK == 64 ? 1 : 2) k_conv_wgrad_kd(WkArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[WkCfg<BLK>::LDS_BYTES];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     switch (wv & 3) {                                     // tap group
-        case 0: wk_run<BLK, 0>(a, lds, wv, lane); break;
-        case 1: wk_run<BLK, 1>(a, lds, wv, lane); break;
-        case 2: wk_run<BLK, 2>(a, lds, wv, lane); break;
-        default: wk_run<BLK, 3>(a, lds, wv, lane); break;
+        case 0: wk_run<BLK, 0, S16>(a, lds, wv, lane); break;
+        case 1: wk_run<BLK, 1, S16>(a, lds, wv, lane); break;
+        case 2: wk_run<BLK, 2, S16>(a, lds, wv, lane); break;
+        default: wk_run<BLK, 3, S16>(a, lds, wv, lane); break;
     }
 }
 
@@ -2630,6 +2958,14 @@ static int fwd_async() {                // FMRI_FWD_ASYNC=0: the tile's stores b
     }
     return v;
 }
+static int fwd_mfma16() {               // FMRI_MFMA16=0: v_mfma_f32_32x32x16_bf16 in the warp-specialised forward kernel (rounds 1-4), 1: 16x16x32 (S16)
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("FMRI_MFMA16");
+        v = e ? atoi(e) : 0;
+    }
+    return v;
+}
 static bool fwd_wide(int mode, int planar, int ntile, int Cout) {
     // 64-wide Cout blocks halve the halo traffic per MFMA, but a launch with fewer (tile, block) pairs than CUs (the 8x16x16 bottleneck
     // level) leaves CUs idle: 32-wide blocks double the pairs there
@@ -2640,21 +2976,47 @@ static int conv3d_fwd_mfma_launch(int mode, const void* src0, int C0, int up0, i
                                   const float* bias, const void* mask, const void* residual, void* y, int N, int D, int H, int W, int Cout,
                                   int act, float alpha, FwdTail tail, hipStream_t st) {
     SrcB s{(const bf16_t*)src0, (const bf16_t*)src1, C0, C1, up0, planar ? 0 : 1, planar};
+    // the parity modes form a fresh halo pointer as [one plain source] + box corner + lane constant (CHEAP_FRESH / FH): a second source or a
+    // fused up-sampling there would read wrong addresses instead of failing
+    if (mode != 0 && (C1 != 0 || up0)) return FMRI_E_SHAPE;
     const bool cube = (D % fw::TD) || (H % fw::TH) || (W % fw::TW);       // only the 8x8x8 tiling fits (conv3d_fwd_mfma_ok)
     const int ntile = cube ? N * (D / 8) * (H / 8) * (W / 8) : N * (D / fw::TD) * (H / fw::TH) * (W / fw::TW);
     const int ncu = fwd_cu_count();
     const int use_ws = fwd_use_ws();
     // fast halo addressing (k_conv_fwd_ws<..., FH = true>): single plain source, at most two 32-channel chunks per freshly addressed halo
-    const bool fh_any = fwd_fast_halo() && !cube && C1 == 0 && !up0 && (mode == 2 ? C0 / 32 : (C0 + C1) / 32) <= 2;
-    const bool fh = fh_any && !planar;                 // (the warp-specialised kernel's form covers the 3-D launches)
-#define FMRI_WS(NT_, PL_, MODE_, RES_, A_, EPI_, GRID_)                                                                    \
+    // (round 5: the warp-specialised kernel's form goes through a buffer descriptor and fixes a tile's out-of-volume offsets up once per
+    // tile: it serves every single-source 3-D launch (same-box A/B, profiles/r05_buffer_halo_ab.log: forward family -1.9 %, step +0.9 %;
+    // FMRI_FH_MAXCH = the most chunks per fresh address for which it is taken, 2 = the round-4 rule)
+    static int fh_maxch = -1;
+    if (fh_maxch < 0) {
+        const char* e = getenv("FMRI_FH_MAXCH");
+        fh_maxch = e ? atoi(e) : 1 << 20;
+    }
+    const int nchunk_fresh = mode == 2 ? C0 / 32 : (C0 + C1) / 32;
+    const bool fh_any = fwd_fast_halo() && !cube && C1 == 0 && !up0 && nchunk_fresh <= 2;
+    const bool fh = fwd_fast_halo() && !cube && C1 == 0 && !up0 && nchunk_fresh <= fh_maxch && !planar;       // (the warp-specialised kernel's form covers the 3-D launches)
+    const bool s16 = fwd_mfma16() && !planar;
+    {
+        static int prio = -1;
+        if (prio < 0) {
+            const char* e = getenv("FMRI_FWD_PRIO");
+            prio = e ? atoi(e) : 0;
+        }
+        tail.prio = prio;
+    }
+#define FMRI_WS2(NT_, PL_, MODE_, RES_, A_, EPI_, FH_, GRID_)                                                              \
     do {                                                                                                                  \
-        if (fh && !(PL_))                                                                                                 \
-            k_conv_fwd_ws<NT_, PL_, MODE_, RES_, A_, EPI_, !(PL_)><<<GRID_, fw::NTHREADS, 0, st>>>(                       \
+        if (s16 && !(PL_))                                                                                                \
+            k_conv_fwd_ws<NT_, PL_, MODE_, RES_, A_, EPI_, FH_, !(PL_)><<<GRID_, fw::NTHREADS, 0, st>>>(                  \
                 s, (const bf16_t*)w, bias, (const bf16_t*)mask, (const bf16_t*)residual, (bf16_t*)y, N, D, H, W, Cout, act, alpha, tail); \
         else                                                                                                              \
-            k_conv_fwd_ws<NT_, PL_, MODE_, RES_, A_, EPI_, false><<<GRID_, fw::NTHREADS, 0, st>>>(                        \
+            k_conv_fwd_ws<NT_, PL_, MODE_, RES_, A_, EPI_, FH_, false><<<GRID_, fw::NTHREADS, 0, st>>>(                   \
                 s, (const bf16_t*)w, bias, (const bf16_t*)mask, (const bf16_t*)residual, (bf16_t*)y, N, D, H, W, Cout, act, alpha, tail); \
+    } while (0)
+#define FMRI_WS(NT_, PL_, MODE_, RES_, A_, EPI_, GRID_)                                                                    \
+    do {                                                                                                                  \
+        if (fh && !(PL_)) FMRI_WS2(NT_, PL_, MODE_, RES_, A_, EPI_, !(PL_), GRID_);                                       \
+        else FMRI_WS2(NT_, PL_, MODE_, RES_, A_, EPI_, false, GRID_);                                                     \
     } while (0)
 #define FMRI_LAUNCH_FWD(NT_, PL_, MODE_, RES_)                                                                             \
     do {                                                                                                                  \
@@ -2681,9 +3043,7 @@ static int conv3d_fwd_mfma_launch(int mode, const void* src0, int C0, int up0, i
         const int np_ = ntile * (Cout / (wide ? 64 : 32));
         if (cube || mode != 0 || planar || !use_ws || !fwd_async() || np_ <= ncu || tail.pool || tail.logits || tail.bias27) return FMRI_E_SHAPE;
         if (tail.nss ? (!mask || residual) : (mask != nullptr)) return FMRI_E_SHAPE;
-#define FMRI_LAUNCH_NT(NT_, EPI_)                                                                                          \
-        k_conv_fwd_ws<NT_, false, 0, false, true, EPI_><<<ncu, fw::NTHREADS, 0, st>>>(s, (const bf16_t*)w, bias, (const bf16_t*)mask,     \
-                                                                                       (const bf16_t*)residual, (bf16_t*)y, N, D, H, W, Cout, act, alpha, tail)
+#define FMRI_LAUNCH_NT(NT_, EPI_) FMRI_WS2(NT_, false, 0, false, true, EPI_, false, ncu)
         if (tail.nss) { if (wide) FMRI_LAUNCH_NT(2, 5); else FMRI_LAUNCH_NT(1, 5); }
         else if (residual) { if (wide) FMRI_LAUNCH_NT(2, 6); else FMRI_LAUNCH_NT(1, 6); }
         else { if (wide) FMRI_LAUNCH_NT(2, 4); else FMRI_LAUNCH_NT(1, 4); }
@@ -2731,6 +3091,7 @@ static int conv3d_fwd_mfma_launch(int mode, const void* src0, int C0, int up0, i
     }
 #undef FMRI_LAUNCH_FWD
 #undef FMRI_WS
+#undef FMRI_WS2
     FMRI_LAUNCH_CHECK();
     return FMRI_OK;
 }
@@ -2891,7 +3252,13 @@ int conv3d_wgrad_mfma_ld(const void* src0, int C0, int up0, int planar, const vo
         if (nsl > nunits) nsl = nunits;
         if (nsl < 1) nsl = 1;
         const WkArgs wa{s, (const bf16_t*)dy, dw, db, N, D, H, W, Cout, nsl, dw_ld};
+        static int wg16 = -1;                // FMRI_WGRAD_MFMA16=1: v_mfma_f32_16x16x32_bf16 in the kd-sharing kernel (wk_compute16)
+        if (wg16 < 0) {
+            const char* e = getenv("FMRI_WGRAD_MFMA16");
+            wg16 = e ? atoi(e) : 0;
+        }
         if (kd_blk == 64) k_conv_wgrad_kd<64><<<combos_kd * nsl, 512, 0, st>>>(wa);
+        else if (wg16) k_conv_wgrad_kd<32, true><<<combos_kd * nsl, 256, 0, st>>>(wa);
         else k_conv_wgrad_kd<32><<<combos_kd * nsl, 256, 0, st>>>(wa);
         FMRI_LAUNCH_CHECK();
         return FMRI_OK;

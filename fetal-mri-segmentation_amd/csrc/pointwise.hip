@@ -20,6 +20,24 @@ extern "C" const char* fmri_error_string(int code) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------ shader-clock stamps (measurement aid)
+// One (s_memtime, s_memrealtime) pair per XCD: s_memtime ticks with the shader clock, s_memrealtime at a constant 100 MHz, so two stamps
+// bracket a region's average shader clock: d(memtime) / d(memrealtime) x 0.1 GHz (MI355X guide, 'DVFS give-back' item 6).  The counters
+// are per XCD, so a workgroup writes the slot of the XCD it runs on (HW_REG_XCC_ID); 64 workgroups reach all eight.
+__global__ void k_clock_stamp(unsigned long long* out) {
+    if (threadIdx.x != 0) return;
+    const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7u;       // XCC_ID[3:0], hwreg 20 on gfx942 / gfx950
+    const unsigned long long t = __builtin_amdgcn_s_memtime(), r = __builtin_amdgcn_s_memrealtime();
+    out[2 * xcc] = t;
+    out[2 * xcc + 1] = r;
+}
+extern "C" int fmri_clock_stamp(unsigned long long* out16, fmri_stream_t stream) {
+    if (!out16) return FMRI_E_SHAPE;
+    k_clock_stamp<<<64, 64, 0, as_stream(stream)>>>(out16);
+    FMRI_LAUNCH_CHECK();
+    return FMRI_OK;
+}
+
 __device__ __forceinline__ void decode_vox(int64_t v, int Do, int Ho, int Wo, int& n, int& d, int& h, int& w) {
     w = (int)(v % Wo); v /= Wo;
     h = (int)(v % Ho); v /= Ho;

@@ -16,7 +16,8 @@ Applied augmenters: flip, scale, iso_scale, rotate, translate, piecewise_affine,
 intensity_multiplication, gaussian_filter (skimage.filters.gaussian), poisson_noise (the reference's shot_noise), speckle_noise,
 gaussian_noise, coarse_dropout (imgaug CoarseDropout) - in the reference's order (augment.py:344-375), i.e. everything the reference's
 default config switches on (fetal/config_utils.py:81-123).  The three imgaug augmenters follow imgaug 0.4.0 as published (the reference
-does not pin a version and the package is not installed here: their oracle says "parity unpinned", oracle/augment_oracle.py).
+does not pin a version and the package is not installed here: their oracle says "parity unpinned", oracle/augment_oracle.py); the elastic
+warp restates `_map_coordinates`' scipy branch, not the cv2.remap branch imgaug prefers for float images when cv2 is importable.
 imgaug's piecewise_affine (commented out in the reference's default config, config_utils.py:101-103) is applied as well when configured,
 between the affine sampling and the elastic transform (augment.py:344-347), on the reference's 2 x 2 grid.
 The noise fields (normal, uniform and Poisson draws) come from a torch device generator (`noise_seed`), not numpy.
@@ -95,9 +96,13 @@ def list_generator(index_list):
         yield from index_list
 
 
+COARSE_MIN_SIZE = 3
+
+
 def _coarse_grid(shape2d, size_percent, rng):
     """imgaug parameters.FromLowerResolution: one size_percent per axis - a list is a choice among its values (the reference's default
-    [0.10, 0.30]), a tuple a uniform range, a number itself; grid = int(extent * percent), at least 1"""
+    [0.10, 0.30]), a tuple a uniform range, a number itself; grid = int(extent * percent), at least MIN_SIZE = 3 per side (the `min_size`
+    imgaug 0.4.0's CoarseDropout passes to FromLowerResolution: a patch under 30 voxels at 10 % still drops cells, not whole slices)"""
     out = []
     for extent in shape2d:
         if isinstance(size_percent, list):
@@ -106,7 +111,7 @@ def _coarse_grid(shape2d, size_percent, rng):
             sp = rng.uniform(size_percent[0], size_percent[1])
         else:
             sp = size_percent
-        out.append(max(int(extent * sp), 1))
+        out.append(max(int(extent * sp), COARSE_MIN_SIZE))
     return tuple(out)
 
 

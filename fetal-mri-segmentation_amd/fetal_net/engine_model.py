@@ -337,9 +337,18 @@ class _Stager(object):
         self.slots = [_Slot() for _ in range(max(2, depth))]
         self.k = 0
         self._thread_ready = False
+        self.owner = None              # the producer thread that fills the ring (set by its first stage() call)
+
+    def busy(self):
+        """is the ring still owned by a LIVE producer thread?  (an on_epoch_end callback that calls evaluate_generator while fit_generator's
+        validation producer runs; a producer whose bounded join timed out inside a slow next(generator)) - such a ring must not be reset
+        and handed to a second thread: two producers would refill slots whose H2D copy or consuming step is still in flight"""
+        return self.owner is not None and self.owner.is_alive()
 
     def reset(self):
         """a new producer thread takes the ring over (the previous one has ended): all slots free, the caller's current stream is the consumer"""
+        assert not self.busy(), "staging ring reset under a live producer thread"
+        self.owner = None
         self.main = self.torch.cuda.current_stream()
         self.k = 0
         self._thread_ready = False
@@ -369,6 +378,7 @@ class _Stager(object):
         if not self._thread_ready:
             torch.cuda.set_device(self.device)            # the producer thread issues device work: bind it to the trainer's GPU first
             self._thread_ready = True
+            self.owner = threading.current_thread()
         slot = self.slots[self.k % len(self.slots)]
         self.k += 1
         while not slot.free.wait(timeout=0.1):
@@ -741,7 +751,8 @@ class Model(object):
             return None
         cache = self.__dict__.setdefault("_stagers", {})
         st = cache.get(role)
-        if st is None or st.device != torch.cuda.current_device():
+        if st is None or st.device != torch.cuda.current_device() or st.busy():
+            # (busy: the cached ring still belongs to a live producer - leave it to that thread and give this call a ring of its own)
             st = cache[role] = _Stager(self, depth=int(os.environ.get("FMRI_STAGE_DEPTH", "3")))
         st.reset()
         return st

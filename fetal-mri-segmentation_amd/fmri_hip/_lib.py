@@ -24,6 +24,7 @@ p, i32, i64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_float
 SIGNATURES = {
     "fmri_version": [],
     "fmri_error_string": [i32],
+    "fmri_clock_stamp": [p, p],
     "fmri_conv3d_uses_mfma": [i32] * 7,
     "fmri_conv3d_fwd": [p, i32, i32, p, i32, p, p, p, p, i32, i32, i32, i32, i32, i32, f32, i32, i32, i32, p],
     "fmri_conv3d_fwd_tail_ok": [i32] * 7,

@@ -98,8 +98,10 @@ class UNetEngine:
         self.dist = dist_ctx
         self.t = 0                       # Adam step counter
         self._pack_stream, self._pack_events, self._pack_event_dec, self._pack_pending = None, None, None, []
-        self._wg_stream = (torch.cuda.Stream(device=self.dev) if (training and self.dev.type == "cuda" and os.environ.get("FMRI_WGRAD_STREAM", "1") != "0")
-                           else None)
+        # FMRI_WGRAD_PRIO (A/B): HIP priority of the weight-gradient stream (0 = default, positive = lower): with a lower one the dispatcher hands free
+        # CUs to the input-gradient chain first and the weight-gradient backlog fills in behind the HBM-bound kernels of the main stream
+        self._wg_stream = (torch.cuda.Stream(device=self.dev, priority=int(os.environ.get("FMRI_WGRAD_PRIO", "0")))
+                           if (training and self.dev.type == "cuda" and os.environ.get("FMRI_WGRAD_STREAM", "1") != "0") else None)
         self.loss_kind, self.loss_param = 0, 1.0      # ops.LOSS_KINDS: 0 = dice_coefficient_loss
         # FMRI_DETERMINISTIC=1: bit-reproducible training steps (same weights + same batch -> the same bits in every gradient and metric):
         # gradient partial sums meet as fixed-point integers in a shadow of G (ops.set_deterministic), the parity-form weight gradient -
@@ -397,8 +399,6 @@ class UNetEngine:
         level-1 convs wait for the 256 -> 512 image, whose kernel - like every kernel next to a persistent conv launch, which fills all
         CUs - only gets CUs between two conv launches: 74 us of stall behind the first level in the rocprofv3 timeline; un-profiled the
         step does not notice: 13.09-13.15 ms either way.)"""
-        if overlap and os.environ.get("FMRI_EXP_SKIP_REPACK", "0") == "1":      # timing experiment only (stale weight images): what the repack costs the step
-            return
         early = set(c["name"] for c in self.plan.enc[0])
         if overlap and self.dev.type == "cuda" and os.environ.get("FMRI_PACK_OVERLAP", "1") != "0":
             if self._pack_stream is None:

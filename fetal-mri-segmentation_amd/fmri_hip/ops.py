@@ -428,6 +428,28 @@ def loss_value_from_sums(s, kind, param=1.0, smooth=1.0):
     return -dice + param * (2 * (Sp - I) + smooth) / ((n - Sy) + Sp + smooth)
 
 
+def clock_stamp(out16):
+    """one {s_memtime, s_memrealtime} pair per XCD into out16 (int64[16], device) on the current stream (include/fmri_hip.h: fmri_clock_stamp)"""
+    _need_cuda(out16)
+    assert out16.dtype == torch.int64 and out16.numel() >= 16 and out16.is_contiguous()
+    check(lib().fmri_clock_stamp(_p(out16), _s()), "fmri_clock_stamp")
+
+
+def clock_ghz(stamp0, stamp1):
+    """average shader clock between two stamps: median over the XCDs both stamps reached of d(memtime) / d(memrealtime) x 0.1 GHz;
+    returns (GHz or None, per-XCD list)"""
+    a, b = stamp0.cpu().numpy().astype("int64"), stamp1.cpu().numpy().astype("int64")
+    per = []
+    for x in range(8):
+        dt, dr = int(b[2 * x] - a[2 * x]), int(b[2 * x + 1] - a[2 * x + 1])
+        if a[2 * x + 1] != 0 and dr > 0 and dt > 0:
+            per.append(dt / dr * 0.1)
+    if not per:
+        return None, per
+    srt = sorted(per)
+    return srt[len(srt) // 2], per
+
+
 def set_deterministic(grad, shadow):
     """register (fp32 gradient buffer, zeroed int64 shadow of the same length) for bit-reproducible gradient accumulation, or (None, None)
     to switch it off (include/fmri_hip.h: fmri_set_deterministic); process-wide"""

@@ -37,6 +37,11 @@ enum { FMRI_IMPL_AUTO = 0, FMRI_IMPL_GENERIC = 1, FMRI_IMPL_MFMA = 2 };
 
 int fmri_version(void);
 const char* fmri_error_string(int code);
+/* Measurement aid (no reference counterpart): writes one {s_memtime, s_memrealtime} pair per XCD into out16[2 * xcd + {0, 1}]
+ * (16 x uint64 of device memory; an XCD no workgroup of the launch reached keeps its old value).  Two stamps on one stream bracket a
+ * region: average shader clock = d(memtime) / d(memrealtime) x 0.1 GHz per XCD - the `clock_ghz` of the bench line (the chip is
+ * power-limited under this workload: the clock explains box-to-box and recipe-to-recipe differences). */
+int fmri_clock_stamp(unsigned long long* out16, fmri_stream_t stream);
 /* 0/1: would fmri_conv3d_fwd / _wgrad take the MFMA path for this shape and dtype? (host-side query, no GPU needed) */
 int fmri_conv3d_uses_mfma(int C0, int C1, int Cout, int D, int H, int W, int dtype);
 
@@ -355,7 +360,9 @@ int fmri_shot_noise_step(void* x, int64_t n, int dtype, const float* stats, int*
                          fmri_stream_t stream);
 /* imgaug ElasticTransformation as the reference applies it (fetal_net/augment.py:149-170; in the DEFAULT config, fetal/config_utils.py:104-107):
  * dst[i][j][c] = src[:, :, c] sampled at (i - d0[i][j], j - d1[i][j]) - one in-plane displacement field for every slice c and for image, truth,
- * previous-slice truth and mask alike; order 1 (image: bilinear) or 0 (labels: nearest, floor(c + 0.5)), mode 'nearest' (coordinates clamped).
+ * previous-slice truth and mask alike; order 1 (image: bilinear) or 0 (labels: nearest, floor(c + 0.5)), mode 'nearest' (coordinates clamped) -
+ * the scipy branch of imgaug 0.4.0's `_map_coordinates` (its cv2.remap branch, taken for float images where cv2 is importable, quantises
+ * coordinates to 1/32 pixel; parity unpinned, see oracle/augment_oracle.py).
  * src, dst: [X][Y] rows of src_ld / dst_ld elements (>= C), dtype FMRI_F32 or FMRI_U8; d0, d1 fp32 [X][Y].  src != dst. */
 int fmri_elastic_warp(const void* src, int dtype, int X, int Y, int C, int src_ld, const float* d0, const float* d1, int order, void* dst,
                       int dst_ld, fmri_stream_t stream);

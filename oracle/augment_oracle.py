@@ -156,7 +156,12 @@ def elastic_shift_maps(shape2d, alpha, sigma, noise):
 
 def elastic_apply(image, dx, dy, order):
     """geometric.py `_map_coordinates`: every channel image[:, :, c] sampled at (y - dy, x - dx), scipy map_coordinates(order, mode='nearest')
-    (the reference passes mode="nearest", order 1 for the volume and 0 for truth / previous truth / mask, augment.py:151-168)"""
+    (the reference passes mode="nearest", order 1 for the volume and 0 for truth / previous truth / mask, augment.py:151-168).
+    This restates the function's SCIPY branch.  imgaug 0.4.0 sends float32 / float64 images at order 0 / 1 through cv2 instead when cv2 is
+    importable (cv2.convertMaps to CV_16SC2 + cv2.remap: coordinates quantised to 1/32 pixel, fixed-point bilinear weights, cvRound for
+    order 0, BORDER_REPLICATE); cv2 exists in no interpreter here, so which branch the reference's environment took is unknown - one more
+    reason this augmenter is PARITY UNPINNED.  At the reference's alpha <= 5, sigma = 10 (displacements ~0.1 pixel) the branches differ by
+    at most 1/64 pixel of coordinate."""
     image = np.asarray(image)
     h, w = image.shape[:2]
     yy, xx = np.meshgrid(np.arange(h, dtype=np.float64), np.arange(w, dtype=np.float64), indexing="ij")
@@ -224,9 +229,12 @@ def coarse_dropout(data, keep_small):
     return (scaled - mn) / scale
 
 
+COARSE_MIN_SIZE = 3
+
+
 def coarse_dropout_grid(shape2d, size_percent, rng):
     """parameters.FromLowerResolution.draw_samples: one size_percent per axis (a list = a choice among its values, a tuple = uniform, a number
-    = itself), grid = int(extent * percent), at least 1"""
+    = itself), grid = int(extent * percent), at least COARSE_MIN_SIZE = 3 per side (CoarseDropout's `min_size` default in imgaug 0.4.0)"""
     out = []
     for extent in shape2d:
         if isinstance(size_percent, list):
@@ -235,7 +243,7 @@ def coarse_dropout_grid(shape2d, size_percent, rng):
             sp = rng.uniform(size_percent[0], size_percent[1])
         else:
             sp = size_percent
-        out.append(max(int(extent * sp), 1))
+        out.append(max(int(extent * sp), COARSE_MIN_SIZE))
     return tuple(out)
 
 

@@ -122,3 +122,24 @@ def test_override_detection_and_producer_shutdown():
     assert get() == 1
     with pytest.raises(RuntimeError):
         get()
+
+
+def test_a_staging_ring_with_a_live_producer_is_not_handed_to_a_second_thread():
+    """`_staging()` reset the cached ring unconditionally - under a live producer (an evaluate_generator call from inside
+    on_epoch_end, a producer whose bounded join timed out) two threads would share slot buffers.  The ring records its producer; a ring
+    that is still owned is left alone (`busy()`), and resetting one asserts."""
+    import threading
+    from fetal_net.engine_model import _Stager
+    st = object.__new__(_Stager)
+    st.owner = None
+    assert not st.busy()
+    release = threading.Event()
+    th = threading.Thread(target=release.wait, daemon=True)
+    th.start()
+    st.owner = th
+    assert st.busy()
+    with pytest.raises(AssertionError):
+        st.reset()
+    release.set()
+    th.join()
+    assert not st.busy()

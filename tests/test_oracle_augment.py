@@ -241,7 +241,7 @@ def test_coarse_dropout_enlarges_the_grid_by_nearest_neighbour_and_drops_to_the_
     assert np.allclose(both, data.min())
     g = [A.coarse_dropout_grid((128, 128), [0.10, 0.30], np.random.RandomState(s)) for s in range(20)]
     assert set(v for pair in g for v in pair) == {12, 38}              # a list is a choice between its two values, per axis
-    assert A.coarse_dropout_grid((5, 5), 0.01, rs) == (1, 1)
+    assert A.coarse_dropout_grid((5, 5), 0.01, rs) == (3, 3)          # min_size = 3 per side (imgaug 0.4.0 CoarseDropout default)
 
 
 def test_piecewise_affine_restatement_on_a_2x2_grid():

@@ -22,8 +22,8 @@ cd /tmp
 want stats && rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o stats -- python3 "$ROOT/bench.py" --steps 10 --warmup 3 --no-cpu-baseline --val-dice-steps 0 --no-secondary --no-exclusive-pass > "$OUT/stats.log" 2>&1
 # one stream: exclusive kernel durations (what bench.py reports as roofline_exclusive)
 want stats && rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_serial" -o stats -- python3 "$ROOT/bench.py" --steps 10 --warmup 3 --no-cpu-baseline --val-dice-steps 0 --no-secondary --serialize-streams --per-layer "$OUT/per_layer.json" > "$OUT/stats_serial.log" 2>&1
-want traffic && rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch" -o fetch -- python3 "$ROOT/bench.py" --steps 1 --warmup 1 --prewarm-seconds 0 --no-cpu-baseline --val-dice-steps 0 --no-secondary --serialize-streams > "$OUT/pmc_fetch.log" 2>&1
-want traffic && rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_write" -o write -- python3 "$ROOT/bench.py" --steps 1 --warmup 1 --prewarm-seconds 0 --no-cpu-baseline --val-dice-steps 0 --no-secondary --serialize-streams > "$OUT/pmc_write.log" 2>&1
+want traffic && rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch" -o fetch -- python3 "$ROOT/bench.py" --steps 2 --warmup 1 --prewarm-seconds 0 --no-cpu-baseline --val-dice-steps 0 --no-secondary --serialize-streams > "$OUT/pmc_fetch.log" 2>&1
+want traffic && rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_write" -o write -- python3 "$ROOT/bench.py" --steps 2 --warmup 1 --prewarm-seconds 0 --no-cpu-baseline --val-dice-steps 0 --no-secondary --serialize-streams > "$OUT/pmc_write.log" 2>&1
 # MFMA utilisation from the counters (north_star / SURVEY 8d "SQ_VALU_MFMA_BUSY_CYCLES"): SQ + GRBM counters only, their own pass, the
 # program directly behind `--`.  SQ_VALU_MFMA_BUSY_CYCLES counts shader cycles in which a SIMD's matrix pipe is busy (32 per
 # v_mfma_f32_32x32x16_bf16), GRBM_GUI_ACTIVE is the sum over the 8 XCDs of their active cycles (MI355X_MICROARCH.md, DVFS give-back).
