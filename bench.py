@@ -358,8 +358,8 @@ def secondary_line(cfg):
     print(json.dumps(line))
 
 
-TRAFFIC_PROFILE = os.path.join("profiles", "r04_pmc_traffic_per_step.json")
-MFMA_PROFILE = os.path.join("profiles", "r04_pmc_mfma.json")
+TRAFFIC_PROFILE = os.path.join("profiles", "r05_pmc_traffic_per_step.json")
+MFMA_PROFILE = os.path.join("profiles", "r05_pmc_mfma.json")
 
 
 def kernel_source_hash():

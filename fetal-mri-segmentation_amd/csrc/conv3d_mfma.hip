@@ -397,12 +397,15 @@ k_conv_fwd_mfma(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__
         if (PL && (instr < 11 || instr >= 57)) return;
         if (instr >= H_INSTR) return;
         const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + hb * HALO_BYTES + instr * 1024);
-        if (tmask == 0) dma16_s(sb, hoff[ph], dst);
-        else {
+        // (round 5: through a buffer descriptor based at the box corner - a row outside the volume gets an out-of-range offset and lands as
+        // zeros; the round-4 form selected the zero page with a 64-bit pointer per lane)
+        unsigned off = hoff[ph];
+        if (tmask != 0) {
             const int pk = h_pack[ph];
             const bool bad = !((pk >> 15) & 1) || (((unsigned)pk >> 16) & tmask) != 0;
-            dma16(bad ? (const void*)zpage : (const void*)(sb + hoff[ph]), dst);
+            off = bad ? DMA_OOB : off;
         }
+        dma16_buf(dma_rsrc(sb), off, dst);
     };
 
     f32x16 acc[2][NT];
@@ -2993,8 +2996,8 @@ static int conv3d_fwd_mfma_launch(int mode, const void* src0, int C0, int up0, i
         fh_maxch = e ? atoi(e) : 1 << 20;
     }
     const int nchunk_fresh = mode == 2 ? C0 / 32 : (C0 + C1) / 32;
-    const bool fh_any = fwd_fast_halo() && !cube && C1 == 0 && !up0 && nchunk_fresh <= 2;
-    const bool fh = fwd_fast_halo() && !cube && C1 == 0 && !up0 && nchunk_fresh <= fh_maxch && !planar;       // (the warp-specialised kernel's form covers the 3-D launches)
+    const bool fh_any = fwd_fast_halo() && !cube && C1 == 0 && !up0 && nchunk_fresh <= fh_maxch;
+    const bool fh = fh_any && !planar;                 // (the warp-specialised kernel's form covers the 3-D launches)
     const bool s16 = fwd_mfma16() && !planar;
     {
         static int prio = -1;
