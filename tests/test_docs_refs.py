@@ -15,7 +15,7 @@ def test_cited_profile_files_exist():
             if "*" in name or not os.path.exists(os.path.join(ROOT, "profiles", name)):
                 missing.append((doc, name))
     text = open(os.path.join(ROOT, "profiles", "README.md")).read()
-    for name in set(re.findall(r"`(r0[34]_[A-Za-z0-9_.\-]+\.(?:jsonl|json|csv|log|txt|md))`", text)):
+    for name in set(re.findall(r"`(r0[345]_[A-Za-z0-9_.\-]+\.(?:jsonl|json|csv|log|txt|md))`", text)):
         if not os.path.exists(os.path.join(ROOT, "profiles", name)):
             missing.append(("profiles/README.md", name))
     assert not missing, missing
@@ -37,7 +37,7 @@ def test_quoted_profile_figures_are_the_generated_ones():
     import sys
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import summarize_profiles as SP
-    tag = "r04"
+    tag = "r05"
     fresh = SP.summary(tag)
     path = os.path.join(ROOT, "profiles", "%s_summary.md" % tag)
     assert os.path.exists(path), "run: python tools/summarize_profiles.py %s" % tag
