@@ -2589,19 +2589,11 @@ struct WkArgs {
 };
 
 // everything a wave does, instantiated per tap group so that the accumulators are one fixed register set for the kernel's lifetime
-// ROLE / NPW (round 5): 0 = every wave issues its share of the LDS-DMA and computes (rounds 2-4); with NPW > 0 producer waves behind the NW
-// MFMA waves of a workgroup, ROLE 1 = an MFMA wave (no DMA: the timing-only build without DMA ran 15 % faster,
-// profiles/r05_wgrad_ablation.log), ROLE 2 = a producer wave (all of the workgroup's DMA, dealt over the NPW producers).  Both roles
-// walk the same unit sequence and meet at the same barriers.
-template <int BLK, int G, bool S16 = false, int ROLE = 0, int NPW = 0>
+template <int BLK, int G, bool S16 = false>
 __device__ __forceinline__ void wk_run(const WkArgs& a, unsigned char* lds, int wv, int lane) {
     static_assert(!S16 || BLK == 32, "the 16x16x32 form is built for the 4-wave kernel");
     typedef WkCfg<BLK> K;
     constexpr int NTAP = G == 3 ? 6 : 7, NW = K::NW, NH = K::NH, ROWB = K::ROWB, RS = K::RS;
-    constexpr bool ISSUES = ROLE != 1, COMPUTES = ROLE != 2;
-    constexpr int NI = ROLE == 2 ? NPW : NW;                      // waves the DMA instructions are dealt over
-    constexpr int XPW_ = (K::X_INSTR + NI - 1) / NI, YPW_ = (K::Y_INSTR + NI - 1) / NI;
-    const int iw = ROLE == 2 ? wv - NW : wv;                      // this wave's index among them
     const SrcB& s = a.s;
     const int N = a.N, D = a.D, H = a.H, W = a.W, Cout = a.Cout;
     const int Cin = s.C0 + s.C1;
@@ -2652,15 +2644,14 @@ __device__ __forceinline__ void wk_run(const WkArgs& a, unsigned char* lds, int 
     // inside a plane and whether that halo row lies inside the volume (bit j of x_ok); per plane what is left is a scalar base, one 64-bit add
     // and a select per instruction.
     int cn = 0, ch0 = 0, cw0 = 0;
-    int x_off[XPW_], y_off[YPW_];
+    int x_off[K::XPW], y_off[K::YPW];
     unsigned x_ok = 0;
     auto col_setup = [&](int n, int h0, int w0) {
         cn = n; ch0 = h0; cw0 = w0;
-        if constexpr (!ISSUES) return;
         x_ok = 0;
 #pragma unroll
-        for (int k = 0; k < XPW_; ++k) {
-            const int id = iw + NI * k;
+        for (int k = 0; k < K::XPW; ++k) {
+            const int id = wv + NW * k;
             const int i = id * 64 + lane;
             const int row = i / RS, ps = i % RS;
             // 128-byte rows flip their 64-byte halves on row bit 1 (wg_slot_off); S16: 64-byte rows flip their 32-byte halves on row bit 2
@@ -2673,8 +2664,8 @@ __device__ __forceinline__ void wk_run(const WkArgs& a, unsigned char* lds, int 
             x_ok |= (ok ? 1u : 0u) << k;
         }
 #pragma unroll
-        for (int k = 0; k < YPW_; ++k) {
-            const int id = (NI - 1 - iw) + NI * k;            // dealt from the other end: the waves with one x instruction fewer go first
+        for (int k = 0; k < K::YPW; ++k) {
+            const int id = (NW - 1 - wv) + NW * k;            // dealt from the other end: the waves with one x instruction fewer go first
             const int i = id * 64 + lane;
             const int row = i / RS, ps = i % RS;
             const int ls = RS == 8 ? (ps ^ (((row >> 1) & 1) << 2)) : (S16 ? (ps ^ (((row >> 2) & 1) << 1)) : ps);
@@ -2683,7 +2674,6 @@ __device__ __forceinline__ void wk_run(const WkArgs& a, unsigned char* lds, int 
     };
     // plane `gd` (may lie outside the volume: zeros) of the cursor's column into x slot `slot`
     auto issue_x = [&](int gd, int slot) {
-        if constexpr (!ISSUES) return;
         const bool dok = (unsigned)gd < (unsigned)D;
         const int gdc = min(max(gd, 0), D - 1) >> shd;
         const bf16_t* const xbase = sp + ((int64_t)cn * sD + gdc) * sH * sW * sC + coff;
@@ -2691,19 +2681,18 @@ __device__ __forceinline__ void wk_run(const WkArgs& a, unsigned char* lds, int 
         // plane outside the volume in d a descriptor of zero records: no zero page, no 64-bit pointer select per lane)
         const i32x4 rs = dma_rsrc(xbase, dok ? (int)DMA_OOB : 0);
 #pragma unroll
-        for (int k = 0; k < XPW_; ++k) {
-            const int id = iw + NI * k;
+        for (int k = 0; k < K::XPW; ++k) {
+            const int id = wv + NW * k;
             if (id < K::X_INSTR)
                 dma16_buf(rs, ((x_ok >> k) & 1) ? (unsigned)x_off[k] : DMA_OOB,
                       __builtin_amdgcn_readfirstlane(lds0 + slot * K::XS_BYTES + id * 1024));
         }
     };
     auto issue_y = [&](int d, int ybuf) {
-        if constexpr (!ISSUES) return;
         const i32x4 yrs = dma_rsrc(a.dy + ((((int64_t)cn * D + d) * H + ch0) * W + cw0) * Cout + co0);
 #pragma unroll
-        for (int k = 0; k < YPW_; ++k) {
-            const int id = (NI - 1 - iw) + NI * k;
+        for (int k = 0; k < K::YPW; ++k) {
+            const int id = (NW - 1 - wv) + NW * k;
             if (id < K::Y_INSTR) dma16_buf(yrs, (unsigned)y_off[k], __builtin_amdgcn_readfirstlane(lds0 + K::NXS * K::XS_BYTES + ybuf * K::YS_BYTES + id * 1024));
         }
     };
@@ -2748,7 +2737,7 @@ __device__ __forceinline__ void wk_run(const WkArgs& a, unsigned char* lds, int 
 #endif
         for (; u < u_end; ++u) {
             PROF_T(w0);
-            if constexpr (ISSUES) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             PROF_T(w1);
             __builtin_amdgcn_s_barrier();                // this unit's planes have landed everywhere; the previous unit is fully read
             PROF_T(w2);
@@ -2765,14 +2754,12 @@ __device__ __forceinline__ void wk_run(const WkArgs& a, unsigned char* lds, int 
                 issue_y(d + 1, yb ^ 1);
             }
             PROF_T(w3);
-            if constexpr (COMPUTES) {
-                int xb[3] = {((xs + 2) & 3) * K::XS_BYTES, ((xs + 3) & 3) * K::XS_BYTES, xs * K::XS_BYTES};
+            int xb[3] = {((xs + 2) & 3) * K::XS_BYTES, ((xs + 3) & 3) * K::XS_BYTES, xs * K::XS_BYTES};
 #pragma unroll
-                for (int k = 0; k < 3; ++k) asm volatile("" : "+s"(xb[k]));       // slot bases stay scalar: base + lane offset is added per read
-                if constexpr (S16) wk_compute16<G>(lds, xb, K::NXS * K::XS_BYTES + yb * K::YS_BYTES, pre_x, pre_y, acc16, bsum, do_bias);
-                else wk_compute<BLK, G>(lds, xb, K::NXS * K::XS_BYTES + yb * K::YS_BYTES, pre_x, pre_y, acc, bsum, do_bias);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            }
+            for (int k = 0; k < 3; ++k) asm volatile("" : "+s"(xb[k]));       // slot bases stay scalar: base + lane offset is added per read
+            if constexpr (S16) wk_compute16<G>(lds, xb, K::NXS * K::XS_BYTES + yb * K::YS_BYTES, pre_x, pre_y, acc16, bsum, do_bias);
+            else wk_compute<BLK, G>(lds, xb, K::NXS * K::XS_BYTES + yb * K::YS_BYTES, pre_x, pre_y, acc, bsum, do_bias);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             PROF_T(w4);
 #ifdef FMRI_PROF
             wprof[0] += w1 - w0; wprof[1] += w2 - w1; wprof[2] += w3 - w2; wprof[3] += w4 - w3; wprof[6] += 1;
@@ -2796,7 +2783,6 @@ __device__ __forceinline__ void wk_run(const WkArgs& a, unsigned char* lds, int 
         if (lane == 0) for (int i = 0; i < 7; ++i) atomicAdd(&g_prof[i], wprof[i]);
 #endif
     }
-    if constexpr (!COMPUTES) return;
     // ---- flush: D rows = co, cols = ci; fp32 atomics, 128 contiguous bytes per half-wave (deterministic mode: fixed-point shadow)
     const FmriDetCfg dc = g_det_cfg;
     if constexpr (S16) {
@@ -2849,22 +2835,11 @@ __device__ __forceinline__ void wk_run(const WkArgs& a, unsigned char* lds, int 
     }
 }
 
-template <int BLK, bool S16 = false, int NPW = 0>
-__global__ void __launch_bounds__((WkCfg<BLK>::NW + NPW) * 64, BLK == 64 ? 1 : 2) k_conv_wgrad_kd(WkArgs a) {
+template <int BLK, bool S16 = false>
+__global__ void __launch_bounds__(WkCfg<BLK>::NW * 64, BLK == 64 ? 1 : 2) k_conv_wgrad_kd(WkArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[WkCfg<BLK>::LDS_BYTES];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if constexpr (NPW > 0) {
-        static_assert(BLK == 32 && !S16, "producer waves: the 4-wave 32x32x16 form");
-        if (wv >= WkCfg<BLK>::NW) { wk_run<BLK, 0, false, 2, NPW>(a, lds, wv, lane); return; }
-        switch (wv) {
-            case 0: wk_run<BLK, 0, false, 1, NPW>(a, lds, wv, lane); break;
-            case 1: wk_run<BLK, 1, false, 1, NPW>(a, lds, wv, lane); break;
-            case 2: wk_run<BLK, 2, false, 1, NPW>(a, lds, wv, lane); break;
-            default: wk_run<BLK, 3, false, 1, NPW>(a, lds, wv, lane); break;
-        }
-        return;
-    }
     switch (wv & 3) {                                     // tap group
         case 0: wk_run<BLK, 0, S16>(a, lds, wv, lane); break;
         case 1: wk_run<BLK, 1, S16>(a, lds, wv, lane); break;
@@ -3285,14 +3260,7 @@ int conv3d_wgrad_mfma_ld(const void* src0, int C0, int up0, int planar, const vo
             const char* e = getenv("FMRI_WGRAD_MFMA16");
             wg16 = e ? atoi(e) : 0;
         }
-        static int kd_npw = -1;              // FMRI_WGRAD_KD_PROD = 1 | 2: that many producer waves per workgroup issue all of its LDS-DMA
-        if (kd_npw < 0) {
-            const char* e = getenv("FMRI_WGRAD_KD_PROD");
-            kd_npw = e ? atoi(e) : 0;
-        }
         if (kd_blk == 64) k_conv_wgrad_kd<64><<<combos_kd * nsl, 512, 0, st>>>(wa);
-        else if (kd_npw == 2) k_conv_wgrad_kd<32, false, 2><<<combos_kd * nsl, 384, 0, st>>>(wa);
-        else if (kd_npw == 1) k_conv_wgrad_kd<32, false, 1><<<combos_kd * nsl, 320, 0, st>>>(wa);
         else if (wg16) k_conv_wgrad_kd<32, true><<<combos_kd * nsl, 256, 0, st>>>(wa);
         else k_conv_wgrad_kd<32><<<combos_kd * nsl, 256, 0, st>>>(wa);
         FMRI_LAUNCH_CHECK();
