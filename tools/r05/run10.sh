@@ -1,6 +1,6 @@
 #!/bin/bash
-# round 5: first profile collection on the committed kernels (7f68888) + the default bench line + every measured configuration
-bash tools/collect_profiles.sh r05 7f68888 > gpurun_out/collect_r05.log 2>&1
+# round 5: profile collection on the committed kernels (ab77eb4) + the default bench line + every measured configuration
+bash tools/collect_profiles.sh r05 ab77eb4 > gpurun_out/collect_r05.log 2>&1
 tail -5 gpurun_out/collect_r05.log
 python3 bench.py > gpurun_out/r05_bench_default.json 2> gpurun_out/r05_bench_default.err
 tail -c 1500 gpurun_out/r05_bench_default.json
