@@ -260,6 +260,331 @@ __global__ void k_coarse_dropout(T* __restrict__ x, int X, int Y, int C, int ld,
     }
 }
 
+
+// ---- the intensity chain with the random draws made IN the kernels (round 5).  The forms above take the draws from the
+// caller (tests feed the oracle's own); a training patch does not need that, and the round trip through torch's generator made a patch
+// ~35 launches: a fill, torch.poisson (121 us per 64x128x128 patch), torch.randn per noise kind, three launches per min / max.  Here:
+//   * Philox4x32-10 (Salmon, Moraes, Dror, Shaw: "Parallel random numbers: as easy as 1, 2, 3", SC'11), keyed by the sampler's seed; the
+//     counter is (element or cell index, call number, rejection round): the draws depend on neither the grid nor the launch order.
+//   * every kernel that rewrites the image also reduces the min / max of what it wrote and the LAST workgroup to finish (a ticket) decodes it
+//     into `stats` and re-arms the workspace - the next step of the chain finds its MinMaxScaler range without a pass of its own.
+// Workspace `ws` (int32 x FMRI_AUG_WS_INTS, zeroed ONCE by the caller; every kernel leaves it zeroed): [2] ticket of the min / max
+// reduction, [3] ticket of the level table, [32 + 32 s] ~key(min) and [33 + 32 s] key(max) of slot s < 16, [544 .. 1568) the 1,024 level
+// marks of the shot noise.
+constexpr int AUG_WS_SLOTS = 32, AUG_WS_PRESENT = 544;
+constexpr int AUG_BLOCKS = 256;       // one atomic pair + one ticket per workgroup: 768 device-scope atomics per launch
+constexpr int AUG_THREADS = 1024;     // ... so the parallelism of the kernels that draw comes from 16 waves per workgroup
+
+struct Philox {
+    unsigned k0, k1;
+    __device__ __forceinline__ uint4 operator()(unsigned c0, unsigned c1, unsigned c2, unsigned c3) const {
+        unsigned a = k0, b = k1;
+#pragma unroll
+        for (int r = 0; r < 10; ++r) {
+            const unsigned h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
+            const unsigned h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+            c0 = h1 ^ c1 ^ a;
+            c1 = l1;
+            c2 = h0 ^ c3 ^ b;
+            c3 = l0;
+            a += 0x9E3779B9u;
+            b += 0xBB67AE85u;
+        }
+        return make_uint4(c0, c1, c2, c3);
+    }
+};
+__device__ __forceinline__ float u01_open_low(unsigned r) { return (float)((r >> 8) + 1u) * (1.f / 16777216.f); }    // (0, 1]
+__device__ __forceinline__ float u01(unsigned r) { return (float)(r >> 8) * (1.f / 16777216.f); }                    // [0, 1)
+
+// workgroup reduction of (lo, hi) -> one atomic pair on one of 16 slot pairs (128 B apart: atomics on ONE address serialise in its L2
+// channel, ~12 ns each); the last workgroup (ticket) folds the slots into stats = {min, max} and leaves slots and ticket zeroed
+__device__ __forceinline__ void emit_minmax(float lo, float hi, int* __restrict__ ws, float* __restrict__ stats) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        lo = fminf(lo, __shfl_xor(lo, o));
+        hi = fmaxf(hi, __shfl_xor(hi, o));
+    }
+    __shared__ float slo[16], shi[16];
+    __shared__ int last;
+    unsigned* w = reinterpret_cast<unsigned*>(ws);
+    if ((threadIdx.x & 63) == 0) { slo[threadIdx.x >> 6] = lo; shi[threadIdx.x >> 6] = hi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < (int)(blockDim.x >> 6); ++i) {
+            lo = fminf(lo, slo[i]);
+            hi = fmaxf(hi, shi[i]);
+        }
+        unsigned* slot = w + AUG_WS_SLOTS + 32 * (blockIdx.x & 15);
+        if (lo <= hi) {
+            atomicMax(&slot[0], ~f2key(lo));
+            atomicMax(&slot[1], f2key(hi));
+        }
+        __threadfence();
+        last = atomicAdd(&w[2], 1u) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (last && threadIdx.x < 32) {
+        __threadfence();
+        unsigned v = atomicExch(&w[AUG_WS_SLOTS + 32 * (threadIdx.x >> 1) + (threadIdx.x & 1)], 0u);      // even lanes ~key(min), odd key(max)
+#pragma unroll
+        for (int o = 2; o < 32; o <<= 1) v = max(v, (unsigned)__shfl_xor((int)v, o));
+        if (threadIdx.x == 0) stats[0] = key2f(~v);
+        if (threadIdx.x == 1) stats[1] = key2f(v);
+        __threadfence();
+        if (threadIdx.x == 0) atomicExch(&w[2], 0u);
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(AUG_THREADS) k_minmax_ws(const T* __restrict__ x, int64_t n, int* __restrict__ ws, float* __restrict__ stats) {
+    constexpr int V = 16 / sizeof(T);
+    float lo = INFINITY, hi = -INFINITY;
+    const int64_t nv = ((reinterpret_cast<uintptr_t>(x) & 15) == 0) ? n / V : 0;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < nv; t += (int64_t)gridDim.x * blockDim.x) {
+        const uint4 q = reinterpret_cast<const uint4*>(x)[t];
+        const T* e = reinterpret_cast<const T*>(&q);
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            const float v = to_f<T>(e[i]);
+            lo = fminf(lo, v);
+            hi = fmaxf(hi, v);
+        }
+    }
+    for (int64_t t = nv * V + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
+        const float v = to_f<T>(x[t]);
+        lo = fminf(lo, v);
+        hi = fmaxf(hi, v);
+    }
+    emit_minmax(lo, hi, ws, stats);
+}
+
+// k_rescale that leaves the new range behind
+template <typename T>
+__global__ void __launch_bounds__(AUG_THREADS) k_rescale_ws(T* __restrict__ x, int64_t n, float* __restrict__ stats, int* __restrict__ ws, int contrast,
+                                                            float lo, float hi, float mult) {
+    const float omin = stats[0], omax = stats[1];
+    float mn = INFINITY, mx = -INFINITY;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
+        float v = to_f<T>(x[t]);
+        if (contrast) {
+            v = fminf(fmaxf(v, lo), hi);
+            if (lo != hi) v = (v - lo) / (hi - lo) * (omax - omin) + omin;
+            else v = fminf(fmaxf(v, omin), omax);
+        }
+        const T o = from_f<T>(v * mult);
+        x[t] = o;
+        const float w = to_f<T>(o);
+        mn = fminf(mn, w);
+        mx = fmaxf(mx, w);
+    }
+    __syncthreads();
+    emit_minmax(mn, mx, ws, stats);
+}
+
+// gaussian (kind 0) / speckle (kind 1) noise as k_noise, the N(0,1) draws by Box-Muller from one Philox block per four elements
+template <typename T>
+__global__ void __launch_bounds__(AUG_THREADS) k_noise_rng(T* __restrict__ x, int64_t n, float* __restrict__ stats, int* __restrict__ ws, int kind, float sigma,
+                                                   Philox rng, unsigned seq) {
+    const float dmin = stats[0], rng_ = stats[1] - stats[0];
+    const float scale = 1.f / (rng_ != 0.f ? rng_ : 1.f), mn = -dmin * scale;
+    float lo = INFINITY, hi = -INFINITY;
+    constexpr int64_t CH = 4 * AUG_THREADS;                    // a chunk = 4 x 1,024 elements: lane-contiguous accesses, 4 draws per thread
+    const int64_t chunks = (n + CH - 1) / CH;
+    for (int64_t c = blockIdx.x; c < chunks; c += gridDim.x) {
+        const uint64_t ctr = (uint64_t)c * AUG_THREADS + threadIdx.x;
+        const uint4 r = rng((unsigned)ctr, (unsigned)(ctr >> 32), seq, 0u);
+        float z[4];
+        {
+            const float m0 = sqrtf(-2.f * __logf(u01_open_low(r.x))), m1 = sqrtf(-2.f * __logf(u01_open_low(r.z)));
+            float s0, c0, s1, c1;
+            __sincosf(6.28318530717958647692f * u01(r.y), &s0, &c0);
+            __sincosf(6.28318530717958647692f * u01(r.w), &s1, &c1);
+            z[0] = m0 * c0; z[1] = m0 * s0; z[2] = m1 * c1; z[3] = m1 * s1;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int64_t t = c * CH + k * AUG_THREADS + threadIdx.x;
+            if (t < n) {
+                float s = fminf(fmaxf(to_f<T>(x[t]) * scale + mn, 0.f), 1.f);
+                const float e = z[k] * sigma;
+                s = kind == 0 ? s + e : s + s * e;
+                s = fminf(fmaxf(s, 0.f), 1.f);
+                const T o = from_f<T>((s - mn) / scale);
+                x[t] = o;
+                const float v = to_f<T>(o);
+                lo = fminf(lo, v);
+                hi = fmaxf(hi, v);
+            }
+        }
+    }
+    __syncthreads();                                           // every thread has read stats before the last workgroup rewrites it
+    emit_minmax(lo, hi, ws, stats);
+}
+
+// Poisson(lam) for 0 <= lam <= 1024.  lam < 10: Knuth's product of uniforms; else Hoermann's transformed rejection PTRS ("The transformed
+// rejection method for generating Poisson random variables", 1993) - the two branches of numpy's legacy random_poisson, i.e. of the
+// np.random.poisson behind skimage.util.random_noise(mode='poisson') that reference augment.py:87-94 calls.  Two uniforms per round.
+__device__ __forceinline__ float poisson_draw(float lam, const Philox& rng, unsigned c0, unsigned c1, unsigned seq) {
+    if (!(lam > 0.f)) return 0.f;
+    unsigned round = 0;
+    if (lam < 10.f) {
+        const float enlam = __expf(-lam);
+        float prod = 1.f;
+        int k = 0;
+        for (;;) {
+            const uint4 r = rng(c0, c1, seq, round++);
+            const unsigned u[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                prod *= u01_open_low(u[i]);
+                if (prod <= enlam) return (float)k;
+                ++k;
+            }
+        }
+    }
+    const float slam = sqrtf(lam), loglam = logf(lam);
+    const float b = 0.931f + 2.53f * slam, a = -0.059f + 0.02483f * b;
+    const float invalpha = 1.1239f + 1.1328f / (b - 3.4f), vr = 0.9277f - 3.6224f / (b - 2.f);
+    for (;;) {
+        const uint4 r = rng(c0, c1, seq, round++);
+        const unsigned u[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+        for (int i = 0; i < 4; i += 2) {
+            const float U = u01(u[i]) - 0.5f, V = u01_open_low(u[i + 1]);
+            const float us = 0.5f - fabsf(U);
+            const float kf = floorf((2.f * a / us + b) * U + lam + 0.43f);
+            if (us >= 0.07f && V <= vr) return kf;
+            if (kf < 0.f || (us < 0.013f && V > us)) continue;
+            // the squeeze failed (~15 % of the rounds): the exact test  log(V invalpha / (a / us^2 + b)) <= -lam + k log(lam) - log(k!).
+            // In fp32 the right side as written is a difference of ~7,000s; with k = lam + d and Stirling's series for log(k!) it is
+            // d - k log1p(d / lam) - log(2 pi k) / 2 - 1 / (12 k) + 1 / (360 k^3): every term is O(d), absolute error ~1e-5 (k < 10: the table)
+            const float lhs = __logf(V * invalpha / (a / (us * us) + b));
+            float rhs;
+            if (kf < 10.f) {
+                constexpr float LOGFACT[10] = {0.f, 0.f, 0.6931471806f, 1.7917594692f, 3.1780538303f, 4.7874917428f, 6.5792512120f, 8.5251613611f,
+                                               10.6046029027f, 12.8018274801f};
+                rhs = -lam + kf * loglam - LOGFACT[(int)kf];
+            } else {
+                const float d = kf - lam, ik = 1.f / kf;
+                rhs = d - kf * log1pf(d / lam) - 0.5f * __logf(6.28318530717958647692f * kf) - ik * (1.f / 12.f) + ik * ik * ik * (1.f / 360.f);
+            }
+            if (lhs <= rhs) return kf;
+        }
+    }
+}
+
+// shot noise, launch 1 of 2: mark the occupied quantisation levels (k_shot_noise phase 0 on the workspace's table)
+template <typename T>
+__global__ void __launch_bounds__(256) k_shot_levels(const T* __restrict__ x, int64_t n, const float* __restrict__ stats, int* __restrict__ ws) {
+    const float dmin = stats[0], rng_ = stats[1] - stats[0];
+    const float scale = 1.f / (rng_ != 0.f ? rng_ : 1.f), mn = -dmin * scale;
+    int* present = ws + AUG_WS_PRESENT;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
+        const float s = fminf(fmaxf(to_f<T>(x[t]) * scale + mn, 0.f), 1.f);
+        present[(int)floorf(s * 1023.f)] = 1;
+    }
+}
+// launch 2 of 2: phases 1 + 2 of k_shot_noise around an in-kernel Poisson draw; clears the level table behind the last reader
+template <typename T>
+__global__ void __launch_bounds__(AUG_THREADS) k_shot_draw(T* __restrict__ x, int64_t n, float* __restrict__ stats, int* __restrict__ ws, Philox rng, unsigned seq) {
+    const float dmin = stats[0], rng_ = stats[1] - stats[0];
+    const float scale = 1.f / (rng_ != 0.f ? rng_ : 1.f), mn = -dmin * scale;
+    int* present = ws + AUG_WS_PRESENT;
+    __shared__ int cnt_s;
+    __shared__ int last_s;
+    if (threadIdx.x == 0) cnt_s = 0;
+    __syncthreads();
+    {
+        int c = present[threadIdx.x] != 0;                     // AUG_THREADS = the 1,024 levels
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+        if ((threadIdx.x & 63) == 0) atomicAdd(&cnt_s, c);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {                                    // every workgroup has the count before the table may be cleared
+        __threadfence();
+        last_s = atomicAdd(reinterpret_cast<unsigned*>(&ws[3]), 1u) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (last_s) {
+        present[threadIdx.x] = 0;
+        if (threadIdx.x == 0) ws[3] = 0;
+    }
+    int v2 = 1;
+    while (v2 < cnt_s) v2 <<= 1;                               // skimage: vals = 2 ** ceil(log2(number of distinct values))
+    const float vals = (float)v2;
+    float lo = INFINITY, hi = -INFINITY;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
+        float s = fminf(fmaxf(to_f<T>(x[t]) * scale + mn, 0.f), 1.f);
+        const float lam = floorf(s * 1023.f) / 1023.f * vals;
+        const float k = poisson_draw(lam, rng, (unsigned)t, (unsigned)((uint64_t)t >> 32), seq);
+        s = fminf(fmaxf(k / vals, 0.f), 1.f);
+        const T o = from_f<T>((s - mn) / scale);
+        x[t] = o;
+        const float v = to_f<T>(o);
+        lo = fminf(lo, v);
+        hi = fmaxf(hi, v);
+    }
+    __syncthreads();
+    emit_minmax(lo, hi, ws, stats);
+}
+
+// The elastic transform's displacement fields (ops.elastic_fields: uniform(-1, 1) noise on the padded image, separable truncated Gaussian,
+// times alpha, padding cropped) in ONE launch: a workgroup makes one row segment of one field - it draws the k x (tw + k - 1) noise pixels under
+// it (pixel p of the padded (2, X + 2k, Y + 2k) grid = output (p & 3) of Philox block p >> 2: any workgroup that needs the pixel draws the same
+// value), blurs along the row, then down the k rows.  field 0 = d1 (imgaug's dx), field 1 = d0 (dy), as ops.elastic_fields.  k <= 31.
+constexpr int EF_KMAX = 31, EF_TW = 128;
+__global__ void __launch_bounds__(256) k_elastic_fields_rng(float* __restrict__ d0, float* __restrict__ d1, int X, int Y, int k,
+                                                            const double* __restrict__ w, float alpha, Philox rng, unsigned seq) {
+    __shared__ float nz[EF_KMAX][EF_TW + EF_KMAX - 1];
+    __shared__ float rb[EF_KMAX][EF_TW];
+    __shared__ float wf[EF_KMAX];
+    const int jt = blockIdx.x * EF_TW, i = blockIdx.y, f = blockIdx.z;
+    const int hp = X + 2 * k, wp = Y + 2 * k, r = k / 2;
+    const int tw = min(EF_TW, Y - jt), span = tw + k - 1;
+    if (threadIdx.x < k) wf[threadIdx.x] = (float)w[threadIdx.x];
+    const int row0 = i + k - r, col0 = jt + k - r;
+    for (int idx = threadIdx.x; idx < k * span; idx += blockDim.x) {
+        const int a = idx / span, b = idx - a * span;
+        const unsigned pix = (unsigned)((f * hp + row0 + a) * wp + col0 + b);
+        const uint4 q = rng(pix >> 2, 0u, seq, 1u);
+        const unsigned sel = pix & 3u;
+        const unsigned u = sel == 0 ? q.x : (sel == 1 ? q.y : (sel == 2 ? q.z : q.w));
+        nz[a][b] = u01(u) * 2.f - 1.f;
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < k * tw; idx += blockDim.x) {
+        const int a = idx / tw, j = idx - a * tw;
+        float acc = 0.f;
+        for (int b = 0; b < k; ++b) acc = fmaf(wf[b], nz[a][j + b], acc);
+        rb[a][j] = acc;
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < tw; j += blockDim.x) {
+        float acc = 0.f;
+        for (int a = 0; a < k; ++a) acc = fmaf(wf[a], rb[a][j], acc);
+        (f == 0 ? d1 : d0)[(int64_t)i * Y + jt + j] = acc * alpha;
+    }
+}
+
+// coarse dropout as k_coarse_dropout, the keep grid drawn in the kernel: cell (si, sj[, c]) is dropped when its uniform draw < rate
+// (imgaug CoarseDropout(p=rate): a Binomial(1 - rate) keep mask at the low resolution)
+template <typename T>
+__global__ void k_coarse_dropout_rng(T* __restrict__ x, int X, int Y, int C, int ld, int hs, int wsz, int kc, float rate, const float* __restrict__ stats,
+                                     Philox rng, unsigned seq) {
+    const int64_t total = (int64_t)X * Y * C;
+    const double fi = (double)hs / X, fj = (double)wsz / Y;
+    const float lo = stats[0];
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(t % C);
+        const int64_t ij = t / C;
+        const int j = (int)(ij % Y), i = (int)(ij / Y);
+        const int si = min((int)floor(i * fi), hs - 1), sj = min((int)floor(j * fj), wsz - 1);
+        const unsigned cell = (unsigned)((si * wsz + sj) * kc + (kc == 1 ? 0 : c));
+        if (u01(rng(cell, 0u, seq, 0u).x) < rate) st_any<T>(x, ij * ld + c, lo);
+    }
+}
+
 }  // namespace
 
 extern "C" int fmri_shot_noise_step(void* x, int64_t n, int dtype, const float* stats, int* present, float* rates, const float* draws, int phase,
@@ -366,6 +691,88 @@ extern "C" int fmri_noise_augment(void* x, int64_t n, int dtype, const float* st
     const int grid = grid_for(n);
     if (dtype == FMRI_F32) k_noise<float><<<grid, 256, 0, st>>>((float*)x, n, stats, noise, kind, sigma);
     else if (dtype == FMRI_BF16) k_noise<bf16_t><<<grid, 256, 0, st>>>((bf16_t*)x, n, stats, noise, kind, sigma);
+    else return FMRI_E_DTYPE;
+    FMRI_LAUNCH_CHECK();
+    return FMRI_OK;
+}
+
+// ---- the same intensity steps with in-kernel Philox draws and chained min / max (see the kernels' comment block above)
+static inline Philox philox_of(uint64_t seed) {
+    Philox p;
+    p.k0 = (unsigned)seed;
+    p.k1 = (unsigned)(seed >> 32);
+    return p;
+}
+
+extern "C" int fmri_minmax_ws(const void* x, int64_t n, int dtype, float* stats, int* ws, fmri_stream_t stream) {
+    if (n < 1 || !x || !stats || !ws) return FMRI_E_SHAPE;
+    hipStream_t st = as_stream(stream);
+    const int grid = grid_for((n + 3) / 4, AUG_THREADS, AUG_BLOCKS);
+    if (dtype == FMRI_F32) k_minmax_ws<float><<<grid, AUG_THREADS, 0, st>>>((const float*)x, n, ws, stats);
+    else if (dtype == FMRI_BF16) k_minmax_ws<bf16_t><<<grid, AUG_THREADS, 0, st>>>((const bf16_t*)x, n, ws, stats);
+    else return FMRI_E_DTYPE;
+    FMRI_LAUNCH_CHECK();
+    return FMRI_OK;
+}
+
+extern "C" int fmri_rescale_intensity_ws(void* x, int64_t n, int dtype, float* stats, int* ws, int contrast, float lo, float hi, float mult,
+                                         fmri_stream_t stream) {
+    if (n < 1 || !x || !stats || !ws) return FMRI_E_SHAPE;
+    hipStream_t st = as_stream(stream);
+    const int grid = grid_for(n, AUG_THREADS, AUG_BLOCKS);
+    if (dtype == FMRI_F32) k_rescale_ws<float><<<grid, AUG_THREADS, 0, st>>>((float*)x, n, stats, ws, contrast, lo, hi, mult);
+    else if (dtype == FMRI_BF16) k_rescale_ws<bf16_t><<<grid, AUG_THREADS, 0, st>>>((bf16_t*)x, n, stats, ws, contrast, lo, hi, mult);
+    else return FMRI_E_DTYPE;
+    FMRI_LAUNCH_CHECK();
+    return FMRI_OK;
+}
+
+extern "C" int fmri_noise_rng(void* x, int64_t n, int dtype, float* stats, int* ws, int kind, float sigma, uint64_t seed, uint32_t seq,
+                              fmri_stream_t stream) {
+    if (n < 1 || (kind != 0 && kind != 1) || !x || !stats || !ws) return FMRI_E_SHAPE;
+    hipStream_t st = as_stream(stream);
+    const int grid = grid_for((n + 3) / 4, AUG_THREADS, AUG_BLOCKS);
+    if (dtype == FMRI_F32) k_noise_rng<float><<<grid, AUG_THREADS, 0, st>>>((float*)x, n, stats, ws, kind, sigma, philox_of(seed), seq);
+    else if (dtype == FMRI_BF16) k_noise_rng<bf16_t><<<grid, AUG_THREADS, 0, st>>>((bf16_t*)x, n, stats, ws, kind, sigma, philox_of(seed), seq);
+    else return FMRI_E_DTYPE;
+    FMRI_LAUNCH_CHECK();
+    return FMRI_OK;
+}
+
+extern "C" int fmri_shot_noise_rng(void* x, int64_t n, int dtype, float* stats, int* ws, uint64_t seed, uint32_t seq, fmri_stream_t stream) {
+    if (n < 1 || !x || !stats || !ws) return FMRI_E_SHAPE;
+    hipStream_t st = as_stream(stream);
+    const int g0 = grid_for(n), g1 = grid_for(n, AUG_THREADS, AUG_BLOCKS);
+    if (dtype == FMRI_F32) {
+        k_shot_levels<float><<<g0, 256, 0, st>>>((const float*)x, n, stats, ws);
+        k_shot_draw<float><<<g1, AUG_THREADS, 0, st>>>((float*)x, n, stats, ws, philox_of(seed), seq);
+    } else if (dtype == FMRI_BF16) {
+        k_shot_levels<bf16_t><<<g0, 256, 0, st>>>((const bf16_t*)x, n, stats, ws);
+        k_shot_draw<bf16_t><<<g1, AUG_THREADS, 0, st>>>((bf16_t*)x, n, stats, ws, philox_of(seed), seq);
+    } else return FMRI_E_DTYPE;
+    FMRI_LAUNCH_CHECK();
+    return FMRI_OK;
+}
+
+extern "C" int fmri_elastic_fields_rng(float* d0, float* d1, int X, int Y, int k, const double* weights, float alpha, uint64_t seed, uint32_t seq,
+                                       fmri_stream_t stream) {
+    if (!d0 || !d1 || !weights || X < 1 || Y < 1 || k < 1 || k > EF_KMAX || (k & 1) == 0) return FMRI_E_SHAPE;
+    if ((int64_t)2 * (X + 2 * k) * (Y + 2 * k) > 0x7fffffff) return FMRI_E_SHAPE;
+    const dim3 grid((Y + EF_TW - 1) / EF_TW, X, 2);
+    k_elastic_fields_rng<<<grid, 256, 0, as_stream(stream)>>>(d0, d1, X, Y, k, weights, alpha, philox_of(seed), seq);
+    FMRI_LAUNCH_CHECK();
+    return FMRI_OK;
+}
+
+extern "C" int fmri_coarse_dropout_rng(void* x, int dtype, int X, int Y, int C, int ld, int hs, int ws_, int kc, float rate, const float* stats,
+                                       uint64_t seed, uint32_t seq, fmri_stream_t stream) {
+    if (X < 1 || Y < 1 || C < 1 || ld < C || hs < 1 || ws_ < 1 || (kc != 1 && kc != C) || !x || !stats || !(rate >= 0.f && rate <= 1.f))
+        return FMRI_E_SHAPE;
+    hipStream_t st = as_stream(stream);
+    const int grid = grid_for((int64_t)X * Y * C);
+    if (dtype == FMRI_F32) k_coarse_dropout_rng<float><<<grid, 256, 0, st>>>((float*)x, X, Y, C, ld, hs, ws_, kc, rate, stats, philox_of(seed), seq);
+    else if (dtype == FMRI_BF16)
+        k_coarse_dropout_rng<bf16_t><<<grid, 256, 0, st>>>((bf16_t*)x, X, Y, C, ld, hs, ws_, kc, rate, stats, philox_of(seed), seq);
     else return FMRI_E_DTYPE;
     FMRI_LAUNCH_CHECK();
     return FMRI_OK;

@@ -126,7 +126,8 @@ class _Sampler(object):
         self.truth_index, self.truth_size = truth_index, truth_size
         self.prev_truth_index, self.prev_truth_size = prev_truth_index, prev_truth_size
         self.n_chan = self.patch_shape[2] + (prev_truth_size if prev_truth_index is not None else 0)
-        self.stats = torch.empty(2, device=ddf.device, dtype=torch.float32)
+        self.stats, self.ws = ops.aug_workspace(ddf.device)
+        self.seed, self.seq = int(noise_seed), 0
         self.gen = torch.Generator(device=ddf.device)
         self.gen.manual_seed(noise_seed)
         # imgaug keeps its own random state (the reference's numpy / python streams are not advanced by its draws): the grid sizes of the coarse
@@ -139,6 +140,10 @@ class _Sampler(object):
                 if strict:
                     raise NotImplementedError(msg)
                 warnings.warn(msg)
+
+    def _next_seq(self):
+        self.seq += 1
+        return self.seq
 
     def sample_into(self, index, x_slot, y_slot, m_slot=None):
         """x_slot: float32 view (X, Y, n_chan) of the batch tensor; y_slot: uint8 view (X, Y, truth_size); m_slot: float32 view
@@ -172,7 +177,11 @@ class _Sampler(object):
             corners[:, 0] = np.clip(corners[:, 0], 0, h - 1)
             corners[:, 1] = np.clip(corners[:, 1], 0, w - 1)
         if p is not None and p["elastic_transform_scale"] > 0:
-            elastic = ops.elastic_fields((ps[0], ps[1]), p["elastic_transform_scale"], self.augment["elastic_transform"]["sigma"], generator=self.gen)
+            sigma = self.augment["elastic_transform"]["sigma"]
+            if ops.elastic_ksize(float(sigma)) <= ops.ELASTIC_RNG_KMAX:
+                elastic = ops.elastic_fields_rng((ps[0], ps[1]), p["elastic_transform_scale"], sigma, self.seed, self._next_seq(), device=ddf.device)
+            else:
+                elastic = ops.elastic_fields((ps[0], ps[1]), p["elastic_transform_scale"], sigma, generator=self.gen)
         warped = elastic is not None or corners is not None
 
         def target(slot, shape, dtype):
@@ -205,31 +214,30 @@ class _Sampler(object):
             if need_intensity:
                 if img is None:                            # image channels interleaved with the previous-slice truth: work on a copy
                     img = x_slot[..., :ps[2]].contiguous()
+                # Every step below wants the image's range (rescale_intensity's out_range, MinMaxScaler): taken ONCE, then each kernel that
+                # rewrites the image leaves the new range in `stats` for the next one; the noise draws are made in the kernels (Philox keyed by
+                # noise_seed, one counter value per call) - fmri_hip.h "in-kernel draws"
+                stats, ws = self.stats, self.ws
+                ops.minmax_ws(img, stats, ws)
                 if p["contrast"] is not None or p["intensity_multiplication"] != 1:
-                    ops.minmax(img, self.stats)
                     lo, hi = p["contrast"] if p["contrast"] is not None else (0.0, 0.0)
-                    ops.rescale_intensity(img, self.stats, p["contrast"] is not None, lo, hi, p["intensity_multiplication"])
+                    ops.rescale_intensity_ws(img, stats, ws, p["contrast"] is not None, lo, hi, p["intensity_multiplication"])
                 # order of reference augment.py:354-367: gaussian filter, shot (poisson) noise, speckle, gaussian noise
                 if p["apply_gaussian_filter"]:
                     smooth = ops.gaussian_filter_f32(img, p["gaussian_sigma"])
                     if smooth is not img:
                         img.copy_(smooth)
+                    ops.minmax_ws(img, stats, ws)
                 if p["apply_poisson_noise"]:
-                    ops.minmax(img, self.stats)
-                    ops.shot_noise(img, self.stats, generator=self.gen)
+                    ops.shot_noise_rng(img, stats, ws, self.seed, self._next_seq())
                 for flag, key, kind in (("apply_speckle_noise", "speckle_noise", 1), ("apply_gaussian_noise", "gaussian_noise", 0)):
                     if p[flag]:
-                        ops.minmax(img, self.stats)
-                        noise = self.torch.randn(img.numel(), device=img.device, dtype=self.torch.float32, generator=self.gen)
-                        ops.noise_augment(img, self.stats, noise, kind, self.augment[key]["sigma"])
+                        ops.noise_rng(img, stats, ws, kind, self.augment[key]["sigma"], self.seed, self._next_seq())
                 if p["coarse_dropout"]:
                     # reference augment.py:373-375 (last step): imgaug CoarseDropout(p=rate, size_percent, per_channel) in a [0, 255] scaling
                     cd = self.augment["coarse_dropout"]
-                    per_channel = bool(cd.get("per_channel", True))
-                    hs, ws = _coarse_grid((ps[0], ps[1]), cd["size_percent"], self.host_rng)
-                    keep = (self.torch.rand((hs, ws, ps[2] if per_channel else 1), device=img.device, generator=self.gen) >= float(cd["rate"]))
-                    ops.minmax(img, self.stats)
-                    ops.coarse_dropout(img, keep.to(self.torch.uint8).contiguous(), self.stats, per_channel)
+                    grid = _coarse_grid((ps[0], ps[1]), cd["size_percent"], self.host_rng)
+                    ops.coarse_dropout_rng(img, grid, cd["rate"], stats, bool(cd.get("per_channel", True)), self.seed, self._next_seq())
                 if img is not x_slot:
                     x_slot[..., :ps[2]] = img
         if self.prev_truth_index is not None:
@@ -246,11 +254,20 @@ class _Sampler(object):
 def device_data_generator(data_file, index_list, batch_size=1, n_labels=1, labels=None, augment=None, patch_shape=None,
                           shuffle_index_list=True, skip_blank=True, truth_index=-1, truth_size=1, truth_downsample=None, truth_crop=True,
                           categorical=True, prev_truth_index=None, prev_truth_size=None, drop_easy_patches=False, is3d=False,
-                          samples_pad=3, strict=False, noise_seed=0, device="cuda"):
+                          samples_pad=3, strict=False, noise_seed=0, device="cuda", prefetch=0):
     """Endless generator of (x, y) CUDA tensors.  `data_file`: a DeviceDataFile, or anything with .root.data / .root.truth
     (uploaded here).  3-D: x (N,1,X,Y,Z), y (N,1,X,Y,truth_size); 2-D: x (N,X,Y,C), y (N,X,Y,truth_size).  skip_blank and
     drop_easy_patches read one scalar back per patch (they decide on the host whether the patch is kept), everything else is
-    enqueue-only."""
+    enqueue-only.
+
+    prefetch (0 | n): n > 0 starts a producer thread with a HIP stream of its own that keeps up to n batches ready (the role of Keras'
+    GeneratorEnqueuer behind the reference's fit_generator, training.py:110-124).  A patch is 12-25 short gather / element-wise launches
+    - launch-latency bound, ~25 us of HBM time per batch - which then run BESIDE the consumer's training step; a consumer that reads a
+    scalar back every step (`train_on_batch`) leaves no other way to overlap them.  The consumer's current stream waits for the batch's
+    event before the yield; the tensors are registered with that stream (record_stream) so the allocator does not recycle them under a
+    step still in flight.  Draw order, and therefore every batch, is the same as with prefetch=0 (tests/test_gpu_augment.py); the draws
+    of batch k+1 ... k+n come from numpy's global state BEFORE batch k is handed out, so a caller that re-seeds between batches wants
+    prefetch=0 (the default).  `Model.fit_generator` has its own producer thread and copy stream: leave prefetch at 0 there."""
     import torch
     if truth_downsample is not None and truth_downsample > 1:
         raise NotImplementedError("truth_downsample is not part of the device generator")
@@ -261,7 +278,8 @@ def device_data_generator(data_file, index_list, batch_size=1, n_labels=1, label
     sampler = _Sampler(ddf, patch_shape, augment, truth_index, truth_size, prev_truth_index, prev_truth_size, strict, noise_seed)
     index_generator = random_list_generator(index_list) if shuffle_index_list else list_generator(index_list)
     ps = sampler.patch_shape
-    while True:
+
+    def produce():
         x = torch.empty((batch_size, ps[0], ps[1], sampler.n_chan), device=ddf.device, dtype=torch.float32)
         y = torch.empty((batch_size, ps[0], ps[1], truth_size), device=ddf.device, dtype=torch.uint8)
         m = torch.empty((batch_size, ps[0], ps[1], truth_size), device=ddf.device, dtype=torch.float32) if ddf.mask is not None else None
@@ -286,4 +304,55 @@ def device_data_generator(data_file, index_list, batch_size=1, n_labels=1, label
             xo, yo, mo = x.unsqueeze(1), yy.unsqueeze(1), (None if m is None else m.unsqueeze(1))
         else:
             xo, yo, mo = x, yy, m
-        yield (xo if mo is None else [xo, mo]), yo
+        return xo, yo, mo
+
+    if not prefetch:
+        while True:
+            xo, yo, mo = produce()
+            yield (xo if mo is None else [xo, mo]), yo
+
+    import queue
+    import threading
+    dev_index = torch.device(ddf.device).index if torch.device(ddf.device).index is not None else torch.cuda.current_device()
+    side = torch.cuda.Stream(device=dev_index)
+    side.wait_stream(torch.cuda.current_stream())      # the volumes were uploaded on the caller's stream: order the side stream behind it once
+    ready_q = queue.Queue(maxsize=int(prefetch))
+    stop = threading.Event()
+
+    def put(item):
+        while not stop.is_set():
+            try:
+                ready_q.put(item, timeout=0.05)
+                return
+            except queue.Full:
+                pass
+
+    def producer():
+        try:
+            torch.cuda.set_device(dev_index)
+            with torch.cuda.stream(side):
+                while not stop.is_set():
+                    batch = produce()
+                    ready = torch.cuda.Event()
+                    ready.record(side)
+                    put((batch, ready, None))
+        except BaseException as e:                     # handed to the consumer: a generator that dies silently would hang the training loop
+            put((None, None, e))
+
+    worker = threading.Thread(target=producer, name="device_data_generator", daemon=True)
+    worker.start()
+    try:
+        while True:
+            batch, ready, err = ready_q.get()
+            if err is not None:
+                raise err
+            xo, yo, mo = batch
+            consumer = torch.cuda.current_stream()
+            consumer.wait_event(ready)
+            for t in (xo, yo, mo):
+                if t is not None:
+                    t.record_stream(consumer)
+            yield (xo if mo is None else [xo, mo]), yo
+    finally:                                           # generator closed or collected: stop the producer, let it leave its put()
+        stop.set()
+        worker.join(timeout=10.0)

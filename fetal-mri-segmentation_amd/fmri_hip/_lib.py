@@ -19,6 +19,7 @@ class FmriError(RuntimeError):
 
 
 p, i32, i64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_float
+u64, u32 = C.c_uint64, C.c_uint32
 
 # name -> argtypes; must list exactly the functions declared in include/fmri_hip.h (tests/test_abi.py checks both ways)
 SIGNATURES = {
@@ -101,6 +102,12 @@ SIGNATURES = {
     "fmri_correlate1d_f32": [p, p, i32, i32, i32, i32, p, i32, i32, p],
     "fmri_elastic_warp": [p, i32, i32, i32, i32, i32, p, p, i32, p, i32, p],
     "fmri_coarse_dropout": [p, i32, i32, i32, i32, i32, p, i32, i32, i32, p, p],
+    "fmri_minmax_ws": [p, i64, i32, p, p, p],
+    "fmri_rescale_intensity_ws": [p, i64, i32, p, p, i32, f32, f32, f32, p],
+    "fmri_noise_rng": [p, i64, i32, p, p, i32, f32, u64, u32, p],
+    "fmri_shot_noise_rng": [p, i64, i32, p, p, u64, u32, p],
+    "fmri_elastic_fields_rng": [p, p, i32, i32, i32, p, f32, u64, u32, p],
+    "fmri_coarse_dropout_rng": [p, i32, i32, i32, i32, i32, i32, i32, i32, f32, p, u64, u32, p],
     "fmri_piecewise_affine2": [p, i32, i32, i32, i32, i32, p, i32, p, i32, p],
     "fmri_avgpool3d_2x_fwd": [p, p, i32, i32, i32, i32, i32, i32, i32, p],
     "fmri_avgpool3d_2x_bwd": [p, p, i32, i32, i32, i32, i32, i32, i32, p],

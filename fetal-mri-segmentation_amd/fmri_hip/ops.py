@@ -812,6 +812,39 @@ def elastic_ksize(sigma):
     return k + 1 if k % 2 == 0 else k
 
 
+_ELASTIC_KERNELS = {}
+ELASTIC_RNG_KMAX = 31
+
+
+def _elastic_kernel(k, sigma, device):
+    """the truncated, normalised Gaussian of cv2.GaussianBlur(ksize=k, sigma) as a device fp64 vector; one pageable upload (a host sync) per
+    (k, sigma, device), not per patch"""
+    import numpy as np
+    device = torch.device(device)
+    if device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    key = (k, float(sigma), device)
+    wd = _ELASTIC_KERNELS.get(key)
+    if wd is None:
+        xs = np.arange(k, dtype=np.float64) - (k - 1) / 2.0
+        w = np.exp(-(xs * xs) / (2.0 * float(sigma) ** 2))
+        wd = _ELASTIC_KERNELS[key] = torch.from_numpy(w / w.sum()).to(device)
+    return wd
+
+
+def elastic_fields_rng(shape2d, alpha, sigma, seed, seq, device="cuda"):
+    """elastic_fields with the noise drawn in the kernel (fmri_elastic_fields_rng: one launch); kernel widths above ELASTIC_RNG_KMAX (sigma >= 12)
+    are not covered - callers use elastic_fields there"""
+    X, Y = int(shape2d[0]), int(shape2d[1])
+    k = elastic_ksize(float(sigma))
+    assert k <= ELASTIC_RNG_KMAX
+    wd = _elastic_kernel(k, sigma, device)
+    d = torch.empty((2, X, Y), device=wd.device, dtype=torch.float32)
+    check(lib().fmri_elastic_fields_rng(_p(d[0]), _p(d[1]), X, Y, k, _p(wd), float(alpha), int(seed) & (2 ** 64 - 1), int(seq) & 0xffffffff, _s()),
+          "fmri_elastic_fields_rng")
+    return d[0], d[1]
+
+
 def elastic_fields(shape2d, alpha, sigma, generator=None, noise=None):
     """-> (d0, d1): the displacement along axis 0 (imgaug's dy) and axis 1 (dx) of an X x Y image, fp32 device tensors.
     imgaug 0.4.0 ElasticTransformation._generate_shift_maps: uniform(-1, 1) noise on the image padded by the kernel width on every side
@@ -827,9 +860,7 @@ def elastic_fields(shape2d, alpha, sigma, generator=None, noise=None):
         noise = torch.rand((2, hp, wp), device=dev, dtype=torch.float32, generator=generator) * 2 - 1
     _need_cuda(noise)
     assert tuple(noise.shape) == (2, hp, wp) and noise.dtype == torch.float32 and noise.is_contiguous()
-    xs = np.arange(k, dtype=np.float64) - (k - 1) / 2.0
-    w = np.exp(-(xs * xs) / (2.0 * float(sigma) ** 2))
-    wd = torch.from_numpy(w / w.sum()).to(noise.device)
+    wd = _elastic_kernel(k, sigma, noise.device)
     a = noise
     for axis in (1, 2):
         b = torch.empty_like(a)
@@ -893,6 +924,55 @@ def coarse_dropout(x, keep, stats, per_channel=True):
     assert keep.dtype == torch.uint8 and keep.is_contiguous() and kc == (C if per_channel else 1)
     assert x.stride(2) == 1 and x.stride(0) == Y * x.stride(1)
     check(lib().fmri_coarse_dropout(_p(x), dt(x), X, Y, C, int(x.stride(1)), _p(keep), hs, ws, kc, _p(stats), _s()), "fmri_coarse_dropout")
+    return x
+
+
+AUG_WS_INTS = 1568        # FMRI_AUG_WS_INTS
+
+
+def aug_workspace(device):
+    """(stats, ws) for the *_rng intensity steps: 2 floats and the zeroed int32 workspace they keep re-armed; one pair per stream of calls"""
+    return torch.zeros(2, device=device, dtype=torch.float32), torch.zeros(AUG_WS_INTS, device=device, dtype=torch.int32)
+
+
+def minmax_ws(x, stats, ws):
+    """stats = {min, max} of x in one launch (fmri_minmax_ws)"""
+    _need_cuda(x, stats, ws)
+    check(lib().fmri_minmax_ws(_p(x), x.numel(), dt(x), _p(stats), _p(ws), _s()), "fmri_minmax_ws")
+    return stats
+
+
+def rescale_intensity_ws(x, stats, ws, contrast, lo=0.0, hi=0.0, mult=1.0):
+    """rescale_intensity that leaves the new min / max in stats"""
+    _need_cuda(x, stats, ws)
+    check(lib().fmri_rescale_intensity_ws(_p(x), x.numel(), dt(x), _p(stats), _p(ws), 1 if contrast else 0, float(lo), float(hi), float(mult), _s()),
+          "fmri_rescale_intensity_ws")
+    return x
+
+
+def noise_rng(x, stats, ws, kind, sigma, seed, seq):
+    """gaussian (kind 0) / speckle (1) noise in place, the normal draws in the kernel; stats: in = min / max of x, out = of the new x"""
+    _need_cuda(x, stats, ws)
+    check(lib().fmri_noise_rng(_p(x), x.numel(), dt(x), _p(stats), _p(ws), int(kind), float(sigma), int(seed) & (2 ** 64 - 1), int(seq) & 0xffffffff,
+                               _s()), "fmri_noise_rng")
+    return x
+
+
+def shot_noise_rng(x, stats, ws, seed, seq):
+    """reference augment.py:87-94 in place, the Poisson draws in the kernel; stats: in = min / max of x, out = of the new x"""
+    _need_cuda(x, stats, ws)
+    check(lib().fmri_shot_noise_rng(_p(x), x.numel(), dt(x), _p(stats), _p(ws), int(seed) & (2 ** 64 - 1), int(seq) & 0xffffffff, _s()),
+          "fmri_shot_noise_rng")
+    return x
+
+
+def coarse_dropout_rng(x, grid, rate, stats, per_channel, seed, seq):
+    """coarse dropout in place on x (X, Y, C), the (hs, ws) keep grid (per slice when per_channel) drawn in the kernel"""
+    _need_cuda(stats)
+    X, Y, C = x.shape
+    assert x.is_cuda and x.stride(2) == 1 and x.stride(0) == Y * x.stride(1)
+    check(lib().fmri_coarse_dropout_rng(_p(x), dt(x), X, Y, C, int(x.stride(1)), int(grid[0]), int(grid[1]), C if per_channel else 1, float(rate),
+                                        _p(stats), int(seed) & (2 ** 64 - 1), int(seq) & 0xffffffff, _s()), "fmri_coarse_dropout_rng")
     return x
 
 

@@ -378,6 +378,36 @@ int fmri_piecewise_affine2(const void* src, int dtype, int X, int Y, int C, int 
  * stats = fmri_minmax of x before the call.  In place; dtype FMRI_F32 or FMRI_BF16. */
 int fmri_coarse_dropout(void* x, int dtype, int X, int Y, int C, int ld, const uint8_t* keep, int hs, int ws, int kc, const float* stats,
                         fmri_stream_t stream);
+/* ---- the same intensity steps with the random draws made IN the kernel (Philox4x32-10 keyed by `seed`, counter = (element or grid-cell index,
+ * `seq`, rejection round): the result depends on (seed, seq) only, not on the launch geometry) and the min / max chained: each call reads
+ * stats = {min, max} of x as it is, and - when it rewrites x - leaves the min / max of the NEW x there for the next step.  A training patch
+ * of the reference's default config (fetal/config_utils.py:81-123: shot noise, speckle / gaussian noise with probability 1/2 each, coarse
+ * dropout; reference fetal_net/augment.py:354-375) is then fmri_minmax_ws + 1 + 2 + 1 + 1 + 1 launches instead of ~35 with the draws taken from
+ * torch's generator (tools/r05/prof_generator.py).  The fed-draw forms above stay: the parity tests hand them the oracle's own draws.
+ * ws: device int32 [FMRI_AUG_WS_INTS], zeroed ONCE by the caller; every call leaves it zeroed.  One ws per stream of calls. */
+#define FMRI_AUG_WS_INTS 1568
+/* stats (2 floats, device) = {min, max} of x[0..n): fmri_minmax in ONE launch (the last workgroup to finish decodes and re-arms ws) */
+int fmri_minmax_ws(const void* x, int64_t n, int dtype, float* stats, int* ws, fmri_stream_t stream);
+/* fmri_rescale_intensity (reference augment.py:125-128, :351-352) that also leaves the min / max of the rescaled x in stats */
+int fmri_rescale_intensity_ws(void* x, int64_t n, int dtype, float* stats, int* ws, int contrast, float lo, float hi, float mult,
+                              fmri_stream_t stream);
+/* fmri_noise_augment with N(0,1) draws by Box-Muller; kind 0 gaussian, 1 speckle (reference augment.py:99-110). In place; updates stats. */
+int fmri_noise_rng(void* x, int64_t n, int dtype, float* stats, int* ws, int kind, float sigma, uint64_t seed, uint32_t seq,
+                   fmri_stream_t stream);
+/* fmri_shot_noise_step phases 0-2 (reference augment.py:87-94) in two launches, the Poisson draws as numpy's legacy sampler makes them
+ * (lam < 10: product of uniforms; else Hoermann's PTRS) - what np.random.poisson runs under skimage's random_noise. In place; updates stats. */
+int fmri_shot_noise_rng(void* x, int64_t n, int dtype, float* stats, int* ws, uint64_t seed, uint32_t seq, fmri_stream_t stream);
+/* imgaug ElasticTransformation's displacement fields (reference augment.py:149-170 -> imgaug 0.4.0 _generate_shift_maps) in one launch:
+ * uniform(-1, 1) noise on the image padded by k on every side, blurred with the k-tap kernel `weights` (device, fp64 [k], normalised; k odd,
+ * <= 31) along both axes, times alpha, padding cropped.  d0 (shift along axis 0, imgaug's dy), d1 (axis 1, dx): fp32 [X][Y] on the device.
+ * Noise pixel p of the padded (2, X + 2k, Y + 2k) grid (block 0 = dx) = 2 * u - 1 with u = (word (p & 3) of Philox(p >> 2, 0, seq, 1)) >> 8) / 2^24. */
+int fmri_elastic_fields_rng(float* d0, float* d1, int X, int Y, int k, const double* weights, float alpha, uint64_t seed, uint32_t seq,
+                            fmri_stream_t stream);
+/* fmri_coarse_dropout with the keep grid drawn in the kernel: cell (si, sj[, c]) of the hs x ws_ (x kc) grid is dropped when its uniform
+ * draw is < rate (imgaug CoarseDropout(p=rate); reference augment.py:116-120).  stats = min / max of x; not rewritten (the dropped
+ * voxels take the minimum). */
+int fmri_coarse_dropout_rng(void* x, int dtype, int X, int Y, int C, int ld, int hs, int ws_, int kc, float rate, const float* stats,
+                            uint64_t seed, uint32_t seq, fmri_stream_t stream);
 /* one axis of skimage.filters.gaussian on an fp32 patch [X][Y][Z] (reference augment.py:113-114): weights fp64 [2*radius+1] on the device,
  * sums in fp64 in scipy's order, result rounded to fp32; mode 0 = 'reflect', 1 = 'nearest' (skimage's default).  src != dst. */
 int fmri_correlate1d_f32(const float* src, float* dst, int X, int Y, int Z, int axis, const double* weights, int radius, int mode,

@@ -325,6 +325,42 @@ def test_coarse_dropout_vs_oracle(ops, per_channel):
     assert 0.05 < dropped.mean() < 0.45 and np.array_equal(got[~dropped], img[~dropped])       # kept voxels are untouched, bit for bit
 
 
+def test_device_generator_prefetch_on_its_own_stream_yields_the_same_batches():
+    """prefetch=2 (a producer thread with a stream of its own keeps two batches ready) against prefetch=0 (inline): same host and device
+    draws in the same order - every batch bit for bit, with the reference's default augmentation on, skip_blank's read-backs included,
+    and with a consumer that reads on a stream of its own.  (shuffle off: the shuffling index generator re-seeds numpy from the OS on
+    every pass, as the reference's does.)"""
+    import threading
+    import torch
+    from fetal_net.device_generator import device_data_generator
+    default = {"flip": [0.5, 0.5, 0.5], "permute": False, "translate": (15, 15, 7), "scale": (0.1, 0.1, 0), "rotate": (0, 0, 90), "poisson_noise": 1,
+               "gaussian_filter": {"prob": 0.0, "max_sigma": 1}, "contrast": {"prob": 0, "min_factor": 0.2, "max_factor": 0.1},
+               "elastic_transform": {"alpha": 5, "sigma": 10},
+               "coarse_dropout": {"rate": 0.2, "size_percent": [0.10, 0.30], "per_channel": True},
+               "gaussian_noise": {"prob": 0.5, "sigma": 0.05}, "speckle_noise": {"prob": 0.5, "sigma": 0.05}}
+    vols, truths = synth_volumes(3, [(72, 72, 40), (64, 80, 36)])
+    df = FakeDataFile(vols, truths)
+    runs = []
+    for prefetch in (0, 2):
+        np.random.seed(11)
+        random.seed(11)
+        gen = device_data_generator(df, [0, 1], batch_size=2, augment=default, patch_shape=(48, 48, 16), skip_blank=True, categorical=True, is3d=True,
+                                    truth_index=0, truth_size=16, noise_seed=3, prefetch=prefetch, shuffle_index_list=False)
+        got = []
+        reader = torch.cuda.Stream()
+        for k in range(4):
+            with torch.cuda.stream(reader if k % 2 else torch.cuda.current_stream()):
+                x, y = next(gen)
+                got.append((x.clone(), y.clone()))
+        torch.cuda.synchronize()
+        gen.close()                                                      # stops and joins the producer thread
+        assert not [t for t in threading.enumerate() if t.name == "device_data_generator"]
+        runs.append([(x.cpu().numpy(), y.cpu().numpy()) for x, y in got])
+    for (x0, y0), (x1, y1) in zip(*runs):
+        assert np.array_equal(x0, x1) and np.array_equal(y0, y1)
+    assert not np.array_equal(runs[0][0][0], runs[0][1][0])
+
+
 def test_device_generator_runs_the_reference_default_augmentation_without_warnings():
     """fetal/config_utils.py:81-123 verbatim: elastic transform and coarse dropout included - no 'not applied' warning; labels stay binary,
     the image stays inside the volume's range, about `rate` of the voxels sit at the patch minimum"""
@@ -452,3 +488,191 @@ def test_piecewise_affine_with_unmoved_corners_is_a_crop_of_the_identity(ops):
     # corners pulled to the image's own corner voxels (what the clip to [0, h-1] x [0, w-1] does to an unmoved grid): a slight zoom, nothing from outside
     out = ops.piecewise_affine(img, [[0, 0], [0, Y - 1], [X - 1, 0], [X - 1, Y - 1]], 1, torch.empty_like(img))
     assert float(out.min()) >= 1.0 - 1e-6
+
+
+# ---------------------------------------------------------------------------------------------- in-kernel draws + chained min / max (fmri_*_rng)
+def _ws_is_armed(ws):
+    return not bool(ws.any().item())
+
+
+@pytest.mark.parametrize("n,dtype,offset", [(1, torch.float32, 0), (1000003, torch.float32, 0), (4096, torch.bfloat16, 0), (12345, torch.bfloat16, 1),
+                                            (70001, torch.float32, 3)])
+def test_minmax_ws_one_launch_equals_torch_and_rearms_its_workspace(ops, n, dtype, offset):
+    stats, ws = ops.aug_workspace("cuda")
+    base = (torch.randn(n + offset, device="cuda") * 3 + 1).to(dtype)
+    x = base[offset:]                                               # offset > 0: a base address that is not 16-byte aligned
+    for _ in range(3):                                              # the same workspace, call after call
+        ops.minmax_ws(x, stats, ws)
+        assert stats.tolist() == [float(x.float().min()), float(x.float().max())]
+        assert _ws_is_armed(ws)
+        x = (x.float() * -0.5 + 2).to(dtype)
+
+
+def _moments(e):
+    e = e.astype(np.float64)
+    m, v = e.mean(), e.var()
+    return m, v, ((e - m) ** 3).mean() / v ** 1.5, ((e - m) ** 4).mean() / v ** 2
+
+
+@pytest.mark.parametrize("kind", [0, 1])
+def test_noise_rng_draws_are_standard_normal_and_the_range_is_chained(ops, kind):
+    """x' = clip(s + e) (gaussian) or clip(s + s e) (speckle) with e = sigma N(0,1), on an image scaled to [0, 1] by its own min / max (exactly 0
+    and 1 are in it): where nothing clips, (x' - x) / sigma [/ x] must be standard normal - moments, a chi-square over 40 bins, no correlation
+    between neighbours - the same for the same (seed, seq), different for another seq; `stats` afterwards = the new image's min / max"""
+    n, sigma = 1 << 20, 0.05
+    rs = np.random.RandomState(7)
+    x0 = (rs.rand(n) * 0.4 + 0.3).astype(np.float32)
+    x0[5], x0[77] = 0.0, 1.0
+    stats, ws = ops.aug_workspace("cuda")
+    outs = []
+    for seq in (1, 1, 2):
+        x = torch.from_numpy(x0).cuda()
+        ops.minmax_ws(x, stats, ws)
+        ops.noise_rng(x, stats, ws, kind, sigma, 1234, seq)
+        assert stats.tolist() == [float(x.min()), float(x.max())] and _ws_is_armed(ws)
+        outs.append(x.cpu().numpy())
+    assert np.array_equal(outs[0], outs[1]) and not np.array_equal(outs[0], outs[2])
+    keep = np.ones(n, bool)
+    keep[[5, 77]] = False
+    e = (outs[0] - x0)[keep].astype(np.float64) / sigma
+    if kind == 1:
+        e = e / x0[keep]
+    m, v, sk, ku = _moments(e)
+    assert abs(m) < 5e-3 and abs(v - 1) < 1e-2 and abs(sk) < 2e-2 and abs(ku - 3) < 5e-2, (m, v, sk, ku)
+    assert abs(np.corrcoef(e[:-1], e[1:])[0, 1]) < 5e-3 and abs(np.corrcoef(e[:-256], e[256:])[0, 1]) < 5e-3
+    import scipy.stats
+    edges = scipy.stats.norm.ppf(np.linspace(0, 1, 41)[1:-1])
+    counts = np.bincount(np.searchsorted(edges, e), minlength=40)
+    chi2 = ((counts - e.size / 40.0) ** 2 / (e.size / 40.0)).sum()
+    assert chi2 < scipy.stats.chi2.ppf(1 - 1e-6, 39), chi2          # fp32 rounding of x' - x is ~1e-6 / sigma of a bin edge: invisible at this n
+    # bf16 image: runs, stays in range, chained range is that of the stored (rounded) values
+    xb = torch.from_numpy(x0).cuda().to(torch.bfloat16)
+    ops.minmax_ws(xb, stats, ws)
+    ops.noise_rng(xb, stats, ws, kind, sigma, 1234, 3)
+    assert stats.tolist() == [float(xb.float().min()), float(xb.float().max())] and 0.0 <= stats[0].item() and stats[1].item() <= 1.0
+
+
+def test_shot_noise_rng_draws_are_poisson_on_both_branches_of_the_sampler(ops):
+    """reference augment.py:87-94 with the draw made in the kernel: the image is quantised to its 1,024 levels, vals = 2 ** ceil(log2(levels in use)),
+    x' = Poisson(level / 1023 * vals) / vals clipped to [0, 1].  Recover the integer draws and test them per rate against the Poisson law:
+    mean and variance for every rate, the full histogram (chi-square) for four rates either side of the sampler's switch at lam = 10."""
+    import scipy.stats
+    n = 1 << 21
+    rs = np.random.RandomState(3)
+    lev = rs.randint(0, 600, size=n)
+    lev[0], lev[1] = 0, 1023
+    x0 = ((lev + 0.5) / 1023.0).astype(np.float32)
+    x0[0], x0[1] = 0.0, 1.0
+    level = np.floor(np.clip(x0, 0, 1) * np.float32(1023.0)).astype(np.int64)
+    assert np.array_equal(level, lev)
+    vals = 1024                                                      # 601 levels in use
+    stats, ws = ops.aug_workspace("cuda")
+    outs = []
+    for seq in (9, 9, 10):
+        x = torch.from_numpy(x0).cuda()
+        ops.minmax_ws(x, stats, ws)
+        ops.shot_noise_rng(x, stats, ws, 99, seq)
+        assert stats.tolist() == [float(x.min()), float(x.max())] and _ws_is_armed(ws)
+        outs.append(x.cpu().numpy().astype(np.float64))
+    assert np.array_equal(outs[0], outs[1]) and not np.array_equal(outs[0], outs[2])
+    k = outs[0] * vals
+    assert np.abs(k - np.round(k)).max() < 1e-3
+    k = np.round(k).astype(np.int64)
+    lam = level / 1023.0 * vals
+    for L in range(0, 600, 7):
+        sel = k[level == L]
+        lm = L / 1023.0 * vals
+        se = np.sqrt(max(lm, 1e-9) / sel.size)
+        assert abs(sel.mean() - lm) < 5 * se + 1e-9, (L, sel.mean(), lm)
+        if L:
+            assert abs(sel.var() / lm - 1) < 6 * np.sqrt(2.0 / sel.size) + 6 / np.sqrt(lm * sel.size), (L, sel.var(), lm)
+    assert (k[level == 0] == 0).all()
+    for L in (3, 9, 10, 11, 40, 599):                               # lam = 3.0, 9.0 (products of uniforms), 10.01, 11.0, 40, 599.6 (PTRS)
+        sel = np.concatenate([k[level == L]] + [np.round(o * vals).astype(np.int64)[level == L] for o in outs[2:]])
+        lm = L / 1023.0 * vals
+        lo_, hi_ = int(scipy.stats.poisson.ppf(1e-3, lm)), int(scipy.stats.poisson.ppf(1 - 1e-3, lm))
+        edges = np.arange(lo_, hi_ + 1)
+        pm = scipy.stats.poisson.pmf(edges, lm)
+        pm = np.concatenate([[scipy.stats.poisson.cdf(lo_ - 1, lm)], pm, [scipy.stats.poisson.sf(hi_, lm)]])
+        cnt = np.bincount(np.clip(sel, lo_ - 1, hi_ + 1) - (lo_ - 1), minlength=pm.size)
+        ok = pm * sel.size > 5
+        chi2 = ((cnt[ok] - pm[ok] * sel.size) ** 2 / (pm[ok] * sel.size)).sum()
+        assert chi2 < scipy.stats.chi2.ppf(1 - 1e-5, ok.sum() - 1), (L, chi2, ok.sum())
+    # a second image through the SAME workspace with fewer levels in use: the level table was cleared behind the first
+    x = torch.from_numpy(((rs.randint(0, 5, size=4096) * 255.75) / 1023.0).astype(np.float32)).cuda()
+    ops.minmax_ws(x, stats, ws)
+    ops.shot_noise_rng(x, stats, ws, 99, 11)
+    kk = x.cpu().numpy().astype(np.float64) * 8                      # 5 levels -> vals = 8
+    assert np.abs(kk - np.round(kk)).max() < 1e-4 and _ws_is_armed(ws)
+
+
+@pytest.mark.parametrize("per_channel", [True, False])
+def test_coarse_dropout_rng_drops_whole_cells_at_the_given_rate(ops, per_channel):
+    X, Y, C, hs, wsz, rate = 64, 128, 128, 7, 13, 0.2
+    x0 = torch.randn(X, Y, C, device="cuda")
+    stats, ws = ops.aug_workspace("cuda")
+    ops.minmax_ws(x0, stats, ws)
+    x = ops.coarse_dropout_rng(x0.clone(), (hs, wsz), rate, stats, per_channel, 5, 1)
+    again = ops.coarse_dropout_rng(x0.clone(), (hs, wsz), rate, stats, per_channel, 5, 1)
+    other = ops.coarse_dropout_rng(x0.clone(), (hs, wsz), rate, stats, per_channel, 5, 2)
+    assert torch.equal(x, again) and not torch.equal(x, other)
+    got, src = x.cpu().numpy(), x0.cpu().numpy()
+    dropped = got != src
+    assert (got[dropped] == src.min()).all()
+    si = np.minimum(np.floor(np.arange(X) * (hs / X)).astype(int), hs - 1)
+    sj = np.minimum(np.floor(np.arange(Y) * (wsz / Y)).astype(int), wsz - 1)
+    cells = np.zeros((hs, wsz, C), bool)
+    seen = np.zeros((hs, wsz, C), bool)
+    for i in range(X):
+        for j in range(Y):
+            d = dropped[i, j] | (src[i, j] == src.min())
+            if seen[si[i], sj[j], 0]:
+                same = (cells[si[i], sj[j]] == dropped[i, j]) | (src[i, j] == src.min())
+                assert same.all()                                     # one decision per cell (and slice)
+            else:
+                cells[si[i], sj[j]] = dropped[i, j]
+                seen[si[i], sj[j]] = True
+            del d
+    if not per_channel:
+        assert (cells == cells[:, :, :1]).all()
+    nd = cells[:, :, 0].size if not per_channel else cells.size
+    frac = (cells[:, :, 0] if not per_channel else cells).mean()
+    assert abs(frac - rate) < 4 * np.sqrt(rate * (1 - rate) / nd) + 1e-9, frac
+
+
+def test_rescale_intensity_ws_equals_the_plain_pass_and_chains_the_range(ops):
+    x0 = torch.randn(70001, device="cuda") * 2 + 1
+    stats, ws = ops.aug_workspace("cuda")
+    for contrast, lo, hi, mult in ((True, -1.0, 2.5, 1.0), (False, 0.0, 0.0, 1.2), (True, 0.5, 0.5, 0.9)):
+        a, b = x0.clone(), x0.clone()
+        ops.minmax_ws(a, stats, ws)
+        before = stats.clone()
+        ops.rescale_intensity(a, before, contrast, lo, hi, mult)
+        ops.rescale_intensity_ws(b, stats, ws, contrast, lo, hi, mult)
+        assert torch.equal(a, b) and stats.tolist() == [float(b.min()), float(b.max())] and _ws_is_armed(ws)
+
+
+@pytest.mark.parametrize("X,Y,sigma,alpha", [(64, 128, 10.0, 5.0), (33, 150, 4.0, 40.0), (9, 7, 2.0, 1.5)])
+def test_elastic_fields_rng_equals_the_host_restatement_of_its_draws(ops, X, Y, sigma, alpha):
+    """the one-launch displacement fields against numpy: the SAME noise (Philox4x32-10 restated in tests/philox_ref.py, pinned to Random123's
+    known answers: pixel p of the padded (2, X + 2k, Y + 2k) grid = word p & 3 of block p >> 2), the same truncated Gaussian along both axes
+    in fp64, times alpha, cropped.  Also pins the kernels' Philox itself, which the noise kernels share."""
+    from philox_ref import philox4x32_10, u01
+    seed, seq = 0x1234567890abcdef, 77
+    k = ops.elastic_ksize(sigma)
+    hp, wp = X + 2 * k, Y + 2 * k
+    pix = np.arange(2 * hp * wp, dtype=np.uint64)
+    words = np.stack(philox4x32_10(pix >> np.uint64(2), 0, seq, 1, seed & 0xffffffff, seed >> 32), axis=-1)
+    noise = (u01(words[np.arange(pix.size), (pix & np.uint64(3)).astype(np.int64)]) * 2 - 1).reshape(2, hp, wp)
+    xs = np.arange(k, dtype=np.float64) - (k - 1) / 2.0
+    w = np.exp(-(xs * xs) / (2.0 * sigma ** 2))
+    w /= w.sum()
+    blur = scipy.ndimage.correlate1d(scipy.ndimage.correlate1d(noise, w, axis=1, mode="constant"), w, axis=2, mode="constant")
+    want = blur[:, k:k + X, k:k + Y] * alpha
+    d0, d1 = ops.elastic_fields_rng((X, Y), alpha, sigma, seed, seq)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(d1.cpu().numpy(), want[0], rtol=0, atol=3e-6 * alpha)
+    np.testing.assert_allclose(d0.cpu().numpy(), want[1], rtol=0, atol=3e-6 * alpha)
+    assert np.abs(want).max() > 0.02 * alpha
+    e0, _ = ops.elastic_fields_rng((X, Y), alpha, sigma, seed, seq + 1)
+    assert not torch.equal(e0, d0)

@@ -15,7 +15,7 @@ import torch
 
 
 def main():
-    from bench_sampler import AUG, Vols
+    from bench_sampler import FULL, Vols
     from fetal_net.device_generator import DeviceDataFile, device_data_generator
     from fetal_net.metrics import dice_coefficient_loss
     from fetal_net.model import unet_model_3d
@@ -31,11 +31,19 @@ def main():
             yield xb, yb
 
     ddf = DeviceDataFile(Vols(6, (96, 192, 192)), patch)
-    dev_gen = device_data_generator(ddf, list(range(6)), batch_size=B, patch_shape=patch, augment=AUG, truth_index=0, truth_size=patch[2], is3d=True,
+    dev_gen = device_data_generator(ddf, list(range(6)), batch_size=B, patch_shape=patch, augment=FULL, truth_index=0, truth_size=patch[2], is3d=True,
                                     categorical=False, skip_blank=False)
-    out = {}
+    xr, yr = next(device_data_generator(ddf, list(range(6)), batch_size=B, patch_shape=patch, augment=FULL, truth_index=0, truth_size=patch[2],
+                                        is3d=True, categorical=False, skip_blank=False))
+
+    def resident_gen():                                     # one device batch re-yielded: the rate the device generator is held against
+        while True:
+            yield xr, yr
+
+    out = {"augment": "reference default (fetal/config_utils.py:81-123)"}
     only = os.environ.get("FMRI_BENCH_FIT_ONLY", "")          # "host" | "device": one leg only (tools/trace_fit.sh)
-    for name, g in (("host_float64_generator", host_gen()), ("device_generator", dev_gen)):
+    for name, g in (("host_float64_generator", host_gen()), ("resident_device_batch", resident_gen()), ("device_generator", dev_gen),
+                    ("resident_device_batch_again", resident_gen())):
         if only and not name.startswith(only):
             continue
         model.fit_generator(g, steps_per_epoch=5, epochs=1, verbose=0)          # warm-up
@@ -44,6 +52,9 @@ def main():
         model.fit_generator(g, steps_per_epoch=steps, epochs=1, verbose=0)
         torch.cuda.synchronize()
         out[name + "_patches_per_s"] = steps * B / (time.time() - t0)
+    if "device_generator_patches_per_s" in out and "resident_device_batch_again_patches_per_s" in out:
+        res = 0.5 * (out["resident_device_batch_patches_per_s"] + out["resident_device_batch_again_patches_per_s"])
+        out["generator_vs_resident"] = out["device_generator_patches_per_s"] / res
     print(json.dumps(out))
 
 

@@ -18,6 +18,11 @@ sys.path.insert(0, os.path.join(ROOT, "fetal-mri-segmentation_amd"))
 AUG = {"flip": [0.5, 0.5, 0.5], "scale": (0.1, 0.1, 0), "rotate": (0, 0, 90), "translate": (15, 15, 7),
        "contrast": {"min_factor": 0.2, "max_factor": 0.1}, "gaussian_noise": {"prob": 0.5, "sigma": 0.05},
        "speckle_noise": {"prob": 0.5, "sigma": 0.05}}
+# the reference's default config, fetal/config_utils.py:81-123, every entry: shot noise always, the elastic warp and the coarse dropout too
+FULL = {"flip": [0.5, 0.5, 0.5], "permute": False, "translate": (15, 15, 7), "scale": (0.1, 0.1, 0), "rotate": (0, 0, 90), "poisson_noise": 1,
+        "gaussian_filter": {"prob": 0.0, "max_sigma": 1}, "contrast": {"prob": 0, "min_factor": 0.2, "max_factor": 0.1},
+        "elastic_transform": {"alpha": 5, "sigma": 10}, "coarse_dropout": {"rate": 0.2, "size_percent": [0.10, 0.30], "per_channel": True},
+        "gaussian_noise": {"prob": 0.5, "sigma": 0.05}, "speckle_noise": {"prob": 0.5, "sigma": 0.05}}
 
 
 class _Root:
@@ -41,7 +46,7 @@ class Vols:
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--batches", type=int, default=20)
+    ap.add_argument("--batches", type=int, default=60)
     ap.add_argument("--batch", type=int, default=4)
     a = ap.parse_args()
     import torch
@@ -52,7 +57,7 @@ def main():
     np.random.seed(0)
     random.seed(0)
     out = {"patch": list(patch), "batch": a.batch, "volumes_resident_MB": ddf.nbytes() / 1e6}
-    for name, aug in (("crop_only", None), ("affine_contrast_noise", AUG)):
+    for name, aug in (("crop_only", None), ("affine_contrast_noise", AUG), ("reference_default", FULL)):
         g = device_data_generator(ddf, list(range(6)), batch_size=a.batch, patch_shape=patch, augment=aug, truth_index=0, truth_size=patch[2],
                                   is3d=True, categorical=False, skip_blank=False)
         for _ in range(3):
@@ -70,25 +75,45 @@ def main():
     from fetal_net.metrics import dice_coefficient_loss
     from fetal_net.model import unet_model_3d
     model = unet_model_3d(input_shape=(1,) + patch, depth=4, n_base_filters=32, initial_learning_rate=1e-4, loss_function=dice_coefficient_loss)
-    g = device_data_generator(ddf, list(range(6)), batch_size=a.batch, patch_shape=patch, augment=AUG, truth_index=0, truth_size=patch[2],
-                              is3d=True, categorical=False, skip_blank=False)
-    x, y = next(g)
-    for _ in range(3):
+    def gen(aug, prefetch):
+        return device_data_generator(ddf, list(range(6)), batch_size=a.batch, patch_shape=patch, augment=aug, truth_index=0, truth_size=patch[2],
+                                     is3d=True, categorical=False, skip_blank=False, prefetch=prefetch)
+
+    x, y = next(gen(FULL, 0))
+    for _ in range(30):
         model.train_on_batch(x, y)
-    torch.cuda.synchronize()
-    t0 = time.time()
-    for _ in range(a.batches):
-        model.train_on_batch(x, y)
-    torch.cuda.synchronize()
-    fixed = time.time() - t0
-    t0 = time.time()
-    for _ in range(a.batches):
-        x, y = next(g)
-        model.train_on_batch(x, y)
-    torch.cuda.synchronize()
-    fed = time.time() - t0
-    out["train_patches_per_s_resident_batch"] = a.batches * a.batch / fixed
-    out["train_patches_per_s_device_generator"] = a.batches * a.batch / fed
+
+    def resident():
+        torch.cuda.synchronize()
+        t0 = time.time()
+        for _ in range(a.batches):
+            model.train_on_batch(x, y)
+        torch.cuda.synchronize()
+        return a.batches * a.batch / (time.time() - t0)
+
+    def fed(g):
+        for _ in range(3):
+            model.train_on_batch(*next(g))
+        torch.cuda.synchronize()
+        t0 = time.time()
+        for _ in range(a.batches):
+            xb, yb = next(g)
+            model.train_on_batch(xb, yb)
+        torch.cuda.synchronize()
+        return a.batches * a.batch / (time.time() - t0)
+
+    # a plain `next(g); train_on_batch` loop, inline and with the generator's own producer thread (prefetch=2); fit_generator's producer
+    # thread is tools/bench_fit.py.  Resident legs interleaved: the box warms
+    res = [resident()]
+    out["train_patches_per_s_device_generator_inline"] = fed(gen(FULL, 0))
+    res.append(resident())
+    out["train_patches_per_s_device_generator"] = fed(gen(FULL, 2))
+    res.append(resident())
+    out["train_patches_per_s_device_generator_partial_aug"] = fed(gen(AUG, 2))
+    res.append(resident())
+    out["train_patches_per_s_resident_batch"] = sum(res) / len(res)
+    out["resident_legs"] = res
+    out["generator_vs_resident"] = out["train_patches_per_s_device_generator"] / out["train_patches_per_s_resident_batch"]
     print(json.dumps(out))
 
 
