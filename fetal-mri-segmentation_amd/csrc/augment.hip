@@ -19,9 +19,21 @@ template <> __device__ __forceinline__ void st_any<uint8_t>(uint8_t* p, int64_t 
 
 // scipy.ndimage.map_coordinates(mode='constant'): a point outside [0, n-1] on any axis takes cval (no interpolation beyond the
 // edges); inside, order 0 picks floor(c + 0.5) and order 1 is trilinear on the enclosing cell.
+constexpr int AFF_MAXB = 16;
+struct AffineB {                        // per patch of a launch: the volume, its extent, the patch corner, the outside value, the affine
+    const void* vol[AFF_MAXB];
+    int X[AFF_MAXB], Y[AFF_MAXB], Z[AFF_MAXB], x0[AFF_MAXB], y0[AFF_MAXB], z0[AFF_MAXB];
+    float cval[AFF_MAXB];
+    Affine34 A[AFF_MAXB];
+};
 template <typename TI, typename TO>
-__global__ void k_affine_sample(const TI* __restrict__ vol, int X, int Y, int Z, Affine34 A, int x0, int y0, int z0, int nx, int ny, int nz,
-                                int order, float cval, TO* __restrict__ out, int ld) {
+__global__ void k_affine_sample(AffineB P, int nx, int ny, int nz, int order, TO* __restrict__ out, int ld, int64_t out_stride) {
+    const int pb = blockIdx.y;
+    const TI* __restrict__ vol = static_cast<const TI*>(P.vol[pb]);
+    const int X = P.X[pb], Y = P.Y[pb], Z = P.Z[pb], x0 = P.x0[pb], y0 = P.y0[pb], z0 = P.z0[pb];
+    const float cval = P.cval[pb];
+    const Affine34& A = P.A[pb];
+    out += pb * out_stride;
     const int64_t total = (int64_t)nx * ny * nz;
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
         const int k = (int)(t % nz);
@@ -187,7 +199,11 @@ __global__ void k_shot_noise(T* __restrict__ x, int64_t n, const float* __restri
 // of coordinate.  Parity unpinned either way (oracle/augment_oracle.py).
 template <typename T>
 __global__ void k_elastic_warp(const T* __restrict__ src, int X, int Y, int C, int src_ld, const float* __restrict__ d0, const float* __restrict__ d1,
-                               int order, T* __restrict__ dst, int dst_ld) {
+                               int order, T* __restrict__ dst, int dst_ld, int64_t src_stride, int64_t dst_stride, int64_t d_stride) {
+    src += blockIdx.y * src_stride;                             // blockIdx.y = patch of the batch
+    dst += blockIdx.y * dst_stride;
+    d0 += blockIdx.y * d_stride;
+    d1 += blockIdx.y * d_stride;
     const int64_t total = (int64_t)X * Y * C;
     for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
         const int c = (int)(t % C);
@@ -274,6 +290,14 @@ __global__ void k_coarse_dropout(T* __restrict__ x, int X, int Y, int C, int ld,
 constexpr int AUG_WS_SLOTS = 32, AUG_WS_PRESENT = 544;
 constexpr int AUG_BLOCKS = 256;       // one atomic pair + one ticket per workgroup: 768 device-scope atomics per launch
 constexpr int AUG_THREADS = 1024;     // ... so the parallelism of the kernels that draw comes from 16 waves per workgroup
+// One launch covers the patches of a batch (blockIdx.y = patch; patch b's image at x + b * stride, its range at stats + 2 b, its workspace
+// at ws + b * AUG_WS_INTS): a 64x128x128 patch is a 5 us kernel of which 4 us are launch ramp, and the step's persistent workgroups leave
+// a generator kernel nowhere to hide - what a batch costs the training step is the NUMBER of its launches.  Per-patch parameters by value.
+constexpr int AUG_MAXB = 16, AUG_WS_INTS = 1568;
+struct SeqB { unsigned v[AUG_MAXB]; };                       // the call number of the patch's draws; 0 = the patch skips this step
+struct RescaleB { int mode[AUG_MAXB]; float lo[AUG_MAXB], hi[AUG_MAXB], mult[AUG_MAXB]; };      // mode 0 skip, 1 multiply, 2 contrast + multiply
+struct GridB { int hs[AUG_MAXB], ws[AUG_MAXB]; };
+struct AlphaB { float v[AUG_MAXB]; };
 
 struct Philox {
     unsigned k0, k1;
@@ -336,7 +360,11 @@ __device__ __forceinline__ void emit_minmax(float lo, float hi, int* __restrict_
 }
 
 template <typename T>
-__global__ void __launch_bounds__(AUG_THREADS) k_minmax_ws(const T* __restrict__ x, int64_t n, int* __restrict__ ws, float* __restrict__ stats) {
+__global__ void __launch_bounds__(AUG_THREADS) k_minmax_ws(const T* __restrict__ x, int64_t n, int64_t stride, int* __restrict__ ws,
+                                                           float* __restrict__ stats) {
+    x += blockIdx.y * stride;
+    ws += blockIdx.y * AUG_WS_INTS;
+    stats += blockIdx.y * 2;
     constexpr int V = 16 / sizeof(T);
     float lo = INFINITY, hi = -INFINITY;
     const int64_t nv = ((reinterpret_cast<uintptr_t>(x) & 15) == 0) ? n / V : 0;
@@ -360,22 +388,40 @@ __global__ void __launch_bounds__(AUG_THREADS) k_minmax_ws(const T* __restrict__
 
 // k_rescale that leaves the new range behind
 template <typename T>
-__global__ void __launch_bounds__(AUG_THREADS) k_rescale_ws(T* __restrict__ x, int64_t n, float* __restrict__ stats, int* __restrict__ ws, int contrast,
-                                                            float lo, float hi, float mult) {
+__global__ void __launch_bounds__(AUG_THREADS) k_rescale_ws(T* __restrict__ x, int64_t n, int64_t stride, float* __restrict__ stats,
+                                                            int* __restrict__ ws, RescaleB P) {
+    const int b = blockIdx.y;
+    if (P.mode[b] == 0) return;
+    x += b * stride;
+    ws += b * AUG_WS_INTS;
+    stats += b * 2;
+    const int contrast = P.mode[b] == 2;
+    const float lo = P.lo[b], hi = P.hi[b], mult = P.mult[b];
     const float omin = stats[0], omax = stats[1];
     float mn = INFINITY, mx = -INFINITY;
-    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
-        float v = to_f<T>(x[t]);
-        if (contrast) {
-            v = fminf(fmaxf(v, lo), hi);
-            if (lo != hi) v = (v - lo) / (hi - lo) * (omax - omin) + omin;
-            else v = fminf(fmaxf(v, omin), omax);
+    constexpr int64_t CH = 4 * AUG_THREADS;                    // four loads in flight per thread (a grid-stride loop has one)
+    for (int64_t c = blockIdx.x; c * CH < n; c += gridDim.x) {
+        float v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int64_t t = c * CH + k * AUG_THREADS + threadIdx.x;
+            v[k] = t < n ? to_f<T>(x[t]) : 0.f;
         }
-        const T o = from_f<T>(v * mult);
-        x[t] = o;
-        const float w = to_f<T>(o);
-        mn = fminf(mn, w);
-        mx = fmaxf(mx, w);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int64_t t = c * CH + k * AUG_THREADS + threadIdx.x;
+            if (t >= n) continue;
+            if (contrast) {
+                v[k] = fminf(fmaxf(v[k], lo), hi);
+                if (lo != hi) v[k] = (v[k] - lo) / (hi - lo) * (omax - omin) + omin;
+                else v[k] = fminf(fmaxf(v[k], omin), omax);
+            }
+            const T o = from_f<T>(v[k] * mult);
+            x[t] = o;
+            const float w = to_f<T>(o);
+            mn = fminf(mn, w);
+            mx = fmaxf(mx, w);
+        }
     }
     __syncthreads();
     emit_minmax(mn, mx, ws, stats);
@@ -383,8 +429,13 @@ __global__ void __launch_bounds__(AUG_THREADS) k_rescale_ws(T* __restrict__ x, i
 
 // gaussian (kind 0) / speckle (kind 1) noise as k_noise, the N(0,1) draws by Box-Muller from one Philox block per four elements
 template <typename T>
-__global__ void __launch_bounds__(AUG_THREADS) k_noise_rng(T* __restrict__ x, int64_t n, float* __restrict__ stats, int* __restrict__ ws, int kind, float sigma,
-                                                   Philox rng, unsigned seq) {
+__global__ void __launch_bounds__(AUG_THREADS) k_noise_rng(T* __restrict__ x, int64_t n, int64_t stride, float* __restrict__ stats,
+                                                           int* __restrict__ ws, int kind, float sigma, Philox rng, SeqB S) {
+    const unsigned seq = S.v[blockIdx.y];
+    if (seq == 0) return;
+    x += blockIdx.y * stride;
+    ws += blockIdx.y * AUG_WS_INTS;
+    stats += blockIdx.y * 2;
     const float dmin = stats[0], rng_ = stats[1] - stats[0];
     const float scale = 1.f / (rng_ != 0.f ? rng_ : 1.f), mn = -dmin * scale;
     float lo = INFINITY, hi = -INFINITY;
@@ -424,11 +475,28 @@ __global__ void __launch_bounds__(AUG_THREADS) k_noise_rng(T* __restrict__ x, in
 // Poisson(lam) for 0 <= lam <= 1024.  lam < 10: Knuth's product of uniforms; else Hoermann's transformed rejection PTRS ("The transformed
 // rejection method for generating Poisson random variables", 1993) - the two branches of numpy's legacy random_poisson, i.e. of the
 // np.random.poisson behind skimage.util.random_noise(mode='poisson') that reference augment.py:87-94 calls.  Two uniforms per round.
-__device__ __forceinline__ float poisson_draw(float lam, const Philox& rng, unsigned c0, unsigned c1, unsigned seq) {
+struct PoissonLevel { float lam, c, b, a, invalpha, vr; };    // c = exp(-lam) for lam < 10, else log(lam)
+__device__ __forceinline__ PoissonLevel poisson_level(float lam) {
+    PoissonLevel L;
+    L.lam = lam;
+    if (lam < 10.f) {
+        L.c = __expf(-lam);
+        L.b = L.a = L.invalpha = L.vr = 0.f;
+    } else {
+        L.c = logf(lam);
+        L.b = 0.931f + 2.53f * sqrtf(lam);
+        L.a = -0.059f + 0.02483f * L.b;
+        L.invalpha = 1.1239f + 1.1328f / (L.b - 3.4f);
+        L.vr = 0.9277f - 3.6224f / (L.b - 2.f);
+    }
+    return L;
+}
+__device__ __forceinline__ float poisson_draw(const PoissonLevel L, const Philox& rng, unsigned c0, unsigned c1, unsigned seq) {
+    const float lam = L.lam;
     if (!(lam > 0.f)) return 0.f;
     unsigned round = 0;
     if (lam < 10.f) {
-        const float enlam = __expf(-lam);
+        const float enlam = L.c;
         float prod = 1.f;
         int k = 0;
         for (;;) {
@@ -442,9 +510,7 @@ __device__ __forceinline__ float poisson_draw(float lam, const Philox& rng, unsi
             }
         }
     }
-    const float slam = sqrtf(lam), loglam = logf(lam);
-    const float b = 0.931f + 2.53f * slam, a = -0.059f + 0.02483f * b;
-    const float invalpha = 1.1239f + 1.1328f / (b - 3.4f), vr = 0.9277f - 3.6224f / (b - 2.f);
+    const float loglam = L.c, b = L.b, a = L.a, invalpha = L.invalpha, vr = L.vr;
     for (;;) {
         const uint4 r = rng(c0, c1, seq, round++);
         const unsigned u[4] = {r.x, r.y, r.z, r.w};
@@ -475,7 +541,12 @@ __device__ __forceinline__ float poisson_draw(float lam, const Philox& rng, unsi
 
 // shot noise, launch 1 of 2: mark the occupied quantisation levels (k_shot_noise phase 0 on the workspace's table)
 template <typename T>
-__global__ void __launch_bounds__(256) k_shot_levels(const T* __restrict__ x, int64_t n, const float* __restrict__ stats, int* __restrict__ ws) {
+__global__ void __launch_bounds__(256) k_shot_levels(const T* __restrict__ x, int64_t n, int64_t stride, const float* __restrict__ stats,
+                                                     int* __restrict__ ws, SeqB S) {
+    if (S.v[blockIdx.y] == 0) return;
+    x += blockIdx.y * stride;
+    ws += blockIdx.y * AUG_WS_INTS;
+    stats += blockIdx.y * 2;
     const float dmin = stats[0], rng_ = stats[1] - stats[0];
     const float scale = 1.f / (rng_ != 0.f ? rng_ : 1.f), mn = -dmin * scale;
     int* present = ws + AUG_WS_PRESENT;
@@ -486,7 +557,13 @@ __global__ void __launch_bounds__(256) k_shot_levels(const T* __restrict__ x, in
 }
 // launch 2 of 2: phases 1 + 2 of k_shot_noise around an in-kernel Poisson draw; clears the level table behind the last reader
 template <typename T>
-__global__ void __launch_bounds__(AUG_THREADS) k_shot_draw(T* __restrict__ x, int64_t n, float* __restrict__ stats, int* __restrict__ ws, Philox rng, unsigned seq) {
+__global__ void __launch_bounds__(AUG_THREADS) k_shot_draw(T* __restrict__ x, int64_t n, int64_t stride, float* __restrict__ stats,
+                                                           int* __restrict__ ws, Philox rng, SeqB S) {
+    const unsigned seq = S.v[blockIdx.y];
+    if (seq == 0) return;
+    x += blockIdx.y * stride;
+    ws += blockIdx.y * AUG_WS_INTS;
+    stats += blockIdx.y * 2;
     const float dmin = stats[0], rng_ = stats[1] - stats[0];
     const float scale = 1.f / (rng_ != 0.f ? rng_ : 1.f), mn = -dmin * scale;
     int* present = ws + AUG_WS_PRESENT;
@@ -513,11 +590,13 @@ __global__ void __launch_bounds__(AUG_THREADS) k_shot_draw(T* __restrict__ x, in
     int v2 = 1;
     while (v2 < cnt_s) v2 <<= 1;                               // skimage: vals = 2 ** ceil(log2(number of distinct values))
     const float vals = (float)v2;
+    __shared__ PoissonLevel levels[AUG_THREADS];               // the sampler's constants of each of the 1,024 rates: one sqrt / log per LEVEL, not per voxel
+    levels[threadIdx.x] = poisson_level((float)threadIdx.x / 1023.f * vals);
+    __syncthreads();
     float lo = INFINITY, hi = -INFINITY;
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
         float s = fminf(fmaxf(to_f<T>(x[t]) * scale + mn, 0.f), 1.f);
-        const float lam = floorf(s * 1023.f) / 1023.f * vals;
-        const float k = poisson_draw(lam, rng, (unsigned)t, (unsigned)((uint64_t)t >> 32), seq);
+        const float k = poisson_draw(levels[(int)floorf(s * 1023.f)], rng, (unsigned)t, (unsigned)((uint64_t)t >> 32), seq);
         s = fminf(fmaxf(k / vals, 0.f), 1.f);
         const T o = from_f<T>((s - mn) / scale);
         x[t] = o;
@@ -534,23 +613,38 @@ __global__ void __launch_bounds__(AUG_THREADS) k_shot_draw(T* __restrict__ x, in
 // it (pixel p of the padded (2, X + 2k, Y + 2k) grid = output (p & 3) of Philox block p >> 2: any workgroup that needs the pixel draws the same
 // value), blurs along the row, then down the k rows.  field 0 = d1 (imgaug's dx), field 1 = d0 (dy), as ops.elastic_fields.  k <= 31.
 constexpr int EF_KMAX = 31, EF_TW = 128;
-__global__ void __launch_bounds__(256) k_elastic_fields_rng(float* __restrict__ d0, float* __restrict__ d1, int X, int Y, int k,
-                                                            const double* __restrict__ w, float alpha, Philox rng, unsigned seq) {
+__global__ void __launch_bounds__(256) k_elastic_fields_rng(float* __restrict__ d, int X, int Y, int k, const double* __restrict__ w, AlphaB A,
+                                                            Philox rng, SeqB S) {
+    const int pb = blockIdx.z >> 1;                             // d: [B][2][X][Y], d[b][0] = d0, d[b][1] = d1
+    float* __restrict__ d0 = d + (int64_t)pb * 2 * X * Y;
+    float* __restrict__ d1 = d0 + (int64_t)X * Y;
+    const unsigned seq = S.v[pb];
+    const float alpha = A.v[pb];
+    if (seq == 0) {                                             // no elastic transform for this patch: a zero field (the warp is the identity)
+        const int jt0 = blockIdx.x * EF_TW;
+        for (int j = threadIdx.x; j < min(EF_TW, Y - jt0); j += blockDim.x) ((blockIdx.z & 1) == 0 ? d1 : d0)[(int64_t)blockIdx.y * Y + jt0 + j] = 0.f;
+        return;
+    }
     __shared__ float nz[EF_KMAX][EF_TW + EF_KMAX - 1];
     __shared__ float rb[EF_KMAX][EF_TW];
     __shared__ float wf[EF_KMAX];
-    const int jt = blockIdx.x * EF_TW, i = blockIdx.y, f = blockIdx.z;
+    const int jt = blockIdx.x * EF_TW, i = blockIdx.y, f = blockIdx.z & 1;
     const int hp = X + 2 * k, wp = Y + 2 * k, r = k / 2;
     const int tw = min(EF_TW, Y - jt), span = tw + k - 1;
     if (threadIdx.x < k) wf[threadIdx.x] = (float)w[threadIdx.x];
     const int row0 = i + k - r, col0 = jt + k - r;
-    for (int idx = threadIdx.x; idx < k * span; idx += blockDim.x) {
-        const int a = idx / span, b = idx - a * span;
-        const unsigned pix = (unsigned)((f * hp + row0 + a) * wp + col0 + b);
-        const uint4 q = rng(pix >> 2, 0u, seq, 1u);
-        const unsigned sel = pix & 3u;
-        const unsigned u = sel == 0 ? q.x : (sel == 1 ? q.y : (sel == 2 ? q.z : q.w));
-        nz[a][b] = u01(u) * 2.f - 1.f;
+    const int gpr = (span + 6) / 4;                            // Philox blocks that can touch one row's span (pixel p = word p & 3 of block p >> 2)
+    for (int idx = threadIdx.x; idx < k * gpr; idx += blockDim.x) {
+        const int a = idx / gpr, g = idx - a * gpr;
+        const unsigned p0 = (unsigned)((f * hp + row0 + a) * wp + col0);
+        const unsigned blk = (p0 >> 2) + g;
+        const uint4 q = rng(blk, 0u, seq, 1u);
+        const unsigned wv[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int b = (int)(blk * 4u + e) - (int)p0;
+            if (b >= 0 && b < span) nz[a][b] = u01(wv[e]) * 2.f - 1.f;
+        }
     }
     __syncthreads();
     for (int idx = threadIdx.x; idx < k * tw; idx += blockDim.x) {
@@ -570,18 +664,30 @@ __global__ void __launch_bounds__(256) k_elastic_fields_rng(float* __restrict__ 
 // coarse dropout as k_coarse_dropout, the keep grid drawn in the kernel: cell (si, sj[, c]) is dropped when its uniform draw < rate
 // (imgaug CoarseDropout(p=rate): a Binomial(1 - rate) keep mask at the low resolution)
 template <typename T>
-__global__ void k_coarse_dropout_rng(T* __restrict__ x, int X, int Y, int C, int ld, int hs, int wsz, int kc, float rate, const float* __restrict__ stats,
-                                     Philox rng, unsigned seq) {
-    const int64_t total = (int64_t)X * Y * C;
+__global__ void k_coarse_dropout_rng(T* __restrict__ x, int X, int Y, int C, int ld, int64_t stride, GridB G, int kc, float rate,
+                                     const float* __restrict__ stats, Philox rng, SeqB S) {
+    const unsigned seq = S.v[blockIdx.y];
+    if (seq == 0) return;
+    x += blockIdx.y * stride;
+    stats += blockIdx.y * 2;
+    const int hs = G.hs[blockIdx.y], wsz = G.ws[blockIdx.y];
     const double fi = (double)hs / X, fj = (double)wsz / Y;
     const float lo = stats[0];
+    // cell q of the keep grid ((si * ws + sj) * kc + c) draws word q & 3 of Philox block q >> 2: a thread takes four neighbouring slices of a
+    // pixel with ONE block when the slices come in fours (C % 4 == 0), else one voxel - the same cells, the same words
+    const int cpt = (C & 3) == 0 ? 4 : 1, CG = C / cpt;
+    const int64_t total = (int64_t)X * Y * CG;
     for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
-        const int c = (int)(t % C);
-        const int64_t ij = t / C;
+        const int c = (int)(t % CG) * cpt;
+        const int64_t ij = t / CG;
         const int j = (int)(ij % Y), i = (int)(ij / Y);
         const int si = min((int)floor(i * fi), hs - 1), sj = min((int)floor(j * fj), wsz - 1);
         const unsigned cell = (unsigned)((si * wsz + sj) * kc + (kc == 1 ? 0 : c));
-        if (u01(rng(cell, 0u, seq, 0u).x) < rate) st_any<T>(x, ij * ld + c, lo);
+        const uint4 q = rng(cell >> 2, 0u, seq, 0u);
+        const unsigned wv[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (e < cpt && u01(wv[kc == 1 ? (cell & 3u) : ((cell + e) & 3u)]) < rate) st_any<T>(x, ij * ld + c + e, lo);
     }
 }
 
@@ -599,16 +705,28 @@ extern "C" int fmri_shot_noise_step(void* x, int64_t n, int dtype, const float* 
     return FMRI_OK;
 }
 
-extern "C" int fmri_elastic_warp(const void* src, int dtype, int X, int Y, int C, int src_ld, const float* d0, const float* d1, int order, void* dst,
-                                int dst_ld, fmri_stream_t stream) {
-    if (X < 1 || Y < 1 || C < 1 || src_ld < C || dst_ld < C || (order != 0 && order != 1) || !d0 || !d1 || src == dst) return FMRI_E_SHAPE;
-    hipStream_t st = as_stream(stream);
-    const int grid = grid_for((int64_t)X * Y * C);
-    if (dtype == FMRI_F32) k_elastic_warp<float><<<grid, 256, 0, st>>>((const float*)src, X, Y, C, src_ld, d0, d1, order, (float*)dst, dst_ld);
-    else if (dtype == FMRI_U8) k_elastic_warp<uint8_t><<<grid, 256, 0, st>>>((const uint8_t*)src, X, Y, C, src_ld, d0, d1, order, (uint8_t*)dst, dst_ld);
+static int elastic_warp_launch(const void* src, int dtype, int X, int Y, int C, int src_ld, const float* d0, const float* d1, int order, void* dst,
+                               int dst_ld, int64_t src_stride, int64_t dst_stride, int64_t d_stride, int B, hipStream_t st) {
+    const dim3 grid(grid_for((int64_t)X * Y * C), B);
+    if (dtype == FMRI_F32)
+        k_elastic_warp<float><<<grid, 256, 0, st>>>((const float*)src, X, Y, C, src_ld, d0, d1, order, (float*)dst, dst_ld, src_stride, dst_stride, d_stride);
+    else if (dtype == FMRI_U8)
+        k_elastic_warp<uint8_t><<<grid, 256, 0, st>>>((const uint8_t*)src, X, Y, C, src_ld, d0, d1, order, (uint8_t*)dst, dst_ld, src_stride, dst_stride,
+                                                      d_stride);
     else return FMRI_E_DTYPE;
     FMRI_LAUNCH_CHECK();
     return FMRI_OK;
+}
+extern "C" int fmri_elastic_warp(const void* src, int dtype, int X, int Y, int C, int src_ld, const float* d0, const float* d1, int order, void* dst,
+                                int dst_ld, fmri_stream_t stream) {
+    if (X < 1 || Y < 1 || C < 1 || src_ld < C || dst_ld < C || (order != 0 && order != 1) || !d0 || !d1 || src == dst) return FMRI_E_SHAPE;
+    return elastic_warp_launch(src, dtype, X, Y, C, src_ld, d0, d1, order, dst, dst_ld, 0, 0, 0, 1, as_stream(stream));
+}
+extern "C" int fmri_elastic_warp_batch(const void* src, int dtype, int X, int Y, int C, int src_ld, int64_t src_stride, const float* d, int order,
+                                      void* dst, int dst_ld, int64_t dst_stride, int B, fmri_stream_t stream) {
+    if (X < 1 || Y < 1 || C < 1 || src_ld < C || dst_ld < C || (order != 0 && order != 1) || !d || src == dst || B < 1 || B > 65535) return FMRI_E_SHAPE;
+    return elastic_warp_launch(src, dtype, X, Y, C, src_ld, d, d + (int64_t)X * Y, order, dst, dst_ld, src_stride, dst_stride, (int64_t)2 * X * Y, B,
+                               as_stream(stream));
 }
 
 extern "C" int fmri_piecewise_affine2(const void* src, int dtype, int X, int Y, int C, int src_ld, const double* tri, int order, void* dst, int dst_ld,
@@ -637,16 +755,10 @@ extern "C" int fmri_coarse_dropout(void* x, int dtype, int X, int Y, int C, int 
     return FMRI_OK;
 }
 
-extern "C" int fmri_affine_sample(const void* vol, int vol_dtype, int X, int Y, int Z, const double* affine, int x0, int y0, int z0, int nx,
-                                  int ny, int nz, int order, float cval, void* out, int out_dtype, int out_ld, fmri_stream_t stream) {
-    if (X < 1 || Y < 1 || Z < 1 || nx < 1 || ny < 1 || nz < 1 || out_ld < nz || (order != 0 && order != 1) || !affine) return FMRI_E_SHAPE;
-    Affine34 A;
-    for (int i = 0; i < 12; ++i) A.a[i] = affine[i];
-    const int64_t total = (int64_t)nx * ny * nz;
-    const int grid = grid_for(total);
-    hipStream_t st = as_stream(stream);
-#define FMRI_AS(TI, TO) \
-    k_affine_sample<TI, TO><<<grid, 256, 0, st>>>((const TI*)vol, X, Y, Z, A, x0, y0, z0, nx, ny, nz, order, cval, (TO*)out, out_ld)
+static int affine_sample_launch(const AffineB& P, int B, int vol_dtype, int nx, int ny, int nz, int order, void* out, int out_dtype, int out_ld,
+                                int64_t out_stride, hipStream_t st) {
+    const dim3 grid(grid_for((int64_t)nx * ny * nz), B);
+#define FMRI_AS(TI, TO) k_affine_sample<TI, TO><<<grid, 256, 0, st>>>(P, nx, ny, nz, order, (TO*)out, out_ld, out_stride)
     if (vol_dtype == FMRI_F32 && out_dtype == FMRI_F32) FMRI_AS(float, float);
     else if (vol_dtype == FMRI_F32 && out_dtype == FMRI_BF16) FMRI_AS(float, bf16_t);
     else if (vol_dtype == FMRI_U8 && out_dtype == FMRI_U8) FMRI_AS(uint8_t, uint8_t);
@@ -655,6 +767,40 @@ extern "C" int fmri_affine_sample(const void* vol, int vol_dtype, int X, int Y, 
     else return FMRI_E_DTYPE;
 #undef FMRI_AS
     FMRI_LAUNCH_CHECK();
+    return FMRI_OK;
+}
+extern "C" int fmri_affine_sample(const void* vol, int vol_dtype, int X, int Y, int Z, const double* affine, int x0, int y0, int z0, int nx,
+                                  int ny, int nz, int order, float cval, void* out, int out_dtype, int out_ld, fmri_stream_t stream) {
+    if (X < 1 || Y < 1 || Z < 1 || nx < 1 || ny < 1 || nz < 1 || out_ld < nz || (order != 0 && order != 1) || !affine) return FMRI_E_SHAPE;
+    AffineB P;
+    P.vol[0] = vol;
+    P.X[0] = X; P.Y[0] = Y; P.Z[0] = Z; P.x0[0] = x0; P.y0[0] = y0; P.z0[0] = z0;
+    P.cval[0] = cval;
+    for (int i = 0; i < 12; ++i) P.A[0].a[i] = affine[i];
+    return affine_sample_launch(P, 1, vol_dtype, nx, ny, nz, order, out, out_dtype, out_ld, 0, as_stream(stream));
+}
+extern "C" int fmri_affine_sample_batch(int B, const void* const* vols, const int* dims, const double* affines, const int* corners, const float* cvals,
+                                        int vol_dtype, int nx, int ny, int nz, int order, void* out, int out_dtype, int out_ld, int64_t out_stride,
+                                        fmri_stream_t stream) {
+    if (B < 1 || !vols || !dims || !affines || !corners || !cvals || nx < 1 || ny < 1 || nz < 1 || out_ld < nz || (order != 0 && order != 1))
+        return FMRI_E_SHAPE;
+    const int esz = out_dtype == FMRI_F32 ? 4 : (out_dtype == FMRI_BF16 ? 2 : 1);
+    for (int b0 = 0; b0 < B; b0 += AFF_MAXB) {
+        const int nb = B - b0 < AFF_MAXB ? B - b0 : AFF_MAXB;
+        AffineB P;
+        for (int b = 0; b < nb; ++b) {
+            const int g = b0 + b;
+            if (!vols[g] || dims[3 * g] < 1 || dims[3 * g + 1] < 1 || dims[3 * g + 2] < 1) return FMRI_E_SHAPE;
+            P.vol[b] = vols[g];
+            P.X[b] = dims[3 * g]; P.Y[b] = dims[3 * g + 1]; P.Z[b] = dims[3 * g + 2];
+            P.x0[b] = corners[3 * g]; P.y0[b] = corners[3 * g + 1]; P.z0[b] = corners[3 * g + 2];
+            P.cval[b] = cvals[g];
+            for (int i = 0; i < 12; ++i) P.A[b].a[i] = affines[12 * g + i];
+        }
+        const int rc = affine_sample_launch(P, nb, vol_dtype, nx, ny, nz, order, (char*)out + (int64_t)b0 * out_stride * esz, out_dtype, out_ld, out_stride,
+                                            as_stream(stream));
+        if (rc != FMRI_OK) return rc;
+    }
     return FMRI_OK;
 }
 
@@ -696,84 +842,133 @@ extern "C" int fmri_noise_augment(void* x, int64_t n, int dtype, const float* st
     return FMRI_OK;
 }
 
-// ---- the same intensity steps with in-kernel Philox draws and chained min / max (see the kernels' comment block above)
+// ---- the same intensity steps with in-kernel Philox draws and chained min / max, over the B patches of a batch (see the kernels' comment
+// block above).  Per-patch arrays live on the HOST and are read at enqueue.
 static inline Philox philox_of(uint64_t seed) {
     Philox p;
     p.k0 = (unsigned)seed;
     p.k1 = (unsigned)(seed >> 32);
     return p;
 }
+static inline SeqB seqs_of(const uint32_t* seqs, int b0, int nb) {
+    SeqB S;
+    for (int b = 0; b < AUG_MAXB; ++b) S.v[b] = b < nb ? seqs[b0 + b] : 0u;
+    return S;
+}
+template <typename T> static inline T* patch_ptr(T* base, int64_t stride, int b0) { return base + (int64_t)b0 * stride; }
+#define FMRI_FOR_CHUNKS(B) for (int b0 = 0, nb = 0; b0 < (B) && ((nb = (B) - b0 < AUG_MAXB ? (B) - b0 : AUG_MAXB), true); b0 += AUG_MAXB)
 
-extern "C" int fmri_minmax_ws(const void* x, int64_t n, int dtype, float* stats, int* ws, fmri_stream_t stream) {
-    if (n < 1 || !x || !stats || !ws) return FMRI_E_SHAPE;
+extern "C" int fmri_minmax_ws_batch(const void* x, int64_t n, int64_t stride, int B, int dtype, float* stats, int* ws, fmri_stream_t stream) {
+    if (n < 1 || B < 1 || B > 65535 || !x || !stats || !ws) return FMRI_E_SHAPE;
     hipStream_t st = as_stream(stream);
-    const int grid = grid_for((n + 3) / 4, AUG_THREADS, AUG_BLOCKS);
-    if (dtype == FMRI_F32) k_minmax_ws<float><<<grid, AUG_THREADS, 0, st>>>((const float*)x, n, ws, stats);
-    else if (dtype == FMRI_BF16) k_minmax_ws<bf16_t><<<grid, AUG_THREADS, 0, st>>>((const bf16_t*)x, n, ws, stats);
+    const dim3 grid(grid_for((n + 3) / 4, AUG_THREADS, AUG_BLOCKS), B);
+    if (dtype == FMRI_F32) k_minmax_ws<float><<<grid, AUG_THREADS, 0, st>>>((const float*)x, n, stride, ws, stats);
+    else if (dtype == FMRI_BF16) k_minmax_ws<bf16_t><<<grid, AUG_THREADS, 0, st>>>((const bf16_t*)x, n, stride, ws, stats);
     else return FMRI_E_DTYPE;
     FMRI_LAUNCH_CHECK();
     return FMRI_OK;
 }
 
-extern "C" int fmri_rescale_intensity_ws(void* x, int64_t n, int dtype, float* stats, int* ws, int contrast, float lo, float hi, float mult,
+extern "C" int fmri_rescale_intensity_ws_batch(void* x, int64_t n, int64_t stride, int B, int dtype, float* stats, int* ws, const float* params,
+                                               fmri_stream_t stream) {
+    if (n < 1 || B < 1 || !x || !stats || !ws || !params) return FMRI_E_SHAPE;
+    if (dtype != FMRI_F32 && dtype != FMRI_BF16) return FMRI_E_DTYPE;
+    hipStream_t st = as_stream(stream);
+    FMRI_FOR_CHUNKS(B) {
+        RescaleB P;
+        for (int b = 0; b < AUG_MAXB; ++b) {
+            const float* q = params + 4 * (b0 + (b < nb ? b : 0));
+            P.mode[b] = b < nb ? (int)q[0] : 0;
+            P.lo[b] = q[1]; P.hi[b] = q[2]; P.mult[b] = q[3];
+            if (P.mode[b] < 0 || P.mode[b] > 2) return FMRI_E_SHAPE;
+        }
+        const dim3 grid(grid_for(n, AUG_THREADS, AUG_BLOCKS), nb);
+        if (dtype == FMRI_F32)
+            k_rescale_ws<float><<<grid, AUG_THREADS, 0, st>>>(patch_ptr((float*)x, stride, b0), n, stride, stats + 2 * b0, ws + b0 * AUG_WS_INTS, P);
+        else
+            k_rescale_ws<bf16_t><<<grid, AUG_THREADS, 0, st>>>(patch_ptr((bf16_t*)x, stride, b0), n, stride, stats + 2 * b0, ws + b0 * AUG_WS_INTS, P);
+    }
+    FMRI_LAUNCH_CHECK();
+    return FMRI_OK;
+}
+
+extern "C" int fmri_noise_rng_batch(void* x, int64_t n, int64_t stride, int B, int dtype, float* stats, int* ws, int kind, float sigma, uint64_t seed,
+                                    const uint32_t* seqs, fmri_stream_t stream) {
+    if (n < 1 || B < 1 || (kind != 0 && kind != 1) || !x || !stats || !ws || !seqs) return FMRI_E_SHAPE;
+    if (dtype != FMRI_F32 && dtype != FMRI_BF16) return FMRI_E_DTYPE;
+    hipStream_t st = as_stream(stream);
+    FMRI_FOR_CHUNKS(B) {
+        const dim3 grid(grid_for((n + 3) / 4, AUG_THREADS, AUG_BLOCKS), nb);
+        const SeqB S = seqs_of(seqs, b0, nb);
+        if (dtype == FMRI_F32)
+            k_noise_rng<float><<<grid, AUG_THREADS, 0, st>>>(patch_ptr((float*)x, stride, b0), n, stride, stats + 2 * b0, ws + b0 * AUG_WS_INTS, kind, sigma,
+                                                            philox_of(seed), S);
+        else
+            k_noise_rng<bf16_t><<<grid, AUG_THREADS, 0, st>>>(patch_ptr((bf16_t*)x, stride, b0), n, stride, stats + 2 * b0, ws + b0 * AUG_WS_INTS, kind, sigma,
+                                                             philox_of(seed), S);
+    }
+    FMRI_LAUNCH_CHECK();
+    return FMRI_OK;
+}
+
+extern "C" int fmri_shot_noise_rng_batch(void* x, int64_t n, int64_t stride, int B, int dtype, float* stats, int* ws, uint64_t seed, const uint32_t* seqs,
                                          fmri_stream_t stream) {
-    if (n < 1 || !x || !stats || !ws) return FMRI_E_SHAPE;
+    if (n < 1 || B < 1 || !x || !stats || !ws || !seqs) return FMRI_E_SHAPE;
+    if (dtype != FMRI_F32 && dtype != FMRI_BF16) return FMRI_E_DTYPE;
     hipStream_t st = as_stream(stream);
-    const int grid = grid_for(n, AUG_THREADS, AUG_BLOCKS);
-    if (dtype == FMRI_F32) k_rescale_ws<float><<<grid, AUG_THREADS, 0, st>>>((float*)x, n, stats, ws, contrast, lo, hi, mult);
-    else if (dtype == FMRI_BF16) k_rescale_ws<bf16_t><<<grid, AUG_THREADS, 0, st>>>((bf16_t*)x, n, stats, ws, contrast, lo, hi, mult);
-    else return FMRI_E_DTYPE;
+    FMRI_FOR_CHUNKS(B) {
+        const dim3 g0(grid_for(n), nb), g1(grid_for(n, AUG_THREADS, AUG_BLOCKS), nb);
+        const SeqB S = seqs_of(seqs, b0, nb);
+        float* sp = stats + 2 * b0;
+        int* wp = ws + b0 * AUG_WS_INTS;
+        if (dtype == FMRI_F32) {
+            k_shot_levels<float><<<g0, 256, 0, st>>>(patch_ptr((const float*)x, stride, b0), n, stride, sp, wp, S);
+            k_shot_draw<float><<<g1, AUG_THREADS, 0, st>>>(patch_ptr((float*)x, stride, b0), n, stride, sp, wp, philox_of(seed), S);
+        } else {
+            k_shot_levels<bf16_t><<<g0, 256, 0, st>>>(patch_ptr((const bf16_t*)x, stride, b0), n, stride, sp, wp, S);
+            k_shot_draw<bf16_t><<<g1, AUG_THREADS, 0, st>>>(patch_ptr((bf16_t*)x, stride, b0), n, stride, sp, wp, philox_of(seed), S);
+        }
+    }
     FMRI_LAUNCH_CHECK();
     return FMRI_OK;
 }
 
-extern "C" int fmri_noise_rng(void* x, int64_t n, int dtype, float* stats, int* ws, int kind, float sigma, uint64_t seed, uint32_t seq,
-                              fmri_stream_t stream) {
-    if (n < 1 || (kind != 0 && kind != 1) || !x || !stats || !ws) return FMRI_E_SHAPE;
-    hipStream_t st = as_stream(stream);
-    const int grid = grid_for((n + 3) / 4, AUG_THREADS, AUG_BLOCKS);
-    if (dtype == FMRI_F32) k_noise_rng<float><<<grid, AUG_THREADS, 0, st>>>((float*)x, n, stats, ws, kind, sigma, philox_of(seed), seq);
-    else if (dtype == FMRI_BF16) k_noise_rng<bf16_t><<<grid, AUG_THREADS, 0, st>>>((bf16_t*)x, n, stats, ws, kind, sigma, philox_of(seed), seq);
-    else return FMRI_E_DTYPE;
-    FMRI_LAUNCH_CHECK();
-    return FMRI_OK;
-}
-
-extern "C" int fmri_shot_noise_rng(void* x, int64_t n, int dtype, float* stats, int* ws, uint64_t seed, uint32_t seq, fmri_stream_t stream) {
-    if (n < 1 || !x || !stats || !ws) return FMRI_E_SHAPE;
-    hipStream_t st = as_stream(stream);
-    const int g0 = grid_for(n), g1 = grid_for(n, AUG_THREADS, AUG_BLOCKS);
-    if (dtype == FMRI_F32) {
-        k_shot_levels<float><<<g0, 256, 0, st>>>((const float*)x, n, stats, ws);
-        k_shot_draw<float><<<g1, AUG_THREADS, 0, st>>>((float*)x, n, stats, ws, philox_of(seed), seq);
-    } else if (dtype == FMRI_BF16) {
-        k_shot_levels<bf16_t><<<g0, 256, 0, st>>>((const bf16_t*)x, n, stats, ws);
-        k_shot_draw<bf16_t><<<g1, AUG_THREADS, 0, st>>>((bf16_t*)x, n, stats, ws, philox_of(seed), seq);
-    } else return FMRI_E_DTYPE;
-    FMRI_LAUNCH_CHECK();
-    return FMRI_OK;
-}
-
-extern "C" int fmri_elastic_fields_rng(float* d0, float* d1, int X, int Y, int k, const double* weights, float alpha, uint64_t seed, uint32_t seq,
-                                       fmri_stream_t stream) {
-    if (!d0 || !d1 || !weights || X < 1 || Y < 1 || k < 1 || k > EF_KMAX || (k & 1) == 0) return FMRI_E_SHAPE;
+extern "C" int fmri_elastic_fields_rng_batch(float* d, int X, int Y, int k, const double* weights, const float* alphas, uint64_t seed, const uint32_t* seqs,
+                                             int B, fmri_stream_t stream) {
+    if (!d || !weights || !alphas || !seqs || B < 1 || X < 1 || X > 65535 || Y < 1 || k < 1 || k > EF_KMAX || (k & 1) == 0) return FMRI_E_SHAPE;
     if ((int64_t)2 * (X + 2 * k) * (Y + 2 * k) > 0x7fffffff) return FMRI_E_SHAPE;
-    const dim3 grid((Y + EF_TW - 1) / EF_TW, X, 2);
-    k_elastic_fields_rng<<<grid, 256, 0, as_stream(stream)>>>(d0, d1, X, Y, k, weights, alpha, philox_of(seed), seq);
+    FMRI_FOR_CHUNKS(B) {
+        AlphaB A;
+        for (int b = 0; b < AUG_MAXB; ++b) A.v[b] = b < nb ? alphas[b0 + b] : 0.f;
+        const dim3 grid((Y + EF_TW - 1) / EF_TW, X, 2 * nb);
+        k_elastic_fields_rng<<<grid, 256, 0, as_stream(stream)>>>(d + (int64_t)b0 * 2 * X * Y, X, Y, k, weights, A, philox_of(seed), seqs_of(seqs, b0, nb));
+    }
     FMRI_LAUNCH_CHECK();
     return FMRI_OK;
 }
 
-extern "C" int fmri_coarse_dropout_rng(void* x, int dtype, int X, int Y, int C, int ld, int hs, int ws_, int kc, float rate, const float* stats,
-                                       uint64_t seed, uint32_t seq, fmri_stream_t stream) {
-    if (X < 1 || Y < 1 || C < 1 || ld < C || hs < 1 || ws_ < 1 || (kc != 1 && kc != C) || !x || !stats || !(rate >= 0.f && rate <= 1.f))
+extern "C" int fmri_coarse_dropout_rng_batch(void* x, int dtype, int X, int Y, int C, int ld, int64_t stride, int B, const int* grids, int kc, float rate,
+                                             const float* stats, uint64_t seed, const uint32_t* seqs, fmri_stream_t stream) {
+    if (X < 1 || Y < 1 || C < 1 || ld < C || B < 1 || !grids || (kc != 1 && kc != C) || !x || !stats || !seqs || !(rate >= 0.f && rate <= 1.f))
         return FMRI_E_SHAPE;
+    if (dtype != FMRI_F32 && dtype != FMRI_BF16) return FMRI_E_DTYPE;
     hipStream_t st = as_stream(stream);
-    const int grid = grid_for((int64_t)X * Y * C);
-    if (dtype == FMRI_F32) k_coarse_dropout_rng<float><<<grid, 256, 0, st>>>((float*)x, X, Y, C, ld, hs, ws_, kc, rate, stats, philox_of(seed), seq);
-    else if (dtype == FMRI_BF16)
-        k_coarse_dropout_rng<bf16_t><<<grid, 256, 0, st>>>((bf16_t*)x, X, Y, C, ld, hs, ws_, kc, rate, stats, philox_of(seed), seq);
-    else return FMRI_E_DTYPE;
+    FMRI_FOR_CHUNKS(B) {
+        GridB G;
+        for (int b = 0; b < AUG_MAXB; ++b) {
+            G.hs[b] = b < nb ? grids[2 * (b0 + b)] : 1;
+            G.ws[b] = b < nb ? grids[2 * (b0 + b) + 1] : 1;
+            if (G.hs[b] < 1 || G.ws[b] < 1) return FMRI_E_SHAPE;
+        }
+        const dim3 grid(grid_for((int64_t)X * Y * C), nb);
+        const SeqB S = seqs_of(seqs, b0, nb);
+        if (dtype == FMRI_F32)
+            k_coarse_dropout_rng<float><<<grid, 256, 0, st>>>(patch_ptr((float*)x, stride, b0), X, Y, C, ld, stride, G, kc, rate, stats + 2 * b0,
+                                                             philox_of(seed), S);
+        else
+            k_coarse_dropout_rng<bf16_t><<<grid, 256, 0, st>>>(patch_ptr((bf16_t*)x, stride, b0), X, Y, C, ld, stride, G, kc, rate, stats + 2 * b0,
+                                                              philox_of(seed), S);
+    }
     FMRI_LAUNCH_CHECK();
     return FMRI_OK;
 }

@@ -127,7 +127,9 @@ class _Sampler(object):
         self.prev_truth_index, self.prev_truth_size = prev_truth_index, prev_truth_size
         self.n_chan = self.patch_shape[2] + (prev_truth_size if prev_truth_index is not None else 0)
         self.stats, self.ws = ops.aug_workspace(ddf.device)
+        self.stats_b = self.ws_b = None                  # the batch path's [B] workspaces, made on first use
         self.seed, self.seq = int(noise_seed), 0
+        self.batched = True
         self.gen = torch.Generator(device=ddf.device)
         self.gen.manual_seed(noise_seed)
         # imgaug keeps its own random state (the reference's numpy / python streams are not advanced by its draws): the grid sizes of the coarse
@@ -145,41 +147,148 @@ class _Sampler(object):
         self.seq += 1
         return self.seq
 
-    def sample_into(self, index, x_slot, y_slot, m_slot=None):
-        """x_slot: float32 view (X, Y, n_chan) of the batch tensor; y_slot: uint8 view (X, Y, truth_size); m_slot: float32 view
-        (X, Y, truth_size) for the distance mask, when the data file has masks"""
-        ops, ddf = self.ops, self.ddf
+    def plan(self, index):
+        """every HOST draw of one patch, in the reference's order (numpy's global state, python's `random`, this sampler's private imgaug
+        state and the call numbers of its in-kernel draws), and the matrices they give - nothing is enqueued.  -> dict for launch_one /
+        launch_batch."""
+        ddf, ps = self.ddf, self.patch_shape
         data, truth = ddf.data[index], ddf.truth[index]
-        ps = self.patch_shape
         corner = [np.random.randint(low=0, high=h) for h in np.array(truth.shape) - np.array(ps)]
-        zt = corner[2] + self.truth_index
+        q = {"index": index, "corner": corner, "corners": None, "elastic_seq": 0, "elastic_rng": True, "shot_seq": 0, "speckle_seq": 0,
+             "gaussian_seq": 0, "dropout_seq": 0, "grid": (1, 1)}
         if self.augment is not None:
             p = draw_augment_parameters(self.augment, 3, ddf.min[index], ddf.max[index])
-            _, A = distort_image(data, np.eye(4), flip_axis=p["flip_axis"], scale_factor=p["scale_factor"],
-                                 rotate_factor=p["rotate_factor"], translate_factor=p["translate_factor"])
-            _, At = distort_image(truth, np.eye(4), flip_axis=p["flip_axis"], scale_factor=p["scale_factor"],
-                                  rotate_factor=p["rotate_factor"], translate_factor=p["translate_factor"])
-            Am = None
-            if m_slot is not None:
-                _, Am = distort_image(ddf.mask[index], np.eye(4), flip_axis=p["flip_axis"], scale_factor=p["scale_factor"],
-                                      rotate_factor=p["rotate_factor"], translate_factor=p["translate_factor"])
+            geo = dict(flip_axis=p["flip_axis"], scale_factor=p["scale_factor"], rotate_factor=p["rotate_factor"], translate_factor=p["translate_factor"])
+            _, A = distort_image(data, np.eye(4), **geo)
+            _, At = distort_image(truth, np.eye(4), **geo)
+            Am = distort_image(ddf.mask[index], np.eye(4), **geo)[1] if ddf.mask is not None else None
         else:
             p, A, At, Am = None, np.eye(4), np.eye(4), np.eye(4)
+        q.update(p=p, A=A, At=At, Am=Am)
+        if p is None:
+            return q
         # imgaug's two geometric augmenters, each a resampling of its own as in the reference: piecewise affine (augment.py:344-347; a 2 x 2 grid:
         # the four corners move by Normal(0, scale) of the extent, clipped to the image; two triangles), then the elastic transform (:349-353).
         # ONE set of moved corners / ONE in-plane displacement field for every slice and for image (bilinear), truth, previous-slice truth and mask
-        # (nearest): the affine samples land in scratch tensors and are warped into the slots
-        elastic, corners = None, None
-        if p is not None and p["piecewise_affine_scale"] > 0:
+        if p["piecewise_affine_scale"] > 0:
             h, w = float(ps[0]), float(ps[1])
             grid = np.array([[0, 0], [0, w], [h, 0], [h, w]], dtype=np.float64)
             corners = grid + self.host_rng.normal(0.0, p["piecewise_affine_scale"], size=(4, 2)) * np.array([h, w])
             corners[:, 0] = np.clip(corners[:, 0], 0, h - 1)
             corners[:, 1] = np.clip(corners[:, 1], 0, w - 1)
-        if p is not None and p["elastic_transform_scale"] > 0:
+            q["corners"] = corners
+        if p["elastic_transform_scale"] > 0:
+            q["elastic_rng"] = self.ops.elastic_ksize(float(self.augment["elastic_transform"]["sigma"])) <= self.ops.ELASTIC_RNG_KMAX
+            q["elastic_seq"] = self._next_seq() if q["elastic_rng"] else -1
+        q["need_intensity"] = bool(p["contrast"] is not None or p["intensity_multiplication"] != 1 or p["apply_speckle_noise"] or p["apply_gaussian_noise"]
+                                   or p["apply_gaussian_filter"] or p["apply_poisson_noise"] or p["coarse_dropout"])
+        if p["apply_poisson_noise"]:
+            q["shot_seq"] = self._next_seq()
+        if p["apply_speckle_noise"]:
+            q["speckle_seq"] = self._next_seq()
+        if p["apply_gaussian_noise"]:
+            q["gaussian_seq"] = self._next_seq()
+        if p["coarse_dropout"]:
+            # reference augment.py:373-375 (last step): imgaug CoarseDropout(p=rate, size_percent, per_channel) in a [0, 255] scaling
+            q["grid"] = _coarse_grid((ps[0], ps[1]), self.augment["coarse_dropout"]["size_percent"], self.host_rng)
+            q["dropout_seq"] = self._next_seq()
+        return q
+
+    def sample_into(self, index, x_slot, y_slot, m_slot=None):
+        """one patch: x_slot: float32 view (X, Y, n_chan) of the batch tensor; y_slot: uint8 view (X, Y, truth_size); m_slot: float32 view
+        (X, Y, truth_size) for the distance mask, when the data file has masks"""
+        self.launch_one(self.plan(index), x_slot, y_slot, m_slot)
+
+    def batchable(self, plans):
+        """can launch_batch take these plans?  Not: previous-slice truth channels, piecewise affine, a Gaussian filter on some patch, an
+        elastic kernel wider than the one-launch field kernel - those go patch by patch (launch_one)"""
+        if self.prev_truth_index is not None or self.n_chan != self.patch_shape[2]:
+            return False
+        return all(q["corners"] is None and q["elastic_seq"] >= 0 and not (q["p"] is not None and q["p"]["apply_gaussian_filter"]) for q in plans)
+
+    def launch(self, plans, x, y, m=None):
+        """x (B, X, Y, n_chan) float32, y (B, X, Y, truth_size) uint8, m like y in float32 or None: the patches of `plans`, in order"""
+        if self.batched and self.batchable(plans):
+            self.launch_batch(plans, x, y, m)
+        else:
+            for b, q in enumerate(plans):
+                self.launch_one(q, x[b], y[b], None if m is None else m[b])
+
+    def launch_batch(self, plans, x, y, m=None):
+        """the patches of a batch with ONE launch per step of the chain (fmri_*_batch): 2-3 gathers, the elastic fields and 2-3 warps, the
+        min / max, then only the intensity steps some patch of the batch drew.  Same arithmetic, same draws as launch_one patch by patch
+        (tests/test_gpu_augment.py)."""
+        ops, ddf, torch, ps = self.ops, self.ddf, self.torch, self.patch_shape
+        B = len(plans)
+        idx = [q["index"] for q in plans]
+        tshape = (ps[0], ps[1], self.truth_size)
+        warped = any(q["elastic_seq"] for q in plans)
+
+        def target(dst, shape, dtype):
+            return dst if not warped else torch.empty((B,) + tuple(shape), device=dst.device, dtype=dtype)
+
+        d = None
+        if warped:
+            d = ops.elastic_fields_rng_batch((ps[0], ps[1]), [q["p"]["elastic_transform_scale"] if q["elastic_seq"] else 0.0 for q in plans],
+                                             self.augment["elastic_transform"]["sigma"], self.seed, [q["elastic_seq"] for q in plans], device=x.device)
+        corners_t = [(q["corner"][0], q["corner"][1], q["corner"][2] + self.truth_index) for q in plans]
+        # image: trilinear, outside = the volume's minimum; labels: nearest, outside = 0 (identity affine = the plain crop)
+        xt = target(x, ps, torch.float32)
+        ops.affine_sample_batch([ddf.data[i] for i in idx], [q["A"] for q in plans], [q["corner"] for q in plans], ps, xt, 1, [ddf.min[i] for i in idx])
+        yt = target(y, tshape, torch.uint8)
+        ops.affine_sample_batch([ddf.truth[i] for i in idx], [q["At"] for q in plans], corners_t, tshape, yt, 0, [0.0] * B)
+        if warped:
+            ops.elastic_warp_batch(xt, d, 1, x)
+            ops.elastic_warp_batch(yt, d, 0, y)
+        if m is not None:
+            # augmented: outside the mask = 0 (interpolate_affine_range, cval 0); plain crop: edge values
+            src = [ddf.mask[q["index"]] if q["p"] is not None else ddf.mask_for_crops(q["index"]) for q in plans]
+            mt = target(m, tshape, torch.float32)
+            ops.affine_sample_batch(src, [q["Am"] for q in plans], corners_t, tshape, mt, 0, [0.0] * B)
+            if warped:
+                ops.elastic_warp_batch(mt, d, 0, m)
+        if not any(q["p"] is not None and q["need_intensity"] for q in plans):
+            return
+        stats, ws = self._workspace(B)
+        ops.minmax_ws_batch(x, stats, ws)
+        params = []
+        for q in plans:
+            p = q["p"]
+            if p is None or (p["contrast"] is None and p["intensity_multiplication"] == 1):
+                params.append((0, 0.0, 0.0, 1.0))
+            else:
+                lo, hi = p["contrast"] if p["contrast"] is not None else (0.0, 0.0)
+                params.append((2 if p["contrast"] is not None else 1, lo, hi, p["intensity_multiplication"]))
+        if any(r[0] for r in params):
+            ops.rescale_intensity_ws_batch(x, stats, ws, params)
+        # order of reference augment.py:354-367: (gaussian filter,) shot (poisson) noise, speckle, gaussian noise; coarse dropout last
+        if any(q["shot_seq"] for q in plans):
+            ops.shot_noise_rng_batch(x, stats, ws, self.seed, [q["shot_seq"] for q in plans])
+        for key, aug_key, kind in (("speckle_seq", "speckle_noise", 1), ("gaussian_seq", "gaussian_noise", 0)):
+            if any(q[key] for q in plans):
+                ops.noise_rng_batch(x, stats, ws, kind, self.augment[aug_key]["sigma"], self.seed, [q[key] for q in plans])
+        if any(q["dropout_seq"] for q in plans):
+            cd = self.augment["coarse_dropout"]
+            ops.coarse_dropout_rng_batch(x, [q["grid"] for q in plans], cd["rate"], stats, bool(cd.get("per_channel", True)), self.seed,
+                                         [q["dropout_seq"] for q in plans])
+
+    def _workspace(self, B):
+        if self.stats_b is None or self.stats_b.shape[0] < B:
+            self.stats_b, self.ws_b = self.ops.aug_workspace(self.ddf.device, max(B, 2))
+        return self.stats_b[:B], self.ws_b[:B]
+
+    def launch_one(self, q, x_slot, y_slot, m_slot=None):
+        """one planned patch, launch by launch (every configuration; the batch path's reference in the tests)"""
+        ops, ddf = self.ops, self.ddf
+        index, corner, p, A, At, Am = q["index"], q["corner"], q["p"], q["A"], q["At"], q["Am"]
+        data, truth = ddf.data[index], ddf.truth[index]
+        ps = self.patch_shape
+        zt = corner[2] + self.truth_index
+        elastic, corners = None, q["corners"]
+        if q["elastic_seq"]:
             sigma = self.augment["elastic_transform"]["sigma"]
-            if ops.elastic_ksize(float(sigma)) <= ops.ELASTIC_RNG_KMAX:
-                elastic = ops.elastic_fields_rng((ps[0], ps[1]), p["elastic_transform_scale"], sigma, self.seed, self._next_seq(), device=ddf.device)
+            if q["elastic_rng"]:
+                elastic = ops.elastic_fields_rng((ps[0], ps[1]), p["elastic_transform_scale"], sigma, self.seed, q["elastic_seq"], device=ddf.device)
             else:
                 elastic = ops.elastic_fields((ps[0], ps[1]), p["elastic_transform_scale"], sigma, generator=self.gen)
         warped = elastic is not None or corners is not None
@@ -209,9 +318,7 @@ class _Sampler(object):
             settle(mt, m_slot, 0)
         img = x_slot if self.n_chan == ps[2] else None
         if p is not None:
-            need_intensity = (p["contrast"] is not None or p["intensity_multiplication"] != 1 or p["apply_speckle_noise"] or p["apply_gaussian_noise"]
-                              or p["apply_gaussian_filter"] or p["apply_poisson_noise"] or p["coarse_dropout"])
-            if need_intensity:
+            if q["need_intensity"]:
                 if img is None:                            # image channels interleaved with the previous-slice truth: work on a copy
                     img = x_slot[..., :ps[2]].contiguous()
                 # Every step below wants the image's range (rescale_intensity's out_range, MinMaxScaler): taken ONCE, then each kernel that
@@ -228,16 +335,14 @@ class _Sampler(object):
                     if smooth is not img:
                         img.copy_(smooth)
                     ops.minmax_ws(img, stats, ws)
-                if p["apply_poisson_noise"]:
-                    ops.shot_noise_rng(img, stats, ws, self.seed, self._next_seq())
-                for flag, key, kind in (("apply_speckle_noise", "speckle_noise", 1), ("apply_gaussian_noise", "gaussian_noise", 0)):
-                    if p[flag]:
-                        ops.noise_rng(img, stats, ws, kind, self.augment[key]["sigma"], self.seed, self._next_seq())
-                if p["coarse_dropout"]:
-                    # reference augment.py:373-375 (last step): imgaug CoarseDropout(p=rate, size_percent, per_channel) in a [0, 255] scaling
+                if q["shot_seq"]:
+                    ops.shot_noise_rng(img, stats, ws, self.seed, q["shot_seq"])
+                for key, aug_key, kind in (("speckle_seq", "speckle_noise", 1), ("gaussian_seq", "gaussian_noise", 0)):
+                    if q[key]:
+                        ops.noise_rng(img, stats, ws, kind, self.augment[aug_key]["sigma"], self.seed, q[key])
+                if q["dropout_seq"]:
                     cd = self.augment["coarse_dropout"]
-                    grid = _coarse_grid((ps[0], ps[1]), cd["size_percent"], self.host_rng)
-                    ops.coarse_dropout_rng(img, grid, cd["rate"], stats, bool(cd.get("per_channel", True)), self.seed, self._next_seq())
+                    ops.coarse_dropout_rng(img, q["grid"], cd["rate"], stats, bool(cd.get("per_channel", True)), self.seed, q["dropout_seq"])
                 if img is not x_slot:
                     x_slot[..., :ps[2]] = img
         if self.prev_truth_index is not None:
@@ -254,11 +359,14 @@ class _Sampler(object):
 def device_data_generator(data_file, index_list, batch_size=1, n_labels=1, labels=None, augment=None, patch_shape=None,
                           shuffle_index_list=True, skip_blank=True, truth_index=-1, truth_size=1, truth_downsample=None, truth_crop=True,
                           categorical=True, prev_truth_index=None, prev_truth_size=None, drop_easy_patches=False, is3d=False,
-                          samples_pad=3, strict=False, noise_seed=0, device="cuda", prefetch=0):
+                          samples_pad=3, strict=False, noise_seed=0, device="cuda", prefetch=0, batched=True):
     """Endless generator of (x, y) CUDA tensors.  `data_file`: a DeviceDataFile, or anything with .root.data / .root.truth
     (uploaded here).  3-D: x (N,1,X,Y,Z), y (N,1,X,Y,truth_size); 2-D: x (N,X,Y,C), y (N,X,Y,truth_size).  skip_blank and
     drop_easy_patches read one scalar back per patch (they decide on the host whether the patch is kept), everything else is
     enqueue-only.
+
+    batched: launch the patches of a batch together, one launch per step of the sampling / augmentation chain (the default; configurations
+    the batch kernels do not cover go patch by patch on their own); False: always patch by patch - same draws, same batches.
 
     prefetch (0 | n): n > 0 starts a producer thread with a HIP stream of its own that keeps up to n batches ready (the role of Keras'
     GeneratorEnqueuer behind the reference's fit_generator, training.py:110-124).  A patch is 12-25 short gather / element-wise launches
@@ -276,6 +384,7 @@ def device_data_generator(data_file, index_list, batch_size=1, n_labels=1, label
     ddf = data_file if isinstance(data_file, DeviceDataFile) else DeviceDataFile(data_file, patch_shape, samples_pad, truth_downsample,
                                                                                  indices=sorted(set(index_list)), device=device)
     sampler = _Sampler(ddf, patch_shape, augment, truth_index, truth_size, prev_truth_index, prev_truth_size, strict, noise_seed)
+    sampler.batched = bool(batched)
     index_generator = random_list_generator(index_list) if shuffle_index_list else list_generator(index_list)
     ps = sampler.patch_shape
 
@@ -284,16 +393,31 @@ def device_data_generator(data_file, index_list, batch_size=1, n_labels=1, label
         y = torch.empty((batch_size, ps[0], ps[1], truth_size), device=ddf.device, dtype=torch.uint8)
         m = torch.empty((batch_size, ps[0], ps[1], truth_size), device=ddf.device, dtype=torch.float32) if ddf.mask is not None else None
         filled = 0
-        while filled < batch_size:
+        while filled < batch_size and drop_easy_patches:
+            # the keep / drop draw of a patch comes from numpy's stream BETWEEN its draws and the next patch's: patch by patch, as the reference
             index = next(index_generator)
             sampler.sample_into(index, x[filled], y[filled], None if m is None else m[filled])
-            if drop_easy_patches:
-                truth_mean = float(y[filled][16:-16, 16:-16, :].float().mean().item())
-                if 1 - np.abs(truth_mean - 0.5) < np.random.random():
-                    continue
+            truth_mean = float(y[filled][16:-16, 16:-16, :].float().mean().item())
+            if 1 - np.abs(truth_mean - 0.5) < np.random.random():
+                continue
             if skip_blank and not bool(y[filled].any().item()):
                 continue
             filled += 1
+        while filled < batch_size:
+            # the patches still missing, planned in the reference's draw order and launched together; blank ones (skip_blank) are dropped behind
+            # ONE read-back, the kept ones move up in order and the next round plans the rest: the same patches in the same slots as one by one
+            need = batch_size - filled
+            plans = [sampler.plan(next(index_generator)) for _ in range(need)]
+            sampler.launch(plans, x[filled:], y[filled:], None if m is None else m[filled:])
+            keep = list(range(need))
+            if skip_blank:
+                keep = [i for i, f in enumerate(y[filled:].reshape(need, -1).any(dim=1).tolist()) if f]
+            for dst, src in enumerate(keep):
+                if dst != src:
+                    for t in (x, y, m):
+                        if t is not None:
+                            t[filled + dst].copy_(t[filled + src])
+            filled += len(keep)
         yy = y
         if categorical:
             # keras.utils.to_categorical(y, 2) (reference generator.py:390-391): a trailing axis of size 1 is dropped before the one-hot

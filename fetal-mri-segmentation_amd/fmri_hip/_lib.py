@@ -102,12 +102,14 @@ SIGNATURES = {
     "fmri_correlate1d_f32": [p, p, i32, i32, i32, i32, p, i32, i32, p],
     "fmri_elastic_warp": [p, i32, i32, i32, i32, i32, p, p, i32, p, i32, p],
     "fmri_coarse_dropout": [p, i32, i32, i32, i32, i32, p, i32, i32, i32, p, p],
-    "fmri_minmax_ws": [p, i64, i32, p, p, p],
-    "fmri_rescale_intensity_ws": [p, i64, i32, p, p, i32, f32, f32, f32, p],
-    "fmri_noise_rng": [p, i64, i32, p, p, i32, f32, u64, u32, p],
-    "fmri_shot_noise_rng": [p, i64, i32, p, p, u64, u32, p],
-    "fmri_elastic_fields_rng": [p, p, i32, i32, i32, p, f32, u64, u32, p],
-    "fmri_coarse_dropout_rng": [p, i32, i32, i32, i32, i32, i32, i32, i32, f32, p, u64, u32, p],
+    "fmri_affine_sample_batch": [i32, p, p, p, p, p, i32, i32, i32, i32, i32, p, i32, i32, i64, p],
+    "fmri_minmax_ws_batch": [p, i64, i64, i32, i32, p, p, p],
+    "fmri_rescale_intensity_ws_batch": [p, i64, i64, i32, i32, p, p, p, p],
+    "fmri_noise_rng_batch": [p, i64, i64, i32, i32, p, p, i32, f32, u64, p, p],
+    "fmri_shot_noise_rng_batch": [p, i64, i64, i32, i32, p, p, u64, p, p],
+    "fmri_elastic_fields_rng_batch": [p, i32, i32, i32, p, p, u64, p, i32, p],
+    "fmri_elastic_warp_batch": [p, i32, i32, i32, i32, i32, i64, p, i32, p, i32, i64, i32, p],
+    "fmri_coarse_dropout_rng_batch": [p, i32, i32, i32, i32, i32, i64, i32, p, i32, f32, p, u64, p, p],
     "fmri_piecewise_affine2": [p, i32, i32, i32, i32, i32, p, i32, p, i32, p],
     "fmri_avgpool3d_2x_fwd": [p, p, i32, i32, i32, i32, i32, i32, i32, p],
     "fmri_avgpool3d_2x_bwd": [p, p, i32, i32, i32, i32, i32, i32, i32, p],

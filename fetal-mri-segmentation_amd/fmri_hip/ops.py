@@ -833,16 +833,9 @@ def _elastic_kernel(k, sigma, device):
 
 
 def elastic_fields_rng(shape2d, alpha, sigma, seed, seq, device="cuda"):
-    """elastic_fields with the noise drawn in the kernel (fmri_elastic_fields_rng: one launch); kernel widths above ELASTIC_RNG_KMAX (sigma >= 12)
-    are not covered - callers use elastic_fields there"""
-    X, Y = int(shape2d[0]), int(shape2d[1])
-    k = elastic_ksize(float(sigma))
-    assert k <= ELASTIC_RNG_KMAX
-    wd = _elastic_kernel(k, sigma, device)
-    d = torch.empty((2, X, Y), device=wd.device, dtype=torch.float32)
-    check(lib().fmri_elastic_fields_rng(_p(d[0]), _p(d[1]), X, Y, k, _p(wd), float(alpha), int(seed) & (2 ** 64 - 1), int(seq) & 0xffffffff, _s()),
-          "fmri_elastic_fields_rng")
-    return d[0], d[1]
+    """elastic_fields with the noise drawn in the kernel, one patch (see elastic_fields_rng_batch) -> (d0, d1)"""
+    d = elastic_fields_rng_batch(shape2d, [alpha], sigma, seed, [seq], device=device)
+    return d[0, 0], d[0, 1]
 
 
 def elastic_fields(shape2d, alpha, sigma, generator=None, noise=None):
@@ -928,51 +921,162 @@ def coarse_dropout(x, keep, stats, per_channel=True):
 
 
 AUG_WS_INTS = 1568        # FMRI_AUG_WS_INTS
+_U64 = 2 ** 64 - 1
 
 
-def aug_workspace(device):
-    """(stats, ws) for the *_rng intensity steps: 2 floats and the zeroed int32 workspace they keep re-armed; one pair per stream of calls"""
-    return torch.zeros(2, device=device, dtype=torch.float32), torch.zeros(AUG_WS_INTS, device=device, dtype=torch.int32)
+def aug_workspace(device, batch=1):
+    """(stats, ws) for the *_rng intensity steps: [batch][2] floats and the zeroed int32 workspaces they keep re-armed; one pair per stream of
+    calls.  The single-patch wrappers below take row 0 of a batch-1 workspace as (stats, ws)."""
+    stats = torch.zeros((batch, 2), device=device, dtype=torch.float32)
+    ws = torch.zeros((batch, AUG_WS_INTS), device=device, dtype=torch.int32)
+    return (stats[0], ws[0]) if batch == 1 else (stats, ws)
 
 
+def _batch_geometry(xb):
+    """xb: (B, ...) device tensor whose patches are dense and equally spaced -> (B, elements per patch, stride in elements)"""
+    B = xb.shape[0]
+    n = xb[0].numel()
+    assert xb.is_cuda and xb[0].is_contiguous() and (B == 1 or xb.stride(0) >= n)
+    return B, n, (xb.stride(0) if B > 1 else n)
+
+
+def _seqs(seqs):
+    import numpy as np
+    a = np.ascontiguousarray(seqs, dtype=np.uint32)
+    return a, a.ctypes.data
+
+
+def minmax_ws_batch(xb, stats, ws):
+    """stats[b] = {min, max} of xb[b], all patches in one launch (fmri_minmax_ws_batch)"""
+    _need_cuda(stats, ws)
+    B, n, stride = _batch_geometry(xb)
+    check(lib().fmri_minmax_ws_batch(_p(xb), n, stride, B, dt(xb), _p(stats), _p(ws), _s()), "fmri_minmax_ws_batch")
+    return stats
+
+
+def rescale_intensity_ws_batch(xb, stats, ws, params):
+    """params: (B, 4) rows {mode, lo, hi, mult}, mode 0 skip / 1 multiply / 2 contrast + multiply; stats[b] updated"""
+    import numpy as np
+    _need_cuda(stats, ws)
+    B, n, stride = _batch_geometry(xb)
+    a = np.ascontiguousarray(params, dtype=np.float32)
+    assert a.shape == (B, 4)
+    check(lib().fmri_rescale_intensity_ws_batch(_p(xb), n, stride, B, dt(xb), _p(stats), _p(ws), a.ctypes.data, _s()), "fmri_rescale_intensity_ws_batch")
+    return xb
+
+
+def noise_rng_batch(xb, stats, ws, kind, sigma, seed, seqs):
+    """gaussian (kind 0) / speckle (1) noise in place on every patch with seqs[b] != 0, the normal draws in the kernel; stats[b] updated"""
+    _need_cuda(stats, ws)
+    B, n, stride = _batch_geometry(xb)
+    a, ap = _seqs(seqs)
+    assert a.shape == (B,)
+    check(lib().fmri_noise_rng_batch(_p(xb), n, stride, B, dt(xb), _p(stats), _p(ws), int(kind), float(sigma), int(seed) & _U64, ap, _s()),
+          "fmri_noise_rng_batch")
+    return xb
+
+
+def shot_noise_rng_batch(xb, stats, ws, seed, seqs):
+    """reference augment.py:87-94 in place on every patch with seqs[b] != 0, the Poisson draws in the kernel; stats[b] updated"""
+    _need_cuda(stats, ws)
+    B, n, stride = _batch_geometry(xb)
+    a, ap = _seqs(seqs)
+    assert a.shape == (B,)
+    check(lib().fmri_shot_noise_rng_batch(_p(xb), n, stride, B, dt(xb), _p(stats), _p(ws), int(seed) & _U64, ap, _s()), "fmri_shot_noise_rng_batch")
+    return xb
+
+
+def coarse_dropout_rng_batch(xb, grids, rate, stats, per_channel, seed, seqs):
+    """coarse dropout in place on xb (B, X, Y, C); grids: (B, 2) keep-grid sizes (per slice when per_channel), drawn in the kernel"""
+    import numpy as np
+    _need_cuda(stats)
+    B, X, Y, C = xb.shape
+    assert xb.is_cuda and xb.stride(3) == 1 and xb.stride(1) == Y * xb.stride(2)
+    g = np.ascontiguousarray(grids, dtype=np.int32)
+    a, ap = _seqs(seqs)
+    assert g.shape == (B, 2) and a.shape == (B,)
+    check(lib().fmri_coarse_dropout_rng_batch(_p(xb), dt(xb), X, Y, C, int(xb.stride(2)), int(xb.stride(0)), B, g.ctypes.data, C if per_channel else 1,
+                                              float(rate), _p(stats), int(seed) & _U64, ap, _s()), "fmri_coarse_dropout_rng_batch")
+    return xb
+
+
+def affine_sample_batch(vols, affines, corners, size, out, order, cvals):
+    """out[b] (dense (nx, ny, nz) patches, equally spaced) = vols[b] sampled at affines[b] . (corners[b] + (i, j, k), 1): fmri_affine_sample for the
+    patches of a batch in one launch.  vols: device tensors of one dtype (float32 or uint8), each (X, Y, Z) contiguous; affines (B, 4, 4) or (B, 3, 4)"""
+    import ctypes
+    import numpy as np
+    B = len(vols)
+    nx, ny, nz = (int(v) for v in size)
+    assert out.is_cuda and tuple(out.shape) == (B, nx, ny, nz) and out[0].is_contiguous()
+    for v in vols:
+        if not v.is_cuda or not v.is_contiguous() or v.dtype != vols[0].dtype or v.dim() != 3:
+            raise RuntimeError("fmri_hip ops need contiguous device volumes of one dtype")
+    ptrs = (ctypes.c_void_p * B)(*[v.data_ptr() for v in vols])
+    dims = np.ascontiguousarray([v.shape for v in vols], dtype=np.int32)
+    A = np.ascontiguousarray(np.asarray(affines, dtype=np.float64)[:, :3, :4])
+    cr = np.ascontiguousarray(corners, dtype=np.int32)
+    cv = np.ascontiguousarray(cvals, dtype=np.float32)
+    assert A.shape == (B, 3, 4) and cr.shape == (B, 3) and cv.shape == (B,)
+    check(lib().fmri_affine_sample_batch(B, ctypes.cast(ptrs, ctypes.c_void_p), dims.ctypes.data, A.ctypes.data, cr.ctypes.data, cv.ctypes.data,
+                                         _dt_any(vols[0]), nx, ny, nz, int(order), _p(out), _dt_any(out), nz, int(out.stride(0)), _s()),
+          "fmri_affine_sample_batch")
+    return out
+
+
+def elastic_fields_rng_batch(shape2d, alphas, sigma, seed, seqs, device="cuda"):
+    """-> d (B, 2, X, Y) fp32: d[b, 0] = shift along axis 0, d[b, 1] along axis 1 (ops.elastic_fields' (d0, d1)), the noise drawn in the kernel
+    (fmri_elastic_fields_rng_batch: one launch); seqs[b] == 0 -> zero fields.  Kernel widths above ELASTIC_RNG_KMAX (sigma >= 12) are not
+    covered - callers use elastic_fields there"""
+    import numpy as np
+    X, Y = int(shape2d[0]), int(shape2d[1])
+    k = elastic_ksize(float(sigma))
+    assert k <= ELASTIC_RNG_KMAX
+    wd = _elastic_kernel(k, sigma, device)
+    al = np.ascontiguousarray(alphas, dtype=np.float32)
+    a, ap = _seqs(seqs)
+    B = al.shape[0]
+    assert a.shape == (B,)
+    d = torch.empty((B, 2, X, Y), device=wd.device, dtype=torch.float32)
+    check(lib().fmri_elastic_fields_rng_batch(_p(d), X, Y, k, _p(wd), al.ctypes.data, int(seed) & _U64, ap, B, _s()), "fmri_elastic_fields_rng_batch")
+    return d
+
+
+def elastic_warp_batch(src, d, order, out):
+    """out[b] = src[b] warped by the fields d[b] (elastic_fields_rng_batch); src, out: (B, X, Y, C) float32 or uint8, patches dense / equally spaced"""
+    _need_cuda(d)
+    B, X, Y, C = src.shape
+    assert src.is_cuda and out.is_cuda and tuple(out.shape) == (B, X, Y, C) and out.dtype == src.dtype and tuple(d.shape) == (B, 2, X, Y)
+    assert d.is_contiguous() and d.dtype == torch.float32
+    for t in (src, out):
+        assert t.stride(3) == 1 and t.stride(1) == Y * t.stride(2), "rows of equal length, channels contiguous"
+    check(lib().fmri_elastic_warp_batch(_p(src), _dt_any(src), X, Y, C, int(src.stride(2)), int(src.stride(0)), _p(d), int(order), _p(out),
+                                        int(out.stride(2)), int(out.stride(0)), B, _s()), "fmri_elastic_warp_batch")
+    return out
+
+
+# one patch = a batch of one (tests; the generator's per-patch path)
 def minmax_ws(x, stats, ws):
-    """stats = {min, max} of x in one launch (fmri_minmax_ws)"""
-    _need_cuda(x, stats, ws)
-    check(lib().fmri_minmax_ws(_p(x), x.numel(), dt(x), _p(stats), _p(ws), _s()), "fmri_minmax_ws")
+    minmax_ws_batch(x.unsqueeze(0), stats, ws)
     return stats
 
 
 def rescale_intensity_ws(x, stats, ws, contrast, lo=0.0, hi=0.0, mult=1.0):
-    """rescale_intensity that leaves the new min / max in stats"""
-    _need_cuda(x, stats, ws)
-    check(lib().fmri_rescale_intensity_ws(_p(x), x.numel(), dt(x), _p(stats), _p(ws), 1 if contrast else 0, float(lo), float(hi), float(mult), _s()),
-          "fmri_rescale_intensity_ws")
+    rescale_intensity_ws_batch(x.unsqueeze(0), stats, ws, [[2 if contrast else 1, lo, hi, mult]])
     return x
 
 
 def noise_rng(x, stats, ws, kind, sigma, seed, seq):
-    """gaussian (kind 0) / speckle (1) noise in place, the normal draws in the kernel; stats: in = min / max of x, out = of the new x"""
-    _need_cuda(x, stats, ws)
-    check(lib().fmri_noise_rng(_p(x), x.numel(), dt(x), _p(stats), _p(ws), int(kind), float(sigma), int(seed) & (2 ** 64 - 1), int(seq) & 0xffffffff,
-                               _s()), "fmri_noise_rng")
+    noise_rng_batch(x.unsqueeze(0), stats, ws, kind, sigma, seed, [seq])
     return x
 
 
 def shot_noise_rng(x, stats, ws, seed, seq):
-    """reference augment.py:87-94 in place, the Poisson draws in the kernel; stats: in = min / max of x, out = of the new x"""
-    _need_cuda(x, stats, ws)
-    check(lib().fmri_shot_noise_rng(_p(x), x.numel(), dt(x), _p(stats), _p(ws), int(seed) & (2 ** 64 - 1), int(seq) & 0xffffffff, _s()),
-          "fmri_shot_noise_rng")
+    shot_noise_rng_batch(x.unsqueeze(0), stats, ws, seed, [seq])
     return x
 
 
 def coarse_dropout_rng(x, grid, rate, stats, per_channel, seed, seq):
-    """coarse dropout in place on x (X, Y, C), the (hs, ws) keep grid (per slice when per_channel) drawn in the kernel"""
-    _need_cuda(stats)
-    X, Y, C = x.shape
-    assert x.is_cuda and x.stride(2) == 1 and x.stride(0) == Y * x.stride(1)
-    check(lib().fmri_coarse_dropout_rng(_p(x), dt(x), X, Y, C, int(x.stride(1)), int(grid[0]), int(grid[1]), C if per_channel else 1, float(rate),
-                                        _p(stats), int(seed) & (2 ** 64 - 1), int(seq) & 0xffffffff, _s()), "fmri_coarse_dropout_rng")
+    coarse_dropout_rng_batch(x.unsqueeze(0), [[int(grid[0]), int(grid[1])]], rate, stats, per_channel, seed, [seq])
     return x
 
 

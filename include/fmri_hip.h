@@ -378,36 +378,50 @@ int fmri_piecewise_affine2(const void* src, int dtype, int X, int Y, int C, int 
  * stats = fmri_minmax of x before the call.  In place; dtype FMRI_F32 or FMRI_BF16. */
 int fmri_coarse_dropout(void* x, int dtype, int X, int Y, int C, int ld, const uint8_t* keep, int hs, int ws, int kc, const float* stats,
                         fmri_stream_t stream);
-/* ---- the same intensity steps with the random draws made IN the kernel (Philox4x32-10 keyed by `seed`, counter = (element or grid-cell index,
- * `seq`, rejection round): the result depends on (seed, seq) only, not on the launch geometry) and the min / max chained: each call reads
- * stats = {min, max} of x as it is, and - when it rewrites x - leaves the min / max of the NEW x there for the next step.  A training patch
- * of the reference's default config (fetal/config_utils.py:81-123: shot noise, speckle / gaussian noise with probability 1/2 each, coarse
- * dropout; reference fetal_net/augment.py:354-375) is then fmri_minmax_ws + 1 + 2 + 1 + 1 + 1 launches instead of ~35 with the draws taken from
- * torch's generator (tools/r05/prof_generator.py).  The fed-draw forms above stay: the parity tests hand them the oracle's own draws.
- * ws: device int32 [FMRI_AUG_WS_INTS], zeroed ONCE by the caller; every call leaves it zeroed.  One ws per stream of calls. */
+/* ---- the same intensity steps with the random draws made IN the kernel and over the B patches of a batch in ONE launch.
+ * Draws: Philox4x32-10 keyed by `seed`, counter = (element or grid-cell index, seqs[b], rejection round) - the result depends on (seed,
+ * seqs[b]) only, not on the launch geometry or on B; seqs[b] == 0 means "patch b skips this step".  Min / max chained: each call reads
+ * stats[b] = {min, max} of patch b as it is and - when it rewrites the patch - leaves the min / max of the NEW values there for the next
+ * step.  Patch b: x + b * stride elements; stats: device float [B][2]; ws: device int32 [B][FMRI_AUG_WS_INTS], zeroed ONCE by the caller
+ * (every call leaves it zeroed; one ws per stream of calls).  seqs, params, grids, alphas: HOST arrays, read at enqueue.
+ * A training batch of the reference's default config (fetal/config_utils.py:81-123: contrast, shot noise, speckle / gaussian noise with
+ * probability 1/2 each, elastic transform, coarse dropout; reference fetal_net/augment.py:344-375) is 13 launches for the whole batch
+ * instead of ~35 per patch with the draws taken from torch's generator (tools/r05/prof_generator.py).  The fed-draw forms above stay: the
+ * parity tests hand them the oracle's own draws. */
 #define FMRI_AUG_WS_INTS 1568
-/* stats (2 floats, device) = {min, max} of x[0..n): fmri_minmax in ONE launch (the last workgroup to finish decodes and re-arms ws) */
-int fmri_minmax_ws(const void* x, int64_t n, int dtype, float* stats, int* ws, fmri_stream_t stream);
-/* fmri_rescale_intensity (reference augment.py:125-128, :351-352) that also leaves the min / max of the rescaled x in stats */
-int fmri_rescale_intensity_ws(void* x, int64_t n, int dtype, float* stats, int* ws, int contrast, float lo, float hi, float mult,
-                              fmri_stream_t stream);
-/* fmri_noise_augment with N(0,1) draws by Box-Muller; kind 0 gaussian, 1 speckle (reference augment.py:99-110). In place; updates stats. */
-int fmri_noise_rng(void* x, int64_t n, int dtype, float* stats, int* ws, int kind, float sigma, uint64_t seed, uint32_t seq,
-                   fmri_stream_t stream);
+/* fmri_affine_sample for B patches: patch b reads vols[b] (extent dims[3b..], all of vol_dtype) at affines[12b..] . (corners[3b..] + (i, j, k), 1)
+ * with outside value cvals[b] and lands at out + b * out_stride elements.  vols: HOST array of device pointers. */
+int fmri_affine_sample_batch(int B, const void* const* vols, const int* dims, const double* affines, const int* corners, const float* cvals,
+                             int vol_dtype, int nx, int ny, int nz, int order, void* out, int out_dtype, int out_ld, int64_t out_stride,
+                             fmri_stream_t stream);
+/* stats[b] = {min, max} of patch b: fmri_minmax in ONE launch for all patches (the last workgroup of a patch decodes and re-arms ws[b]) */
+int fmri_minmax_ws_batch(const void* x, int64_t n, int64_t stride, int B, int dtype, float* stats, int* ws, fmri_stream_t stream);
+/* fmri_rescale_intensity (reference augment.py:125-128, :351-352) per patch; params[b] = {mode, lo, hi, mult}: mode 0 skip, 1 multiply by
+ * mult only, 2 contrast to [lo, hi] then multiply.  Updates stats[b]. */
+int fmri_rescale_intensity_ws_batch(void* x, int64_t n, int64_t stride, int B, int dtype, float* stats, int* ws, const float* params,
+                                    fmri_stream_t stream);
+/* fmri_noise_augment with N(0,1) draws by Box-Muller; kind 0 gaussian, 1 speckle (reference augment.py:99-110). In place; updates stats[b]. */
+int fmri_noise_rng_batch(void* x, int64_t n, int64_t stride, int B, int dtype, float* stats, int* ws, int kind, float sigma, uint64_t seed,
+                         const uint32_t* seqs, fmri_stream_t stream);
 /* fmri_shot_noise_step phases 0-2 (reference augment.py:87-94) in two launches, the Poisson draws as numpy's legacy sampler makes them
- * (lam < 10: product of uniforms; else Hoermann's PTRS) - what np.random.poisson runs under skimage's random_noise. In place; updates stats. */
-int fmri_shot_noise_rng(void* x, int64_t n, int dtype, float* stats, int* ws, uint64_t seed, uint32_t seq, fmri_stream_t stream);
+ * (lam < 10: product of uniforms; else Hoermann's PTRS) - what np.random.poisson runs under skimage's random_noise. Updates stats[b]. */
+int fmri_shot_noise_rng_batch(void* x, int64_t n, int64_t stride, int B, int dtype, float* stats, int* ws, uint64_t seed, const uint32_t* seqs,
+                              fmri_stream_t stream);
 /* imgaug ElasticTransformation's displacement fields (reference augment.py:149-170 -> imgaug 0.4.0 _generate_shift_maps) in one launch:
  * uniform(-1, 1) noise on the image padded by k on every side, blurred with the k-tap kernel `weights` (device, fp64 [k], normalised; k odd,
- * <= 31) along both axes, times alpha, padding cropped.  d0 (shift along axis 0, imgaug's dy), d1 (axis 1, dx): fp32 [X][Y] on the device.
- * Noise pixel p of the padded (2, X + 2k, Y + 2k) grid (block 0 = dx) = 2 * u - 1 with u = (word (p & 3) of Philox(p >> 2, 0, seq, 1)) >> 8) / 2^24. */
-int fmri_elastic_fields_rng(float* d0, float* d1, int X, int Y, int k, const double* weights, float alpha, uint64_t seed, uint32_t seq,
-                            fmri_stream_t stream);
-/* fmri_coarse_dropout with the keep grid drawn in the kernel: cell (si, sj[, c]) of the hs x ws_ (x kc) grid is dropped when its uniform
- * draw is < rate (imgaug CoarseDropout(p=rate); reference augment.py:116-120).  stats = min / max of x; not rewritten (the dropped
- * voxels take the minimum). */
-int fmri_coarse_dropout_rng(void* x, int dtype, int X, int Y, int C, int ld, int hs, int ws_, int kc, float rate, const float* stats,
-                            uint64_t seed, uint32_t seq, fmri_stream_t stream);
+ * <= 31) along both axes, times alphas[b], padding cropped.  d: device fp32 [B][2][X][Y]; d[b][0] = shift along axis 0 (imgaug's dy), d[b][1]
+ * = along axis 1 (dx); a patch with seqs[b] == 0 gets zero fields.  Noise pixel p of the padded (2, X + 2k, Y + 2k) grid (block 0 = dx)
+ * = 2 u - 1 with u = (word (p & 3) of Philox(p >> 2, 0, seqs[b], 1) >> 8) / 2^24. */
+int fmri_elastic_fields_rng_batch(float* d, int X, int Y, int k, const double* weights, const float* alphas, uint64_t seed, const uint32_t* seqs,
+                                  int B, fmri_stream_t stream);
+/* fmri_elastic_warp for B patches with the fields of fmri_elastic_fields_rng_batch: patch b = src + b * src_stride -> dst + b * dst_stride */
+int fmri_elastic_warp_batch(const void* src, int dtype, int X, int Y, int C, int src_ld, int64_t src_stride, const float* d, int order, void* dst,
+                            int dst_ld, int64_t dst_stride, int B, fmri_stream_t stream);
+/* fmri_coarse_dropout with the keep grid drawn in the kernel: cell (si, sj[, c]) of patch b's grids[2b] x grids[2b+1] (x kc) grid is dropped
+ * when its uniform draw is < rate (imgaug CoarseDropout(p=rate); reference augment.py:116-120).  stats[b] = min / max of the patch; not
+ * rewritten (the dropped voxels take the minimum). */
+int fmri_coarse_dropout_rng_batch(void* x, int dtype, int X, int Y, int C, int ld, int64_t stride, int B, const int* grids, int kc, float rate,
+                                  const float* stats, uint64_t seed, const uint32_t* seqs, fmri_stream_t stream);
 /* one axis of skimage.filters.gaussian on an fp32 patch [X][Y][Z] (reference augment.py:113-114): weights fp64 [2*radius+1] on the device,
  * sums in fp64 in scipy's order, result rounded to fp32; mode 0 = 'reflect', 1 = 'nearest' (skimage's default).  src != dst. */
 int fmri_correlate1d_f32(const float* src, float* dst, int X, int Y, int Z, int axis, const double* weights, int radius, int mode,

@@ -325,13 +325,14 @@ def test_coarse_dropout_vs_oracle(ops, per_channel):
     assert 0.05 < dropped.mean() < 0.45 and np.array_equal(got[~dropped], img[~dropped])       # kept voxels are untouched, bit for bit
 
 
-def test_device_generator_prefetch_on_its_own_stream_yields_the_same_batches():
-    """prefetch=2 (a producer thread with a stream of its own keeps two batches ready) against prefetch=0 (inline): same host and device
-    draws in the same order - every batch bit for bit, with the reference's default augmentation on, skip_blank's read-backs included,
-    and with a consumer that reads on a stream of its own.  (shuffle off: the shuffling index generator re-seeds numpy from the OS on
-    every pass, as the reference's does.)"""
+@pytest.mark.parametrize("masks", [False, True])
+def test_device_generator_batched_launches_and_prefetch_thread_yield_the_same_batches(masks):
+    """three ways to the same batches, bit for bit: patch by patch (batched=False: the form every other test of this file checks against the
+    oracle and the reference's fixtures), the patches of a batch launched together (the default), and that with a producer thread on a stream of
+    its own keeping two batches ready (prefetch=2) while the consumer reads on alternating streams.  The reference's default augmentation is on;
+    the second volume's labels are almost empty, so skip_blank's read-back drops patches and the kept ones move up.  (shuffle off: the shuffling
+    index generator re-seeds numpy from the OS on every pass, as the reference's does.)"""
     import threading
-    import torch
     from fetal_net.device_generator import device_data_generator
     default = {"flip": [0.5, 0.5, 0.5], "permute": False, "translate": (15, 15, 7), "scale": (0.1, 0.1, 0), "rotate": (0, 0, 90), "poisson_noise": 1,
                "gaussian_filter": {"prob": 0.0, "max_sigma": 1}, "contrast": {"prob": 0, "min_factor": 0.2, "max_factor": 0.1},
@@ -339,26 +340,50 @@ def test_device_generator_prefetch_on_its_own_stream_yields_the_same_batches():
                "coarse_dropout": {"rate": 0.2, "size_percent": [0.10, 0.30], "per_channel": True},
                "gaussian_noise": {"prob": 0.5, "sigma": 0.05}, "speckle_noise": {"prob": 0.5, "sigma": 0.05}}
     vols, truths = synth_volumes(3, [(72, 72, 40), (64, 80, 36)])
-    df = FakeDataFile(vols, truths)
-    runs = []
-    for prefetch in (0, 2):
+    truths[1][:] = 0
+    truths[1][20:30, 30:44, 10:20] = 1                                  # most patches of volume 1 are blank
+    mk = [np.random.RandomState(4).rand(*t.shape).astype(np.float32) for t in truths] if masks else None
+    df = FakeDataFile(vols, truths, mk)
+    runs, dropped = [], 0
+    for batched, prefetch in ((False, 0), (True, 0), (True, 2)):
         np.random.seed(11)
         random.seed(11)
-        gen = device_data_generator(df, [0, 1], batch_size=2, augment=default, patch_shape=(48, 48, 16), skip_blank=True, categorical=True, is3d=True,
-                                    truth_index=0, truth_size=16, noise_seed=3, prefetch=prefetch, shuffle_index_list=False)
+        gen = device_data_generator(df, [0, 1], batch_size=3, augment=default, patch_shape=(48, 48, 16), skip_blank=True, categorical=True, is3d=True,
+                                    truth_index=0, truth_size=16, noise_seed=3, prefetch=prefetch, batched=batched, shuffle_index_list=False)
         got = []
         reader = torch.cuda.Stream()
         for k in range(4):
             with torch.cuda.stream(reader if k % 2 else torch.cuda.current_stream()):
                 x, y = next(gen)
-                got.append((x.clone(), y.clone()))
+                got.append([t.clone() for t in (x if masks else [x])] + [y.clone()])
         torch.cuda.synchronize()
         gen.close()                                                      # stops and joins the producer thread
         assert not [t for t in threading.enumerate() if t.name == "device_data_generator"]
-        runs.append([(x.cpu().numpy(), y.cpu().numpy()) for x, y in got])
-    for (x0, y0), (x1, y1) in zip(*runs):
-        assert np.array_equal(x0, x1) and np.array_equal(y0, y1)
+        runs.append([[t.cpu().numpy() for t in b] for b in got])
+    for variant in runs[1:]:
+        for b0, b1 in zip(runs[0], variant):
+            assert len(b0) == len(b1) == (3 if masks else 2)
+            for t0, t1 in zip(b0, b1):
+                assert t0.shape == t1.shape and np.array_equal(t0, t1)
     assert not np.array_equal(runs[0][0][0], runs[0][1][0])
+    assert all(b[-1].reshape(3, -1, 2)[..., 1].any(axis=1).all() for b in runs[0])      # no blank patch was kept
+
+
+def test_device_generator_without_augmentation_batched_equals_patch_by_patch():
+    from fetal_net.device_generator import device_data_generator
+    vols, truths = synth_volumes(5, [(40, 44, 24), (36, 50, 30)])
+    mk = [np.random.RandomState(4).rand(*t.shape).astype(np.float32) for t in truths]
+    df = FakeDataFile(vols, truths, mk)
+    outs = []
+    for batched in (False, True):
+        np.random.seed(2)
+        random.seed(2)
+        gen = device_data_generator(df, [0, 1], batch_size=5, augment=None, patch_shape=(32, 32, 8), skip_blank=False, categorical=False, is3d=False,
+                                    truth_index=3, truth_size=2, batched=batched, shuffle_index_list=False)
+        (x, m), y = next(gen)
+        outs.append([t.cpu().numpy() for t in (x, m, y)])
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)
 
 
 def test_device_generator_runs_the_reference_default_augmentation_without_warnings():
