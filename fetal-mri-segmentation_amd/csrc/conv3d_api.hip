@@ -413,6 +413,16 @@ extern "C" int fmri_conv3d_upcat_dgrad(const void* dy, int Cout, const void* w_u
                                        fmri_stream_t stream) {
     return upcat_dgrad(dy, Cout, w_up_dgrad, w_skip_dgrad, mask_low, mask_skip, dx_low, dx_skip, N, D, H, W, C0, C1, dtype, 0, stream);
 }
+// Conv3D(3x3x3, strides 2, 'same' on even dims) forward on the gather launch above (fmri_hip/strided_parity.py: the filter's 27 taps in 27 of
+// the 64 (parity, block offset) slots), with the conv's own fp32 bias in the accumulators like every other forward launch
+extern "C" int fmri_conv3d_stride2_fwd(const void* x, int Cin, const void* w_s2_fwd, const float* bias, void* y, int N, int D, int H, int W, int Cout,
+                                       int dtype, fmri_stream_t stream) {
+    if (!x || !w_s2_fwd || !y || N <= 0) return FMRI_E_SHAPE;
+    if (!(upcat_ok(Cout, 0, Cin, D, H, W, dtype, 0) & 1)) return FMRI_E_SHAPE;
+    if ((((uintptr_t)x) | ((uintptr_t)w_s2_fwd) | ((uintptr_t)y) | ((uintptr_t)bias)) & 15) return FMRI_E_ALIGN;
+    return conv3d_fwd_mfma_ex(2, x, Cin, 0, 0, nullptr, 0, w_s2_fwd, bias, nullptr, nullptr, y, N, D / 2, H / 2, W / 2, Cout, FMRI_ACT_NONE, 0.f,
+                              as_stream(stream));
+}
 extern "C" int fmri_conv3d_upcat_wgrad(const void* src0_low, int C0, const void* src1, int C1, const void* dy, float* dw, float* db,
                                        float* dwc_scratch, int N, int D, int H, int W, int Cout, int dtype, void* workspace,
                                        int64_t workspace_bytes, fmri_stream_t stream) {

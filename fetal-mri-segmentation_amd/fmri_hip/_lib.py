@@ -86,6 +86,7 @@ SIGNATURES = {
     "fmri_conv3d_pack_up_weights": [p, i32, i32, i32, p, p, p, p, i32, p],
     "fmri_conv3d_upcat_fwd": [p, i32, p, i32, p, p, p, p, i32, i32, i32, i32, i32, i32, f32, i32, p],
     "fmri_conv3d_upcat_dgrad": [p, i32, p, p, p, p, p, p, i32, i32, i32, i32, i32, i32, i32, p],
+    "fmri_conv3d_stride2_fwd": [p, i32, p, p, p, i32, i32, i32, i32, i32, i32, p],
     "fmri_conv3d_upcat_wgrad": [p, i32, p, i32, p, p, p, p, i32, i32, i32, i32, i32, i32, p, i64, p],
     "fmri_conv2d_upcat_ok": [i32, i32, i32, i32, i32, i32, i32],
     "fmri_conv2d_pack_up_weights": [p, i32, i32, i32, p, p, p, p, i32, p],

@@ -346,11 +346,6 @@ class LayerGraphEngine(object):
             for name, op in self.convs.items():
                 if op.get("sub") != (2, 2, 2) or op["k"] != 3 or op["act"] != ACT_NONE or len(op["ins"]) != 1:
                     continue
-                # the bias of this form is a bf16 tensor added in a second pass (two roundings): harmless only where a normalisation layer
-                # consumes the output and removes a per-channel constant - every other strided conv keeps the kernel-epilogue bias
-                readers = [o2 for o2 in self.ops if op["out"] in o2.get("ins", ())]
-                if not readers or any(o2["kind"] != "norm" for o2 in readers):
-                    continue
                 coutp, cinp = self.shape[name][0], self.Wp32[name].shape[2]
                 fine = tuple(self.shape[op["ins"][0]][1:])
                 if any(d % 2 for d in fine) or self._is_input(op["ins"]):
@@ -362,7 +357,7 @@ class LayerGraphEngine(object):
                         self._s2 = StridedParity(dev)
                     self.Ws2[name] = dict(fwd=torch.zeros((8, 8, coutp, cinp), dtype=self.dtype, device=dev),
                                           dgrad=torch.zeros((8, 8, cinp, coutp), dtype=self.dtype, device=dev) if self.training else None,
-                                          wgrad=bool(ok & 2) and self.training, bias=torch.zeros(coutp, dtype=self.dtype, device=dev))
+                                          wgrad=bool(ok & 2) and self.training)
                     if self.Ws2[name]["wgrad"]:
                         self.Ws2[name].update(dw27=torch.zeros((27, cinp, coutp), dtype=f32, device=dev), db=torch.zeros(cinp, dtype=f32, device=dev))
         # UpSampling3D -> Conv3D (reference isensee2017.py:101-104): parity form, 8 pre-summed 2x2x2 filters on the low-res tensor
@@ -485,7 +480,6 @@ class LayerGraphEngine(object):
                 if name in self.Ws2:
                     W = self.Ws2[name]
                     self._s2.pack(self.Wp32[name], W["fwd"], W["dgrad"])
-                    W["bias"].copy_(self.bp[name])
                     if W["wgrad"]:
                         continue                              # no stride-1 image is read any more
                     ops.pack_weights(self.Wp32[name], self.Wf[name], None)      # (the stride-1 weight-gradient path reads neither image; kept for load/save symmetry)
@@ -575,10 +569,8 @@ class LayerGraphEngine(object):
             if kind == "conv":
                 name = o["name"]
                 if name in self.Ws2:
-                    # stride 2 on the parity kernels: the gather launch over the input + the bias (one more bf16 rounding than a bias inside
-                    # the accumulators; the instance norm behind the conv removes a per-channel constant anyway)
-                    ops.conv3d_upcat_dgrad(self._t(o["ins"][0]), self.Ws2[name]["fwd"], None, None, None, out, None)
-                    out.add_(self.Ws2[name]["bias"])
+                    # stride 2 on the parity kernels: the gather launch over the input, the fp32 master bias in its accumulators
+                    ops.conv3d_stride2_fwd(self._t(o["ins"][0]), self.Ws2[name]["fwd"], self.bp[name], out)
                     continue
                 dst = out if o["sub"] is None else self.full[name]
                 if self.pad:

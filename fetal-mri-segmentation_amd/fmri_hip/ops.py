@@ -559,6 +559,18 @@ def conv3d_upcat_dgrad(dy, w_up_d, w_sk_d, mask_low, mask_skip, dx_low, dx_skip,
                                         c0, c1, dt(dy), _s()), "fmri_conv3d_upcat_dgrad")
 
 
+def conv3d_stride2_fwd(x, w_s2_fwd, bias, y):
+    """Conv3D(3x3x3, strides 2, 'same') forward: x [N,D,H,W,Cin] (even dims), w_s2_fwd [8,8,Cout,Cin] (StridedParity.pack), bias fp32 [Cout] or
+    None (added in the fp32 accumulators), y [N,D/2,H/2,W/2,Cout] (fmri_conv3d_stride2_fwd)"""
+    _need_cuda(x, w_s2_fwd, bias, y)
+    N, D, H, W, Cin = x.shape
+    Cout = y.shape[-1]
+    assert tuple(y.shape) == (N, D // 2, H // 2, W // 2, Cout) and tuple(w_s2_fwd.shape) == (8, 8, Cout, Cin)
+    assert bias is None or (bias.dtype == torch.float32 and bias.numel() >= Cout)
+    check(lib().fmri_conv3d_stride2_fwd(_p(x), Cin, _p(w_s2_fwd), _p(bias), _p(y), N, D, H, W, Cout, dt(x), _s()), "fmri_conv3d_stride2_fwd")
+    return y
+
+
 def conv3d_upcat_wgrad(src0_low, src1, dy, dw, db, dwc_scratch, workspace=None, planar=False):
     _need_cuda(src0_low, src1, dy, dw, db, dwc_scratch, workspace)
     N, D, H, W, Cout = dy.shape

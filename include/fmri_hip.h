@@ -127,6 +127,14 @@ int fmri_conv3d_upcat_fwd(const void* src0_low, int C0, const void* src1, int C1
 int fmri_conv3d_upcat_dgrad(const void* dy, int Cout, const void* w_up_dgrad, const void* w_skip_dgrad, const void* mask_low,
                             const void* mask_skip, void* dx_low, void* dx_skip, int N, int D, int H, int W, int C0, int C1, int dtype,
                             fmri_stream_t stream);
+/* Conv3D(3x3x3, strides (2,2,2), padding 'same') on even D, H, W (reference fetal_net/model/unet3d/isensee2017.py:51: the context pathway's
+ * down-sampling convs): y [N][D/2][H/2][W/2][Cout] = bias + sum_t W[t] x[2o + t] (TF pads one plane BEHIND the volume) as ONE gather launch of
+ * the kernel above over x [N][D][H][W][Cin].  w_s2_fwd: the 27 taps in 27 of the 64 (parity, block offset) slots of a w_up_dgrad-shaped image
+ * [8][8][Cout][Cin] (fmri_hip/strided_parity.py builds it); bias fp32 [Cout] or NULL, added in the fp32 accumulators.  Shapes as
+ * fmri_conv3d_upcat_ok(Cout, 0, Cin, D, H, W) bit 0.  Input gradient: fmri_conv3d_upcat_fwd with the scatter image; weight gradient:
+ * fmri_conv3d_upcat_wgrad (27 of its 64 slot gradients). */
+int fmri_conv3d_stride2_fwd(const void* x, int Cin, const void* w_s2_fwd, const float* bias, void* y, int N, int D, int H, int W, int Cout, int dtype,
+                            fmri_stream_t stream);
 
 /* dw [27][Cout][C0+C1] fp32 and db [Cout] (optional) ACCUMULATED, like fmri_conv3d_wgrad(up0 = 1) but with 8 instead of 27 taps of
  * work on the up-sampled channels.  dwc_scratch: 64*Cout*C0 floats of device scratch (overwritten).  workspace: as fmri_conv3d_wgrad

@@ -434,6 +434,12 @@ def test_stride2_conv_on_the_parity_kernels_is_exact_on_dyadic_data(ops, shape):
     wk = keras_kernel_from_packed(w).float().requires_grad_(True)
     ref = F.conv3d(F.pad(xr, (0, 1, 0, 1, 0, 1)), wk, None, stride=2)
     assert torch.equal(y.cpu().view(torch.int16), to_ndhwc(ref.detach()).to(bf).view(torch.int16)), "forward"
+    # the entry point the Isensee engine calls: the same launch with the conv's fp32 bias in the accumulators (one rounding, of the sum)
+    b = dy4((Cout,), -8, 9, 16.0) + 2.0 ** -12                          # not representable in bf16: a bias rounded on its own would show
+    yb = torch.empty_like(y)
+    ops.conv3d_stride2_fwd(x.to(bf).cuda(), fwd_img, b.cuda(), yb)
+    refb = F.conv3d(F.pad(xr, (0, 1, 0, 1, 0, 1)), wk, b, stride=2)
+    assert torch.equal(yb.cpu().view(torch.int16), to_ndhwc(refb.detach()).to(bf).view(torch.int16)), "forward with bias"
     dy = dy4((N, D // 2, H // 2, W // 2, Cout), -2, 3, 2.0)
     ref.backward(to_ncdhw(dy))
     dx = torch.empty((N, D, H, W, Cin), device="cuda", dtype=bf)
