@@ -20,7 +20,11 @@ does not pin a version and the package is not installed here: their oracle says 
 warp restates `_map_coordinates`' scipy branch, not the cv2.remap branch imgaug prefers for float images when cv2 is importable.
 imgaug's piecewise_affine (commented out in the reference's default config, config_utils.py:101-103) is applied as well when configured,
 between the affine sampling and the elastic transform (augment.py:344-347), on the reference's 2 x 2 grid.
-The noise fields (normal, uniform and Poisson draws) come from a torch device generator (`noise_seed`), not numpy.
+The noise fields (normal, uniform and Poisson draws) are made inside the kernels by a counter-based generator (Philox4x32-10 keyed by
+`noise_seed`; csrc/augment.hip), not by numpy: same distributions, other streams.  The patches of a batch are PLANNED one after the other
+on the host (every draw of the reference, in its order) and then LAUNCHED together, one launch per step of the chain (`_Sampler.plan` /
+`launch_batch`); configurations the batch kernels do not cover (previous-slice truth channels, piecewise affine, the Gaussian filter,
+drop_easy_patches' interleaved draws) go patch by patch (`launch_one`) - same draws, same batches (tests/test_gpu_augment.py).
 """
 import random
 import warnings
