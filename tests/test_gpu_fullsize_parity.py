@@ -4,8 +4,8 @@ XCD-aware tile / column numbering).
 
  (i)   N = 1: logits, Dice and ALL 30 parameter gradients against oracle.loss_and_grads (fp32, the CPU restatement of
        fetal_net/model/unet3d/unet.py:17-86 + metrics.py:11-32) run live on the box;
- (ii)  N = 4 = the exact step bench.py times (same seeds): logits, Dice and every gradient tensor against the fp32 generic-kernel
-       engine at FULL depth (D = 64);
+ (ii)  N = 4 = the step bench.py times: a live batch of the learnable task against the ORACLE (logits, Dice, all 30 gradient tensors;
+       round 5), and the round 1-3 recipe (same seeds) against the fp32 generic-kernel engine at FULL depth (D = 64);
  (iii) exact tests: small dyadic inputs make every product and every partial sum exact in fp32 whatever the summation order, so the
        kernels must reproduce a CPU computation BIT FOR BIT after the one final bf16 rounding - forward, input gradient and weight
        gradient at full size, on shapes spanning several XCD blocks and several weight-gradient column runs;
@@ -34,6 +34,9 @@ BARS = {                                # measured (MI355X, round 2)
     "n4_logits_rel": 1.2e-2,            # 5.8e-3
     "n4_dice_abs": 5.0e-6,              # 2.3e-6
     "n4_grad_l2_rel": 2.4e-2,           # 1.16e-2
+    "n4o_logits_rel": 1.4e-2,           # 6.8e-3   (round 5) batch 4 of the learnable task against the oracle itself
+    "n4o_dice_abs": 3.5e-5,             # 1.74e-5
+    "n4o_grad_l2_rel": 1.7e-2,          # 8.1e-3
     "cfg3_2d_logits_rel": 1.7e-2,       # 8.2e-3
     "cfg3_2d_dice_abs": 2.2e-5,         # 1.05e-5
     "cfg3_2d_grad_l2_rel": 2.0e-2,      # 1.0e-2
@@ -107,6 +110,42 @@ def test_n1_full_size_bf16_default_switches_vs_oracle():
         print("  %-10s kernel %.3e  bias %.3e" % (name, e, eb))
         worst, worst_b = max(worst, e), max(worst_b, eb)
     _check("n1_grad_l2_rel", max(worst, worst_b))
+
+
+def test_n4_live_batch_bf16_default_switches_vs_oracle():
+    """the step bench.py times - batch 4 of the learnable task, every default switch - against the ORACLE itself (round 4's review: the N = 4 step
+    met the oracle only through the fp32 engine): logits, Dice and all 30 gradient tensors, global-batch Dice over the four samples"""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import learnable_task as LT
+    from fmri_hip.engine import UNetEngine, UNetPlan
+    from oracle import unet_oracle as O
+    N = 4
+    spec = O.Spec((1,) + SPATIAL, depth=4, n_base_filters=32)
+    W = spec.init_weights(42)
+    rs = np.random.RandomState(8)
+    for k in W:
+        if k.endswith("/bias"):
+            W[k] = (rs.randn(*W[k].shape) * 0.05).astype(np.float32)
+    x, y = LT.host_batch(31, N, SPATIAL, dtype=np.float32)                       # (N, 1, X, Y, Z) float32 / uint8
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    ref = O.loss_and_grads(spec, W, x, y, dtype=torch.float32)
+    eng = UNetEngine(UNetPlan(1, SPATIAL, depth=4, n_base_filters=32), N, dtype=torch.bfloat16)
+    assert len(eng.upcat) == 3 and eng._wg_stream is not None
+    eng.load_keras_weights(W)
+    xd = torch.from_numpy(x).cuda().to(torch.bfloat16).reshape(N, *SPATIAL, 1).contiguous()
+    yd = torch.from_numpy(y).cuda().reshape(-1).contiguous()
+    eng.forward(xd)
+    sums = eng.loss_forward(yd)
+    eng.backward(yd)
+    torch.cuda.synchronize()
+    _check("n4o_logits_rel", _rel(eng.logits.cpu().numpy().reshape(ref["logits"].shape), ref["logits"]))
+    _check("n4o_dice_abs", abs(eng.metrics_from_sums(sums.cpu().numpy())["dice_coefficient"] - ref["dice"]))
+    worst = 0.0
+    for name in eng.layout:
+        worst = max(worst, _l2(_grad_keras_layout(eng, name), ref["grads"][name + "/kernel"]),
+                    _l2(eng.b_view(name, eng.G).cpu().numpy(), ref["grads"][name + "/bias"]))
+    _check("n4o_grad_l2_rel", worst)
 
 
 def test_n4_bench_step_bf16_vs_fp32_engine_full_depth():
