@@ -217,7 +217,7 @@ def val_dice_leg(batch, steps, spatial=(64, 128, 128), volume=(160, 256, 256), l
             "train_model_seconds": round(t_train, 2), "seconds": round(time.perf_counter() - t0, 2)}, model
 
 
-def reference_api_leg(model, batch, spatial=(64, 128, 128), steps=40, pool=4):
+def reference_api_leg(model, batch, spatial=(64, 128, 128), steps=40, pool=4, generator_leg=True):
     """patches/s of the SAME training step driven through the reference-facing surface (`Model.fit_generator`, what train_model() calls):
     (a) a reference-style host generator yielding float64 numpy batches (generator.py:397-401; a small pool of ready batches of the learnable
     task: isolates the boundary cost), (b) the same batches already in HBM, (c) the bare engine loop on them (= the headline's loop).  All
@@ -247,6 +247,54 @@ def reference_api_leg(model, batch, spatial=(64, 128, 128), steps=40, pool=4):
             model.fit_generator(g, steps_per_epoch=steps, epochs=1, verbose=0)
             torch.cuda.synchronize()
             out[name + "_patches_per_s"] = steps * batch / (time.perf_counter() - t0)
+        if generator_leg:
+            # (d) fetal_net.device_generator with the reference's DEFAULT augmentation (fetal/config_utils.py:81-123, every entry: affine, contrast,
+            # shot / speckle / gaussian noise, elastic transform, coarse dropout) sampling patches from volumes resident in HBM, against (b):
+            # what feeding the step from the device sampler costs
+            import random
+            from fetal_net.device_generator import DeviceDataFile, device_data_generator
+            full = {"flip": [0.5, 0.5, 0.5], "permute": False, "translate": (15, 15, 7), "scale": (0.1, 0.1, 0), "rotate": (0, 0, 90), "poisson_noise": 1,
+                    "gaussian_filter": {"prob": 0.0, "max_sigma": 1}, "contrast": {"prob": 0, "min_factor": 0.2, "max_factor": 0.1},
+                    "elastic_transform": {"alpha": 5, "sigma": 10}, "coarse_dropout": {"rate": 0.2, "size_percent": [0.10, 0.30], "per_channel": True},
+                    "gaussian_noise": {"prob": 0.5, "sigma": 0.05}, "speckle_noise": {"prob": 0.5, "sigma": 0.05}}
+
+            class _Vols(object):
+                pass
+            vols = _Vols()
+            vols.root = _Vols()
+            vshape = tuple(s + s // 2 for s in spatial)
+            pairs = [LT.device_patch(LT.HELD_OUT + 800_000 + k, vshape) for k in range(3)]
+            vols.root.data = [x.float().cpu().numpy() for x, _ in pairs]
+            vols.root.truth = [y.cpu().numpy().astype(np.uint8) for _, y in pairs]
+            np.random.seed(0)
+            random.seed(0)
+            ddf = DeviceDataFile(vols, spatial)
+
+            def make(seed):
+                return device_data_generator(ddf, [0, 1, 2], batch_size=batch, patch_shape=spatial, augment=full, truth_index=0,
+                                             truth_size=spatial[2], is3d=True, categorical=False, skip_blank=False, noise_seed=seed)
+
+            # like against like: the SAME generator's batches made beforehand and cycled from HBM (other data - cleaner, or with other zero
+            # fractions - runs the power-limited step at another clock: `device_batches` above is not the reference for this leg)
+            pg = make(1)
+            ready = [next(pg) for _ in range(8)]
+            pg.close()
+            g = make(2)
+
+            def timed(gen):
+                model.fit_generator(gen, steps_per_epoch=5, epochs=1, verbose=0)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                model.fit_generator(gen, steps_per_epoch=steps, epochs=1, verbose=0)
+                torch.cuda.synchronize()
+                return steps * batch / (time.perf_counter() - t0)
+
+            r0 = timed(cycle(ready))
+            out["device_generator_default_augmentation_patches_per_s"] = timed(g)
+            g.close()
+            r1 = timed(cycle(ready))
+            out["device_generator_ready_batches_patches_per_s"] = [r0, r1]
+            out["device_generator_vs_its_ready_batches"] = out["device_generator_default_augmentation_patches_per_s"] / (0.5 * (r0 + r1))
         eng = model.engine(batch)
         res = [(model._to_device_x(x), model._to_device_y(y)) for x, y in dev]
         for k in range(5):

@@ -135,6 +135,11 @@ def summary(tag):
         if ra:
             w("* `reference_api` (fit_generator): host float64 generator %.1f, device batches %.1f, bare engine loop %.1f patches/s" % (
                 ra["host_float64_generator_patches_per_s"], ra["device_batches_patches_per_s"], ra["resident_batch_patches_per_s"]))
+            if "device_generator_default_augmentation_patches_per_s" in ra:
+                w("* `reference_api`, device generator with the reference's default augmentation: %.1f patches/s = %.3f of the same generator's batches "
+                  "cycled from HBM (%.1f before, %.1f after)" % (
+                      ra["device_generator_default_augmentation_patches_per_s"], ra["device_generator_vs_its_ready_batches"],
+                      ra["device_generator_ready_batches_patches_per_s"][0], ra["device_generator_ready_batches_patches_per_s"][1]))
         s = b.get("secondary")
         if s:
             w("* `secondary`: configs[3] %.0f slices/s (%.2f ms, %.3f of the MFMA peak); configs[4] %.1f ms per volume end to end, %.1f ms device tile loop "
