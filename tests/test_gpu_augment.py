@@ -369,6 +369,33 @@ def test_device_generator_batched_launches_and_prefetch_thread_yield_the_same_ba
     assert all(b[-1].reshape(3, -1, 2)[..., 1].any(axis=1).all() for b in runs[0])      # no blank patch was kept
 
 
+def test_device_generator_batches_beyond_one_launch_chunk_equal_patch_by_patch():
+    """19 patches per batch: the batch kernels take 16 patches per launch (per-patch parameters travel by value), so this batch is two
+    chunks of every step - pointers, statistics and workspaces of the second chunk offset by hand in the C layer"""
+    from fetal_net.device_generator import device_data_generator
+    default = {"flip": [0.5, 0.5, 0.5], "translate": (5, 5, 3), "scale": (0.1, 0.1, 0), "rotate": (0, 0, 90), "poisson_noise": 1,
+               "contrast": {"prob": 0, "min_factor": 0.2, "max_factor": 0.1}, "elastic_transform": {"alpha": 5, "sigma": 4},
+               "coarse_dropout": {"rate": 0.2, "size_percent": [0.10, 0.30], "per_channel": True},
+               "gaussian_noise": {"prob": 0.5, "sigma": 0.05}, "speckle_noise": {"prob": 0.5, "sigma": 0.05}}
+    vols, truths = synth_volumes(9, [(40, 44, 24), (36, 50, 30), (48, 40, 20)])
+    mk = [np.random.RandomState(5).rand(*t.shape).astype(np.float32) for t in truths]
+    df = FakeDataFile(vols, truths, mk)
+    outs = []
+    for batched in (False, True):
+        np.random.seed(21)
+        random.seed(21)
+        gen = device_data_generator(df, [0, 1, 2], batch_size=19, augment=default, patch_shape=(32, 32, 8), skip_blank=False, categorical=False,
+                                    is3d=True, truth_index=0, truth_size=8, batched=batched, shuffle_index_list=False, noise_seed=4)
+        b = []
+        for _ in range(2):
+            (x, m), y = next(gen)
+            b += [x.cpu().numpy(), m.cpu().numpy(), y.cpu().numpy()]
+        outs.append(b)
+    for a, b in zip(*outs):
+        assert a.shape == b.shape and np.array_equal(a, b)
+    assert not np.array_equal(outs[0][0][16], outs[0][0][3])
+
+
 def test_device_generator_without_augmentation_batched_equals_patch_by_patch():
     from fetal_net.device_generator import device_data_generator
     vols, truths = synth_volumes(5, [(40, 44, 24), (36, 50, 30)])
