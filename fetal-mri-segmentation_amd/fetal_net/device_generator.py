@@ -373,9 +373,9 @@ def device_data_generator(data_file, index_list, batch_size=1, n_labels=1, label
     the batch kernels do not cover go patch by patch on their own); False: always patch by patch - same draws, same batches.
 
     prefetch (0 | n): n > 0 starts a producer thread with a HIP stream of its own that keeps up to n batches ready (the role of Keras'
-    GeneratorEnqueuer behind the reference's fit_generator, training.py:110-124).  A patch is 12-25 short gather / element-wise launches
-    - launch-latency bound, ~25 us of HBM time per batch - which then run BESIDE the consumer's training step; a consumer that reads a
-    scalar back every step (`train_on_batch`) leaves no other way to overlap them.  The consumer's current stream waits for the batch's
+    GeneratorEnqueuer behind the reference's fit_generator, training.py:110-124).  A batch is 11-13 short gather / element-wise launches
+    (~0.34 ms of device time with the reference's default augmentation) which then run BESIDE the consumer's training step; a consumer
+    that reads a scalar back every step (`train_on_batch`) leaves no other way to overlap them.  The consumer's current stream waits for the batch's
     event before the yield; the tensors are registered with that stream (record_stream) so the allocator does not recycle them under a
     step still in flight.  Draw order, and therefore every batch, is the same as with prefetch=0 (tests/test_gpu_augment.py); the draws
     of batch k+1 ... k+n come from numpy's global state BEFORE batch k is handed out, so a caller that re-seeds between batches wants
