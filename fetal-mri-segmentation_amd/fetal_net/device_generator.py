@@ -392,7 +392,20 @@ def device_data_generator(data_file, index_list, batch_size=1, n_labels=1, label
     index_generator = random_list_generator(index_list) if shuffle_index_list else list_generator(index_list)
     ps = sampler.patch_shape
 
+    last_done = [None]
+
     def produce():
+        # the sampler's range / workspace buffers are reused batch after batch: a caller that pulls batches under changing streams must not
+        # start batch k + 1's chain while batch k's still runs on another stream (same stream: ordered anyway, the wait is free)
+        cur = torch.cuda.current_stream()
+        if last_done[0] is not None:
+            cur.wait_event(last_done[0])
+        out = produce_batch()
+        last_done[0] = torch.cuda.Event()
+        last_done[0].record(cur)
+        return out
+
+    def produce_batch():
         x = torch.empty((batch_size, ps[0], ps[1], sampler.n_chan), device=ddf.device, dtype=torch.float32)
         y = torch.empty((batch_size, ps[0], ps[1], truth_size), device=ddf.device, dtype=torch.uint8)
         m = torch.empty((batch_size, ps[0], ps[1], truth_size), device=ddf.device, dtype=torch.float32) if ddf.mask is not None else None
