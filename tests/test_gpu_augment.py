@@ -728,33 +728,3 @@ def test_elastic_fields_rng_equals_the_host_restatement_of_its_draws(ops, X, Y, 
     assert np.abs(want).max() > 0.02 * alpha
     e0, _ = ops.elastic_fields_rng((X, Y), alpha, sigma, seed, seq + 1)
     assert not torch.equal(e0, d0)
-
-
-def test_get_training_and_validation_generators_over_the_device_generator(tmp_path):
-    """fetal_net.generator.get_training_and_validation_generators (reference generator.py:58-146): the split files, the step counts and two endless
-    generators of device batches over one resident copy of the volumes"""
-    import pickle
-    from fetal_net.generator import get_training_and_validation_generators
-    vols, truths = synth_volumes(11, [(40, 44, 24)] * 6)
-    df = FakeDataFile(vols, truths)
-    files = [str(tmp_path / n) for n in ("train.pkl", "val.pkl", "test.pkl")]
-    random.seed(4)
-    np.random.seed(4)
-    tr, va, n_tr, n_va = get_training_and_validation_generators(df, 3, 1, files[0], files[1], files[2], patch_shape=(32, 32, 8), data_split=0.6,
-                                                                augment={"flip": [0.5, 0.5, 0.5], "gaussian_noise": {"prob": 1.0, "sigma": 0.05}},
-                                                                validation_batch_size=2, truth_index=3, truth_size=1, patches_per_epoch=12,
-                                                                categorical=False, is3d=True, verbose=False)
-    lists = [pickle.load(open(f, "rb")) for f in files]
-    assert sorted(lists[0] + lists[1] + lists[2]) == list(range(6)) and len(lists[2]) == 1 and len(lists[0]) == 3 and len(lists[1]) == 2
-    assert (n_tr, n_va) == (4, 6)
-    x, y = next(tr)
-    xv, yv = next(va)
-    assert tuple(x.shape) == (3, 1, 32, 32, 8) and tuple(y.shape) == (3, 1, 32, 32, 1) and x.is_cuda and y.dtype == torch.uint8
-    assert tuple(xv.shape) == (2, 1, 32, 32, 8) and tuple(yv.shape) == (2, 1, 32, 32, 1)
-    assert y.any() and torch.isfinite(x).all()                       # skip_blank_train: no blank training patch
-    # the split is re-used, not redrawn
-    tr2, va2, _, _ = get_training_and_validation_generators(df, 3, 1, files[0], files[1], files[2], patch_shape=(32, 32, 8), patches_per_epoch=12,
-                                                            categorical=False, is3d=True, verbose=False)
-    assert [pickle.load(open(f, "rb")) for f in files] == lists
-    for g in (tr, va, tr2, va2):
-        g.close()
