@@ -352,8 +352,11 @@ __device__ __forceinline__ void emit_minmax(float lo, float hi, int* __restrict_
         unsigned v = atomicExch(&w[AUG_WS_SLOTS + 32 * (threadIdx.x >> 1) + (threadIdx.x & 1)], 0u);      // even lanes ~key(min), odd key(max)
 #pragma unroll
         for (int o = 2; o < 32; o <<= 1) v = max(v, (unsigned)__shfl_xor((int)v, o));
-        if (threadIdx.x == 0) stats[0] = key2f(~v);
-        if (threadIdx.x == 1) stats[1] = key2f(v);
+        // no workgroup contributed (every element NaN, or an empty patch): all slots are still 0 - leave the range {0, 0}, which the
+        // consumers treat as rng = 1, instead of decoding the two ends of the key space into a range that poisons every later step
+        const bool none = (__shfl((int)v, 0) | __shfl((int)v, 1)) == 0;
+        if (threadIdx.x == 0) stats[0] = none ? 0.f : key2f(~v);
+        if (threadIdx.x == 1) stats[1] = none ? 0.f : key2f(v);
         __threadfence();
         if (threadIdx.x == 0) atomicExch(&w[2], 0u);
     }

@@ -78,8 +78,6 @@ class PlainDataFile(object):
             g = self._f[k]
             self._groups.append(g)
             setattr(self.root, k, _Samples(g, n))
-        if "mask" not in names:
-            self.root.mask = []                        # the reference's files always carry the (possibly empty) `mask` array (data.py:17)
         if "subject_ids" in self._f:
             d = self._f["subject_ids"]
             self.root.subject_ids = [bytes(v) for v in np.atleast_1d(np.asarray(d[()]))]
@@ -218,54 +216,6 @@ def write_plain_data_file(out_file, data, truth, mask=None, subject_ids=None):
             f.create_dataset("subject_ids", data=ids).close()
     os.replace(tmp, out_file)
     return out_file
-
-
-# ------------------------------------------------------------------------------------------------ building a data file from images
-def normalize_data_storage(data_storage):
-    """reference normalize.py:70-83 ('all'): every volume minus the MEAN of the per-volume means, over the mean of the per-volume standard
-    deviations (in place on the list) -> (data_storage, mean, std)"""
-    means = [np.asarray(d).mean(axis=(-1, -2, -3)) for d in data_storage]
-    stds = [np.asarray(d).std(axis=(-1, -2, -3)) for d in data_storage]
-    mean, std = np.asarray(means).mean(axis=0), np.asarray(stds).mean(axis=0)
-    for i in range(len(data_storage)):
-        data_storage[i] = (np.asarray(data_storage[i]) - mean) / std
-    return data_storage, mean, std
-
-
-def normalize_data_storage_each(data_storage):
-    """reference normalize.py:86-92 ('each'): every volume z-scored by its own mean / std -> (data_storage, None, None)"""
-    for i in range(len(data_storage)):
-        d = np.asarray(data_storage[i])
-        data_storage[i] = (d - d.mean(axis=(-1, -2, -3))) / d.std(axis=(-1, -2, -3))
-    return data_storage, None, None
-
-
-def write_data_to_file(training_data_files, out_file, truth_dtype=np.uint8, subject_ids=None, normalize='all', scale=None, preproc=None):
-    """reference data.py:42-74 (called by fetal/utils.py:17 when the experiment's data file does not exist yet): one tuple of image files per
-    subject - (volume, truth[, mask]) - read, optionally zoomed (volume: scipy's default cubic spline, truth: nearest; data.py:26-27) and
-    pre-processed, stored as float64 / truth_dtype / float64, then normalised ('all' | 'each' | anything else: not).  -> (out_file, (mean, std)).
-    The file is written in this package's plain HDF5 layout (write_plain_data_file: what open_data_file, the generators and
-    tools/convert_data_file.py read), not as PyTables VLArrays of pickles; images are read by fetal_net.utils.nifti (single-file NIfTI-1)."""
-    from scipy.ndimage import zoom
-    from .utils.nifti import load_nifti
-    data, truth, mask = [], [], []
-    for set_of_files in training_data_files:
-        subject = [load_nifti(os.path.abspath(f), scaled=True) for f in set_of_files]
-        if scale is not None:
-            subject[0] = zoom(subject[0], scale)
-            subject[1] = zoom(subject[1], scale, order=0)
-        if preproc is not None:
-            subject[0] = preproc(subject[0])
-        data.append(np.asarray(subject[0]).astype(np.float64))
-        truth.append(np.asarray(subject[1], dtype=truth_dtype))
-        if len(subject) > 2:
-            mask.append(np.asarray(subject[2]).astype(np.float64))
-    if isinstance(normalize, str):
-        _, mean, std = {'all': normalize_data_storage, 'each': normalize_data_storage_each}[normalize](data)
-    else:
-        mean, std = None, None
-    write_plain_data_file(out_file, data, truth, mask=mask if mask else None, subject_ids=list(subject_ids) if subject_ids else None)
-    return out_file, (mean, std)
 
 
 # ------------------------------------------------------------------------------------------------ split lists, normalisation record

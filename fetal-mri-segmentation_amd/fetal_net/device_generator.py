@@ -148,7 +148,8 @@ class _Sampler(object):
                 warnings.warn(msg)
 
     def _next_seq(self):
-        self.seq += 1
+        # the kernels take the call number as uint32 and 0 means "this patch skips the step": wrap inside 1 .. 2^32 - 1
+        self.seq = self.seq % 0xFFFFFFFF + 1
         return self.seq
 
     def plan(self, index):
@@ -379,7 +380,10 @@ def device_data_generator(data_file, index_list, batch_size=1, n_labels=1, label
     event before the yield; the tensors are registered with that stream (record_stream) so the allocator does not recycle them under a
     step still in flight.  Draw order, and therefore every batch, is the same as with prefetch=0 (tests/test_gpu_augment.py); the draws
     of batch k+1 ... k+n come from numpy's global state BEFORE batch k is handed out, so a caller that re-seeds between batches wants
-    prefetch=0 (the default).  `Model.fit_generator` has its own producer thread and copy stream: leave prefetch at 0 there."""
+    prefetch=0 (the default).  With prefetch > 0 those draws happen on the producer THREAD against the process-global numpy / `random` states:
+    anything else in the process that draws from them (a validation generator on the main thread, for one) interleaves with the
+    producer by timing, and the batches of both stop being reproducible - seeded reproducibility holds for prefetch=0 only.
+    `Model.fit_generator` has its own producer thread and copy stream: leave prefetch at 0 there."""
     import torch
     if truth_downsample is not None and truth_downsample > 1:
         raise NotImplementedError("truth_downsample is not part of the device generator")

@@ -346,84 +346,6 @@ def predict_augment(data, model, overlap_factor, patch_shape, num_augments=32):
     return np.stack(out, axis=0)
 
 
-# ---------------------------------------------------------------------------------------------- the reference's older helpers
-# reference prediction.py:214-275: nothing in the reference calls them any more (run_validation_case writes its files itself); kept so that a
-# script written against the reference's module finds every name.  Restated call for call; the two places that differ say so.
-def get_prediction_labels(prediction, threshold=0.5, labels=None):
-    """reference prediction.py:214-224, as written: per sample, argmax over axis 1 of the (n_labels, x, y, z) array (the reference's choice -
-    a label map over (n_labels, y, z); it only passes the next line when n_labels == x), voxels whose maximum over axis 0 is below the
-    threshold set to 0, label values mapped through `labels`"""
-    n_samples = prediction.shape[0]
-    label_arrays = []
-    for sample_number in range(n_samples):
-        label_data = np.argmax(prediction[sample_number], axis=1)
-        label_data[np.max(prediction[sample_number], axis=0) < threshold] = 0
-        if labels:
-            for value in np.unique(label_data).tolist()[1:]:
-                label_data[label_data == value] = labels[value - 1]
-        label_arrays.append(np.array(label_data, dtype=np.uint8))
-    return label_arrays
-
-
-def get_test_indices(testing_file):
-    """reference prediction.py:227-228"""
-    from .data import pickle_load
-    return pickle_load(testing_file)
-
-
-def predict_from_data_file(model, open_data_file, index):
-    """reference prediction.py:231-232"""
-    return model.predict(open_data_file.root.data[index])
-
-
-def predict_and_get_image(model, data, affine):
-    """reference prediction.py:235-236: the first label channel of the first sample as an image"""
-    from .utils.nifti import NiftiImage
-    return NiftiImage(np.asarray(model.predict(data))[0, 0], affine)
-
-
-def predict_from_data_file_and_get_image(model, open_data_file, index):
-    """reference prediction.py:239-240"""
-    return predict_and_get_image(model, open_data_file.root.data[index], open_data_file.root.affine)
-
-
-def predict_from_data_file_and_write_image(model, open_data_file, index, out_file):
-    """reference prediction.py:243-245"""
-    image = predict_from_data_file_and_get_image(model, open_data_file, index)
-    image.to_filename(out_file)
-
-
-def prediction_to_image(prediction, label_map=False, threshold=0.5, labels=None):
-    """reference prediction.py:248-267.  One sample: its array as it is, or (label_map) an int8 map of `label` (labels[0], else 1) where the
-    first channel exceeds the threshold; several samples with several channels: the label arrays' first entry, or one image per channel.
-    Two lines of the reference cannot run as written and are repaired, not restated: it indexes the (x, y, z) map with the (C, x, y, z)
-    comparison (an IndexError for every input), and it calls multi_class_prediction(prediction) without the second argument (a TypeError) -
-    here the first channel decides, and the affine defaults to the identity like get_image's."""
-    from .utils.nifti import get_image
-    if prediction.shape[0] == 1:
-        data = prediction[0]
-        if label_map:
-            label_map_data = np.zeros(prediction[0, 0].shape, np.int8)
-            label = labels[0] if labels else 1
-            label_map_data[data[0] > threshold if data.shape != label_map_data.shape else data > threshold] = label
-            data = label_map_data
-    elif prediction.shape[1] > 1:
-        if label_map:
-            label_map_data = get_prediction_labels(prediction, threshold=threshold, labels=labels)
-            data = label_map_data[0]
-        else:
-            return multi_class_prediction(prediction)
-    else:
-        raise RuntimeError("Invalid prediction array shape: {0}".format(prediction.shape))
-    return get_image(data)
-
-
-def multi_class_prediction(prediction, affine=None):
-    """reference prediction.py:270-274: one image per label channel of the first sample"""
-    from .utils.nifti import get_image
-    return [get_image(prediction[0, i], affine) for i in range(prediction.shape[1])]
-
-
 def run_validation_case(data_index, output_dir, model, data_file, training_modalities, patch_shape, overlap_factor=0,
                         permute=False, prev_truth_index=None, prev_truth_size=None, use_augmentations=False):
     """Predict one case of an opened data file (any object with `.root.data[i]` / `.root.truth[i]`) and write

@@ -77,32 +77,3 @@ def load_nifti(path, return_affine=False, scaled=True):
     else:
         affine[0, 0], affine[1, 1], affine[2, 2] = pixdim[1:4]
     return data, affine
-
-
-class NiftiImage(object):
-    """What the reference's helpers hand around as `nib.Nifti1Image(dataobj, affine)` (utils/utils.py:18-21 `get_image`), as far as they use it:
-    `.dataobj`, `.affine`, `.shape`, `.get_data()` / `.get_fdata()`, `.to_filename(path)` (through save_nifti above)."""
-
-    def __init__(self, dataobj, affine=None):
-        self.dataobj = np.asarray(dataobj)
-        self.affine = np.eye(4) if affine is None else np.asarray(affine, np.float64)
-
-    @property
-    def shape(self):
-        return self.dataobj.shape
-
-    def get_data(self):
-        return self.dataobj
-
-    def get_fdata(self):
-        return np.asarray(self.dataobj, dtype=np.float64)
-
-    def to_filename(self, path):
-        return save_nifti(self.dataobj, path, self.affine)
-
-
-def get_image(data, affine=None, nib_class=NiftiImage):
-    """reference fetal_net/utils/utils.py:18-21"""
-    if affine is None:
-        affine = np.eye(4)
-    return nib_class(dataobj=data, affine=affine)

@@ -42,7 +42,10 @@ const char* fmri_error_string(int code);
  * region: average shader clock = d(memtime) / d(memrealtime) x 0.1 GHz per XCD - the `clock_ghz` of the bench line (the chip is
  * power-limited under this workload: the clock explains box-to-box and recipe-to-recipe differences). */
 int fmri_clock_stamp(unsigned long long* out16, fmri_stream_t stream);
-/* 0/1: would fmri_conv3d_fwd / _wgrad take the MFMA path for this shape and dtype? (host-side query, no GPU needed) */
+/* 0/1: would fmri_conv3d_fwd / _wgrad take the MFMA path for this shape and dtype? (host-side query, no GPU needed)
+ * Size limit of the MFMA path: its LDS-DMA addresses a halo box / a plane with 32-bit byte offsets below 2^31 (an offset at or above
+ * 2^31 is the hardware's "write zeros" encoding): forward needs 2 * (min(D, 4) + 2) * H * W * max(C0, C1) * 2 B < 2^31, the weight
+ * gradient H * W * max(C0, C1, Cout) * 2 B < 2^31; larger layers fall back to the generic kernels (AUTO) or return FMRI_E_SHAPE (MFMA). */
 int fmri_conv3d_uses_mfma(int C0, int C1, int Cout, int D, int H, int W, int dtype);
 
 /* ---- Conv3D 3x3x3, stride 1, 'same' (+BiasAdd +activation) — reference unet3d/unet.py:102,113 (create_convolution_block)

@@ -130,7 +130,7 @@ def test_bf16_training_reaches_the_dice_of_fp32_and_of_the_cpu_oracle(tmp_path):
 # curve is steepest: bf16 0.82 vs 0.79), 4.5e-3 fp32 vs oracle; per step 6.4e-2 with bf16, 1.05e-2 fp32 vs oracle.
 BARS = {("bf16", "fp32"): (7e-3, 7e-3, 5e-3, 6e-2, 1.3e-1),
         ("bf16", "oracle"): (7e-3, 7e-3, 5e-3, 6e-2, 1.3e-1),
-        ("fp32", "oracle"): (7e-3, 7e-3, 7e-3, 9e-3, 2.1e-2)}
+        ("fp32", "oracle"): (5e-3, 5e-3, 7e-3, 9e-3, 2.1e-2)}
 # (round 5: the volume's hard Dice of fp32 vs the oracle came out 4.1e-3 apart in one of ~15 further runs of unchanged code - the bar was 3.5e-3 = 2x
-# the maximum of the first six; a thresholded volume moves in steps and the fp32 engine's atomics reorder every run.  The three end-point bars of this pair are
-# now those of the bf16 pairs, 7e-3 = 2x the largest end-point difference seen between ANY two runs: two runs of one engine differ by as much)
+# the maximum of the first six; a thresholded volume moves in steps and the fp32 engine's atomics reorder every run.  Only that thresholded
+# bar is widened (7e-3 = 2x the largest end-point difference seen between ANY two runs); the two held-out bars of the fp32 pair stay at 5e-3)

@@ -1,16 +1,16 @@
 """The recorded full `pytest -m gpu` run must belong to the kernel sources of THIS tree (a round shipped nine kernel commits
-behind its last recorded GPU suite run).  profiles/r05_gputest_final.log is written by tools/gputest_stamp.sh on the GPU box; its first
+behind its last recorded GPU suite run).  profiles/r06_gputest_final.log is written by tools/gputest_stamp.sh on the GPU box; its first
 line carries the sha256 over csrc/*.hip + common.h + the public header (bench.kernel_source_hash)."""
 import os
 import re
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LOG = os.path.join(ROOT, "profiles", "r05_gputest_final.log")
+LOG = os.path.join(ROOT, "profiles", "r06_gputest_final.log")
 
 
 def test_recorded_gpu_suite_run_matches_the_kernel_sources():
     import bench
-    assert os.path.exists(LOG), "no recorded GPU suite run: gpurun -- 'bash tools/gputest_stamp.sh r05', then copy the log to profiles/"
+    assert os.path.exists(LOG), "no recorded GPU suite run: gpurun -- 'bash tools/gputest_stamp.sh r06', then copy the log to profiles/"
     text = open(LOG).read()
     m = re.search(r"kernel_source_hash=([0-9a-f]+)", text.splitlines()[0])
     assert m, "unstamped log"

@@ -26,7 +26,7 @@ def wrap(name):
         e0.record()
         r = orig(*a, **k)
         e1.record()
-        shp = tuple(tuple(t.shape) for t in a[:6] if torch.is_tensor(t))
+        shp = tuple(tuple(t.shape) if torch.is_tensor(t) else None for t in a[:7])
         rec.setdefault((name, shp), []).append((e0, e1))
         return r
     setattr(ops, name, f)
@@ -50,18 +50,53 @@ K = 5
 for _ in range(K):
     eng.train_step(x, y, 1e-4)
 torch.cuda.synchronize()
+PEAK = 2500.0          # dense bf16 TFLOP/s (MI355X guide)
+
+
+def conv_flops(name, s):
+    """algorithmic flops of one launch by the reference's tap count (3 x 3 taps per output pixel): 2 * 9 * Cin * Cout * pixels.
+    s = shapes of the first seven positional arguments (None where the argument is no tensor); planar tensors are [1][slices][H][W][C]"""
+    def pix(t):
+        return t[0] * t[1] * t[2] * t[3]
+
+    def ch(t):
+        return 0 if t is None else t[4]
+    if name == "conv3d_fwd":                    # (src0, src1, w, bias, y)
+        return 2.0 * 9 * (ch(s[0]) + ch(s[1])) * ch(s[4]) * pix(s[4])
+    if name == "conv3d_fwd_tail":               # (src0, w, bias, y)
+        return 2.0 * 9 * ch(s[0]) * ch(s[3]) * pix(s[3])
+    if name == "conv3d_dgrad":                  # (dy, w_dgrad, dx)
+        return 2.0 * 9 * ch(s[0]) * ch(s[2]) * pix(s[0])
+    if name == "conv3d_wgrad":                  # (src0, src1, dy, dw, db)
+        return 2.0 * 9 * (ch(s[0]) + ch(s[1])) * ch(s[2]) * pix(s[2])
+    if name == "conv3d_upcat_fwd":              # (src0_low, src1, w_up_f, w_sk_f, bias, y)
+        return 2.0 * 9 * (ch(s[0]) + ch(s[1])) * ch(s[5]) * pix(s[5])
+    if name == "conv3d_upcat_dgrad":            # (dy, w_up_d, w_sk_d, mask_low, mask_skip, dx_low, dx_skip)
+        return 2.0 * 9 * (ch(s[5]) + ch(s[6])) * ch(s[0]) * pix(s[0])
+    if name == "conv3d_upcat_wgrad":            # (src0_low, src1, dy, dw, db, dwc)
+        return 2.0 * 9 * (ch(s[0]) + ch(s[1])) * ch(s[2]) * pix(s[2])
+    return None
+
+
 rows = []
 for (name, shp), ev in rec.items():
-    ms = sum(a.elapsed_time(b) for a, b in ev) / K
-    rows.append((ms, name, shp, len(ev) // K))
-tot = sum(r[0] for r in rows)
-for ms, name, shp, n in sorted(rows, reverse=True):
-    fl = ""
-    if name.startswith("conv3d") and "pack" not in name:
-        # first tensor = input (or dy), find Cin / Cout from the shapes
-        try:
-            pix = shp[0][1] * shp[0][2] * shp[0][3] if "upcat" not in name else None
-        except Exception:
-            pix = None
-    print("%8.3f ms  x%d  %-22s %s" % (ms, n, name, shp))
-print("total %.3f ms per step (exclusive)" % tot)
+    ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
+    n = len(ev) // K
+    fl = conv_flops(name, shp)
+    rows.append({"op": name, "shapes": [list(t) for t in shp if t is not None], "launches_per_step": n, "ms_per_launch": round(ms, 4), "ms_per_step": round(ms * n, 4),
+                 "gflop": round(fl / 1e9, 1) if fl else None, "mfma_frac": round(fl / (ms * 1e-3) / 1e12 / PEAK, 4) if fl else None})
+rows.sort(key=lambda r: -r["ms_per_step"])
+tot = sum(r["ms_per_step"] for r in rows)
+conv = [r for r in rows if r["gflop"]]
+cms, cfl = sum(r["ms_per_step"] for r in conv), sum(r["gflop"] * r["launches_per_step"] for r in conv)
+for r in rows:
+    print("%8.3f ms  x%d  %-22s %-6s %s" % (r["ms_per_step"], r["launches_per_step"], r["op"], "" if r["mfma_frac"] is None else "%.2f" % r["mfma_frac"], r["shapes"]))
+print("total %.3f ms per step (exclusive); 3x3 convs %.3f ms, %.0f GFLOP algorithmic = %.3f of the MFMA peak" % (tot, cms, cfl, cfl / cms / PEAK if cms else 0))
+out = {"workload": "configs[3]: 2-D U-Net depth 4 / 32 filters, batch %d x %dx%dx%d, bf16, one stream (exclusive HIP-event times, mean over %d steps)" % (B, X, Y, C, K),
+       "rows": rows, "total_ms_per_step": round(tot, 3), "conv_ms_per_step": round(cms, 3), "conv_gflop_per_step": round(cfl, 1),
+       "conv_mfma_frac": round(cfl / cms / PEAK, 4) if cms else None}
+if len(sys.argv) > 1:
+    import bench
+    out["kernel_source_hash"] = bench.kernel_source_hash()
+    out["git_head"] = sys.argv[2] if len(sys.argv) > 2 else None
+    json.dump(out, open(sys.argv[1], "w"), indent=1)

@@ -14,7 +14,7 @@ from bench_conv import LAYERS
 from fmri_hip import ops, _lib
 
 L = _lib.lib()
-L.fmri_debug_prof.argtypes = [ctypes.c_void_p, ctypes.c_int]
+L.fmri_debug_prof_wgrad.argtypes = [ctypes.c_void_p, ctypes.c_int]
 buf = (ctypes.c_ulonglong * 12)()
 N = 4
 for name, C0, up0, C1, Cout, D, H, W in LAYERS:
@@ -27,10 +27,10 @@ for name, C0, up0, C1, Cout, D, H, W in LAYERS:
     for _ in range(2):
         ops.conv3d_wgrad(x, None, dy, dw, db)
     torch.cuda.synchronize()
-    L.fmri_debug_prof(None, 1)
+    L.fmri_debug_prof_wgrad(None, 1)
     ops.conv3d_wgrad(x, None, dy, dw, db)
     torch.cuda.synchronize()
-    L.fmri_debug_prof(buf, 0)
+    L.fmri_debug_prof_wgrad(buf, 0)
     p = list(buf)
     tot, units = max(p[5], 1), max(p[6], 1)
     sec = [p[i] / tot * 100 for i in range(4)]
