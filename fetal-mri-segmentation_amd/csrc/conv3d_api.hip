@@ -10,21 +10,22 @@ bool conv3d_wgrad_mfma_ok(int C0, int C1, int Cout, int D, int H, int W, int dty
 bool conv3d_fwd_needs_cube(int D, int H, int W);
 bool conv3d_wgrad_cout32_ok(int C0, int C1, int Cout, int N, int D, int H, int W, int dtype, int planar, int up0);
 int conv3d_fwd_mfma(const void*, int, int, int, const void*, int, const void*, const float*, const void*, void*, int, int, int, int, int, int,
-                    float, hipStream_t);
+                    float, int, hipStream_t);
+int conv3d_wgrad_mfma_f32(const void*, int, int, const void*, int, const void*, float*, float*, int, int, int, int, int, hipStream_t);
 int conv3d_wgrad_mfma(const void*, int, int, int, const void*, int, const void*, float*, float*, int, int, int, int, int, void*, int64_t,
                       hipStream_t);
 int64_t conv3d_wgrad_mfma_ws_bytes(int C0, int C1, int Cout, int N, int D, int H, int W, int planar);
 int conv3d_upcat_wgrad_mfma(const void*, int, const void*, int, const void*, float*, float*, float*, int, int, int, int, int, int, void*, int64_t,
                             hipStream_t);
 int conv3d_fwd_mfma_ex(int, const void*, int, int, int, const void*, int, const void*, const float*, const void*, const void*, void*, int, int, int,
-                       int, int, int, float, hipStream_t);
+                       int, int, int, float, int, hipStream_t);
 
 int conv3d_upcat_wgrad_mfma_ex(const void*, int, const void*, int, const void*, float*, float*, float*, int, int, int, int, int, int, int, void*,
                                int64_t, hipStream_t);
-int conv3d_fwd_mfma_res_b27(const void*, int, const void*, const float*, const void*, void*, int, int, int, int, int, int, float, hipStream_t);
+int conv3d_fwd_mfma_res_b27(const void*, int, const void*, const float*, const void*, void*, int, int, int, int, int, int, float, int, hipStream_t);
 int conv3d_fwd_tail_ok(int C0, int Cout, int N, int D, int H, int W, int dtype);
 int conv3d_fwd_mfma_tail(const void*, int, const void*, const float*, void*, void*, const float*, const float*, float*, int, int, int, int, int, int,
-                         float, hipStream_t);
+                         float, int, hipStream_t);
 
 int conv3d_fwd_ntail_ok(int C0, int C1, int Cout, int N, int D, int H, int W, int dtype);
 int conv3d_fwd_mfma_ntail(int, const void*, int, int, const void*, int, const void*, const float*, const void*, void*, int, int, int, int, int, int,
@@ -58,11 +59,11 @@ extern "C" int fmri_conv3d_fwd(const void* src0, int C0, int up0, const void* sr
     if (dtype != FMRI_F32 && dtype != FMRI_BF16) return FMRI_E_DTYPE;
     if (impl != FMRI_IMPL_GENERIC && !mask && conv3d_first_ok(C0, C1, Cout, D, H, W, dtype, up0, planar))
         return conv3d_first_fwd(src0, C0, planar, w, bias, y, N, D, H, W, Cout, act, alpha, as_stream(stream));
-    const bool can = conv3d_fwd_mfma_ok(C0, C1, Cout, D, H, W, dtype) && !(planar && conv3d_fwd_needs_cube(D, H, W));
+    const bool can = conv3d_fwd_mfma_ok(C0, C1, Cout, D, H, W, dtype) && !(planar && (dtype == FMRI_F32 || conv3d_fwd_needs_cube(D, H, W)));    // (the fp32 MFMA form covers 3-D launches)
     if (impl == FMRI_IMPL_MFMA && !can) return FMRI_E_SHAPE;
     if (can && impl != FMRI_IMPL_GENERIC) {
         if ((((uintptr_t)src0) | ((uintptr_t)src1) | ((uintptr_t)w) | ((uintptr_t)y) | ((uintptr_t)mask)) & 15) return FMRI_E_ALIGN;
-        return conv3d_fwd_mfma(src0, C0, up0, planar, src1, C1, w, bias, mask, y, N, D, H, W, Cout, act, alpha, as_stream(stream));
+        return conv3d_fwd_mfma(src0, C0, up0, planar, src1, C1, w, bias, mask, y, N, D, H, W, Cout, act, alpha, dtype, as_stream(stream));
     }
     return conv3d_fwd_generic(src0, C0, up0, planar, src1, C1, w, bias, mask, y, N, D, H, W, Cout, act, alpha, dtype, as_stream(stream));
 }
@@ -77,10 +78,10 @@ extern "C" int fmri_conv3d_fwd_tail(const void* src0, int C0, const void* w, con
                                     fmri_stream_t stream) {
     int rc = check_common(src0, C0, 0, 0, nullptr, 0, N, D, H, W, Cout);
     if (rc) return rc;
-    if (dtype != FMRI_BF16) return FMRI_E_DTYPE;
+    if (dtype != FMRI_BF16 && dtype != FMRI_F32) return FMRI_E_DTYPE;
     if (!w || !y || (!y_pool && !logits)) return FMRI_E_SHAPE;
     if ((((uintptr_t)src0) | ((uintptr_t)w) | ((uintptr_t)y) | ((uintptr_t)y_pool) | ((uintptr_t)w1)) & 15) return FMRI_E_ALIGN;
-    return conv3d_fwd_mfma_tail(src0, C0, w, bias, y, y_pool, w1, b1, logits, N, D, H, W, Cout, act, alpha, as_stream(stream));
+    return conv3d_fwd_mfma_tail(src0, C0, w, bias, y, y_pool, w1, b1, logits, N, D, H, W, Cout, act, alpha, dtype, as_stream(stream));
 }
 
 extern "C" int fmri_conv3d_dgrad(const void* dy, int Cout, const void* w_dgrad, const void* mask, void* dx, int N, int D, int H,
@@ -99,7 +100,7 @@ extern "C" int fmri_conv3d_wgrad(const void* src0, int C0, int up0, const void* 
     if (!dy || !dw) return FMRI_E_SHAPE;
     if (impl != FMRI_IMPL_GENERIC && conv3d_first_ok(C0, C1, Cout, D, H, W, dtype, up0, planar))
         return conv3d_first_wgrad(src0, C0, planar, dy, dw, db, N, D, H, W, Cout, as_stream(stream));
-    bool can = conv3d_wgrad_mfma_ok(C0, C1, Cout, D, H, W, dtype);
+    bool can = conv3d_wgrad_mfma_ok(C0, C1, Cout, D, H, W, dtype) && !(planar && dtype == FMRI_F32);       // (the fp32 MFMA form covers 3-D launches)
     if (!can && (Cout % 64) && conv3d_wgrad_cout32_ok(C0, C1, Cout, N, D, H, W, dtype, planar, up0)) {
         can = true;                       // 32-wide Cout on the kd-sharing kernel (32 x 32 blocks): without a workspace, so that it takes the launch
         workspace = nullptr;
@@ -108,6 +109,7 @@ extern "C" int fmri_conv3d_wgrad(const void* src0, int C0, int up0, const void* 
     if (impl == FMRI_IMPL_MFMA && !can) return FMRI_E_SHAPE;
     if (can && impl != FMRI_IMPL_GENERIC) {
         if ((((uintptr_t)src0) | ((uintptr_t)src1) | ((uintptr_t)dy)) & 15) return FMRI_E_ALIGN;
+        if (dtype == FMRI_F32) return conv3d_wgrad_mfma_f32(src0, C0, up0, src1, C1, dy, dw, db, N, D, H, W, Cout, as_stream(stream));
         return conv3d_wgrad_mfma(src0, C0, up0, planar, src1, C1, dy, dw, db, N, D, H, W, Cout, workspace, workspace_bytes, as_stream(stream));
     }
     return conv3d_wgrad_generic(src0, C0, up0, planar, src1, C1, dy, dw, db, N, D, H, W, Cout, dtype, as_stream(stream));
@@ -117,7 +119,7 @@ extern "C" int fmri_conv3d_wgrad_cout32_ok(int C0, int C1, int Cout, int N, int 
     return conv3d_wgrad_cout32_ok(C0, C1, Cout, N, D, H, W, dtype, planar, up0) ? 1 : 0;
 }
 extern "C" int64_t fmri_conv3d_wgrad_workspace_bytes(int C0, int C1, int Cout, int N, int D, int H, int W, int dtype, int planar) {
-    if (!conv3d_wgrad_mfma_ok(C0, C1, Cout, D, H, W, dtype)) return 0;
+    if (dtype != FMRI_BF16 || !conv3d_wgrad_mfma_ok(C0, C1, Cout, D, H, W, dtype)) return 0;      // (the fp32 form has no slab flush)
     if (conv3d_first_ok(C0, C1, Cout, D, H, W, dtype, 0, planar)) return 0;
     return conv3d_wgrad_mfma_ws_bytes(C0, C1, Cout, N, D, H, W, planar);
 }
@@ -188,13 +190,15 @@ __global__ void __launch_bounds__(256) k_pack_up_weights(const float* __restrict
 // D,H,W = output (full-resolution) dims; planar: D = number of slices (not up-sampled).  bit 0: forward + input gradients, bit 1: weight gradient
 int upcat_ok(int C0, int C1, int Cout, int D, int H, int W, int dtype, int planar) {
     if (((planar ? 0 : D) | H | W) & 1) return 0;
+    if (planar && dtype == FMRI_F32) return 0;           // fp32 on the MFMA kernels: 3-D launches only
     const int Dl = planar ? D : D / 2;
-    if (C0 <= 0 || C1 < 0 || Cout * (planar ? 4 : 8) > 4096) return 0;       // up-backward sends (classes x Cout) channels of dy through the zero page
+    if (C0 <= 0 || C1 < 0 || Cout * (planar ? 4 : 8) * (dtype == FMRI_F32 ? 2 : 1) > 4096) return 0;       // up-backward sends (classes x Cout) channels of dy through the zero page
     // C1 = 0: a convolution of a purely up-sampled tensor (reference isensee2017.py:101-104 create_up_sampling_module)
     if (conv3d_fwd_needs_cube(Dl, H / 2, W / 2) || conv3d_fwd_needs_cube(D, H, W)) return 0;      // the parity launches use the 4x8x16 tiling
     const bool fb = conv3d_fwd_mfma_ok(C0, 0, Cout, Dl, H / 2, W / 2, dtype) && conv3d_fwd_mfma_ok(Cout, 0, C0, Dl, H / 2, W / 2, dtype) &&
                     (C1 == 0 || (conv3d_fwd_mfma_ok(C1, 0, Cout, D, H, W, dtype) && conv3d_fwd_mfma_ok(Cout, 0, C1, D, H, W, dtype)));
-    const bool wg_ = conv3d_wgrad_mfma_ok(C0, 0, Cout, Dl, H / 2, W / 2, dtype) && (C1 == 0 || conv3d_wgrad_mfma_ok(C1, 0, Cout, D, H, W, dtype));
+    // (fp32: the parity-form weight gradient is not built - the 27-tap kernel with the fused up-sampled source takes the launch)
+    const bool wg_ = dtype == FMRI_BF16 && conv3d_wgrad_mfma_ok(C0, 0, Cout, Dl, H / 2, W / 2, dtype) && (C1 == 0 || conv3d_wgrad_mfma_ok(C1, 0, Cout, D, H, W, dtype));
     return (fb ? 1 : 0) | (fb && wg_ ? 2 : 0);
 }
 
@@ -222,13 +226,13 @@ int upcat_fwd(const void* src0_low, int C0, const void* src1, int C1, const void
     const int Dl = planar ? D : D / 2;
     if (C1 == 0)        // nothing to add: the parity launch finishes the output itself
         return conv3d_fwd_mfma_ex(1, src0_low, C0, 0, planar, nullptr, 0, w_up_fwd, bias, nullptr, nullptr, y, N, Dl, H / 2, W / 2, Cout, act, alpha,
-                                  as_stream(stream));
+                                  dtype, as_stream(stream));
     // 1. partial sums of the up-sampled channels, scattered by parity class into y
     int rc = conv3d_fwd_mfma_ex(1, src0_low, C0, 0, planar, nullptr, 0, w_up_fwd, nullptr, nullptr, nullptr, y, N, Dl, H / 2, W / 2, Cout,
-                                FMRI_ACT_NONE, 0.f, as_stream(stream));
+                                FMRI_ACT_NONE, 0.f, dtype, as_stream(stream));
     if (rc) return rc;
     // 2. plain conv over the skip channels; its epilogue adds the partial sums (in place), the bias, and applies the activation
-    return conv3d_fwd_mfma_ex(0, src1, C1, 0, planar, nullptr, 0, w_skip_fwd, bias, nullptr, y, y, N, D, H, W, Cout, act, alpha, as_stream(stream));
+    return conv3d_fwd_mfma_ex(0, src1, C1, 0, planar, nullptr, 0, w_skip_fwd, bias, nullptr, y, y, N, D, H, W, Cout, act, alpha, dtype, as_stream(stream));
 }
 
 int upcat_dgrad(const void* dy, int Cout, const void* w_up_dgrad, const void* w_skip_dgrad, const void* mask_low, const void* mask_skip,
@@ -240,11 +244,11 @@ int upcat_dgrad(const void* dy, int Cout, const void* w_up_dgrad, const void* w_
         return FMRI_E_ALIGN;
     // gradient of the low-res tensor: one launch over the space-to-depth view of dy (parity classes x Cout channels, mirrored taps)
     int rc = conv3d_fwd_mfma_ex(2, dy, Cout, 0, planar, nullptr, 0, w_up_dgrad, nullptr, mask_low, nullptr, dx_low, N, planar ? D : D / 2, H / 2,
-                                W / 2, C0, FMRI_ACT_NONE, 0.f, as_stream(stream));
+                                W / 2, C0, FMRI_ACT_NONE, 0.f, dtype, as_stream(stream));
     if (rc || C1 == 0) return rc;
     // gradient of the skip tensor: the plain tap-flipped transposed convolution restricted to the skip rows
     return conv3d_fwd_mfma_ex(0, dy, Cout, 0, planar, nullptr, 0, w_skip_dgrad, nullptr, mask_skip, nullptr, dx_skip, N, D, H, W, C1, FMRI_ACT_NONE,
-                              0.f, as_stream(stream));
+                              0.f, dtype, as_stream(stream));
 }
 
 int upcat_wgrad(const void* src0_low, int C0, const void* src1, int C1, const void* dy, float* dw, float* db, float* dwc_scratch, int N, int D,
@@ -313,9 +317,9 @@ extern "C" int fmri_conv3d_upcat_fwd_bias27(const void* src0_low, int C0, const 
     if (!(upcat_ok(C0, C1, Cout, D, H, W, dtype, 0) & 1)) return FMRI_E_SHAPE;
     if ((((uintptr_t)src0_low) | ((uintptr_t)src1) | ((uintptr_t)w_up_fwd) | ((uintptr_t)w_skip_fwd) | ((uintptr_t)y) | ((uintptr_t)bias27)) & 15) return FMRI_E_ALIGN;
     int rc = conv3d_fwd_mfma_ex(1, src0_low, C0, 0, 0, nullptr, 0, w_up_fwd, nullptr, nullptr, nullptr, y, N, D / 2, H / 2, W / 2, Cout, FMRI_ACT_NONE, 0.f,
-                                as_stream(stream));
+                                dtype, as_stream(stream));
     if (rc) return rc;
-    return conv3d_fwd_mfma_res_b27(src1, C1, w_skip_fwd, bias27, y, y, N, D, H, W, Cout, act, alpha, as_stream(stream));
+    return conv3d_fwd_mfma_res_b27(src1, C1, w_skip_fwd, bias27, y, y, N, D, H, W, Cout, act, alpha, dtype, as_stream(stream));
 }
 extern "C" int fmri_conv3d_upcat_wgrad_parts(const void* src0_low, int C0, const void* src1, int C1, const void* dy, float* dw, float* db,
                                              float* dwc, int N, int D, int H, int W, int Cout, int dtype, void* workspace, int64_t workspace_bytes,
@@ -374,7 +378,7 @@ extern "C" int fmri_conv3d_upcat_fwd_stats(const void* src0_low, int C0, const v
     const int nent = (per_instance ? N : 1) * Cout * 2, nslot = conv3d_fwd_ntail_slots();
     int rc;
     rc = conv3d_fwd_mfma_ex(1, src0_low, C0, 0, 0, nullptr, 0, w_up_fwd, nullptr, nullptr, nullptr, y, N, D / 2, H / 2, W / 2, Cout, FMRI_ACT_NONE, 0.f,
-                            as_stream(stream));
+                            dtype, as_stream(stream));
     if (rc) return rc;
     rc = conv3d_fwd_mfma_ntail(0, src1, C1, 0, nullptr, 0, w_skip_fwd, bias, y, y, N, D, H, W, Cout, act, alpha, ws, per_instance, nullptr,
                                as_stream(stream));
@@ -421,7 +425,7 @@ extern "C" int fmri_conv3d_stride2_fwd(const void* x, int Cin, const void* w_s2_
     if (!(upcat_ok(Cout, 0, Cin, D, H, W, dtype, 0) & 1)) return FMRI_E_SHAPE;
     if ((((uintptr_t)x) | ((uintptr_t)w_s2_fwd) | ((uintptr_t)y) | ((uintptr_t)bias)) & 15) return FMRI_E_ALIGN;
     return conv3d_fwd_mfma_ex(2, x, Cin, 0, 0, nullptr, 0, w_s2_fwd, bias, nullptr, nullptr, y, N, D / 2, H / 2, W / 2, Cout, FMRI_ACT_NONE, 0.f,
-                              as_stream(stream));
+                              dtype, as_stream(stream));
 }
 extern "C" int fmri_conv3d_upcat_wgrad(const void* src0_low, int C0, const void* src1, int C1, const void* dy, float* dw, float* db,
                                        float* dwc_scratch, int N, int D, int H, int W, int Cout, int dtype, void* workspace,

@@ -621,12 +621,21 @@ k_conv_fwd_mfma(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__
 // as ONE k-step.  LDS bytes per MAC are the same ((M + N) * K); what changes is the energy per MAC: on live data the chip is power-limited
 //  and holds a higher clock on this shape (MI355X guide, 'DVFS give-back' item 7).  A 16-lane group of a fragment read is one
 // h-row of the halo at one 16-byte slot - the access pattern the column-keyed swizzle was derived for - and no row rotation is needed.
-template <int NT, bool PL, int MODE, bool RES, bool ASYNC = false, int EPI = -1, bool FH = false, bool S16 = false>   // FH: fast halo addressing (producers, below)
+// F32 (round 6, the parity mode on the benchmarked kernel structure): fp32 tensors and filters on v_mfma_f32_32x32x2_f32 (exact fp32: the
+// guide's chip table - an fmaf chain per output).  A 64-byte halo / filter row is then 16 fp32 channels instead of 32 bf16 ones and everything
+// that moves or addresses BYTES is unchanged: the launcher passes every channel count that is a memory stride in units of 2 bytes (s.C0, s.C1 =
+// twice the real counts; `Cout` stays the real count of filter rows, CoutB = 2 Cout is the voxel stride of y / mask / residual / pool), so halo
+// box, LDS-DMA pieces, swizzle, rings, phases, barriers, the asynchronous drain and its tails are the instructions of the bf16 launch.  What
+// differs: a 16-byte fragment is 4 k-values per lane instead of 8 - four MFMAs of k = 2 in place of one of k = 16 - the staged tile holds fp32
+// (NT = 1: 32 channels x 4 B = the 128-byte voxel line of the 64-wide bf16 block), and the element-wise tails (ReLU mask, residual, pool)
+// work on floats.
+template <int NT, bool PL, int MODE, bool RES, bool ASYNC = false, int EPI = -1, bool FH = false, bool S16 = false, bool F32 = false>   // FH: fast halo addressing (producers, below)
 __global__ void __launch_bounds__(fw::NTHREADS)
 k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ bias, const bf16_t* __restrict__ mask,
               const bf16_t* residual, bf16_t* y, int N, int D, int H, int W, int Cout, int act, float alpha, FwdTail tail) {
     constexpr int TD = fw::TD, TH = fw::TH, TW = fw::TW;
     static_assert(!(RES && MODE != 0), "unsupported combination");
+    static_assert(!F32 || (NT == 1 && !PL && !RES && !S16 && EPI < 4 && EPI != 2), "fp32 form: 32-wide blocks, 3-D, asynchronous residual, no logits / normalisation tails");
     constexpr bool PAR = MODE != 0;
     // TIGHT (round 3; the 3-D parity modes): a parity class reads, per axis, only the low-res voxels {g-1, g} or {g, g+1} - a
     // (TD+1) x (TH+1) x (TW+1) box whose origin depends on the parity, not the 6 x 10 x 18 box of the 3-tap conv: 765 instead of 1080 rows,
@@ -641,6 +650,7 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
     constexpr int HALO_STRIDE = TIGHT ? STAGE_BYTES : HALO_BYTES;
     constexpr int HALO_SPAN = HALO_STRIDE + HALO_BYTES;          // bytes of the halo / stage area
     constexpr int BN = 32 * NT;
+    constexpr int BNB = F32 ? 2 * BN : BN;           // the block's width in 2-byte units: bytes of a staged / stored voxel line = 2 * BNB
     constexpr int NKW = PAR ? 2 : 3;
     // TIGHT also has LDS to spare (2 x 48 + 16 KiB of halo / stage): a phase covers RPP = 2 (kd', kh') filter rows - 64 instead of 32 MFMAs
     // per wave and barrier, 2 phases per chunk - with 16 KiB filter slots (BN = 64)
@@ -660,7 +670,7 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
     static_assert(NPH * RPP == NROW, "rows per phase");
     constexpr int PH0 = PL ? 3 : 0;
     constexpr bool ASY = ASYNC && !RES && !PL && MODE == 0;
-    constexpr bool HAS_MASK = EPI < 0 || EPI == 1, HAS_LOGITS = EPI < 0 || EPI == 2, HAS_POOL = EPI <= 0;
+    constexpr bool HAS_MASK = EPI < 0 || EPI == 1, HAS_LOGITS = !F32 && (EPI < 0 || EPI == 2), HAS_POOL = EPI <= 0;
     // EPI 3 (ASYNC only): y = act(staged + residual) - the skip launch of the parity form.  The MFMA waves stage bf16(acc + bias) WITHOUT the
     // activation; the producers add the residual lines (prefetched like the mask lines) in fp32, activate, round and store.  One bf16 rounding
     // more than the RES epilogue (which adds the residual to the fp32 accumulators): both partial sums of the parity form - the up-sampled
@@ -684,7 +694,7 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
     // than the synchronous epilogue); the halo pieces of that item's successor follow in phases DP .. NPH-2
     constexpr int DP = ASY ? 4 : 0;
     static_assert(!ASY || NPH >= DP + 3, "asynchronous epilogue: phases DP .. NPH-2 carry the halo pieces");
-    static_assert(4 * 32 * JT * BN * 2 <= (TIGHT ? STAGE_BYTES : HALO_BYTES) && 4 * 32 * BN * 4 <= (TIGHT ? STAGE_BYTES : HALO_BYTES),
+    static_assert(4 * 32 * JT * BNB * 2 <= (TIGHT ? STAGE_BYTES : HALO_BYTES) && 4 * 32 * BN * 4 <= (TIGHT ? STAGE_BYTES : HALO_BYTES),
                   "epilogue staging must fit the consumed halo slot (+ gap)");
     static_assert(!TIGHT || HALO_BYTES + STAGE_BYTES - HALO_BYTES <= HALO_STRIDE, "stage of slot 0 must end where slot 1 begins");
     __shared__ __attribute__((aligned(16))) unsigned char lds[HALO_SPAN + 2 * FILT_BYTES];
@@ -698,6 +708,7 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
     const int ncb = MODE == 1 ? NPAR * cbn : cbn;
     const int twn = W / TW, thn = H / TH, tdn = D / TD;
     const int npairs = N * tdn * thn * twn * ncb;
+    const int CoutB = F32 ? 2 * Cout : Cout;         // voxel stride of y / mask / residual / pool in 2-byte units
 
     const int t = threadIdx.x, lane = t & 63;
     const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -753,7 +764,7 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
     constexpr unsigned long long HKEY = HW == 18 ? 0xfa50fa50ull /* (hw >> 1) & 3 */ : 0x267fe640ull /* HW = 17 (TIGHT): 0 0 0 1 2 1 2 3 3 3 3 1 2 1 2 0 0 */;
     static_assert(HW == 18 || HW == 17, "halo width");
     auto halo_key = [](int hw) { return (int)((HKEY >> (2 * hw)) & 3); };
-    constexpr int CPV_ = BN / 8;                     // 16-byte pieces per voxel
+    constexpr int CPV_ = BNB / 8;                    // 16-byte pieces per voxel
     constexpr int VPI_ = 64 / CPV_;                  // voxels per store instruction
     // address in y (and in the mask / residual) of piece q of tile voxel v (column tile v >> 5, lane v & 31):
     // wave-uniform tile origin (64-bit, scalar registers) + 32-bit lane offset - as one 64-bit sum per lane hipcc hoisted a sign-extended
@@ -763,14 +774,14 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
         int64_t org;
         unsigned off;
         if constexpr (MODE == 1 && PL) {
-            org = ((((int64_t)it.n * D + it.d0) * 2 * H + 2 * it.h0 + ((it.par >> 1) & 1)) * 2 * W + 2 * it.w0 + (it.par & 1)) * Cout + it.co0;
-            off = ((tile_d(rt) * 2 * H + 2 * tile_h(rt, rr)) * 2 * W + 2 * lane_w(rr)) * Cout + q * 8;
+            org = ((((int64_t)it.n * D + it.d0) * 2 * H + 2 * it.h0 + ((it.par >> 1) & 1)) * 2 * W + 2 * it.w0 + (it.par & 1)) * CoutB + (F32 ? 2 : 1) * it.co0;
+            off = ((tile_d(rt) * 2 * H + 2 * tile_h(rt, rr)) * 2 * W + 2 * lane_w(rr)) * CoutB + q * 8;
         } else if constexpr (MODE == 1) {
-            org = ((((int64_t)it.n * 2 * D + 2 * it.d0 + (it.par >> 2)) * 2 * H + 2 * it.h0 + ((it.par >> 1) & 1)) * 2 * W + 2 * it.w0 + (it.par & 1)) * Cout + it.co0;
-            off = ((2 * tile_d(rt) * 2 * H + 2 * tile_h(rt, rr)) * 2 * W + 2 * lane_w(rr)) * Cout + q * 8;
+            org = ((((int64_t)it.n * 2 * D + 2 * it.d0 + (it.par >> 2)) * 2 * H + 2 * it.h0 + ((it.par >> 1) & 1)) * 2 * W + 2 * it.w0 + (it.par & 1)) * CoutB + (F32 ? 2 : 1) * it.co0;
+            off = ((2 * tile_d(rt) * 2 * H + 2 * tile_h(rt, rr)) * 2 * W + 2 * lane_w(rr)) * CoutB + q * 8;
         } else {
-            org = ((((int64_t)it.n * D + it.d0) * H + it.h0) * W + it.w0) * Cout + it.co0;
-            off = ((tile_d(rt) * H + tile_h(rt, rr)) * W + lane_w(rr)) * Cout + q * 8;
+            org = ((((int64_t)it.n * D + it.d0) * H + it.h0) * W + it.w0) * CoutB + (F32 ? 2 : 1) * it.co0;
+            off = ((tile_d(rt) * H + tile_h(rt, rr)) * W + lane_w(rr)) * CoutB + q * 8;
         }
         return reinterpret_cast<const char*>(base + org) + (off * 2u);
     };
@@ -863,15 +874,15 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
         constexpr int CPV = CPV_, VPI = VPI_;
         constexpr int NIT = 512 / (NW * VPI);        // store instructions per wave
         static_assert(NIT % NPARTS == 0, "parts");
-        constexpr int SWM = NT == 2 ? 7 : 3;
+        constexpr int SWM = BNB == 64 ? 7 : 3;
         const unsigned char* const stage = lds + slot * HALO_BYTES;
         if constexpr (HAS_SUMS && PART == 0) nsum_group(it);
         constexpr bool FD = FASTD && NW == 4;
         const int ln = lane;
         // (FD: the swizzle term of the staged voxel depends on the lane only - v & 7 = (lane / 8) & 7, (v >> 2) & 3 = (lane / 16) & 3 - so a
         // lane reads all its lines from one LDS address + immediate offsets)
-        const int vs_l = NT == 2 ? ((lane / CPV) & 7) : (((lane / CPV) >> 2) & 3);
-        const unsigned char* const stage_l = stage + (lane / CPV) * (BN * 2) + ((((lane % CPV) ^ vs_l) & SWM) << 4);
+        const int vs_l = BNB == 64 ? ((lane / CPV) & 7) : (((lane / CPV) >> 2) & 3);
+        const unsigned char* const stage_l = stage + (lane / CPV) * (BNB * 2) + ((((lane % CPV) ^ vs_l) & SWM) << 4);
         auto gp = [&](const bf16_t* base, int kk, int v, int q) -> const char* {
             if constexpr (FD) return line_ptr(base, it, w, kk);
             else return piece_ptr(base, it, v, q);
@@ -879,10 +890,10 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
 #pragma unroll
         for (int kk = PART * (NIT / NPARTS); kk < (PART + 1) * (NIT / NPARTS); ++kk) {
             const int v = w * (512 / NW) + kk * VPI + ln / CPV, q = ln % CPV;       // tile-wide voxel index: column tile v >> 5, lane v & 31
-            const int vs = NT == 2 ? (v & 7) : ((v >> 2) & 3);
+            const int vs = BNB == 64 ? (v & 7) : ((v >> 2) & 3);
             uint4 o4;
-            if constexpr (FD) o4 = *reinterpret_cast<const uint4*>(stage_l + (w * (512 / NW) + kk * VPI) * (BN * 2));
-            else o4 = *reinterpret_cast<const uint4*>(stage + v * (BN * 2) + (((q ^ vs) & SWM) << 4));
+            if constexpr (FD) o4 = *reinterpret_cast<const uint4*>(stage_l + (w * (512 / NW) + kk * VPI) * (BNB * 2));
+            else o4 = *reinterpret_cast<const uint4*>(stage + v * (BNB * 2) + (((q ^ vs) & SWM) << 4));
             const int rt = v >> 5, rr = v & 31;
             if (HAS_MASK && mask) {
                 uint4 m4;
@@ -890,10 +901,15 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
                 else m4 = *reinterpret_cast<const uint4*>(gp(mask, kk, v, q));
                 const unsigned mm[4] = {m4.x, m4.y, m4.z, m4.w};
                 unsigned* const oo = reinterpret_cast<unsigned*>(&o4);
+                if constexpr (F32) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) oo[i] = __uint_as_float(mm[i]) > 0.f ? oo[i] : 0u;       // four floats: dx = y > 0 ? dx : 0
+                } else {
                 unsigned z2 = 0u, o2 = 0x00010001u;
                 asm volatile("" : "+v"(z2), "+v"(o2));          // two registers for the whole drain, not an immediate per instruction
 #pragma unroll
                 for (int i = 0; i < 4; ++i) oo[i] &= pos_mask2(mm[i], z2, o2);
+                }
             }
             if constexpr (HAS_RESID) {
                 uint4 r4;
@@ -901,6 +917,14 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
                 else r4 = *reinterpret_cast<const uint4*>(gp(residual, kk, v, q));
                 const unsigned rr4[4] = {r4.x, r4.y, r4.z, r4.w};
                 unsigned* const oo = reinterpret_cast<unsigned*>(&o4);
+                if constexpr (F32) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        float vv = __uint_as_float(oo[i]) + __uint_as_float(rr4[i]);
+                        vv = vmax(vv, __builtin_fmaf(vv, act_s, 0.f));
+                        oo[i] = __float_as_uint(vv);
+                    }
+                } else
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     float lo = __uint_as_float(oo[i] << 16) + __uint_as_float(rr4[i] << 16);
@@ -983,9 +1007,13 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
                         const int d = 2 * pd + (c >> 2), h = 2 * ph + ((c >> 1) & 1), w_ = 2 * pw + (c & 1);
                         // inverse of (tile_d, tile_h, lane_w): column tile rt = d*4 + h/2, lane rr = (h&1)*16 + (w rotated by HW mod 16 on odd rows)
                         const int v = (d * 4 + (h >> 1)) * 32 + ((h & 1) ? 16 + ((w_ + (HW & 15)) & 15) : w_);
-                        const int vs = NT == 2 ? (v & 7) : ((v >> 2) & 3);
-                        const uint4 p4 = *reinterpret_cast<const uint4*>(stage + v * (BN * 2) + (((q ^ vs) & SWM) << 4));
+                        const int vs = BNB == 64 ? (v & 7) : ((v >> 2) & 3);
+                        const uint4 p4 = *reinterpret_cast<const uint4*>(stage + v * (BNB * 2) + (((q ^ vs) & SWM) << 4));
                         const unsigned pp[4] = {p4.x, p4.y, p4.z, p4.w};
+                        if constexpr (F32) {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) mx[i] = c == 0 ? __uint_as_float(pp[i]) : vmax(mx[i], __uint_as_float(pp[i]));
+                        } else
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
                             const float lo = __uint_as_float(pp[i] << 16), hi = __uint_as_float(pp[i] & 0xffff0000u);
@@ -994,12 +1022,15 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
                         }
                     }
                     uint4 o;
+                    if constexpr (F32) o = make_uint4(__float_as_uint(mx[0]), __float_as_uint(mx[1]), __float_as_uint(mx[2]), __float_as_uint(mx[3]));
+                    else {
                     o.x = (__float_as_uint(mx[0]) >> 16) | (__float_as_uint(mx[1]) & 0xffff0000u);
                     o.y = (__float_as_uint(mx[2]) >> 16) | (__float_as_uint(mx[3]) & 0xffff0000u);
                     o.z = (__float_as_uint(mx[4]) >> 16) | (__float_as_uint(mx[5]) & 0xffff0000u);
                     o.w = (__float_as_uint(mx[6]) >> 16) | (__float_as_uint(mx[7]) & 0xffff0000u);
-                    const int64_t po = ((((int64_t)it.n * (D >> 1) + (it.d0 >> 1) + pd) * (H >> 1) + (it.h0 >> 1) + ph) * (W >> 1) + (it.w0 >> 1) + pw) * Cout +
-                                       it.co0 + q * 8;
+                    }
+                    const int64_t po = ((((int64_t)it.n * (D >> 1) + (it.d0 >> 1) + pd) * (H >> 1) + (it.h0 >> 1) + ph) * (W >> 1) + (it.w0 >> 1) + pw) * CoutB +
+                                       (F32 ? 2 : 1) * it.co0 + q * 8;
                     if (live) *reinterpret_cast<uint4*>(tail.pool + po) = o;
                 }
             }
@@ -1633,7 +1664,13 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
 #pragma unroll
                     for (int c = 0; c < CN; ++c) {
                         if constexpr (S16) acc[j][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa_[ab][c], fb_[0][j % NBR], acc[j][c], 0, 0, 0);
-                        else acc[j][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_[ab][c], fb_[ab][j], acc[j][c], 0, 0, 0);
+                        else if constexpr (F32) {
+                            // the 16 bytes of a fragment are four fp32 k-values: lanes 0-31 hold channels 8 ks + i, lanes 32-63 channels
+                            // 8 ks + 4 + i of the same row - the two k of MFMA i, in both operands alike
+                            const f32x4 af = __builtin_bit_cast(f32x4, fa_[ab][c]), bf = __builtin_bit_cast(f32x4, fb_[ab][j]);
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) acc[j][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[i], acc[j][c], 0, 0, 0);
+                        } else acc[j][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_[ab][c], fb_[ab][j], acc[j][c], 0, 0, 0);
                     }
                     if constexpr (S16) {
                         // the fragment NBR blocks on takes this one's place: of this step while it has them, else of the next one
@@ -1736,13 +1773,13 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
             // the consumed halo slot), line-major stores
             constexpr int CPV = BN / 8;                  // 16-byte pieces per voxel
             constexpr int VPI = 64 / CPV;                // voxels per store instruction
-            constexpr int SWM = NT == 2 ? 7 : 3;
+            constexpr int SWM = BNB == 64 ? 7 : 3;
             float4 bvn[NT][4];
             load_bias(has_next ? nxt.co0 : cur.co0, bvn);
             PROF_T(e0);
             __builtin_amdgcn_s_barrier();
             PROF_T(e1);
-            unsigned char* const stage = lds + hb * HALO_BYTES + cw * (32 * JT * BN * 2);
+            unsigned char* const stage = lds + hb * HALO_BYTES + cw * (32 * JT * BNB * 2);
             // the activation is a launch constant: none (every input-gradient launch) costs nothing, ReLU one v_max per value, LeakyReLU two
             // operations - the general max(v, alpha * v) form for all three spent 256 VALU instructions per tile and wave on the identity
             auto stage_tile = [&](auto act_tag) {
@@ -1784,6 +1821,27 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
                             }
                             const int q = p * 4 + ((kq & 1) << 1) + (kq >> 1);
                             *reinterpret_cast<uint4*>(stage + v * (BN * 2) + (((q ^ vs) & SWM) << 4)) = make_uint4(pk[0][0], pk[0][1], pk[1][0], pk[1][1]);
+                        }
+                    }
+                } else if constexpr (F32) {
+                    // a lane's registers 4 gq .. 4 gq + 3 are channels 8 gq + 4 hk .. + 3 of its voxel: one 16-byte piece (number 2 gq + hk of the
+                    // voxel's eight) as they are - no packing, no half-wave exchange
+#pragma unroll
+                    for (int j = 0; j < JT; ++j) {
+                        const int v = j * 32 + r;
+                        const int vs = v & 7;
+#pragma unroll
+                        for (int gq = 0; gq < 4; ++gq) {
+                            float o[4];
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                const float vv = acc[j][0][4 * gq + i];
+                                if constexpr (ACT == FMRI_ACT_LEAKY) o[i] = vmax(vv, __builtin_fmaf(vv, act_s, 0.f));
+                                else if constexpr (ACT == FMRI_ACT_RELU) o[i] = vmax(vv, 0.f);
+                                else o[i] = vv;
+                            }
+                            const int q = 2 * gq + hk;
+                            *reinterpret_cast<float4*>(stage + v * (BNB * 2) + (((q ^ vs) & SWM) << 4)) = make_float4(o[0], o[1], o[2], o[3]);
                         }
                     }
                 } else
@@ -1888,8 +1946,22 @@ k_conv_fwd_ws(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ b
 }  // namespace
 
 // --------------------------------------------------------------------------------------------------------- host dispatch
+static int fwd_f32_mfma() {             // FMRI_F32_MFMA=0: fp32 tensors stay on the VALU kernels of conv3d_generic.hip (rounds 1-5)
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("FMRI_F32_MFMA");
+        v = e ? atoi(e) : 1;
+    }
+    return v;
+}
 bool conv3d_fwd_mfma_ok(int C0, int C1, int Cout, int D, int H, int W, int dtype) {
-    if (dtype != FMRI_BF16) return false;
+    if (dtype == FMRI_F32) {
+        // fp32 on v_mfma_f32_32x32x2_f32 (k_conv_fwd_ws<..., F32>): 16-channel chunks (64-byte rows), 32-wide Cout blocks, the 4x8x16 tiling
+        if (!fwd_f32_mfma() || (C0 % 16) || (C1 % 16) || C0 + C1 < 16 || (Cout % 32)) return false;
+        if ((D % fw::TD) || (H % fw::TH) || (W % fw::TW)) return false;
+        C0 *= 2;                                         // everything below counts 2-byte units
+        C1 *= 2;
+    } else if (dtype != FMRI_BF16) return false;
     if ((C0 % 32) || (C1 % 32) || C0 + C1 < 32 || (Cout % 32)) return false;
     if (C0 + C1 > 4096) return false;                    // zero-page length (see g_zero_page)
     // buffer-descriptor LDS-DMA (dma16_buf): a lane's 32-bit byte offset from the item's box corner must stay below DMA_OOB = 2^31, or a
@@ -1944,9 +2016,48 @@ static bool fwd_wide(int mode, int planar, int ntile, int Cout) {
     return Cout % 64 == 0 && (int64_t)ntile * (Cout / 64) * (mode == 1 ? (planar ? 4 : 8) : 1) >= fwd_cu_count();
 }
 
+// fp32 launches: 32-wide Cout blocks, asynchronous epilogue throughout (plain store / pooled copy, ReLU mask, residual), parity modes on the
+// tight box; channel counts that are memory strides go in as 2-byte units (see k_conv_fwd_ws, F32)
+static int conv3d_fwd_mfma_launch_f32(int mode, const void* src0, int C0, int up0, int planar, const void* src1, int C1, const void* w,
+                                      const float* bias, const void* mask, const void* residual, void* y, int N, int D, int H, int W, int Cout,
+                                      int act, float alpha, FwdTail tail, hipStream_t st) {
+    if (planar || (D % fw::TD) || (H % fw::TH) || (W % fw::TW) || tail.logits || tail.nws) return FMRI_E_SHAPE;
+    if (mode != 0 && (C1 != 0 || up0)) return FMRI_E_SHAPE;
+    SrcB s{(const bf16_t*)src0, (const bf16_t*)src1, 2 * C0, 2 * C1, up0, 1, 0};
+    const int ntile = N * (D / fw::TD) * (H / fw::TH) * (W / fw::TW);
+    const int ncu = fwd_cu_count();
+    const int np = ntile * (Cout / 32) * (mode == 1 ? 8 : 1);
+    const int grid = np < ncu ? np : ncu;
+    const bool fh = fwd_fast_halo() && C1 == 0 && !up0;
+    tail.prio = 0;
+#define FMRI_F32K(MODE_, A_, EPI_, FH_)                                                                                   \
+    k_conv_fwd_ws<1, false, MODE_, false, A_, EPI_, FH_, false, true><<<grid, fw::NTHREADS, 0, st>>>(                     \
+        s, (const bf16_t*)w, bias, (const bf16_t*)mask, (const bf16_t*)residual, (bf16_t*)y, N, D, H, W, Cout, act, alpha, tail)
+    if (mode == 1) {
+        if (mask || residual || tail.pool) return FMRI_E_SHAPE;
+        FMRI_F32K(1, false, -1, true);
+    } else if (mode == 2) {
+        if (residual || tail.pool) return FMRI_E_SHAPE;
+        FMRI_F32K(2, false, -1, true);
+    } else if (residual) {
+        if (mask || tail.pool) return FMRI_E_SHAPE;
+        if (fh) FMRI_F32K(0, true, 3, true); else FMRI_F32K(0, true, 3, false);
+    } else if (mask) {
+        if (tail.pool) return FMRI_E_SHAPE;
+        if (fh) FMRI_F32K(0, true, 1, true); else FMRI_F32K(0, true, 1, false);
+    } else {
+        if (fh) FMRI_F32K(0, true, 0, true); else FMRI_F32K(0, true, 0, false);
+    }
+#undef FMRI_F32K
+    FMRI_LAUNCH_CHECK();
+    return FMRI_OK;
+}
+
 static int conv3d_fwd_mfma_launch(int mode, const void* src0, int C0, int up0, int planar, const void* src1, int C1, const void* w,
                                   const float* bias, const void* mask, const void* residual, void* y, int N, int D, int H, int W, int Cout,
-                                  int act, float alpha, FwdTail tail, hipStream_t st) {
+                                  int act, float alpha, FwdTail tail, int dtype, hipStream_t st) {
+    if (dtype == FMRI_F32)
+        return conv3d_fwd_mfma_launch_f32(mode, src0, C0, up0, planar, src1, C1, w, bias, mask, residual, y, N, D, H, W, Cout, act, alpha, tail, st);
     SrcB s{(const bf16_t*)src0, (const bf16_t*)src1, C0, C1, up0, planar ? 0 : 1, planar};
     // the parity modes form a fresh halo pointer as [one plain source] + box corner + lane constant (CHEAP_FRESH / FH): a second source or a
     // fused up-sampling there would read wrong addresses instead of failing
@@ -2068,29 +2179,30 @@ static int conv3d_fwd_mfma_launch(int mode, const void* src0, int C0, int up0, i
     return FMRI_OK;
 }
 int conv3d_fwd_mfma_ex(int mode, const void* src0, int C0, int up0, int planar, const void* src1, int C1, const void* w, const float* bias,
-                       const void* mask, const void* residual, void* y, int N, int D, int H, int W, int Cout, int act, float alpha,
+                       const void* mask, const void* residual, void* y, int N, int D, int H, int W, int Cout, int act, float alpha, int dtype,
                        hipStream_t st) {
     return conv3d_fwd_mfma_launch(mode, src0, C0, up0, planar, src1, C1, w, bias, mask, residual, y, N, D, H, W, Cout, act, alpha,
-                                  FwdTail{nullptr, nullptr, nullptr, nullptr, nullptr}, st);
+                                  FwdTail{nullptr, nullptr, nullptr, nullptr, nullptr}, dtype, st);
 }
 // bit 0: the 2x2x2 max-pooled copy can be produced by the conv's epilogue, bit 1: the final 1x1x1 conv to one label can (plain 3-D
 // warp-specialised launch on the 4x8x16 tiling; the logits need the voxel's whole channel range in one workgroup: Cout == block width)
 int conv3d_fwd_tail_ok(int C0, int Cout, int N, int D, int H, int W, int dtype) {
     if (!conv3d_fwd_mfma_ok(C0, 0, Cout, D, H, W, dtype) || conv3d_fwd_needs_cube(D, H, W) || fwd_use_ws() == 0) return 0;
+    if (dtype == FMRI_F32) return 1;                     // the pooled copy rides the fp32 drain; the logits need a 64-wide block
     const int ntile = N * (D / fw::TD) * (H / fw::TH) * (W / fw::TW);
     const int bn = fwd_wide(0, 0, ntile, Cout) ? 64 : 32;
     return 1 | (Cout == bn ? 2 : 0);
 }
 int conv3d_fwd_mfma_tail(const void* src0, int C0, const void* w, const float* bias, void* y, void* pool, const float* w1, const float* b1,
-                         float* logits, int N, int D, int H, int W, int Cout, int act, float alpha, hipStream_t st) {
-    const int ok = conv3d_fwd_tail_ok(C0, Cout, N, D, H, W, FMRI_BF16);
+                         float* logits, int N, int D, int H, int W, int Cout, int act, float alpha, int dtype, hipStream_t st) {
+    const int ok = conv3d_fwd_tail_ok(C0, Cout, N, D, H, W, dtype);
     if ((pool && !(ok & 1)) || (logits && (!(ok & 2) || !w1 || !b1))) return FMRI_E_SHAPE;
     return conv3d_fwd_mfma_launch(0, src0, C0, 0, 0, nullptr, 0, w, bias, nullptr, nullptr, y, N, D, H, W, Cout, act, alpha,
-                                  FwdTail{(bf16_t*)pool, w1, b1, logits, nullptr}, st);
+                                  FwdTail{(bf16_t*)pool, w1, b1, logits, nullptr}, dtype, st);
 }
 // can this plain 3-D launch carry a normalisation tail (statistics of its output / the backward reductions in its asynchronous epilogue)?
 int conv3d_fwd_ntail_ok(int C0, int C1, int Cout, int N, int D, int H, int W, int dtype) {
-    if (!conv3d_fwd_mfma_ok(C0, C1, Cout, D, H, W, dtype) || conv3d_fwd_needs_cube(D, H, W) || !fwd_use_ws() || !fwd_async()) return 0;
+    if (dtype != FMRI_BF16 || !conv3d_fwd_mfma_ok(C0, C1, Cout, D, H, W, dtype) || conv3d_fwd_needs_cube(D, H, W) || !fwd_use_ws() || !fwd_async()) return 0;
     const int ntile = N * (D / fw::TD) * (H / fw::TH) * (W / fw::TW);
     return ntile * (Cout / (fwd_wide(0, 0, ntile, Cout) ? 64 : 32)) > fwd_cu_count();
 }
@@ -2108,17 +2220,17 @@ int conv3d_fwd_mfma_ntail(int kind, const void* src0, int C0, int up0, const voi
     t.n_grp = per_instance ? N : 1;
     if (kind == 1) t.nss = nss;
     return conv3d_fwd_mfma_launch(0, src0, C0, up0, 0, src1, C1, w, bias, kind == 1 ? lines : nullptr, kind == 1 ? nullptr : lines, y, N, D, H, W,
-                                  Cout, act, alpha, t, st);
+                                  Cout, act, alpha, t, FMRI_BF16, st);
 }
 // plain 3-D conv whose epilogue adds `residual` and whose bias depends on the output voxel's border class (FwdTail::bias27); only the
 // warp-specialised kernel implements it
 int conv3d_fwd_mfma_res_b27(const void* src, int C, const void* w, const float* bias27, const void* residual, void* y, int N, int D, int H,
-                            int W, int Cout, int act, float alpha, hipStream_t st) {
+                            int W, int Cout, int act, float alpha, int dtype, hipStream_t st) {
     if (!fwd_use_ws() || !bias27 || !residual) return FMRI_E_SHAPE;
     return conv3d_fwd_mfma_launch(0, src, C, 0, 0, nullptr, 0, w, bias27 + 13 * (int64_t)Cout, nullptr, residual, y, N, D, H, W, Cout, act, alpha,
-                                  FwdTail{nullptr, nullptr, nullptr, nullptr, bias27}, st);
+                                  FwdTail{nullptr, nullptr, nullptr, nullptr, bias27}, dtype, st);
 }
 int conv3d_fwd_mfma(const void* src0, int C0, int up0, int planar, const void* src1, int C1, const void* w, const float* bias,
-                    const void* mask, void* y, int N, int D, int H, int W, int Cout, int act, float alpha, hipStream_t st) {
-    return conv3d_fwd_mfma_ex(0, src0, C0, up0, planar, src1, C1, w, bias, mask, nullptr, y, N, D, H, W, Cout, act, alpha, st);
+                    const void* mask, void* y, int N, int D, int H, int W, int Cout, int act, float alpha, int dtype, hipStream_t st) {
+    return conv3d_fwd_mfma_ex(0, src0, C0, up0, planar, src1, C1, w, bias, mask, nullptr, y, N, D, H, W, Cout, act, alpha, dtype, st);
 }

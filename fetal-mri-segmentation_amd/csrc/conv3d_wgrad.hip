@@ -405,39 +405,49 @@ k_conv_wgrad_mfma(SrcB s, const bf16_t* __restrict__ dy, float* __restrict__ dw,
 //   BLK = 32: (32 Cout, 32 Cin) block, 4 waves, TWO workgroups per CU (64 KiB of LDS each) - two independent barrier domains, as in the
 //             kernel above; 112 accumulator registers per wave leave room for a 4-deep fragment ring.  19.5 KB of DMA per 216 MFMAs =
 //             90 B per MFMA (-33 %).
-//   BLK = 64: (64 Cout, 64 Cin) block, 8 waves = (Cin half, tap group), ONE workgroup per CU; an x fragment serves two MFMAs (both Cout
-//             halves: 0.64 KB of LDS reads per MFMA) and the DMA drops to 45 B per MFMA - but 224 of a wave's 256 registers are accumulators:
-//             the fragment pipeline is one read deep, hipcc spills ~30 registers per unit, and a single barrier domain per CU overlaps nothing.
-//             Measured 8-25 % SLOWER than the per-kd kernel; kept for the record (FMRI_WGRAD_KD_BLK=64).
+//   BLK = 64 (round 6, "one wave per SIMD"): (64 Cout, 32 Cin) block, 4 waves, ONE workgroup per CU.  A wave holds 7 taps x 2 Cout halves x
+//             32 x 32 = 224 accumulator registers and has its SIMD's whole 512-entry register file: an x fragment serves two MFMAs (0.64 KB of
+//             LDS reads per MFMA instead of 1.14), 27.5 KB of DMA per 432 MFMAs = 64 B per MFMA, the fragment ring runs PF reads ahead in
+//             registers (nobody else hides the read latency), and the unit's DMA pieces are issued one at a time BETWEEN MFMAs (SPREAD) instead
+//             of as a burst behind the barrier.  (Rounds 2-5 had a (64, 64) block on 8 waves here - two waves per SIMD at 224 accumulators
+//             each, i.e. inside 256 registers: spills, one barrier domain for eight waves, 8-25 % slower.  Removed.)
 // Flush: fp32 atomics (128 contiguous bytes per half-wave).  Bit-identical sums on exactly representable data (tests).
-template <int BLK>
+// F32 (round 6, the fp32 parity mode on this kernel's structure): fp32 planes, a (32 Cout, 32 Cin) block on v_mfma_f32_32x32x2_f32 - rows of
+// 128 bytes for both operands, the plane ring / DMA pieces / cursor / flush of the bf16 kernel; a fragment is ONE voxel per half-wave
+// (lane = channel), so it is a plain ds_read_b32 per operand and MFMA, no transposing read.  One workgroup per CU (124 KiB of LDS).
+template <int BLK, bool F32 = false>
 struct WkCfg {
-    static constexpr int NW = BLK == 64 ? 8 : 4;                 // waves per workgroup (all of them issue DMA)
-    static constexpr int NH = BLK == 64 ? 2 : 1;                 // Cout halves (32 channels each) per wave
-    static constexpr int ROWB = BLK * 2;                          // bytes per x / dy row in LDS
-    static constexpr int RS = ROWB / 16;                          // 16-byte slots per row
-    static constexpr int X_INSTR = (wg::XROWS * RS + 63) / 64;    // DMA wave-instructions per x plane: 23 / 12
-    static constexpr int Y_INSTR = wg::YROWS * RS / 64;           // ... per dy plane: 16 / 8
+    static constexpr int NW = 4;                                  // waves per workgroup = tap groups (all of them issue DMA)
+    static constexpr int NH = F32 ? 1 : BLK / 32;                 // Cout halves (32 channels each) per wave
+    static constexpr int XROWB = F32 ? 128 : 64, YROWB = F32 ? 128 : BLK * 2;      // bytes per x row (32 input channels) / per dy row in LDS
+    static constexpr int XRS = XROWB / 16, YRS = YROWB / 16;      // 16-byte slots per row
+    static constexpr int X_INSTR = (wg::XROWS * XRS + 63) / 64;   // DMA wave-instructions per x plane: 12
+    static constexpr int Y_INSTR = wg::YROWS * YRS / 64;          // ... per dy plane: 8 / 16
     static constexpr int XS_BYTES = X_INSTR * 1024, YS_BYTES = Y_INSTR * 1024;
     static constexpr int NXS = 4, NYS = 2;
-    static constexpr int LDS_BYTES = NXS * XS_BYTES + NYS * YS_BYTES;      // 126,976 / 65,536
-    static constexpr int PF = BLK == 64 ? 1 : 3;                  // x fragments in flight ahead of their MFMAs
-    static constexpr int XPW = (X_INSTR + NW - 1) / NW, YPW = (Y_INSTR + NW - 1) / NW;
+    static constexpr int LDS_BYTES = NXS * XS_BYTES + NYS * YS_BYTES;      // 65,536 / 81,920
+    static constexpr int PF = BLK == 64 ? 4 : 3;                  // x fragments in flight ahead of their MFMAs
+    static constexpr int XPW = (X_INSTR + NW - 1) / NW, YPW = (Y_INSTR + NW - 1) / NW;      // 3, 2 / 4
+#ifndef FMRI_KD32_SPREAD
+#define FMRI_KD32_SPREAD 0
+#endif
+    static constexpr bool SPREAD = (BLK == 64 || FMRI_KD32_SPREAD) && !F32;      // DMA pieces of the next unit issued between the MFMAs of this one
+    static constexpr int SP0 = 1, SPD = 3;                        // ... piece p behind step SP0 + SPD * p (a step = NH MFMAs)
 };
 
-template <int BLK, int G>   // tap group: taps 7G .. 7G + NTAP - 1 of the 27
+template <int BLK, int G, class Hook>   // tap group: taps 7G .. 7G + NTAP - 1 of the 27; hook(step) runs behind every step's MFMAs
 __device__ __forceinline__ void wk_compute(const unsigned char* lds, const int (&xb)[3], int yb, const int (&pre_x)[4], int pre_y,
-                                           f32x16 (&acc)[G == 3 ? 6 : 7][WkCfg<BLK>::NH], float (&bsum)[2], bool do_bias) {
+                                           f32x16 (&acc)[G == 3 ? 6 : 7][WkCfg<BLK>::NH], float (&bsum)[2], bool do_bias, Hook&& hook) {
     typedef WkCfg<BLK> K;
-    constexpr int NTAP = G == 3 ? 6 : 7, T0 = 7 * G, NH = K::NH, ROWB = K::ROWB;
+    constexpr int NTAP = G == 3 ? 6 : 7, T0 = 7 * G, NH = K::NH, XROWB = K::XROWB, YROWB = K::YROWB;
     typedef __attribute__((ext_vector_type(8))) short s16x8;
     auto load_a = [&](int ks8, s16x8 (&av)[NH]) {
 #pragma unroll
         for (int h = 0; h < NH; ++h) {
             // the second Cout half sits 4 slots further: bit 6 of the in-row offset
-            const unsigned char* p0 = lds + yb + (h ? (pre_y ^ 64) : pre_y) + ks8 * wg::TW * ROWB;
+            const unsigned char* p0 = lds + yb + (h ? (pre_y ^ 64) : pre_y) + ks8 * wg::TW * YROWB;
             s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p0);
-            s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p0 + 4 * ROWB));
+            s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p0 + 4 * YROWB));
             av[h] = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
         }
     };
@@ -446,37 +456,46 @@ __device__ __forceinline__ void wk_compute(const unsigned char* lds, const int (
     auto load_b = [&](int st) {
         const int ks8 = st / NTAP, t = T0 + st % NTAP, kd = t / 9, kh = (t / 3) % 3, kw = t % 3;
         const int c = (ks8 + kh) * wg::XW + kw;
-        const unsigned char* pb = lds + xb[kd] + pre_x[c & 3] + (c >> 2) * 4 * ROWB;
+        const unsigned char* pb = lds + xb[kd] + pre_x[c & 3] + (c >> 2) * 4 * XROWB;
         s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)pb);
-        s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(pb + 4 * ROWB));
+        s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(pb + 4 * XROWB));
         return __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
     };
     // Fixed register budget: the dy fragments of a k-step are single-buffered, the x fragments run PF steps ahead of their MFMAs in a
     // register ring; sched_barrier keeps the compiler from hoisting more reads (left alone it spills thousands of registers at BLK = 64).
     constexpr int NS = 8 * NTAP, PF = K::PF, RING = PF + 1;
-    s16x8 av[NH], b[RING];
+    // DBA (one wave per SIMD): the dy fragments of the next k-step are requested three steps before it starts (double-buffered) - with
+    // two waves per SIMD the partner covers that latency and the registers are better spent elsewhere
+    constexpr bool DBA = BLK == 64;
+    s16x8 av[DBA ? 2 : 1][NH], b[RING];
 #pragma unroll
     for (int q = 0; q < PF; ++q) b[q] = load_b(q);
+    if constexpr (DBA) load_a(0, av[0]);
 #pragma unroll
     for (int ks8 = 0; ks8 < 8; ++ks8) {
-        load_a(ks8, av);
+        const int ab = DBA ? (ks8 & 1) : 0;
+        if constexpr (!DBA) load_a(ks8, av[0]);
         if constexpr (G == 3) {
             if (do_bias) {
                 // bias gradient = sum of the dy fragments (the 6-tap group has registers to spare)
 #pragma unroll
                 for (int h = 0; h < NH; ++h)
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) bsum[h] += bf2f((unsigned short)av[h][q]);
+                    for (int q = 0; q < 8; ++q) bsum[h] += bf2f((unsigned short)av[ab][h][q]);
             }
         }
 #pragma unroll
         for (int j = 0; j < NTAP; ++j) {
             const int st = ks8 * NTAP + j;
             if (st + PF < NS) b[(st + PF) % RING] = load_b(st + PF);
+            if constexpr (DBA) {
+                if (j == NTAP - 3 && ks8 + 1 < 8) load_a(ks8 + 1, av[ab ^ 1]);
+            }
             const bf16x8_t bb = __builtin_bit_cast(bf16x8_t, b[st % RING]);
 #pragma unroll
             for (int h = 0; h < NH; ++h)
-                acc[j][h] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, av[h]), bb, acc[j][h], 0, 0, 0);
+                acc[j][h] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, av[ab][h]), bb, acc[j][h], 0, 0, 0);
+            hook(ks8 * NTAP + j);            // (the loops are fully unrolled: the step is a constant in every copy)
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -545,6 +564,31 @@ __device__ __forceinline__ void wk_compute16(const unsigned char* lds, const int
     }
 }
 
+// fp32 form of wk_compute: k-step ks = voxels 2 ks, 2 ks + 1 of the 8 x 16 plane tile (h-row ks >> 3, w = 2 (ks & 7) + (lane >> 5)); lane & 31 is
+// the channel of both operands.  Row index = (compile-time constant c) + (lane >> 5); 128-byte rows flip their 64-byte halves on bit 1 of the row
+// (the DMA's image, wg_slot_off<128>): addr(c) = pre[c & 3] + (c >> 2) * 512, as in the bf16 form.
+template <int G>
+__device__ __forceinline__ void wk_compute_f32(const unsigned char* lds, const int (&xb)[3], int yb, const int (&pre)[4], f32x16 (&acc)[G == 3 ? 6 : 7][1],
+                                               float (&bsum)[2], bool do_bias) {
+    constexpr int NTAP = G == 3 ? 6 : 7, T0 = 7 * G;
+#pragma unroll
+    for (int ks = 0; ks < 64; ++ks) {
+        const int ks8 = ks >> 3, w2 = 2 * (ks & 7);
+        const int cy = ks8 * wg::TW + w2;
+        const float av = *reinterpret_cast<const float*>(lds + yb + pre[cy & 3] + (cy >> 2) * 512);
+        if constexpr (G == 3) {
+            if (do_bias) bsum[0] += av;
+        }
+#pragma unroll
+        for (int j = 0; j < NTAP; ++j) {
+            const int t = T0 + j, kd = t / 9, kh = (t / 3) % 3, kw = t % 3;
+            const int cx = (ks8 + kh) * wg::XW + kw + w2;
+            const float bv = *reinterpret_cast<const float*>(lds + xb[kd] + pre[cx & 3] + (cx >> 2) * 512);
+            acc[j][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[j][0], 0, 0, 0);
+        }
+    }
+}
+
 struct WkArgs {
     SrcB s;
     const bf16_t* dy;
@@ -554,20 +598,23 @@ struct WkArgs {
 };
 
 // everything a wave does, instantiated per tap group so that the accumulators are one fixed register set for the kernel's lifetime
-template <int BLK, int G, bool S16 = false>
+template <int BLK, int G, bool S16 = false, bool F32 = false>
 __device__ __forceinline__ void wk_run(const WkArgs& a, unsigned char* lds, int wv, int lane) {
     static_assert(!S16 || BLK == 32, "the 16x16x32 form is built for the 4-wave kernel");
-    typedef WkCfg<BLK> K;
-    constexpr int NTAP = G == 3 ? 6 : 7, NW = K::NW, NH = K::NH, ROWB = K::ROWB, RS = K::RS;
+    static_assert(!F32 || (BLK == 32 && !S16), "the fp32 form: 32 x 32 blocks");
+    typedef WkCfg<BLK, F32> K;
+    constexpr int EU = F32 ? 2 : 1;                      // 2-byte units per element: channel counts that are memory strides come in these (s.C0, s.C1)
+    constexpr int NTAP = G == 3 ? 6 : 7, NW = K::NW, NH = K::NH, XROWB = K::XROWB, YROWB = K::YROWB, XRS = K::XRS, YRS = K::YRS;
     const SrcB& s = a.s;
     const int N = a.N, D = a.D, H = a.H, W = a.W, Cout = a.Cout;
     const int Cin = s.C0 + s.C1;
-    const int ncib = Cin / BLK, ncob = Cout / BLK;
+    const int ncib = Cin / (32 * EU), ncob = Cout / BLK;
+    const int CoutB = EU * Cout;                         // voxel stride of dy in 2-byte units
     const int ncombo = ncob * ncib;
     const int wg_id = xcd_logical_id(blockIdx.x, gridDim.x);      // the (Cout, Cin) blocks of one slab (same planes) on one XCD / L2
     const int combo = wg_id % ncombo, slab = wg_id / ncombo;
     const int cib = combo % ncib, cob = combo / ncib;
-    const int co0 = cob * BLK, cc = cib * BLK;
+    const int co0 = cob * BLK, ccr = cib * 32, cc = ccr * EU;          // ccr: first input channel of the block; cc: the same in 2-byte units
 
     const bool from0 = cc < s.C0;
     const bf16_t* sp = from0 ? s.p0 : s.p1;
@@ -578,9 +625,8 @@ __device__ __forceinline__ void wk_run(const WkArgs& a, unsigned char* lds, int 
     const int sD = D >> shd, sH = H >> sh, sW = W >> sh;
 
     const int r = lane & 31, hk = lane >> 5;
-    const int it = BLK == 64 ? (wv >> 2) : 0;              // Cin half (BLK = 64: waves g and g + 4 share a SIMD)
-    // bias gradient = sum over the dy fragments: in the 6-tap group (it has registers to spare) of Cin half 0 / Cin block 0
-    const bool do_bias = G == 3 && (a.db != nullptr) && cib == 0 && it == 0;
+    // bias gradient = sum over the dy fragments: in the 6-tap group (it has registers to spare) of Cin block 0
+    const bool do_bias = G == 3 && (a.db != nullptr) && cib == 0;
 
     f32x16 acc[S16 ? 1 : NTAP][NH];
     f32x4 acc16[S16 ? NTAP : 1][2][2];
@@ -608,19 +654,33 @@ __device__ __forceinline__ void wk_run(const WkArgs& a, unsigned char* lds, int 
     // issue side keeps a cursor (cn, ch0, cw0) of the column being issued and, per column, the lane constants of its pieces: element offset
     // inside a plane and whether that halo row lies inside the volume (bit j of x_ok); per plane what is left is a scalar base, one 64-bit add
     // and a select per instruction.
+    // SPREAD (one wave per SIMD): the 6-tap wave has 16 MFMAs fewer per unit than the 7-tap waves, and a DMA piece costs its wave ~60 cycles
+    // of issue - the pieces are dealt so that the sums are level: the dy plane's instructions 0-14 to waves 0-2 (five each), its last one and
+    // the whole x plane (12) to wave 3.  Otherwise round-robin over the waves.
+#ifndef FMRI_W1_BALANCE
+#define FMRI_W1_BALANCE 0
+#endif
+#ifndef FMRI_W1_DESC_HOOK
+#define FMRI_W1_DESC_HOOK 1
+#endif
+    constexpr bool BAL = K::SPREAD && FMRI_W1_BALANCE;
+    constexpr int XPW_ = BAL ? (G == 3 ? K::X_INSTR : 0) : K::XPW, YPW_ = BAL ? (G == 3 ? 1 : 5) : K::YPW;
+    static_assert(!BAL || (K::Y_INSTR == 16 && K::X_INSTR == 12), "piece table of the one-wave-per-SIMD form");
+    auto xid = [&](int k) { return BAL ? k : wv + NW * k; };
+    auto yid = [&](int k) { return BAL ? (G == 3 ? 15 : 5 * G + k) : (NW - 1 - wv) + NW * k; };   // (round-robin: dealt from the other end - the waves with one x instruction fewer go first)
     int cn = 0, ch0 = 0, cw0 = 0;
-    int x_off[K::XPW], y_off[K::YPW];
+    int x_off[XPW_ > 0 ? XPW_ : 1], y_off[YPW_];
     unsigned x_ok = 0;
     auto col_setup = [&](int n, int h0, int w0) {
         cn = n; ch0 = h0; cw0 = w0;
         x_ok = 0;
 #pragma unroll
-        for (int k = 0; k < K::XPW; ++k) {
-            const int id = wv + NW * k;
+        for (int k = 0; k < XPW_; ++k) {
+            const int id = xid(k);
             const int i = id * 64 + lane;
-            const int row = i / RS, ps = i % RS;
+            const int row = i / XRS, ps = i % XRS;
             // 128-byte rows flip their 64-byte halves on row bit 1 (wg_slot_off); S16: 64-byte rows flip their 32-byte halves on row bit 2
-            const int ls = RS == 8 ? (ps ^ (((row >> 1) & 1) << 2)) : (S16 ? (ps ^ (((row >> 2) & 1) << 1)) : ps);
+            const int ls = XRS == 8 ? (ps ^ (((row >> 1) & 1) << 2)) : (S16 ? (ps ^ (((row >> 2) & 1) << 1)) : ps);
             const int xh = row / wg::XW, xw = row % wg::XW;
             const int gh = h0 - 1 + xh, gw = w0 - 1 + xw;
             const bool ok = id < K::X_INSTR && row < wg::XROWS && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W;
@@ -629,46 +689,55 @@ __device__ __forceinline__ void wk_run(const WkArgs& a, unsigned char* lds, int 
             x_ok |= (ok ? 1u : 0u) << k;
         }
 #pragma unroll
-        for (int k = 0; k < K::YPW; ++k) {
-            const int id = (NW - 1 - wv) + NW * k;            // dealt from the other end: the waves with one x instruction fewer go first
+        for (int k = 0; k < YPW_; ++k) {
+            const int id = yid(k);
             const int i = id * 64 + lane;
-            const int row = i / RS, ps = i % RS;
-            const int ls = RS == 8 ? (ps ^ (((row >> 1) & 1) << 2)) : (S16 ? (ps ^ (((row >> 2) & 1) << 1)) : ps);
-            y_off[k] = (((row >> 4) * W + (row & 15)) * Cout + ls * 8) * 2;      // bytes
+            const int row = i / YRS, ps = i % YRS;
+            const int ls = YRS == 8 ? (ps ^ (((row >> 1) & 1) << 2)) : (S16 ? (ps ^ (((row >> 2) & 1) << 1)) : ps);
+            y_off[k] = (((row >> 4) * W + (row & 15)) * CoutB + ls * 8) * 2;     // bytes
         }
     };
     // plane `gd` (may lie outside the volume: zeros) of the cursor's column into x slot `slot`
-    auto issue_x = [&](int gd, int slot) {
+    // (round 5: through a buffer descriptor - a halo row outside the volume in h or w gets an out-of-range offset and lands as zeros, a
+    // plane outside the volume in d a descriptor of zero records: no zero page, no 64-bit pointer select per lane)
+    auto x_rsrc = [&](int gd) {
         const bool dok = (unsigned)gd < (unsigned)D;
         const int gdc = min(max(gd, 0), D - 1) >> shd;
-        const bf16_t* const xbase = sp + ((int64_t)cn * sD + gdc) * sH * sW * sC + coff;
-        // (round 5: through a buffer descriptor - a halo row outside the volume in h or w gets an out-of-range offset and lands as zeros, a
-        // plane outside the volume in d a descriptor of zero records: no zero page, no 64-bit pointer select per lane)
-        const i32x4 rs = dma_rsrc(xbase, dok ? (int)DMA_OOB : 0);
+        return dma_rsrc(sp + ((int64_t)cn * sD + gdc) * sH * sW * sC + coff, dok ? (int)DMA_OOB : 0);
+    };
+    auto y_rsrc = [&](int d) { return dma_rsrc(a.dy + ((((int64_t)cn * D + d) * H + ch0) * W + cw0) * CoutB + EU * co0); };
+    auto x_piece = [&](i32x4 rs, int slot, int k) {                 // piece k of this wave (k is a constant at every call site)
+        const int id = xid(k);
+        if (id < K::X_INSTR)
+            dma16_buf(rs, ((x_ok >> k) & 1) ? (unsigned)x_off[k] : DMA_OOB, __builtin_amdgcn_readfirstlane(lds0 + slot * K::XS_BYTES + id * 1024));
+    };
+    auto y_piece = [&](i32x4 rs, int ybuf, int k) {
+        const int id = yid(k);
+        if (id < K::Y_INSTR) dma16_buf(rs, (unsigned)y_off[k], __builtin_amdgcn_readfirstlane(lds0 + K::NXS * K::XS_BYTES + ybuf * K::YS_BYTES + id * 1024));
+    };
+    auto issue_x = [&](int gd, int slot) {
+        const i32x4 rs = x_rsrc(gd);
 #pragma unroll
-        for (int k = 0; k < K::XPW; ++k) {
-            const int id = wv + NW * k;
-            if (id < K::X_INSTR)
-                dma16_buf(rs, ((x_ok >> k) & 1) ? (unsigned)x_off[k] : DMA_OOB,
-                      __builtin_amdgcn_readfirstlane(lds0 + slot * K::XS_BYTES + id * 1024));
-        }
+        for (int k = 0; k < XPW_; ++k) x_piece(rs, slot, k);
     };
     auto issue_y = [&](int d, int ybuf) {
-        const i32x4 yrs = dma_rsrc(a.dy + ((((int64_t)cn * D + d) * H + ch0) * W + cw0) * Cout + co0);
+        const i32x4 rs = y_rsrc(d);
 #pragma unroll
-        for (int k = 0; k < K::YPW; ++k) {
-            const int id = (NW - 1 - wv) + NW * k;
-            if (id < K::Y_INSTR) dma16_buf(yrs, (unsigned)y_off[k], __builtin_amdgcn_readfirstlane(lds0 + K::NXS * K::XS_BYTES + ybuf * K::YS_BYTES + id * 1024));
-        }
+        for (int k = 0; k < YPW_; ++k) y_piece(rs, ybuf, k);
     };
 
     // ---- per-lane constants of the transposing fragment reads (see k_conv_wgrad_mfma)
     const int gq = lane >> 4, qd = (lane & 15) >> 2, pp = lane & 3;
     const int lrow = 8 * (gq >> 1) + qd;
-    const int lslot_x = it * 4 + 2 * (gq & 1) + (pp >> 1), lslot_y = 2 * (gq & 1) + (pp >> 1);
+    const int lslot_x = 2 * (gq & 1) + (pp >> 1), lslot_y = 2 * (gq & 1) + (pp >> 1);
     int pre_x[S16 ? 8 : 4];
     int pre_y;
-    if constexpr (S16) {
+    if constexpr (F32) {
+        // row (m + hk) of a 128-byte-row image, channel r: one dword per lane (the x and the dy image share the layout)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) pre_x[m] = (m + hk) * 128 + ((r * 4) ^ ((((m + hk) >> 1) & 1) << 6));
+        pre_y = 0;
+    } else if constexpr (S16) {
         // lane (g = k-group, qd = voxel row of the read, pp = 8-byte piece of the 32-byte half): voxel (h-row g >> 1, w = 4 (g & 1) + qd) of the step
         const int lx = (gq >> 1) * wg::XW + 4 * (gq & 1) + qd, ly = (gq >> 1) * wg::TW + 4 * (gq & 1) + qd;
 #pragma unroll
@@ -676,8 +745,8 @@ __device__ __forceinline__ void wk_run(const WkArgs& a, unsigned char* lds, int 
         pre_y = (ly * 64 + pp * 8) ^ (((ly >> 2) & 1) << 5);
     } else {
 #pragma unroll
-        for (int m = 0; m < 4; ++m) pre_x[m] = wg_slot_off<ROWB>(lrow + m, lslot_x) + (pp & 1) * 8;
-        pre_y = wg_slot_off<ROWB>(lrow, lslot_y) + (pp & 1) * 8;
+        for (int m = 0; m < 4; ++m) pre_x[m] = wg_slot_off<XROWB>(lrow + m, lslot_x) + (pp & 1) * 8;
+        pre_y = wg_slot_off<YROWB>(lrow, lslot_y) + (pp & 1) * 8;
     }
 
     const int per = (nunits + a.nslab - 1) / a.nslab;
@@ -708,6 +777,7 @@ __device__ __forceinline__ void wk_run(const WkArgs& a, unsigned char* lds, int 
             PROF_T(w2);
             const bool more = u + 1 < u_end;
             const bool fresh = more && d + 1 == D;       // the next unit starts a new column: it needs three new planes, one slot is free
+            i32x4 nx_rs = {0, 0, 0, 0}, ny_rs = {0, 0, 0, 0};
             if (more) {
                 if (fresh) {                             // advance the cursor to the next column of the run
                     int w0 = cw0 + wg::TW, h0 = ch0, n = cn;
@@ -715,15 +785,39 @@ __device__ __forceinline__ void wk_run(const WkArgs& a, unsigned char* lds, int 
                     col_setup(n, h0, w0);
                     d = -1;
                 }
-                issue_x(fresh ? -1 : d + 2, (xs + 1) & 3);
-                issue_y(d + 1, yb ^ 1);
+                if constexpr (K::SPREAD && !FMRI_W1_DESC_HOOK) {
+                    nx_rs = x_rsrc(fresh ? -1 : d + 2);
+                    ny_rs = y_rsrc(d + 1);
+                }
+                if constexpr (!K::SPREAD) {
+                    issue_x(fresh ? -1 : d + 2, (xs + 1) & 3);
+                    issue_y(d + 1, yb ^ 1);
+                }
             }
             PROF_T(w3);
             int xb[3] = {((xs + 2) & 3) * K::XS_BYTES, ((xs + 3) & 3) * K::XS_BYTES, xs * K::XS_BYTES};
 #pragma unroll
             for (int k = 0; k < 3; ++k) asm volatile("" : "+s"(xb[k]));       // slot bases stay scalar: base + lane offset is added per read
-            if constexpr (S16) wk_compute16<G>(lds, xb, K::NXS * K::XS_BYTES + yb * K::YS_BYTES, pre_x, pre_y, acc16, bsum, do_bias);
-            else wk_compute<BLK, G>(lds, xb, K::NXS * K::XS_BYTES + yb * K::YS_BYTES, pre_x, pre_y, acc, bsum, do_bias);
+            const int nslot = (xs + 1) & 3, nyb = yb ^ 1;
+            auto hook = [&](int st) {
+                if constexpr (K::SPREAD) {
+                    // behind step 0: the next unit's two descriptors - ~60 scalar instructions (64-bit multiplies) that sat between the barrier
+                    // and the unit's first MFMA; piece p of the next unit behind step SP0 + SPD p, the dy pieces first
+                    constexpr int SPD = (BAL && G == 3) ? 2 : K::SPD;
+                    if (FMRI_W1_DESC_HOOK && st == 0 && more) {
+                        nx_rs = x_rsrc(fresh ? -1 : d + 2);
+                        ny_rs = y_rsrc(d + 1);
+                    }
+                    if (st >= K::SP0 && (st - K::SP0) % SPD == 0 && (st - K::SP0) / SPD < XPW_ + YPW_ && more) {
+                        const int pc = (st - K::SP0) / SPD;
+                        if (pc < YPW_) y_piece(ny_rs, nyb, pc);
+                        else x_piece(nx_rs, nslot, pc - YPW_);
+                    }
+                }
+            };
+            if constexpr (F32) wk_compute_f32<G>(lds, xb, K::NXS * K::XS_BYTES + yb * K::YS_BYTES, pre_x, acc, bsum, do_bias);
+            else if constexpr (S16) wk_compute16<G>(lds, xb, K::NXS * K::XS_BYTES + yb * K::YS_BYTES, pre_x, pre_y, acc16, bsum, do_bias);
+            else wk_compute<BLK, G>(lds, xb, K::NXS * K::XS_BYTES + yb * K::YS_BYTES, pre_x, pre_y, acc, bsum, do_bias, hook);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             PROF_T(w4);
 #ifdef FMRI_PROF
@@ -762,7 +856,7 @@ __device__ __forceinline__ void wk_run(const WkArgs& a, unsigned char* lds, int 
 #pragma unroll
                     for (int reg = 0; reg < 4; ++reg) {
                         const int co = co0 + ho * 16 + 4 * (lane >> 4) + reg;
-                        const int ci = cc + hi * 16 + (lane & 15);
+                        const int ci = ccr + hi * 16 + (lane & 15);
                         fmri_grad_add(dc, &a.dw[((int64_t)tap * Cout + co) * a.dw_ld + ci], acc16[j][ho][hi][reg]);
                     }
         }
@@ -786,7 +880,7 @@ __device__ __forceinline__ void wk_run(const WkArgs& a, unsigned char* lds, int 
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
                 const int co = co0 + h * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * hk;
-                const int ci = cc + it * 32 + r;
+                const int ci = ccr + r;
                 fmri_grad_add(dc, &a.dw[((int64_t)tap * Cout + co) * a.dw_ld + ci], acc[j][h][reg]);
             }
     }
@@ -800,16 +894,16 @@ __device__ __forceinline__ void wk_run(const WkArgs& a, unsigned char* lds, int 
     }
 }
 
-template <int BLK, bool S16 = false>
-__global__ void __launch_bounds__(WkCfg<BLK>::NW * 64, BLK == 64 ? 1 : 2) k_conv_wgrad_kd(WkArgs a) {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[WkCfg<BLK>::LDS_BYTES];
+template <int BLK, bool S16 = false, bool F32 = false>
+__global__ void __launch_bounds__(256, (BLK == 64 || F32) ? 1 : 2) k_conv_wgrad_kd(WkArgs a) {     // BLK = 64: no second workgroup -> 512 registers per wave
+    __shared__ __attribute__((aligned(16))) unsigned char lds[WkCfg<BLK, F32>::LDS_BYTES];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     switch (wv & 3) {                                     // tap group
-        case 0: wk_run<BLK, 0, S16>(a, lds, wv, lane); break;
-        case 1: wk_run<BLK, 1, S16>(a, lds, wv, lane); break;
-        case 2: wk_run<BLK, 2, S16>(a, lds, wv, lane); break;
-        default: wk_run<BLK, 3, S16>(a, lds, wv, lane); break;
+        case 0: wk_run<BLK, 0, S16, F32>(a, lds, wv, lane); break;
+        case 1: wk_run<BLK, 1, S16, F32>(a, lds, wv, lane); break;
+        case 2: wk_run<BLK, 2, S16, F32>(a, lds, wv, lane); break;
+        default: wk_run<BLK, 3, S16, F32>(a, lds, wv, lane); break;
     }
 }
 
@@ -872,7 +966,18 @@ k_wgrad_reduce(const float* __restrict__ ws, float* __restrict__ dw, int Cout, i
 
 }  // namespace
 
+static int wgrad_f32_mfma() {           // FMRI_F32_MFMA=0: fp32 tensors stay on the VALU kernels of conv3d_generic.hip (rounds 1-5)
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("FMRI_F32_MFMA");
+        v = e ? atoi(e) : 1;
+    }
+    return v;
+}
 bool conv3d_wgrad_mfma_ok(int C0, int C1, int Cout, int D, int H, int W, int dtype) {
+    if (dtype == FMRI_F32)                // k_conv_wgrad_kd<32, false, F32>: (32 Cout, 32 Cin) blocks of fp32 planes
+        return wgrad_f32_mfma() && !(C0 % 32) && !(C1 % 32) && C0 + C1 >= 32 && !(Cout % 32) && !(H % wg::TH) && !(W % wg::TW) &&
+               (long long)H * W * (C0 > C1 ? C0 : C1) * 4 < (1ll << 31) && (long long)H * W * Cout * 4 < (1ll << 31);
     if (dtype != FMRI_BF16) return false;
     if ((C0 % 32) || (C1 % 32) || C0 + C1 < 32 || (Cout % 64)) return false;
     if ((H % wg::TH) || (W % wg::TW)) return false;
@@ -914,6 +1019,16 @@ int64_t conv3d_wgrad_mfma_ws_bytes(int C0, int C1, int Cout, int N, int D, int H
     return (int64_t)combos * nslab * (CIB == 32 ? 2 : 1) * 9 * 64 * CIB * (int64_t)sizeof(float);
 }
 
+// launches of at least this many FLOPs take the kd-sharing kernel with its atomic flush, smaller ones the per-kd kernel with the slab flush
+// (FMRI_WGRAD_KD_MIN_GFLOP overrides: A/B)
+static double wgrad_kd_min_flops() {
+    static double v = -1.0;
+    if (v < 0) {
+        const char* e = getenv("FMRI_WGRAD_KD_MIN_GFLOP");
+        v = e ? atof(e) * 1e9 : 0.3e12;
+    }
+    return v;
+}
 // does this launch take the kd-sharing kernel (k_conv_wgrad_kd)?  use_ws: the slab flush was chosen for it
 static bool wgrad_takes_kd(int C0, int C1, int Cout, int N, int D, int H, int W, int planar, int up0, bool use_ws, int* blk_out) {
     static int kd_mode = -1, kd_blk = 32;
@@ -923,11 +1038,13 @@ static bool wgrad_takes_kd(int C0, int C1, int Cout, int N, int D, int H, int W,
         const char* f = getenv("FMRI_WGRAD_KD_BLK");
         kd_blk = (f && atoi(f) == 64) ? 64 : 32;
     }
-    if (blk_out) *blk_out = kd_blk;
     const double flops_ = 2.0 * (planar ? 9 : 27) * (double)(C0 + C1) * Cout * (double)N * D * H * W;
     const bool narrow = (C0 % 64) || (C1 % 64);
-    return kd_mode && !planar && !use_ws && (!up0 || kd_mode == 3) && (C0 % kd_blk == 0) && (C1 % kd_blk == 0) && (Cout % kd_blk == 0) &&
-           ((kd_mode >= 2 && flops_ >= 0.3e12) || (narrow && kd_blk == 32 && flops_ >= 0.1e12));
+    const bool base = kd_mode && !planar && !use_ws && (!up0 || kd_mode == 3) && (C0 % 32 == 0) && (C1 % 32 == 0) && (Cout % 32 == 0);
+    // FMRI_WGRAD_KD_BLK=64: the one-wave-per-SIMD (64 Cout, 32 Cin) form on every launch of >= 0.3 TFLOP whose Cout it tiles; 32 elsewhere
+    const bool w1 = base && kd_blk == 64 && (Cout % 64 == 0) && (kd_mode == 3 || (kd_mode >= 2 && flops_ >= wgrad_kd_min_flops()));
+    if (blk_out) *blk_out = w1 ? 64 : 32;
+    return w1 || (base && ((kd_mode >= 2 && flops_ >= wgrad_kd_min_flops()) || (narrow && flops_ >= 0.1e12)));
 }
 // A 32-wide Cout (not a multiple of the per-kd kernel's 64-wide block) is fine where the kd-sharing kernel with its 32 x 32 blocks takes the
 // launch: no workspace (slab flush), see wgrad_takes_kd.  Lets the channel-padded layer-graph engine pass a 32-channel dy as it is (it
@@ -952,7 +1069,7 @@ int conv3d_wgrad_mfma_ld(const void* src0, int C0, int up0, int planar, const vo
     }
     const double flops_ = 2.0 * (planar ? 9 : 27) * (double)(C0 + C1) * Cout * (double)N * D * H * W;
     const bool use_ws = workspace != nullptr && workspace_bytes >= conv3d_wgrad_mfma_ws_bytes(C0, C1, Cout, N, D, H, W, planar) &&
-                        (force_slab == 1 || flops_ < 0.3e12);
+                        (force_slab == 1 || flops_ < wgrad_kd_min_flops());
     // kd-sharing kernels (a workgroup owns a (Cout, Cin) block for all 27 taps and walks columns; see k_conv_wgrad_kd).  Measured per layer
     // (profiles/r02_wgrad_kd_sharing_ab.log): the 4-wave form wins where the per-kd kernel has to fall back to 32-wide Cin blocks (enc0b
     // 32 -> 64 at full resolution: -17 %), is level with it on the 64- and 128-channel layers (0 ... -5 %) and loses on the fused-upsample
@@ -963,10 +1080,10 @@ int conv3d_wgrad_mfma_ld(const void* src0, int C0, int up0, int planar, const vo
     // >= 0.1 TFLOP (the default until then), 2 (default) = also every launch of >= 0.3 TFLOP without fused up-sampling (below that the
     // per-kd kernel is ahead, with the slab flush or - callers without a workspace, e.g. the layer-graph engine - with the atomic one:
     // Isensee defaults 11.3 vs 11.65 ms per step), 3 = the fused-upsample launches too;
-    // FMRI_WGRAD_KD_BLK = 32 (4-wave workgroups, two per CU) | 64 (8-wave workgroup, one per CU: slower, kept for the record).
+    // FMRI_WGRAD_KD_BLK = 32 (two workgroups per CU, 32 x 32 blocks) | 64 (one workgroup per CU, one wave per SIMD, 64 x 32 blocks; round 6).
     int kd_blk = 32;
     if (wgrad_takes_kd(C0, C1, Cout, N, D, H, W, planar, up0, use_ws, &kd_blk)) {
-        const int combos_kd = (Cout / kd_blk) * (Cin / kd_blk);
+        const int combos_kd = (Cout / kd_blk) * (Cin / 32);
         const int nunits = N * D * (H / wg::TH) * (W / wg::TW);
         static int kd_wgs = -1;
         if (kd_wgs < 0) {
@@ -977,7 +1094,7 @@ int conv3d_wgrad_mfma_ld(const void* src0, int C0, int up0, int planar, const vo
         // 27 x 32 x 32 fp32 atomics onto the same filter block as the others of its column, so half the workgroups are half the flush
         // traffic: weight-gradient family 4.64-4.73 -> 4.44-4.57 ms per step, step +0.2 ... 2.1 % in four interleaved same-box pairs;
         // one per CU leaves the second slot of the CUs empty: 5.1-5.2 ms).  FMRI_WGRAD_KD_WGS overrides.
-        const int target = kd_wgs > 0 ? kd_wgs : 2 * fwd_cu_count();
+        const int target = kd_wgs > 0 ? kd_wgs : (kd_blk == 64 ? 1 : 2) * fwd_cu_count();      // BLK = 64: one (512-register) workgroup per CU
         int nsl = (target + combos_kd - 1) / combos_kd;
         if (nsl > nunits) nsl = nunits;
         if (nsl < 1) nsl = 1;
@@ -987,7 +1104,7 @@ int conv3d_wgrad_mfma_ld(const void* src0, int C0, int up0, int planar, const vo
             const char* e = getenv("FMRI_WGRAD_MFMA16");
             wg16 = e ? atoi(e) : 0;
         }
-        if (kd_blk == 64) k_conv_wgrad_kd<64><<<combos_kd * nsl, 512, 0, st>>>(wa);
+        if (kd_blk == 64) k_conv_wgrad_kd<64><<<combos_kd * nsl, 256, 0, st>>>(wa);
         else if (wg16) k_conv_wgrad_kd<32, true><<<combos_kd * nsl, 256, 0, st>>>(wa);
         else k_conv_wgrad_kd<32><<<combos_kd * nsl, 256, 0, st>>>(wa);
         FMRI_LAUNCH_CHECK();
@@ -1018,6 +1135,21 @@ int conv3d_wgrad_mfma_ld(const void* src0, int C0, int up0, int planar, const vo
         if (CIB == 64) k_wgrad_reduce<64><<<grid, 256, 0, st>>>(ws, dw, Cout, dw_ld, nslab, combos, ncob, ncib, planar, 1);
         else k_wgrad_reduce<32><<<grid, 256, 0, st>>>(ws, dw, Cout, dw_ld, nslab, combos, ncob, ncib, planar, 2);
     }
+    FMRI_LAUNCH_CHECK();
+    return FMRI_OK;
+}
+// fp32 planes (3-D; a fused x2 up-sampled first source is fine): one kernel form for every size, atomic flush, one workgroup per CU
+int conv3d_wgrad_mfma_f32(const void* src0, int C0, int up0, const void* src1, int C1, const void* dy, float* dw, float* db, int N, int D, int H, int W,
+                          int Cout, hipStream_t st) {
+    if (!conv3d_wgrad_mfma_ok(C0, C1, Cout, D, H, W, FMRI_F32)) return FMRI_E_SHAPE;
+    SrcB s{(const bf16_t*)src0, (const bf16_t*)src1, 2 * C0, 2 * C1, up0, 1, 0};      // memory strides in 2-byte units (see wk_run, EU)
+    const int combos = (Cout / 32) * ((C0 + C1) / 32);
+    const int nunits = N * D * (H / wg::TH) * (W / wg::TW);
+    int nsl = (fwd_cu_count() + combos - 1) / combos;
+    if (nsl > nunits) nsl = nunits;
+    if (nsl < 1) nsl = 1;
+    const WkArgs wa{s, (const bf16_t*)dy, dw, db, N, D, H, W, Cout, nsl, C0 + C1};
+    k_conv_wgrad_kd<32, false, true><<<combos * nsl, 256, 0, st>>>(wa);
     FMRI_LAUNCH_CHECK();
     return FMRI_OK;
 }

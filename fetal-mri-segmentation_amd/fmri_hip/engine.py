@@ -369,7 +369,9 @@ class UNetEngine:
         p = self.plan
         out = {}
         self.upcat_wgrad = set()                           # ... of which the weight gradient takes the parity form too (never in deterministic mode)
-        if self.dtype != torch.bfloat16 or os.environ.get("FMRI_UPCAT", "1") == "0":
+        # (fp32, round 6: the parity form runs on the fp32 instantiation of the same MFMA kernels where fmri_conv3d_upcat_ok says so - 3-D,
+        # channels in multiples of 16; FMRI_F32_MFMA=0 keeps fp32 on the VALU kernels and with them on the 27-tap fused-upsample form)
+        if (self.dtype != torch.bfloat16 and self.planar) or os.environ.get("FMRI_UPCAT", "1") == "0":
             return out
         for lv in p.dec:
             a = lv[0]

@@ -42,7 +42,10 @@ def test_mfma_dispatch_query():
     assert L.fmri_conv3d_uses_mfma(128, 64, 64, 64, 128, 128, BF16) == 3
     assert L.fmri_conv3d_uses_mfma(256, 0, 512, 8, 16, 16, BF16) == 3
     assert L.fmri_conv3d_uses_mfma(1, 0, 32, 64, 128, 128, BF16) == 4
-    assert L.fmri_conv3d_uses_mfma(32, 0, 64, 64, 128, 128, F32) == 0
+    # fp32 (round 6): the fp32 instantiation of the same kernels where channels come in multiples of 16 (forward) / 32 (weight gradient)
+    assert L.fmri_conv3d_uses_mfma(32, 0, 64, 64, 128, 128, F32) == 3
+    assert L.fmri_conv3d_uses_mfma(16, 0, 32, 64, 128, 128, F32) == 1
+    assert L.fmri_conv3d_uses_mfma(8, 0, 16, 16, 64, 64, F32) == 0       # config 1 (base 8) in fp32 -> generic path
     assert L.fmri_conv3d_uses_mfma(8, 0, 16, 16, 64, 64, BF16) == 0     # config 1 (base 8) -> generic path
 
 
