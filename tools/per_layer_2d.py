@@ -78,23 +78,58 @@ def conv_flops(name, s):
     return None
 
 
+def conv_bytes(name, s):
+    """algorithmic bf16 bytes of one launch: each tensor once (inputs + output + filters; the input-gradient form also reads the ReLU mask)"""
+    def sz(t):
+        return 0 if t is None else 2.0 * t[0] * t[1] * t[2] * t[3] * t[4]
+    if name == "conv3d_fwd":
+        return sz(s[0]) + sz(s[1]) + sz(s[4]) + 2.0 * 9 * ((s[0][4] if s[0] else 0) + (s[1][4] if s[1] else 0)) * s[4][4]
+    if name == "conv3d_fwd_tail":
+        return sz(s[0]) + sz(s[3]) + 2.0 * 9 * s[0][4] * s[3][4]
+    if name == "conv3d_dgrad":
+        return sz(s[0]) + 2 * sz(s[2]) + 2.0 * 9 * s[0][4] * s[2][4]
+    if name == "conv3d_wgrad":
+        return sz(s[0]) + sz(s[1]) + sz(s[2]) + 4.0 * 9 * ((s[0][4] if s[0] else 0) + (s[1][4] if s[1] else 0)) * s[2][4]
+    if name == "conv3d_upcat_fwd":
+        return sz(s[0]) + sz(s[1]) + sz(s[5]) + 2.0 * 9 * (s[0][4] + s[1][4]) * s[5][4]
+    if name == "conv3d_upcat_dgrad":
+        return sz(s[0]) + 2 * sz(s[5]) + 2 * sz(s[6]) + 2.0 * 9 * (s[5][4] + s[6][4]) * s[0][4]
+    if name == "conv3d_upcat_wgrad":
+        return sz(s[0]) + sz(s[1]) + sz(s[2]) + 4.0 * 9 * (s[0][4] + s[1][4]) * s[2][4]
+    return None
+
+
+PEAK_HBM = 8000.0      # GB/s (MI355X guide)
 rows = []
 for (name, shp), ev in rec.items():
     ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
     n = len(ev) // K
     fl = conv_flops(name, shp)
+    by = conv_bytes(name, shp) if fl else None
+    # the launch's own roofline: an MFMA-bound time and an HBM-bound time, whichever is longer (3 x 3 convs have a third of the 3-D layers'
+    # arithmetic intensity: the full-resolution 2-D layers are HBM-bound)
+    t_mfma = fl / (PEAK * 1e12) * 1e3 if fl else None
+    t_hbm = by / (PEAK_HBM * 1e9) * 1e3 if by else None
     rows.append({"op": name, "shapes": [list(t) for t in shp if t is not None], "launches_per_step": n, "ms_per_launch": round(ms, 4), "ms_per_step": round(ms * n, 4),
-                 "gflop": round(fl / 1e9, 1) if fl else None, "mfma_frac": round(fl / (ms * 1e-3) / 1e12 / PEAK, 4) if fl else None})
+                 "gflop": round(fl / 1e9, 1) if fl else None, "mfma_frac": round(fl / (ms * 1e-3) / 1e12 / PEAK, 4) if fl else None,
+                 "algorithmic_mb": round(by / 1e6, 1) if by else None, "hbm_frac": round(by / (ms * 1e-3) / 1e9 / PEAK_HBM, 4) if by else None,
+                 "roofline_ms": round(max(t_mfma, t_hbm), 4) if fl else None, "bound": ("hbm" if t_hbm > t_mfma else "mfma") if fl else None,
+                 "roofline_frac": round(max(t_mfma, t_hbm) / ms, 4) if fl else None})
 rows.sort(key=lambda r: -r["ms_per_step"])
 tot = sum(r["ms_per_step"] for r in rows)
 conv = [r for r in rows if r["gflop"]]
 cms, cfl = sum(r["ms_per_step"] for r in conv), sum(r["gflop"] * r["launches_per_step"] for r in conv)
+croof = sum(r["roofline_ms"] * r["launches_per_step"] for r in conv)
 for r in rows:
-    print("%8.3f ms  x%d  %-22s %-6s %s" % (r["ms_per_step"], r["launches_per_step"], r["op"], "" if r["mfma_frac"] is None else "%.2f" % r["mfma_frac"], r["shapes"]))
-print("total %.3f ms per step (exclusive); 3x3 convs %.3f ms, %.0f GFLOP algorithmic = %.3f of the MFMA peak" % (tot, cms, cfl, cfl / cms / PEAK if cms else 0))
+    print("%8.3f ms  x%d  %-22s %-16s %s" % (r["ms_per_step"], r["launches_per_step"], r["op"],
+                                            "" if r["mfma_frac"] is None else "%.2f mfma %.2f %s" % (r["mfma_frac"], r["roofline_frac"], r["bound"]), r["shapes"]))
+print("total %.3f ms per step (exclusive); 3x3 convs %.3f ms, %.0f GFLOP algorithmic = %.3f of the MFMA peak; sum of the launches' own rooflines "
+      "(max of MFMA- and HBM-bound time) %.3f ms = %.3f of the measured" % (tot, cms, cfl, cfl / cms / PEAK if cms else 0, croof, croof / cms if cms else 0))
 out = {"workload": "configs[3]: 2-D U-Net depth 4 / 32 filters, batch %d x %dx%dx%d, bf16, one stream (exclusive HIP-event times, mean over %d steps)" % (B, X, Y, C, K),
        "rows": rows, "total_ms_per_step": round(tot, 3), "conv_ms_per_step": round(cms, 3), "conv_gflop_per_step": round(cfl, 1),
-       "conv_mfma_frac": round(cfl / cms / PEAK, 4) if cms else None}
+       "conv_mfma_frac": round(cfl / cms / PEAK, 4) if cms else None, "conv_roofline_ms_per_step": round(croof, 3),
+       "conv_roofline_frac": round(croof / cms, 4) if cms else None,
+       "note": "roofline_ms of a launch = max(algorithmic FLOPs / 2.5 PF, algorithmic bf16 bytes / 8 TB/s): the full-resolution 3 x 3 layers are HBM-bound"}
 if len(sys.argv) > 1:
     import bench
     out["kernel_source_hash"] = bench.kernel_source_hash()
