@@ -37,7 +37,7 @@ def test_quoted_profile_figures_are_the_generated_ones():
     import sys
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import summarize_profiles as SP
-    tag = "r05"
+    tag = "r06"
     fresh = SP.summary(tag)
     path = os.path.join(ROOT, "profiles", "%s_summary.md" % tag)
     assert os.path.exists(path), "run: python tools/summarize_profiles.py %s" % tag
