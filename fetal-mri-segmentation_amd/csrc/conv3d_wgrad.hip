@@ -907,6 +907,293 @@ __global__ void __launch_bounds__(256, (BLK == 64 || F32) ? 1 : 2) k_conv_wgrad_
     }
 }
 
+// ============================================================================ parity-form weight gradient, kd'-sharing (round 6)
+// k_conv_wgrad_mfma<.., UPW> gives every (kd', parity, Cout block, Cin block) its own workgroup with 4 accumulators per wave: a 23 KiB x plane and
+// a 16 KiB gathered dy plane are staged for 128 MFMAs - 305 B of LDS-DMA and 1.25 KB of LDS reads per MFMA, the matrix pipe 0.39-0.47 busy
+// (profiles/r06_pmc_mfma.json).  Here a workgroup owns (parity, 64 Cout, 64 Cin) for BOTH kd' planes and all four (kh', kw'): 8 taps.  Walking up
+// a column of low-res d-plane tiles, unit g needs the x planes g + pd - 1 (kd' = 0) and g + pd (kd' = 1): the second is the next unit's first, so
+// ONE new x plane and one gathered dy plane per unit feed 256 MFMAs - 152 B of LDS-DMA per MFMA.  Wave = (kd', kh') tap pair x both kw' x the
+// whole 64 x 64 block: 2 x 2 x 2 accumulators (128 registers); a dy fragment serves 4 MFMAs, an x fragment 2: 0.75 KB of LDS reads per MFMA.
+// One workgroup per CU (3 x 23 + 2 x 16 KiB of LDS), one wave per SIMD; the DMA pieces and descriptors of the next unit are issued between the
+// MFMAs as in k_conv_wgrad_kd<64>.  Same result layout as the UPW kernel: dWc[p][kd'][kh'][kw'][Cout][C0] fp32 (atomics).
+struct WuCfg {
+    static constexpr int NW = 4;
+    static constexpr int ROWB = 128, RS = 8;                               // 64 channels x 2 B per x row and per dy row
+    static constexpr int X_INSTR = (wg::XROWS * RS + 63) / 64;             // 23
+    static constexpr int Y_INSTR = wg::YROWS * RS / 64;                    // 16
+    static constexpr int XS_BYTES = X_INSTR * 1024, YS_BYTES = Y_INSTR * 1024;
+    static constexpr int NXS = 3, NYS = 2;
+    static constexpr int LDS_BYTES = NXS * XS_BYTES + NYS * YS_BYTES;      // 103,424
+    static constexpr int XPW = (X_INSTR + NW - 1) / NW, YPW = Y_INSTR / NW;        // 6, 4
+#ifndef FMRI_WU_PF
+#define FMRI_WU_PF 3
+#endif
+#ifndef FMRI_WU_SPD
+#define FMRI_WU_SPD 2
+#endif
+    static constexpr int PF = FMRI_WU_PF;                                  // x fragments in flight ahead of their MFMAs
+    static constexpr int SP0 = 1, SPD = FMRI_WU_SPD;                                 // DMA piece p of the next unit behind step SP0 + SPD p (32 steps per unit: the last of the ten 12 steps before its end)
+};
+
+// W8: eight waves - waves 0-3 own Cin half 0 of the block, waves 4-7 Cin half 1 (64 accumulator registers each): two waves per SIMD, so that one
+// wave's DMA issue (10 pieces of ~100 cycles per 64-MFMA unit in the 4-wave form: 66 cycles per MFMA, profiles/r06_upw_kd_prof.log) runs under
+// its partner's MFMAs; a dy fragment then serves 2 MFMAs instead of 4 (1 KB of LDS reads per MFMA instead of 0.75).  Measured level with the
+// 4-wave form (62-66 cycles per MFMA slot, a 15 % barrier share: profiles/r06_upw_kd8_prof.log): kept as FMRI_UPW_KD=2, not the default.
+template <int G, bool W8>          // wave group G: taps kd' = G >> 1, kh' = G & 1, kw' = 0 | 1
+__device__ __forceinline__ void wu_run(const WkArgs& a, unsigned char* lds, int wv, int lane) {
+    typedef WuCfg K;
+    constexpr int KDP = G >> 1, KHP = G & 1, NW = W8 ? 8 : K::NW, ROWB = K::ROWB, RS = K::RS;
+    constexpr int NI = W8 ? 1 : 2;                                         // Cin halves per wave
+    constexpr int XPW = (K::X_INSTR + NW - 1) / NW, YPW = K::Y_INSTR / NW; // DMA pieces per wave and unit: 6 + 4 | 3 + 2
+    const int ih0 = W8 ? (wv >> 2) : 0;                                    // this wave's (first) Cin half
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    const SrcB& s = a.s;
+    const int N = a.N, D = a.D, H = a.H, W = a.W, Cout = a.Cout;          // D, H, W: the LOW-res grid (dy is [N][2D][2H][2W][Cout])
+    const int Cin = s.C0;
+    const int ncib = Cin / 64, ncob = Cout / 64;
+    const int ncombo = 8 * ncob * ncib;
+    const int wg_id = xcd_logical_id(blockIdx.x, gridDim.x);
+    int combo = wg_id % ncombo;
+    const int slab = wg_id / ncombo;
+    const int cib = combo % ncib; combo /= ncib;
+    const int cob = combo % ncob;
+    const int par = combo / ncob;                                          // output parity class (pd, ph, pw)
+    const int pd = par >> 2, ph = (par >> 1) & 1, pw = par & 1;
+    const int co0 = cob * 64, cc = cib * 64;
+    const int r = lane & 31, hk = lane >> 5;
+    const bool do_bias = G == 0 && a.db != nullptr && cib == 0 && ih0 == 0;            // each parity class covers its own eighth of the voxels
+
+    f32x16 acc[2][2][NI];                                                  // [kw'][Cout half][Cin half]
+#pragma unroll
+    for (int q = 0; q < 4 * NI; ++q)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc[q / (2 * NI)][(q / NI) & 1][q % NI][k] = 0.f;
+    float bsum[2] = {0.f, 0.f};
+
+    const int twn = W / wg::TW, thn = H / wg::TH;
+    const int nunits = N * D * thn * twn;
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr(lds));
+
+    // ---- DMA: per-lane constants of the column (cn, ch0, cw0); x rows outside the volume get an out-of-range offset (zeros)
+    int cn = 0, ch0 = 0, cw0 = 0;
+    int x_off[XPW], y_off[YPW];
+    unsigned x_ok = 0;
+    auto col_setup = [&](int n, int h0, int w0) {
+        cn = n; ch0 = h0; cw0 = w0;
+        x_ok = 0;
+#pragma unroll
+        for (int k = 0; k < XPW; ++k) {
+            const int id = wv + NW * k;
+            const int i = id * 64 + lane;
+            const int row = i / RS, ps = i % RS;
+            const int ls = ps ^ (((row >> 1) & 1) << 2);
+            const int xh = row / wg::XW, xw = row % wg::XW;
+            const int gh = h0 - 1 + xh, gw = w0 - 1 + xw;
+            const bool ok = id < K::X_INSTR && row < wg::XROWS && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W;
+            const int ghc = min(max(gh, 0), H - 1), gwc = min(max(gw, 0), W - 1);
+            x_off[k] = ((ghc * W + gwc) * Cin + ls * 8) * 2;                // bytes
+            x_ok |= (ok ? 1u : 0u) << k;
+        }
+#pragma unroll
+        for (int k = 0; k < YPW; ++k) {
+            const int id = (NW - 1 - wv) + NW * k;
+            const int i = id * 64 + lane;
+            const int row = i / RS, ps = i % RS;
+            const int ls = ps ^ (((row >> 1) & 1) << 2);
+            y_off[k] = (((row >> 4) * 4 * W + (row & 15) * 2) * Cout + ls * 8) * 2;        // voxel (2 h + ph, 2 w + pw) of the full-res plane
+        }
+    };
+    auto x_rsrc = [&](int gd) {                           // low-res plane gd of sample cn (outside the volume: zero records)
+        const bool dok = (unsigned)gd < (unsigned)D;
+        const int gdc = min(max(gd, 0), D - 1);
+        return dma_rsrc(s.p0 + ((int64_t)cn * D + gdc) * H * W * Cin + cc, dok ? (int)DMA_OOB : 0);
+    };
+    auto y_rsrc = [&](int d) {
+        return dma_rsrc(a.dy + ((((int64_t)cn * 2 * D + 2 * d + pd) * 2 * H + 2 * ch0 + ph) * 2 * W + 2 * cw0 + pw) * Cout + co0);
+    };
+    auto x_piece = [&](i32x4 rs, int slot, int k) {
+        const int id = wv + NW * k;
+        if (id < K::X_INSTR)
+            dma16_buf(rs, ((x_ok >> k) & 1) ? (unsigned)x_off[k] : DMA_OOB, __builtin_amdgcn_readfirstlane(lds0 + slot * K::XS_BYTES + id * 1024));
+    };
+    auto y_piece = [&](i32x4 rs, int ybuf, int k) {
+        const int id = (NW - 1 - wv) + NW * k;
+        dma16_buf(rs, (unsigned)y_off[k], __builtin_amdgcn_readfirstlane(lds0 + K::NXS * K::XS_BYTES + ybuf * K::YS_BYTES + id * 1024));
+    };
+    auto issue_x = [&](int gd, int slot) {
+        const i32x4 rs = x_rsrc(gd);
+#pragma unroll
+        for (int k = 0; k < XPW; ++k) x_piece(rs, slot, k);
+    };
+    auto issue_y = [&](int d, int ybuf) {
+        const i32x4 rs = y_rsrc(d);
+#pragma unroll
+        for (int k = 0; k < YPW; ++k) y_piece(rs, ybuf, k);
+    };
+
+    // ---- per-lane constants of the transposing fragment reads.  x: halo row of output voxel (h, w) under tap (kh', kw') = (h + kh' + ph) * XW + w + kw' + pw:
+    // the parity's shift ph * XW + pw goes into the lane part, the rest is a compile-time constant c: addr(c) = pre_x[c & 3] + (c >> 2) * 4 * ROWB
+    const int gq = lane >> 4, qd = (lane & 15) >> 2, pp = lane & 3;
+    const int lrow = 8 * (gq >> 1) + qd;
+    const int lslot = 2 * (gq & 1) + (pp >> 1);
+    const int shift = ph * wg::XW + pw;
+    int pre_x[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) pre_x[m] = (wg_slot_off<ROWB>(lrow + shift + m, lslot) + (pp & 1) * 8) ^ (ih0 << 6);       // Cin half 1: ^ 64
+    const int pre_y = wg_slot_off<ROWB>(lrow, lslot) + (pp & 1) * 8;                                         // Cout half 1: ^ 64
+
+    const int per = (nunits + a.nslab - 1) / a.nslab;
+    int u = slab * per;
+    const int u_end = min(nunits, u + per);
+    if (u < u_end) {
+        int d;
+        {
+            int q = u;
+            d = q % D; q /= D;
+            const int w0 = (q % twn) * wg::TW; q /= twn;
+            col_setup(q / thn, (q % thn) * wg::TH, w0);
+        }
+        issue_x(d + pd - 1, 0);
+        issue_x(d + pd, 1);
+        issue_y(d, 0);
+        int lo = 0, yb = 0;                               // ring slot of the kd' = 0 plane (kd' = 1: lo + 1, free: lo + 2, mod 3); dy slot
+#ifdef FMRI_PROF
+        unsigned long long wprof[12] = {};               // [0] DMA wait, [1] barrier, [2] column set-up, [3] fragment reads + MFMAs + DMA issue, [4] fresh-column tail, [6] units
+        PROF_T(wk0);
+#endif
+        for (; u < u_end; ++u) {
+            PROF_T(w0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            PROF_T(w1);
+            __builtin_amdgcn_s_barrier();                 // this unit's planes have landed everywhere; the previous unit is fully read
+            PROF_T(w2);
+            const bool more = u + 1 < u_end;
+            const bool fresh = more && d + 1 == D;        // the next unit starts a new column: two new planes, one slot is free
+            if (more && fresh) {
+                int w0 = cw0 + wg::TW, h0 = ch0, n = cn;
+                if (w0 == W) { w0 = 0; h0 += wg::TH; if (h0 == H) { h0 = 0; ++n; } }
+                col_setup(n, h0, w0);
+                d = -1;
+            }
+            PROF_T(w3);
+            const int hi = lo == 2 ? 0 : lo + 1, fr = hi == 2 ? 0 : hi + 1;
+            int xbase = (KDP ? hi : lo) * K::XS_BYTES;
+            asm volatile("" : "+s"(xbase));
+            const int ybase = K::NXS * K::XS_BYTES + yb * K::YS_BYTES;
+            const int nyb = yb ^ 1;
+            i32x4 nx_rs = {0, 0, 0, 0}, ny_rs = {0, 0, 0, 0};
+            // fragments: dy (A) per k-step and Cout half, x (B) per (k-step, kw', Cin half) = step st, PF steps ahead in a register ring
+            auto load_a = [&](int ks8, s16x8 (&av)[2]) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const unsigned char* p0 = lds + ybase + (h ? (pre_y ^ 64) : pre_y) + ks8 * wg::TW * ROWB;
+                    s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p0);
+                    s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p0 + 4 * ROWB));
+                    av[h] = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
+                }
+            };
+            auto load_b = [&](int st) {
+                const int ks8 = st / (2 * NI), j = (st / NI) & 1, i = st % NI;
+                const int c = (ks8 + KHP) * wg::XW + j;
+                const unsigned char* pb = lds + xbase + (i ? (pre_x[c & 3] ^ 64) : pre_x[c & 3]) + (c >> 2) * 4 * ROWB;
+                s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)pb);
+                s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(pb + 4 * ROWB));
+                return __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
+            };
+            constexpr int NS = 16 * NI, PF = K::PF, RING = PF + 1;
+            s16x8 av[2][2], b[RING];
+#pragma unroll
+            for (int q = 0; q < PF; ++q) b[q] = load_b(q);
+            load_a(0, av[0]);
+#pragma unroll
+            for (int st = 0; st < NS; ++st) {
+                const int ks8 = st / (2 * NI), j = (st / NI) & 1, i = st % NI, ab = ks8 & 1;
+                if (st + PF < NS) b[(st + PF) % RING] = load_b(st + PF);
+                if (st % (2 * NI) == (NI == 2 ? 1 : 0) && ks8 + 1 < 8) load_a(ks8 + 1, av[ab ^ 1]);
+                if (st % (2 * NI) == 0 && do_bias) {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) bsum[h] += bf2f((unsigned short)av[ab][h][q]);
+                }
+                const bf16x8_t bb = __builtin_bit_cast(bf16x8_t, b[st % RING]);
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+                    acc[j][h][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, av[ab][h]), bb, acc[j][h][i], 0, 0, 0);
+                // the next unit: its two descriptors behind step 0, its DMA pieces one at a time behind steps SP0 + SPD p (dy first)
+                if (more) {
+                    if (st == 0) {
+                        nx_rs = x_rsrc(fresh ? pd - 1 : d + 1 + pd);
+                        ny_rs = y_rsrc(d + 1);
+                    }
+                    if (st >= K::SP0 && (st - K::SP0) % K::SPD == 0 && (st - K::SP0) / K::SPD < XPW + YPW) {
+                        const int pc = (st - K::SP0) / K::SPD;
+                        if (pc < YPW) y_piece(ny_rs, nyb, pc);
+                        else x_piece(nx_rs, fr, pc - YPW);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            PROF_T(w4);
+#ifdef FMRI_PROF
+            wprof[0] += w1 - w0; wprof[1] += w2 - w1; wprof[2] += w3 - w2; wprof[3] += w4 - w3; wprof[6] += 1;
+#endif
+            if (fresh) {
+                __builtin_amdgcn_s_barrier();             // everybody is done with the old column's planes: its kd' = 0 slot takes the new column's second plane
+                issue_x(pd, lo);
+                lo = fr;                                  // new column: kd' = 0 plane in the slot that was free, kd' = 1 plane in the old `lo`: the ring runs lo, lo + 1
+                // (slots: new lo = fr, new hi must be fr + 1 mod 3 = old lo: holds)
+            } else {
+                lo = hi;
+            }
+            yb ^= 1;
+            ++d;
+#ifdef FMRI_PROF
+            { PROF_T(w5); wprof[4] += w5 - w4; }
+#endif
+        }
+#ifdef FMRI_PROF
+        { PROF_T(wk1); wprof[5] = wk1 - wk0; }
+        if (lane == 0) for (int i = 0; i < 7; ++i) atomicAdd(&g_prof[i], wprof[i]);
+#endif
+    }
+    // ---- flush: dWc[p][kd'][kh'][kw'][Cout][C0], fp32 atomics (128 contiguous bytes per half-wave)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int co = co0 + h * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * hk;
+                    const int ci = cc + (ih0 + i) * 32 + r;
+                    atomicAdd(&a.dw[((int64_t)((par * 2 + KDP) * 4 + KHP * 2 + j) * Cout + co) * Cin + ci], acc[j][h][i][reg]);
+                }
+    if (do_bias) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            float bq = bsum[h];
+            bq += __shfl_down(bq, 32);
+            if (hk == 0) atomicAdd(&a.db[co0 + h * 32 + r], bq);
+        }
+    }
+}
+
+template <bool W8>
+__global__ void __launch_bounds__(W8 ? 512 : 256, 1) k_conv_wgrad_up_kd(WkArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[WuCfg::LDS_BYTES];
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    switch (wv & 3) {
+        case 0: wu_run<0, W8>(a, lds, wv, lane); break;
+        case 1: wu_run<1, W8>(a, lds, wv, lane); break;
+        case 2: wu_run<2, W8>(a, lds, wv, lane); break;
+        default: wu_run<3, W8>(a, lds, wv, lane); break;
+    }
+}
+
 // dw[(kd*9+tap)][co0+co][cc+ci] += sum over the slabs of combo (kd, cob, cib).  Block = 32 float4 columns x 8 slab groups: every
 // thread sums its share of the slabs for 4 consecutive elements (4 loads in flight), the 8 partial sums meet in LDS in a fixed order
 // (bit-reproducible), one thread per column adds the total to dw.  Workgroup index of the wgrad launch = slab * ncombo + combo.
@@ -1214,8 +1501,24 @@ int conv3d_upcat_wgrad_mfma_ex(const void* src0_low, int C0, const void* src1, i
         float* const dbu = C1 == 0 ? db : nullptr;         // with skip channels the plain launch below produces the bias gradient
         const char* e = getenv("FMRI_WGRAD_WS");
         const int ws_mode = e ? atoi(e) : 0;
-        const bool ws_up = wide && (ws_mode == 1 || (ws_mode == 2 && 2.0 * 8 * 8 * (double)C0 * Cout * N * Dl * Hl * Wl >= 0.3e12));
-        if (ws_up) k_conv_wgrad_mfma<2, true, true><<<combos * nslab, 512, 0, st>>>(s, (const bf16_t*)dy, dwc, dbu, N, Dl, Hl, Wl, Cout, nslab, nullptr, C0);
+        // kd'-sharing form (k_conv_wgrad_up_kd, round 6): 3-D, 64-wide blocks of both channel counts.  FMRI_UPW_KD=0: the per-kd' kernel (rounds 2-5),
+        // 1 (default): four waves, 2: eight waves.  Same-box A/B (profiles/r06_upw_kd8_ab.log): step 299.0 -> 300.8 / 301.0 patches/s, the three
+        // launches' weight gradients 2.30 -> 2.21 ms; both forms run at 62-66 cycles per MFMA slot (profiles/r06_upw_kd_prof.log, r06_upw_kd8_prof.log):
+        // at 152 B of LDS-DMA per MFMA the kernel asks the L2 for ~5.6 TB/s (2.5 GB per dec0a launch)
+        static int upw_kd = -1;
+        if (upw_kd < 0) {
+            const char* f = getenv("FMRI_UPW_KD");
+            upw_kd = f ? atoi(f) : 1;
+        }
+        if (upw_kd && !planar && wide && Cout % 64 == 0) {
+            const int combos_kd = 8 * (Cout / 64) * (C0 / 64);
+            int nsl = (fwd_cu_count() + combos_kd - 1) / combos_kd;
+            if (nsl > nunits) nsl = nunits;
+            if (nsl < 1) nsl = 1;
+            const WkArgs wa{s, (const bf16_t*)dy, dwc, dbu, N, Dl, Hl, Wl, Cout, nsl, C0};
+            if (upw_kd == 2) k_conv_wgrad_up_kd<true><<<combos_kd * nsl, 512, 0, st>>>(wa);        // FMRI_UPW_KD=2: the 8-wave form (two waves per SIMD): level
+            else k_conv_wgrad_up_kd<false><<<combos_kd * nsl, 256, 0, st>>>(wa);
+        } else if (wide && (ws_mode == 1 || (ws_mode == 2 && 2.0 * 8 * 8 * (double)C0 * Cout * N * Dl * Hl * Wl >= 0.3e12))) k_conv_wgrad_mfma<2, true, true><<<combos * nslab, 512, 0, st>>>(s, (const bf16_t*)dy, dwc, dbu, N, Dl, Hl, Wl, Cout, nslab, nullptr, C0);
         else if (wide) k_conv_wgrad_mfma<2, true><<<combos * nslab, wg::NTHREADS, 0, st>>>(s, (const bf16_t*)dy, dwc, dbu, N, Dl, Hl, Wl, Cout, nslab, nullptr, C0);
         else k_conv_wgrad_mfma<1, true><<<combos * nslab, wg::NTHREADS, 0, st>>>(s, (const bf16_t*)dy, dwc, dbu, N, Dl, Hl, Wl, Cout, nslab, nullptr, C0);
     }

@@ -497,6 +497,14 @@ for tag, (N, D, H, W, C0, C1, Cout, up0) in dict(cols=(5, 4, 128, 128, 64, 0, 64
     ops.conv3d_wgrad(x0.to(torch.bfloat16).cuda(), None if x1 is None else x1.to(torch.bfloat16).cuda(), dy.to(torch.bfloat16).cuda(), dw, db, up0=bool(up0))
     torch.cuda.synchronize()
     out[tag + "_dw"], out[tag + "_db"] = dw.cpu().numpy(), db.cpu().numpy()
+# (c) the parity-form weight gradient (fmri_conv3d_upcat_wgrad): kd'-sharing kernel (default) against the per-kd' kernel (FMRI_UPW_KD=0)
+N, D, H, W, C0, C1, Cout = 2, 8, 32, 64, 128, 64, 64
+xl, xs = dyadic((N, D // 2, H // 2, W // 2, C0), -4, 4, 4), dyadic((N, D, H, W, C1), -4, 4, 4)
+dy = dyadic((N, D, H, W, Cout), -2, 2, 2, density=1.0 / 16)
+dw, db = torch.zeros((27, Cout, C0 + C1), device="cuda"), torch.zeros(Cout, device="cuda")
+ops.conv3d_upcat_wgrad(xl.to(torch.bfloat16).cuda(), xs.to(torch.bfloat16).cuda(), dy.to(torch.bfloat16).cuda(), dw, db, torch.empty(64 * Cout * C0, device="cuda"))
+torch.cuda.synchronize()
+out["upcat_dw"], out["upcat_db"] = dw.cpu().numpy(), db.cpu().numpy()
 np.savez(sys.argv[1], **out)
 print("DONE")
 """
@@ -507,18 +515,20 @@ def test_kd_sharing_weight_gradient_kernels_are_exact(tmp_path):
     x-plane ring; FMRI_WGRAD_KD=3 forces them wherever the shape allows: the 4-wave / 32-block form that is the default on every launch without
     fused up-sampling, and
     the 8-wave / 64-block form) against the per-kd kernel (FMRI_WGRAD_KD=0) on dyadic data whose sums are exact in fp32 in any order: all three
-    must agree BIT FOR BIT - runs that cross column boundaries, a dual source, a fused up-sampled source"""
+    must agree BIT FOR BIT - runs that cross column boundaries, a dual source, a fused up-sampled source; and (round 6) the parity-form weight
+    gradient from the kd'-sharing kernel k_conv_wgrad_up_kd (default) against the per-kd' kernel (FMRI_UPW_KD=0)"""
     import subprocess
     import sys
     f = tmp_path / "kd.py"
     f.write_text(KD_SCRIPT % ROOT)
     res = []
-    for tag, env in (("kd32", dict(FMRI_WGRAD_KD="3")), ("kd64", dict(FMRI_WGRAD_KD="3", FMRI_WGRAD_KD_BLK="64")), ("perkd", dict(FMRI_WGRAD_KD="0"))):
+    for tag, env in (("kd32", dict(FMRI_WGRAD_KD="3", FMRI_UPW_KD="2")), ("kd64", dict(FMRI_WGRAD_KD="3", FMRI_WGRAD_KD_BLK="64")),      # (kd32 arm: the 8-wave parity form, kd64 arm: the default 4-wave one)
+                     ("perkd", dict(FMRI_WGRAD_KD="0", FMRI_UPW_KD="0"))):
         o = str(tmp_path / (tag + ".npz"))
         r = subprocess.run([sys.executable, str(f), o], capture_output=True, text=True, timeout=900, env=dict(os.environ, **env))
         assert r.returncode == 0 and "DONE" in r.stdout, (tag, r.stdout[-1000:], r.stderr[-3000:])
         res.append(np.load(o))
-    assert len(res[0].files) == 6
+    assert len(res[0].files) == 8
     for k in res[0].files:
         assert float(np.abs(res[2][k]).max()) > 0
         assert np.array_equal(res[0][k], res[2][k]), ("kd32", k)
