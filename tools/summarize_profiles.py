@@ -79,12 +79,12 @@ def summary(tag):
         w("## rocprofv3 kernel stats, %s (`%s`, %d profiled steps; %s)" % (kind, fname, steps, stamp.lstrip("# ")))
         w("")
         fc, ft = _family(out, steps, ("k_conv_fwd_ws", "k_conv_fwd_mfma"))
-        wc, wt = _family(out, steps, ("k_conv_wgrad_mfma", "k_conv_wgrad_kd"))
+        wc, wt = _family(out, steps, ("k_conv_wgrad_mfma", "k_conv_wgrad_kd", "k_conv_wgrad_up_kd"))
         tot = sum(v[1] for v in out.values()) / max(steps, 1)
         w("* forward / input-gradient family (`k_conv_fwd_*`): %.0f launches per step, **%.2f ms per step**, %.0f us per launch" % (fc, ft, ft / max(fc, 1) * 1e3))
-        w("* weight-gradient family (`k_conv_wgrad_mfma`, `k_conv_wgrad_kd`): %.0f launches per step, **%.2f ms per step**, %.0f us per launch" % (wc, wt, wt / max(wc, 1) * 1e3))
+        w("* weight-gradient family (`k_conv_wgrad_mfma`, `k_conv_wgrad_kd`, `k_conv_wgrad_up_kd`): %.0f launches per step, **%.2f ms per step**, %.0f us per launch" % (wc, wt, wt / max(wc, 1) * 1e3))
         w("* everything else: %.2f ms per step; all kernels: %.2f ms per step" % (tot - ft - wt, tot))
-        rest = sorted(((v[1] / max(steps, 1), n) for n, v in out.items() if not n.startswith(("k_conv_fwd_ws", "k_conv_fwd_mfma", "k_conv_wgrad_mfma", "k_conv_wgrad_kd"))), reverse=True)[:8]
+        rest = sorted(((v[1] / max(steps, 1), n) for n, v in out.items() if not n.startswith(("k_conv_fwd_ws", "k_conv_fwd_mfma", "k_conv_wgrad_mfma", "k_conv_wgrad_kd", "k_conv_wgrad_up_kd"))), reverse=True)[:8]
         w("* largest of the rest (ms per step): " + ", ".join("`%s` %.3f" % (n[:40], t) for t, n in rest))
         w("")
     tr = _json("%s_pmc_traffic_per_step.json" % tag)
