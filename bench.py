@@ -13,7 +13,10 @@ anything touches the GPU - relays rank 0's JSON line and exits non-zero when any
 Prints ONE JSON line on rank 0.  Besides the driver contract it carries
   "roofline"     for the dominant kernel (live HIP-event timing of its launches in the timed region: every launch of every 10th timed
                  step - event brackets on every step cost 2.3 % of the step, see --launch-timing-every), and
-  "cpu_baseline" the CPU oracle (torch-CPU restatement; Keras/TF are absent here and on the GPU box) timed on the host.
+  "cpu_baseline" the CPU oracle (torch-CPU restatement; Keras/TF are absent here and on the GPU box) timed on the host (the only leg that
+                 touches oracle/; its first step's forward pass is also the reference of the next item),
+  "parity_mode"  what FMRI_DTYPE=fp32 costs and delivers at this configuration: patches/s of the fp32 step on the fp32 instantiation of the
+                 same MFMA kernels, logits / Dice of one patch against that reference (north-star bars 1e-3 / 1e-4).
 """
 import argparse
 import json
@@ -139,12 +142,18 @@ def cpu_baseline(budget_s=25.0):
     torch.set_num_threads(best)
     spec = O.Spec((1, 64, 128, 128))
     W = spec.init_weights(42)
+    W0 = dict(W)                            # the initial weights (Adam rebinds the entries of W, it does not write into the arrays)
     x, y = O.synthetic_batch((1, 1, 64, 128, 128))
     opt = O.KerasAdam(W, lr=1e-4, dtype=np.float32)
     t0 = time.time()
     n = 0
+    ref = None
     while True:
-        O.train_step(spec, W, opt, x, y, dtype=torch.float32)
+        r = O.train_step(spec, W, opt, x, y, dtype=torch.float32)
+        if n == 0:
+            # the first timed step's forward pass, on the initial weights: the reference the parity-mode leg compares the fp32 engine with
+            # (the oracle is used in THIS leg only; what leaves it is data)
+            ref = {"weights": W0, "x": x, "y": y, "logits": r["logits"], "dice": r["dice"]}
         n += 1
         if n >= 3 or time.time() - t0 > budget_s:
             break
@@ -152,7 +161,7 @@ def cpu_baseline(budget_s=25.0):
     return {"value": n / dt, "unit": "patches/s", "cores": best, "kind": "port",
             "sample": "%d full training steps (fwd+Dice+bwd+Adam, fp32, torch-CPU/oneDNN restatement of the Keras path) on one "
                       "1x64x128x128 patch of the same depth-4/32-filter model, %d threads (best of %s on a probe; host has %d); "
-                      "Keras/TF not installed" % (n, best, cands, ncpu)}
+                      "Keras/TF not installed" % (n, best, cands, ncpu)}, ref
 
 
 def val_dice_leg(batch, steps, spatial=(64, 128, 128), volume=(160, 256, 256), lr=1e-4, log=None):
@@ -217,16 +226,16 @@ def val_dice_leg(batch, steps, spatial=(64, 128, 128), volume=(160, 256, 256), l
             "train_model_seconds": round(t_train, 2), "seconds": round(time.perf_counter() - t0, 2)}, model
 
 
-def parity_mode_leg(batch, spatial=(64, 128, 128), steps=3):
+def parity_mode_leg(batch, ref=None, spatial=(64, 128, 128), steps=3):
     """What the parity mode costs and delivers: FMRI_DTYPE=fp32 at the benchmarked configuration.  fp32 tensors run the
     fp32 instantiation of the SAME kernels (v_mfma_f32_32x32x2_f32: halo box, LDS-DMA, swizzle, asynchronous drain, pooled-copy tail, parity
     form, kd-sharing weight gradient - csrc/conv3d_mfma.hip / conv3d_wgrad.hip, F32), so the north-star's 1e-3 logits bar is met by the
     benchmarked kernel structure.  patches_per_s: full training steps on a live batch; logits_rel / dice_abs: one patch against the CPU oracle
-    (reference unet3d/unet.py:68, metrics.py:11-15) on the same weights."""
+    (reference unet3d/unet.py:68, metrics.py:11-15) on the same weights - `ref` is the first step of the cpu_baseline leg (weights, batch,
+    logits, Dice: plain arrays; this leg does not touch oracle/), None with --no-cpu-baseline."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import learnable_task as LT
     from fmri_hip.engine import UNetEngine, UNetPlan
-    from oracle import unet_oracle as O
     plan = UNetPlan(1, spatial, depth=4, n_base_filters=32)
     eng = UNetEngine(plan, batch, dtype=torch.float32)
     x, y = LT.device_batch(LT.HELD_OUT + 900_000, batch, spatial)
@@ -241,21 +250,20 @@ def parity_mode_leg(batch, spatial=(64, 128, 128), steps=3):
     fl = sum(2.0 * 27 * c["cin"] * c["cout"] * batch * int(np.prod(plan.level_dims(c["level"]))) for c in plan.convs_forward_order()) * 3
     del eng
     torch.cuda.empty_cache()
-    spec = O.Spec((1,) + tuple(spatial), depth=4, n_base_filters=32)
-    W = spec.init_weights(42)
-    xo, yo = O.synthetic_batch((1, 1) + tuple(spatial))
-    torch.set_num_threads(min(32, os.cpu_count() or 1))
-    ref = O.loss_and_grads(spec, W, xo, yo, dtype=torch.float32)
-    e1 = UNetEngine(plan, 1, dtype=torch.float32)
-    e1.load_keras_weights(W)
-    e1.forward(torch.from_numpy(xo).cuda().reshape(1, *spatial, 1).contiguous())
-    sums = e1.loss_forward(torch.from_numpy(yo).cuda().reshape(-1).contiguous())
-    torch.cuda.synchronize()
-    lg = e1.logits.cpu().numpy().reshape(ref["logits"].shape)
+    logits_rel = dice_abs = None
+    if ref is not None:
+        e1 = UNetEngine(plan, 1, dtype=torch.float32)
+        e1.load_keras_weights(ref["weights"])
+        e1.forward(torch.from_numpy(ref["x"]).cuda().reshape(1, *spatial, 1).contiguous())
+        sums = e1.loss_forward(torch.from_numpy(ref["y"]).cuda().reshape(-1).contiguous())
+        torch.cuda.synchronize()
+        lg = e1.logits.cpu().numpy().reshape(ref["logits"].shape)
+        logits_rel = float(np.abs(lg - ref["logits"]).max() / np.abs(ref["logits"]).max())
+        dice_abs = float(abs(e1.metrics_from_sums(sums.cpu().numpy())["dice_coefficient"] - ref["dice"]))
     on_mfma = all(lib_uses_mfma(c, plan) for c in plan.convs_forward_order() if c["cin"] > 1)
     return {"dtype": "fp32", "patches_per_s": batch / dt, "ms_per_step": dt * 1e3, "steps": steps,
-            "logits_rel": float(np.abs(lg - ref["logits"]).max() / np.abs(ref["logits"]).max()), "logits_bar": 1e-3,
-            "dice_abs": float(abs(e1.metrics_from_sums(sums.cpu().numpy())["dice_coefficient"] - ref["dice"])), "dice_bar": 1e-4,
+            "logits_rel": logits_rel, "logits_bar": 1e-3, "dice_abs": dice_abs, "dice_bar": 1e-4,
+            "reference": "the CPU oracle's forward pass of the cpu_baseline leg (same weights, same patch)" if ref is not None else "none: --no-cpu-baseline",
             "f32_mfma_frac": fl / dt / 1e12 / 157.3,
             "kernels": "fp32 instantiation of the benchmarked MFMA kernels (v_mfma_f32_32x32x2_f32; peak 157.3 TFLOP/s = the fp32 vector rate)" if on_mfma
                        else "VALU kernels (conv3d_generic.hip): FMRI_F32_MFMA=0 or a shape outside the MFMA family",
@@ -1039,9 +1047,11 @@ def main():
             out["secondary"] = {"cfg4": cfg4_leg(model), "cfg3": cfg3_leg()}
             del model
             torch.cuda.empty_cache()
-            out["parity_mode"] = parity_mode_leg(a.batch)
+    ref = None
     if world == 1 and not a.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline()
+        out["cpu_baseline"], ref = cpu_baseline()
+    if world == 1 and not a.no_secondary:
+        out["parity_mode"] = parity_mode_leg(a.batch, ref)
     print(json.dumps(out))
 
 

@@ -132,6 +132,9 @@ def test_bench_contract_smoke():
     assert j["n_gpus"] == 1 and j["steps"] == 2 and j["dtype"] == "bf16" and j["value"] > 10
     r = j["roofline"]
     assert r["bound"] == "mfma" and 0 < r["frac"] < 1 and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    # the parity-mode leg runs the fp32 step on the MFMA kernels; without the cpu_baseline leg it has no oracle reference to compare with
+    pm = j["parity_mode"]
+    assert pm["dtype"] == "fp32" and pm["patches_per_s"] > 1 and pm["logits_rel"] is None and pm["kernels"].startswith("fp32 instantiation")
 
 
 WS_SCRIPT = r"""
