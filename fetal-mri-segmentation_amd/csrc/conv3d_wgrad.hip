@@ -428,10 +428,9 @@ struct WkCfg {
     static constexpr int LDS_BYTES = NXS * XS_BYTES + NYS * YS_BYTES;      // 65,536 / 81,920
     static constexpr int PF = BLK == 64 ? 4 : 3;                  // x fragments in flight ahead of their MFMAs
     static constexpr int XPW = (X_INSTR + NW - 1) / NW, YPW = (Y_INSTR + NW - 1) / NW;      // 3, 2 / 4
-#ifndef FMRI_KD32_SPREAD
-#define FMRI_KD32_SPREAD 0
-#endif
-    static constexpr bool SPREAD = (BLK == 64 || FMRI_KD32_SPREAD) && !F32;      // DMA pieces of the next unit issued between the MFMAs of this one
+    // DMA pieces of the next unit issued between the MFMAs of this one (one wave per SIMD: nobody else issues under this wave's matrix work).
+    // The 32-block kernel keeps its burst behind the barrier: the spread form is level there (profiles/r06_kd32_spread_ab.log)
+    static constexpr bool SPREAD = BLK == 64 && !F32;
     static constexpr int SP0 = 1, SPD = 3;                        // ... piece p behind step SP0 + SPD * p (a step = NH MFMAs)
 };
 
@@ -654,22 +653,13 @@ __device__ __forceinline__ void wk_run(const WkArgs& a, unsigned char* lds, int 
     // issue side keeps a cursor (cn, ch0, cw0) of the column being issued and, per column, the lane constants of its pieces: element offset
     // inside a plane and whether that halo row lies inside the volume (bit j of x_ok); per plane what is left is a scalar base, one 64-bit add
     // and a select per instruction.
-    // SPREAD (one wave per SIMD): the 6-tap wave has 16 MFMAs fewer per unit than the 7-tap waves, and a DMA piece costs its wave ~60 cycles
-    // of issue - the pieces are dealt so that the sums are level: the dy plane's instructions 0-14 to waves 0-2 (five each), its last one and
-    // the whole x plane (12) to wave 3.  Otherwise round-robin over the waves.
-#ifndef FMRI_W1_BALANCE
-#define FMRI_W1_BALANCE 0
-#endif
-#ifndef FMRI_W1_DESC_HOOK
-#define FMRI_W1_DESC_HOOK 1
-#endif
-    constexpr bool BAL = K::SPREAD && FMRI_W1_BALANCE;
-    constexpr int XPW_ = BAL ? (G == 3 ? K::X_INSTR : 0) : K::XPW, YPW_ = BAL ? (G == 3 ? 1 : 5) : K::YPW;
-    static_assert(!BAL || (K::Y_INSTR == 16 && K::X_INSTR == 12), "piece table of the one-wave-per-SIMD form");
-    auto xid = [&](int k) { return BAL ? k : wv + NW * k; };
-    auto yid = [&](int k) { return BAL ? (G == 3 ? 15 : 5 * G + k) : (NW - 1 - wv) + NW * k; };   // (round-robin: dealt from the other end - the waves with one x instruction fewer go first)
+    // (One wave per SIMD: dealing the pieces so that the 6-tap wave, which has 16 MFMAs fewer per unit, carries 13 of the 28 was measured
+    // SLOWER - profiles/r06_wgrad_w1_layers.log, variant c - and is gone.)
+    constexpr int XPW_ = K::XPW, YPW_ = K::YPW;
+    auto xid = [&](int k) { return wv + NW * k; };
+    auto yid = [&](int k) { return (NW - 1 - wv) + NW * k; };      // dealt from the other end: the waves with one x instruction fewer go first
     int cn = 0, ch0 = 0, cw0 = 0;
-    int x_off[XPW_ > 0 ? XPW_ : 1], y_off[YPW_];
+    int x_off[XPW_], y_off[YPW_];
     unsigned x_ok = 0;
     auto col_setup = [&](int n, int h0, int w0) {
         cn = n; ch0 = h0; cw0 = w0;
@@ -785,10 +775,6 @@ __device__ __forceinline__ void wk_run(const WkArgs& a, unsigned char* lds, int 
                     col_setup(n, h0, w0);
                     d = -1;
                 }
-                if constexpr (K::SPREAD && !FMRI_W1_DESC_HOOK) {
-                    nx_rs = x_rsrc(fresh ? -1 : d + 2);
-                    ny_rs = y_rsrc(d + 1);
-                }
                 if constexpr (!K::SPREAD) {
                     issue_x(fresh ? -1 : d + 2, (xs + 1) & 3);
                     issue_y(d + 1, yb ^ 1);
@@ -803,8 +789,8 @@ __device__ __forceinline__ void wk_run(const WkArgs& a, unsigned char* lds, int 
                 if constexpr (K::SPREAD) {
                     // behind step 0: the next unit's two descriptors - ~60 scalar instructions (64-bit multiplies) that sat between the barrier
                     // and the unit's first MFMA; piece p of the next unit behind step SP0 + SPD p, the dy pieces first
-                    constexpr int SPD = (BAL && G == 3) ? 2 : K::SPD;
-                    if (FMRI_W1_DESC_HOOK && st == 0 && more) {
+                    constexpr int SPD = K::SPD;
+                    if (st == 0 && more) {
                         nx_rs = x_rsrc(fresh ? -1 : d + 2);
                         ny_rs = y_rsrc(d + 1);
                     }
@@ -925,14 +911,8 @@ struct WuCfg {
     static constexpr int NXS = 3, NYS = 2;
     static constexpr int LDS_BYTES = NXS * XS_BYTES + NYS * YS_BYTES;      // 103,424
     static constexpr int XPW = (X_INSTR + NW - 1) / NW, YPW = Y_INSTR / NW;        // 6, 4
-#ifndef FMRI_WU_PF
-#define FMRI_WU_PF 3
-#endif
-#ifndef FMRI_WU_SPD
-#define FMRI_WU_SPD 2
-#endif
-    static constexpr int PF = FMRI_WU_PF;                                  // x fragments in flight ahead of their MFMAs
-    static constexpr int SP0 = 1, SPD = FMRI_WU_SPD;                                 // DMA piece p of the next unit behind step SP0 + SPD p (32 steps per unit: the last of the ten 12 steps before its end)
+    static constexpr int PF = 3;                                           // x fragments in flight ahead of their MFMAs (5: level)
+    static constexpr int SP0 = 1, SPD = 2;                                 // DMA piece p of the next unit behind step SP0 + SPD p (32 steps per unit; SPD 1 level, 3 slower: profiles/r06_upw_kd_tune.log)
 };
 
 // W8: eight waves - waves 0-3 own Cin half 0 of the block, waves 4-7 Cin half 1 (64 accumulator registers each): two waves per SIMD, so that one
