@@ -61,6 +61,24 @@ def test_forward_bias_relu(ops, case):
     assert_close(y, f64(y2), *TOL, what=name + " vs generic kernel")
 
 
+@pytest.mark.parametrize("act,alpha", [(0, 0.0), (2, 0.01)], ids=["no_activation", "leaky_relu"])
+def test_forward_three_chunks_three_blocks_other_activations(ops, act, alpha):
+    """48 input channels = three 16-channel chunks (the second halo slot is re-used within a tile), 96 output channels = three 32-wide blocks,
+    three samples; the epilogue's other two activations (none: every input-gradient launch; LeakyReLU: the Isensee models)"""
+    from fmri_hip._lib import IMPL_MFMA
+    N, D, H, W, C0, Cout = 3, 8, 16, 32, 48, 96
+    x = rnd((N, D, H, W, C0), 31, F32)
+    w = rnd((27, Cout, C0), 32, F32, scale=0.2)
+    bias = rnd((Cout,), 33, F32)
+    y = torch.full((N, D, H, W, Cout), float("nan"), dtype=F32, device="cuda")
+    ops.conv3d_fwd(x, None, w, bias, y, act=act, alpha=alpha, impl=IMPL_MFMA)
+    torch.cuda.synchronize()
+    ref = ref_conv_fwd(f64(x), None, False, f64(w), f64(bias), 0)
+    if act == 2:
+        ref = torch.where(ref > 0, ref, alpha * ref)
+    assert_close(y, ref, *TOL, what="act %d" % act)
+
+
 @pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
 def test_input_gradient_form_with_relu_mask(ops, case):
     name, N, D, H, W, C0, up0, C1, Cout = case
