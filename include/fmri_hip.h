@@ -45,7 +45,10 @@ int fmri_clock_stamp(unsigned long long* out16, fmri_stream_t stream);
 /* 0/1: would fmri_conv3d_fwd / _wgrad take the MFMA path for this shape and dtype? (host-side query, no GPU needed)
  * Size limit of the MFMA path: its LDS-DMA addresses a halo box / a plane with 32-bit byte offsets below 2^31 (an offset at or above
  * 2^31 is the hardware's "write zeros" encoding): forward needs 2 * (min(D, 4) + 2) * H * W * max(C0, C1) * 2 B < 2^31, the weight
- * gradient H * W * max(C0, C1, Cout) * 2 B < 2^31; larger layers fall back to the generic kernels (AUTO) or return FMRI_E_SHAPE (MFMA). */
+ * gradient H * W * max(C0, C1, Cout) * 2 B < 2^31; larger layers fall back to the generic kernels (AUTO) or return FMRI_E_SHAPE (MFMA).
+ * dtype FMRI_F32 (round 6): the fp32 instantiation of the same kernels (v_mfma_f32_32x32x2_f32: an exact fp32 fmaf chain per output) takes
+ * 3-D launches on the 4x8x16 tiling whose channel counts are multiples of 16 (forward / input gradient; Cout in multiples of 32) resp. 32
+ * (weight gradient); the size limits above count 4 bytes per element.  Environment FMRI_F32_MFMA=0 keeps fp32 on the generic kernels. */
 int fmri_conv3d_uses_mfma(int C0, int C1, int Cout, int D, int H, int W, int dtype);
 
 /* ---- Conv3D 3x3x3, stride 1, 'same' (+BiasAdd +activation) — reference unet3d/unet.py:102,113 (create_convolution_block)
@@ -60,8 +63,9 @@ int fmri_conv3d_fwd(const void* src0, int C0, int up0, const void* src1, int C1,
                     const void* mask, void* y, int N, int D, int H, int W, int Cout, int act, float alpha, int dtype,
                     int impl, int planar, fmri_stream_t stream);
 
-/* ---- Conv3D block with its HBM-bound consumer folded into the epilogue (bf16 MFMA path only; single full-resolution source).
- * The tile of y is still in LDS when it is stored; from those same bf16 values the kernel can also produce
+/* ---- Conv3D block with its HBM-bound consumer folded into the epilogue (MFMA path only; single full-resolution source; bf16, and fp32 for
+ * the pooled copy - the fp32 form works on 32-wide blocks, which never see a voxel's whole channel range: no logits there).
+ * The tile of y is still in LDS when it is stored; from those same stored values the kernel can also produce
  *   y_pool [N][D/2][H/2][W/2][Cout]  = MaxPooling3D(2) of y            (reference unet3d/unet.py:51 behind the encoder block :45-50)
  *   logits [N*D*H*W] fp32            = Conv3D(1, (1,1,1))(y) = sum_c w1[c]*y[v][c] + b1[0]   (reference unet.py:68, n_labels = 1)
  * so that neither fmri_maxpool3d_2x_fwd nor fmri_conv1x1_fwd has to read y back.  Either output may be NULL (not both).
@@ -81,7 +85,7 @@ int fmri_conv3d_dgrad(const void* dy, int Cout, const void* w_dgrad, const void*
  * Same dual-source / fused-upsample input description as fmri_conv3d_fwd.
  * workspace (optional, device, fp32 scratch of at least fmri_conv3d_wgrad_workspace_bytes(...) bytes): the MFMA path then flushes its
  * per-workgroup partial sums with plain stores and reduces them in a second launch (bit-reproducible, faster than the fp32-atomic
- * flush used when workspace == NULL). */
+ * flush used when workspace == NULL).  fp32 planes on the MFMA path (channel counts in multiples of 32, 3-D) always use the atomic flush. */
 int fmri_conv3d_wgrad(const void* src0, int C0, int up0, const void* src1, int C1, const void* dy, float* dw, float* db,
                       int N, int D, int H, int W, int Cout, int dtype, int impl, int planar, void* workspace,
                       int64_t workspace_bytes, fmri_stream_t stream);
@@ -114,7 +118,8 @@ int fmri_border_class_sums(const void* dy, float* out27, int N, int D, int H, in
 /* ---- [nearest_up2(src0) | src1] -> Conv3D(3x3x3) without the redundant taps (reference unet.py:132-138 UpSampling3D, :61
  * concatenate, :102 Conv3D).  Output voxel 2g+p of the up-sampled source only sees low-res voxels {g-1,g} (p = 0) or {g,g+1}
  * (p = 1) per axis with pre-summed weights: 8 parity classes x 8 taps on the LOW-res tensor instead of 27 taps on 8x the voxels.
- * Same result as fmri_conv3d_fwd(up0 = 1) up to one extra bf16 rounding of the up-sampled channels' partial sum. bf16, 3-D only.
+ * Same result as fmri_conv3d_fwd(up0 = 1) up to one extra rounding (to the storage dtype) of the up-sampled channels' partial sum.  3-D; bf16, and
+ * fp32 where fmri_conv3d_upcat_ok says so (bit 0; the fp32 weight gradient takes the 27-tap kernel: bit 1 is bf16 only).
  * fmri_conv3d_upcat_ok (D,H,W = OUTPUT dims): bit 0 = forward / input gradients supported, bit 1 = weight gradient too. */
 int fmri_conv3d_upcat_ok(int C0, int C1, int Cout, int D, int H, int W, int dtype);
 /* w: fp32 master [27][Cout][C0+C1] (up-sampled channels first).  Outputs (any may be NULL): w_up_fwd [8][8][Cout][C0],
