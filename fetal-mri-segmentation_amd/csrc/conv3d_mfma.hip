@@ -458,9 +458,19 @@ k_conv_fwd_mfma(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__
             constexpr int VPI = 64 / LPV;                // voxels per instruction
             float4 bvn[NT][4];
             load_bias(has_next ? nxt.co0 : cur.co0, bvn);
+            const int64_t org = ((((int64_t)cur.n * D + cur.d0) * H + cur.h0) * W + cur.w0) * Cout + cur.co0;
+            // the residual's lines of this wave's two column tiles, requested in front of the barrier and the fp32 transposition (round 6: they
+            // were loaded inside the store loop, one exposed memory latency per column tile - see the ReLU-mask lines of the plain epilogue)
+            uint4 rq[2][32 / VPI];
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int kk = 0; kk < 32 / VPI; ++kk) {
+                    const int rt = 2 * wv + j, rr = kk * VPI + lane / LPV, q8 = lane % LPV;
+                    rq[j][kk] = *reinterpret_cast<const uint4*>(residual + org + ((tile_d(rt) * H + tile_h(rt, rr)) * W + lane_w(rr)) * Cout + q8 * 8);
+                }
             __builtin_amdgcn_s_barrier();
             unsigned char* const stage = lds + hb * HALO_BYTES + wv * (32 * BN * 4);
-            const int64_t org = ((((int64_t)cur.n * D + cur.d0) * H + cur.h0) * W + cur.w0) * Cout + cur.co0;
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
 #pragma unroll
@@ -478,7 +488,7 @@ k_conv_fwd_mfma(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__
                     const float4 a0 = *reinterpret_cast<const float4*>(stage + rr * (BN * 4) + ((((2 * q8) ^ rr) & (PPV - 1)) << 4));
                     const float4 a1 = *reinterpret_cast<const float4*>(stage + rr * (BN * 4) + ((((2 * q8 + 1) ^ rr) & (PPV - 1)) << 4));
                     const int64_t ao = org + ((tile_d(rt) * H + tile_h(rt, rr)) * W + lane_w(rr)) * Cout + q8 * 8;
-                    const uint4 r4 = *reinterpret_cast<const uint4*>(residual + ao);
+                    const uint4 r4 = rq[j][kk];
                     // (the partial sum is rounded to bf16 before the residual is added - what the asynchronous form, EPI 3 of k_conv_fwd_ws,
                     // stages: every form of this launch gives the same bits, whichever one the grid size selects)
                     const unsigned p0 = pack2bf(a0.x, a0.y), p1 = pack2bf(a0.z, a0.w), p2 = pack2bf(a1.x, a1.y), p3 = pack2bf(a1.z, a1.w);
@@ -505,6 +515,32 @@ k_conv_fwd_mfma(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__
             constexpr int SWM = NT == 2 ? 7 : 3;         // piece swizzle: row v keeps piece q at slot q ^ sw(v)
             float4 bvn[NT][4];                           // bias of the next tile (lands while this one is packed)
             load_bias(has_next ? nxt.co0 : cur.co0, bvn);
+            // address in y (and in the mask) of the 16-byte piece this lane stores in iteration kk: wave-uniform 64-bit tile origin + 32-bit
+            // offset inside the tile's bounding box
+            auto out_off = [&](int kk) -> int64_t {
+                const int v = kk * VPI + lane / CPV, q = lane % CPV;
+                const int rt = 2 * wv + (v >> 5), rr = v & 31;
+                if constexpr (MODE == 1 && PL) {   // parity class (ph, pw) of the [D][2H][2W] output
+                    const int64_t org = ((((int64_t)cur.n * D + cur.d0) * 2 * H + 2 * cur.h0 + ((cur.par >> 1) & 1)) * 2 * W + 2 * cur.w0 + (cur.par & 1)) * Cout +
+                                        cur.co0;
+                    return org + ((tile_d(rt) * 2 * H + 2 * tile_h(rt, rr)) * 2 * W + 2 * lane_w(rr)) * Cout + q * 8;
+                } else if constexpr (MODE == 1) {   // parity class p of the [2D][2H][2W] output
+                    const int64_t org = ((((int64_t)cur.n * 2 * D + 2 * cur.d0 + (cur.par >> 2)) * 2 * H + 2 * cur.h0 + ((cur.par >> 1) & 1)) * 2 * W +
+                                         2 * cur.w0 + (cur.par & 1)) * Cout + cur.co0;
+                    return org + ((2 * tile_d(rt) * 2 * H + 2 * tile_h(rt, rr)) * 2 * W + 2 * lane_w(rr)) * Cout + q * 8;
+                } else {
+                    const int64_t org = ((((int64_t)cur.n * D + cur.d0) * H + cur.h0) * W + cur.w0) * Cout + cur.co0;
+                    return org + ((tile_d(rt) * H + tile_h(rt, rr)) * W + lane_w(rr)) * Cout + q * 8;
+                }
+            };
+            // the ReLU mask lines of this wave's stores are requested HERE, in front of the barrier and the packing of the tile (round 6: they
+            // were loaded inside the store loop, their latency exposed once per tile - the input-gradient launches of the 2-D path, which stay on
+            // this kernel, ran 25-35 % behind the forward launches of the same shape: profiles/r06_cfg3_per_layer.json)
+            uint4 mk4[CPV];
+            if (mask) {
+#pragma unroll
+                for (int kk = 0; kk < CPV; ++kk) mk4[kk] = *reinterpret_cast<const uint4*>(mask + out_off(kk));
+            }
             __builtin_amdgcn_s_barrier();
             PROF_T(te2);
             unsigned char* const stage = lds + hb * HALO_BYTES + wv * (64 * BN * 2);
@@ -550,30 +586,14 @@ k_conv_fwd_mfma(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__
                 const int v = kk * VPI + lane / CPV, q = lane % CPV;
                 const int vs = NT == 2 ? (v & 7) : ((v >> 2) & 3);
                 uint4 o4 = *reinterpret_cast<const uint4*>(stage + v * (BN * 2) + (((q ^ vs) & SWM) << 4));
-                const int rt = 2 * wv + (v >> 5), rr = v & 31;
-                // wave-uniform 64-bit tile origin + 32-bit offset inside the tile's bounding box
-                int64_t ao;
-                if constexpr (MODE == 1 && PL) {   // parity class (ph, pw) of the [D][2H][2W] output
-                    const int64_t org = ((((int64_t)cur.n * D + cur.d0) * 2 * H + 2 * cur.h0 + ((cur.par >> 1) & 1)) * 2 * W + 2 * cur.w0 + (cur.par & 1)) * Cout +
-                                        cur.co0;
-                    ao = org + ((tile_d(rt) * 2 * H + 2 * tile_h(rt, rr)) * 2 * W + 2 * lane_w(rr)) * Cout + q * 8;
-                } else if constexpr (MODE == 1) {   // parity class p of the [2D][2H][2W] output
-                    const int64_t org = ((((int64_t)cur.n * 2 * D + 2 * cur.d0 + (cur.par >> 2)) * 2 * H + 2 * cur.h0 + ((cur.par >> 1) & 1)) * 2 * W +
-                                         2 * cur.w0 + (cur.par & 1)) * Cout + cur.co0;
-                    ao = org + ((2 * tile_d(rt) * 2 * H + 2 * tile_h(rt, rr)) * 2 * W + 2 * lane_w(rr)) * Cout + q * 8;
-                } else {
-                    const int64_t org = ((((int64_t)cur.n * D + cur.d0) * H + cur.h0) * W + cur.w0) * Cout + cur.co0;
-                    ao = org + ((tile_d(rt) * H + tile_h(rt, rr)) * W + lane_w(rr)) * Cout + q * 8;
-                }
+                const int64_t ao = out_off(kk);
                 if (mask) {
-                    const uint4 m4 = *reinterpret_cast<const uint4*>(mask + ao);
-                    const unsigned mm[4] = {m4.x, m4.y, m4.z, m4.w};
+                    const unsigned mm[4] = {mk4[kk].x, mk4[kk].y, mk4[kk].z, mk4[kk].w};
                     unsigned* const oo = reinterpret_cast<unsigned*>(&o4);
+                    unsigned z2 = 0u, o2 = 0x00010001u;
+                    asm volatile("" : "+v"(z2), "+v"(o2));
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        if (!(__uint_as_float(mm[i] << 16) > 0.f)) oo[i] &= 0xffff0000u;
-                        if (!(__uint_as_float(mm[i] & 0xffff0000u) > 0.f)) oo[i] &= 0x0000ffffu;
-                    }
+                    for (int i = 0; i < 4; ++i) oo[i] &= pos_mask2(mm[i], z2, o2);        // three packed-integer instructions per dword (was eight: see k_conv_fwd_ws)
                 }
                 *reinterpret_cast<uint4*>(y + ao) = o4;
             }
