@@ -23,9 +23,9 @@ int conv3d_fwd_mfma_ex(int, const void*, int, int, int, const void*, int, const 
 int conv3d_upcat_wgrad_mfma_ex(const void*, int, const void*, int, const void*, float*, float*, float*, int, int, int, int, int, int, int, void*,
                                int64_t, hipStream_t);
 int conv3d_fwd_mfma_res_b27(const void*, int, const void*, const float*, const void*, void*, int, int, int, int, int, int, float, int, hipStream_t);
-int conv3d_fwd_tail_ok(int C0, int Cout, int N, int D, int H, int W, int dtype);
+int conv3d_fwd_tail_ok(int C0, int Cout, int N, int D, int H, int W, int dtype, int planar);
 int conv3d_fwd_mfma_tail(const void*, int, const void*, const float*, void*, void*, const float*, const float*, float*, int, int, int, int, int, int,
-                         float, int, hipStream_t);
+                         float, int, int, hipStream_t);
 
 int conv3d_fwd_ntail_ok(int C0, int C1, int Cout, int N, int D, int H, int W, int dtype);
 int conv3d_fwd_mfma_ntail(int, const void*, int, int, const void*, int, const void*, const float*, const void*, void*, int, int, int, int, int, int,
@@ -70,7 +70,7 @@ extern "C" int fmri_conv3d_fwd(const void* src0, int C0, int up0, const void* sr
 
 extern "C" int fmri_conv3d_fwd_tail_ok(int C0, int Cout, int N, int D, int H, int W, int dtype) {
     if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || C0 <= 0 || Cout <= 0) return 0;
-    return conv3d_fwd_tail_ok(C0, Cout, N, D, H, W, dtype);
+    return conv3d_fwd_tail_ok(C0, Cout, N, D, H, W, dtype, 0);
 }
 
 extern "C" int fmri_conv3d_fwd_tail(const void* src0, int C0, const void* w, const float* bias, void* y, void* y_pool, const float* w1,
@@ -81,7 +81,23 @@ extern "C" int fmri_conv3d_fwd_tail(const void* src0, int C0, const void* w, con
     if (dtype != FMRI_BF16 && dtype != FMRI_F32) return FMRI_E_DTYPE;
     if (!w || !y || (!y_pool && !logits)) return FMRI_E_SHAPE;
     if ((((uintptr_t)src0) | ((uintptr_t)w) | ((uintptr_t)y) | ((uintptr_t)y_pool) | ((uintptr_t)w1)) & 15) return FMRI_E_ALIGN;
-    return conv3d_fwd_mfma_tail(src0, C0, w, bias, y, y_pool, w1, b1, logits, N, D, H, W, Cout, act, alpha, dtype, as_stream(stream));
+    return conv3d_fwd_mfma_tail(src0, C0, w, bias, y, y_pool, w1, b1, logits, N, D, H, W, Cout, act, alpha, dtype, 0, as_stream(stream));
+}
+
+// the same for the 2-D models: D slices of H x W (planar launches), y_pool = MaxPooling2D(2) per slice
+extern "C" int fmri_conv3d_fwd_tail_planar_ok(int C0, int Cout, int N, int D, int H, int W, int dtype) {
+    if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || C0 <= 0 || Cout <= 0) return 0;
+    return conv3d_fwd_tail_ok(C0, Cout, N, D, H, W, dtype, 1);
+}
+extern "C" int fmri_conv3d_fwd_tail_planar(const void* src0, int C0, const void* w, const float* bias, void* y, void* y_pool, const float* w1,
+                                           const float* b1, float* logits, int N, int D, int H, int W, int Cout, int act, float alpha,
+                                           int dtype, fmri_stream_t stream) {
+    int rc = check_common(src0, C0, 0, 1, nullptr, 0, N, D, H, W, Cout);
+    if (rc) return rc;
+    if (dtype != FMRI_BF16) return FMRI_E_DTYPE;
+    if (!w || !y || (!y_pool && !logits)) return FMRI_E_SHAPE;
+    if ((((uintptr_t)src0) | ((uintptr_t)w) | ((uintptr_t)y) | ((uintptr_t)y_pool) | ((uintptr_t)w1)) & 15) return FMRI_E_ALIGN;
+    return conv3d_fwd_mfma_tail(src0, C0, w, bias, y, y_pool, w1, b1, logits, N, D, H, W, Cout, act, alpha, dtype, 1, as_stream(stream));
 }
 
 extern "C" int fmri_conv3d_dgrad(const void* dy, int Cout, const void* w_dgrad, const void* mask, void* dx, int N, int D, int H,

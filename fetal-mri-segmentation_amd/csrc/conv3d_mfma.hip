@@ -21,6 +21,11 @@ struct FwdItem {          // one (tile, Cout block, 32-channel chunk) unit of th
     int n, d0, h0, w0, co0, ch, par;
 };
 
+// a lane's value of `v` moved by a DPP control (quad_perm 0x00-0xFF, row_half_mirror 0x141, ...): one VALU instruction, no LDS
+template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+
 // Optional extra outputs of a plain (MODE 0, no residual) warp-specialised launch, produced from the tile while it sits in LDS as bf16
 // - i.e. from exactly the values that are stored to y - so that the HBM-bound consumers of y need no pass of their own:
 //   pool    [N][D/2][H/2][W/2][Cout]   2x2x2 max of y            (MaxPooling3D behind an encoder block, reference unet.py:51)
@@ -64,10 +69,14 @@ struct FwdTail {
 // CUBE: the workgroup tile is 8 x 8 x 8 instead of 4 x 8 x 16 voxels (halo 10^3 = 1000 rows): the shape of the deepest levels of
 // deep models (e.g. 8^3 at level 4 of a 128^3 Isensee net), whose W is not a multiple of 16.  A 32-voxel column tile is then 4 h-rows
 // of 8 voxels; everything else is the same machinery.
-template <int NT, bool PL, int MODE, bool RES, bool CUBE = false, bool FH = false>  // NT = 32-wide Cout tiles per workgroup (BN = 32*NT); PL = planar; FH: see k_conv_fwd_ws
+// TAIL (round 6; planar plain launches): the epilogue also writes the 2x2 max-pooled slices (tail.pool, [N][D][H/2][W/2][Cout]) and / or the
+// logits of a final 1x1 conv to one label (tail.logits; needs Cout == BN) from the staged tile - what EPI 0 / 2 of k_conv_fwd_ws do for the
+// 3-D launches (MaxPooling2D behind an encoder block and the final Conv2D of unet_model_2d: reference unet/unet.py:67,82).
+template <int NT, bool PL, int MODE, bool RES, bool CUBE = false, bool FH = false, bool TAIL = false>  // NT = 32-wide Cout tiles per workgroup (BN = 32*NT); PL = planar; FH: see k_conv_fwd_ws
 __global__ void __launch_bounds__(fw::NTHREADS)
 k_conv_fwd_mfma(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__ bias, const bf16_t* __restrict__ mask,
-                const bf16_t* residual, bf16_t* y, int N, int D, int H, int W, int Cout, int act, float alpha) {
+                const bf16_t* residual, bf16_t* y, int N, int D, int H, int W, int Cout, int act, float alpha, FwdTail tail) {
+    static_assert(!TAIL || (PL && MODE == 0 && !RES && !CUBE), "the tails of this kernel: planar plain launches");
     constexpr int NTHREADS = fw::NTHREADS;
     constexpr int TD = CUBE ? 8 : fw::TD, TH = CUBE ? 8 : fw::TH, TW = CUBE ? 8 : fw::TW;
     constexpr int HD = TD + 2, HH = TH + 2, HW = TW + 2, HVOX = HD * HH * HW;
@@ -249,6 +258,17 @@ k_conv_fwd_mfma(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__
         dma16_buf(dma_rsrc(sb), off, dst);
     };
 
+    // TAIL: this lane's 8 weights of the final 1x1 conv (the store loop gives a lane piece q = lane % (BN / 8) of a voxel in every iteration)
+    float4 w1a = make_float4(0.f, 0.f, 0.f, 0.f), w1b = w1a;
+    float b1v = 0.f;
+    if constexpr (TAIL) {
+        if (tail.logits) {
+            const int q = lane % (32 * NT / 8);
+            w1a = *reinterpret_cast<const float4*>(tail.w1 + q * 8);
+            w1b = *reinterpret_cast<const float4*>(tail.w1 + q * 8 + 4);
+            b1v = tail.b1[0];
+        }
+    }
     f32x16 acc[2][NT];
     // The accumulators of a tile START from its bias (MFMA D rows = output channel (reg&3) + 8*(reg>>2) + 4*hk), so the
     // epilogue has no bias add and needs no bias registers during the phase loop; the next tile's values are fetched inside the
@@ -596,6 +616,83 @@ k_conv_fwd_mfma(SrcB s, const bf16_t* __restrict__ wt, const float* __restrict__
                     for (int i = 0; i < 4; ++i) oo[i] &= pos_mask2(mm[i], z2, o2);        // three packed-integer instructions per dword (was eight: see k_conv_fwd_ws)
                 }
                 *reinterpret_cast<uint4*>(y + ao) = o4;
+                if constexpr (TAIL) {
+                    if (tail.logits) {
+                        // final 1x1 conv to one label: the CPV lanes of a voxel hold its BN (= Cout) channels, 8 each (the form of k_conv_fwd_ws)
+                        float part = __uint_as_float(o4.x << 16) * w1a.x;
+                        part = __builtin_fmaf(__uint_as_float(o4.x & 0xffff0000u), w1a.y, part);
+                        part = __builtin_fmaf(__uint_as_float(o4.y << 16), w1a.z, part);
+                        part = __builtin_fmaf(__uint_as_float(o4.y & 0xffff0000u), w1a.w, part);
+                        part = __builtin_fmaf(__uint_as_float(o4.z << 16), w1b.x, part);
+                        part = __builtin_fmaf(__uint_as_float(o4.z & 0xffff0000u), w1b.y, part);
+                        part = __builtin_fmaf(__uint_as_float(o4.w << 16), w1b.z, part);
+                        part = __builtin_fmaf(__uint_as_float(o4.w & 0xffff0000u), w1b.w, part);
+                        // sum over the voxel's CPV adjacent lanes with DPP moves (quad swaps, then the other quad of the half row) - the
+                        // same pairs in the same order as __shfl_xor 1, 2, 4, whose three dependent ds_bpermute round trips per store
+                        // iteration cost this launch 47 us on the MFMA waves (isolated, dec0b of configs[3]); measured after: see DESIGN 6.4
+                        part += dpp_mov<0xB1>(part);               // quad_perm [1, 0, 3, 2]
+                        part += dpp_mov<0x4E>(part);               // quad_perm [2, 3, 0, 1]
+                        if constexpr (CPV == 8) part += dpp_mov<0x141>(part);      // row_half_mirror: lane i <- lane 7 - i of its 8
+                        const int rt = 2 * wv + (v >> 5), rr = v & 31;
+                        if (q == 0)
+                            tail.logits[(((int64_t)cur.n * D + cur.d0 + tile_d(rt)) * H + cur.h0 + tile_h(rt, rr)) * W + cur.w0 + lane_w(rr)] = part + b1v;
+                    }
+                }
+            }
+            if constexpr (TAIL) {
+                if (tail.pool) {
+                    // 2x2 max pooling of the wave's own 64 staged voxels: a column tile is two h-rows x 16 w of one slice = 8 windows, so the wave
+                    // owns 16 pooled voxels x CPV 16-byte pieces.  After ReLU every value is >= +0 and the bf16 bit patterns order like
+                    // unsigned integers: four packed-integer maxima per source piece; any other activation goes through fp32.
+                    constexpr int NPP = (16 * CPV + 63) / 64;
+#pragma unroll
+                    for (int pi = 0; pi < NPP; ++pi) {
+                        const int idx = pi * 64 + lane;
+                        const bool live = idx < 16 * CPV;
+                        const int pv = (live ? idx : 0) / CPV, q = idx % CPV, j = pv >> 3, pw = pv & 7;
+                        uint4 src[4];
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            const int w_ = 2 * pw + (c & 1);
+                            const int v = j * 32 + ((c >> 1) ? 16 + ((w_ + (HW & 15)) & 15) : w_);       // inverse of lane_w: see the row rotation above
+                            const int vs = NT == 2 ? (v & 7) : ((v >> 2) & 3);
+                            src[c] = *reinterpret_cast<const uint4*>(stage + v * (BN * 2) + (((q ^ vs) & SWM) << 4));
+                        }
+                        uint4 o;
+                        if (act_s == 0.f) {
+                            unsigned* const oo = reinterpret_cast<unsigned*>(&o);
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                unsigned a = reinterpret_cast<const unsigned*>(&src[0])[i], b = reinterpret_cast<const unsigned*>(&src[1])[i];
+                                unsigned c2 = reinterpret_cast<const unsigned*>(&src[2])[i], d2 = reinterpret_cast<const unsigned*>(&src[3])[i];
+                                asm("v_pk_max_u16 %0, %0, %1" : "+v"(a) : "v"(b));
+                                asm("v_pk_max_u16 %0, %0, %1" : "+v"(c2) : "v"(d2));
+                                asm("v_pk_max_u16 %0, %0, %1" : "+v"(a) : "v"(c2));
+                                oo[i] = a;
+                            }
+                        } else {
+                            float mx[8];
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) {
+                                const unsigned pp[4] = {src[c].x, src[c].y, src[c].z, src[c].w};
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) {
+                                    const float lo = __uint_as_float(pp[i] << 16), hi = __uint_as_float(pp[i] & 0xffff0000u);
+                                    mx[2 * i] = c == 0 ? lo : vmax(mx[2 * i], lo);
+                                    mx[2 * i + 1] = c == 0 ? hi : vmax(mx[2 * i + 1], hi);
+                                }
+                            }
+                            o.x = (__float_as_uint(mx[0]) >> 16) | (__float_as_uint(mx[1]) & 0xffff0000u);
+                            o.y = (__float_as_uint(mx[2]) >> 16) | (__float_as_uint(mx[3]) & 0xffff0000u);
+                            o.z = (__float_as_uint(mx[4]) >> 16) | (__float_as_uint(mx[5]) & 0xffff0000u);
+                            o.w = (__float_as_uint(mx[6]) >> 16) | (__float_as_uint(mx[7]) & 0xffff0000u);
+                        }
+                        const int rt = 2 * wv + j;
+                        const int64_t po = ((((int64_t)cur.n * D + cur.d0 + tile_d(rt)) * (H >> 1) + (cur.h0 >> 1) + (rt & 3)) * (W >> 1) + (cur.w0 >> 1) + pw) * Cout +
+                                           cur.co0 + q * 8;
+                        if (live) *reinterpret_cast<uint4*>(tail.pool + po) = o;
+                    }
+                }
             }
             PROF_T(te1);
             PROF_ADD(4, te0, te1);
@@ -2134,10 +2231,10 @@ static int conv3d_fwd_mfma_launch(int mode, const void* src0, int C0, int up0, i
             FMRI_WS(NT_, PL_, MODE_, RES_, false, -1, (np < ncu ? np : ncu));                                             \
         else if (fh_any && (MODE_) == 0)                                                                                  \
             k_conv_fwd_mfma<NT_, PL_, MODE_, RES_, false, (MODE_) == 0><<<np < ncu ? np : ncu, fw::NTHREADS, 0, st>>>(    \
-                s, (const bf16_t*)w, bias, (const bf16_t*)mask, (const bf16_t*)residual, (bf16_t*)y, N, D, H, W, Cout, act, alpha); \
+                s, (const bf16_t*)w, bias, (const bf16_t*)mask, (const bf16_t*)residual, (bf16_t*)y, N, D, H, W, Cout, act, alpha, tail); \
         else                                                                                                              \
             k_conv_fwd_mfma<NT_, PL_, MODE_, RES_><<<np < ncu ? np : ncu, fw::NTHREADS, 0, st>>>(                         \
-                s, (const bf16_t*)w, bias, (const bf16_t*)mask, (const bf16_t*)residual, (bf16_t*)y, N, D, H, W, Cout, act, alpha); \
+                s, (const bf16_t*)w, bias, (const bf16_t*)mask, (const bf16_t*)residual, (bf16_t*)y, N, D, H, W, Cout, act, alpha, tail); \
     } while (0)
     const bool wide = fwd_wide(mode, planar, ntile, Cout);
     if (tail.nws) {
@@ -2154,16 +2251,29 @@ static int conv3d_fwd_mfma_launch(int mode, const void* src0, int C0, int up0, i
         FMRI_LAUNCH_CHECK();
         return FMRI_OK;
     }
+    if (planar && (tail.pool || tail.logits)) {
+        // 2-D slices: the pooled copy / the final conv's logits come out of the symmetric kernel's epilogue (TAIL instantiations)
+        if (cube || mode != 0 || residual || mask || C1 != 0 || up0 || (tail.logits && Cout != (wide ? 64 : 32))) return FMRI_E_SHAPE;
+        const int np = ntile * (Cout / (wide ? 64 : 32));
+#define FMRI_PT(NT_, FH_)                                                                                                  \
+    k_conv_fwd_mfma<NT_, true, 0, false, false, FH_, true><<<np < ncu ? np : ncu, fw::NTHREADS, 0, st>>>(                  \
+        s, (const bf16_t*)w, bias, nullptr, nullptr, (bf16_t*)y, N, D, H, W, Cout, act, alpha, tail)
+        if (wide) { if (fh_any) FMRI_PT(2, true); else FMRI_PT(2, false); }
+        else { if (fh_any) FMRI_PT(1, true); else FMRI_PT(1, false); }
+#undef FMRI_PT
+        FMRI_LAUNCH_CHECK();
+        return FMRI_OK;
+    }
     if (cube) {
         if (mode != 0 || residual || planar) return FMRI_E_SHAPE;
         const int nt = wide ? 2 : 1;
         const int np = ntile * (Cout / (32 * nt));
         if (wide)
             k_conv_fwd_mfma<2, false, 0, false, true><<<np < ncu ? np : ncu, fw::NTHREADS, 0, st>>>(
-                s, (const bf16_t*)w, bias, (const bf16_t*)mask, nullptr, (bf16_t*)y, N, D, H, W, Cout, act, alpha);
+                s, (const bf16_t*)w, bias, (const bf16_t*)mask, nullptr, (bf16_t*)y, N, D, H, W, Cout, act, alpha, tail);
         else
             k_conv_fwd_mfma<1, false, 0, false, true><<<np < ncu ? np : ncu, fw::NTHREADS, 0, st>>>(
-                s, (const bf16_t*)w, bias, (const bf16_t*)mask, nullptr, (bf16_t*)y, N, D, H, W, Cout, act, alpha);
+                s, (const bf16_t*)w, bias, (const bf16_t*)mask, nullptr, (bf16_t*)y, N, D, H, W, Cout, act, alpha, tail);
     } else if (mode == 1 && planar) {
         if (wide) FMRI_LAUNCH_FWD(2, true, 1, false); else FMRI_LAUNCH_FWD(1, true, 1, false);
     } else if (mode == 1) {
@@ -2206,18 +2316,24 @@ int conv3d_fwd_mfma_ex(int mode, const void* src0, int C0, int up0, int planar, 
 }
 // bit 0: the 2x2x2 max-pooled copy can be produced by the conv's epilogue, bit 1: the final 1x1x1 conv to one label can (plain 3-D
 // warp-specialised launch on the 4x8x16 tiling; the logits need the voxel's whole channel range in one workgroup: Cout == block width)
-int conv3d_fwd_tail_ok(int C0, int Cout, int N, int D, int H, int W, int dtype) {
-    if (!conv3d_fwd_mfma_ok(C0, 0, Cout, D, H, W, dtype) || conv3d_fwd_needs_cube(D, H, W) || fwd_use_ws() == 0) return 0;
-    if (dtype == FMRI_F32) return 1;                     // the pooled copy rides the fp32 drain; the logits need a 64-wide block
+// planar: D slices of H x W, the pooled copy is MaxPooling2D(2) per slice (the symmetric kernel's TAIL instantiations)
+int conv3d_fwd_tail_ok(int C0, int Cout, int N, int D, int H, int W, int dtype, int planar) {
+    if (!conv3d_fwd_mfma_ok(C0, 0, Cout, D, H, W, dtype) || conv3d_fwd_needs_cube(D, H, W)) return 0;
     const int ntile = N * (D / fw::TD) * (H / fw::TH) * (W / fw::TW);
+    if (planar) {
+        if (dtype != FMRI_BF16) return 0;
+        return 1 | (Cout == (fwd_wide(0, 1, ntile, Cout) ? 64 : 32) ? 2 : 0);
+    }
+    if (fwd_use_ws() == 0) return 0;
+    if (dtype == FMRI_F32) return 1;                     // the pooled copy rides the fp32 drain; the logits need a 64-wide block
     const int bn = fwd_wide(0, 0, ntile, Cout) ? 64 : 32;
     return 1 | (Cout == bn ? 2 : 0);
 }
 int conv3d_fwd_mfma_tail(const void* src0, int C0, const void* w, const float* bias, void* y, void* pool, const float* w1, const float* b1,
-                         float* logits, int N, int D, int H, int W, int Cout, int act, float alpha, int dtype, hipStream_t st) {
-    const int ok = conv3d_fwd_tail_ok(C0, Cout, N, D, H, W, dtype);
+                         float* logits, int N, int D, int H, int W, int Cout, int act, float alpha, int dtype, int planar, hipStream_t st) {
+    const int ok = conv3d_fwd_tail_ok(C0, Cout, N, D, H, W, dtype, planar);
     if ((pool && !(ok & 1)) || (logits && (!(ok & 2) || !w1 || !b1))) return FMRI_E_SHAPE;
-    return conv3d_fwd_mfma_launch(0, src0, C0, 0, 0, nullptr, 0, w, bias, nullptr, nullptr, y, N, D, H, W, Cout, act, alpha,
+    return conv3d_fwd_mfma_launch(0, src0, C0, 0, planar, nullptr, 0, w, bias, nullptr, nullptr, y, N, D, H, W, Cout, act, alpha,
                                   FwdTail{(bf16_t*)pool, w1, b1, logits, nullptr}, dtype, st);
 }
 // can this plain 3-D launch carry a normalisation tail (statistics of its output / the backward reductions in its asynchronous epilogue)?

@@ -510,17 +510,19 @@ __device__ __forceinline__ double wave_sum(double v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
     return v;
 }
-__global__ void k_sigmoid_dice_fwd(const float* __restrict__ logits, const uint8_t* __restrict__ y, const float* __restrict__ wgt,
+// VEC = 4: 16-byte loads of logits / weights / probabilities, 4-byte loads of the labels (the launcher checks alignment and n % 4); at most 512
+// workgroups, each ending in nine double atomics on one 128-byte line (4 x 64x128x128 logits, per launch: scalar loads + 1,024 workgroups
+// 27.6 us; this form with 128 / 256 / 512 / 1,024 workgroups 38.6 / 25.0 / 20.5 / 22.8 us - profiles/r06_dice_kernel_ab.log; the same sums).
+template <int VEC>
+__global__ void __launch_bounds__(256) k_sigmoid_dice_fwd(const float* __restrict__ logits, const uint8_t* __restrict__ y, const float* __restrict__ wgt,
                                    float* __restrict__ probs, double* __restrict__ sums, int64_t n) {
     double s[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        float z = logits[i];
+    auto one = [&](float z, float t, float w, float& p_out) {
         float p = 1.f / (1.f + __expf(-z));
-        if (probs) probs[i] = p;
-        float t = (float)y[i];
+        p_out = p;
         {   // binary cross-entropy with Keras' clipping, and the reference focal term (metrics.py:80-87: alpha .5, gamma 2)
             const float pc = fminf(fmaxf(p, 1e-7f), 1.f - 1e-7f);
-            s[7] += (double)((wgt ? wgt[i] : 1.f) * (t > 0.5f ? -__logf(pc) : -__logf(1.f - pc)));   // weight_mask * xent (metrics.py:72-76)
+            s[7] += (double)(w * (t > 0.5f ? -__logf(pc) : -__logf(1.f - pc)));   // weight_mask * xent (metrics.py:72-76)
             s[8] += (double)(t > 0.5f ? -0.5f * (1.f - p) * (1.f - p) * __logf(p) : -0.5f * p * p * __logf(1.f - p));
         }
         s[0] += (double)(t * p);
@@ -531,6 +533,24 @@ __global__ void k_sigmoid_dice_fwd(const float* __restrict__ logits, const uint8
         s[4] += tb;
         s[5] += pb;
         s[6] += (rintf(p) == t) ? 1.0 : 0.0;
+    };
+    const int64_t nv = n / VEC;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nv; i += (int64_t)gridDim.x * blockDim.x) {
+        if constexpr (VEC == 4) {
+            const float4 z = reinterpret_cast<const float4*>(logits)[i];
+            const uchar4 t = reinterpret_cast<const uchar4*>(y)[i];
+            float4 w = make_float4(1.f, 1.f, 1.f, 1.f), p;
+            if (wgt) w = reinterpret_cast<const float4*>(wgt)[i];
+            one(z.x, (float)t.x, w.x, p.x);
+            one(z.y, (float)t.y, w.y, p.y);
+            one(z.z, (float)t.z, w.z, p.z);
+            one(z.w, (float)t.w, w.w, p.w);
+            if (probs) reinterpret_cast<float4*>(probs)[i] = p;
+        } else {
+            float p;
+            one(logits[i], (float)y[i], wgt ? wgt[i] : 1.f, p);
+            if (probs) probs[i] = p;
+        }
     }
     __shared__ double red[9][4];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -693,7 +713,11 @@ extern "C" int fmri_weighted_dice_bwd(const float* probs, const uint8_t* y_true,
 extern "C" int fmri_sigmoid_dice_fwd_weighted(const float* logits, const uint8_t* y_true, const float* weight, float* probs, double* sums,
                                               int64_t n, fmri_stream_t stream) {
     if (n <= 0 || !weight) return FMRI_E_SHAPE;
-    k_sigmoid_dice_fwd<<<grid_for(n, 256, 1024), 256, 0, as_stream(stream)>>>(logits, y_true, weight, probs, sums, n);
+    {
+        const bool v4 = n % 4 == 0 && !((((uintptr_t)logits) | ((uintptr_t)probs) | ((uintptr_t)weight)) & 15) && !(((uintptr_t)y_true) & 3);
+        if (v4) k_sigmoid_dice_fwd<4><<<grid_for(n / 4, 256, 512), 256, 0, as_stream(stream)>>>(logits, y_true, weight, probs, sums, n);
+        else k_sigmoid_dice_fwd<1><<<grid_for(n, 256, 512), 256, 0, as_stream(stream)>>>(logits, y_true, weight, probs, sums, n);
+    }
     if (h_det_on) k_isums_finish<<<1, 64, 0, as_stream(stream)>>>(sums);
     FMRI_LAUNCH_CHECK();
     return FMRI_OK;
@@ -710,7 +734,11 @@ extern "C" int fmri_sigmoid_loss_bwd_weighted(const float* probs, const uint8_t*
 extern "C" int fmri_sigmoid_dice_fwd(const float* logits, const uint8_t* y_true, float* probs, double* sums, int64_t n,
                                      fmri_stream_t stream) {
     if (n <= 0) return FMRI_E_SHAPE;
-    k_sigmoid_dice_fwd<<<grid_for(n, 256, 1024), 256, 0, as_stream(stream)>>>(logits, y_true, nullptr, probs, sums, n);
+    {
+        const bool v4 = n % 4 == 0 && !((((uintptr_t)logits) | ((uintptr_t)probs) | ((uintptr_t)logits)) & 15) && !(((uintptr_t)y_true) & 3);
+        if (v4) k_sigmoid_dice_fwd<4><<<grid_for(n / 4, 256, 512), 256, 0, as_stream(stream)>>>(logits, y_true, nullptr, probs, sums, n);
+        else k_sigmoid_dice_fwd<1><<<grid_for(n, 256, 512), 256, 0, as_stream(stream)>>>(logits, y_true, nullptr, probs, sums, n);
+    }
     if (h_det_on) k_isums_finish<<<1, 64, 0, as_stream(stream)>>>(sums);
     FMRI_LAUNCH_CHECK();
     return FMRI_OK;

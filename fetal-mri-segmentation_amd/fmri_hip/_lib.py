@@ -30,6 +30,8 @@ SIGNATURES = {
     "fmri_conv3d_fwd": [p, i32, i32, p, i32, p, p, p, p, i32, i32, i32, i32, i32, i32, f32, i32, i32, i32, p],
     "fmri_conv3d_fwd_tail_ok": [i32] * 7,
     "fmri_conv3d_fwd_tail": [p, i32, p, p, p, p, p, p, p, i32, i32, i32, i32, i32, i32, f32, i32, p],
+    "fmri_conv3d_fwd_tail_planar_ok": [i32] * 7,
+    "fmri_conv3d_fwd_tail_planar": [p, i32, p, p, p, p, p, p, p, i32, i32, i32, i32, i32, i32, f32, i32, p],
     "fmri_conv3d_dgrad": [p, i32, p, p, p, i32, i32, i32, i32, i32, i32, i32, i32, p],
     "fmri_conv3d_wgrad": [p, i32, i32, p, i32, p, p, p, i32, i32, i32, i32, i32, i32, i32, i32, p, i64, p],
     "fmri_conv3d_wgrad_workspace_bytes": [i32] * 9,

@@ -561,14 +561,17 @@ class UNetEngine:
 
     def _tail_ok(self, c):
         """what the epilogue of conv block `c` can produce besides its output (ops.conv3d_fwd_tail_ok bits): only plain single-source
-        3-D blocks without a normalisation layer (the consumer then reads the block's OUTPUT); FMRI_TAIL_FUSE=0 switches it off (A/B)"""
-        if c.get("norm") or self.planar or self.dtype != torch.bfloat16 or os.environ.get("FMRI_TAIL_FUSE", "1") == "0":
+        blocks without a normalisation layer (the consumer then reads the block's OUTPUT); FMRI_TAIL_FUSE=0 switches it off (A/B).  2-D
+        (round 6): MaxPooling2D / the final Conv2D out of the planar kernel's epilogue, FMRI_TAIL_FUSE_2D=0 switches that off."""
+        if c.get("norm") or self.dtype != torch.bfloat16 or os.environ.get("FMRI_TAIL_FUSE", "1") == "0":
+            return 0
+        if self.planar and os.environ.get("FMRI_TAIL_FUSE_2D", "1") == "0":
             return 0
         key = (c["name"], self.N)
         cache = self.__dict__.setdefault("_tail_cache", {})
         if key not in cache:                                   # a host-side query per (layer, batch size), not per step
             d = self._dims(c["level"])
-            cache[key] = ops.conv3d_fwd_tail_ok(c["cin"], c["cout"], d[0], d[1], d[2], d[3], self.dtype)
+            cache[key] = ops.conv3d_fwd_tail_ok(c["cin"], c["cout"], d[0], d[1], d[2], d[3], self.dtype, planar=self.planar)
         return cache[key]
 
     def _ntail_ok(self, c0, c1, cout, level, kind=1):
@@ -601,7 +604,7 @@ class UNetEngine:
             w1 = self.w_view(final["name"]).reshape(-1) if final is not None else None
             ops.conv3d_fwd_tail(src0, self.Wf[name], self.b_view(name), out, pool=pool, w1=w1,
                                 b1=self.b_view(final["name"]) if final is not None else None,
-                                logits=self.logits.reshape(-1) if final is not None else None, act=act)
+                                logits=self.logits.reshape(-1) if final is not None else None, act=act, planar=self.planar)
             return self.act[name]
         # normalised block with training statistics: the conv sums its own output in its epilogue where the launch allows it
         per, eos = self._norm_mode()

@@ -51,23 +51,27 @@ def conv3d_fwd(src0, src1, w, bias, y, up0=False, act=ACT_RELU, alpha=0.0, mask=
     return y
 
 
-def conv3d_fwd_tail_ok(C0, Cout, N, D, H, W, dtype):
-    """bit 0: the conv epilogue can also write the 2x2x2 max-pooled tensor, bit 1: ... the logits of a final 1x1x1 conv to one label"""
-    return int(lib().fmri_conv3d_fwd_tail_ok(C0, Cout, N, D, H, W, BF16 if dtype == torch.bfloat16 else F32))
+def conv3d_fwd_tail_ok(C0, Cout, N, D, H, W, dtype, planar=False):
+    """bit 0: the conv epilogue can also write the 2x2x2 (planar: 2x2 per slice) max-pooled tensor, bit 1: ... the logits of a final
+    1x1x1 conv to one label"""
+    f = lib().fmri_conv3d_fwd_tail_planar_ok if planar else lib().fmri_conv3d_fwd_tail_ok
+    return int(f(C0, Cout, N, D, H, W, BF16 if dtype == torch.bfloat16 else F32))
 
 
-def conv3d_fwd_tail(src0, w, bias, y, pool=None, w1=None, b1=None, logits=None, act=ACT_RELU, alpha=0.0):
-    """conv block whose epilogue also produces MaxPooling3D(2)(y) and / or the final 1x1x1 conv's logits (fmri_conv3d_fwd_tail)"""
+def conv3d_fwd_tail(src0, w, bias, y, pool=None, w1=None, b1=None, logits=None, act=ACT_RELU, alpha=0.0, planar=False):
+    """conv block whose epilogue also produces MaxPooling3D(2)(y) (planar: MaxPooling2D(2) of every slice) and / or the final 1x1x1 conv's
+    logits (fmri_conv3d_fwd_tail / fmri_conv3d_fwd_tail_planar)"""
     _need_cuda(src0, w, bias, y, pool, w1, b1, logits)
     N, D, H, W, Cout = y.shape
     C0 = src0.shape[-1]
     assert w.shape == (27, Cout, C0)
     if pool is not None:
-        assert tuple(pool.shape) == (N, D // 2, H // 2, W // 2, Cout) and pool.dtype == y.dtype
+        assert tuple(pool.shape) == (N, D if planar else D // 2, H // 2, W // 2, Cout) and pool.dtype == y.dtype
     if logits is not None:
         assert logits.dtype == torch.float32 and logits.numel() == N * D * H * W and w1.dtype == torch.float32 and w1.numel() == Cout
-    check(lib().fmri_conv3d_fwd_tail(_p(src0), C0, _p(w), _p(bias), _p(y), _p(pool), _p(w1), _p(b1), _p(logits), N, D, H, W, Cout, act,
-                                     float(alpha), dt(y), _s()), "fmri_conv3d_fwd_tail")
+    f = lib().fmri_conv3d_fwd_tail_planar if planar else lib().fmri_conv3d_fwd_tail
+    check(f(_p(src0), C0, _p(w), _p(bias), _p(y), _p(pool), _p(w1), _p(b1), _p(logits), N, D, H, W, Cout, act, float(alpha), dt(y), _s()),
+          "fmri_conv3d_fwd_tail_planar" if planar else "fmri_conv3d_fwd_tail")
     return y
 
 

@@ -74,6 +74,12 @@ int fmri_conv3d_fwd_tail_ok(int C0, int Cout, int N, int D, int H, int W, int dt
 int fmri_conv3d_fwd_tail(const void* src0, int C0, const void* w, const float* bias, void* y, void* y_pool, const float* w1,
                          const float* b1, float* logits, int N, int D, int H, int W, int Cout, int act, float alpha, int dtype,
                          fmri_stream_t stream);
+/* The same for the 2-D models (planar launches: D slices of H x W, bf16): y_pool [N][D][H/2][W/2][Cout] = MaxPooling2D(2) of every slice
+ * (reference unet/unet.py:67 behind the encoder block :57-63), logits = the final Conv2D(n_labels = 1, (1, 1)) (unet/unet.py:82). */
+int fmri_conv3d_fwd_tail_planar_ok(int C0, int Cout, int N, int D, int H, int W, int dtype);
+int fmri_conv3d_fwd_tail_planar(const void* src0, int C0, const void* w, const float* bias, void* y, void* y_pool, const float* w1,
+                                const float* b1, float* logits, int N, int D, int H, int W, int Cout, int act, float alpha, int dtype,
+                                fmri_stream_t stream);
 
 /* ---- Conv3DBackpropInputV2 (autodiff of unet.py:102): dx = conv(dy, w_dgrad) * (mask > 0).
  * w_dgrad [27][Cin][Cout] is the tap-flipped, transposed copy made by fmri_conv3d_pack_weights. */

@@ -931,6 +931,64 @@ def test_conv3d_fwd_tail(ops, case):
             ops.conv3d_fwd_tail(x, w, bias, y, w1=w1, b1=b1, logits=torch.empty(N * D * H * W, dtype=torch.float32, device="cuda"))
 
 
+PLANAR_TAIL_CASES = [
+    # name, slices, H, W, C0, Cout, act, expected ok bits (on a 256-CU device)
+    ("narrow_32", 8, 16, 32, 32, 32, 1, 3),             # 32-wide Cout block == Cout: pool + logits
+    ("few_tiles_64", 8, 32, 32, 32, 64, 1, 1),          # fewer (tile, 64-block) pairs than CUs -> 32-wide blocks: pool only
+    ("wide_64", 16, 64, 128, 32, 64, 1, 3),             # the shape class of the 2-D network's last block
+    ("wide_64_two_chunks", 16, 64, 128, 64, 64, 1, 3),
+    ("wide_128_pool", 8, 64, 128, 64, 128, 1, 1),       # two 64-blocks per voxel: pool only
+    ("wide_64_leaky", 16, 64, 128, 32, 64, 2, 3),       # not ReLU: the pooled maximum goes through fp32 (negative values)
+    ("wide_64_linear", 16, 64, 128, 32, 64, 0, 3),
+]
+
+
+@pytest.mark.parametrize("case", PLANAR_TAIL_CASES, ids=[c[0] for c in PLANAR_TAIL_CASES])
+def test_conv3d_fwd_tail_planar(ops, case):
+    """fmri_conv3d_fwd_tail_planar (2-D models): the planar conv block's epilogue also writes MaxPooling2D(2) of every slice and the final
+    1x1 conv's logits from the staged tile.  y BIT-identical to fmri_conv3d_fwd(planar), the pooled slices to fmri_maxpool3d_2x_fwd(planar),
+    the logits equal to fmri_conv1x1_fwd up to fp32 summation order; y and logits against fp64 as well (reference unet/unet.py:57-67, :82)."""
+    name, S, H, W, C0, Cout, act, bits = case
+    bf = torch.bfloat16
+    ok = ops.conv3d_fwd_tail_ok(C0, Cout, 1, S, H, W, bf, planar=True)
+    if torch.cuda.get_device_properties(0).multi_processor_count == 256:
+        assert ok == bits, (name, ok)
+    x = rnd((1, S, H, W, C0), 31, bf)
+    w = rnd((27, Cout, C0), 32, bf, scale=0.1)
+    bias = rnd((Cout,), 33, torch.float32, scale=0.3)
+    w1 = rnd((Cout,), 34, torch.float32, scale=0.2)
+    b1 = rnd((1,), 35, torch.float32)
+    y0 = torch.empty((1, S, H, W, Cout), dtype=bf, device="cuda")
+    ops.conv3d_fwd(x, None, w, bias, y0, act=act, alpha=0.1, planar=True)
+    p0 = torch.empty((1, S, H // 2, W // 2, Cout), dtype=bf, device="cuda")
+    ops.maxpool_fwd(y0, p0, planar=True)
+    l0 = torch.empty((S * H * W, 1), dtype=torch.float32, device="cuda")
+    ops.conv1x1_fwd(y0, w1.reshape(1, Cout), b1, l0)
+    y = torch.full_like(y0, float("nan"))
+    pool = torch.full_like(p0, float("nan"))
+    logits = torch.full((S * H * W,), float("nan"), dtype=torch.float32, device="cuda") if ok & 2 else None
+    assert ok & 1
+    ops.conv3d_fwd_tail(x, w, bias, y, pool=pool, w1=w1 if ok & 2 else None, b1=b1 if ok & 2 else None, logits=logits, act=act, alpha=0.1,
+                        planar=True)
+    torch.cuda.synchronize()
+    assert torch.equal(y.view(torch.int16), y0.view(torch.int16))
+    assert torch.equal(pool.view(torch.int16), p0.view(torch.int16))
+    ref = ref_conv_fwd(f64(x), None, False, f64(w), f64(bias), 1 if act == 1 else 0, planar=True)
+    if act == 2:
+        ref = torch.where(ref > 0, ref, 0.1 * ref)
+    assert_close(y, ref, *TOL[bf], what=name + " planar tail y")
+    if ok & 2:
+        assert_close(logits.reshape(-1, 1), l0, 2e-6, 2e-6, what=name + " planar tail logits vs conv1x1 kernel")
+        assert_close(logits, ((f64(y) @ f64(w1)) + f64(b1)).reshape(-1), 2e-6, 2e-6, what=name + " planar tail logits vs fp64")
+        # the logits alone (no pooled copy)
+        lg = torch.full_like(logits, float("nan"))
+        ops.conv3d_fwd_tail(x, w, bias, y, w1=w1, b1=b1, logits=lg, act=act, alpha=0.1, planar=True)
+        assert torch.equal(lg, logits)
+    else:
+        with pytest.raises(RuntimeError):
+            ops.conv3d_fwd_tail(x, w, bias, y, w1=w1, b1=b1, logits=torch.empty(S * H * W, dtype=torch.float32, device="cuda"), planar=True)
+
+
 def test_engine_tail_fusion_equals_separate_kernels(monkeypatch):
     """the engine with the pooling / final-conv tails fused into the conv epilogues (default) against FMRI_TAIL_FUSE=0: identical
     activations and pooled tensors, logits equal to fp32 summation order, same Dice, gradients equal to atomics order"""
@@ -955,6 +1013,38 @@ def test_engine_tail_fusion_equals_separate_kernels(monkeypatch):
     for k in aa:
         assert torch.equal(aa[k].view(torch.int16), ab[k].view(torch.int16)), k
     assert_close(la, lb, 2e-6, 2e-6, what="fused logits")
+    assert abs(sa[0] - sb[0]) <= 1e-6 * abs(sb[0]) and sa[7] == sb[7]
+    assert float((ga - gb).abs().max()) <= 1e-4 * float(gb.abs().max())
+
+
+@pytest.mark.parametrize("slices", [16, 6])
+def test_engine_2d_tail_fusion_equals_separate_kernels(monkeypatch, slices):
+    """the 2-D engine with MaxPooling2D / the final Conv2D in the planar conv epilogues (default) against FMRI_TAIL_FUSE_2D=0: identical
+    activations and pooled tensors, logits equal to fp32 summation order, same Dice, gradients equal to atomics order.  6 slices: not a
+    multiple of the 4-slice tile - nothing is fused there and the engine must still agree with itself."""
+    from fmri_hip.engine import UNetEngine, UNetPlan
+    X, Y, C = 64, 128, 5
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn((1, slices, X, Y, C), generator=g).cuda().to(torch.bfloat16)
+    yv = (torch.rand((slices * X * Y,), generator=g) > 0.7).to(torch.uint8).cuda()
+    out = {}
+    for fuse in ("1", "0"):
+        monkeypatch.setenv("FMRI_TAIL_FUSE_2D", fuse)
+        eng = UNetEngine(UNetPlan(C, (X, Y), depth=3, n_base_filters=32, ndim=2), slices, dtype=torch.bfloat16, seed=11)
+        if fuse == "1" and slices % 4 == 0:
+            assert eng._tail_ok(eng.plan.enc[0][1]) & 1 and eng._tail_ok(eng.plan.dec[-1][1]) & 2
+        if fuse == "0":
+            assert eng._tail_ok(eng.plan.enc[0][1]) == 0
+        eng.forward(x)
+        s = eng.loss_forward(yv).cpu().numpy().copy()
+        eng.backward(yv)
+        torch.cuda.synchronize()
+        out[fuse] = (eng.logits.clone(), {k: v.clone() for k, v in eng.act.items()}, s, eng.G.clone())
+    la, aa, sa, ga = out["1"]
+    lb, ab, sb, gb = out["0"]
+    for k in aa:
+        assert torch.equal(aa[k].view(torch.int16), ab[k].view(torch.int16)), k
+    assert_close(la, lb, 2e-6, 2e-6, what="fused 2-D logits")
     assert abs(sa[0] - sb[0]) <= 1e-6 * abs(sb[0]) and sa[7] == sb[7]
     assert float((ga - gb).abs().max()) <= 1e-4 * float(gb.abs().max())
 
