@@ -102,7 +102,10 @@ def conv_bytes(name, s):
 PEAK_HBM = 8000.0      # GB/s (MI355X guide)
 rows = []
 for (name, shp), ev in rec.items():
-    ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
+    # median over the K steps: a pair of events also spans whatever the HOST does between a launch's kernels - one stalled step put 7.9 ms
+    # on a 0.7 ms launch in the mean of the first r06 collection
+    ts = sorted(a.elapsed_time(b) for a, b in ev)
+    ms = ts[len(ts) // 2]
     n = len(ev) // K
     fl = conv_flops(name, shp)
     by = conv_bytes(name, shp) if fl else None
@@ -125,7 +128,7 @@ for r in rows:
                                             "" if r["mfma_frac"] is None else "%.2f mfma %.2f %s" % (r["mfma_frac"], r["roofline_frac"], r["bound"]), r["shapes"]))
 print("total %.3f ms per step (exclusive); 3x3 convs %.3f ms, %.0f GFLOP algorithmic = %.3f of the MFMA peak; sum of the launches' own rooflines "
       "(max of MFMA- and HBM-bound time) %.3f ms = %.3f of the measured" % (tot, cms, cfl, cfl / cms / PEAK if cms else 0, croof, croof / cms if cms else 0))
-out = {"workload": "configs[3]: 2-D U-Net depth 4 / 32 filters, batch %d x %dx%dx%d, bf16, one stream (exclusive HIP-event times, mean over %d steps)" % (B, X, Y, C, K),
+out = {"workload": "configs[3]: 2-D U-Net depth 4 / 32 filters, batch %d x %dx%dx%d, bf16, one stream (exclusive HIP-event times, median over %d steps)" % (B, X, Y, C, K),
        "rows": rows, "total_ms_per_step": round(tot, 3), "conv_ms_per_step": round(cms, 3), "conv_gflop_per_step": round(cfl, 1),
        "conv_mfma_frac": round(cfl / cms / PEAK, 4) if cms else None, "conv_roofline_ms_per_step": round(croof, 3),
        "conv_roofline_frac": round(croof / cms, 4) if cms else None,
