@@ -823,14 +823,15 @@ def main():
         timer.wrap(ops, "conv3d_wgrad", lab_wgrad)
         timer.wrap(ops, "conv3d_upcat_fwd", lab_up_fwd, launches=2)
         timer.wrap(ops, "conv3d_upcat_dgrad", lab_up_dgrad, launches=2)
-        # the optimizer step repacks the deep layers' weight images on a side stream, under the next step's first convolutions: their event
-        # brackets measure a concurrent span, not a cost on the step's critical path
+        # (FMRI_PACK_BATCHED=0 only:) the optimizer step repacks the deep layers' weight images on a side stream, under the next step's first
+        # convolutions: their event brackets measure a concurrent span, not a cost on the step's critical path
         def lab_pack(*aa, **kk):
             return "pack_weights" if torch.cuda.current_stream() == torch.cuda.default_stream() else "pack_weights_side_stream_overlapped"
 
         timer.wrap(ops, "conv3d_pack_up_weights", lab_pack)
         timer.wrap(ops, "conv3d_upcat_wgrad", lab_up_wgrad, launches=2)
         timer.wrap(ops, "pack_weights", lab_pack)
+        timer.wrap(ops, "pack_weights_batched", lambda *aa, **kk: "pack_weights_batched")       # round 6: one launch for all images, main stream
         for nm in ("maxpool_fwd", "maxpool_bwd", "upsample_bwd", "conv1x1_fwd", "conv1x1_bwd", "sigmoid_dice_fwd",
                    "sigmoid_dice_bwd", "adam_step"):
             timer.wrap(ops, nm, (lambda n_: (lambda *aa, **kk: n_))(nm))

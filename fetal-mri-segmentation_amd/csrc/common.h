@@ -135,3 +135,17 @@ __device__ __forceinline__ void pack_tile(F src, T* __restrict__ f_dst, int64_t 
     __syncthreads();
 }
 
+// one workgroup of fmri_conv3d_pack_weights: block b = (tap, Cout tile, Cin tile) of the fp32 master [27][Cout][Cin] -> the forward image
+// (same layout) and the tap-flipped transposed input-gradient image [26 - tap][Cin][Cout]
+template <typename T>
+__device__ __forceinline__ void pack_plain_block(int b, const float* __restrict__ w, T* __restrict__ wf, T* __restrict__ wd, int Cout, int Cin,
+                                                 T (*tile)[PACK_PITCH(T)]) {
+    const int tci = (Cin + 63) >> 6, tco = (Cout + 63) >> 6;
+    const int ci0 = (b % tci) << 6; b /= tci;
+    const int co0 = (b % tco) << 6;
+    const int tap = b / tco;
+    const float* const wt = w + (int64_t)tap * Cout * Cin;
+    pack_tile<T>([&](int co, int ci) { return wt[(int64_t)co * Cin + ci]; }, wf ? wf + (int64_t)tap * Cout * Cin : nullptr, Cin,
+                 wd ? wd + (int64_t)(26 - tap) * Cin * Cout : nullptr, Cout, co0, ci0, Cout, Cin, tile);
+}
+

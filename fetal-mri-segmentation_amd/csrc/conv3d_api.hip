@@ -155,14 +155,12 @@ __device__ __forceinline__ int tap_class(int p, int k) { return p == 0 ? (k >= 1
 // (tap, Cout tile, C1 tile) of the skip filters; both images of a tile (row-major forward, transposed input-gradient) are written coalesced
 // (pack_tile, common.h).  The pre-sums run over (kd, kh, kw) in ascending order in fp32, then one rounding.
 template <typename T>
-__global__ void __launch_bounds__(256) k_pack_up_weights(const float* __restrict__ w, int C0, int C1, int Cout, int planar, T* __restrict__ up_f,
-                                                         T* __restrict__ up_d, T* __restrict__ sk_f, T* __restrict__ sk_d) {
-    __shared__ T tile[64][PACK_PITCH(T)];
+__device__ __forceinline__ void pack_up_block(int b, const float* __restrict__ w, int C0, int C1, int Cout, int planar, T* __restrict__ up_f,
+                                              T* __restrict__ up_d, T* __restrict__ sk_f, T* __restrict__ sk_d, T (*tile)[PACK_PITCH(T)]) {
     const int Cin = C0 + C1;
     const int tco = (Cout + 63) >> 6, tc0 = (C0 + 63) >> 6, tc1 = (C1 + 63) >> 6;
     const int ncls = planar ? 16 : 64;
     const int n_up = ncls * tco * tc0;
-    int b = blockIdx.x;
     if (b < n_up) {
         const int ci0 = (b % tc0) << 6; b /= tc0;
         const int co0 = (b % tco) << 6;
@@ -202,6 +200,34 @@ __global__ void __launch_bounds__(256) k_pack_up_weights(const float* __restrict
     pack_tile<T>([&](int co, int c1) { return wt[(int64_t)co * Cin + c1]; }, sk_f ? sk_f + (int64_t)t * Cout * C1 : nullptr, C1,
                  sk_d ? sk_d + (int64_t)(26 - t) * C1 * Cout : nullptr, Cout, co0, ci0, Cout, C1, tile);
 }
+template <typename T>
+__global__ void __launch_bounds__(256) k_pack_up_weights(const float* __restrict__ w, int C0, int C1, int Cout, int planar, T* __restrict__ up_f,
+                                                         T* __restrict__ up_d, T* __restrict__ sk_f, T* __restrict__ sk_d) {
+    __shared__ T tile[64][PACK_PITCH(T)];
+    pack_up_block<T>(blockIdx.x, w, C0, C1, Cout, planar, up_f, up_d, sk_f, sk_d, tile);
+}
+
+// Every weight image of a model in ONE launch (round 6; fmri_pack_weights_batched).  table[layer][10] int64:
+//   [0] kind (0: fmri_conv3d_pack_weights, 1: fmri_conv3d / conv2d_pack_up_weights)   [1] first workgroup of the layer
+//   [2] w (fp32 master)   [3..6] destinations: kind 0 {w_fwd, w_dgrad, -, -}, kind 1 {w_up_fwd, w_up_dgrad, w_skip_fwd, w_skip_dgrad}
+//   [7] Cout   [8] Cin (kind 0) / C0 (kind 1)   [9] C1 | planar << 32 (kind 1)
+// A workgroup finds its layer (the table is small and wave-uniform) and runs the layer's own per-launch code on its local block number:
+// the images are the bits the per-layer launches write.
+template <typename T>
+__global__ void __launch_bounds__(256) k_pack_batched(const long long* __restrict__ table, int n_layers) {
+    __shared__ T tile[64][PACK_PITCH(T)];
+    int L = 0;
+    for (int i = 1; i < n_layers; ++i)
+        if ((long long)blockIdx.x >= table[i * 10 + 1]) L = i;
+    const long long* const r = table + L * 10;
+    const int b = (int)(blockIdx.x - r[1]);
+    const float* const w = reinterpret_cast<const float*>(r[2]);
+    if (r[0] == 0)
+        pack_plain_block<T>(b, w, reinterpret_cast<T*>(r[3]), reinterpret_cast<T*>(r[4]), (int)r[7], (int)r[8], tile);
+    else
+        pack_up_block<T>(b, w, (int)r[8], (int)(r[9] & 0xffffffffll), (int)r[7], (int)(r[9] >> 32), reinterpret_cast<T*>(r[3]), reinterpret_cast<T*>(r[4]),
+                         reinterpret_cast<T*>(r[5]), reinterpret_cast<T*>(r[6]), tile);
+}
 
 // D,H,W = output (full-resolution) dims; planar: D = number of slices (not up-sampled).  bit 0: forward + input gradients, bit 1: weight gradient
 int upcat_ok(int C0, int C1, int Cout, int D, int H, int W, int dtype, int planar) {
@@ -218,6 +244,16 @@ int upcat_ok(int C0, int C1, int Cout, int D, int H, int W, int dtype, int plana
     return (fb ? 1 : 0) | (fb && wg_ ? 2 : 0);
 }
 
+}  // namespace
+extern "C" int fmri_pack_weights_batched(const int64_t* table, int n_layers, int n_blocks, int dtype, fmri_stream_t stream) {
+    if (!table || n_layers <= 0 || n_blocks <= 0) return FMRI_E_SHAPE;
+    if (dtype == FMRI_BF16) k_pack_batched<bf16_t><<<n_blocks, 256, 0, as_stream(stream)>>>(reinterpret_cast<const long long*>(table), n_layers);
+    else if (dtype == FMRI_F32) k_pack_batched<float><<<n_blocks, 256, 0, as_stream(stream)>>>(reinterpret_cast<const long long*>(table), n_layers);
+    else return FMRI_E_DTYPE;
+    FMRI_LAUNCH_CHECK();
+    return FMRI_OK;
+}
+namespace {
 int upcat_pack(const float* w, int C0, int C1, int Cout, void* w_up_fwd, void* w_up_dgrad, void* w_skip_fwd, void* w_skip_dgrad, int dtype,
                int planar, fmri_stream_t stream) {
     if (!w || C0 <= 0 || C1 < 0 || Cout <= 0) return FMRI_E_SHAPE;

@@ -789,14 +789,7 @@ extern "C" int fmri_adam_step(float* p, const float* g, float* m, float* v, int6
 template <typename T>
 __global__ void __launch_bounds__(256) k_pack_weights(const float* __restrict__ w, T* __restrict__ wf, T* __restrict__ wd, int Cout, int Cin) {
     __shared__ T tile[64][PACK_PITCH(T)];
-    const int tci = (Cin + 63) >> 6, tco = (Cout + 63) >> 6;
-    int b = blockIdx.x;
-    const int ci0 = (b % tci) << 6; b /= tci;
-    const int co0 = (b % tco) << 6;
-    const int tap = b / tco;
-    const float* const wt = w + (int64_t)tap * Cout * Cin;
-    pack_tile<T>([&](int co, int ci) { return wt[(int64_t)co * Cin + ci]; }, wf ? wf + (int64_t)tap * Cout * Cin : nullptr, Cin,
-                 wd ? wd + (int64_t)(26 - tap) * Cin * Cout : nullptr, Cout, co0, ci0, Cout, Cin, tile);
+    pack_plain_block<T>(blockIdx.x, w, wf, wd, Cout, Cin, tile);
 }
 extern "C" int fmri_conv3d_pack_weights(const float* w, void* w_fwd, void* w_dgrad, int Cout, int Cin, int dtype,
                                         fmri_stream_t stream) {

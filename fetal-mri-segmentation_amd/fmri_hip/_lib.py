@@ -37,6 +37,7 @@ SIGNATURES = {
     "fmri_conv3d_wgrad_workspace_bytes": [i32] * 9,
     "fmri_conv3d_wgrad_cout32_ok": [i32] * 10,
     "fmri_conv3d_pack_weights": [p, p, p, i32, i32, i32, p],
+    "fmri_pack_weights_batched": [p, i32, i32, i32, p],
     "fmri_conv1x1_fwd": [p, p, p, p, i64, i32, i32, i32, p],
     "fmri_conv1x1_bwd": [p, p, p, p, p, p, i64, i32, i32, i32, i32, p],
     "fmri_sigmoid_dice_fwd": [p, p, p, p, i64, p],

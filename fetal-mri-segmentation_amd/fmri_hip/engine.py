@@ -394,13 +394,20 @@ class UNetEngine:
 
     def refresh_weight_copies(self, overlap=False):
         """compute-dtype images of the fp32 parameters (forward filters, tap-flipped transposed filters for the input gradients, parity
-        filters).  overlap=True (the optimizer step): only the first encoder level is repacked on the current stream; the other layers -
+        filters).  Default (round 6): ONE launch for all of them on the current stream (ops.pack_weights_batched).  The scheme it replaced,
+        kept behind FMRI_PACK_BATCHED=0: overlap=True (the optimizer step): only the first encoder level is repacked on the current stream; the other layers -
         whose weights are the large ones and are first read a whole level later - are repacked on a side stream, in order of first use,
         with one event per encoder level and one for the decoder: `forward` waits for a level's event in front of that level, i.e. the
         repack runs under the first convolutions of the NEXT step instead of in front of them.  (One event for the whole encoder made the
         level-1 convs wait for the 256 -> 512 image, whose kernel - like every kernel next to a persistent conv launch, which fills all
         CUs - only gets CUs between two conv launches: 74 us of stall behind the first level in the rocprofv3 timeline; un-profiled the
         step does not notice: 13.09-13.15 ms either way.)"""
+        if self.dev.type == "cuda" and os.environ.get("FMRI_PACK_BATCHED", "1") != "0":
+            # round 6: one launch on the current stream for all plain / parity-form images (FMRI_PACK_BATCHED=0: the per-layer launches, on the
+            # side stream when overlap=True - the round-2 ... round-5 scheme below)
+            self._join_packs()
+            self._repack(lambda name: True, batched=True)
+            return
         early = set(c["name"] for c in self.plan.enc[0])
         if overlap and self.dev.type == "cuda" and os.environ.get("FMRI_PACK_OVERLAP", "1") != "0":
             if self._pack_stream is None:
@@ -431,9 +438,25 @@ class UNetEngine:
             k = self._pack_pending.pop(0)
             torch.cuda.current_stream(self.dev).wait_event(self._pack_event_dec if k == "dec" else self._pack_events[k])
 
-    def _repack(self, want):
+    def _pack_table(self):
+        """the images of _repack's first and third loop (plain layers, parity-form layers) as one table for ops.pack_weights_batched"""
+        if getattr(self, "_ptab", None) is None:
+            ent = [("plain", self.w_view(n), self.Wf[n], self.Wd.get(n)) for n in self.Wf if n not in self.Wfd]
+            for n, W in self.Wup.items():
+                c0, c1 = self.upcat[n]
+                ent.append(("up", self.w_view(n), c0, c1, W["up_f"], W["up_d"], W["sk_f"], W["sk_d"], self.planar))
+            self._ptab = ops.pack_table(ent, self.dev) if ent else (None, 0)
+        return self._ptab
+
+    def _repack(self, want, batched=False):
+        """batched: every plain / parity-form image in ONE launch (want must then accept every layer); the per-layer launches are
+        launch-bound - 14 of them cost the configs[1] step 0.12 ms wherever they run (tools/r06/pack_cost.py)"""
+        if batched:
+            tab, nb = self._pack_table()
+            if tab is not None:
+                ops.pack_weights_batched(tab, nb, self.dtype)
         for name in self.Wf:
-            if want(name) and name not in self.Wfd:
+            if not batched and want(name) and name not in self.Wfd:
                 ops.pack_weights(self.w_view(name), self.Wf[name], self.Wd.get(name))
         for name, F in self.Wfd.items():
             if not want(name):
@@ -447,7 +470,7 @@ class UNetEngine:
                 F["up_d"].copy_(weff[:, self.fold.mirror].transpose(-1, -2))            # Wc[p][1 - t']^T (fmri_conv3d_pack_up_weights' w_up_dgrad)
                 F["sk_d"].copy_(w3[:, :, F["cmid"]:].flip(0).transpose(1, 2))           # tap-flipped transposed skip filters
         for name, W in self.Wup.items():
-            if want(name):
+            if not batched and want(name):
                 c0, c1 = self.upcat[name]
                 ops.conv3d_pack_up_weights(self.w_view(name), c0, c1, W["up_f"], W["up_d"], W["sk_f"], W["sk_d"], planar=self.planar)
         for name, wt in self.Wt.items():

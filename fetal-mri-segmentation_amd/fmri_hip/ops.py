@@ -103,6 +103,34 @@ def pack_weights(w, w_fwd, w_dgrad):
     check(lib().fmri_conv3d_pack_weights(_p(w), _p(w_fwd), _p(w_dgrad), Cout, Cin, d, _s()), "fmri_conv3d_pack_weights")
 
 
+def pack_table(entries, device):
+    """the device table of fmri_pack_weights_batched.  entries: ("plain", w, w_fwd, w_dgrad) or ("up", w, C0, C1, up_f, up_d, sk_f, sk_d, planar)
+    with the tensors of pack_weights / conv3d_pack_up_weights (None = not wanted).  Returns (table int64 [n][10], n_blocks); the table holds
+    raw device addresses: the tensors must stay alive and in place."""
+    rows, first = [], 0
+    ptr = lambda t: 0 if t is None else t.data_ptr()
+    for e in entries:
+        if e[0] == "plain":
+            _, w, wf, wd = e
+            _, Cout, Cin = w.shape
+            rows.append([0, first, ptr(w), ptr(wf), ptr(wd), 0, 0, Cout, Cin, 0])
+            first += 27 * ((Cout + 63) // 64) * ((Cin + 63) // 64)
+        else:
+            _, w, C0, C1, up_f, up_d, sk_f, sk_d, planar = e
+            Cout = w.shape[1]
+            rows.append([1, first, ptr(w), ptr(up_f), ptr(up_d), ptr(sk_f), ptr(sk_d), Cout, C0, C1 | (int(bool(planar)) << 32)])
+            tco = (Cout + 63) // 64
+            first += (16 if planar else 64) * tco * ((C0 + 63) // 64) + 27 * tco * ((C1 + 63) // 64)
+    return torch.tensor(rows, dtype=torch.int64, device=device), first
+
+
+def pack_weights_batched(table, n_blocks, dtype):
+    """every weight image of a model in one launch (fmri_pack_weights_batched); table, n_blocks from pack_table"""
+    _need_cuda(table)
+    check(lib().fmri_pack_weights_batched(_p(table), table.shape[0], n_blocks, BF16 if dtype == torch.bfloat16 else F32, _s()),
+          "fmri_pack_weights_batched")
+
+
 def conv1x1_fwd(x, w, b, logits):
     _need_cuda(x, w, b, logits)
     C = x.shape[-1]

@@ -178,6 +178,15 @@ int fmri_conv2d_upcat_wgrad(const void* src0_low, int C0, const void* src1, int 
  * Either destination may be NULL. */
 int fmri_conv3d_pack_weights(const float* w, void* w_fwd, void* w_dgrad, int Cout, int Cin, int dtype,
                              fmri_stream_t stream);
+/* Every weight image of a model in ONE launch (the per-layer launches above are launch-bound: 14 of them cost the configs[1] step 0.12 ms).
+ * table (device memory): n_layers records of 10 int64:
+ *   [0] kind: 0 = fmri_conv3d_pack_weights, 1 = fmri_conv3d_pack_up_weights / fmri_conv2d_pack_up_weights
+ *   [1] number of the layer's first workgroup (records ascending; the layer takes the workgroups its own launch would: 27 * ceil(Cout/64) *
+ *       ceil(Cin/64), or (64 | planar 16) * ceil(Cout/64) * ceil(C0/64) + 27 * ceil(Cout/64) * ceil(C1/64))
+ *   [2] w   [3..6] destinations - kind 0: {w_fwd, w_dgrad, 0, 0}, kind 1: {w_up_fwd, w_up_dgrad, w_skip_fwd, w_skip_dgrad} (0 = not wanted)
+ *   [7] Cout   [8] Cin (kind 0) or C0 (kind 1)   [9] kind 1: C1 | planar << 32
+ * n_blocks = the sum of the layers' workgroups.  The images are bit-identical to those of the per-layer calls. */
+int fmri_pack_weights_batched(const int64_t* table, int n_layers, int n_blocks, int dtype, fmri_stream_t stream);
 
 /* ---- final Conv3D(n_labels,(1,1,1)) — reference unet.py:68.  logits[v][l] (fp32) = sum_c x[v][c]*w[l][c] + b[l]. */
 int fmri_conv1x1_fwd(const void* x, const float* w, const float* b, float* logits, int64_t nvox, int C, int L,

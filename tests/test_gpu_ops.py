@@ -931,6 +931,72 @@ def test_conv3d_fwd_tail(ops, case):
             ops.conv3d_fwd_tail(x, w, bias, y, w1=w1, b1=b1, logits=torch.empty(N * D * H * W, dtype=torch.float32, device="cuda"))
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32], ids=["bf16", "fp32"])
+def test_pack_weights_batched_equals_the_per_layer_launches(ops, dtype):
+    """fmri_pack_weights_batched: every weight image of a model in one launch - plain layers (ragged channel counts included), a 3-D and a
+    2-D parity-form layer, destinations that are not wanted - against fmri_conv3d_pack_weights / fmri_conv3d|conv2d_pack_up_weights: the
+    same bits (a workgroup runs the layer's own code on its local block number)."""
+    g = torch.Generator().manual_seed(17)
+    mk = lambda *sh: torch.randn(*sh, generator=g).cuda()
+    em = lambda *sh: torch.full(sh, float("nan"), dtype=dtype, device="cuda")
+    plain = [(64, 32), (128, 64), (40, 24), (96, 200)]                       # (Cout, Cin): tiles that do not fill 64 x 64 as well
+    ups = [(128, 64, 64, False), (64, 32, 32, True), (96, 0, 64, False)]     # (C0, C1, Cout, planar); C1 = 0: purely up-sampled input
+    ent, ref, got = [], [], []
+    for i, (co, ci) in enumerate(plain):
+        w = mk(27, co, ci)
+        a = [em(27, co, ci), em(27, ci, co) if i != 1 else None]             # one layer without the input-gradient image
+        b = [em(27, co, ci), em(27, ci, co) if i != 1 else None]
+        ops.pack_weights(w, a[0], a[1])
+        ent.append(("plain", w, b[0], b[1]))
+        ref += a
+        got += b
+    for c0, c1, co, planar in ups:
+        w = mk(27, co, c0 + c1)
+        n = 4 if planar else 8
+        mkimg = lambda: [em(n, n, co, c0), em(n, n, c0, co), em(27, co, c1) if c1 else None, em(27, c1, co) if c1 else None]
+        a, b = mkimg(), mkimg()
+        ops.conv3d_pack_up_weights(w, c0, c1, a[0], a[1], a[2], a[3], planar=planar)
+        ent.append(("up", w, c0, c1, b[0], b[1], b[2], b[3], planar))
+        ref += a
+        got += b
+    tab, nb = ops.pack_table(ent, "cuda")
+    ops.pack_weights_batched(tab, nb, dtype)
+    torch.cuda.synchronize()
+    view = lambda t: t.view(torch.int16 if dtype == torch.bfloat16 else torch.int32)
+    for k, (r, o) in enumerate(zip(ref, got)):
+        if r is not None:
+            assert torch.equal(view(r), view(o)), k
+
+
+def test_engine_batched_repack_equals_the_per_layer_repack(monkeypatch):
+    """the engine's weight images after an optimizer step with FMRI_PACK_BATCHED=1 (default) and =0: the same bits, 3-D and 2-D"""
+    from fmri_hip.engine import UNetEngine, UNetPlan
+    for ndim in (3, 2):
+        imgs = {}
+        for mode in ("1", "0"):
+            monkeypatch.setenv("FMRI_PACK_BATCHED", mode)
+            if ndim == 3:
+                eng = UNetEngine(UNetPlan(1, (16, 32, 32), depth=3, n_base_filters=32), 1, dtype=torch.bfloat16, seed=5)
+                x = torch.randn((1, 16, 32, 32, 1), generator=torch.Generator().manual_seed(1)).cuda().to(torch.bfloat16)
+                nv = 16 * 32 * 32
+            else:
+                eng = UNetEngine(UNetPlan(5, (64, 64), depth=3, n_base_filters=32, ndim=2), 8, dtype=torch.bfloat16, seed=5)
+                x = torch.randn((1, 8, 64, 64, 5), generator=torch.Generator().manual_seed(1)).cuda().to(torch.bfloat16)
+                nv = 8 * 64 * 64
+            y = (torch.rand((nv,), generator=torch.Generator().manual_seed(2)) > 0.7).to(torch.uint8).cuda()
+            eng.P.copy_(torch.randn(eng.P.shape, generator=torch.Generator().manual_seed(3)) * 0.05)     # the same parameters in both arms
+            eng.refresh_weight_copies(overlap=True)
+            eng._join_packs()
+            torch.cuda.synchronize()
+            imgs[mode] = {("f", k): v.clone() for k, v in eng.Wf.items()}
+            imgs[mode].update({("d", k): v.clone() for k, v in eng.Wd.items()})
+            for k, W in eng.Wup.items():
+                imgs[mode].update({(kk, k): v.clone() for kk, v in W.items() if v is not None})
+        assert imgs["1"].keys() == imgs["0"].keys() and len(imgs["1"]) > 10
+        for k in imgs["1"]:
+            assert torch.equal(imgs["1"][k].view(torch.int16), imgs["0"][k].view(torch.int16)), (ndim, k)
+
+
 PLANAR_TAIL_CASES = [
     # name, slices, H, W, C0, Cout, act, expected ok bits (on a 256-CU device)
     ("narrow_32", 8, 16, 32, 32, 32, 1, 3),             # 32-wide Cout block == Cout: pool + logits

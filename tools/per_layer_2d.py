@@ -34,7 +34,7 @@ def wrap(name):
 
 for n in ("conv3d_fwd", "conv3d_fwd_tail", "conv3d_dgrad", "conv3d_wgrad", "conv3d_upcat_fwd", "conv3d_upcat_dgrad", "conv3d_upcat_wgrad", "maxpool_fwd",
           "maxpool_bwd", "upsample_bwd", "conv1x1_fwd", "conv1x1_bwd", "sigmoid_dice_fwd", "sigmoid_loss_bwd", "adam_step", "pack_weights",
-          "conv3d_pack_up_weights"):
+          "conv3d_pack_up_weights", "pack_weights_batched"):
     wrap(n)
 B, X, Y, C = 64, 256, 256, 5
 eng = UNetEngine(UNetPlan(C, (X, Y), depth=4, n_base_filters=32, ndim=2), B, dtype=torch.bfloat16)
